@@ -1,0 +1,434 @@
+#!/usr/bin/env python3
+"""Golden-vector generator (runs ONLY in the build container, where /root/reference exists).
+
+Imports the reference implementation (AechPro/rlgym-ppo @ v1.3.13) with `wandb`/`gym` stubbed
+(SURVEY.md section 8(c)), drives its hot-path functions on small seeded inputs, and stores the
+inputs + outputs as .npz fixtures next to this script.  The fixtures are DATA: no reference source
+or bytecode is written anywhere.  Nothing in tests/, bench.py or smoke() imports the reference;
+they read only the .npz files produced here.
+
+    python tests/golden/make_golden.py          # regenerates every fixture
+
+Versions that produced the committed fixtures are stored inside each file (key `_versions`).
+Fixture ids follow SURVEY.md section 8(c): G1..G10.
+"""
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF = "/root/reference"
+
+
+def _import_reference():
+    wandb = types.ModuleType("wandb")
+    wr = types.ModuleType("wandb.wandb_run")
+    wr.Run = object
+    wandb.wandb_run = wr
+    sys.modules["wandb"] = wandb
+    sys.modules["wandb.wandb_run"] = wr
+    sys.modules["gym"] = types.ModuleType("gym")
+    sys.path.insert(0, REF)
+    import rlgym_ppo  # noqa: F401
+    from rlgym_ppo.ppo import (ContinuousPolicy, DiscreteFF, ExperienceBuffer, MultiDiscreteFF,
+                               PPOLearner, ValueEstimator)
+    from rlgym_ppo.util import WelfordRunningStat, torch_functions
+    return dict(ContinuousPolicy=ContinuousPolicy, DiscreteFF=DiscreteFF, ExperienceBuffer=ExperienceBuffer,
+                MultiDiscreteFF=MultiDiscreteFF, PPOLearner=PPOLearner, ValueEstimator=ValueEstimator,
+                WelfordRunningStat=WelfordRunningStat, torch_functions=torch_functions)
+
+
+VERSIONS = json.dumps({"numpy": np.__version__, "torch": torch.__version__, "reference": "rlgym-ppo 1.3.13"})
+
+
+def save(name, **arrays):
+    arrays["_versions"] = np.array(VERSIONS)
+    out = {}
+    for k, v in arrays.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+        out[k] = np.asarray(v)
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print("wrote", name, {k: (v.shape, str(v.dtype)) for k, v in out.items() if not k.startswith("_")})
+
+
+def params_of(module, prefix):
+    return {f"{prefix}{k}": v.detach().clone() for k, v in module.state_dict().items()}
+
+
+def grads_of(module, prefix):
+    return {f"{prefix}{k}": p.grad.detach().clone() for k, p in module.named_parameters()}
+
+
+# ---------------------------------------------------------------------------------------------
+def g1_g2_forward(R):
+    """G1: DiscreteFF.get_action (discrete_policy.py:44-62) incl. the Exp(1) noise; G2: ValueEstimator."""
+    torch.manual_seed(11)
+    pol = R["DiscreteFF"](107, 90, (32, 32), "cpu")
+    val = R["ValueEstimator"](107, (32, 32), "cpu")
+    rs = np.random.RandomState(5)
+    obs = np.clip(rs.randn(64, 107), -5, 5).astype(np.float32)
+    with torch.no_grad():
+        probs = torch.clamp(pol.get_output(obs).view(-1, 90), min=1e-11, max=1)
+        st = torch.get_rng_state()
+        actions, logp = pol.get_action(obs)
+        torch.set_rng_state(st)
+        q = torch.empty(64, 90).exponential_(1)  # same draw multinomial consumed
+        det_action, det_lp = pol.get_action(obs, deterministic=True)
+        values = val(obs)
+        # float64 observations are coerced to f32 by the reference (value_estimator.py:30-36)
+        values64 = val(obs.astype(np.float64))
+    save("g1_discrete_forward", obs=obs, q=q, probs=probs, actions=actions, logp=logp,
+         det_action=np.int64(det_action), **params_of(pol, "p."))
+    save("g2_value_forward", obs=obs, values=values, values_from_f64=values64, **params_of(val, "v."))
+
+
+def make_gae_inputs(n, seed, trunc_dtype):
+    rs = np.random.RandomState(seed)
+    rews = rs.randn(n).astype(np.float32) * 2.0
+    values = rs.randn(n + 1).astype(np.float32)
+    dones = np.zeros(n, np.float32)
+    trunc = np.zeros(n, trunc_dtype)
+    # ragged trajectories; every trajectory end is done or truncated (quirk Q4), plus mid-trajectory dones
+    t = 0
+    while t < n:
+        ln = int(rs.randint(1, 60))
+        end = min(t + ln, n) - 1
+        if rs.rand() < 0.5:
+            dones[end] = 1
+        else:
+            trunc[end] = 1
+        t = end + 1
+    mid = rs.rand(n) < 0.02
+    dones[mid] = 1
+    trunc[dones == 1] = 0
+    return rews, dones, trunc, values
+
+
+def g3_gae(R):
+    """G3: compute_gae (torch_functions.py:36-78) with the exact input types learner.py:352-366 passes."""
+    out = {}
+    case = 0
+    for trunc_dtype in (np.float64, np.float32):
+        for ret_std in (None, np.float32(1.7), np.float32(1e-3)):
+            for n in (1, 7, 512):
+                rews, dones, trunc, values = make_gae_inputs(n, 100 + case, trunc_dtype)
+                vlist = torch.as_tensor(values).flatten().tolist()  # python floats, as learner.py:352
+                vt, adv, rets = R["torch_functions"].compute_gae(rews, dones, trunc, vlist, gamma=0.99, lmbda=0.95,
+                                                                return_std=ret_std)
+                pre = f"c{case}."
+                out[pre + "rews"] = rews
+                out[pre + "dones"] = dones
+                out[pre + "trunc"] = trunc
+                out[pre + "values"] = values
+                out[pre + "ret_std"] = np.float32(np.nan) if ret_std is None else ret_std
+                out[pre + "value_targets"] = vt
+                out[pre + "advantages"] = adv
+                out[pre + "returns"] = np.asarray([float(r) for r in rets], np.float64)
+                case += 1
+    # one more with non-default gamma/lambda = 1 (no decay: exercises the long-range carry)
+    rews, dones, trunc, values = make_gae_inputs(300, 999, np.float64)
+    dones[:] = 0
+    trunc[:] = 0
+    trunc[-1] = 1
+    vt, adv, rets = R["torch_functions"].compute_gae(rews, dones, trunc, torch.as_tensor(values).tolist(),
+                                                    gamma=1.0, lmbda=1.0, return_std=None)
+    pre = f"c{case}."
+    out.update({pre + "rews": rews, pre + "dones": dones, pre + "trunc": trunc, pre + "values": values,
+                pre + "ret_std": np.float32(np.nan), pre + "value_targets": vt, pre + "advantages": adv,
+                pre + "returns": np.asarray([float(r) for r in rets], np.float64),
+                pre + "gamma": np.float64(1.0), pre + "lmbda": np.float64(1.0)})
+    out["n_cases"] = np.int64(case + 1)
+    save("g3_gae", **out)
+
+
+def _loss_and_grads(R, learner_like, obs, acts, old_logp, adv, targets, clip, ent_coef, mb_ratio):
+    """The per-minibatch body of PPOLearner.learn (ppo_learner.py:146-185) run with the reference's modules."""
+    policy, value_net = learner_like
+    policy.zero_grad()
+    value_net.zero_grad()
+    vals = value_net(obs).view_as(targets)
+    log_probs, entropy = policy.get_backprop_data(obs, acts)
+    log_probs = log_probs.view_as(old_logp)
+    ratio = torch.exp(log_probs - old_logp)
+    clipped = torch.clamp(ratio, 1.0 - clip, 1.0 + clip)
+    with torch.no_grad():
+        log_ratio = log_probs - old_logp
+        kl = ((torch.exp(log_ratio) - 1) - log_ratio).mean()
+        clip_fraction = torch.mean((torch.abs(ratio - 1) > clip).float())
+    policy_loss = -torch.min(ratio * adv, clipped * adv).mean()
+    value_loss = torch.nn.MSELoss()(vals, targets) * mb_ratio
+    ppo_loss = (policy_loss - entropy * ent_coef) * mb_ratio
+    ppo_loss.backward()
+    value_loss.backward()
+    return dict(logp=log_probs.detach(), entropy=entropy.detach(), ratio=ratio.detach(), kl=kl, clip_fraction=clip_fraction,
+                policy_loss=policy_loss.detach(), value_loss=(value_loss / mb_ratio).detach(), vals=vals.detach())
+
+
+def g4_discrete_loss(R):
+    """G4: one minibatch of loss + grads, ratios engineered to hit in-range / clipped / tie, and a prob < 1e-11."""
+    torch.manual_seed(21)
+    pol = R["DiscreteFF"](107, 90, (32, 32), "cpu")
+    val = R["ValueEstimator"](107, (32, 32), "cpu")
+    with torch.no_grad():
+        pol.model[4].weight.mul_(60.0)  # spread logits so that some clamped probs sit at 1e-11
+    rs = np.random.RandomState(7)
+    n = 96
+    obs = torch.as_tensor(np.clip(rs.randn(n, 107), -5, 5).astype(np.float32))
+    with torch.no_grad():
+        probs = torch.clamp(pol.get_output(obs), 1e-11, 1)
+        acts = torch.multinomial(probs, 1, True)
+        # force a few chosen actions to be ones whose prob is clamped (gradient-dead region)
+        low = probs.argmin(-1)
+        acts[:8, 0] = low[:8]
+        logp = torch.log(probs).gather(-1, acts).flatten()
+    target_ratio = np.ones(n, np.float32)
+    target_ratio[8:24] = 0.5   # clipped low
+    target_ratio[24:40] = 1.5  # clipped high
+    target_ratio[40:56] = 0.8  # exactly on the lower clip edge (1 - 0.2 in fp32 arithmetic is not exact: near-tie)
+    target_ratio[56:72] = 1.2
+    # rows 72.. keep ratio == 1 exactly: torch.min tie
+    old_logp = (logp - torch.log(torch.as_tensor(target_ratio))).float()
+    adv = torch.as_tensor(rs.randn(n).astype(np.float32) * 2)
+    targets = torch.as_tensor(rs.randn(n).astype(np.float32))
+    res = _loss_and_grads(R, (pol, val), obs, acts.float(), old_logp, adv, targets, 0.2, 0.005, 0.25)
+    save("g4_discrete_loss", obs=obs, acts=acts.float(), old_logp=old_logp, adv=adv, targets=targets,
+         clip=np.float32(0.2), ent_coef=np.float32(0.005), mb_ratio=np.float32(0.25), probs=probs,
+         **{"out." + k: v for k, v in res.items()}, **params_of(pol, "p."), **params_of(val, "v."),
+         **grads_of(pol, "gp."), **grads_of(val, "gv."))
+
+
+def _synthetic_experience(rs, n, d, policy, act_shape):
+    states = np.clip(rs.randn(n, d), -5, 5).astype(np.float32)
+    with torch.no_grad():
+        a, lp = policy.get_action(states)
+    actions = a.numpy().astype(np.float32).reshape((n,) + act_shape)
+    log_probs = lp.numpy().astype(np.float32)
+    rewards = rs.randn(n).astype(np.float32)
+    next_states = np.clip(rs.randn(n, d), -5, 5).astype(np.float32)
+    dones = (rs.rand(n) < 0.03).astype(np.float32)
+    trunc = ((rs.rand(n) < 0.03) & (dones == 0)).astype(np.float32)
+    values = rs.randn(n).astype(np.float32)
+    adv = rs.randn(n).astype(np.float32)
+    return states, actions, log_probs, rewards, next_states, dones, trunc, values, adv
+
+
+def _run_learn(R, policy_type, d, n_act, layers, n, B, MB, epochs, seed, tag, act_shape=()):
+    """G5/G9: full PPOLearner.learn on a synthetic buffer; records params after each optimiser step."""
+    torch.manual_seed(seed)
+    np.random.seed(seed)
+    learner = R["PPOLearner"](d, n_act, policy_type, layers, layers, (0.1, 1.0), B, epochs, 3e-4, 3e-4, 0.2, 0.005, MB, "cpu")
+    init = {**params_of(learner.policy, "p0."), **params_of(learner.value_net, "v0.")}
+    buf = R["ExperienceBuffer"](n, seed, "cpu")
+    rs = np.random.RandomState(seed + 1)
+    exp = _synthetic_experience(rs, n, d, learner.policy, act_shape)
+    buf.submit_experience(*exp)
+    snaps = {}
+    step_no = [0]
+    orig = learner.value_optimizer.step
+
+    def rec(*a, **k):  # value optimizer steps last (ppo_learner.py:192-193): snapshot after it
+        r = orig(*a, **k)
+        s = step_no[0]
+        vec_p = torch.nn.utils.parameters_to_vector(learner.policy.parameters()).detach().clone()
+        vec_v = torch.nn.utils.parameters_to_vector(learner.value_net.parameters()).detach().clone()
+        snaps[f"step{s}.policy"] = vec_p
+        snaps[f"step{s}.value"] = vec_v
+        step_no[0] += 1
+        return r
+
+    learner.value_optimizer.step = rec
+    report = learner.learn(buf)
+    report.pop("PPO Batch Consumption Time")
+    names = ["states", "actions", "log_probs", "rewards", "next_states", "dones", "truncated", "values", "advantages"]
+    rep = {"report." + k: np.float64(v) for k, v in report.items()}
+    opt_state = learner.policy_optimizer.state_dict()
+    save(tag, **init, **{"exp." + k: v for k, v in zip(names, exp)}, **snaps, **rep, n_steps=np.int64(step_no[0]),
+         cfg=np.array(json.dumps(dict(policy_type=policy_type, d=d, n_act=n_act, layers=layers, n=n, B=B, MB=MB,
+                                      epochs=epochs, seed=seed, lr=3e-4, clip=0.2, ent=0.005))),
+         adam_step=np.float64(float(opt_state["state"][0]["step"])),
+         adam_exp_avg0=opt_state["state"][0]["exp_avg"], adam_exp_avg_sq0=opt_state["state"][0]["exp_avg_sq"])
+    return learner
+
+
+def g5_learn(R):
+    _run_learn(R, 0, 107, 90, (32, 32), 1024, 512, 128, 2, 123, "g5_learn_discrete")
+
+
+def g6_shuffle(R):
+    """G6: ExperienceBuffer.get_all_batches_shuffled index stream (experience_buffer.py:89-102)."""
+    buf = R["ExperienceBuffer"](1000, 123, "cpu")
+    n = 1000
+    ar = np.arange(n, dtype=np.float32)
+    buf.submit_experience(ar[:, None].repeat(3, 1), ar, ar, ar, ar[:, None].repeat(3, 1), ar, ar, ar, ar)
+    out = {}
+    for epoch in range(2):
+        got = [b[0].numpy().astype(np.int64) for b in buf.get_all_batches_shuffled(300)]
+        out[f"epoch{epoch}"] = np.stack(got)  # 3 batches of 300; the last 100 indices are dropped (quirk Q7)
+    buf.clear()  # re-seeds (experience_buffer.py:104-118)
+    buf.submit_experience(ar[:, None].repeat(3, 1), ar, ar, ar, ar[:, None].repeat(3, 1), ar, ar, ar, ar)
+    out["after_clear"] = np.stack([b[0].numpy().astype(np.int64) for b in buf.get_all_batches_shuffled(300)])
+    # raw permutations at the benchmark size, checksummed
+    rs = np.random.RandomState(123)
+    p = rs.permutation(524288)
+    out["perm524288_head"] = p[:64]
+    out["perm524288_xor"] = np.bitwise_xor.reduce(p * np.arange(1, p.size + 1))
+    out["perm524288_wsum"] = np.sum((p * (np.arange(p.size) % 1000003)) % 2147483647)
+    p2 = rs.permutation(524288)
+    out["perm524288_second_head"] = p2[:64]
+    save("g6_shuffle", **out)
+
+
+def g7_welford(R):
+    """G7: WelfordRunningStat (running_stats.py:15-137) as driven by learner.py:368-372."""
+    rs = np.random.RandomState(3)
+    st = R["WelfordRunningStat"](1)
+    rets = (rs.randn(300) * 3 + 1).astype(np.float64)
+    out = {"returns": rets, "std_initial": st.std.copy(), "mean_initial": st.mean.copy()}
+    st.increment(list(rets[:1]), 1)
+    out["std_after1"] = st.std.copy()
+    st.increment(list(rets[1:150]), 149)
+    out["mean150"], out["std150"] = st.mean.copy(), st.std.copy()
+    st.increment(list(rets[150:]), 150)
+    out["mean300"], out["std300"] = st.mean.copy(), st.std.copy()
+    js = st.to_json()
+    out["json_mean"], out["json_var"], out["json_count"] = np.asarray(js["mean"]), np.asarray(js["var"]), np.int64(js["count"])
+    # vector obs stats (shape (5,)) incl. the increment(samples, num) row loop (batched_agent_manager.py:377-380)
+    ob = R["WelfordRunningStat"](5)
+    obs = rs.randn(12, 5).astype(np.float32)
+    ob.increment(obs[:4], 4)
+    ob.increment(obs[4:], 8)
+    out["obs"], out["obs_mean"], out["obs_std"] = obs, ob.mean.copy(), ob.std.copy()
+    # merge path (running_stats.py:71-98)
+    a, b = R["WelfordRunningStat"](5), R["WelfordRunningStat"](5)
+    a.increment(obs[:5], 5)
+    b.increment(obs[5:], 7)
+    a.increment_from_serialized_other(b.serialize())
+    out["merged_mean"], out["merged_var"], out["merged_count"] = a.running_mean.copy(), a.running_variance.copy(), np.int64(a.count)
+    save("g7_welford", **out)
+
+
+def g8_fifo(R):
+    """G8: ExperienceBuffer._cat four cases (experience_buffer.py:18-37) through submit_experience."""
+    out = {}
+
+    def run(tag, size, chunks):
+        buf = R["ExperienceBuffer"](size, 1, "cpu")
+        base = 0
+        for c in chunks:
+            ar = np.arange(base, base + c, dtype=np.float32)
+            base += c
+            buf.submit_experience(ar[:, None].repeat(2, 1), ar, ar, ar, ar[:, None].repeat(2, 1), ar, ar, ar, ar)
+        out[tag + ".rewards"] = buf.rewards
+        out[tag + ".states"] = buf.states
+        out[tag + ".chunks"] = np.asarray(chunks)
+        out[tag + ".size"] = np.int64(size)
+
+    run("under", 10, [3, 4])           # t1+t2 <= size
+    run("exact", 10, [3, 10])          # len(t2) == size
+    run("over", 10, [6, 7])            # t1+t2 > size
+    run("huge", 10, [4, 25])           # len(t2) > size
+    run("stream", 10, [4, 4, 4, 4, 1, 12, 3])
+    save("g8_fifo", **out)
+
+
+def g9_other_heads(R):
+    """G9: continuous (d=231, k=8) and multi-discrete versions of G1/G4 (+ a short learn())."""
+    # ---- continuous forward/sample
+    torch.manual_seed(31)
+    pol = R["ContinuousPolicy"](231, 16, (48, 48), "cpu", var_min=0.1, var_max=1.0)
+    val = R["ValueEstimator"](231, (48, 48), "cpu")
+    rs = np.random.RandomState(9)
+    obs = torch.as_tensor(np.clip(rs.randn(80, 231), -5, 5).astype(np.float32))
+    with torch.no_grad():
+        mean, std = pol.get_output(obs)
+        st = torch.get_rng_state()
+        act, lp = pol.get_action(obs)
+        torch.set_rng_state(st)
+        eps = torch.empty(80, 8).normal_(0, 1)  # Normal.sample consumes normal_(mean=0,std=1) then mean+std*eps
+        det_mean, _ = pol.get_action(obs, deterministic=True)
+    out = dict(obs=obs, mean=mean, std=std, eps=eps, act=act, logp=lp, det=det_mean)
+    # engineered old log-probs for the loss
+    tr = np.ones(80, np.float32)
+    tr[:20] = 0.6
+    tr[20:40] = 1.4
+    old = (lp - torch.log(torch.as_tensor(tr))).float()
+    adv = torch.as_tensor(rs.randn(80).astype(np.float32))
+    tg = torch.as_tensor(rs.randn(80).astype(np.float32))
+    res = _loss_and_grads(R, (pol, val), obs, act, old, adv, tg, 0.2, 0.005, 0.5)
+    save("g9_continuous", **out, old_logp=old, adv=adv, targets=tg, clip=np.float32(0.2), ent_coef=np.float32(0.005),
+         mb_ratio=np.float32(0.5), **{"out." + k: v for k, v in res.items()}, **params_of(pol, "p."),
+         **params_of(val, "v."), **grads_of(pol, "gp."), **grads_of(val, "gv."))
+
+    # ---- multi-discrete
+    torch.manual_seed(41)
+    pol = R["MultiDiscreteFF"](107, (32, 32), "cpu")
+    val = R["ValueEstimator"](107, (32, 32), "cpu")
+    obs = torch.as_tensor(np.clip(rs.randn(72, 107), -5, 5).astype(np.float32))
+    with torch.no_grad():
+        logits = pol.get_output(obs)
+        st = torch.get_rng_state()
+        act, lp = pol.get_action(obs)
+        torch.set_rng_state(st)
+        q = torch.empty(72 * 8, 3).exponential_(1)  # Categorical.sample -> multinomial on [n*8, 3] probs
+        det, _ = pol.get_action(obs, deterministic=True)
+    tr = np.ones(72, np.float32)
+    tr[:18] = 0.6
+    tr[18:36] = 1.4
+    old = (lp - torch.log(torch.as_tensor(tr))).float()
+    adv = torch.as_tensor(rs.randn(72).astype(np.float32))
+    tg = torch.as_tensor(rs.randn(72).astype(np.float32))
+    res = _loss_and_grads(R, (pol, val), obs, act, old, adv, tg, 0.2, 0.005, 0.5)
+    save("g9_multidiscrete", obs=obs, logits=logits, q=q, act=act, logp=lp, det=np.asarray(det), old_logp=old, adv=adv,
+         targets=tg, clip=np.float32(0.2), ent_coef=np.float32(0.005), mb_ratio=np.float32(0.5),
+         **{"out." + k: v for k, v in res.items()}, **params_of(pol, "p."), **params_of(val, "v."),
+         **grads_of(pol, "gp."), **grads_of(val, "gv."))
+
+    _run_learn(R, 2, 231, 8, (48, 48), 512, 256, 128, 2, 77, "g9_learn_continuous", act_shape=(8,))
+    _run_learn(R, 1, 107, 8, (32, 32), 512, 256, 128, 2, 78, "g9_learn_multidiscrete", act_shape=(8,))
+
+
+def g10_checkpoint(R):
+    """G10: state_dict key lists + Adam state layout after 2 optimiser steps (ppo_learner.py:240-271)."""
+    torch.manual_seed(5)
+    learner = R["PPOLearner"](107, 90, 0, (32, 32), (32, 32), (0.1, 1.0), 128, 2, 3e-4, 3e-4, 0.2, 0.005, 64, "cpu")
+    buf = R["ExperienceBuffer"](128, 5, "cpu")
+    rs = np.random.RandomState(6)
+    buf.submit_experience(*_synthetic_experience(rs, 128, 107, learner.policy, ()))
+    learner.learn(buf)
+    sd = learner.policy_optimizer.state_dict()
+    meta = dict(policy_keys=list(learner.policy.state_dict().keys()),
+                value_keys=list(learner.value_net.state_dict().keys()),
+                adam_param_group_keys=sorted(sd["param_groups"][0].keys()),
+                adam_param_group={k: (v if not isinstance(v, (tuple, list)) else list(v))
+                                  for k, v in sd["param_groups"][0].items()},
+                adam_state_keys=sorted(sd["state"][0].keys()),
+                adam_state_ids=sorted(sd["state"].keys()),
+                adam_step_dtype=str(sd["state"][0]["step"].dtype),
+                adam_step_value=float(sd["state"][0]["step"]),
+                cumulative_model_updates=learner.cumulative_model_updates)
+    save("g10_checkpoint", meta=np.array(json.dumps(meta)))
+
+
+def main():
+    if not os.path.isdir(REF):
+        raise SystemExit("reference tree not present: fixtures can only be regenerated in the build container")
+    R = _import_reference()
+    torch.set_num_threads(1)  # deterministic reduction order in the CPU GEMMs that produce the fixtures
+    g1_g2_forward(R)
+    g3_gae(R)
+    g4_discrete_loss(R)
+    g5_learn(R)
+    g6_shuffle(R)
+    g7_welford(R)
+    g8_fifo(R)
+    g9_other_heads(R)
+    g10_checkpoint(R)
+
+
+if __name__ == "__main__":
+    main()
