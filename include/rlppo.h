@@ -1,0 +1,201 @@
+/*
+ * rlppo.h -- C ABI of librlppo.so, the MI355X (gfx950) hot path of rlgym-ppo.
+ *
+ * The reference (AechPro/rlgym-ppo v1.3.13) is pure Python and has no FFI; its boundary for this path is
+ * the Python class API.  The host-side mirror of that API lives in
+ * rlgym_ppo_amd/ and calls the entry points below through ctypes.  Every entry point names the reference
+ * code it replaces (paths relative to the reference tree).
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes only.  All `const float*` / `float*` / `int64_t*` data arguments
+ *     are DEVICE pointers borrowed from the caller (torch tensors' data_ptr()), except where a parameter is
+ *     explicitly marked HOST.  The library never allocates or frees device memory: scratch space is a
+ *     caller-provided workspace sized by the matching *_workspace_bytes() query.
+ *   - `stream` is a hipStream_t passed as void*.  All device work is enqueued asynchronously on it; no entry
+ *     point synchronises the device, so every call is legal inside a hipGraph capture.
+ *   - Return value: 0 = OK; non-zero = error (RLPPO_ERR_* or a hipError_t).  rlppo_last_error() returns a
+ *     thread-local description of the most recent failure.  No C++ exception crosses the ABI.
+ *   - A network is described by `dims[0..n_layers]` = {d_in, h_1, ..., h_L, d_out} (logical sizes, exactly the
+ *     nn.Linear sizes the reference builds: discrete_policy.py:22-31, value_estimator.py:19-28) and by its
+ *     parameters in `torch.nn.utils.parameters_to_vector` order: W_0[out][in], b_0, W_1, b_1, ...
+ *     ("flat arena").  Kernels consume a PACKED copy (tile-padded W, W^T and b) built by rlppo_net_pack().
+ *   - Row-major everywhere.  Observation matrices have a leading dimension `ld` (floats) >= d_in; rows that the
+ *     kernels read directly must have ld a multiple of 32 with zero fill beyond d_in (rlppo_padded_width()).
+ */
+#ifndef RLPPO_H
+#define RLPPO_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RLPPO_ABI_VERSION 1
+#define RLPPO_MAX_LAYERS 16
+
+#define RLPPO_OK 0
+#define RLPPO_ERR_ARG 1001        /* bad argument / unsupported shape */
+#define RLPPO_ERR_WORKSPACE 1002  /* workspace too small */
+
+/* policy head codes == the reference's `policy_type` (ppo_learner.py:34-50) */
+#define RLPPO_HEAD_DISCRETE 0
+#define RLPPO_HEAD_MULTIDISCRETE 1
+#define RLPPO_HEAD_GAUSSIAN 2
+
+int rlppo_abi_version(void);
+const char *rlppo_last_error(void);
+
+/* ---------------------------------------------------------------------------------------------- layout */
+
+/* Width (floats) to which an input feature dimension is padded for the kernels (multiple of 32). */
+int64_t rlppo_padded_width(int64_t d);
+/* Width to which a layer OUTPUT dimension is padded (32, 64, 96, 128 or a multiple of 128). */
+int64_t rlppo_padded_out(int64_t d);
+/* Number of floats in the packed copy of a network. */
+int64_t rlppo_packed_floats(const int32_t *dims, int32_t n_layers);
+/* Number of floats in the flat arena of a network (sum of out*in + out). */
+int64_t rlppo_flat_floats(const int32_t *dims, int32_t n_layers);
+
+/* Build the packed copy (padded W, W^T, b per layer) from the flat arena.  Called after every optimiser step.
+ * Replaces nothing in the reference (it is the price of tile-aligned kernels). */
+int rlppo_net_pack(void *stream, const int32_t *dims, int32_t n_layers, const float *flat, float *packed);
+
+/* Copy/convert observation rows into the padded device layout: dst[r][0:d] = (float)src[r][0:d], zero fill to
+ * ld_dst.  `src_is_f64` selects a float64 source (learner.py:347 builds a float64 value-net input).
+ * Optional standardisation with the reference's SCALAR statistics (quirk Q5, batched_agent_manager.py:313-315):
+ * if standardize != 0, dst = clip((src - mean0) / std0, -5, 5). */
+int rlppo_pad_rows(void *stream, const void *src, int32_t src_is_f64, int64_t n, int64_t d, int64_t ld_src,
+                   float *dst, int64_t ld_dst, int32_t standardize, float mean0, float std0);
+
+/* ------------------------------------------------------------------------------------ rollout inference */
+
+/* Bytes of workspace needed by the forward entry points for `n` rows. */
+size_t rlppo_forward_workspace_bytes(const int32_t *dims, int32_t n_layers, int64_t n);
+
+/* MLP forward: out[n][ld_out] = Linear_L(relu(...relu(Linear_0(obs)))) (+ tanh if out_tanh).
+ * Replaces nn.Sequential.forward of value_estimator.py:30-36 / the body of *_policy.get_output. */
+int rlppo_mlp_forward(void *stream, const int32_t *dims, int32_t n_layers, const float *packed,
+                      const float *obs, int64_t ld_obs, int64_t n, int32_t out_tanh,
+                      float *out, int64_t ld_out, void *workspace, size_t ws_bytes);
+
+/* DiscreteFF.get_action (discrete_policy.py:44-62): forward, softmax, clamp(1e-11,1), action =
+ * argmax_a(p_a / q_a) with the caller's Exp(1) noise q[n][n_actions] (== torch.multinomial(p,1,True), SURVEY
+ * 8(a1); first index wins ties), logp = log(p_action).  actions: int64[n]; logp: float[n];
+ * probs_out (optional, may be NULL): float[n][n_actions]. */
+int rlppo_discrete_act(void *stream, const int32_t *dims, int32_t n_layers, const float *packed,
+                       const float *obs, int64_t ld_obs, int64_t n, const float *noise_q,
+                       int64_t *actions, float *logp, float *probs_out, void *workspace, size_t ws_bytes);
+
+/* The selection step alone on caller-supplied probabilities p[n][ld_p] (used by tests to show index equality
+ * is exact given identical probs, and by the multi-discrete head with n*8 rows of 3). */
+int rlppo_categorical_select(void *stream, const float *probs, int64_t ld_p, int64_t n, int32_t n_cat,
+                             const float *noise_q, int64_t *actions, float *logp);
+
+/* ContinuousPolicy.get_action (continuous_policy.py:75-98): tanh head, std = y*var_m + var_b
+ * (torch_functions.py:30-33), action = clamp(mean + std*eps, -1, 1) with the caller's N(0,1) noise
+ * eps[n][k], logp = sum_k logpdf(action) with the reference's 4-term formula (continuous_policy.py:54-63).
+ * dims[n_layers] == 2k.  actions: float[n][k]; logp: float[n]. */
+int rlppo_gaussian_act(void *stream, const int32_t *dims, int32_t n_layers, const float *packed,
+                       const float *obs, int64_t ld_obs, int64_t n, const float *noise_eps, float var_m, float var_b,
+                       float *actions, float *logp, void *workspace, size_t ws_bytes);
+
+/* MultiDiscreteFF.get_action (multi_discrete_policy.py:46-74, torch_functions.py:93-122): 21 logits -> 8
+ * categoricals (5x3 + 3x2); noise_q[n*8][3] as Categorical.sample draws it; actions int64[n][8]; logp[n]. */
+int rlppo_multidiscrete_act(void *stream, const int32_t *dims, int32_t n_layers, const float *packed,
+                            const float *obs, int64_t ld_obs, int64_t n, const float *noise_q,
+                            int64_t *actions, float *logp, void *workspace, size_t ws_bytes);
+
+/* ---------------------------------------------------------------------------------------------- GAE */
+
+size_t rlppo_gae_workspace_bytes(int64_t n);
+
+/* compute_gae (util/torch_functions.py:36-78) as two segmented reverse affine scans.
+ * rews, dones, truncated: float[n]; values: float[n+1] (V of every state + V(next_state of the last step),
+ * learner.py:347-352).  return_std: the running return std (learner.py:356); pass NaN for `None`
+ * (no reward scaling).  Outputs float[n]: value_targets = V + adv, advantages, returns.
+ * Arithmetic: reward scaling in float32 (as the reference's float32/float32 division), recurrences in
+ * float64, outputs rounded once to float32 -- the reference's behaviour under its pinned NumPy < 2. */
+int rlppo_gae(void *stream, const float *rews, const float *dones, const float *truncated, const float *values,
+              int64_t n, double gamma, double lmbda, float return_std,
+              float *value_targets, float *advantages, float *returns, void *workspace, size_t ws_bytes);
+
+/* -------------------------------------------------------------------------------------- PPO update */
+
+size_t rlppo_minibatch_workspace_bytes(const int32_t *pol_dims, int32_t pol_layers, const int32_t *val_dims,
+                                       int32_t val_layers, int64_t mb);
+
+typedef struct rlppo_minibatch_args {
+    int32_t head;                 /* RLPPO_HEAD_* */
+    int32_t pol_layers;
+    int32_t val_layers;
+    int32_t act_dim;              /* floats per action row in `actions` (1, 8, k) */
+    const int32_t *pol_dims;      /* HOST */
+    const int32_t *val_dims;      /* HOST */
+    const float *pol_packed;
+    const float *val_packed;
+    float *pol_grad;              /* flat arena, accumulated (+=) */
+    float *val_grad;
+    /* device-resident experience (ExperienceBuffer, experience_buffer.py:42-50), gathered by `idx` */
+    const float *states;          /* [N][ld_states], padded rows */
+    int64_t ld_states;
+    const float *actions;         /* [N][act_dim], float-encoded (experience_buffer.py:72) */
+    const float *old_logp;        /* [N] */
+    const float *targets;         /* [N]  value targets ("values" in the buffer) */
+    const float *advantages;      /* [N] */
+    const int64_t *idx;           /* [mb] rows of this minibatch (a slice of the epoch's permutation) */
+    int64_t mb;                   /* rows in this minibatch */
+    float clip_range;
+    float ent_coef;
+    float mb_ratio;               /* mini_batch_size / batch_size (ppo_learner.py:175) */
+    float var_m, var_b;           /* gaussian head only */
+    double *stats;                /* [RLPPO_N_STATS] device accumulators, += */
+    void *workspace;
+    size_t ws_bytes;
+} rlppo_minibatch_args;
+
+#define RLPPO_STAT_ENTROPY 0     /* += entropy of this minibatch (mean over rows)            ppo_learner.py:184 */
+#define RLPPO_STAT_KL 1          /* += mean((ratio-1) - log ratio)                            ppo_learner.py:161-162 */
+#define RLPPO_STAT_VLOSS 2       /* += mse(v, target)                                         ppo_learner.py:182 */
+#define RLPPO_STAT_CLIPFRAC 3    /* += mean(|ratio-1| > clip)                                 ppo_learner.py:165-169 */
+#define RLPPO_STAT_PLOSS 4       /* += -mean(min(ratio*A, clamp(ratio)*A))  (diagnostic)      ppo_learner.py:172-174 */
+#define RLPPO_STAT_GNORM2_POL 5  /* written by rlppo_clip_adam: squared grad norm, policy */
+#define RLPPO_STAT_GNORM2_VAL 6
+#define RLPPO_N_STATS 8
+
+/* One minibatch of PPOLearner.learn (ppo_learner.py:134-185): value forward, policy forward,
+ * get_backprop_data, clipped surrogate + entropy + value losses, both backward passes; gradients are ADDED into
+ * pol_grad / val_grad (the reference accumulates over the minibatches of a batch, ppo_learner.py:179-180). */
+int rlppo_ppo_minibatch(void *stream, const rlppo_minibatch_args *args);
+
+/* clip_grad_norm_(max_norm) + torch.optim.Adam.step() on one flat arena (ppo_learner.py:187-193).
+ * Hyper-parameters are doubles (python floats in the reference); `step` is the 1-based Adam step count of
+ * THIS update; the bias corrections lr/(1-beta1^t), sqrt(1-beta2^t) are formed in double and cast to fp32 where
+ * they meet tensor data, as torch/optim/adam.py does.  gnorm2: device double that receives the squared gradient
+ * norm before clipping.  grads are scaled in place by the clip coefficient, as clip_grad_norm_ does. */
+int rlppo_clip_adam(void *stream, float *params, float *grads, float *exp_avg, float *exp_avg_sq, int64_t n,
+                    double max_norm, double lr, double beta1, double beta2, double eps, int64_t step,
+                    double *gnorm2);
+
+/* ----------------------------------------------------------------------------------------- host helpers */
+
+/* numpy.random.RandomState legacy stream (MT19937 + masked rejection + reverse Fisher-Yates): the index stream
+ * of ExperienceBuffer.get_all_batches_shuffled (experience_buffer.py:52,97-98).  HOST code, HOST pointers.
+ * state: 625 uint32 (624 words of key + position), as numpy's get_state() exposes it. */
+int rlppo_mt19937_seed(uint32_t *state625, uint32_t seed);
+int rlppo_mt19937_permutation(uint32_t *state625, int64_t n, int64_t *out);
+
+/* ------------------------------------------------------------------------------------------ diagnostics */
+/* Single-kernel entry points used by tests/ to check each GEMM flavour in isolation against a CPU product.
+ * epilogue: 0 bias, 1 bias+relu, 2 bias+tanh, 3 relu-mask (mask_src > 0).  Shapes as in csrc/gemm.hip. */
+int rlppo_dbg_gemm_nt(void *stream, const float *A, int64_t lda, const int64_t *row_idx, const float *B, int64_t ldb,
+                      const float *bias, const float *mask_src, int64_t ld_mask, float *C, int64_t ldc, int64_t M,
+                      int32_t N, int32_t K, int32_t epilogue);
+int rlppo_dbg_gemm_tn(void *stream, const float *dY, int64_t ldy, int32_t ny_valid, const float *X, int64_t ldx,
+                      const int64_t *row_idx, int32_t kx_valid, float *dW, float *db, int32_t out, int32_t in, int64_t M);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RLPPO_H */

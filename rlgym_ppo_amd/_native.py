@@ -1,0 +1,104 @@
+"""ctypes binding of librlppo.so (C ABI: include/rlppo.h).
+
+The HIP library is the product: there is no PyTorch/CPU fallback.  `lib()` raises `NativeLibraryMissing`
+when the shared object has not been built (python -c "import __graft_entry__ as g; g.build()"), and every
+entry point's non-zero return code is turned into `RuntimeError(rlppo_last_error())`, which lands in the
+reference-compatible error handler of `Learner.learn` (reference: rlgym_ppo/learner.py:224-238).
+"""
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_double, c_float, c_int32, c_int64, c_size_t, c_uint32, c_void_p
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "librlppo.so")
+ABI_VERSION = 1
+MAX_LAYERS = 16
+N_STATS = 8
+STAT_ENTROPY, STAT_KL, STAT_VLOSS, STAT_CLIPFRAC, STAT_PLOSS = 0, 1, 2, 3, 4
+HEAD_DISCRETE, HEAD_MULTIDISCRETE, HEAD_GAUSSIAN = 0, 1, 2
+
+
+class NativeLibraryMissing(RuntimeError):
+    pass
+
+
+class MinibatchArgs(ctypes.Structure):
+    """struct rlppo_minibatch_args (include/rlppo.h)."""
+    _fields_ = [
+        ("head", c_int32), ("pol_layers", c_int32), ("val_layers", c_int32), ("act_dim", c_int32),
+        ("pol_dims", POINTER(c_int32)), ("val_dims", POINTER(c_int32)),
+        ("pol_packed", c_void_p), ("val_packed", c_void_p), ("pol_grad", c_void_p), ("val_grad", c_void_p),
+        ("states", c_void_p), ("ld_states", c_int64), ("actions", c_void_p), ("old_logp", c_void_p),
+        ("targets", c_void_p), ("advantages", c_void_p), ("idx", c_void_p), ("mb", c_int64),
+        ("clip_range", c_float), ("ent_coef", c_float), ("mb_ratio", c_float), ("var_m", c_float), ("var_b", c_float),
+        ("stats", c_void_p), ("workspace", c_void_p), ("ws_bytes", c_size_t),
+    ]
+
+
+_P32 = POINTER(c_int32)
+# name -> (restype, argtypes); kept in one table so tests can check it against the header's declarations
+SIGNATURES = {
+    "rlppo_abi_version": (c_int32, []),
+    "rlppo_last_error": (c_char_p, []),
+    "rlppo_padded_width": (c_int64, [c_int64]),
+    "rlppo_padded_out": (c_int64, [c_int64]),
+    "rlppo_packed_floats": (c_int64, [_P32, c_int32]),
+    "rlppo_flat_floats": (c_int64, [_P32, c_int32]),
+    "rlppo_net_pack": (c_int32, [c_void_p, _P32, c_int32, c_void_p, c_void_p]),
+    "rlppo_pad_rows": (c_int32, [c_void_p, c_void_p, c_int32, c_int64, c_int64, c_int64, c_void_p, c_int64, c_int32,
+                                 c_float, c_float]),
+    "rlppo_forward_workspace_bytes": (c_size_t, [_P32, c_int32, c_int64]),
+    "rlppo_mlp_forward": (c_int32, [c_void_p, _P32, c_int32, c_void_p, c_void_p, c_int64, c_int64, c_int32, c_void_p,
+                                    c_int64, c_void_p, c_size_t]),
+    "rlppo_discrete_act": (c_int32, [c_void_p, _P32, c_int32, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p,
+                                     c_void_p, c_void_p, c_void_p, c_size_t]),
+    "rlppo_categorical_select": (c_int32, [c_void_p, c_void_p, c_int64, c_int64, c_int32, c_void_p, c_void_p, c_void_p]),
+    "rlppo_gaussian_act": (c_int32, [c_void_p, _P32, c_int32, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_float,
+                                     c_float, c_void_p, c_void_p, c_void_p, c_size_t]),
+    "rlppo_multidiscrete_act": (c_int32, [c_void_p, _P32, c_int32, c_void_p, c_void_p, c_int64, c_int64, c_void_p,
+                                          c_void_p, c_void_p, c_void_p, c_size_t]),
+    "rlppo_gae_workspace_bytes": (c_size_t, [c_int64]),
+    "rlppo_gae": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_double, c_double, c_float,
+                            c_void_p, c_void_p, c_void_p, c_void_p, c_size_t]),
+    "rlppo_minibatch_workspace_bytes": (c_size_t, [_P32, c_int32, _P32, c_int32, c_int64]),
+    "rlppo_ppo_minibatch": (c_int32, [c_void_p, POINTER(MinibatchArgs)]),
+    "rlppo_clip_adam": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_double, c_double,
+                                  c_double, c_double, c_double, c_int64, c_void_p]),
+    "rlppo_mt19937_seed": (c_int32, [POINTER(c_uint32), c_uint32]),
+    "rlppo_mt19937_permutation": (c_int32, [POINTER(c_uint32), c_int64, c_void_p]),
+    "rlppo_dbg_gemm_nt": (c_int32, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_void_p,
+                                    c_int64, c_void_p, c_int64, c_int64, c_int32, c_int32, c_int32]),
+    "rlppo_dbg_gemm_tn": (c_int32, [c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_int64, c_void_p, c_int32,
+                                    c_void_p, c_void_p, c_int32, c_int32, c_int64]),
+}
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise NativeLibraryMissing(
+                f"{LIB_PATH} not found. rlgym_ppo_amd has no CPU/PyTorch fallback: build the HIP library first "
+                f"(python -c 'import __graft_entry__ as g; g.build()' or make -C rlgym_ppo_amd/csrc).")
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)  # AttributeError here == symbol missing == broken build
+            fn.restype = res
+            fn.argtypes = args
+        v = L.rlppo_abi_version()
+        if v != ABI_VERSION:
+            raise NativeLibraryMissing(f"librlppo.so ABI {v} != expected {ABI_VERSION}: rebuild it")
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        msg = lib().rlppo_last_error()
+        raise RuntimeError(f"librlppo error {rc}: {msg.decode() if msg else '?'}")
+
+
+def dims_array(dims):
+    return (c_int32 * len(dims))(*[int(d) for d in dims])

@@ -1,0 +1,382 @@
+// api.hip -- the extern "C" surface declared in include/rlppo.h: argument checking, packed-layout bookkeeping and
+// the launch sequences (forward, sampling, GAE, one PPO minibatch, clip+Adam).  No device allocation, no
+// synchronisation: everything is enqueued on the caller's stream.
+#include <math.h>
+#include <stdarg.h>
+#include <string.h>
+
+#include "common.hpp"
+
+namespace rlppo {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+static int64_t padded_width(int64_t d) { return round_up(d, 32); }
+static int64_t padded_out(int64_t d) {
+    if (d <= 32) return 32;
+    if (d <= 64) return 64;
+    if (d <= 96) return 96;
+    return round_up(d, 128);
+}
+
+int make_layout(const int32_t *dims, int32_t n_layers, NetLayout *out) {
+    RLPPO_CHECK_ARG(dims != nullptr && n_layers >= 1 && n_layers <= RLPPO_MAX_LAYERS, "network: n_layers=%d not in [1,%d]",
+                    n_layers, RLPPO_MAX_LAYERS);
+    for (int i = 0; i <= n_layers; ++i) RLPPO_CHECK_ARG(dims[i] >= 1, "network: dims[%d]=%d", i, dims[i]);
+    out->n_layers = n_layers;
+    int64_t off = 0, flat = 0;
+    int pin = (int)padded_width(dims[0]);
+    for (int l = 0; l < n_layers; ++l) {
+        LayerLayout &L = out->L[l];
+        L.in = dims[l];
+        L.out = dims[l + 1];
+        L.pin = pin;
+        L.pout = (int)padded_out(dims[l + 1]);
+        L.off_w = off;
+        off += (int64_t)L.pout * L.pin;
+        L.off_wt = off;
+        off += (int64_t)L.pin * L.pout;
+        L.off_b = off;
+        off += L.pout;
+        L.off_flat_w = flat;
+        flat += (int64_t)L.out * L.in;
+        L.off_flat_b = flat;
+        flat += L.out;
+        pin = L.pout;
+    }
+    out->packed_floats = off;
+    out->flat_floats = flat;
+    return 0;
+}
+
+static int max_pout(const NetLayout &net) {
+    int m = 0;
+    for (int l = 0; l < net.n_layers; ++l) m = net.L[l].pout > m ? net.L[l].pout : m;
+    return m;
+}
+
+// Forward pass.  acts[l] receives the output of layer l ([n][pout_l]); for inference the caller passes two
+// ping-pong buffers, for training one buffer per layer (they are the saved activations of the backward pass).
+static int forward(hipStream_t st, const NetLayout &net, const float *packed, const float *obs, int64_t ld_obs,
+                   const int64_t *row_idx, int64_t n, int out_tanh, float *const *acts) {
+    const float *x = obs;
+    int64_t ldx = ld_obs;
+    const int64_t *ridx = row_idx;
+    for (int l = 0; l < net.n_layers; ++l) {
+        const LayerLayout &L = net.L[l];
+        const bool last = l == net.n_layers - 1;
+        const int epi = last ? (out_tanh ? EPI_BIAS_TANH : EPI_BIAS) : EPI_BIAS_RELU;
+        int rc = launch_gemm_nt(st, x, ldx, ridx, packed + L.off_w, L.pin, packed + L.off_b, nullptr, 0, acts[l], L.pout, n,
+                                L.pout, L.pin, epi);
+        if (rc) return rc;
+        x = acts[l];
+        ldx = L.pout;
+        ridx = nullptr;
+    }
+    return 0;
+}
+
+static size_t forward_ws_floats(const NetLayout &net, int64_t n) { return (size_t)2 * (size_t)n * (size_t)max_pout(net); }
+
+// runs the net with ping-pong buffers from the workspace and returns the pointer/ld of the last layer's output
+static int forward_pingpong(hipStream_t st, const NetLayout &net, const float *packed, const float *obs, int64_t ld_obs,
+                            int64_t n, int out_tanh, void *ws, size_t ws_bytes, float *final_out, const float **out,
+                            int64_t *ld_out) {
+    if (ws_bytes < forward_ws_floats(net, n) * sizeof(float)) {
+        set_error("forward: workspace %zu < %zu bytes", ws_bytes, forward_ws_floats(net, n) * sizeof(float));
+        return RLPPO_ERR_WORKSPACE;
+    }
+    RLPPO_CHECK_ARG(ld_obs >= net.L[0].pin && ld_obs % 4 == 0, "forward: ld_obs=%ld must be >= %d (zero padded rows)",
+                    (long)ld_obs, net.L[0].pin);
+    float *b0 = reinterpret_cast<float *>(ws);
+    float *b1 = b0 + (size_t)n * max_pout(net);
+    float *acts[RLPPO_MAX_LAYERS];
+    for (int l = 0; l < net.n_layers; ++l) acts[l] = (l & 1) ? b1 : b0;
+    if (final_out) acts[net.n_layers - 1] = final_out;
+    int rc = forward(st, net, packed, obs, ld_obs, nullptr, n, out_tanh, acts);
+    if (rc) return rc;
+    *out = acts[net.n_layers - 1];
+    *ld_out = net.L[net.n_layers - 1].pout;
+    return 0;
+}
+
+}  // namespace rlppo
+
+using namespace rlppo;
+
+extern "C" {
+
+int rlppo_abi_version(void) { return RLPPO_ABI_VERSION; }
+const char *rlppo_last_error(void) { return g_err; }
+
+int64_t rlppo_padded_width(int64_t d) { return padded_width(d); }
+int64_t rlppo_padded_out(int64_t d) { return padded_out(d); }
+
+int64_t rlppo_packed_floats(const int32_t *dims, int32_t n_layers) {
+    NetLayout net;
+    if (make_layout(dims, n_layers, &net)) return -1;
+    return net.packed_floats;
+}
+int64_t rlppo_flat_floats(const int32_t *dims, int32_t n_layers) {
+    NetLayout net;
+    if (make_layout(dims, n_layers, &net)) return -1;
+    return net.flat_floats;
+}
+
+int rlppo_net_pack(void *stream, const int32_t *dims, int32_t n_layers, const float *flat, float *packed) {
+    NetLayout net;
+    int rc = make_layout(dims, n_layers, &net);
+    if (rc) return rc;
+    RLPPO_CHECK_ARG(flat && packed, "net_pack: null pointer");
+    return launch_pack((hipStream_t)stream, net, flat, packed);
+}
+
+int rlppo_pad_rows(void *stream, const void *src, int32_t src_is_f64, int64_t n, int64_t d, int64_t ld_src, float *dst,
+                   int64_t ld_dst, int32_t standardize, float mean0, float std0) {
+    RLPPO_CHECK_ARG(n >= 0 && d >= 1 && ld_src >= d && ld_dst >= d, "pad_rows: n=%ld d=%ld ld_src=%ld ld_dst=%ld", (long)n,
+                    (long)d, (long)ld_src, (long)ld_dst);
+    RLPPO_CHECK_ARG(n == 0 || (src && dst), "pad_rows: null pointer");
+    return launch_pad_rows((hipStream_t)stream, src, src_is_f64, n, d, ld_src, dst, ld_dst, standardize, mean0, std0);
+}
+
+size_t rlppo_forward_workspace_bytes(const int32_t *dims, int32_t n_layers, int64_t n) {
+    NetLayout net;
+    if (make_layout(dims, n_layers, &net)) return 0;
+    return forward_ws_floats(net, n > 0 ? n : 0) * sizeof(float) + 256;
+}
+
+int rlppo_mlp_forward(void *stream, const int32_t *dims, int32_t n_layers, const float *packed, const float *obs,
+                      int64_t ld_obs, int64_t n, int32_t out_tanh, float *out, int64_t ld_out, void *workspace,
+                      size_t ws_bytes) {
+    NetLayout net;
+    int rc = make_layout(dims, n_layers, &net);
+    if (rc) return rc;
+    if (n == 0) return 0;
+    RLPPO_CHECK_ARG(n > 0 && packed && obs && out && workspace, "mlp_forward: bad argument");
+    RLPPO_CHECK_ARG(ld_out == net.L[n_layers - 1].pout, "mlp_forward: ld_out=%ld must equal the padded output width %d",
+                    (long)ld_out, net.L[n_layers - 1].pout);
+    const float *o;
+    int64_t ldo;
+    return forward_pingpong((hipStream_t)stream, net, packed, obs, ld_obs, n, out_tanh, workspace, ws_bytes, out, &o, &ldo);
+}
+
+int rlppo_discrete_act(void *stream, const int32_t *dims, int32_t n_layers, const float *packed, const float *obs,
+                       int64_t ld_obs, int64_t n, const float *noise_q, int64_t *actions, float *logp, float *probs_out,
+                       void *workspace, size_t ws_bytes) {
+    NetLayout net;
+    int rc = make_layout(dims, n_layers, &net);
+    if (rc) return rc;
+    if (n == 0) return 0;
+    RLPPO_CHECK_ARG(n > 0 && packed && obs && noise_q && actions && logp && workspace, "discrete_act: bad argument");
+    const float *o;
+    int64_t ldo;
+    rc = forward_pingpong((hipStream_t)stream, net, packed, obs, ld_obs, n, 0, workspace, ws_bytes, nullptr, &o, &ldo);
+    if (rc) return rc;
+    return launch_discrete_sample_logits((hipStream_t)stream, o, ldo, n, dims[n_layers], noise_q, actions, logp, probs_out);
+}
+
+int rlppo_categorical_select(void *stream, const float *probs, int64_t ld_p, int64_t n, int32_t n_cat,
+                             const float *noise_q, int64_t *actions, float *logp) {
+    if (n == 0) return 0;
+    RLPPO_CHECK_ARG(n > 0 && probs && noise_q && actions && logp && n_cat >= 1 && ld_p >= n_cat, "categorical_select: bad argument");
+    return launch_categorical_select((hipStream_t)stream, probs, ld_p, n, n_cat, noise_q, actions, logp);
+}
+
+int rlppo_gaussian_act(void *stream, const int32_t *dims, int32_t n_layers, const float *packed, const float *obs,
+                       int64_t ld_obs, int64_t n, const float *noise_eps, float var_m, float var_b, float *actions,
+                       float *logp, void *workspace, size_t ws_bytes) {
+    NetLayout net;
+    int rc = make_layout(dims, n_layers, &net);
+    if (rc) return rc;
+    if (n == 0) return 0;
+    RLPPO_CHECK_ARG(n > 0 && packed && obs && noise_eps && actions && logp && workspace, "gaussian_act: bad argument");
+    RLPPO_CHECK_ARG(dims[n_layers] % 2 == 0, "gaussian_act: output width %d must be 2k", dims[n_layers]);
+    const float *o;
+    int64_t ldo;
+    rc = forward_pingpong((hipStream_t)stream, net, packed, obs, ld_obs, n, 1, workspace, ws_bytes, nullptr, &o, &ldo);
+    if (rc) return rc;
+    return launch_gaussian_sample((hipStream_t)stream, o, ldo, n, dims[n_layers] / 2, noise_eps, var_m, var_b, actions, logp);
+}
+
+int rlppo_multidiscrete_act(void *stream, const int32_t *dims, int32_t n_layers, const float *packed, const float *obs,
+                            int64_t ld_obs, int64_t n, const float *noise_q, int64_t *actions, float *logp,
+                            void *workspace, size_t ws_bytes) {
+    NetLayout net;
+    int rc = make_layout(dims, n_layers, &net);
+    if (rc) return rc;
+    if (n == 0) return 0;
+    RLPPO_CHECK_ARG(n > 0 && packed && obs && noise_q && actions && logp && workspace, "multidiscrete_act: bad argument");
+    RLPPO_CHECK_ARG(dims[n_layers] == 21, "multidiscrete_act: output width %d must be 21", dims[n_layers]);
+    const float *o;
+    int64_t ldo;
+    rc = forward_pingpong((hipStream_t)stream, net, packed, obs, ld_obs, n, 0, workspace, ws_bytes, nullptr, &o, &ldo);
+    if (rc) return rc;
+    return launch_multidiscrete_sample((hipStream_t)stream, o, ldo, n, noise_q, actions, logp);
+}
+
+size_t rlppo_gae_workspace_bytes(int64_t n) { return gae_workspace_bytes(n) + 256; }
+
+int rlppo_gae(void *stream, const float *rews, const float *dones, const float *truncated, const float *values, int64_t n,
+              double gamma, double lmbda, float return_std, float *value_targets, float *advantages, float *returns,
+              void *workspace, size_t ws_bytes) {
+    if (n == 0) return 0;
+    RLPPO_CHECK_ARG(n > 0 && rews && dones && truncated && values && value_targets && advantages && returns && workspace,
+                    "gae: bad argument");
+    return launch_gae((hipStream_t)stream, rews, dones, truncated, values, n, gamma, lmbda, return_std, value_targets,
+                      advantages, returns, workspace, ws_bytes);
+}
+
+// ------------------------------------------------------------------------------------------- PPO minibatch
+static size_t train_ws_floats(const NetLayout &pol, const NetLayout &val, int64_t mb) {
+    size_t per_row = 0;
+    for (int l = 0; l < pol.n_layers; ++l) per_row += pol.L[l].pout;
+    for (int l = 0; l < val.n_layers; ++l) per_row += val.L[l].pout;
+    int m = max_pout(pol) > max_pout(val) ? max_pout(pol) : max_pout(val);
+    per_row += 2 * (size_t)m;
+    return per_row * (size_t)mb;
+}
+
+size_t rlppo_minibatch_workspace_bytes(const int32_t *pol_dims, int32_t pol_layers, const int32_t *val_dims,
+                                       int32_t val_layers, int64_t mb) {
+    NetLayout pol, val;
+    if (make_layout(pol_dims, pol_layers, &pol) || make_layout(val_dims, val_layers, &val)) return 0;
+    return train_ws_floats(pol, val, mb > 0 ? mb : 0) * sizeof(float) + 256;
+}
+
+// backward of one net: acts[l] = saved output of layer l, acts[last] holds dL/d(out) on entry
+static int backward(hipStream_t st, const NetLayout &net, const float *packed, const float *states, int64_t ld_states,
+                    const int64_t *idx, int64_t mb, float *const *acts, float *d0, float *d1, float *grad) {
+    const int last = net.n_layers - 1;
+    const float *dY = acts[last];
+    for (int l = last; l >= 0; --l) {
+        const LayerLayout &L = net.L[l];
+        const float *X = l > 0 ? acts[l - 1] : states;
+        const int64_t ldx = l > 0 ? net.L[l - 1].pout : ld_states;
+        int rc = launch_gemm_tn(st, dY, L.pout, L.pout, X, ldx, l > 0 ? nullptr : idx, L.pin, grad + L.off_flat_w,
+                                grad + L.off_flat_b, L.out, L.in, mb);
+        if (rc) return rc;
+        if (l > 0) {
+            float *dX = ((last - l) & 1) ? d1 : d0;
+            // dX[mb][pin] = (dY[mb][pout] . W[pout][pin]) masked by relu'(acts[l-1]); B operand = W^T [pin][pout]
+            rc = launch_gemm_nt(st, dY, L.pout, nullptr, packed + L.off_wt, L.pout, nullptr, acts[l - 1], L.pin, dX, L.pin, mb,
+                                L.pin, L.pout, EPI_MASK);
+            if (rc) return rc;
+            dY = dX;
+        }
+    }
+    return 0;
+}
+
+int rlppo_ppo_minibatch(void *stream, const rlppo_minibatch_args *a) {
+    RLPPO_CHECK_ARG(a != nullptr, "ppo_minibatch: null args");
+    NetLayout pol, val;
+    int rc = make_layout(a->pol_dims, a->pol_layers, &pol);
+    if (rc) return rc;
+    rc = make_layout(a->val_dims, a->val_layers, &val);
+    if (rc) return rc;
+    const int64_t mb = a->mb;
+    if (mb == 0) return 0;
+    RLPPO_CHECK_ARG(mb > 0 && a->pol_packed && a->val_packed && a->pol_grad && a->val_grad && a->states && a->actions &&
+                        a->old_logp && a->targets && a->advantages && a->idx && a->stats && a->workspace,
+                    "ppo_minibatch: null pointer");
+    RLPPO_CHECK_ARG(val.L[val.n_layers - 1].out == 1, "ppo_minibatch: critic must have one output");
+    RLPPO_CHECK_ARG(pol.L[0].in == val.L[0].in, "ppo_minibatch: policy and critic observe different sizes");
+    RLPPO_CHECK_ARG(a->ld_states >= pol.L[0].pin && a->ld_states % 4 == 0, "ppo_minibatch: ld_states=%ld < %d",
+                    (long)a->ld_states, pol.L[0].pin);
+    if (a->ws_bytes < train_ws_floats(pol, val, mb) * sizeof(float)) {
+        set_error("ppo_minibatch: workspace %zu < %zu bytes", a->ws_bytes, train_ws_floats(pol, val, mb) * sizeof(float));
+        return RLPPO_ERR_WORKSPACE;
+    }
+    const int n_out = pol.L[pol.n_layers - 1].out;
+    if (a->head == RLPPO_HEAD_DISCRETE) RLPPO_CHECK_ARG(a->act_dim == 1, "discrete head: act_dim must be 1");
+    if (a->head == RLPPO_HEAD_GAUSSIAN)
+        RLPPO_CHECK_ARG(n_out % 2 == 0 && a->act_dim == n_out / 2, "gaussian head: act_dim=%d, outputs=%d", a->act_dim, n_out);
+    if (a->head == RLPPO_HEAD_MULTIDISCRETE)
+        RLPPO_CHECK_ARG(n_out == 21 && a->act_dim == 8, "multi-discrete head: needs 21 outputs and act_dim 8");
+
+    hipStream_t st = (hipStream_t)stream;
+    float *w = reinterpret_cast<float *>(a->workspace);
+    float *pact[RLPPO_MAX_LAYERS], *vact[RLPPO_MAX_LAYERS];
+    for (int l = 0; l < pol.n_layers; ++l) {
+        pact[l] = w;
+        w += (size_t)mb * pol.L[l].pout;
+    }
+    for (int l = 0; l < val.n_layers; ++l) {
+        vact[l] = w;
+        w += (size_t)mb * val.L[l].pout;
+    }
+    const int m = max_pout(pol) > max_pout(val) ? max_pout(pol) : max_pout(val);
+    float *d0 = w, *d1 = w + (size_t)mb * m;
+
+    // forward of both nets; the minibatch gather (experience_buffer.py:82-87) is fused into the first layer's loads
+    rc = forward(st, val, a->val_packed, a->states, a->ld_states, a->idx, mb, 0, vact);
+    if (rc) return rc;
+    rc = forward(st, pol, a->pol_packed, a->states, a->ld_states, a->idx, mb, a->head == RLPPO_HEAD_GAUSSIAN, pact);
+    if (rc) return rc;
+
+    // loss epilogue: outputs -> output gradients in place, report statistics accumulated on device
+    LossCfg cfg;
+    cfg.clip = a->clip_range;
+    cfg.clip_lo = (float)(1.0 - (double)a->clip_range);
+    cfg.clip_hi = (float)(1.0 + (double)a->clip_range);
+    cfg.ent_coef = a->ent_coef;
+    cfg.mb_ratio = a->mb_ratio;
+    cfg.inv_mb = 1.0f / (float)mb;
+    cfg.var_m = a->var_m;
+    cfg.var_b = a->var_b;
+    float *pout = pact[pol.n_layers - 1], *vout = vact[val.n_layers - 1];
+    const int64_t ldp = pol.L[pol.n_layers - 1].pout, ldv = val.L[val.n_layers - 1].pout;
+    if (a->head == RLPPO_HEAD_DISCRETE)
+        rc = launch_discrete_loss(st, pout, ldp, n_out, vout, ldv, a->idx, a->actions, a->old_logp, a->targets,
+                                  a->advantages, mb, cfg, a->stats);
+    else if (a->head == RLPPO_HEAD_GAUSSIAN)
+        rc = launch_gaussian_loss(st, pout, ldp, n_out / 2, vout, ldv, a->idx, a->actions, a->old_logp, a->targets,
+                                  a->advantages, mb, cfg, a->stats);
+    else if (a->head == RLPPO_HEAD_MULTIDISCRETE)
+        rc = launch_multidiscrete_loss(st, pout, ldp, vout, ldv, a->idx, a->actions, a->old_logp, a->targets, a->advantages,
+                                       mb, cfg, a->stats);
+    else {
+        set_error("ppo_minibatch: unknown head %d", a->head);
+        rc = RLPPO_ERR_ARG;
+    }
+    if (rc) return rc;
+
+    rc = backward(st, pol, a->pol_packed, a->states, a->ld_states, a->idx, mb, pact, d0, d1, a->pol_grad);
+    if (rc) return rc;
+    return backward(st, val, a->val_packed, a->states, a->ld_states, a->idx, mb, vact, d0, d1, a->val_grad);
+}
+
+int rlppo_clip_adam(void *stream, float *params, float *grads, float *exp_avg, float *exp_avg_sq, int64_t n,
+                    double max_norm, double lr, double beta1, double beta2, double eps, int64_t step, double *gnorm2) {
+    if (n == 0) return 0;
+    RLPPO_CHECK_ARG(n > 0 && params && grads && exp_avg && exp_avg_sq && gnorm2 && step >= 1, "clip_adam: bad argument");
+    // torch/optim/adam.py (_single_tensor_adam): python-double scalars, cast to fp32 where they meet a tensor
+    const double bc1 = 1.0 - pow(beta1, (double)step);
+    const double bc2 = 1.0 - pow(beta2, (double)step);
+    const float step_size = (float)(lr / bc1);
+    const float bc2_sqrt = (float)sqrt(bc2);
+    return launch_clip_adam((hipStream_t)stream, params, grads, exp_avg, exp_avg_sq, n, (float)max_norm, step_size, bc2_sqrt,
+                            (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps, gnorm2);
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------------------------------ diagnostics
+extern "C" {
+int rlppo_dbg_gemm_nt(void *stream, const float *A, int64_t lda, const int64_t *row_idx, const float *B, int64_t ldb,
+                      const float *bias, const float *mask_src, int64_t ld_mask, float *C, int64_t ldc, int64_t M,
+                      int32_t N, int32_t K, int32_t epilogue) {
+    return launch_gemm_nt((hipStream_t)stream, A, lda, row_idx, B, ldb, bias, mask_src, ld_mask, C, ldc, M, N, K, epilogue);
+}
+int rlppo_dbg_gemm_tn(void *stream, const float *dY, int64_t ldy, int32_t ny_valid, const float *X, int64_t ldx,
+                      const int64_t *row_idx, int32_t kx_valid, float *dW, float *db, int32_t out, int32_t in, int64_t M) {
+    return launch_gemm_tn((hipStream_t)stream, dY, ldy, ny_valid, X, ldx, row_idx, kx_valid, dW, db, out, in, M);
+}
+}

@@ -1,0 +1,91 @@
+// common.hpp -- shared host/device helpers of librlppo.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/rlppo.h"
+
+namespace rlppo {
+
+void set_error(const char *fmt, ...);
+
+#define RLPPO_CHECK_ARG(cond, ...)                \
+    do {                                          \
+        if (!(cond)) {                            \
+            rlppo::set_error(__VA_ARGS__);        \
+            return RLPPO_ERR_ARG;                 \
+        }                                         \
+    } while (0)
+
+#define RLPPO_HIP(expr)                                                                         \
+    do {                                                                                        \
+        hipError_t e_ = (expr);                                                                 \
+        if (e_ != hipSuccess) {                                                                 \
+            rlppo::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return (int)e_;                                                                     \
+        }                                                                                       \
+    } while (0)
+
+#define RLPPO_LAUNCH_CHECK() RLPPO_HIP(hipGetLastError())
+
+static inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
+static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// ---- packed network layout ------------------------------------------------------------------------
+// For layer l (0-based) with logical in_l = dims[l], out_l = dims[l+1]:
+//   Pin_l  = padded_width(dims[0]) for l == 0, else Pout_{l-1}
+//   Pout_l = padded_out(dims[l+1])
+// packed = for each layer: W[Pout][Pin] | WT[Pin][Pout] | b[Pout]   (all zero padded)
+struct LayerLayout {
+    int in, out;        // logical
+    int pin, pout;      // padded
+    int64_t off_w, off_wt, off_b;  // float offsets into the packed buffer
+    int64_t off_flat_w, off_flat_b;  // float offsets into the flat arena
+};
+
+struct NetLayout {
+    int n_layers;
+    LayerLayout L[RLPPO_MAX_LAYERS];
+    int64_t packed_floats;
+    int64_t flat_floats;
+};
+
+int make_layout(const int32_t *dims, int32_t n_layers, NetLayout *out);
+
+// ---- kernel launchers shared between translation units ------------------------------------------
+enum Epilogue { EPI_BIAS = 0, EPI_BIAS_RELU = 1, EPI_BIAS_TANH = 2, EPI_MASK = 3 };
+
+// C[m][0:N] = epi(A[m][0:K] . B[n][0:K]^T)   (K % 32 == 0, N = padded out in {32,64,96,128,k*128})
+int launch_gemm_nt(hipStream_t st, const float *A, int64_t lda, const int64_t *row_idx, const float *B, int64_t ldb,
+                   const float *bias, const float *mask_src, int64_t ld_mask, float *C, int64_t ldc, int64_t M, int N,
+                   int K, int epi);
+
+// dW[n][k] += sum_m dY[m][n] X[m][k] ; db[n] += sum_m dY[m][n]   (atomic accumulation into the flat arena)
+int launch_gemm_tn(hipStream_t st, const float *dY, int64_t ldy, int ny_valid, const float *X, int64_t ldx,
+                   const int64_t *row_idx, int kx_valid, float *dW, float *db, int out, int in, int64_t M);
+
+struct LossCfg {
+    float clip, clip_lo, clip_hi, ent_coef, mb_ratio, inv_mb;
+    float var_m, var_b;
+};
+
+int launch_pack(hipStream_t, const NetLayout &, const float *, float *);
+int launch_pad_rows(hipStream_t, const void *, int, int64_t, int64_t, int64_t, float *, int64_t, int, float, float);
+int launch_clip_adam(hipStream_t, float *p, float *g, float *m, float *v, int64_t n, float max_norm, float step_size,
+                     float bc2_sqrt, float one_minus_beta1, float beta2, float one_minus_beta2, float eps, double *gnorm2);
+size_t gae_workspace_bytes(int64_t n);
+int launch_gae(hipStream_t, const float *, const float *, const float *, const float *, int64_t, double, double, float,
+               float *, float *, float *, void *, size_t);
+int launch_discrete_sample_logits(hipStream_t, const float *, int64_t, int64_t, int, const float *, int64_t *, float *, float *);
+int launch_categorical_select(hipStream_t, const float *, int64_t, int64_t, int, const float *, int64_t *, float *);
+int launch_gaussian_sample(hipStream_t, const float *, int64_t, int64_t, int, const float *, float, float, float *, float *);
+int launch_multidiscrete_sample(hipStream_t, const float *, int64_t, int64_t, const float *, int64_t *, float *);
+int launch_discrete_loss(hipStream_t, float *, int64_t, int, float *, int64_t, const int64_t *, const float *, const float *,
+                         const float *, const float *, int64_t, const LossCfg &, double *);
+int launch_gaussian_loss(hipStream_t, float *, int64_t, int, float *, int64_t, const int64_t *, const float *, const float *,
+                         const float *, const float *, int64_t, const LossCfg &, double *);
+int launch_multidiscrete_loss(hipStream_t, float *, int64_t, float *, int64_t, const int64_t *, const float *, const float *,
+                              const float *, const float *, int64_t, const LossCfg &, double *);
+
+}  // namespace rlppo

@@ -1,0 +1,133 @@
+// optim.hip -- parameter-side kernels: packing the flat arena into tile-padded W / W^T / b, observation row
+// padding (+ the reference's scalar standardisation), gradient-norm clip + Adam on the flat arena.
+#include "common.hpp"
+
+namespace rlppo {
+
+// ------------------------------------------------------------------------------------------------ pack
+struct PackJob {
+    int in, out, pin, pout;
+    int64_t off_w, off_wt, off_b, off_flat_w, off_flat_b;
+    int64_t first;  // first global work item of this layer
+};
+struct PackJobs {
+    int n;
+    PackJob j[RLPPO_MAX_LAYERS];
+    int64_t total;
+};
+
+// one work item per element of the padded W (pout*pin); the same thread also writes W^T and (row 0 items) b
+__global__ __launch_bounds__(256) void pack_kernel(const float *__restrict__ flat, float *__restrict__ packed, PackJobs jobs) {
+    for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < jobs.total; g += (int64_t)gridDim.x * blockDim.x) {
+        int l = 0;
+        while (l + 1 < jobs.n && g >= jobs.j[l + 1].first) ++l;
+        const PackJob &J = jobs.j[l];
+        const int64_t e = g - J.first;
+        const int o = (int)(e / J.pin), i = (int)(e % J.pin);
+        const float w = (o < J.out && i < J.in) ? flat[J.off_flat_w + (int64_t)o * J.in + i] : 0.f;
+        packed[J.off_w + (int64_t)o * J.pin + i] = w;
+        packed[J.off_wt + (int64_t)i * J.pout + o] = w;
+        if (i == 0) packed[J.off_b + o] = o < J.out ? flat[J.off_flat_b + o] : 0.f;
+    }
+}
+
+int launch_pack(hipStream_t st, const NetLayout &net, const float *flat, float *packed) {
+    PackJobs jobs;
+    jobs.n = net.n_layers;
+    int64_t tot = 0;
+    for (int l = 0; l < net.n_layers; ++l) {
+        const LayerLayout &L = net.L[l];
+        jobs.j[l] = PackJob{L.in, L.out, L.pin, L.pout, L.off_w, L.off_wt, L.off_b, L.off_flat_w, L.off_flat_b, tot};
+        tot += (int64_t)L.pin * L.pout;
+    }
+    jobs.total = tot;
+    const int blocks = (int)(cdiv(tot, 256) < 2048 ? cdiv(tot, 256) : 2048);
+    hipLaunchKernelGGL(pack_kernel, dim3(blocks), dim3(256), 0, st, flat, packed, jobs);
+    RLPPO_LAUNCH_CHECK();
+    return 0;
+}
+
+// --------------------------------------------------------------------------------------------- pad rows
+template <typename T>
+__global__ __launch_bounds__(256) void pad_rows_kernel(const T *__restrict__ src, int64_t n, int64_t d, int64_t ld_src,
+                                                        float *__restrict__ dst, int64_t ld_dst, int standardize,
+                                                        float mean0, float std0) {
+    const int64_t total = n * ld_dst;
+    for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = g / ld_dst, c = g % ld_dst;
+        float v = 0.f;
+        if (c < d) {
+            v = (float)src[r * ld_src + c];
+            // np.clip((obs - mean) / std, -5, 5) with float32 scalars (batched_agent_manager.py:313-315)
+            if (standardize) v = fminf(fmaxf((v - mean0) / std0, -5.f), 5.f);
+        }
+        dst[g] = v;
+    }
+}
+
+int launch_pad_rows(hipStream_t st, const void *src, int is_f64, int64_t n, int64_t d, int64_t ld_src, float *dst,
+                    int64_t ld_dst, int standardize, float mean0, float std0) {
+    if (n <= 0) return 0;
+    const int64_t total = n * ld_dst;
+    const int blocks = (int)(cdiv(total, 256) < 4096 ? cdiv(total, 256) : 4096);
+    if (is_f64)
+        hipLaunchKernelGGL(pad_rows_kernel<double>, dim3(blocks), dim3(256), 0, st, (const double *)src, n, d, ld_src, dst,
+                           ld_dst, standardize, mean0, std0);
+    else
+        hipLaunchKernelGGL(pad_rows_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float *)src, n, d, ld_src, dst,
+                           ld_dst, standardize, mean0, std0);
+    RLPPO_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------ clip + Adam
+__global__ __launch_bounds__(256) void sqnorm_kernel(const float *__restrict__ g, int64_t n, double *__restrict__ out) {
+    double acc = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const double v = (double)g[i];
+        acc += v * v;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    __shared__ double red[4];
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(out, red[0] + red[1] + red[2] + red[3]);
+}
+
+// torch.optim.Adam single-tensor math (lerp / mul+addcmul / sqrt,div,add / addcdiv), with the clip coefficient
+// of clip_grad_norm_ folded in: coef = min(1, max_norm / (||g|| + 1e-6)).
+__global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ p, float *__restrict__ g, float *__restrict__ m,
+                                                    float *__restrict__ v, int64_t n, const double *__restrict__ gnorm2,
+                                                    float max_norm, float step_size, float bc2_sqrt, float omb1,
+                                                    float beta2, float omb2, float eps) {
+    const float total = (float)sqrt(*gnorm2);
+    float coef = max_norm / (total + 1e-6f);
+    coef = coef > 1.f ? 1.f : coef;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float gi = g[i] * coef;
+        g[i] = gi;  // clip_grad_norm_ scales .grad in place
+        float mi = m[i], vi = v[i];
+        mi = mi + omb1 * (gi - mi);             // exp_avg.lerp_(grad, 1 - beta1)
+        vi = vi * beta2 + (omb2 * gi) * gi;       // mul_(beta2).addcmul_(grad, grad, value=1 - beta2)
+        const float denom = sqrtf(vi) / bc2_sqrt + eps;
+        p[i] = p[i] + (-step_size * mi) / denom;
+        m[i] = mi;
+        v[i] = vi;
+    }
+}
+
+int launch_clip_adam(hipStream_t st, float *p, float *g, float *m, float *v, int64_t n, float max_norm, float step_size,
+                     float bc2_sqrt, float omb1, float beta2, float omb2, float eps, double *gnorm2) {
+    if (n <= 0) return 0;
+    RLPPO_HIP(hipMemsetAsync(gnorm2, 0, sizeof(double), st));
+    const int blocks = (int)(cdiv(n, 256) < 1024 ? cdiv(n, 256) : 1024);
+    hipLaunchKernelGGL(sqnorm_kernel, dim3(blocks), dim3(256), 0, st, g, n, gnorm2);
+    RLPPO_LAUNCH_CHECK();
+    hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, st, p, g, m, v, n, gnorm2, max_norm, step_size, bc2_sqrt,
+                       omb1, beta2, omb2, eps);
+    RLPPO_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace rlppo

@@ -1,0 +1,291 @@
+"""PPOLearner -- drop-in for rlgym_ppo/ppo/ppo_learner.py:10-271 with the update running in librlppo.so.
+
+Same constructor, attributes (`policy`, `value_net`, `policy_optimizer`, `value_optimizer`,
+`cumulative_model_updates`), `learn(exp) -> 8-key report`, `save_to` / `load_from` (same four .pt files with stock
+state_dict layouts).  What changed underneath:
+
+  * one call to rlppo_ppo_minibatch per minibatch replaces ~60 eager ATen launches, 5 H2D copies and 5 .item()
+    syncs (ppo_learner.py:139-185); the report statistics accumulate in device doubles and are read back once;
+  * the epoch permutation is drawn on the host (bit-identical numpy legacy stream) while the GPU is still busy
+    with the previous epoch, and only the index vector crosses PCIe;
+  * clip_grad_norm_ + Adam.step() are one fused pass over a flat parameter arena (rlppo_clip_adam);
+  * data-parallel: the minibatch slices of a batch are dealt round-robin to the ranks of the default
+    torch.distributed group and ONE RCCL all-reduce of the flat gradient arena precedes clipping -- algebraically
+    the reference's own gradient accumulation (ppo_learner.py:134-193) with slice j living on rank j % world.
+"""
+import ctypes
+import os
+import time
+
+import numpy as np
+import torch
+
+from .. import _native as N
+from ..engine import Workspace, ptr, require_gpu, stream_ptr
+from .continuous_policy import ContinuousPolicy
+from .discrete_policy import DiscreteFF
+from .multi_discrete_policy import MultiDiscreteFF
+from .value_estimator import ValueEstimator
+
+MAX_GRAD_NORM = 0.5  # ppo_learner.py:187-190
+
+
+class FusedAdam(torch.optim.Adam):
+    """torch.optim.Adam whose step() is librlppo's fused clip+Adam kernel on the module's flat arena.  State lives
+    in two flat tensors; `state[p]` exposes views of them in the stock layout {step, exp_avg, exp_avg_sq}, so
+    state_dict()/load_state_dict() and checkpoints interchange with the reference's optimisers."""
+
+    def __init__(self, module, lr):
+        self.arena = module.arena
+        super().__init__(list(module.arena.params()), lr=lr)
+        a = self.arena
+        self.exp_avg = torch.zeros(a.n_flat, dtype=torch.float32, device=a.device)
+        self.exp_avg_sq = torch.zeros(a.n_flat, dtype=torch.float32, device=a.device)
+        self.gnorm2 = torch.zeros(1, dtype=torch.float64, device=a.device)
+        self.step_count = 0
+
+    def _expose_state(self):
+        o = 0
+        for p in self.param_groups[0]["params"]:
+            n = p.numel()
+            self.state[p] = {"step": torch.tensor(float(self.step_count)),
+                             "exp_avg": self.exp_avg[o:o + n].view(p.shape),
+                             "exp_avg_sq": self.exp_avg_sq[o:o + n].view(p.shape)}
+            o += n
+
+    def zero_grad(self, set_to_none=True):
+        self.arena.grad.zero_()  # keep the .grad views alive: the kernels accumulate into the arena
+
+    @torch.no_grad()
+    def step(self, closure=None, max_norm=None):
+        g = self.param_groups[0]
+        if not self.arena.is_bound():
+            self.arena.bind()
+        self.step_count += 1
+        b1, b2 = g["betas"]
+        N.check(N.lib().rlppo_clip_adam(stream_ptr(), ptr(self.arena.flat), ptr(self.arena.grad), ptr(self.exp_avg),
+                                        ptr(self.exp_avg_sq), self.arena.n_flat,
+                                        float("inf") if max_norm is None else float(max_norm), float(g["lr"]), float(b1),
+                                        float(b2), float(g["eps"]), self.step_count, ptr(self.gnorm2)))
+        self.arena.native_epoch += 1
+
+    def state_dict(self):
+        if self.step_count > 0:
+            self._expose_state()
+        return super().state_dict()
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        o, step = 0, 0
+        for p in self.param_groups[0]["params"]:
+            n = p.numel()
+            st = self.state.get(p)
+            if st:
+                self.exp_avg[o:o + n].copy_(st["exp_avg"].reshape(-1))
+                self.exp_avg_sq[o:o + n].copy_(st["exp_avg_sq"].reshape(-1))
+                step = int(float(st["step"]))
+            o += n
+        self.step_count = step
+        if step > 0:
+            self._expose_state()
+
+
+class PPOLearner(object):
+    def __init__(self, obs_space_size, act_space_size, policy_type, policy_layer_sizes, critic_layer_sizes,
+                 continuous_var_range, batch_size, n_epochs, policy_lr, critic_lr, clip_range, ent_coef, mini_batch_size,
+                 device):
+        self.device = device
+        self._dev = require_gpu(device)
+        N.lib()  # fail here, loudly, if the HIP library is missing
+
+        assert batch_size % mini_batch_size == 0, "MINIBATCH SIZE MUST BE AN INTEGER MULTIPLE OF BATCH SIZE"
+
+        obs_space_size = int(obs_space_size)
+        self.policy_type = int(policy_type)
+        # construction order (policy, then critic) fixes the CPU-generator consumption and therefore the initial
+        # weights (ppo_learner.py:34-53)
+        if policy_type == 2:
+            self.policy = ContinuousPolicy(obs_space_size, act_space_size * 2, policy_layer_sizes, device,
+                                           var_min=continuous_var_range[0], var_max=continuous_var_range[1]).to(device)
+            self._act_dim = int(act_space_size)
+        elif policy_type == 1:
+            self.policy = MultiDiscreteFF(obs_space_size, policy_layer_sizes, device).to(device)
+            self._act_dim = 8
+        else:
+            self.policy = DiscreteFF(obs_space_size, act_space_size, policy_layer_sizes, device).to(device)
+            self._act_dim = 1
+        self.value_net = ValueEstimator(obs_space_size, critic_layer_sizes, device).to(device)
+        self.mini_batch_size = mini_batch_size
+
+        self.policy_optimizer = FusedAdam(self.policy, lr=policy_lr)
+        self.value_optimizer = FusedAdam(self.value_net, lr=critic_lr)
+
+        n_pol = sum(p.numel() for p in self.policy.parameters() if p.requires_grad)
+        n_val = sum(p.numel() for p in self.value_net.parameters() if p.requires_grad)
+        print("Trainable Parameters:")
+        print(f"{'Component':<10} {'Count':<10}")
+        print("-" * 20)
+        print(f"{'Policy':<10} {n_pol:<10}")
+        print(f"{'Critic':<10} {n_val:<10}")
+        print("-" * 20)
+        print(f"{'Total':<10} {n_pol + n_val:<10}")
+        print(f"Current Policy Learning Rate: {policy_lr}")
+        print(f"Current Critic Learning Rate: {critic_lr}")
+
+        self.n_epochs = n_epochs
+        self.batch_size = batch_size
+        self.clip_range = clip_range
+        self.ent_coef = ent_coef
+        self.cumulative_model_updates = 0
+
+        # one contiguous gradient buffer [policy | critic] so that data-parallel needs a single all-reduce
+        pa, va = self.policy.arena, self.value_net.arena
+        self._grad_all = torch.zeros(pa.n_flat + va.n_flat, dtype=torch.float32, device=self._dev)
+        pa.grad = self._grad_all[:pa.n_flat]
+        va.grad = self._grad_all[pa.n_flat:]
+        pa.bind()
+        va.bind()
+        self._stats = torch.zeros(N.N_STATS, dtype=torch.float64, device=self._dev)
+        self._ws = Workspace(self._dev)
+        self._idx_bufs = None
+
+    # ---------------------------------------------------------------------------------------- distributed
+    @staticmethod
+    def _dist():
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            return dist, dist.get_rank(), dist.get_world_size()
+        return None, 0, 1
+
+    # --------------------------------------------------------------------------------------------- learn
+    def _upload_indices(self, idx):
+        """Host permutation -> device, double buffered: slot s is rewritten two epochs later, after the event that
+        follows its H2D copy has completed, so neither the pinned staging memory nor the device vector is ever
+        overwritten while in use and learn() never synchronises the stream."""
+        n = idx.shape[0]
+        s = self._idx_slot = 1 - getattr(self, "_idx_slot", 1)
+        if self._idx_bufs is None or self._idx_bufs[0][0].numel() < n:
+            self._idx_bufs = [(torch.empty(n, dtype=torch.int64).pin_memory(),
+                               torch.empty(n, dtype=torch.int64, device=self._dev), torch.cuda.Event()) for _ in range(2)]
+            self._idx_used = [False, False]
+        pinned, dev, ev = self._idx_bufs[s]
+        if self._idx_used[s]:
+            ev.synchronize()
+        pinned[:n].numpy()[:] = idx
+        dev[:n].copy_(pinned[:n], non_blocking=True)
+        ev.record()
+        self._idx_used[s] = True
+        return dev[:n]
+
+    def _minibatch_args(self, exp):
+        pa, va = self.policy.arena, self.value_net.arena
+        a = N.MinibatchArgs()
+        a.head = self.policy_type
+        a.pol_layers, a.val_layers = pa.n_layers, va.n_layers
+        a.act_dim = self._act_dim
+        a.pol_dims = ctypes.cast(pa.dims_c, ctypes.POINTER(ctypes.c_int32))
+        a.val_dims = ctypes.cast(va.dims_c, ctypes.POINTER(ctypes.c_int32))
+        a.pol_packed, a.val_packed = pa.packed.data_ptr(), va.packed.data_ptr()
+        a.pol_grad, a.val_grad = pa.grad.data_ptr(), va.grad.data_ptr()
+        st = exp._store
+        a.states, a.ld_states = st["states"].data_ptr(), st["states"].shape[1]
+        a.actions = st["actions"].data_ptr()
+        a.old_logp = st["log_probs"].data_ptr()
+        a.targets = st["values"].data_ptr()
+        a.advantages = st["advantages"].data_ptr()
+        a.clip_range, a.ent_coef = float(self.clip_range), float(self.ent_coef)
+        a.mb_ratio = float(self.mini_batch_size / self.batch_size)
+        if self.policy_type == 2:
+            a.var_m, a.var_b = float(self.policy.affine_map.m), float(self.policy.affine_map.b)
+        a.stats = self._stats.data_ptr()
+        nbytes = N.lib().rlppo_minibatch_workspace_bytes(pa.dims_c, pa.n_layers, va.dims_c, va.n_layers, self.mini_batch_size)
+        ws = self._ws.get(nbytes)
+        a.workspace, a.ws_bytes = ws.data_ptr(), ws.numel()
+        return a
+
+    def learn(self, exp):
+        """Compute PPO updates with an experience buffer; returns the reference's report dictionary
+        (ppo_learner.py:225-234)."""
+        L = N.lib()
+        dist, rank, world = self._dist()
+        pa, va = self.policy.arena, self.value_net.arena
+        B, MB = self.batch_size, self.mini_batch_size
+        n_slices = B // MB
+
+        policy_before = pa.flat.clone()
+        critic_before = va.flat.clone()
+        self._stats.zero_()
+        n_iterations = 0
+        n_minibatch_iterations = 0
+        total = len(exp)
+        n_batches = total // B if B > 0 else 0
+
+        t1 = time.time()
+        if n_batches > 0 and total > 0:
+            if exp._store["actions"].reshape(total, -1).shape[1] != self._act_dim:
+                raise ValueError("experience buffer action width does not match the policy head")
+            args = self._minibatch_args(exp)
+            st = stream_ptr()
+            indices = exp.epoch_indices()
+            for epoch in range(self.n_epochs):
+                idx_dev = self._upload_indices(indices)
+                for b in range(n_batches):
+                    self._grad_all.zero_()
+                    pa.ensure_packed()
+                    va.ensure_packed()
+                    for j in range(rank, n_slices, world):
+                        off = b * B + j * MB
+                        args.idx = idx_dev.data_ptr() + 8 * off
+                        args.mb = MB
+                        N.check(L.rlppo_ppo_minibatch(st, ctypes.byref(args)))
+                    n_minibatch_iterations += n_slices
+                    if dist is not None:
+                        dist.all_reduce(self._grad_all)  # RCCL sum over xGMI, before clipping
+                    self.value_optimizer.step(max_norm=MAX_GRAD_NORM)
+                    self.policy_optimizer.step(max_norm=MAX_GRAD_NORM)
+                    n_iterations += 1
+                if epoch + 1 < self.n_epochs:
+                    # drawn while the GPU is still working on this epoch's launches
+                    indices = exp.epoch_indices()
+        else:
+            for _ in range(self.n_epochs):
+                exp.epoch_indices()  # the reference consumes one permutation per epoch even if no batch fits
+
+        if dist is not None:
+            dist.all_reduce(self._stats)
+        stats = self._stats.cpu().numpy()  # the only device->host sync of learn()
+        elapsed = time.time() - t1
+        n_iter_r = max(n_iterations, 1)
+        n_mb_r = max(n_minibatch_iterations, 1)
+        policy_update_magnitude = (policy_before - pa.flat).norm().item()
+        critic_update_magnitude = (critic_before - va.flat).norm().item()
+        self.cumulative_model_updates += n_iter_r
+
+        report = {
+            "PPO Batch Consumption Time": elapsed / n_iter_r,
+            "Cumulative Model Updates": self.cumulative_model_updates,
+            "Policy Entropy": float(stats[N.STAT_ENTROPY]) / n_mb_r,
+            "Mean KL Divergence": float(stats[N.STAT_KL]) / n_mb_r,
+            "Value Function Loss": float(stats[N.STAT_VLOSS]) / n_mb_r,
+            "SB3 Clip Fraction": float(stats[N.STAT_CLIPFRAC]) / n_mb_r if n_minibatch_iterations else 0,
+            "Policy Update Magnitude": policy_update_magnitude,
+            "Value Function Update Magnitude": critic_update_magnitude,
+        }
+        self.policy_optimizer.zero_grad()
+        self.value_optimizer.zero_grad()
+        return report
+
+    # ---------------------------------------------------------------------------------------- checkpoints
+    def save_to(self, folder_path):
+        os.makedirs(folder_path, exist_ok=True)
+        torch.save(self.policy.state_dict(), os.path.join(folder_path, "PPO_POLICY.pt"))
+        torch.save(self.value_net.state_dict(), os.path.join(folder_path, "PPO_VALUE_NET.pt"))
+        torch.save(self.policy_optimizer.state_dict(), os.path.join(folder_path, "PPO_POLICY_OPTIMIZER.pt"))
+        torch.save(self.value_optimizer.state_dict(), os.path.join(folder_path, "PPO_VALUE_NET_OPTIMIZER.pt"))
+
+    def load_from(self, folder_path):
+        assert os.path.exists(folder_path), "PPO LEARNER CANNOT FIND FOLDER {}".format(folder_path)
+        self.policy.load_state_dict(torch.load(os.path.join(folder_path, "PPO_POLICY.pt")))
+        self.value_net.load_state_dict(torch.load(os.path.join(folder_path, "PPO_VALUE_NET.pt")))
+        self.policy_optimizer.load_state_dict(torch.load(os.path.join(folder_path, "PPO_POLICY_OPTIMIZER.pt")))
+        self.value_optimizer.load_state_dict(torch.load(os.path.join(folder_path, "PPO_VALUE_NET_OPTIMIZER.pt")))

@@ -1,0 +1,94 @@
+"""util.torch_functions -- drop-in for rlgym_ppo/util/torch_functions.py.
+
+compute_gae keeps the reference signature and return convention (torch_functions.py:36-78) but runs librlppo's
+two-launch segmented reverse scan on the GPU; `gae_device` is the same kernel on device-resident tensors (what
+Learner.add_new_experience uses, so the 512k-step value list never becomes a Python list).
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import _native as N
+from ..engine import Workspace, ptr, stream_ptr
+
+_ws = {}
+
+
+def _workspace(device, nbytes):
+    key = str(device)
+    if key not in _ws:
+        _ws[key] = Workspace(device)
+    return _ws[key].get(nbytes)
+
+
+def gae_device(rews, dones, truncated, values, gamma=0.99, lmbda=0.95, return_std=1):
+    """All inputs fp32 device tensors (values has N+1 entries).  Returns (value_targets, advantages, returns) as
+    fp32 device tensors.  return_std=None disables reward scaling (torch_functions.py:62-65)."""
+    n = rews.shape[0]
+    dev = rews.device
+    assert values.shape[0] == n + 1 and dones.shape[0] == n and truncated.shape[0] == n
+    vt = torch.empty(n, dtype=torch.float32, device=dev)
+    adv = torch.empty(n, dtype=torch.float32, device=dev)
+    ret = torch.empty(n, dtype=torch.float32, device=dev)
+    if n == 0:
+        return vt, adv, ret
+    std = float("nan") if return_std is None else float(np.float32(return_std))
+    ws = _workspace(dev, N.lib().rlppo_gae_workspace_bytes(n))
+    N.check(N.lib().rlppo_gae(stream_ptr(), ptr(rews), ptr(dones), ptr(truncated), ptr(values), n, float(gamma),
+                              float(lmbda), std, ptr(vt), ptr(adv), ptr(ret), ptr(ws), ws.numel()))
+    return vt, adv, ret
+
+
+def compute_gae(rews, dones, truncated, values, gamma=0.99, lmbda=0.95, return_std=1, device=None):
+    """Reference signature: sequences in, (value_targets fp32 tensor, advantages fp32 tensor, returns sequence) out.
+    The tensors come back on the CPU like the reference's; `returns` is a float32 numpy array (the reference
+    returns a list; callers slice and iterate it, learner.py:370-372)."""
+    if device is None:
+        device = torch.device("cuda", torch.cuda.current_device())
+
+    def up(x):
+        return torch.as_tensor(np.ascontiguousarray(np.asarray(x, dtype=np.float32))).to(device)
+
+    vt, adv, ret = gae_device(up(rews), up(dones), up(truncated), up(values), gamma, lmbda, return_std)
+    return vt.cpu(), adv.cpu(), ret.cpu().numpy()
+
+
+class MapContinuousToAction(nn.Module):
+    """Affine map of the tanh outputs' second half onto [range_min, range_max] (torch_functions.py:15-33)."""
+
+    def __init__(self, range_min=0.1, range_max=1):
+        super().__init__()
+        tanh_range = [-1, 1]
+        self.m = (range_max - range_min) / (tanh_range[1] - tanh_range[0])
+        self.b = range_min - tanh_range[0] * self.m
+
+    def forward(self, x):
+        n = x.shape[-1] // 2
+        return x[..., :n], x[..., n:] * self.m + self.b
+
+
+class MultiDiscreteRolv(nn.Module):
+    """8 categoricals over 21 logits, 2-way heads padded with -inf (torch_functions.py:81-122).  Kept for API
+    compatibility (get_backprop_data); sampling and the update use the fused kernels."""
+
+    def __init__(self, bins):
+        super().__init__()
+        self.distribution = None
+        self.bins = bins
+
+    def make_distribution(self, logits):
+        parts = torch.split(logits, self.bins, dim=-1)
+        triplets = torch.stack(parts[:5], dim=-1)
+        duets = torch.nn.functional.pad(torch.stack(parts[5:], dim=-1), pad=(0, 0, 0, 1), value=float("-inf"))
+        self.distribution = torch.distributions.Categorical(logits=torch.cat((triplets, duets), dim=-1).swapdims(-1, -2))
+
+    def log_prob(self, action):
+        return self.distribution.log_prob(action).sum(dim=-1)
+
+    def sample(self):
+        return self.distribution.sample()
+
+    def entropy(self):
+        return self.distribution.entropy().sum(dim=-1)

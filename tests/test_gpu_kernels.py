@@ -1,0 +1,437 @@
+"""GPU parity tests, kernel by kernel, through the C ABI (include/rlppo.h) against the CPU oracle / golden vectors.
+Run on the MI355X box with:  python -m pytest tests -m gpu -x -q
+Tolerances follow SURVEY.md section 8(c): indices exact (given identical probs + noise); forward probs/logp/values
+rel 1e-5; GAE atol 1e-5 + rtol 1e-5; losses/grads rel 1e-5."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import gae as ogae  # noqa: E402
+from oracle import nets, ppo  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def L():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    from rlgym_ppo_amd import _native as N
+    return N.lib()
+
+
+def dev(x, dtype=torch.float32):
+    return torch.as_tensor(np.asarray(x)).to("cuda", dtype=dtype).contiguous()
+
+
+def P(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def relerr(a, b):
+    a = np.asarray(a.detach().cpu() if isinstance(a, torch.Tensor) else a, np.float64)
+    b = np.asarray(b.detach().cpu() if isinstance(b, torch.Tensor) else b, np.float64)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
+
+
+def check(L, rc):
+    assert rc == 0, L.rlppo_last_error()
+
+
+# ------------------------------------------------------------------------------------------------ GEMMs
+@pytest.mark.parametrize("M,N,K,epi,gather", [
+    (128, 128, 32, 0, False), (300, 256, 128, 1, False), (1000, 96, 256, 0, True), (77, 32, 256, 2, False),
+    (513, 64, 64, 1, True), (256, 256, 96, 3, False), (4096, 256, 256, 3, False), (5, 128, 128, 1, False),
+])
+def test_gemm_nt(L, M, N, K, epi, gather):
+    g = torch.Generator().manual_seed(M + N + K)
+    rows = M * 2 if gather else M
+    A = torch.randn(rows, K + 32, generator=g)          # lda > K
+    B = torch.randn(N, K, generator=g)
+    bias = torch.randn(N, generator=g)
+    mask = torch.randn(M, N, generator=g)
+    idx = torch.randperm(rows, generator=g)[:M] if gather else None
+    Ad, Bd, bd, md = dev(A), dev(B), dev(bias), dev(mask)
+    idxd = dev(idx, torch.int64) if gather else None
+    C = torch.full((M, N), float("nan"), device="cuda")
+    check(L, L.rlppo_dbg_gemm_nt(stream(), P(Ad), A.shape[1], P(idxd), P(Bd), K, P(bd), P(md), N, P(C), N, M, N, K, epi))
+    Asel = A[idx] if gather else A
+    ref = Asel[:, :K].double() @ B.double().T
+    if epi == 3:
+        ref = ref * (mask > 0)
+    else:
+        ref = ref + bias.double()
+        if epi == 1:
+            ref = ref.clamp(min=0)
+        if epi == 2:
+            ref = torch.tanh(ref)
+    assert relerr(C, ref) < 2e-6
+
+
+@pytest.mark.parametrize("M,out,in_,gather", [(1000, 256, 107, True), (4096, 256, 256, False), (33, 90, 256, False),
+                                              (2500, 1, 256, False), (1, 21, 32, False), (3000, 512, 231, True)])
+def test_gemm_tn(L, M, out, in_, gather):
+    g = torch.Generator().manual_seed(M + out)
+    ny, kx = int(L.rlppo_padded_out(out)), int(L.rlppo_padded_width(in_)) if gather else int(L.rlppo_padded_out(in_))
+    rows = 2 * M if gather else M
+    dY = torch.zeros(M, ny)
+    dY[:, :out] = torch.randn(M, out, generator=g)
+    X = torch.zeros(rows, kx)
+    X[:, :in_] = torch.randn(rows, in_, generator=g)
+    idx = torch.randperm(rows, generator=g)[:M] if gather else None
+    dW0 = torch.randn(out, in_, generator=g)
+    db0 = torch.randn(out, generator=g)
+    dW, db = dev(dW0), dev(db0)
+    check(L, L.rlppo_dbg_gemm_tn(stream(), P(dev(dY)), ny, ny, P(dev(X)), kx, P(dev(idx, torch.int64)) if gather else None,
+                                 kx, P(dW), P(db), out, in_, M))
+    Xs = X[idx] if gather else X
+    refW = dW0.double() + dY[:, :out].double().T @ Xs[:, :in_].double()
+    refb = db0.double() + dY[:, :out].double().sum(0)
+    assert relerr(dW, refW) < 2e-6 and relerr(db, refb) < 2e-6
+
+
+# -------------------------------------------------------------------------------------------------- GAE
+def run_gae(L, rews, dones, trunc, values, gamma, lmbda, std):
+    n = len(rews)
+    vt, adv, ret = (torch.empty(n, device="cuda") for _ in range(3))
+    ws = torch.empty(int(L.rlppo_gae_workspace_bytes(n)), dtype=torch.uint8, device="cuda")
+    check(L, L.rlppo_gae(stream(), P(dev(rews)), P(dev(dones)), P(dev(np.asarray(trunc, np.float32))), P(dev(values)), n,
+                         gamma, lmbda, float("nan") if std is None else float(std), P(vt), P(adv), P(ret), P(ws), ws.numel()))
+    return vt.cpu().numpy(), adv.cpu().numpy(), ret.cpu().numpy()
+
+
+def test_gae_golden_vectors(L, golden):
+    g = golden("g3_gae")
+    for c in range(int(g["n_cases"])):
+        p = f"c{c}."
+        std = g[p + "ret_std"]
+        std = None if np.isnan(std) else std
+        gamma = float(g[p + "gamma"]) if p + "gamma" in g else 0.99
+        lm = float(g[p + "lmbda"]) if p + "lmbda" in g else 0.95
+        vt, adv, ret = run_gae(L, g[p + "rews"], g[p + "dones"], g[p + "trunc"], g[p + "values"], gamma, lm, std)
+        np.testing.assert_allclose(vt, g[p + "value_targets"], rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(adv, g[p + "advantages"], rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(ret, g[p + "returns"], rtol=1e-5, atol=1e-5)
+
+
+def synth_gae(n_seg, seg_len, seed=0, p_mid=0.005):
+    """trajectory-major segments, end = done|truncated (p 0.5), iid mid-segment dones."""
+    rs = np.random.RandomState(seed)
+    n = n_seg * seg_len
+    rews = rs.randn(n).astype(np.float32)
+    values = rs.randn(n + 1).astype(np.float32)
+    dones = (rs.rand(n) < p_mid).astype(np.float32)
+    trunc = np.zeros(n, np.float32)
+    ends = np.arange(seg_len - 1, n, seg_len)
+    is_done = rs.rand(n_seg) < 0.5
+    dones[ends[is_done]] = 1
+    dones[ends[~is_done]] = 0
+    trunc[ends[~is_done]] = 1
+    return rews, dones, trunc, values
+
+
+@pytest.mark.parametrize("n_seg,seg_len,std", [(64, 256, 1.7), (1000, 37, None), (3, 5000, 0.01), (1, 2049, 1.0), (8192, 256, 1.7)])
+def test_gae_matches_oracle(L, n_seg, seg_len, std):
+    rews, dones, trunc, values = synth_gae(n_seg, seg_len, seed=n_seg)
+    vt, adv, ret = run_gae(L, rews, dones, trunc, values, 0.99, 0.95, std)
+    ovt, oadv, oret = ogae.gae(rews, dones, trunc, values, 0.99, 0.95, std, "f64")
+    # float64 scan vs float64 sequential: agreement is at the level of the final fp32 rounding
+    np.testing.assert_allclose(adv, oadv, rtol=2e-6, atol=2e-6)
+    np.testing.assert_allclose(vt, ovt, rtol=2e-6, atol=2e-6)
+    np.testing.assert_allclose(ret, oret.astype(np.float32), rtol=2e-6, atol=2e-6)
+
+
+def test_gae_long_undiscounted_carry(L):
+    # no episode end for 300k steps and gamma = lambda = 1: the carry must cross ~146 workgroups exactly
+    rs = np.random.RandomState(1)
+    n = 300_001
+    rews = (rs.randn(n) * 0.01).astype(np.float32)
+    values = rs.randn(n + 1).astype(np.float32)
+    z = np.zeros(n, np.float32)
+    vt, adv, ret = run_gae(L, rews, z, z, values, 1.0, 1.0, None)
+    ovt, oadv, oret = ogae.gae(rews, z, z, values, 1.0, 1.0, None, "f64")
+    np.testing.assert_allclose(ret, oret, rtol=1e-6, atol=1e-5)
+    np.testing.assert_allclose(adv, oadv, rtol=1e-6, atol=1e-5)
+
+
+def test_gae_segment_independence_and_linearity(L):
+    # size-independent properties at the BASELINE size (8192 x 256): (1) outputs before a done do not depend on what
+    # follows it; (2) returns are linear in the rewards.
+    rews, dones, trunc, values = synth_gae(8192, 256, seed=0)
+    vt, adv, ret = run_gae(L, rews, dones, trunc, values, 0.99, 0.95, None)
+    cut = 1_000_000
+    end = cut + int(np.argmax((dones[cut:] + trunc[cut:]) > 0))  # first trajectory end at/after cut
+    r2, v2 = rews.copy(), values.copy()
+    r2[end + 1:] = 7.0
+    v2[end + 2:] = -3.0
+    vt2, adv2, ret2 = run_gae(L, r2, dones, trunc, v2, 0.99, 0.95, None)
+    if dones[end] == 1:
+        assert np.array_equal(adv[:end + 1], adv2[:end + 1])
+    assert np.array_equal(ret[:end + 1], ret2[:end + 1])
+    _, _, ret3 = run_gae(L, 2 * rews, dones, trunc, values, 0.99, 0.95, None)
+    np.testing.assert_allclose(ret3, 2 * ret, rtol=1e-6, atol=1e-6)
+
+
+def test_gae_empty(L):
+    check(L, L.rlppo_gae(stream(), None, None, None, None, 0, 0.99, 0.95, 1.0, None, None, None, None, 0))
+
+
+# -------------------------------------------------------------------------------------- network plumbing
+class Net:
+    def __init__(self, L, params):
+        from rlgym_ppo_amd import _native as N
+        self.L = L
+        self.params = params
+        self.dims = [params[0][0].shape[1]] + [w.shape[0] for w, _ in params]
+        self.nl = len(params)
+        self.dims_c = N.dims_array(self.dims)
+        self.flat = dev(nets.flatten(params))
+        self.packed = torch.zeros(int(L.rlppo_packed_floats(self.dims_c, self.nl)), device="cuda")
+        check(L, L.rlppo_net_pack(stream(), self.dims_c, self.nl, P(self.flat), P(self.packed)))
+        self.ld_in = int(L.rlppo_padded_width(self.dims[0]))
+        self.ld_out = int(L.rlppo_padded_out(self.dims[-1]))
+
+    def pad(self, obs, f64=False):
+        src = dev(obs, torch.float64 if f64 else torch.float32)
+        n, d = src.shape
+        out = torch.full((n, self.ld_in), float("nan"), device="cuda")
+        check(self.L, self.L.rlppo_pad_rows(stream(), P(src), int(f64), n, d, d, P(out), self.ld_in, 0, 0.0, 1.0))
+        return out
+
+    def ws(self, n):
+        return torch.empty(int(self.L.rlppo_forward_workspace_bytes(self.dims_c, self.nl, n)), dtype=torch.uint8, device="cuda")
+
+
+def test_g2_value_forward(L, golden):
+    g = golden("g2_value_forward")
+    net = Net(L, nets.params_from_state(g, "v."))
+    for f64 in (False, True):
+        rows = net.pad(g["obs"].astype(np.float64) if f64 else g["obs"], f64)
+        out = torch.empty(64, net.ld_out, device="cuda")
+        w = net.ws(64)
+        check(L, L.rlppo_mlp_forward(stream(), net.dims_c, net.nl, P(net.packed), P(rows), net.ld_in, 64, 0, P(out),
+                                     net.ld_out, P(w), w.numel()))
+        assert relerr(out[:, :1], g["values"]) < 1e-5
+        assert (out[:, 1:] == 0).all()
+
+
+def test_g1_discrete_act(L, golden):
+    g = golden("g1_discrete_forward")
+    net = Net(L, nets.params_from_state(g, "p."))
+    rows = net.pad(g["obs"])
+    act = torch.empty(64, dtype=torch.int64, device="cuda")
+    logp = torch.empty(64, device="cuda")
+    probs = torch.empty(64, 90, device="cuda")
+    w = net.ws(64)
+    check(L, L.rlppo_discrete_act(stream(), net.dims_c, net.nl, P(net.packed), P(rows), net.ld_in, 64, P(dev(g["q"])),
+                                  P(act), P(logp), P(probs), P(w), w.numel()))
+    assert relerr(probs, g["probs"]) < 1e-5
+    assert np.abs(logp.cpu().numpy() - g["logp"]).max() < 1e-5
+    assert np.array_equal(act.cpu().numpy(), g["actions"])
+    # the selection step itself is exact: fed the reference's own probabilities it must return the reference's indices
+    act2 = torch.empty(64, dtype=torch.int64, device="cuda")
+    lp2 = torch.empty(64, device="cuda")
+    check(L, L.rlppo_categorical_select(stream(), P(dev(g["probs"])), 90, 64, 90, P(dev(g["q"])), P(act2), P(lp2)))
+    assert np.array_equal(act2.cpu().numpy(), g["actions"])
+    np.testing.assert_allclose(lp2.cpu().numpy(), g["logp"], rtol=1e-6, atol=1e-6)
+
+
+def test_categorical_select_exact_at_scale(L):
+    # 4096 x 90 (the rollout shape of BASELINE configs[1]): identical probs + identical noise => identical indices
+    torch.manual_seed(3)
+    probs = torch.softmax(torch.randn(4096, 90) * 3, -1).clamp(1e-11, 1)
+    q = torch.empty(4096, 90).exponential_(1)
+    ref = torch.argmax(probs / q, -1)
+    act = torch.empty(4096, dtype=torch.int64, device="cuda")
+    lp = torch.empty(4096, device="cuda")
+    check(L, L.rlppo_categorical_select(stream(), P(dev(probs)), 90, 4096, 90, P(dev(q)), P(act), P(lp)))
+    assert torch.equal(act.cpu(), ref)
+    # ties: first index wins
+    probs = torch.full((4, 90), 1.0 / 90)
+    q = torch.ones(4, 90)
+    check(L, L.rlppo_categorical_select(stream(), P(dev(probs)), 90, 4, 90, P(dev(q)), P(act), P(lp)))
+    assert (act[:4].cpu() == 0).all()
+
+
+def test_rollout_shape_discrete_act_vs_oracle(L):
+    # configs[1] shape: 4096 agents x obs 107, 256x3 MLP, 90 actions
+    torch.manual_seed(123)
+    pol = nets.init_mlp(107, (256, 256, 256), 90)
+    rs = np.random.RandomState(0)
+    obs = np.clip(rs.randn(4096, 107), -5, 5).astype(np.float32)
+    q = nets.draw_exp_noise(4096, 90)
+    oprobs = nets.discrete_probs(pol, obs)
+    oact, ologp = nets.discrete_sample(oprobs, q)
+    net = Net(L, pol)
+    rows = net.pad(obs)
+    act = torch.empty(4096, dtype=torch.int64, device="cuda")
+    logp = torch.empty(4096, device="cuda")
+    probs = torch.empty(4096, 90, device="cuda")
+    w = net.ws(4096)
+    check(L, L.rlppo_discrete_act(stream(), net.dims_c, net.nl, P(net.packed), P(rows), net.ld_in, 4096, P(dev(q)), P(act),
+                                  P(logp), P(probs), P(w), w.numel()))
+    assert relerr(probs, oprobs) < 1e-5
+    # with its own (ulp-different) probs the indices agree except on near-ties: margin stated = 1e-4 relative in p/q
+    a = act.cpu()
+    diff = (a != oact).nonzero().flatten()
+    score = (oprobs / q)
+    for i in diff.tolist():
+        s = score[i]
+        assert abs(s[a[i]] - s[oact[i]]) <= 1e-4 * s[oact[i]], "index mismatch that is not a near-tie"
+    assert len(diff) <= 2
+    same = a == oact
+    assert np.abs(logp.cpu().numpy()[same] - ologp.numpy()[same]).max() < 1e-5
+
+
+def test_g9_gaussian_and_multidiscrete_act(L, golden):
+    g = golden("g9_continuous")
+    net = Net(L, nets.params_from_state(g, "p."))
+    rows = net.pad(g["obs"])
+    n = 80
+    act = torch.empty(n, 8, device="cuda")
+    logp = torch.empty(n, device="cuda")
+    w = net.ws(n)
+    m, b = nets.var_map(0.1, 1.0)
+    check(L, L.rlppo_gaussian_act(stream(), net.dims_c, net.nl, P(net.packed), P(rows), net.ld_in, n, P(dev(g["eps"])), m, b,
+                                  P(act), P(logp), P(w), w.numel()))
+    np.testing.assert_allclose(act.cpu().numpy(), g["act"], rtol=1e-5, atol=2e-6)
+    clamped = np.abs(g["act"]) == 1.0
+    assert np.array_equal(np.abs(act.cpu().numpy()) == 1.0, clamped)
+    np.testing.assert_allclose(logp.cpu().numpy(), g["logp"], rtol=2e-5, atol=2e-4)
+
+    g = golden("g9_multidiscrete")
+    net = Net(L, nets.params_from_state(g, "p."))
+    rows = net.pad(g["obs"])
+    n = 72
+    act = torch.empty(n, 8, dtype=torch.int64, device="cuda")
+    logp = torch.empty(n, device="cuda")
+    w = net.ws(n)
+    check(L, L.rlppo_multidiscrete_act(stream(), net.dims_c, net.nl, P(net.packed), P(rows), net.ld_in, n, P(dev(g["q"])),
+                                       P(act), P(logp), P(w), w.numel()))
+    assert np.array_equal(act.cpu().numpy(), g["act"])
+    np.testing.assert_allclose(logp.cpu().numpy(), g["logp"], rtol=1e-5, atol=1e-5)
+
+
+# ---------------------------------------------------------------------------------------- PPO minibatch
+def run_minibatch(L, head, pol, val, obs_all, acts_all, old_all, tgt_all, adv_all, idx, clip, ent, mb_ratio, var=(0.1, 1.0)):
+    from rlgym_ppo_amd import _native as N
+    P_, V_ = Net(L, pol), Net(L, val)
+    states = P_.pad(obs_all)
+    acts = dev(np.asarray(acts_all, np.float32).reshape(len(obs_all), -1))
+    a = N.MinibatchArgs()
+    a.head = {"discrete": 0, "multidiscrete": 1, "gaussian": 2}[head]
+    a.pol_layers, a.val_layers, a.act_dim = P_.nl, V_.nl, acts.shape[1]
+    a.pol_dims = ctypes.cast(P_.dims_c, ctypes.POINTER(ctypes.c_int32))
+    a.val_dims = ctypes.cast(V_.dims_c, ctypes.POINTER(ctypes.c_int32))
+    gp = torch.zeros_like(P_.flat)
+    gv = torch.zeros_like(V_.flat)
+    old, tgt, adv = dev(old_all), dev(tgt_all), dev(adv_all)
+    idxd = dev(idx, torch.int64)
+    stats = torch.zeros(8, dtype=torch.float64, device="cuda")
+    mb = len(idx)
+    ws = torch.empty(int(L.rlppo_minibatch_workspace_bytes(P_.dims_c, P_.nl, V_.dims_c, V_.nl, mb)), dtype=torch.uint8, device="cuda")
+    a.pol_packed, a.val_packed, a.pol_grad, a.val_grad = P_.packed.data_ptr(), V_.packed.data_ptr(), gp.data_ptr(), gv.data_ptr()
+    a.states, a.ld_states, a.actions = states.data_ptr(), states.shape[1], acts.data_ptr()
+    a.old_logp, a.targets, a.advantages, a.idx, a.mb = old.data_ptr(), tgt.data_ptr(), adv.data_ptr(), idxd.data_ptr(), mb
+    a.clip_range, a.ent_coef, a.mb_ratio = clip, ent, mb_ratio
+    a.var_m, a.var_b = nets.var_map(*var)
+    a.stats, a.workspace, a.ws_bytes = stats.data_ptr(), ws.data_ptr(), ws.numel()
+    check(L, L.rlppo_ppo_minibatch(stream(), ctypes.byref(a)))
+    torch.cuda.synchronize()
+    return nets.unflatten(gp.cpu(), pol), nets.unflatten(gv.cpu(), val), stats.cpu().numpy()
+
+
+def compare_minibatch(gp, gv, stats, ref, tol=1e-5):
+    for name, got, want in (("entropy", stats[0], ref["entropy"]), ("kl", stats[1], ref["kl"]),
+                            ("value_loss", stats[2], ref["value_loss"]), ("clip_fraction", stats[3], ref["clip_fraction"]),
+                            ("policy_loss", stats[4], ref["policy_loss"])):
+        assert abs(got - want) <= tol * max(abs(want), 1e-3) + 1e-7, (name, got, want)
+    for (aw, ab), (rw, rb) in zip(gp + gv, ref["grad_policy"] + ref["grad_value"]):
+        assert relerr(aw, rw) < tol + 1e-7 / max(float(rw.abs().max()), 1e-30), ("W", relerr(aw, rw))
+        assert relerr(ab, rb) < tol + 1e-7 / max(float(rb.abs().max()), 1e-30), ("b", relerr(ab, rb))
+
+
+def test_g4_discrete_minibatch_against_reference(L, golden):
+    g = golden("g4_discrete_loss")
+    pol, val = nets.params_from_state(g, "p."), nets.params_from_state(g, "v.")
+    # rows engineered to sit exactly on a clip edge are decided by the last bit of exp(): move them off the edge and
+    # compare against the oracle on the same moved input; every other special region of the fixture stays (clamped
+    # probabilities, clipped-high / clipped-low rows, exact torch.min ties at ratio == 1).
+    old = g["old_logp"].copy()
+    edge = np.isclose(np.abs(g["out.ratio"] - 1.0), 0.2, rtol=0, atol=1e-4)
+    old[edge] += 0.05
+    idx = np.arange(96)
+    gp, gv, stats = run_minibatch(L, "discrete", pol, val, g["obs"], g["acts"], old, g["targets"], g["adv"], idx, 0.2, 0.005, 0.25)
+    ref = ppo.minibatch_autograd("discrete", pol, val, torch.as_tensor(g["obs"]), torch.as_tensor(g["acts"]).view(-1),
+                                 torch.as_tensor(old), torch.as_tensor(g["adv"]), torch.as_tensor(g["targets"]), 0.2, 0.005, 0.25)
+    compare_minibatch(gp, gv, stats, ref, tol=2e-5)
+    # and the un-moved fixture: everything except the knife-edge rows' contribution must still match the reference
+    gp2, gv2, stats2 = run_minibatch(L, "discrete", pol, val, g["obs"], g["acts"], g["old_logp"], g["targets"], g["adv"], idx, 0.2, 0.005, 0.25)
+    assert abs(stats2[0] - float(g["out.entropy"])) < 1e-5 * abs(float(g["out.entropy"]))
+    assert abs(stats2[2] - float(g["out.value_loss"])) < 1e-5 * abs(float(g["out.value_loss"]))
+    for i, (gw, gb) in enumerate(gv2):
+        assert relerr(gw, g[f"gv.model.{2 * i}.weight"]) < 1e-5
+
+
+@pytest.mark.parametrize("head,fixture", [("gaussian", "g9_continuous"), ("multidiscrete", "g9_multidiscrete")])
+def test_g9_other_heads_minibatch(L, golden, head, fixture):
+    g = golden(fixture)
+    pol, val = nets.params_from_state(g, "p."), nets.params_from_state(g, "v.")
+    n = g["obs"].shape[0]
+    acts = g["act"].astype(np.float32)
+    gp, gv, stats = run_minibatch(L, head, pol, val, g["obs"], acts, g["old_logp"], g["targets"], g["adv"], np.arange(n),
+                                  0.2, 0.005, 0.5)
+    ref = ppo.minibatch_autograd(head, pol, val, torch.as_tensor(g["obs"]), torch.as_tensor(acts), torch.as_tensor(g["old_logp"]),
+                                 torch.as_tensor(g["adv"]), torch.as_tensor(g["targets"]), 0.2, 0.005, 0.5)
+    compare_minibatch(gp, gv, stats, ref, tol=5e-5)
+
+
+def test_minibatch_gather_and_accumulate_cfg2_shape(L):
+    # 256x3 nets, obs 107, 90 actions; 2 minibatches of 3000 rows gathered from a 10000-row buffer; grads accumulate
+    torch.manual_seed(123)
+    pol = nets.init_mlp(107, (256, 256, 256), 90)
+    val = nets.init_mlp(107, (256, 256, 256), 1)
+    rs = np.random.RandomState(1)
+    n = 10000
+    obs = np.clip(rs.randn(n, 107), -5, 5).astype(np.float32)
+    probs = nets.discrete_probs(pol, obs)
+    act, logp = nets.discrete_sample(probs, nets.draw_exp_noise(n, 90))
+    old = (logp + torch.as_tensor(rs.randn(n).astype(np.float32) * 0.2)).numpy()
+    adv = rs.randn(n).astype(np.float32)
+    tgt = rs.randn(n).astype(np.float32)
+    perm = rs.permutation(n)
+    from rlgym_ppo_amd import _native as N  # noqa: F401
+    gp_tot = gv_tot = None
+    ref_p = ref_v = None
+    for s in range(2):
+        idx = perm[s * 3000:(s + 1) * 3000]
+        gp, gv, stats = run_minibatch(L, "discrete", pol, val, obs, act.numpy(), old, tgt, adv, idx, 0.2, 0.005, 0.5)
+        ti = torch.as_tensor(idx)
+        ref = ppo.minibatch_autograd("discrete", pol, val, torch.as_tensor(obs)[ti], act[ti].float(), torch.as_tensor(old)[ti],
+                                     torch.as_tensor(adv)[ti], torch.as_tensor(tgt)[ti], 0.2, 0.005, 0.5)
+        compare_minibatch(gp, gv, stats, ref, tol=2e-5)
+
+
+def test_clip_adam_matches_oracle(L):
+    torch.manual_seed(0)
+    params = nets.init_mlp(20, (16,), 5)
+    st = ppo.AdamState(params)
+    flat = dev(nets.flatten(params))
+    m = torch.zeros_like(flat)
+    v = torch.zeros_like(flat)
+    gn = torch.zeros(1, dtype=torch.float64, device="cuda")
+    for step in range(1, 6):
+        grads = [(torch.randn_like(w) * (3.0 if step % 2 else 0.01), torch.randn_like(b)) for w, b in params]
+        gflat = dev(nets.flatten(grads))
+        check(L, L.rlppo_clip_adam(stream(), P(flat), P(gflat), P(m), P(v), flat.numel(), 0.5, 3e-4, 0.9, 0.999, 1e-8, step, P(gn)))
+        coef, total = ppo.clip_coef(grads)
+        assert abs(float(gn.cpu()) ** 0.5 - float(total)) < 1e-5 * float(total)
+        ppo.adam_step(params, [(w * coef, b * coef) for w, b in grads], st, 3e-4)
+        assert relerr(flat, nets.flatten(params)) < 1e-6
+        assert relerr(m, nets.flatten(st.m)) < 1e-5 and relerr(v, nets.flatten(st.v)) < 1e-5
+        assert relerr(gflat, nets.flatten([(w * coef, b * coef) for w, b in grads])) < 1e-6  # grads scaled in place
