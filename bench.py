@@ -1,0 +1,307 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the hot path (BASELINE.json): PPO-update samples/s.
+
+    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+Workload = BASELINE.json configs[1] ("1xMI355X: 4096 parallel agents, obs=107 f32, |A|=90 discrete, 256x3 MLP,
+512k-sample buffer"): a 524,288-sample device-resident ExperienceBuffer (4096 agents x 128 steps), ppo_batch_size
+524,288, ppo_minibatch_size 65,536, lr 3e-4, clip 0.2, ent 0.005, synthetic data, random-init
+weights.  One *step* = one PPOLearner.learn() call = `--epochs` (default 10, the reference's ppo_epochs default,
+learner.py:51) shuffled passes over the whole buffer, i.e. epochs x 524,288 samples through forward + loss + backward
++ clip + Adam, including the host-side legacy-MT19937 shuffle and the index upload.  value = samples / wall time,
+whole job (all ranks).  With N ranks the 8 minibatch slices of every batch are dealt round-robin to the ranks and one
+RCCL all-reduce of the flat gradient arena precedes the optimiser step (total work fixed: strong scaling).
+
+Extra objects on the same JSON line (N=1 only): `roofline` for the dominant kernel of the timed region, `gae` =
+the GAE scan (BASELINE configs[2]: 8192 x 256, HBM-bound) with its own roofline, `rollout` = policy inference
+obs/s at 4096 x 107, `cpu_baseline` = the CPU oracle (a port of the reference's op sequence; kind "port") timed on
+this box's host cores on a bounded sample.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
+MFMA_F32_PEAK_TF = 157.3    # MI355X_MICROARCH.md: fp32-input MFMA = fp32 vector peak
+OBS, ACT, HID = 107, 90, (256, 256, 256)
+N_AGENTS, N_STEPS = 4096, 128
+N_SAMPLES = N_AGENTS * N_STEPS  # 524,288
+BATCH, MINIBATCH = 524288, 65536
+FLOP_PER_SAMPLE = 1_931_776     # fwd + bwd of both nets, cfg2
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def build_workload(device, seed=123):
+    from rlgym_ppo_amd.ppo import ExperienceBuffer, PPOLearner
+    torch.manual_seed(seed)
+    np.random.seed(seed)
+    learner = PPOLearner(OBS, ACT, 0, HID, HID, (0.1, 1.0), BATCH, 10, 3e-4, 3e-4, 0.2, 0.005, MINIBATCH, device)
+    g = torch.Generator(device=device).manual_seed(seed)
+    states = torch.randn(N_SAMPLES, OBS, device=device, generator=g).clamp_(-5, 5)
+    acts, logps = [], []
+    for s in range(0, N_SAMPLES, 65536):  # actions sampled by the policy itself at init weights -> ratio ~ 1 at step 0
+        noise = torch.empty(65536, ACT, device=device).exponential_(1, generator=g)
+        a, lp = learner.policy.get_action(states[s:s + 65536], noise=noise)
+        acts.append(a)
+        logps.append(lp)
+    actions = torch.cat(acts).float()
+    log_probs = torch.cat(logps)
+    adv = torch.randn(N_SAMPLES, device=device, generator=g)
+    tgt = torch.randn(N_SAMPLES, device=device, generator=g)
+    z = torch.zeros(N_SAMPLES, device=device)
+    buf = ExperienceBuffer(N_SAMPLES, seed, "cpu")
+    buf.submit_experience(states, actions, log_probs, z, states[:1].expand(N_SAMPLES, OBS), z, z, tgt, adv)
+    return learner, buf
+
+
+# ------------------------------------------------------------------------------------------- kernel timing
+def time_region(fn, reps, warm=3):
+    """Average device time of fn() in ms, HIP events on torch's current stream (the stream librlppo launches on)."""
+    for _ in range(warm):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    e1.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def kernel_breakdown(learner):
+    """Times every GEMM launch shape of one cfg2 minibatch through the diagnostic entry points and returns
+    (rows, dominant) where rows = [(name, launches per minibatch, ms per launch, flop per launch)]."""
+    from rlgym_ppo_amd import _native as N
+    L = N.lib()
+    dev = learner._dev
+    M = MINIBATCH
+    st = lambda: ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    P = lambda t: ctypes.c_void_p(t.data_ptr())
+    A128 = torch.randn(M, 128, device=dev)
+    A256 = torch.randn(M, 256, device=dev)
+    A96 = torch.randn(M, 96, device=dev)
+    A32 = torch.randn(M, 32, device=dev)
+    W = torch.randn(256, 256, device=dev) * 0.05
+    bias = torch.zeros(256, device=dev)
+    C256 = torch.empty(M, 256, device=dev)
+    C96 = torch.empty(M, 96, device=dev)
+    C32 = torch.empty(M, 32, device=dev)
+    idx = torch.randperm(M, device=dev)
+    dW = torch.zeros(256 * 256, device=dev)
+    db = torch.zeros(256, device=dev)
+
+    def nt(A, lda, ridx, ldb, C, ldc, n, k, epi, mask=None):
+        return lambda: N.check(L.rlppo_dbg_gemm_nt(st(), P(A), lda, P(ridx) if ridx is not None else None, P(W), ldb, P(bias),
+                                                    P(mask) if mask is not None else None, n, P(C), ldc, M, n, k, epi))
+
+    def tn(dY, ny, X, kx, ridx, out, in_):
+        return lambda: N.check(L.rlppo_dbg_gemm_tn(st(), P(dY), ny, ny, P(X), kx, P(ridx) if ridx is not None else None, kx,
+                                                    P(dW), P(db), out, in_, M))
+
+    shapes = [
+        ("gemm_nt fwd L0 gather 128->256 (x2 nets)", 2, nt(A128, 128, idx, 128, C256, 256, 256, 128, 1), 2 * M * 256 * 128),
+        ("gemm_nt fwd hidden 256->256 (x4)", 4, nt(A256, 256, None, 256, C256, 256, 256, 256, 1), 2 * M * 256 * 256),
+        ("gemm_nt fwd head 256->96", 1, nt(A256, 256, None, 256, C96, 96, 96, 256, 0), 2 * M * 96 * 256),
+        ("gemm_nt fwd value head 256->32", 1, nt(A256, 256, None, 256, C32, 32, 32, 256, 0), 2 * M * 32 * 256),
+        ("gemm_nt dX hidden 256->256 mask (x4)", 4, nt(A256, 256, None, 256, C256, 256, 256, 256, 3, A256), 2 * M * 256 * 256),
+        ("gemm_nt dX head 96->256 mask", 1, nt(A96, 96, None, 96, C256, 256, 256, 96, 3, A256), 2 * M * 256 * 96),
+        ("gemm_nt dX value head 32->256 mask", 1, nt(A32, 32, None, 32, C256, 256, 256, 32, 3, A256), 2 * M * 256 * 32),
+        ("gemm_tn dW hidden 256x256 (x4)", 4, tn(A256, 256, A256, 256, None, 256, 256), 2 * M * 256 * 256),
+        ("gemm_tn dW L0 gather 256x107 (x2)", 2, tn(A256, 256, A128, 128, idx, 256, 107), 2 * M * 256 * 128),
+        ("gemm_tn dW head 90x256", 1, tn(A96, 96, A256, 256, None, 90, 256), 2 * M * 128 * 256),
+        ("gemm_tn dW value head 1x256", 1, tn(A32, 32, A256, 256, None, 1, 256), 2 * M * 128 * 256),
+    ]
+    rows = []
+    for name, count, fn, flop in shapes:
+        ms = time_region(fn, 10)
+        rows.append(dict(kernel=name, launches_per_minibatch=count, ms_per_launch=round(ms, 4),
+                         gflop_per_launch=round(flop / 1e9, 3), tflops=round(flop / ms / 1e9, 2)))
+    dominant = max(rows, key=lambda r: r["launches_per_minibatch"] * r["ms_per_launch"])
+    return rows, dominant
+
+
+def gae_bench():
+    """BASELINE configs[2]: 8192 trajectories x 256 steps, gamma .99 lambda .95, return_std 1.7, fp32, seed 0."""
+    from rlgym_ppo_amd.util import torch_functions
+    rs = np.random.RandomState(0)
+    n_seg, seg = 8192, 256
+    n = n_seg * seg
+    rews = rs.randn(n).astype(np.float32)
+    values = rs.randn(n + 1).astype(np.float32)
+    dones = (rs.rand(n) < 0.005).astype(np.float32)
+    trunc = np.zeros(n, np.float32)
+    ends = np.arange(seg - 1, n, seg)
+    is_done = rs.rand(n_seg) < 0.5
+    dones[ends[is_done]] = 1
+    dones[ends[~is_done]] = 0
+    trunc[ends[~is_done]] = 1
+    d = lambda x: torch.as_tensor(x).cuda()
+    R, D, T, V = d(rews), d(dones), d(trunc), d(values)
+    fn = lambda: torch_functions.gae_device(R, D, T, V, 0.99, 0.95, 1.7)
+    fn()
+    ms = time_region(fn, 50, warm=5)
+    alg_bytes = 28 * n
+    out = dict(workload="8192 trajectories x 256 steps fp32 (BASELINE configs[2])", steps=n, ms_per_scan=round(ms, 5),
+               steps_per_s=round(n / ms * 1e3), launches=2,
+               roofline=dict(bound="hbm", achieved=round(alg_bytes / ms / 1e6, 1), peak=HBM_PEAK_GBS, unit="GB/s",
+                             frac=round(alg_bytes / ms / 1e6 / HBM_PEAK_GBS, 4), traffic=None,
+                             note="achieved = 28 algorithmic B/step x steps / (summary + apply launches, HIP events)"))
+    # CPU side: the C port and the interpreter-bound Python form (the reference runs a Python loop) on bounded samples
+    from oracle import gae as ogae
+    t = time.perf_counter()
+    ogae.gae(rews, dones, trunc, values, 0.99, 0.95, 1.7, "f64")
+    out["cpu_c_port_steps_per_s"] = round(n / (time.perf_counter() - t))
+    m = 65536
+    t = time.perf_counter()
+    ogae.gae_python(rews[:m], dones[:m], trunc[:m], values[:m + 1], 0.99, 0.95, 1.7)
+    out["cpu_python_loop_steps_per_s"] = round(m / (time.perf_counter() - t))
+    out["cpu_sample"] = "C port: all 2,097,152 steps; Python-loop form: first 65,536 steps; 1 thread"
+    return out
+
+
+def rollout_bench(learner):
+    """Rollout inference at the configs[1] shape: obs [4096,107] on the host -> actions/logp on the host, per step."""
+    rs = np.random.RandomState(0)
+    obs = np.clip(rs.randn(N_AGENTS, OBS), -5, 5).astype(np.float32)
+    q_host = torch.empty(N_AGENTS, ACT).exponential_(1)
+    q_dev = q_host.cuda()
+    pol = learner.policy
+
+    def timed(fn, reps=30):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t) / reps
+
+    t_parity = timed(lambda: pol.get_action(obs))                 # host-drawn Exp(1) noise (reference's CPU stream)
+    t_given = timed(lambda: pol.get_action(obs, noise=q_dev))     # noise already resident
+    return dict(workload="4096 x 107 obs per step, 256x3 policy, 90 actions",
+                obs_per_s_host_noise=round(N_AGENTS / t_parity), ms_per_step_host_noise=round(t_parity * 1e3, 3),
+                obs_per_s_resident_noise=round(N_AGENTS / t_given), ms_per_step_resident_noise=round(t_given * 1e3, 3),
+                note="host_noise = torch CPU exponential_ draw (bit-exact action parity mode) + H2D/D2H included")
+
+
+def cpu_baseline(seed=123):
+    """The oracle's learn() (torch-CPU eager, the reference's op sequence) on one epoch of the same workload."""
+    from oracle import nets, ppo
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    torch.manual_seed(seed)
+    pol = nets.init_mlp(OBS, HID, ACT)
+    val = nets.init_mlp(OBS, HID, 1)
+    g = torch.Generator().manual_seed(seed)
+    n = N_SAMPLES
+    states = torch.randn(n, OBS, generator=g).clamp_(-5, 5)
+    with torch.no_grad():
+        probs = nets.discrete_probs(pol, states[:65536])
+        a, lp = nets.discrete_sample(probs, torch.empty(65536, ACT).exponential_(1, generator=g))
+    reps = n // 65536
+    buf = dict(states=states, actions=a.float().repeat(reps), log_probs=lp.repeat(reps),
+               values=torch.randn(n, generator=g), advantages=torch.randn(n, generator=g))
+    rng = np.random.RandomState(seed)
+    t = time.perf_counter()
+    ppo.learn("discrete", pol, val, buf, BATCH, MINIBATCH, 1, 0.2, 0.005, 3e-4, 3e-4, rng)
+    dt = time.perf_counter() - t
+    return dict(value=round(n / dt), unit="samples/s", cores=cores, kind="port",
+                sample="1 epoch (1 optimiser step, 8 minibatches of 65,536) over the same 524,288-sample cfg2 buffer, "
+                       "torch-CPU eager oracle, %d threads, %.1f s" % (cores, dt))
+
+
+# ---------------------------------------------------------------------------------------------------- main
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--epochs", type=int, default=10)
+    ap.add_argument("--no-extras", action="store_true", help="skip roofline / gae / rollout / cpu_baseline legs")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", 0))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    if world != args.gpus:
+        log(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}; using WORLD_SIZE")
+    torch.cuda.set_device(local_rank)
+    device = f"cuda:{local_rank}"
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(device))
+
+    import contextlib
+    with contextlib.redirect_stdout(sys.stderr):
+        learner, buf = build_workload(device)
+    learner.n_epochs = args.epochs
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        learner.learn(buf)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        report = learner.learn(buf)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    samples = args.steps * args.epochs * (N_SAMPLES // BATCH) * BATCH
+    value = samples / dt
+    out = {
+        "metric": "ppo_update_samples_per_sec", "value": round(value, 1), "unit": "samples/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "BASELINE configs[1]: 4096 agents x 128 steps = 524,288-sample buffer, obs 107 f32, "
+                               "90 discrete actions, 256x3 policy + 256x3 critic; ppo_batch 524,288, minibatch 65,536",
+                   "epochs_per_step": args.epochs, "samples_per_step": args.epochs * BATCH,
+                   "parallelism": f"dp{world}: minibatch slices round-robin over ranks, 1 RCCL all-reduce/optimiser step",
+                   "last_report": {k: (round(v, 6) if isinstance(v, float) else v) for k, v in report.items()}},
+    }
+    if rank == 0 and world == 1 and not args.no_extras:
+        rows, dom = kernel_breakdown(learner)
+        for r in rows:
+            log("  %-44s x%d  %8.4f ms  %7.2f TFLOP/s" % (r["kernel"], r["launches_per_minibatch"], r["ms_per_launch"], r["tflops"]))
+        out["roofline"] = dict(bound="mfma", achieved=dom["tflops"], peak=MFMA_F32_PEAK_TF, unit="TFLOP/s",
+                               frac=round(dom["tflops"] / MFMA_F32_PEAK_TF, 4), traffic=None, kernel=dom["kernel"],
+                               note="algorithmic flop per launch / mean launch duration (HIP events, 10 launches)")
+        out["update_flop_efficiency"] = dict(
+            achieved=round(FLOP_PER_SAMPLE * value / 1e12, 2), peak=MFMA_F32_PEAK_TF, unit="TFLOP/s",
+            frac=round(FLOP_PER_SAMPLE * value / 1e12 / MFMA_F32_PEAK_TF, 4),
+            note="1,931,776 algorithmic flop/sample x measured samples/s (whole learn(), host shuffle included)")
+        out["kernel_breakdown"] = rows
+        out["gae"] = gae_bench()
+        out["rollout"] = rollout_bench(learner)
+        out["cpu_baseline"] = cpu_baseline()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

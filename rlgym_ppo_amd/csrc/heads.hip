@@ -180,10 +180,9 @@ __global__ __launch_bounds__(256) void discrete_loss_kernel(float *__restrict__ 
                                                              const float *__restrict__ advantages, int64_t mb,
                                                              LossCfg cfg, double *__restrict__ stats) {
     const int lane = threadIdx.x & 63;
-    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    const bool active = row < mb;
     float st[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
-    if (active) {
+    // grid-stride over rows: statistics stay in registers, so a launch issues 5 atomics per BLOCK, not per 4 rows
+    for (int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); row < mb; row += (int64_t)gridDim.x * 4) {
         const int64_t src = idx[row];
         float *z = logits + row * ld;
         float p[EPL], pc[EPL], lp[EPL];
@@ -231,11 +230,11 @@ __global__ __launch_bounds__(256) void discrete_loss_kernel(float *__restrict__ 
             if (c < ld) z[c] = c < A ? p[e] * (gp[e] - dot) : 0.f;
         }
         if (lane == 0) {
-            st[RLPPO_STAT_ENTROPY] = ent * cfg.inv_mb;
-            st[RLPPO_STAT_KL] = ((ratio - 1.f) - lr) * cfg.inv_mb;
-            st[RLPPO_STAT_CLIPFRAC] = (fabsf(ratio - 1.f) > cfg.clip ? 1.f : 0.f) * cfg.inv_mb;
-            st[RLPPO_STAT_PLOSS] = -smin * cfg.inv_mb;
-            st[RLPPO_STAT_VLOSS] = value_row(vout + row * ldv, targets[src], cfg) * cfg.inv_mb;
+            st[RLPPO_STAT_ENTROPY] += ent * cfg.inv_mb;
+            st[RLPPO_STAT_KL] += ((ratio - 1.f) - lr) * cfg.inv_mb;
+            st[RLPPO_STAT_CLIPFRAC] += (fabsf(ratio - 1.f) > cfg.clip ? 1.f : 0.f) * cfg.inv_mb;
+            st[RLPPO_STAT_PLOSS] += -smin * cfg.inv_mb;
+            st[RLPPO_STAT_VLOSS] += value_row(vout + row * ldv, targets[src], cfg) * cfg.inv_mb;
         }
     }
     block_stats_add(stats, st, true);
@@ -245,7 +244,7 @@ int launch_discrete_loss(hipStream_t st, float *logits, int64_t ld, int A, float
                          const float *actions, const float *old_logp, const float *targets, const float *adv, int64_t mb,
                          const LossCfg &cfg, double *stats) {
     if (mb <= 0) return 0;
-    dim3 grid((unsigned)cdiv(mb, 4)), block(256);
+    dim3 grid((unsigned)(cdiv(mb, 4) < 2048 ? cdiv(mb, 4) : 2048)), block(256);
     RLPPO_CHECK_ARG(ld <= 64 * 32, "discrete head: padded width %ld too large", (long)ld);
     if (ld <= 128)
         hipLaunchKernelGGL((discrete_loss_kernel<2>), grid, block, 0, st, logits, ld, A, vout, ldv, idx, actions, old_logp, targets, adv, mb, cfg, stats);

@@ -1,0 +1,32 @@
+"""Data-parallel plumbing of the PPO update (the only place the hot path has a real exchange step).
+
+The reference sums the gradients of the B/MB minibatch slices of a batch, each scaled by MB/B, before ONE
+clip + Adam (rlgym_ppo/ppo/ppo_learner.py:134-193).  Dealing slice j to rank j % world and summing the flat
+gradient arenas with one all-reduce is therefore the same computation; the permutation is drawn identically on
+every rank (same seed), the buffer is replicated, clip + Adam run replicated on the reduced gradients.
+One process per GPU; backend "nccl" (= RCCL over xGMI) on the GPU box, "gloo" in the CPU tests.
+"""
+import torch
+
+
+def dist_info():
+    """(dist module or None, rank, world) for the default process group."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        return dist, dist.get_rank(), dist.get_world_size()
+    return None, 0, 1
+
+
+def slices_for_rank(n_slices, rank, world):
+    """Minibatch slice numbers of one batch that `rank` computes (round-robin)."""
+    return list(range(rank, n_slices, world))
+
+
+def all_reduce_sum(tensor, dist=None):
+    """In-place sum over ranks of one flat buffer ([grad_policy | grad_value]: 1.37 MB for the 256x3 nets -- latency
+    bound, so exactly one collective per optimiser step)."""
+    if dist is None:
+        dist, _, _ = dist_info()
+    if dist is not None:
+        dist.all_reduce(tensor, op=dist.ReduceOp.SUM)
+    return tensor

@@ -21,6 +21,7 @@ import numpy as np
 import torch
 
 from .. import _native as N
+from ..dp import all_reduce_sum, dist_info, slices_for_rank
 from ..engine import Workspace, ptr, require_gpu, stream_ptr
 from .continuous_policy import ContinuousPolicy
 from .discrete_policy import DiscreteFF
@@ -149,14 +150,6 @@ class PPOLearner(object):
         self._ws = Workspace(self._dev)
         self._idx_bufs = None
 
-    # ---------------------------------------------------------------------------------------- distributed
-    @staticmethod
-    def _dist():
-        import torch.distributed as dist
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            return dist, dist.get_rank(), dist.get_world_size()
-        return None, 0, 1
-
     # --------------------------------------------------------------------------------------------- learn
     def _upload_indices(self, idx):
         """Host permutation -> device, double buffered: slot s is rewritten two epochs later, after the event that
@@ -207,7 +200,7 @@ class PPOLearner(object):
         """Compute PPO updates with an experience buffer; returns the reference's report dictionary
         (ppo_learner.py:225-234)."""
         L = N.lib()
-        dist, rank, world = self._dist()
+        dist, rank, world = dist_info()
         pa, va = self.policy.arena, self.value_net.arena
         B, MB = self.batch_size, self.mini_batch_size
         n_slices = B // MB
@@ -233,14 +226,14 @@ class PPOLearner(object):
                     self._grad_all.zero_()
                     pa.ensure_packed()
                     va.ensure_packed()
-                    for j in range(rank, n_slices, world):
+                    for j in slices_for_rank(n_slices, rank, world):
                         off = b * B + j * MB
                         args.idx = idx_dev.data_ptr() + 8 * off
                         args.mb = MB
                         N.check(L.rlppo_ppo_minibatch(st, ctypes.byref(args)))
                     n_minibatch_iterations += n_slices
                     if dist is not None:
-                        dist.all_reduce(self._grad_all)  # RCCL sum over xGMI, before clipping
+                        all_reduce_sum(self._grad_all, dist)  # RCCL over xGMI, before clipping
                     self.value_optimizer.step(max_norm=MAX_GRAD_NORM)
                     self.policy_optimizer.step(max_norm=MAX_GRAD_NORM)
                     n_iterations += 1
@@ -251,8 +244,7 @@ class PPOLearner(object):
             for _ in range(self.n_epochs):
                 exp.epoch_indices()  # the reference consumes one permutation per epoch even if no batch fits
 
-        if dist is not None:
-            dist.all_reduce(self._stats)
+        all_reduce_sum(self._stats, dist)
         stats = self._stats.cpu().numpy()  # the only device->host sync of learn()
         elapsed = time.time() - t1
         n_iter_r = max(n_iterations, 1)

@@ -1,0 +1,147 @@
+"""CPU checks of the boundary: the C-ABI library loads and exports every symbol include/rlppo.h declares (no compute
+calls -- there is no GPU here), the ctypes table covers the header, the host-only entry points work, and the oracle
+is imported only where the rules allow."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_functions():
+    src = open(os.path.join(ROOT, "include", "rlppo.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(rlppo_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_every_declared_symbol_is_exported_and_bound():
+    from rlgym_ppo_amd import _native as N
+    L = N.lib()
+    names = header_functions()
+    assert len(names) >= 20
+    raw = ctypes.CDLL(N.LIB_PATH)
+    for name in names:
+        assert hasattr(raw, name), f"{name} declared in include/rlppo.h but not exported by librlppo.so"
+        assert name in N.SIGNATURES, f"{name} has no ctypes signature in rlgym_ppo_amd/_native.py"
+    assert sorted(N.SIGNATURES) == names, "ctypes table and header disagree"
+    assert L.rlppo_abi_version() == N.ABI_VERSION
+
+
+def test_layout_queries_host_only():
+    from rlgym_ppo_amd import _native as N
+    L = N.lib()
+    assert [L.rlppo_padded_width(d) for d in (1, 32, 33, 107, 231)] == [32, 32, 64, 128, 256]
+    assert [L.rlppo_padded_out(d) for d in (1, 16, 21, 33, 90, 96, 97, 256, 300)] == [32, 32, 32, 64, 96, 96, 128, 256, 384]
+    d = N.dims_array([107, 256, 256, 256, 90])
+    assert L.rlppo_flat_floats(d, 4) == 182362                       # cfg2 policy parameter count
+    assert L.rlppo_flat_floats(N.dims_array([107, 256, 256, 256, 1]), 4) == 159489
+    assert L.rlppo_flat_floats(N.dims_array([231, 512, 512, 512, 512, 16]), 5) == 914960  # cfg5 policy
+    assert L.rlppo_packed_floats(d, 4) == 2 * (256 * 128 + 256 * 256 * 2 + 96 * 256) + 256 * 3 + 96
+    assert L.rlppo_flat_floats(N.dims_array([0, 4]), 1) == -1 and b"dims" in L.rlppo_last_error()
+    # argument errors come back as codes + message, never as exceptions across the ABI
+    assert L.rlppo_net_pack(None, N.dims_array([4, 4]), 99, None, None) == 1001
+    assert b"n_layers" in L.rlppo_last_error()
+    with pytest.raises(RuntimeError, match="librlppo error 1001"):
+        N.check(L.rlppo_net_pack(None, N.dims_array([4, 4]), 99, None, None))
+
+
+def test_minibatch_args_struct_matches_header_field_order():
+    from rlgym_ppo_amd import _native as N
+    src = open(os.path.join(ROOT, "include", "rlppo.h")).read()
+    body = src[src.index("typedef struct rlppo_minibatch_args {"):src.index("} rlppo_minibatch_args;")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    fields = []
+    for decl in body.split(";")[:-1]:
+        decl = decl.split("{")[-1].strip()
+        if not decl:
+            continue
+        for part in decl.split(","):
+            fields.append(re.findall(r"[A-Za-z_][A-Za-z0-9_]*", part)[-1])
+    assert fields == [f[0] for f in N.MinibatchArgs._fields_]
+
+
+def test_mt19937_permutation_is_numpys_legacy_stream(golden):
+    from rlgym_ppo_amd import _native as N
+    from rlgym_ppo_amd.engine import LegacyPermutation
+    g = golden("g6_shuffle")
+    rng = np.random.RandomState(123)
+    perm = LegacyPermutation(rng)
+    p1 = perm.permutation(524288)
+    assert np.array_equal(p1[:64], g["perm524288_head"])
+    assert np.bitwise_xor.reduce(p1 * np.arange(1, p1.size + 1)) == g["perm524288_xor"]
+    assert np.sum((p1 * (np.arange(p1.size) % 1000003)) % 2147483647) == g["perm524288_wsum"]
+    assert np.array_equal(perm.permutation(524288)[:64], g["perm524288_second_head"])
+    # generator object stays in sync with numpy's own implementation, for every size class incl. 0/1/2 and non-2^k
+    ref = np.random.RandomState(7)
+    mine = LegacyPermutation(np.random.RandomState(7))
+    for n in (0, 1, 2, 3, 5, 64, 1000, 4097, 70000):
+        assert np.array_equal(mine.permutation(n), ref.permutation(n)), n
+    assert mine.rng.randint(1 << 30) == ref.randint(1 << 30)
+    # seeding entry point == RandomState(seed)
+    st = np.empty(625, np.uint32)
+    N.lib().rlppo_mt19937_seed(st.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)), 123)
+    assert np.array_equal(st[:624], np.random.RandomState(123).get_state()[1]) and st[624] == 624
+
+
+def test_oracle_is_only_imported_where_allowed():
+    allowed = {"bench.py", "__graft_entry__.py"}
+    pat = re.compile(r"^\s*(from|import)\s+oracle\b", re.M)
+    offenders = []
+    for dirpath, _, files in os.walk(ROOT):
+        rel = os.path.relpath(dirpath, ROOT)
+        if rel.startswith((".git", "gpurun_out", "scratch", "tests", "oracle")):
+            continue
+        for f in files:
+            if f.endswith(".py"):
+                path = os.path.join(dirpath, f)
+                if pat.search(open(path).read()) and os.path.relpath(path, ROOT) not in allowed:
+                    offenders.append(os.path.relpath(path, ROOT))
+    assert offenders == [], offenders
+    # the product package does not even mention it
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "rlgym_ppo_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".cpp")):
+                assert "oracle" not in open(os.path.join(dirpath, f)).read().replace("oracle/gae_oracle.c mode 0", ""), f
+
+
+def test_product_refuses_to_run_without_a_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from rlgym_ppo_amd.ppo import PPOLearner
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        PPOLearner(107, 90, 0, (32,), (32,), (0.1, 1.0), 64, 1, 3e-4, 3e-4, 0.2, 0.005, 64, "cpu")
+    with pytest.raises(RuntimeError):
+        PPOLearner(107, 90, 0, (32,), (32,), (0.1, 1.0), 64, 1, 3e-4, 3e-4, 0.2, 0.005, 64, "cuda:0")
+
+
+def test_welford_matches_reference(golden):
+    from rlgym_ppo_amd.util import WelfordRunningStat
+    g = golden("g7_welford")
+    st = WelfordRunningStat(1)
+    rets = g["returns"]
+    assert np.array_equal(st.std, g["std_initial"]) and np.array_equal(st.mean, g["mean_initial"])
+    st.increment(list(rets[:1]), 1)
+    assert np.array_equal(st.std, g["std_after1"])
+    st.increment(list(rets[1:150]), 149)
+    assert np.array_equal(st.mean, g["mean150"]) and np.array_equal(st.std, g["std150"])
+    st.increment(list(rets[150:]), 150)
+    assert np.array_equal(st.mean, g["mean300"]) and np.array_equal(st.std, g["std300"])
+    js = st.to_json()
+    assert np.array_equal(js["mean"], g["json_mean"]) and np.array_equal(js["var"], g["json_var"]) and js["count"] == g["json_count"]
+    ob = WelfordRunningStat(5)
+    ob.increment(g["obs"][:4], 4)
+    ob.increment(g["obs"][4:], 8)
+    assert np.array_equal(ob.mean, g["obs_mean"]) and np.array_equal(ob.std, g["obs_std"])
+    a, b = WelfordRunningStat(5), WelfordRunningStat(5)
+    a.increment(g["obs"][:5], 5)
+    b.increment(g["obs"][5:], 7)
+    a.increment_from_serialized_other(b.serialize())
+    assert np.array_equal(a.running_mean, g["merged_mean"]) and np.array_equal(a.running_variance, g["merged_var"])
+    assert a.count == g["merged_count"]
+    c = WelfordRunningStat(1)
+    c.from_json(js)
+    assert c.count == st.count and np.allclose(c.std, st.std)
