@@ -1,0 +1,73 @@
+"""A gym-free synthetic environment speaking the interface the env workers expect (reset/step/observation_space/
+action_space), so the whole Learner loop can run without RocketSim or gym.  Deterministic given its seed."""
+import numpy as np
+
+
+class _Space:
+    def __init__(self, shape=None, n=None):
+        self.shape, self._n = shape, n
+        if n is not None:
+            self.n = n
+
+    def seed(self, s):
+        pass
+
+
+class Discrete(_Space):
+    pass
+
+
+class MultiDiscrete(_Space):
+    pass
+
+
+class Box(_Space):
+    pass
+
+
+class SyntheticEnv:
+    def __init__(self, obs_dim=107, n_actions=90, n_agents=2, ep_len=17, seed=0, kind="discrete", new_gym_api=True):
+        self.obs_dim, self.n_agents, self.ep_len, self.kind = obs_dim, n_agents, ep_len, kind
+        self.rs = np.random.RandomState(seed)
+        self.observation_space = _Space(shape=(obs_dim,))
+        if kind == "discrete":
+            self.action_space = Discrete(n=n_actions)
+        elif kind == "multidiscrete":
+            self.action_space = MultiDiscrete(shape=(8,))
+        else:
+            self.action_space = Box(shape=(n_actions,))
+        self.new_gym_api = new_gym_api
+        self.t = 0
+
+    def _obs(self):
+        return (self.rs.randn(self.n_agents, self.obs_dim) * 2 + 0.5).astype(np.float32)
+
+    def reset(self):
+        self.t = 0
+        return self._obs()
+
+    def step(self, actions):
+        actions = np.asarray(actions)
+        assert actions.shape[0] == self.n_agents
+        self.t += 1
+        rew = [float(np.tanh(np.sum(actions[i]) * 0.01) + self.rs.randn() * 0.1) for i in range(self.n_agents)]
+        done = self.t >= self.ep_len
+        truncated = (not done) and (self.t % 11 == 0)
+        if self.new_gym_api:
+            return self._obs(), rew, done, truncated, {"state": None}
+        return self._obs(), rew, done, {"state": None}
+
+    def close(self):
+        pass
+
+
+def make_discrete_env():
+    return SyntheticEnv(kind="discrete")
+
+
+def make_continuous_env():
+    return SyntheticEnv(obs_dim=231, n_actions=8, n_agents=3, kind="continuous")
+
+
+def make_multidiscrete_env():
+    return SyntheticEnv(kind="multidiscrete", new_gym_api=False)

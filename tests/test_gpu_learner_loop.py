@@ -1,0 +1,96 @@
+"""End-to-end Learner loop on the GPU with a synthetic gym-free environment: env workers (process mode and in-process
+mode), rollout inference, value pass + GAE on the device, PPO update, report keys, checkpoint save + auto-load."""
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+import synthetic_env  # noqa: E402
+
+
+def run(env_fn, tmp_path, n_proc, **kw):
+    from rlgym_ppo_amd import Learner
+    cfg = dict(n_proc=n_proc, min_inference_size=2, timestep_limit=1400, exp_buffer_size=1024, ts_per_iteration=512,
+               ppo_epochs=2, ppo_batch_size=512, ppo_minibatch_size=256, policy_layer_sizes=(64, 64),
+               critic_layer_sizes=(64, 64), checkpoints_save_folder=str(tmp_path / "ckpt"), add_unix_timestamp=False,
+               save_every_ts=1000, checkpoint_load_folder=None, random_seed=3)
+    cfg.update(kw)
+    learner = Learner(env_fn, **cfg)
+    try:
+        learner._learn()  # learn() would swallow exceptions (reference behaviour); the test wants them raised
+    finally:
+        learner.agent.cleanup()
+    return learner
+
+
+def test_learner_loop_process_mode(tmp_path, capsys):
+    learner = run(synthetic_env.make_discrete_env, tmp_path, n_proc=2)
+    out = capsys.readouterr().out
+    assert out.count("BEGIN ITERATION REPORT") == 3 and "Policy Entropy" in out
+    assert learner.agent.cumulative_timesteps >= 1400 and learner.epoch == 3
+    assert learner.ppo_learner.cumulative_model_updates == 2 * 1 + 2 * 2 + 2 * 2   # buffer 512, 1024, 1024 samples
+    assert len(learner.experience_buffer) == 1024
+    ck = tmp_path / "ckpt"
+    steps = sorted(int(p) for p in os.listdir(ck))
+    assert steps, "a checkpoint should have been written at >= 1000 timesteps"
+    files = sorted(os.listdir(ck / str(steps[-1])))
+    assert files == ["BOOK_KEEPING_VARS.json", "PPO_POLICY.pt", "PPO_POLICY_OPTIMIZER.pt", "PPO_VALUE_NET.pt",
+                     "PPO_VALUE_NET_OPTIMIZER.pt"]
+    book = json.load(open(ck / str(steps[-1]) / "BOOK_KEEPING_VARS.json"))
+    assert {"cumulative_timesteps", "cumulative_model_updates", "policy_average_reward", "epoch", "ts_since_last_save",
+            "reward_running_stats", "obs_running_stats"} <= set(book)
+    # auto-load "latest" resumes counters and weights
+    from rlgym_ppo_amd import Learner
+    resumed = Learner(synthetic_env.make_discrete_env, n_proc=0, checkpoints_save_folder=str(ck), add_unix_timestamp=False,
+                      checkpoint_load_folder="latest", policy_layer_sizes=(64, 64), critic_layer_sizes=(64, 64),
+                      ppo_batch_size=512, ppo_minibatch_size=256, exp_buffer_size=1024, ts_per_iteration=512)
+    try:
+        assert resumed.agent.cumulative_timesteps == book["cumulative_timesteps"]
+        assert resumed.ppo_learner.cumulative_model_updates == book["cumulative_model_updates"]
+        sd = torch.load(ck / str(steps[-1]) / "PPO_POLICY.pt")
+        for k, v in resumed.ppo_learner.policy.state_dict().items():
+            assert torch.equal(v.cpu(), sd[k].cpu())
+    finally:
+        resumed.agent.cleanup()
+
+
+@pytest.mark.parametrize("env_fn", [synthetic_env.make_continuous_env, synthetic_env.make_multidiscrete_env])
+def test_learner_loop_in_process_other_heads(tmp_path, env_fn, capsys):
+    learner = run(env_fn, tmp_path, n_proc=0, timestep_limit=1000)
+    out = capsys.readouterr().out
+    assert out.count("BEGIN ITERATION REPORT") == 2
+    assert np.isfinite(learner.ppo_learner.policy.arena.flat.cpu().numpy()).all()
+
+
+def test_add_new_experience_matches_oracle(tmp_path):
+    """Value pass + GAE + buffer submit on the device vs the oracle on the same collected experience."""
+    from oracle import gae as ogae
+    from oracle import nets
+    from rlgym_ppo_amd import Learner
+    learner = Learner(synthetic_env.make_discrete_env, n_proc=0, min_inference_size=1, exp_buffer_size=600,
+                      ts_per_iteration=300, ppo_batch_size=300, policy_layer_sizes=(64, 64), critic_layer_sizes=(64, 64),
+                      checkpoints_save_folder=str(tmp_path / "c"), add_unix_timestamp=False, checkpoint_load_folder=None)
+    try:
+        exp, _, n, _ = learner.agent.collect_timesteps(300)
+        states, actions, log_probs, rewards, next_states, dones, truncated = exp
+        assert states.shape[1] == 107 and truncated[-1] + dones[-1] == 1  # quirk Q4
+        val = [(l.weight.detach().cpu(), l.bias.detach().cpu()) for l in learner.ppo_learner.value_net.arena.linears]
+        learner.add_new_experience(exp)
+        ov = nets.value_forward(val, np.concatenate([states, next_states[-1:]], 0)).flatten().numpy()
+        ovt, oadv, oret = ogae.gae(rewards, dones, truncated, ov, 0.99, 0.95, 1.0, "f64")  # return std is 1 before any stats
+        buf = learner.experience_buffer
+        np.testing.assert_allclose(buf.advantages.cpu().numpy(), oadv, rtol=2e-5, atol=2e-5)
+        np.testing.assert_allclose(buf.values.cpu().numpy(), ovt, rtol=2e-5, atol=2e-5)
+        assert np.array_equal(buf.states.cpu().numpy(), states) and np.array_equal(buf.next_states.cpu().numpy(), next_states)
+        assert learner.return_stats.count == 150
+        ref_stats = __import__("rlgym_ppo_amd.util", fromlist=["WelfordRunningStat"]).WelfordRunningStat(1)
+        ref_stats.increment(oret[:150].astype(np.float32), 150)
+        np.testing.assert_allclose(learner.return_stats.std, ref_stats.std, rtol=1e-5)
+    finally:
+        learner.agent.cleanup()
