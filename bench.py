@@ -153,13 +153,24 @@ def gae_bench():
     R, D, T, V = d(rews), d(dones), d(trunc), d(values)
     fn = lambda: torch_functions.gae_device(R, D, T, V, 0.99, 0.95, 1.7)
     fn()
-    ms = time_region(fn, 50, warm=5)
+    from rlgym_ppo_amd import _native as N
+    # A/B of the two implementations, interleaved in one process (cdna_hip_programming.md rule 24)
+    times = {0: [], 1: []}
+    for _ in range(5):
+        for algo in (0, 1):
+            N.check(N.lib().rlppo_dbg_set(1, algo))
+            times[algo].append(time_region(fn, 20, warm=2))
+    N.check(N.lib().rlppo_dbg_set(1, 1))
+    ms = float(np.median(times[1]))
+    ms_two = float(np.median(times[0]))
     alg_bytes = 28 * n
     out = dict(workload="8192 trajectories x 256 steps fp32 (BASELINE configs[2])", steps=n, ms_per_scan=round(ms, 5),
-               steps_per_s=round(n / ms * 1e3), launches=2,
+               steps_per_s=round(n / ms * 1e3), algorithm="single-pass decoupled look-back (memset node + 1 kernel)",
+               ms_per_scan_two_launch=round(ms_two, 5),
                roofline=dict(bound="hbm", achieved=round(alg_bytes / ms / 1e6, 1), peak=HBM_PEAK_GBS, unit="GB/s",
                              frac=round(alg_bytes / ms / 1e6 / HBM_PEAK_GBS, 4), traffic=None,
-                             note="achieved = 28 algorithmic B/step x steps / (summary + apply launches, HIP events)"))
+                             note="achieved = 28 algorithmic B/step x steps / time per scan (HIP events around 20 back-to-back scans, "
+                                  "median of 5 rounds; includes the state memset node)"))
     # CPU side: the C port and the interpreter-bound Python form (the reference runs a Python loop) on bounded samples
     from oracle import gae as ogae
     t = time.perf_counter()

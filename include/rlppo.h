@@ -189,6 +189,8 @@ int rlppo_mt19937_permutation(uint32_t *state625, int64_t n, int64_t *out);
 /* ------------------------------------------------------------------------------------------ diagnostics */
 /* Single-kernel entry points used by tests/ to check each GEMM flavour in isolation against a CPU product.
  * epilogue: 0 bias, 1 bias+relu, 2 bias+tanh, 3 relu-mask (mask_src > 0).  Shapes as in csrc/gemm.hip. */
+/* Tuning switches for A/B measurements.  key 1: GAE algorithm (1 = single-pass look-back, default; 0 = two launches). */
+int rlppo_dbg_set(int32_t key, int32_t value);
 int rlppo_dbg_gemm_nt(void *stream, const float *A, int64_t lda, const int64_t *row_idx, const float *B, int64_t ldb,
                       const float *bias, const float *mask_src, int64_t ld_mask, float *C, int64_t ldc, int64_t M,
                       int32_t N, int32_t K, int32_t epilogue);

@@ -220,7 +220,12 @@ class BatchedAgentManager(object):
             self._sync_trajectories()
         for pid, traj in enumerate(self.trajectory_map):
             self.completed_trajectories.append(traj)
-            self.trajectory_map[pid] = BatchedTrajectory()
+            fresh = BatchedTrajectory()
+            if traj.state is not None and traj.reward is None:
+                # an action is in flight for this worker: keep its (state, action, log_prob) so that the response,
+                # which arrives during the next collect_timesteps call, is paired with the step that produced it
+                fresh.state, fresh.action, fresh.log_prob = traj.state, traj.action, traj.log_prob
+            self.trajectory_map[pid] = fresh
         for traj in self.completed_trajectories:
             for seq in traj.get_all():
                 seq[6][-1] = 1 if seq[5][-1] == 0 else 0

@@ -370,6 +370,14 @@ int rlppo_clip_adam(void *stream, float *params, float *grads, float *exp_avg, f
 
 // ------------------------------------------------------------------------------------------ diagnostics
 extern "C" {
+int rlppo_dbg_set(int32_t key, int32_t value) {
+    if (key == 1) {
+        set_gae_algo(value);
+        return 0;
+    }
+    set_error("dbg_set: unknown key %d", key);
+    return RLPPO_ERR_ARG;
+}
 int rlppo_dbg_gemm_nt(void *stream, const float *A, int64_t lda, const int64_t *row_idx, const float *B, int64_t ldb,
                       const float *bias, const float *mask_src, int64_t ld_mask, float *C, int64_t ldc, int64_t M,
                       int32_t N, int32_t K, int32_t epilogue) {

@@ -75,6 +75,7 @@ int launch_pad_rows(hipStream_t, const void *, int, int64_t, int64_t, int64_t, f
 int launch_clip_adam(hipStream_t, float *p, float *g, float *m, float *v, int64_t n, float max_norm, float step_size,
                      float bc2_sqrt, float one_minus_beta1, float beta2, float one_minus_beta2, float eps, double *gnorm2);
 size_t gae_workspace_bytes(int64_t n);
+void set_gae_algo(int algo);
 int launch_gae(hipStream_t, const float *, const float *, const float *, const float *, int64_t, double, double, float,
                float *, float *, float *, void *, size_t);
 int launch_discrete_sample_logits(hipStream_t, const float *, int64_t, int64_t, int, const float *, int64_t *, float *, float *);

@@ -44,7 +44,8 @@ struct GaeParams {
 
 // Loads the GAE_EPT steps of this thread and turns them into per-step coefficients.
 struct Steps {
-    double a_adv[GAE_EPT], b_adv[GAE_EPT], a_ret[GAE_EPT];
+    double b_adv[GAE_EPT];
+    float m[GAE_EPT];  // nd * nt (exact for 0/1 flags); a_adv = gamma*lambda*m, a_ret = gamma*m are formed on use
     float r[GAE_EPT], v[GAE_EPT];
 };
 
@@ -90,12 +91,10 @@ __device__ __forceinline__ void load_steps(const float *__restrict__ rews, const
             float rn = r[e];
             if (p.use_std) rn = fminf(fmaxf(r[e] / p.ret_std, -10.f), 10.f);
             s.b_adv[e] = ((double)rn + p.gamma * (double)v[e + 1] * nd) - (double)v[e];
-            s.a_adv[e] = p.gl * nd * nt;
-            s.a_ret[e] = p.gamma * nd * nt;
+            s.m[e] = (float)(nd * nt);
         } else {  // past the end: identity, so partial blocks need no special casing downstream
             s.b_adv[e] = 0.0;
-            s.a_adv[e] = 1.0;
-            s.a_ret[e] = 1.0;
+            s.m[e] = -1.f;  // marker: a_adv = a_ret = 1
             r[e] = 0.f;
         }
         s.r[e] = r[e];
@@ -103,14 +102,22 @@ __device__ __forceinline__ void load_steps(const float *__restrict__ rews, const
     }
 }
 
-__device__ __forceinline__ Aff2 thread_composite(const Steps &s) {
+__device__ __forceinline__ double coef_adv(const Steps &s, int e, const GaeParams &p) {
+    return s.m[e] < 0.f ? 1.0 : p.gl * (double)s.m[e];
+}
+__device__ __forceinline__ double coef_ret(const Steps &s, int e, const GaeParams &p) {
+    return s.m[e] < 0.f ? 1.0 : p.gamma * (double)s.m[e];
+}
+
+__device__ __forceinline__ Aff2 thread_composite(const Steps &s, const GaeParams &p) {
     Aff2 c = aff_identity();
 #pragma unroll
     for (int e = GAE_EPT - 1; e >= 0; --e) {  // right to left: c <- step_e o c
-        c.b = s.b_adv[e] + s.a_adv[e] * c.b;
-        c.a = s.a_adv[e] * c.a;
-        c.d = (double)s.r[e] + s.a_ret[e] * c.d;
-        c.c = s.a_ret[e] * c.c;
+        const double aa = coef_adv(s, e, p), ar = coef_ret(s, e, p);
+        c.b = s.b_adv[e] + aa * c.b;
+        c.a = aa * c.a;
+        c.d = (double)s.r[e] + ar * c.d;
+        c.c = ar * c.c;
     }
     return c;
 }
@@ -139,7 +146,7 @@ __global__ __launch_bounds__(GAE_THREADS) void gae_summary_kernel(const float *_
     const int64_t t0 = ((int64_t)blockIdx.x * GAE_THREADS + threadIdx.x) * GAE_EPT;
     Steps s;
     load_steps(rews, dones, trunc, values, t0, n, p, s);
-    const Aff2 c = block_reduce(thread_composite(s), lds4);
+    const Aff2 c = block_reduce(thread_composite(s, p), lds4);
     if (threadIdx.x == 0) summaries[blockIdx.x] = c;
 }
 
@@ -171,7 +178,7 @@ __global__ __launch_bounds__(GAE_THREADS) void gae_apply_kernel(const float *__r
     const double carry_adv = right.b, carry_ret = right.d;
 
     // ---- in-block exclusive suffix scan of the thread composites
-    const Aff2 mine = thread_composite(s);
+    const Aff2 mine = thread_composite(s, p);
     Aff2 inc = mine;  // inclusive suffix over lanes lane..63
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
@@ -190,8 +197,8 @@ __global__ __launch_bounds__(GAE_THREADS) void gae_apply_kernel(const float *__r
     float o_adv[GAE_EPT], o_vt[GAE_EPT], o_ret[GAE_EPT];
 #pragma unroll
     for (int e = GAE_EPT - 1; e >= 0; --e) {
-        x_adv = s.b_adv[e] + s.a_adv[e] * x_adv;
-        x_ret = (double)s.r[e] + s.a_ret[e] * x_ret;
+        x_adv = s.b_adv[e] + coef_adv(s, e, p) * x_adv;
+        x_ret = (double)s.r[e] + coef_ret(s, e, p) * x_ret;
         o_adv[e] = (float)x_adv;
         o_vt[e] = (float)((double)s.v[e] + x_adv);
         o_ret[e] = (float)x_ret;
@@ -215,15 +222,237 @@ __global__ __launch_bounds__(GAE_THREADS) void gae_apply_kernel(const float *__r
     }
 }
 
-size_t gae_workspace_bytes(int64_t n) { return (size_t)(cdiv(n > 0 ? n : 1, GAE_BLOCK)) * sizeof(Aff2); }
+// ------------------------------------------------------------------------------------------ single pass
+// One launch: chained scan with decoupled look-back.  Workgroups take chunks right-to-left through a ticket counter
+// (a chunk only ever waits on chunks whose tickets were drawn earlier, so progress never depends on dispatch order or
+// residency), publish their composite, look at the chunks to their right until an inclusive value or A == 0 is
+// found (normally one hop), publish their own inclusive value and finish the in-block scan.  Every published word
+// travels in an 8-byte {tag, value} granule written by ONE agent-scope relaxed atomic store (write-through, sc1) and
+// read by agent-scope relaxed atomic loads that bypass L1: the data is its own flag, no fences
+// (cdna_hip_programming.md Guideline 16, form R2).  No memset: tags are per-launch epochs (see the kernel).
+typedef unsigned long long u64;
+constexpr int LB_AGG = 8;                       // granules of the aggregate record: 4 doubles
+constexpr int LB_INC = 4;                       // granules of the inclusive record: 2 doubles
+constexpr int LB_STRIDE = 16;                   // granules per chunk (128 B: one line per chunk)
+constexpr int LOOKAHEAD = 256;                  // raw steps of the next chunk inspected by wave 0 (4 per lane)
+constexpr unsigned LB_SPIN_LIMIT = 1u << 22;    // bounded spin: give up (error word set) instead of hanging the GPU
+
+__device__ __forceinline__ void put_granule(u64 *p, unsigned tag, unsigned v) {
+    __hip_atomic_store(p, ((u64)tag << 32) | v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void put_double(u64 *p, unsigned tag, double d) {
+    const u64 bits = (u64)__double_as_longlong(d);
+    put_granule(p, tag, (unsigned)bits);
+    put_granule(p + 1, tag, (unsigned)(bits >> 32));
+}
+
+__global__ __launch_bounds__(GAE_THREADS, 4) void gae_lookback_kernel(const float *__restrict__ rews,
+                                                                    const float *__restrict__ dones,
+                                                                    const float *__restrict__ trunc,
+                                                                    const float *__restrict__ values, int64_t n,
+                                                                    GaeParams p, u64 *__restrict__ state,
+                                                                    unsigned *__restrict__ epoch_word,
+                                                                    unsigned *__restrict__ error_word, int n_blocks,
+                                                                    float *__restrict__ vt_out,
+                                                                    float *__restrict__ adv_out,
+                                                                    float *__restrict__ ret_out) {
+    __shared__ Aff2 wave_tot[4];
+    __shared__ double s_carry[2];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // Tags are unique per launch without a memset: tag = (epoch word left by the previous launch on this workspace)
+    // + 1, and the workgroup that owns chunk 0 -- the end of the dependency chain, so every other workgroup has read
+    // the word by then -- stores the new value on its way out.  Whatever the word holds on first use, records of
+    // earlier launches (or never-written memory) carry a different tag in all 8 / 4 granules of a record.
+    const unsigned TAG_AGG = __hip_atomic_load(epoch_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+    const unsigned TAG_INC = TAG_AGG;
+    // Chunks are taken right-to-left, grid-strided.  A chunk waits only on chunks to its right, i.e. on work of this
+    // same round owned by lower block ids or on earlier rounds; the launcher sizes the grid to the number of
+    // co-resident workgroups, so every awaited chunk belongs to a running workgroup whatever the dispatch order.
+    for (int chunk = n_blocks - 1 - (int)blockIdx.x; chunk >= 0; chunk -= (int)gridDim.x) {
+    const int64_t t0 = ((int64_t)chunk * GAE_THREADS + threadIdx.x) * GAE_EPT;
+
+    Steps s;
+    load_steps(rews, dones, trunc, values, t0, n, p, s);
+    const Aff2 mine = thread_composite(s, p);
+    // one shuffle scan serves both purposes: lane l gets the composite of lanes l..63 (needed for the outputs) and
+    // lane 0's value is the wave total (needed for the chunk aggregate)
+    Aff2 inc = mine;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const Aff2 o = shfl_down_aff(inc, off);
+        if (lane + off < 64) inc = compose(inc, o);
+    }
+    if (lane == 0) wave_tot[wave] = inc;
+    __syncthreads();
+    const Aff2 agg = compose(compose(wave_tot[0], wave_tot[1]), compose(wave_tot[2], wave_tot[3]));
+    u64 *rec = state + (size_t)chunk * LB_STRIDE;
+
+    if (wave == 0) {
+        double carry_adv = 0.0, carry_ret = 0.0;
+        if (chunk + 1 < n_blocks) {
+            if (lane == 0) {  // publish the aggregate first so that chunks to the left can pass through this one
+                put_double(rec + 0, TAG_AGG, agg.a);
+                put_double(rec + 2, TAG_AGG, agg.b);
+                put_double(rec + 4, TAG_AGG, agg.c);
+                put_double(rec + 6, TAG_AGG, agg.d);
+            }
+            // Fast path: compose the first LOOKAHEAD raw steps of the next chunk.  A trajectory end inside them
+            // (a == 0) fixes the carry with no dependence on any other workgroup -- the normal case for rollout data.
+            Aff2 acc = aff_identity();
+            bool done = false;
+            {
+                const int64_t tb = (int64_t)(chunk + 1) * GAE_BLOCK + 4 * lane;
+                Aff2 la = aff_identity();
+                float lr[4], ld[4], lt[4], lv[5];
+                if (tb + 4 <= n) {  // 16-byte aligned: one dwordx4 per array
+                    typedef float f4 __attribute__((ext_vector_type(4)));
+                    const f4 r4 = *reinterpret_cast<const f4 *>(rews + tb), d4 = *reinterpret_cast<const f4 *>(dones + tb);
+                    const f4 t4 = *reinterpret_cast<const f4 *>(trunc + tb), v4 = *reinterpret_cast<const f4 *>(values + tb);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        lr[e] = r4[e];
+                        ld[e] = d4[e];
+                        lt[e] = t4[e];
+                        lv[e] = v4[e];
+                    }
+                    lv[4] = values[tb + 4];
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const bool ok = tb + e < n;
+                        lr[e] = ok ? rews[tb + e] : 0.f;
+                        ld[e] = ok ? dones[tb + e] : 0.f;
+                        lt[e] = ok ? trunc[tb + e] : 0.f;
+                        lv[e] = ok ? values[tb + e] : 0.f;
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (tb + e + 1 <= n) lv[e + 1] = values[tb + e + 1];
+                }
+#pragma unroll
+                for (int e = 3; e >= 0; --e) {
+                    if (tb + e < n) {
+                        const double nd = (double)(1.0f - ld[e]), nt = (double)(1.0f - lt[e]);
+                        const float rn = p.use_std ? fminf(fmaxf(lr[e] / p.ret_std, -10.f), 10.f) : lr[e];
+                        const double b = ((double)rn + p.gamma * (double)lv[e + 1] * nd) - (double)lv[e];
+                        const double aa = p.gl * (double)(float)(nd * nt), ar = p.gamma * (double)(float)(nd * nt);
+                        la = Aff2{aa * la.a, b + aa * la.b, ar * la.c, (double)lr[e] + ar * la.d};
+                    }
+                }
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) {
+                    const Aff2 o = shfl_down_aff(la, off);
+                    if (lane + off < 64) la = compose(la, o);
+                }
+                la = Aff2{__shfl(la.a, 0), __shfl(la.b, 0), __shfl(la.c, 0), __shfl(la.d, 0)};
+                const bool covers_all = (int64_t)(chunk + 1) * GAE_BLOCK + LOOKAHEAD >= n;  // ran off the end: x = 0 there
+                if ((la.a == 0.0 && la.c == 0.0) || covers_all) {
+                    carry_adv = la.b;
+                    carry_ret = la.d;
+                    done = true;
+                }
+            }
+            int j = chunk + 1;
+            unsigned spins = 0;
+            while (!done) {
+                // lanes 0..11 read the 12 granules of chunk j (8 aggregate + 4 inclusive)
+                u64 g = 0;
+                if (lane < LB_AGG + LB_INC)
+                    g = __hip_atomic_load(state + (size_t)j * LB_STRIDE + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned tag = (unsigned)(g >> 32), val = (unsigned)g;
+                const u64 inc_ok = __ballot(lane >= LB_AGG && lane < LB_AGG + LB_INC && tag == TAG_INC);
+                const u64 agg_ok = __ballot(lane < LB_AGG && tag == TAG_AGG);
+                auto dbl = [&](int first) {
+                    const unsigned lo = __shfl(val, first), hi = __shfl(val, first + 1);
+                    return __longlong_as_double((long long)(((u64)hi << 32) | lo));
+                };
+                if (inc_ok == 0xF00ull) {
+                    const double xa = dbl(8), xr = dbl(10);
+                    carry_adv = acc.b + acc.a * xa;
+                    carry_ret = acc.d + acc.c * xr;
+                    done = true;
+                } else if (agg_ok == 0xFFull) {
+                    const Aff2 r = Aff2{dbl(0), dbl(2), dbl(4), dbl(6)};
+                    acc = compose(acc, r);
+                    if (acc.a == 0.0 && acc.c == 0.0) {  // a trajectory end cuts both recurrences: nothing further matters
+                        carry_adv = acc.b;
+                        carry_ret = acc.d;
+                        done = true;
+                    } else {
+                        ++j;  // chunk n_blocks-1 always publishes an inclusive record, so j never runs off the end
+                        spins = 0;
+                    }
+                } else {
+                    __builtin_amdgcn_s_sleep(2);
+                    if (++spins > LB_SPIN_LIMIT) {
+                        if (lane == 0) atomicExch(error_word, 1u);
+                        done = true;
+                    }
+                }
+            }
+        }
+        if (lane == 0) {
+            put_double(rec + 8, TAG_INC, agg.b + agg.a * carry_adv);   // x at the first step of this chunk
+            put_double(rec + 10, TAG_INC, agg.d + agg.c * carry_ret);
+            s_carry[0] = carry_adv;
+            s_carry[1] = carry_ret;
+        }
+    }
+
+    // ---- exclusive suffix of this thread within the chunk, then the carry
+    __syncthreads();  // publishes s_carry
+    const double carry_adv = s_carry[0], carry_ret = s_carry[1];
+    Aff2 after = shfl_down_aff(inc, 1);
+    if (lane == 63) after = aff_identity();
+    for (int w = wave + 1; w < 4; ++w) after = compose(after, wave_tot[w]);
+    double x_adv = after.b + after.a * carry_adv;
+    double x_ret = after.d + after.c * carry_ret;
+
+    float o_adv[GAE_EPT], o_vt[GAE_EPT], o_ret[GAE_EPT];
+#pragma unroll
+    for (int e = GAE_EPT - 1; e >= 0; --e) {
+        x_adv = s.b_adv[e] + coef_adv(s, e, p) * x_adv;
+        x_ret = (double)s.r[e] + coef_ret(s, e, p) * x_ret;
+        o_adv[e] = (float)x_adv;
+        o_vt[e] = (float)((double)s.v[e] + x_adv);
+        o_ret[e] = (float)x_ret;
+    }
+    if (t0 + GAE_EPT <= n) {
+        typedef float f4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+        for (int h = 0; h < GAE_EPT / 4; ++h) {
+            *reinterpret_cast<f4 *>(adv_out + t0 + 4 * h) = f4{o_adv[4 * h], o_adv[4 * h + 1], o_adv[4 * h + 2], o_adv[4 * h + 3]};
+            *reinterpret_cast<f4 *>(vt_out + t0 + 4 * h) = f4{o_vt[4 * h], o_vt[4 * h + 1], o_vt[4 * h + 2], o_vt[4 * h + 3]};
+            *reinterpret_cast<f4 *>(ret_out + t0 + 4 * h) = f4{o_ret[4 * h], o_ret[4 * h + 1], o_ret[4 * h + 2], o_ret[4 * h + 3]};
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < GAE_EPT; ++e)
+            if (t0 + e < n) {
+                adv_out[t0 + e] = o_adv[e];
+                vt_out[t0 + e] = o_vt[e];
+                ret_out[t0 + e] = o_ret[e];
+            }
+    }
+    if (chunk == 0 && threadIdx.x == 0) __hip_atomic_store(epoch_word, TAG_AGG, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();  // LDS (lds4, wave_tot, s_carry) is reused by the next round
+    }
+}
+
+static int g_gae_algo = 1;  // 1 = single-pass look-back (default), 0 = two launches (summary + apply)
+void set_gae_algo(int a) { g_gae_algo = a; }
+
+// workspace: [0,16) ticket + error word (+pad) | look-back state (128 B per chunk) ; the two-launch path uses the same
+// region for its per-chunk composites (32 B per chunk)
+size_t gae_workspace_bytes(int64_t n) { return 16 + (size_t)(cdiv(n > 0 ? n : 1, GAE_BLOCK)) * LB_STRIDE * sizeof(u64); }
 
 int launch_gae(hipStream_t st, const float *rews, const float *dones, const float *trunc, const float *values, int64_t n,
                double gamma, double lmbda, float ret_std, float *vt, float *adv, float *ret, void *ws, size_t ws_bytes) {
     if (n == 0) return 0;
     RLPPO_CHECK_ARG(n > 0, "gae: n=%ld", (long)n);
     RLPPO_CHECK_ARG(((uintptr_t)rews | (uintptr_t)dones | (uintptr_t)trunc | (uintptr_t)values | (uintptr_t)vt |
-                     (uintptr_t)adv | (uintptr_t)ret) % 16 == 0,
-                    "gae: arrays must be 16-byte aligned");
+                     (uintptr_t)adv | (uintptr_t)ret | (uintptr_t)ws) % 16 == 0,
+                    "gae: arrays and workspace must be 16-byte aligned");
     if (ws_bytes < gae_workspace_bytes(n)) {
         set_error("gae: workspace %zu < %zu bytes", ws_bytes, gae_workspace_bytes(n));
         return RLPPO_ERR_WORKSPACE;
@@ -234,7 +463,28 @@ int launch_gae(hipStream_t st, const float *rews, const float *dones, const floa
     p.use_std = !(ret_std != ret_std);  // NaN means "no scaling" (return_std=None)
     p.ret_std = ret_std;
     const int nb = (int)cdiv(n, GAE_BLOCK);
-    Aff2 *summ = reinterpret_cast<Aff2 *>(ws);
+    if (g_gae_algo == 1) {
+        unsigned *hdr = reinterpret_cast<unsigned *>(ws);
+        u64 *state = reinterpret_cast<u64 *>(reinterpret_cast<char *>(ws) + 16);
+        static int resident = 0;  // co-resident workgroups of this kernel on the device (queried once)
+        if (resident == 0) {
+            int per_cu = 0, dev = 0;
+            hipDeviceProp_t prop;
+            RLPPO_HIP(hipGetDevice(&dev));
+            RLPPO_HIP(hipGetDeviceProperties(&prop, dev));
+            RLPPO_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gae_lookback_kernel, GAE_THREADS, 0));
+            // the occupancy API over-reports by one block per CU only in the SGPR-limited 7-8 blocks/CU regime
+            // (MI355X_MICROARCH.md "Residency and cooperative launch"); this kernel is VGPR-limited far below that
+            per_cu = per_cu > 6 ? 6 : (per_cu < 1 ? 1 : per_cu);
+            resident = per_cu * prop.multiProcessorCount;
+        }
+        const int grid = nb < resident ? nb : resident;
+        hipLaunchKernelGGL(gae_lookback_kernel, dim3(grid), dim3(GAE_THREADS), 0, st, rews, dones, trunc, values, n, p, state,
+                           hdr, hdr + 1, nb, vt, adv, ret);
+        RLPPO_LAUNCH_CHECK();
+        return 0;
+    }
+    Aff2 *summ = reinterpret_cast<Aff2 *>(reinterpret_cast<char *>(ws) + 16);
     hipLaunchKernelGGL(gae_summary_kernel, dim3(nb), dim3(GAE_THREADS), 0, st, rews, dones, trunc, values, n, p, summ);
     RLPPO_LAUNCH_CHECK();
     hipLaunchKernelGGL(gae_apply_kernel, dim3(nb), dim3(GAE_THREADS), 0, st, rews, dones, trunc, values, n, p, summ, nb,

@@ -9,6 +9,8 @@
 #include <stdint.h>
 #include <string.h>
 
+#include <vector>
+
 #include "../../include/rlppo.h"
 
 namespace {
@@ -56,25 +58,66 @@ int rlppo_mt19937_seed(uint32_t *st, uint32_t seed) {
 }
 
 int rlppo_mt19937_permutation(uint32_t *st, int64_t n, int64_t *out) {
-    if (!st || n < 0 || (n > 0 && !out) || n > 0xffffffffLL) return RLPPO_ERR_ARG;
-    for (int64_t i = 0; i < n; i++) out[i] = i;
-    for (int64_t i = n - 1; i >= 1; i--) {
-        // random_interval(max = i): smallest all-ones mask >= i, redraw until <= i
-        uint64_t mask = (uint64_t)i;
-        mask |= mask >> 1;
-        mask |= mask >> 2;
-        mask |= mask >> 4;
-        mask |= mask >> 8;
-        mask |= mask >> 16;
-        mask |= mask >> 32;
-        uint64_t j;
-        do {
-            j = next32(st) & mask;
-        } while (j > (uint64_t)i);
-        const int64_t t = out[j];
-        out[j] = out[i];
-        out[i] = t;
+    if (!st || n < 0 || (n > 0 && !out) || n > 0x7fffffffLL) return RLPPO_ERR_ARG;
+    // Same draws and swaps as numpy's _shuffle_raw, restructured for the CPU: (1) the generator is run a whole
+    // 624-word block at a time (regenerate + temper into a cache); (2) the rejection test of random_interval is
+    // branch-free (every stream word is consumed exactly once; an accepted word advances i); (3) the random targets
+    // of a batch of consecutive i are drawn first and their cache lines prefetched, then the swaps are applied in
+    // order on a 32-bit working copy (2 MB at 512k samples).
+    static thread_local std::vector<int32_t> work;
+    work.resize((size_t)n);
+    int32_t *w = work.data();
+    for (int64_t i = 0; i < n; i++) w[i] = (int32_t)i;
+
+    uint32_t cache[N];
+    uint32_t pos = st[N] > (uint32_t)N ? (uint32_t)N : st[N];
+    auto temper_block = [&](uint32_t from) {
+        for (uint32_t k = from; k < (uint32_t)N; k++) {
+            uint32_t y = st[k];
+            y ^= (y >> 11);
+            y ^= (y << 7) & 0x9d2c5680u;
+            y ^= (y << 15) & 0xefc60000u;
+            y ^= (y >> 18);
+            cache[k] = y;
+        }
+    };
+    temper_block(pos);
+
+    constexpr int BATCH = 64;
+    uint32_t js[BATCH + 1];
+    int64_t i = n - 1;
+    while (i >= 1) {
+        const int want = (int)(i < BATCH ? i : BATCH);
+        int cnt = 0;
+        uint32_t ii = (uint32_t)i;
+        while (cnt < want) {
+            // ii stays in (lo, mask] for a long run, so the mask is hoisted out of the accept chain (cmp + sub only)
+            const uint32_t mask = 0xffffffffu >> __builtin_clz(ii);  // smallest all-ones mask >= ii
+            const uint32_t lo = mask >> 1;
+            while (cnt < want && ii > lo) {
+                if (pos >= (uint32_t)N) {
+                    regen(st);
+                    temper_block(0);
+                    pos = 0;
+                }
+                const uint32_t v = cache[pos++] & mask;
+                const uint32_t acc = v <= ii;
+                js[cnt] = v;
+                cnt += (int)acc;
+                ii -= acc;
+            }
+        }
+        for (int k = 0; k < want; k++) __builtin_prefetch(&w[js[k]], 1, 1);
+        for (int k = 0; k < want; k++) {
+            const int64_t t_i = i - k;
+            const int32_t t = w[js[k]];
+            w[js[k]] = w[t_i];
+            w[t_i] = t;
+        }
+        i -= want;
     }
+    st[N] = pos;
+    for (int64_t k = 0; k < n; k++) out[k] = w[k];
     return 0;
 }
 }

@@ -107,7 +107,31 @@ def run_gae(L, rews, dones, trunc, values, gamma, lmbda, std):
     return vt.cpu().numpy(), adv.cpu().numpy(), ret.cpu().numpy()
 
 
-def test_gae_golden_vectors(L, golden):
+@pytest.fixture(params=[1, 0], ids=["lookback", "two_launch"], autouse=False)
+def gae_algo(L, request):
+    """Both GAE implementations are held to the same checks: single-pass decoupled look-back (default) and the
+    two-launch summary + apply form."""
+    check(L, L.rlppo_dbg_set(1, request.param))
+    yield request.param
+    check(L, L.rlppo_dbg_set(1, 1))
+
+
+def test_gae_lookback_stress_repeated(L):
+    # the look-back hand-off is timing dependent: repeat a many-chunk scan and demand bit-identical outputs every time
+    rews, dones, trunc, values = synth_gae(8192, 256, seed=5, p_mid=0.0)
+    dones[:] = 0
+    trunc[:] = 0           # no trajectory ends at all: every chunk must chain through ALL chunks to its right
+    trunc[-1] = 1
+    ref = run_gae(L, rews, dones, trunc, values, 0.999, 0.999, None)
+    ovt, oadv, oret = ogae.gae(rews, dones, trunc, values, 0.999, 0.999, None, "f64")
+    np.testing.assert_allclose(ref[1], oadv, rtol=1e-5, atol=1e-4)
+    for _ in range(20):
+        again = run_gae(L, rews, dones, trunc, values, 0.999, 0.999, None)
+        for a, b in zip(ref, again):
+            assert np.array_equal(a, b)
+
+
+def test_gae_golden_vectors(L, golden, gae_algo):
     g = golden("g3_gae")
     for c in range(int(g["n_cases"])):
         p = f"c{c}."
@@ -138,7 +162,7 @@ def synth_gae(n_seg, seg_len, seed=0, p_mid=0.005):
 
 
 @pytest.mark.parametrize("n_seg,seg_len,std", [(64, 256, 1.7), (1000, 37, None), (3, 5000, 0.01), (1, 2049, 1.0), (8192, 256, 1.7)])
-def test_gae_matches_oracle(L, n_seg, seg_len, std):
+def test_gae_matches_oracle(L, n_seg, seg_len, std, gae_algo):
     rews, dones, trunc, values = synth_gae(n_seg, seg_len, seed=n_seg)
     vt, adv, ret = run_gae(L, rews, dones, trunc, values, 0.99, 0.95, std)
     ovt, oadv, oret = ogae.gae(rews, dones, trunc, values, 0.99, 0.95, std, "f64")
@@ -148,7 +172,7 @@ def test_gae_matches_oracle(L, n_seg, seg_len, std):
     np.testing.assert_allclose(ret, oret.astype(np.float32), rtol=2e-6, atol=2e-6)
 
 
-def test_gae_long_undiscounted_carry(L):
+def test_gae_long_undiscounted_carry(L, gae_algo):
     # no episode end for 300k steps and gamma = lambda = 1: the carry must cross ~146 workgroups exactly
     rs = np.random.RandomState(1)
     n = 300_001
@@ -161,7 +185,7 @@ def test_gae_long_undiscounted_carry(L):
     np.testing.assert_allclose(adv, oadv, rtol=1e-6, atol=1e-5)
 
 
-def test_gae_segment_independence_and_linearity(L):
+def test_gae_segment_independence_and_linearity(L, gae_algo):
     # size-independent properties at the BASELINE size (8192 x 256): (1) outputs before a done do not depend on what
     # follows it; (2) returns are linear in the rewards.
     rews, dones, trunc, values = synth_gae(8192, 256, seed=0)

