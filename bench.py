@@ -211,29 +211,38 @@ def rollout_bench(learner):
 
 
 def cpu_baseline(seed=123):
-    """The oracle's learn() (torch-CPU eager, the reference's op sequence) on one epoch of the same workload."""
+    """The oracle's learn() (torch-CPU eager, the reference's op sequence; kind "port") on a BOUNDED sample of the same
+    workload: a 131,072-sample slice of the cfg2 buffer = one optimiser step of 2 minibatches of 65,536 (same nets, same
+    minibatch size, same per-sample work as the GPU run).  Thread count: the better of 16 and min(cores, 64) -- on the
+    256-thread GPU-box host, torch-CPU with all hardware threads is ~20x SLOWER than with 16-64 (oversubscribed MKL/OpenMP),
+    which would misrepresent the reference."""
     from oracle import nets, ppo
     cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
+    n, B = 131072, 131072
     torch.manual_seed(seed)
-    pol = nets.init_mlp(OBS, HID, ACT)
-    val = nets.init_mlp(OBS, HID, 1)
     g = torch.Generator().manual_seed(seed)
-    n = N_SAMPLES
     states = torch.randn(n, OBS, generator=g).clamp_(-5, 5)
+    pol0 = nets.init_mlp(OBS, HID, ACT)
+    val0 = nets.init_mlp(OBS, HID, 1)
     with torch.no_grad():
-        probs = nets.discrete_probs(pol, states[:65536])
+        probs = nets.discrete_probs(pol0, states[:65536])
         a, lp = nets.discrete_sample(probs, torch.empty(65536, ACT).exponential_(1, generator=g))
-    reps = n // 65536
-    buf = dict(states=states, actions=a.float().repeat(reps), log_probs=lp.repeat(reps),
+    buf = dict(states=states, actions=a.float().repeat(2), log_probs=lp.repeat(2),
                values=torch.randn(n, generator=g), advantages=torch.randn(n, generator=g))
-    rng = np.random.RandomState(seed)
-    t = time.perf_counter()
-    ppo.learn("discrete", pol, val, buf, BATCH, MINIBATCH, 1, 0.2, 0.005, 3e-4, 3e-4, rng)
-    dt = time.perf_counter() - t
-    return dict(value=round(n / dt), unit="samples/s", cores=cores, kind="port",
-                sample="1 epoch (1 optimiser step, 8 minibatches of 65,536) over the same 524,288-sample cfg2 buffer, "
-                       "torch-CPU eager oracle, %d threads, %.1f s" % (cores, dt))
+    best = None
+    for threads in sorted({min(cores, 16), min(cores, 64)}):
+        torch.set_num_threads(threads)
+        pol = [(w.clone(), b.clone()) for w, b in pol0]
+        val = [(w.clone(), b.clone()) for w, b in val0]
+        t = time.perf_counter()
+        ppo.learn("discrete", pol, val, buf, B, MINIBATCH, 1, 0.2, 0.005, 3e-4, 3e-4, np.random.RandomState(seed))
+        dt = time.perf_counter() - t
+        if best is None or dt < best[0]:
+            best = (dt, threads)
+    dt, threads = best
+    return dict(value=round(n / dt), unit="samples/s", cores=threads, kind="port",
+                sample="1 optimiser step over 131,072 samples (2 minibatches of 65,536) of the cfg2 workload, torch-CPU eager "
+                       "oracle, %d threads (best of 16 / min(cores,64); host has %d), %.1f s" % (threads, cores, dt))
 
 
 # ---------------------------------------------------------------------------------------------------- main

@@ -131,6 +131,8 @@ typedef struct rlppo_minibatch_args {
     int32_t pol_layers;
     int32_t val_layers;
     int32_t act_dim;              /* floats per action row in `actions` (1, 8, k) */
+    int32_t slot;                 /* 0..RLPPO_MAX_SLOTS-1: minibatches given different slots (and different workspaces) may run
+                                     concurrently on library-owned streams; rlppo_ppo_join() makes `stream` wait for all of them */
     const int32_t *pol_dims;      /* HOST */
     const int32_t *val_dims;      /* HOST */
     const float *pol_packed;
@@ -164,10 +166,18 @@ typedef struct rlppo_minibatch_args {
 #define RLPPO_STAT_GNORM2_VAL 6
 #define RLPPO_N_STATS 8
 
+#define RLPPO_MAX_SLOTS 8
+
 /* One minibatch of PPOLearner.learn (ppo_learner.py:134-185): value forward, policy forward,
  * get_backprop_data, clipped surrogate + entropy + value losses, both backward passes; gradients are ADDED into
  * pol_grad / val_grad (the reference accumulates over the minibatches of a batch, ppo_learner.py:179-180). */
 int rlppo_ppo_minibatch(void *stream, const rlppo_minibatch_args *args);
+
+/* Orders `stream` after every minibatch enqueued through non-zero slots since the last join (call it before the
+ * gradient all-reduce / rlppo_clip_adam).  Independent minibatches of one batch only meet in the gradient arena
+ * (atomic adds), so they may overlap; each launch is short (50-100 us), and overlapping chains fill the CUs that one
+ * chain's ramp-up and tail leave idle. */
+int rlppo_ppo_join(void *stream);
 
 /* clip_grad_norm_(max_norm) + torch.optim.Adam.step() on one flat arena (ppo_learner.py:187-193).
  * Hyper-parameters are doubles (python floats in the reference); `step` is the 1-based Adam step count of
@@ -191,6 +201,8 @@ int rlppo_mt19937_permutation(uint32_t *state625, int64_t n, int64_t *out);
  * epilogue: 0 bias, 1 bias+relu, 2 bias+tanh, 3 relu-mask (mask_src > 0).  Shapes as in csrc/gemm.hip. */
 /* Tuning switches for A/B measurements.  key 1: GAE algorithm (1 = single-pass look-back, default; 0 = two launches). */
 int rlppo_dbg_set(int32_t key, int32_t value);
+/* Register-only fp32 MFMA loop: out[blocks*256] floats, clocks[2*blocks] = {shader cycles, 100 MHz ticks} per block. */
+int rlppo_dbg_mfma_probe(void *stream, float *out, int32_t blocks, int32_t iters, uint64_t *clocks);
 int rlppo_dbg_gemm_nt(void *stream, const float *A, int64_t lda, const int64_t *row_idx, const float *B, int64_t ldb,
                       const float *bias, const float *mask_src, int64_t ld_mask, float *C, int64_t ldc, int64_t M,
                       int32_t N, int32_t K, int32_t epilogue);

@@ -14,6 +14,7 @@ LIB_PATH = os.path.join(HERE, "librlppo.so")
 ABI_VERSION = 1
 MAX_LAYERS = 16
 N_STATS = 8
+MAX_SLOTS = 8
 STAT_ENTROPY, STAT_KL, STAT_VLOSS, STAT_CLIPFRAC, STAT_PLOSS = 0, 1, 2, 3, 4
 HEAD_DISCRETE, HEAD_MULTIDISCRETE, HEAD_GAUSSIAN = 0, 1, 2
 
@@ -25,7 +26,7 @@ class NativeLibraryMissing(RuntimeError):
 class MinibatchArgs(ctypes.Structure):
     """struct rlppo_minibatch_args (include/rlppo.h)."""
     _fields_ = [
-        ("head", c_int32), ("pol_layers", c_int32), ("val_layers", c_int32), ("act_dim", c_int32),
+        ("head", c_int32), ("pol_layers", c_int32), ("val_layers", c_int32), ("act_dim", c_int32), ("slot", c_int32),
         ("pol_dims", POINTER(c_int32)), ("val_dims", POINTER(c_int32)),
         ("pol_packed", c_void_p), ("val_packed", c_void_p), ("pol_grad", c_void_p), ("val_grad", c_void_p),
         ("states", c_void_p), ("ld_states", c_int64), ("actions", c_void_p), ("old_logp", c_void_p),
@@ -62,11 +63,13 @@ SIGNATURES = {
                             c_void_p, c_void_p, c_void_p, c_void_p, c_size_t]),
     "rlppo_minibatch_workspace_bytes": (c_size_t, [_P32, c_int32, _P32, c_int32, c_int64]),
     "rlppo_ppo_minibatch": (c_int32, [c_void_p, POINTER(MinibatchArgs)]),
+    "rlppo_ppo_join": (c_int32, [c_void_p]),
     "rlppo_clip_adam": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_double, c_double,
                                   c_double, c_double, c_double, c_int64, c_void_p]),
     "rlppo_mt19937_seed": (c_int32, [POINTER(c_uint32), c_uint32]),
     "rlppo_mt19937_permutation": (c_int32, [POINTER(c_uint32), c_int64, c_void_p]),
     "rlppo_dbg_set": (c_int32, [c_int32, c_int32]),
+    "rlppo_dbg_mfma_probe": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_void_p]),
     "rlppo_dbg_gemm_nt": (c_int32, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_void_p,
                                     c_int64, c_void_p, c_int64, c_int64, c_int32, c_int32, c_int32]),
     "rlppo_dbg_gemm_tn": (c_int32, [c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_int64, c_void_p, c_int32,

@@ -234,12 +234,35 @@ int rlppo_gae(void *stream, const float *rews, const float *dones, const float *
 }
 
 // ------------------------------------------------------------------------------------------- PPO minibatch
+static int g_two_streams = 1;  // tuning: rlppo_dbg_set(4, 0/1)
+// Library-owned streams: slot s > 0 runs its policy chain on g_main[s]; every slot runs its critic chain on g_side[s].
+static hipStream_t g_main[RLPPO_MAX_SLOTS] = {}, g_side[RLPPO_MAX_SLOTS] = {};
+static hipEvent_t g_ev_fork[RLPPO_MAX_SLOTS] = {}, g_ev_join[RLPPO_MAX_SLOTS] = {}, g_ev_slot[RLPPO_MAX_SLOTS] = {};
+static bool g_slot_pending[RLPPO_MAX_SLOTS] = {};
+
+static int ensure_slot(int s) {
+    if (!g_side[s]) {
+        RLPPO_HIP(hipStreamCreateWithFlags(&g_side[s], hipStreamNonBlocking));
+        RLPPO_HIP(hipStreamCreateWithFlags(&g_main[s], hipStreamNonBlocking));
+        RLPPO_HIP(hipEventCreateWithFlags(&g_ev_fork[s], hipEventDisableTiming));
+        RLPPO_HIP(hipEventCreateWithFlags(&g_ev_join[s], hipEventDisableTiming));
+        RLPPO_HIP(hipEventCreateWithFlags(&g_ev_slot[s], hipEventDisableTiming));
+    }
+    return 0;
+}
+// `to` waits for everything enqueued on `from` so far
+static int order_after(hipStream_t to, hipStream_t from, hipEvent_t ev) {
+    RLPPO_HIP(hipEventRecord(ev, from));
+    RLPPO_HIP(hipStreamWaitEvent(to, ev, 0));
+    return 0;
+}
+
 static size_t train_ws_floats(const NetLayout &pol, const NetLayout &val, int64_t mb) {
     size_t per_row = 0;
     for (int l = 0; l < pol.n_layers; ++l) per_row += pol.L[l].pout;
     for (int l = 0; l < val.n_layers; ++l) per_row += val.L[l].pout;
     int m = max_pout(pol) > max_pout(val) ? max_pout(pol) : max_pout(val);
-    per_row += 2 * (size_t)m;
+    per_row += 4 * (size_t)m;  // two ping-pong dX buffers per net (the two backward chains run concurrently)
     return per_row * (size_t)mb;
 }
 
@@ -301,7 +324,18 @@ int rlppo_ppo_minibatch(void *stream, const rlppo_minibatch_args *a) {
     if (a->head == RLPPO_HEAD_MULTIDISCRETE)
         RLPPO_CHECK_ARG(n_out == 21 && a->act_dim == 8, "multi-discrete head: needs 21 outputs and act_dim 8");
 
-    hipStream_t st = (hipStream_t)stream;
+    const int slot = a->slot;
+    RLPPO_CHECK_ARG(slot >= 0 && slot < RLPPO_MAX_SLOTS, "ppo_minibatch: slot %d not in [0, %d)", slot, RLPPO_MAX_SLOTS);
+    rc = ensure_slot(slot);
+    if (rc) return rc;
+    hipStream_t caller = (hipStream_t)stream;
+    hipStream_t st = caller;
+    if (slot > 0) {  // this minibatch's chains run beside the caller's stream; rlppo_ppo_join() brings them back
+        st = g_main[slot];
+        rc = order_after(st, caller, g_ev_slot[slot]);
+        if (rc) return rc;
+        g_slot_pending[slot] = true;
+    }
     float *w = reinterpret_cast<float *>(a->workspace);
     float *pact[RLPPO_MAX_LAYERS], *vact[RLPPO_MAX_LAYERS];
     for (int l = 0; l < pol.n_layers; ++l) {
@@ -313,13 +347,27 @@ int rlppo_ppo_minibatch(void *stream, const rlppo_minibatch_args *a) {
         w += (size_t)mb * val.L[l].pout;
     }
     const int m = max_pout(pol) > max_pout(val) ? max_pout(pol) : max_pout(val);
-    float *d0 = w, *d1 = w + (size_t)mb * m;
+    float *d0 = w, *d1 = w + (size_t)mb * m, *d2 = w + 2 * (size_t)mb * m, *d3 = w + 3 * (size_t)mb * m;
 
     // forward of both nets; the minibatch gather (experience_buffer.py:82-87) is fused into the first layer's loads
-    rc = forward(st, val, a->val_packed, a->states, a->ld_states, a->idx, mb, 0, vact);
+    // The two networks are independent until the loss epilogue and again after it, so their launch chains run on
+    // two streams (the caller's + one library-owned side stream, forked/joined with events: capturable).  Each
+    // launch is only 50-100 us long at K <= 256, so letting one chain's kernels fill the CUs that the other chain's
+    // ramp-up / tail leaves idle is worth more than any single-kernel tweak.
+    hipStream_t side = st;
+    if (g_two_streams) {
+        side = g_side[slot];
+        rc = order_after(side, st, g_ev_fork[slot]);
+        if (rc) return rc;
+    }
+    rc = forward(side, val, a->val_packed, a->states, a->ld_states, a->idx, mb, 0, vact);
     if (rc) return rc;
     rc = forward(st, pol, a->pol_packed, a->states, a->ld_states, a->idx, mb, a->head == RLPPO_HEAD_GAUSSIAN, pact);
     if (rc) return rc;
+    if (side != st) {
+        rc = order_after(st, side, g_ev_join[slot]);
+        if (rc) return rc;
+    }
 
     // loss epilogue: outputs -> output gradients in place, report statistics accumulated on device
     LossCfg cfg;
@@ -348,9 +396,26 @@ int rlppo_ppo_minibatch(void *stream, const rlppo_minibatch_args *a) {
     }
     if (rc) return rc;
 
+    if (g_two_streams) {
+        rc = order_after(side, st, g_ev_fork[slot]);
+        if (rc) return rc;
+    }
+    rc = backward(side, val, a->val_packed, a->states, a->ld_states, a->idx, mb, vact, d2, d3, a->val_grad);
+    if (rc) return rc;
     rc = backward(st, pol, a->pol_packed, a->states, a->ld_states, a->idx, mb, pact, d0, d1, a->pol_grad);
     if (rc) return rc;
-    return backward(st, val, a->val_packed, a->states, a->ld_states, a->idx, mb, vact, d0, d1, a->val_grad);
+    if (side != st) rc = order_after(st, side, g_ev_join[slot]);
+    return rc;
+}
+
+int rlppo_ppo_join(void *stream) {
+    for (int s = 1; s < RLPPO_MAX_SLOTS; ++s)
+        if (g_slot_pending[s]) {
+            int rc = order_after((hipStream_t)stream, g_main[s], g_ev_slot[s]);
+            if (rc) return rc;
+            g_slot_pending[s] = false;
+        }
+    return 0;
 }
 
 int rlppo_clip_adam(void *stream, float *params, float *grads, float *exp_avg, float *exp_avg_sq, int64_t n,
@@ -375,8 +440,23 @@ int rlppo_dbg_set(int32_t key, int32_t value) {
         set_gae_algo(value);
         return 0;
     }
+    if (key == 2) {
+        set_tn_rows(value);
+        return 0;
+    }
+    if (key == 3) {
+        set_nt_ws(value);
+        return 0;
+    }
+    if (key == 4) {
+        g_two_streams = value;
+        return 0;
+    }
     set_error("dbg_set: unknown key %d", key);
     return RLPPO_ERR_ARG;
+}
+int rlppo_dbg_mfma_probe(void *stream, float *out, int32_t blocks, int32_t iters, uint64_t *clocks) {
+    return launch_mfma_probe((hipStream_t)stream, out, blocks, iters, (unsigned long long *)clocks);
 }
 int rlppo_dbg_gemm_nt(void *stream, const float *A, int64_t lda, const int64_t *row_idx, const float *B, int64_t ldb,
                       const float *bias, const float *mask_src, int64_t ld_mask, float *C, int64_t ldc, int64_t M,

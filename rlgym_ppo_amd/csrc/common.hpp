@@ -76,6 +76,9 @@ int launch_clip_adam(hipStream_t, float *p, float *g, float *m, float *v, int64_
                      float bc2_sqrt, float one_minus_beta1, float beta2, float one_minus_beta2, float eps, double *gnorm2);
 size_t gae_workspace_bytes(int64_t n);
 void set_gae_algo(int algo);
+void set_tn_rows(int rows);
+void set_nt_ws(int on);
+int launch_mfma_probe(hipStream_t st, float *out, int blocks, int iters, unsigned long long *clocks);
 int launch_gae(hipStream_t, const float *, const float *, const float *, const float *, int64_t, double, double, float,
                float *, float *, float *, void *, size_t);
 int launch_discrete_sample_logits(hipStream_t, const float *, int64_t, int64_t, int, const float *, int64_t *, float *, float *);

@@ -179,6 +179,193 @@ static int launch_nt_1(hipStream_t st, dim3 grid, int epi, const float *A, int64
     return RLPPO_ERR_ARG;
 }
 
+// --------------------------------------------------------------------------------- gemm_nt, weights-stationary
+// Second form of the same product for K <= 256 (every layer of the 256x3 nets): the whole B column tile
+// ([16*NB rows][K] fp32, <= 128 KB) is loaded into LDS ONCE per workgroup and stays there while the workgroup walks
+// over row tiles; every wave streams its own 32 A rows straight from global memory into MFMA fragments (one dwordx4
+// per 16x16 block and 16-deep k chunk, 4 chunks in flight), so the main loop has NO barrier and the 8 waves of a
+// workgroup drift apart instead of stalling together (the lock-step stalls of the staged kernel above cost ~35 % of
+// the MFMA pipe, profiles/r01_pmc_sq_v2.csv).  Row tiles are processed as one flattened (tile, k-chunk) pipeline so
+// the loads of the next tile are in flight while the current tile's epilogue stores drain.
+constexpr int WS_WAVES = 8;
+constexpr int WS_ROWS = WS_WAVES * 32;  // 256 rows per row tile
+constexpr int WS_DEPTH = 4;             // k chunks (16 floats) of A kept in flight per wave
+
+// Off by default: measured inside the whole update (tools/ab_update.py) the staged kernel is 5 % faster, because with
+// two kernels in flight (policy / critic chains) the staged form's 64 KB workgroups of both kernels share a CU, while
+// the stationary form's 128 KB workgroups cannot.  Kept selectable: rlppo_dbg_set(3, 1).
+static int g_nt_ws = 0;
+void set_nt_ws(int v) { g_nt_ws = v; }
+
+template <int NB, int EPI, bool GATHER>
+__global__ __launch_bounds__(512) void gemm_nt_ws_kernel(const float *__restrict__ A, int64_t lda,
+                                                          const int64_t *__restrict__ row_idx,
+                                                          const float *__restrict__ B, int64_t ldb,
+                                                          const float *__restrict__ bias,
+                                                          const float *__restrict__ mask_src, int64_t ld_mask,
+                                                          float *__restrict__ C, int64_t ldc, int64_t M, int K,
+                                                          int n_row_tiles) {
+    constexpr int BN = NB * 16;
+    __shared__ __attribute__((aligned(16))) float Bs[BN * 256];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int r16 = lane & 15, q = lane >> 4;
+    const int n0 = blockIdx.y * BN;
+    const int kch = K >> 2;                       // 16-byte chunks per B row
+    const int swm = (kch & 15) == 0 ? 15 : 7;     // XOR swizzle mask (K is a multiple of 32, so kch % 8 == 0)
+
+    // ---- stationary operand: B[n0 .. n0+BN)[0..K) -> LDS, chunk c of row r stored at chunk c ^ (r & swm)
+    // (indexing Bs in float4 units tells the compiler the accesses are 16-byte aligned: ds_read_b128 / ds_write_b128)
+    f32x4 *Bs4 = reinterpret_cast<f32x4 *>(Bs);
+    for (int base = tid; base < BN * kch; base += 512 * 8) {  // 8 independent loads in flight per thread
+        f32x4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int id = base + u * 512;
+            if (id < BN * kch) {
+                const int r = id / kch, c = id - r * kch;
+                v[u] = *reinterpret_cast<const f32x4 *>(B + (int64_t)(n0 + r) * ldb + c * 4);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int id = base + u * 512;
+            if (id < BN * kch) {
+                const int r = id / kch, c = id - r * kch;
+                Bs4[r * kch + (c ^ (r & swm))] = v[u];
+            }
+        }
+    }
+    __syncthreads();
+
+    const int nkc = K >> 4;                       // 16-float k chunks per tile
+    const int my_tiles = (n_row_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int total = my_tiles * nkc;             // flattened (tile, chunk) steps of this workgroup
+
+    // row pointers of the tile currently being LOADED (two 16-row blocks per wave)
+    auto tile_row = [&](int t_local, int i) -> int64_t {
+        int64_t m = ((int64_t)blockIdx.x + (int64_t)t_local * gridDim.x) * WS_ROWS + wave * 32 + i * 16 + r16;
+        return m < M ? m : M - 1;  // clamp: rows past M are computed but never stored
+    };
+    const float *pa[2];
+    int64_t nxt_src[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int64_t m = tile_row(0, i);
+        pa[i] = A + (GATHER ? row_idx[m] : m) * lda + q * 4;
+        nxt_src[i] = GATHER ? row_idx[tile_row(1 < my_tiles ? 1 : 0, i)] : 0;
+    }
+    int ld_tile = 0, ld_kc = 0;  // position of the next load in the flattened sequence
+
+    f32x4 ring[WS_DEPTH][2];
+    auto issue = [&](f32x4 (&dst)[2]) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) dst[i] = *reinterpret_cast<const f32x4 *>(pa[i] + ld_kc * 16);
+        if (++ld_kc == nkc) {  // advance to the next tile of this workgroup
+            ld_kc = 0;
+            ++ld_tile;
+            const int t = ld_tile < my_tiles ? ld_tile : my_tiles - 1;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int64_t m = tile_row(t, i);
+                pa[i] = A + (GATHER ? nxt_src[i] : m) * lda + q * 4;
+                if (GATHER) nxt_src[i] = row_idx[tile_row(t + 1 < my_tiles ? t + 1 : t, i)];
+            }
+        }
+    };
+#pragma unroll
+    for (int d = 0; d < WS_DEPTH; ++d) issue(ring[d]);  // loads past the end re-read the last tile (harmless)
+
+    f32x4 acc[2][NB];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    int cs_tile = 0, cs_kc = 0;  // position of the chunk being consumed
+    for (int step = 0; step < total; step += WS_DEPTH) {
+#pragma unroll
+        for (int u = 0; u < WS_DEPTH; ++u) {
+            if (step + u < total) {  // wave-uniform
+                f32x4 fa[2] = {ring[u][0], ring[u][1]};
+                issue(ring[u]);  // refill this ring slot with the chunk WS_DEPTH steps ahead
+                f32x4 fb[NB];
+                const int c = cs_kc * 4 + q;
+#pragma unroll
+                for (int j = 0; j < NB; ++j) {
+                    const int r = j * 16 + r16;
+                    fb[j] = Bs4[r * kch + (c ^ (r & swm))];
+                }
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < NB; ++j) acc[i][j] = MFMA16(fb[j][s], fa[i][s], acc[i][j]);
+                if (++cs_kc == nkc) {  // tile finished: epilogue, then fresh accumulators
+                    cs_kc = 0;
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        const int64_t m = ((int64_t)blockIdx.x + (int64_t)cs_tile * gridDim.x) * WS_ROWS + wave * 32 + i * 16 + r16;
+#pragma unroll
+                        for (int j = 0; j < NB; ++j) {
+                            const int n = n0 + j * 16 + q * 4;
+                            f32x4 v = acc[i][j];
+                            acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                            if (m < M) {
+                                if (EPI == EPI_MASK) {
+                                    const f32x4 h = *reinterpret_cast<const f32x4 *>(mask_src + m * ld_mask + n);
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e) v[e] = h[e] > 0.f ? v[e] : 0.f;
+                                } else {
+                                    const f32x4 bv = *reinterpret_cast<const f32x4 *>(bias + n);
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e) {
+                                        float x = v[e] + bv[e];
+                                        if (EPI == EPI_BIAS_RELU) x = x > 0.f ? x : 0.f;
+                                        if (EPI == EPI_BIAS_TANH) x = tanhf(x);
+                                        v[e] = x;
+                                    }
+                                }
+                                *reinterpret_cast<f32x4 *>(C + m * ldc + n) = v;
+                            }
+                        }
+                    }
+                    ++cs_tile;
+                }
+            }
+        }
+    }
+}
+
+template <int NB, int EPI>
+static int launch_ws_2(hipStream_t st, dim3 grid, const float *A, int64_t lda, const int64_t *row_idx, const float *B,
+                       int64_t ldb, const float *bias, const float *mask_src, int64_t ld_mask, float *C, int64_t ldc,
+                       int64_t M, int K, int n_row_tiles) {
+    if (row_idx)
+        hipLaunchKernelGGL((gemm_nt_ws_kernel<NB, EPI, true>), grid, dim3(512), 0, st, A, lda, row_idx, B, ldb, bias,
+                           mask_src, ld_mask, C, ldc, M, K, n_row_tiles);
+    else
+        hipLaunchKernelGGL((gemm_nt_ws_kernel<NB, EPI, false>), grid, dim3(512), 0, st, A, lda, row_idx, B, ldb, bias,
+                           mask_src, ld_mask, C, ldc, M, K, n_row_tiles);
+    RLPPO_LAUNCH_CHECK();
+    return 0;
+}
+
+template <int NB>
+static int launch_ws_1(hipStream_t st, dim3 grid, int epi, const float *A, int64_t lda, const int64_t *row_idx,
+                       const float *B, int64_t ldb, const float *bias, const float *mask_src, int64_t ld_mask, float *C,
+                       int64_t ldc, int64_t M, int K, int n_row_tiles) {
+    switch (epi) {
+        case EPI_BIAS: return launch_ws_2<NB, EPI_BIAS>(st, grid, A, lda, row_idx, B, ldb, bias, mask_src, ld_mask, C, ldc, M, K, n_row_tiles);
+        case EPI_BIAS_RELU: return launch_ws_2<NB, EPI_BIAS_RELU>(st, grid, A, lda, row_idx, B, ldb, bias, mask_src, ld_mask, C, ldc, M, K, n_row_tiles);
+        case EPI_BIAS_TANH: return launch_ws_2<NB, EPI_BIAS_TANH>(st, grid, A, lda, row_idx, B, ldb, bias, mask_src, ld_mask, C, ldc, M, K, n_row_tiles);
+        case EPI_MASK: return launch_ws_2<NB, EPI_MASK>(st, grid, A, lda, row_idx, B, ldb, bias, mask_src, ld_mask, C, ldc, M, K, n_row_tiles);
+    }
+    set_error("gemm_nt: bad epilogue %d", epi);
+    return RLPPO_ERR_ARG;
+}
+
 int launch_gemm_nt(hipStream_t st, const float *A, int64_t lda, const int64_t *row_idx, const float *B, int64_t ldb,
                    const float *bias, const float *mask_src, int64_t ld_mask, float *C, int64_t ldc, int64_t M, int N,
                    int K, int epi) {
@@ -198,6 +385,20 @@ int launch_gemm_nt(hipStream_t st, const float *A, int64_t lda, const int64_t *r
         set_error("gemm_nt: N=%d is not a padded output width", N);
         return RLPPO_ERR_ARG;
     }
+    if (g_nt_ws && K <= 256 && M >= 4 * WS_ROWS) {
+        // one workgroup per CU: grid.x * (column tiles) ~ number of CUs, each workgroup walks several row tiles
+        const int n_row_tiles = (int)cdiv(M, WS_ROWS);
+        const int col_tiles = N / (nb * 16);
+        int gx = 256 / col_tiles;
+        if (gx > n_row_tiles) gx = n_row_tiles;
+        dim3 wgrid((unsigned)gx, (unsigned)col_tiles);
+        switch (nb) {
+            case 8: return launch_ws_1<8>(st, wgrid, epi, A, lda, row_idx, B, ldb, bias, mask_src, ld_mask, C, ldc, M, K, n_row_tiles);
+            case 6: return launch_ws_1<6>(st, wgrid, epi, A, lda, row_idx, B, ldb, bias, mask_src, ld_mask, C, ldc, M, K, n_row_tiles);
+            case 4: return launch_ws_1<4>(st, wgrid, epi, A, lda, row_idx, B, ldb, bias, mask_src, ld_mask, C, ldc, M, K, n_row_tiles);
+            default: return launch_ws_1<2>(st, wgrid, epi, A, lda, row_idx, B, ldb, bias, mask_src, ld_mask, C, ldc, M, K, n_row_tiles);
+        }
+    }
     dim3 grid((unsigned)cdiv(M, BM), (unsigned)(N / (nb * 16)));
     switch (nb) {
         case 8: return launch_nt_1<8>(st, grid, epi, A, lda, row_idx, B, ldb, bias, mask_src, ld_mask, C, ldc, M, K);
@@ -208,16 +409,17 @@ int launch_gemm_nt(hipStream_t st, const float *A, int64_t lda, const int64_t *r
 }
 
 // ------------------------------------------------------------------------------------------------- gemm_tn
+static int g_tn_rows_override = 0;  // tuning: rlppo_dbg_set(2, rows)
+void set_tn_rows(int r) { g_tn_rows_override = r; }
 constexpr int TM = 32;        // sample rows per LDS stage
 constexpr int TLD = 128 + 16; // LDS row stride (floats): +16 puts rows m and m+1 on opposite bank halves (ds_read_b32)
-constexpr int ROWS_PER_WG = 1024;
 
 template <bool GATHER>
 __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const float *__restrict__ dY, int64_t ldy, int ny_valid,
                                                           const float *__restrict__ X, int64_t ldx,
                                                           const int64_t *__restrict__ row_idx, int kx_valid,
                                                           float *__restrict__ dW, float *__restrict__ db, int out,
-                                                          int in, int64_t M) {
+                                                          int in, int64_t M, int rows_per_wg) {
     __shared__ __attribute__((aligned(16))) float lds[2 * 2 * TM * TLD];
     float *Ys = lds;                 // [2][TM][TLD]
     float *Xs = lds + 2 * TM * TLD;  // [2][TM][TLD]
@@ -227,8 +429,8 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const float *__restrict
     const int r16 = lane & 15, q = lane >> 4;
     const int wn = wave >> 1, wk = wave & 1;
     const int n0 = blockIdx.x * 128, k0 = blockIdx.y * 128;
-    const int64_t mbeg = (int64_t)blockIdx.z * ROWS_PER_WG;
-    const int64_t mend = (mbeg + ROWS_PER_WG < M) ? mbeg + ROWS_PER_WG : M;
+    const int64_t mbeg = (int64_t)blockIdx.z * rows_per_wg;
+    const int64_t mend = (mbeg + rows_per_wg < M) ? mbeg + rows_per_wg : M;
     const int steps = (int)((mend - mbeg + TM - 1) / TM);
 
     // staging: chunk = tid & 31 (16 B of a 128-float row), rows (tid >> 5) + 8 i
@@ -241,7 +443,9 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const float *__restrict
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float bsum = 0.f;  // thread t < 128 of k-tile 0 accumulates the column sum for db[n0 + t]
+    // db: every thread keeps the column sums of the dY rows IT stages (4 columns), straight from the staging registers
+    f32x4 bs4 = f32x4{0.f, 0.f, 0.f, 0.f};
+    const bool want_db = db != nullptr && blockIdx.y == 0;
 
     f32x4 ry[4], rx[4];
     auto load_tile = [&](int step) {
@@ -264,6 +468,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const float *__restrict
         for (int i = 0; i < 4; ++i) {
             *reinterpret_cast<f32x4 *>(&Ys[(buf * TM + ld_row + 8 * i) * TLD + ld_chunk * 4]) = ry[i];
             *reinterpret_cast<f32x4 *>(&Xs[(buf * TM + ld_row + 8 * i) * TLD + ld_chunk * 4]) = rx[i];
+            if (want_db) bs4 += ry[i];
         }
     };
 
@@ -294,10 +499,6 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const float *__restrict
                     for (int j = 0; j < 4; ++j) acc[i][j] = MFMA16(fa[i], fb[j], acc[i][j]);
             }
         }
-        if (db != nullptr && blockIdx.y == 0 && tid < 128) {
-#pragma unroll 8
-            for (int m = 0; m < TM; ++m) bsum += Yc[m * TLD + tid];
-        }
         if (more) store_tile(cur ^ 1);
         __syncthreads();
     }
@@ -314,7 +515,17 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const float *__restrict
                 if (n < out && k < in) atomicAdd(dW + (int64_t)n * in + k, acc[i][j][e]);
             }
         }
-    if (db != nullptr && blockIdx.y == 0 && tid < 128 && (n0 + tid) < out) atomicAdd(db + n0 + tid, bsum);
+    if (want_db) {  // 8 threads (tid >> 5) hold partial sums of the same 4 columns: fold them through LDS
+        float *red = lds;  // [8][128]; the staging buffers are dead (the loop ended with a barrier)
+        *reinterpret_cast<f32x4 *>(&red[ld_row * 128 + ld_chunk * 4]) = bs4;
+        __syncthreads();
+        if (tid < 128 && (n0 + tid) < out) {
+            float sum = 0.f;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) sum += red[r * 128 + tid];
+            atomicAdd(db + n0 + tid, sum);
+        }
+    }
 }
 
 int launch_gemm_tn(hipStream_t st, const float *dY, int64_t ldy, int ny_valid, const float *X, int64_t ldx,
@@ -324,15 +535,66 @@ int launch_gemm_tn(hipStream_t st, const float *dY, int64_t ldy, int ny_valid, c
                         kx_valid <= ldx && out <= ny_valid && in <= kx_valid,
                     "gemm_tn: bad shapes ny=%d kx=%d ldy=%ld ldx=%ld out=%d in=%d", ny_valid, kx_valid, (long)ldy,
                     (long)ldx, out, in);
-    dim3 grid((unsigned)cdiv(out, 128), (unsigned)cdiv(in, 128), (unsigned)cdiv(M, ROWS_PER_WG));
+    // Split over the sample axis.  Measured on MI355X at M = 65,536 (tools/sweep_tn.py, us per launch):
+    //   rows/WG      128    256    512   1024   2048
+    //   256x256     157.5  123.9  103.0  104.6  197.5      few splits -> idle CUs; many splits -> fp32 atomic traffic
+    //   256x107     159.2  110.4  103.6  149.6  265.2
+    //   90x256       83.6   62.8   62.7   98.7  187.6
+    //   1x256        48.6   44.6   52.7   95.7  188.3
+    const int64_t tiles = cdiv(out, 128) * cdiv(in, 128);
+    int64_t rows = tiles >= 2 ? 512 : 256;
+    if (M < 64 * rows) rows = round_up(cdiv(M, 64) > 32 ? cdiv(M, 64) : 32, TM);  // small M: still use the chip
+    if (g_tn_rows_override > 0) rows = g_tn_rows_override;
+    const int rows_per_wg = (int)rows;
+    dim3 grid((unsigned)cdiv(out, 128), (unsigned)cdiv(in, 128), (unsigned)cdiv(M, rows_per_wg));
     if (row_idx)
         hipLaunchKernelGGL((gemm_tn_kernel<true>), grid, dim3(256), 0, st, dY, ldy, ny_valid, X, ldx, row_idx, kx_valid,
-                           dW, db, out, in, M);
+                           dW, db, out, in, M, rows_per_wg);
     else
         hipLaunchKernelGGL((gemm_tn_kernel<false>), grid, dim3(256), 0, st, dY, ldy, ny_valid, X, ldx, row_idx, kx_valid,
-                           dW, db, out, in, M);
+                           dW, db, out, in, M, rows_per_wg);
     RLPPO_LAUNCH_CHECK();
     return 0;
 }
 
+}  // namespace rlppo
+
+// ------------------------------------------------------------------------------------------ MFMA ceiling probe
+// Register-only loop of v_mfma_f32_16x16x4_f32 on 16 independent accumulators (the instruction mix of the GEMM inner
+// loops without any memory traffic): measures what the chip sustains on THIS box (clock under load included), so
+// that roofline fractions can also be read against an achievable ceiling.  Diagnostic entry point only.
+namespace rlppo {
+__global__ __launch_bounds__(256) void mfma_probe_kernel(float *out, int iters, unsigned long long *clocks) {
+    f32x4 acc[16];
+    float a[4], b[4];
+    const float seed = (float)(threadIdx.x % 37) * 0.03125f - 0.5f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = f32x4{seed, -seed, 0.5f * seed, 0.25f};
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        a[s] = seed * (float)(s + 1) * 0.37f + 0.01f;
+        b[s] = 0.91f - seed * (float)(s + 1) * 0.11f;
+    }
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[i] = MFMA16(a[s], b[(s + i) & 3], acc[i]);
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) sum += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    out[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = sum;
+    if (threadIdx.x == 0 && clocks) {
+        clocks[2 * blockIdx.x] = t1 - t0;      // shader cycles
+        clocks[2 * blockIdx.x + 1] = r1 - r0;  // 100 MHz ticks
+    }
+}
+int launch_mfma_probe(hipStream_t st, float *out, int blocks, int iters, unsigned long long *clocks) {
+    hipLaunchKernelGGL(mfma_probe_kernel, dim3(blocks), dim3(256), 0, st, out, iters, clocks);
+    RLPPO_LAUNCH_CHECK();
+    return 0;
+}
 }  // namespace rlppo

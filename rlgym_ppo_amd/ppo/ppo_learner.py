@@ -148,6 +148,7 @@ class PPOLearner(object):
         va.bind()
         self._stats = torch.zeros(N.N_STATS, dtype=torch.float64, device=self._dev)
         self._ws = Workspace(self._dev)
+        self.n_slots = int(os.environ.get("RLPPO_SLOTS", 4))  # minibatches of a batch kept in flight concurrently
         self._idx_bufs = None
 
     # --------------------------------------------------------------------------------------------- learn
@@ -191,9 +192,12 @@ class PPOLearner(object):
         if self.policy_type == 2:
             a.var_m, a.var_b = float(self.policy.affine_map.m), float(self.policy.affine_map.b)
         a.stats = self._stats.data_ptr()
-        nbytes = N.lib().rlppo_minibatch_workspace_bytes(pa.dims_c, pa.n_layers, va.dims_c, va.n_layers, self.mini_batch_size)
-        ws = self._ws.get(nbytes)
-        a.workspace, a.ws_bytes = ws.data_ptr(), ws.numel()
+        # one activation workspace per slot: minibatches in different slots overlap on the GPU (rlppo_ppo_join)
+        nbytes = int(N.lib().rlppo_minibatch_workspace_bytes(pa.dims_c, pa.n_layers, va.dims_c, va.n_layers, self.mini_batch_size))
+        nbytes = (nbytes + 255) // 256 * 256
+        ws = self._ws.get(nbytes * self.n_slots)
+        self._slot_ws = [ws.data_ptr() + i * nbytes for i in range(self.n_slots)]
+        a.workspace, a.ws_bytes = self._slot_ws[0], nbytes
         return a
 
     def learn(self, exp):
@@ -226,11 +230,14 @@ class PPOLearner(object):
                     self._grad_all.zero_()
                     pa.ensure_packed()
                     va.ensure_packed()
-                    for j in slices_for_rank(n_slices, rank, world):
+                    for k, j in enumerate(slices_for_rank(n_slices, rank, world)):
+                        args.slot = k % self.n_slots
+                        args.workspace = self._slot_ws[args.slot]
                         off = b * B + j * MB
                         args.idx = idx_dev.data_ptr() + 8 * off
                         args.mb = MB
                         N.check(L.rlppo_ppo_minibatch(st, ctypes.byref(args)))
+                    N.check(L.rlppo_ppo_join(st))
                     n_minibatch_iterations += n_slices
                     if dist is not None:
                         all_reduce_sum(self._grad_all, dist)  # RCCL over xGMI, before clipping

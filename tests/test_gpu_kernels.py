@@ -47,6 +47,9 @@ def check(L, rc):
 @pytest.mark.parametrize("M,N,K,epi,gather", [
     (128, 128, 32, 0, False), (300, 256, 128, 1, False), (1000, 96, 256, 0, True), (77, 32, 256, 2, False),
     (513, 64, 64, 1, True), (256, 256, 96, 3, False), (4096, 256, 256, 3, False), (5, 128, 128, 1, False),
+    # M >= 1024 and K <= 256 take the weights-stationary kernel (persistent row tiles, ragged last tile, gather)
+    (5000, 256, 128, 1, True), (3000, 96, 256, 0, False), (2048, 32, 256, 0, False), (1500, 256, 96, 3, False),
+    (1100, 256, 32, 3, False), (70000, 256, 256, 1, False), (66000, 128, 64, 2, True), (1024, 64, 256, 1, False),
 ])
 def test_gemm_nt(L, M, N, K, epi, gather):
     g = torch.Generator().manual_seed(M + N + K)

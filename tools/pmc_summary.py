@@ -1,0 +1,19 @@
+"""Condenses rocprofv3 --pmc counter_collection CSVs into one small per-kernel table (mean per dispatch)."""
+import csv
+import glob
+import sys
+from collections import defaultdict
+
+out = defaultdict(lambda: defaultdict(list))
+for path in glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True):
+    for row in csv.DictReader(open(path)):
+        name = row["Kernel_Name"]
+        name = name[:name.index("(")] if "(" in name else name
+        if not name.startswith(("void rlppo", "rlppo")):
+            continue
+        out[name.replace("void ", "")][row["Counter_Name"]].append(float(row["Counter_Value"]))
+counters = sorted({c for k in out.values() for c in k})
+print("kernel," + ",".join(counters) + ",dispatches")
+for k in sorted(out):
+    n = max(len(v) for v in out[k].values())
+    print(k + "," + ",".join("%.6g" % (sum(out[k][c]) / len(out[k][c])) if out[k][c] else "" for c in counters) + f",{n}")

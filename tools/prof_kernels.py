@@ -1,0 +1,43 @@
+"""Runs every kernel flavour of one cfg2 minibatch + the GAE scan a few times (for rocprofv3 --pmc / --kernel-trace)."""
+import ctypes
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from rlgym_ppo_amd import _native as N  # noqa: E402
+from rlgym_ppo_amd.util import torch_functions  # noqa: E402
+
+L = N.lib()
+M = 65536
+st = lambda: ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+P = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
+dev = "cuda"
+A128, A256, A96, A32 = (torch.randn(M, k, device=dev) for k in (128, 256, 96, 32))
+W = torch.randn(256, 256, device=dev) * 0.05
+bias = torch.zeros(256, device=dev)
+C256, C96, C32 = (torch.empty(M, k, device=dev) for k in (256, 96, 32))
+idx = torch.randperm(M, device=dev)
+dW = torch.zeros(256 * 256, device=dev)
+db = torch.zeros(256, device=dev)
+reps = int(os.environ.get("REPS", 3))
+for _ in range(reps):
+    N.check(L.rlppo_dbg_gemm_nt(st(), P(A128), 128, P(idx), P(W), 128, P(bias), None, 0, P(C256), 256, M, 256, 128, 1))
+    N.check(L.rlppo_dbg_gemm_nt(st(), P(A256), 256, None, P(W), 256, P(bias), None, 0, P(C256), 256, M, 256, 256, 1))
+    N.check(L.rlppo_dbg_gemm_nt(st(), P(A256), 256, None, P(W), 256, P(bias), None, 0, P(C96), 96, M, 96, 256, 0))
+    N.check(L.rlppo_dbg_gemm_nt(st(), P(A256), 256, None, P(W), 256, None, P(A256), 256, P(C256), 256, M, 256, 256, 3))
+    N.check(L.rlppo_dbg_gemm_tn(st(), P(A256), 256, 256, P(A256), 256, None, 256, P(dW), P(db), 256, 256, M))
+    N.check(L.rlppo_dbg_gemm_tn(st(), P(A256), 256, 256, P(A128), 128, P(idx), 128, P(dW), P(db), 256, 107, M))
+    N.check(L.rlppo_dbg_gemm_tn(st(), P(A96), 96, 96, P(A256), 256, None, 256, P(dW), P(db), 90, 256, M))
+rs = np.random.RandomState(0)
+n = 8192 * 256
+d = lambda x: torch.as_tensor(x).cuda()
+R, V = d(rs.randn(n).astype(np.float32)), d(rs.randn(n + 1).astype(np.float32))
+D = d((rs.rand(n) < 0.005).astype(np.float32))
+T = torch.zeros(n, device="cuda")
+T[255::256] = 1
+for _ in range(reps * 3):
+    torch_functions.gae_device(R, D, T, V, 0.99, 0.95, 1.7)
+torch.cuda.synchronize()
