@@ -452,6 +452,10 @@ int rlppo_dbg_set(int32_t key, int32_t value) {
         g_two_streams = value;
         return 0;
     }
+    if (key == 5) {
+        set_nt_bk(value);
+        return 0;
+    }
     set_error("dbg_set: unknown key %d", key);
     return RLPPO_ERR_ARG;
 }

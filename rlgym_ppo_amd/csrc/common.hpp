@@ -78,6 +78,7 @@ size_t gae_workspace_bytes(int64_t n);
 void set_gae_algo(int algo);
 void set_tn_rows(int rows);
 void set_nt_ws(int on);
+void set_nt_bk(int bk);
 int launch_mfma_probe(hipStream_t st, float *out, int blocks, int iters, unsigned long long *clocks);
 int launch_gae(hipStream_t, const float *, const float *, const float *, const float *, int64_t, double, double, float,
                float *, float *, float *, void *, size_t);

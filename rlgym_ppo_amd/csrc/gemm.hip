@@ -26,24 +26,34 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
 constexpr int BM = 128;  // rows per workgroup (gemm_nt)
-constexpr int BK = 32;   // K step (floats) = 8 chunks of 16 B per LDS row
 
-// LDS tile of R rows x 32 floats, 16-byte chunks XOR-swizzled by (row & 7): ds_read_b128 fragment reads
-// (16 rows x 4 chunks per instruction) then touch 16 distinct 16-B slots -> conflict free.
-__device__ __forceinline__ int swz(int row, int chunk) { return row * BK + ((chunk ^ (row & 7)) << 2); }
+// LDS tile of R rows x BKT floats in 16-byte chunks, XOR-swizzled so that a ds_read_b128 fragment read (16 rows x
+// 4 chunk columns per instruction, issued to four 16-lane groups) touches 16 distinct 16-byte slots of the 256-byte
+// bank row -> conflict free (checked with SQ_LDS_BANK_CONFLICT = 0, profiles/r01_pmc_sq_v2.csv).
+//   BKT = 32: 8 chunks per row,  chunk ^ (row & 7)
+//   BKT = 16: 4 chunks per row,  chunk ^ ((-(row >> 2)) & 3)
+template <int BKT>
+__device__ __forceinline__ int swz(int row, int chunk) {
+    if (BKT == 32) return row * 32 + ((chunk ^ (row & 7)) << 2);
+    return row * 16 + ((chunk ^ ((0 - (row >> 2)) & 3)) << 2);
+}
 
-template <int NB, int EPI, bool GATHER>
-__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const float *__restrict__ A, int64_t lda,
+template <int NB, int EPI, bool GATHER, int BKT>
+__global__ __launch_bounds__(256, BKT == 16 ? 3 : 2) void gemm_nt_kernel(const float *__restrict__ A, int64_t lda,
                                                           const int64_t *__restrict__ row_idx,
                                                           const float *__restrict__ B, int64_t ldb,
                                                           const float *__restrict__ bias,
                                                           const float *__restrict__ mask_src, int64_t ld_mask,
                                                           float *__restrict__ C, int64_t ldc, int64_t M, int K) {
     constexpr int BN = NB * 16;
-    constexpr int B_ITERS = BN / 32;  // rows of the B tile each thread stages (32 rows per pass)
-    __shared__ __attribute__((aligned(16))) float lds[2 * BM * BK + 2 * BN * BK];
+    constexpr int CPR = BKT / 4;          // 16-byte chunks per staged row
+    constexpr int RPP = 256 / CPR;        // rows staged per pass of the 256 threads
+    constexpr int A_ITERS = BM / RPP;
+    constexpr int B_ITERS = BN / RPP;
+    static_assert(BN % RPP == 0, "column tile must be a whole number of staging passes");
+    __shared__ __attribute__((aligned(16))) float lds[2 * BM * BKT + 2 * BN * BKT];
     float *As = lds;
-    float *Bs = lds + 2 * BM * BK;
+    float *Bs = lds + 2 * BM * BKT;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -51,12 +61,12 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const float *__restrict
     const int64_t m0 = (int64_t)blockIdx.x * BM;
     const int n0 = blockIdx.y * BN;
 
-    // staging assignment: chunk = tid & 7 (16 B), rows (tid >> 3) + 32 * i
-    const int ld_chunk = tid & 7, ld_row = tid >> 3;
-    const float *a_ptr[4];
+    // staging assignment: chunk = tid % CPR (16 B), rows tid / CPR + RPP * i
+    const int ld_chunk = tid % CPR, ld_row = tid / CPR;
+    const float *a_ptr[A_ITERS];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        int64_t m = m0 + ld_row + 32 * i;
+    for (int i = 0; i < A_ITERS; ++i) {
+        int64_t m = m0 + ld_row + RPP * i;
         if (m >= M) m = M - 1;  // clamp: rows past M are computed but never stored
         int64_t src = GATHER ? row_idx[m] : m;
         a_ptr[i] = A + src * lda + ld_chunk * 4;
@@ -69,40 +79,40 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const float *__restrict
 #pragma unroll
         for (int j = 0; j < NB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    f32x4 ra[4], rb[B_ITERS];
-    const int nk = K / BK;
+    f32x4 ra[A_ITERS], rb[B_ITERS];
+    const int nk = K / BKT;
 
     // prologue: tile 0 -> LDS buffer 0
 #pragma unroll
-    for (int i = 0; i < 4; ++i) ra[i] = *reinterpret_cast<const f32x4 *>(a_ptr[i]);
+    for (int i = 0; i < A_ITERS; ++i) ra[i] = *reinterpret_cast<const f32x4 *>(a_ptr[i]);
 #pragma unroll
-    for (int i = 0; i < B_ITERS; ++i) rb[i] = *reinterpret_cast<const f32x4 *>(b_ptr + (int64_t)(32 * i) * ldb);
+    for (int i = 0; i < B_ITERS; ++i) rb[i] = *reinterpret_cast<const f32x4 *>(b_ptr + (int64_t)(RPP * i) * ldb);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4 *>(&As[swz(ld_row + 32 * i, ld_chunk)]) = ra[i];
+    for (int i = 0; i < A_ITERS; ++i) *reinterpret_cast<f32x4 *>(&As[swz<BKT>(ld_row + RPP * i, ld_chunk)]) = ra[i];
 #pragma unroll
-    for (int i = 0; i < B_ITERS; ++i) *reinterpret_cast<f32x4 *>(&Bs[swz(ld_row + 32 * i, ld_chunk)]) = rb[i];
+    for (int i = 0; i < B_ITERS; ++i) *reinterpret_cast<f32x4 *>(&Bs[swz<BKT>(ld_row + RPP * i, ld_chunk)]) = rb[i];
     __syncthreads();
 
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
         const bool more = (kt + 1) < nk;
         if (more) {
-            const int koff = (kt + 1) * BK;
+            const int koff = (kt + 1) * BKT;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) ra[i] = *reinterpret_cast<const f32x4 *>(a_ptr[i] + koff);
+            for (int i = 0; i < A_ITERS; ++i) ra[i] = *reinterpret_cast<const f32x4 *>(a_ptr[i] + koff);
 #pragma unroll
             for (int i = 0; i < B_ITERS; ++i)
-                rb[i] = *reinterpret_cast<const f32x4 *>(b_ptr + (int64_t)(32 * i) * ldb + koff);
+                rb[i] = *reinterpret_cast<const f32x4 *>(b_ptr + (int64_t)(RPP * i) * ldb + koff);
         }
-        const float *Ac = As + cur * BM * BK + (wave * 32) * BK;
-        const float *Bc = Bs + cur * BN * BK;
+        const float *Ac = As + cur * BM * BKT + (wave * 32) * BKT;
+        const float *Bc = Bs + cur * BN * BKT;
 #pragma unroll
-        for (int kc = 0; kc < 2; ++kc) {
+        for (int kc = 0; kc < BKT / 16; ++kc) {
             f32x4 fa[2], fb[NB];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) fa[i] = *reinterpret_cast<const f32x4 *>(&Ac[swz(i * 16 + r16, kc * 4 + q)]);
+            for (int i = 0; i < 2; ++i) fa[i] = *reinterpret_cast<const f32x4 *>(&Ac[swz<BKT>(i * 16 + r16, kc * 4 + q)]);
 #pragma unroll
-            for (int j = 0; j < NB; ++j) fb[j] = *reinterpret_cast<const f32x4 *>(&Bc[swz(j * 16 + r16, kc * 4 + q)]);
+            for (int j = 0; j < NB; ++j) fb[j] = *reinterpret_cast<const f32x4 *>(&Bc[swz<BKT>(j * 16 + r16, kc * 4 + q)]);
 #pragma unroll
             for (int s = 0; s < 4; ++s)
 #pragma unroll
@@ -113,12 +123,12 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const float *__restrict
                         acc[i][j] = MFMA16(fb[j][s], fa[i][s], acc[i][j]);
         }
         if (more) {
-            float *An = As + (cur ^ 1) * BM * BK;
-            float *Bn = Bs + (cur ^ 1) * BN * BK;
+            float *An = As + (cur ^ 1) * BM * BKT;
+            float *Bn = Bs + (cur ^ 1) * BN * BKT;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4 *>(&An[swz(ld_row + 32 * i, ld_chunk)]) = ra[i];
+            for (int i = 0; i < A_ITERS; ++i) *reinterpret_cast<f32x4 *>(&An[swz<BKT>(ld_row + RPP * i, ld_chunk)]) = ra[i];
 #pragma unroll
-            for (int i = 0; i < B_ITERS; ++i) *reinterpret_cast<f32x4 *>(&Bn[swz(ld_row + 32 * i, ld_chunk)]) = rb[i];
+            for (int i = 0; i < B_ITERS; ++i) *reinterpret_cast<f32x4 *>(&Bn[swz<BKT>(ld_row + RPP * i, ld_chunk)]) = rb[i];
         }
         __syncthreads();
     }
@@ -151,15 +161,26 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const float *__restrict
     }
 }
 
+static int g_nt_bk = 32;  // tuning: rlppo_dbg_set(5, 16 | 32): K step of the staged kernel
+void set_nt_bk(int v) { g_nt_bk = v; }
+
 template <int NB, int EPI>
 static int launch_nt_2(hipStream_t st, dim3 grid, const float *A, int64_t lda, const int64_t *row_idx, const float *B,
                        int64_t ldb, const float *bias, const float *mask_src, int64_t ld_mask, float *C, int64_t ldc,
                        int64_t M, int K) {
-    if (row_idx)
-        hipLaunchKernelGGL((gemm_nt_kernel<NB, EPI, true>), grid, dim3(256), 0, st, A, lda, row_idx, B, ldb, bias,
+    constexpr bool can16 = (NB * 16) % 64 == 0;  // BK=16 stages 64 rows per pass
+    if (can16 && g_nt_bk == 16) {
+        if (row_idx)
+            hipLaunchKernelGGL((gemm_nt_kernel<NB, EPI, true, can16 ? 16 : 32>), grid, dim3(256), 0, st, A, lda, row_idx, B,
+                               ldb, bias, mask_src, ld_mask, C, ldc, M, K);
+        else
+            hipLaunchKernelGGL((gemm_nt_kernel<NB, EPI, false, can16 ? 16 : 32>), grid, dim3(256), 0, st, A, lda, row_idx,
+                               B, ldb, bias, mask_src, ld_mask, C, ldc, M, K);
+    } else if (row_idx)
+        hipLaunchKernelGGL((gemm_nt_kernel<NB, EPI, true, 32>), grid, dim3(256), 0, st, A, lda, row_idx, B, ldb, bias,
                            mask_src, ld_mask, C, ldc, M, K);
     else
-        hipLaunchKernelGGL((gemm_nt_kernel<NB, EPI, false>), grid, dim3(256), 0, st, A, lda, row_idx, B, ldb, bias,
+        hipLaunchKernelGGL((gemm_nt_kernel<NB, EPI, false, 32>), grid, dim3(256), 0, st, A, lda, row_idx, B, ldb, bias,
                            mask_src, ld_mask, C, ldc, M, K);
     RLPPO_LAUNCH_CHECK();
     return 0;
@@ -370,7 +391,7 @@ int launch_gemm_nt(hipStream_t st, const float *A, int64_t lda, const int64_t *r
                    const float *bias, const float *mask_src, int64_t ld_mask, float *C, int64_t ldc, int64_t M, int N,
                    int K, int epi) {
     if (M <= 0) return 0;
-    RLPPO_CHECK_ARG(K > 0 && K % BK == 0, "gemm_nt: K=%d must be a positive multiple of %d", K, BK);
+    RLPPO_CHECK_ARG(K > 0 && K % 32 == 0, "gemm_nt: K=%d must be a positive multiple of 32", K);
     RLPPO_CHECK_ARG(lda % 4 == 0 && ldb % 4 == 0 && ldc % 4 == 0 && lda >= K && ldb >= K && ldc >= N,
                     "gemm_nt: leading dimensions lda=%ld ldb=%ld ldc=%ld incompatible with K=%d N=%d", (long)lda,
                     (long)ldb, (long)ldc, K, N);
@@ -448,6 +469,16 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const float *__restrict
     const bool want_db = db != nullptr && blockIdx.y == 0;
 
     f32x4 ry[4], rx[4];
+    // gathered X rows: the row indices of stage st+2 are fetched while the data of stage st+1 is in flight, so the
+    // dependent index -> address -> data chain costs one memory latency per stage instead of two
+    int64_t src_next[4];
+    auto load_idx = [&](int step) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int64_t m = mbeg + (int64_t)step * TM + ld_row + 8 * i;
+            src_next[i] = (GATHER && m < mend) ? row_idx[m] : 0;
+        }
+    };
     auto load_tile = [&](int step) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -455,13 +486,10 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const float *__restrict
             const bool ok = m < mend;
             f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
             ry[i] = (ok && y_col_ok) ? *reinterpret_cast<const f32x4 *>(dY + m * ldy + n0 + ld_chunk * 4) : z;
-            if (ok && x_col_ok) {
-                const int64_t src = GATHER ? row_idx[m] : m;
-                rx[i] = *reinterpret_cast<const f32x4 *>(X + src * ldx + k0 + ld_chunk * 4);
-            } else {
-                rx[i] = z;
-            }
+            const int64_t src = GATHER ? src_next[i] : m;
+            rx[i] = (ok && x_col_ok) ? *reinterpret_cast<const f32x4 *>(X + src * ldx + k0 + ld_chunk * 4) : z;
         }
+        if (GATHER) load_idx(step + 1);
     };
     auto store_tile = [&](int buf) {
 #pragma unroll
@@ -473,6 +501,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const float *__restrict
     };
 
     if (steps > 0) {
+        load_idx(0);
         load_tile(0);
         store_tile(0);
     }

@@ -8,7 +8,7 @@ L = N.lib()
 with contextlib.redirect_stdout(sys.stderr):
     learner, buf = bench.build_workload("cuda:0")
 learner.n_epochs = 3
-configs = {"slots=1": (1, ((3, 0), (4, 1))), "slots=2": (2, ((3, 0), (4, 1))), "slots=4": (4, ((3, 0), (4, 1))), "slots=8": (8, ((3, 0), (4, 1))), "slots=4 ws=1": (4, ((3, 1), (4, 1))), "slots=1 streams=1": (1, ((3, 0), (4, 0)))}
+configs = {"bk32": (1, ((3, 0), (4, 1), (5, 32))), "bk16": (1, ((3, 0), (4, 1), (5, 16))), "bk16 slots=4": (4, ((3, 0), (4, 1), (5, 16))), "ws": (1, ((3, 1), (4, 1), (5, 32)))}
 res = {k: [] for k in configs}
 learner.learn(buf)
 for rnd in range(3):
