@@ -260,12 +260,20 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", 1))
     if world != args.gpus:
         log(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}; using WORLD_SIZE")
+    # RLPPO_BENCH_DRYRUN=1: exercise the N > 1 code path on a single-GPU box (all ranks on cuda:0, gloo); numbers from
+    # such a run are meaningless and are tagged as such.  The driver's real runs use one rank per GPU over RCCL.
+    dryrun = os.environ.get("RLPPO_BENCH_DRYRUN") == "1"
+    if dryrun:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = f"cuda:{local_rank}"
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(device))
+        if dryrun:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(device))
 
     import contextlib
     with contextlib.redirect_stdout(sys.stderr):
@@ -295,7 +303,8 @@ def main():
     out = {
         "metric": "ppo_update_samples_per_sec", "value": round(value, 1), "unit": "samples/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
-        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+        "data": "synthetic" + (" (DRY RUN: all ranks on one GPU over gloo, not a measurement)" if dryrun else ""),
         "config": {"workload": "BASELINE configs[1]: 4096 agents x 128 steps = 524,288-sample buffer, obs 107 f32, "
                                "90 discrete actions, 256x3 policy + 256x3 critic; ppo_batch 524,288, minibatch 65,536",
                    "epochs_per_step": args.epochs, "samples_per_step": args.epochs * BATCH,

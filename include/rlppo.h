@@ -202,6 +202,9 @@ int rlppo_mt19937_permutation(uint32_t *state625, int64_t n, int64_t *out);
 /* Tuning switches for A/B measurements.  key 1: GAE algorithm (1 = single-pass look-back, default; 0 = two launches). */
 int rlppo_dbg_set(int32_t key, int32_t value);
 /* Register-only fp32 MFMA loop: out[blocks*256] floats, clocks[2*blocks] = {shader cycles, 100 MHz ticks} per block. */
+/* GEMM inner-loop probe: 64 MFMAs per chunk + (mode&1) A fragments from LDS, (mode&2) B fragments from LDS, (mode&4) B
+ * fragments from a 256x256 fp32 matrix W in global memory.  out: blocks*threads floats. */
+int rlppo_dbg_probe2(void *stream, int32_t mode, int32_t threads, int32_t blocks, const float *W, float *out, int32_t chunks);
 int rlppo_dbg_mfma_probe(void *stream, float *out, int32_t blocks, int32_t iters, uint64_t *clocks);
 int rlppo_dbg_gemm_nt(void *stream, const float *A, int64_t lda, const int64_t *row_idx, const float *B, int64_t ldb,
                       const float *bias, const float *mask_src, int64_t ld_mask, float *C, int64_t ldc, int64_t M,

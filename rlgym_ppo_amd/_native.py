@@ -69,6 +69,7 @@ SIGNATURES = {
     "rlppo_mt19937_seed": (c_int32, [POINTER(c_uint32), c_uint32]),
     "rlppo_mt19937_permutation": (c_int32, [POINTER(c_uint32), c_int64, c_void_p]),
     "rlppo_dbg_set": (c_int32, [c_int32, c_int32]),
+    "rlppo_dbg_probe2": (c_int32, [c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_int32]),
     "rlppo_dbg_mfma_probe": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_void_p]),
     "rlppo_dbg_gemm_nt": (c_int32, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_void_p,
                                     c_int64, c_void_p, c_int64, c_int64, c_int32, c_int32, c_int32]),
@@ -94,6 +95,11 @@ def lib():
         v = L.rlppo_abi_version()
         if v != ABI_VERSION:
             raise NativeLibraryMissing(f"librlppo.so ABI {v} != expected {ABI_VERSION}: rebuild it")
+        # RLPPO_TUNE="key=value,key=value": tuning switches of rlppo_dbg_set (A/B measurements, profiling)
+        for item in filter(None, os.environ.get("RLPPO_TUNE", "").split(",")):
+            k, v = item.split("=")
+            if L.rlppo_dbg_set(int(k), int(v)) != 0:
+                raise RuntimeError(f"RLPPO_TUNE: bad switch {item}")
         _lib = L
     return _lib
 

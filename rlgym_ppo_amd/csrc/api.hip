@@ -66,6 +66,7 @@ static int max_pout(const NetLayout &net) {
 // ping-pong buffers, for training one buffer per layer (they are the saved activations of the backward pass).
 static int forward(hipStream_t st, const NetLayout &net, const float *packed, const float *obs, int64_t ld_obs,
                    const int64_t *row_idx, int64_t n, int out_tanh, float *const *acts) {
+    if (fused_eligible(net, n)) return launch_fused_forward(st, net, packed, obs, ld_obs, row_idx, n, out_tanh, acts);
     const float *x = obs;
     int64_t ldx = ld_obs;
     const int64_t *ridx = row_idx;
@@ -100,6 +101,8 @@ static int forward_pingpong(hipStream_t st, const NetLayout &net, const float *p
     float *acts[RLPPO_MAX_LAYERS];
     for (int l = 0; l < net.n_layers; ++l) acts[l] = (l & 1) ? b1 : b0;
     if (final_out) acts[net.n_layers - 1] = final_out;
+    if (fused_eligible(net, n))  // the fused chain keeps hidden activations on chip: nothing to store for inference
+        for (int l = 0; l + 1 < net.n_layers; ++l) acts[l] = nullptr;
     int rc = forward(st, net, packed, obs, ld_obs, nullptr, n, out_tanh, acts);
     if (rc) return rc;
     *out = acts[net.n_layers - 1];
@@ -262,7 +265,7 @@ static size_t train_ws_floats(const NetLayout &pol, const NetLayout &val, int64_
     for (int l = 0; l < pol.n_layers; ++l) per_row += pol.L[l].pout;
     for (int l = 0; l < val.n_layers; ++l) per_row += val.L[l].pout;
     int m = max_pout(pol) > max_pout(val) ? max_pout(pol) : max_pout(val);
-    per_row += 4 * (size_t)m;  // two ping-pong dX buffers per net (the two backward chains run concurrently)
+    per_row += (size_t)(pol.n_layers - 1 + val.n_layers - 1) * (size_t)m;  // one dX buffer per layer and net
     return per_row * (size_t)mb;
 }
 
@@ -275,23 +278,28 @@ size_t rlppo_minibatch_workspace_bytes(const int32_t *pol_dims, int32_t pol_laye
 
 // backward of one net: acts[l] = saved output of layer l, acts[last] holds dL/d(out) on entry
 static int backward(hipStream_t st, const NetLayout &net, const float *packed, const float *states, int64_t ld_states,
-                    const int64_t *idx, int64_t mb, float *const *acts, float *d0, float *d1, float *grad) {
+                    const int64_t *idx, int64_t mb, float *const *acts, float *const *dx, float *grad) {
+    // dx[l-1] receives dL/d(acts[l-1]) = dY of layer l-1 (one buffer per layer: the dW launches read them later)
     const int last = net.n_layers - 1;
-    const float *dY = acts[last];
+    const bool fused = fused_eligible(net, mb);
+    int rc;
+    if (fused) {  // whole dX chain in one launch (csrc/fused.hip), then the weight gradients
+        rc = launch_fused_backward(st, net, packed, mb, acts, dx);
+        if (rc) return rc;
+    }
     for (int l = last; l >= 0; --l) {
         const LayerLayout &L = net.L[l];
+        const float *dY = l == last ? acts[last] : dx[l];
         const float *X = l > 0 ? acts[l - 1] : states;
         const int64_t ldx = l > 0 ? net.L[l - 1].pout : ld_states;
-        int rc = launch_gemm_tn(st, dY, L.pout, L.pout, X, ldx, l > 0 ? nullptr : idx, L.pin, grad + L.off_flat_w,
-                                grad + L.off_flat_b, L.out, L.in, mb);
+        rc = launch_gemm_tn(st, dY, L.pout, L.pout, X, ldx, l > 0 ? nullptr : idx, L.pin, grad + L.off_flat_w,
+                            grad + L.off_flat_b, L.out, L.in, mb);
         if (rc) return rc;
-        if (l > 0) {
-            float *dX = ((last - l) & 1) ? d1 : d0;
+        if (l > 0 && !fused) {
             // dX[mb][pin] = (dY[mb][pout] . W[pout][pin]) masked by relu'(acts[l-1]); B operand = W^T [pin][pout]
-            rc = launch_gemm_nt(st, dY, L.pout, nullptr, packed + L.off_wt, L.pout, nullptr, acts[l - 1], L.pin, dX, L.pin, mb,
-                                L.pin, L.pout, EPI_MASK);
+            rc = launch_gemm_nt(st, dY, L.pout, nullptr, packed + L.off_wt, L.pout, nullptr, acts[l - 1], L.pin, dx[l - 1],
+                                L.pin, mb, L.pin, L.pout, EPI_MASK);
             if (rc) return rc;
-            dY = dX;
         }
     }
     return 0;
@@ -347,7 +355,15 @@ int rlppo_ppo_minibatch(void *stream, const rlppo_minibatch_args *a) {
         w += (size_t)mb * val.L[l].pout;
     }
     const int m = max_pout(pol) > max_pout(val) ? max_pout(pol) : max_pout(val);
-    float *d0 = w, *d1 = w + (size_t)mb * m, *d2 = w + 2 * (size_t)mb * m, *d3 = w + 3 * (size_t)mb * m;
+    float *pdx[RLPPO_MAX_LAYERS], *vdx[RLPPO_MAX_LAYERS];
+    for (int l = 0; l + 1 < pol.n_layers; ++l) {
+        pdx[l] = w;
+        w += (size_t)mb * m;
+    }
+    for (int l = 0; l + 1 < val.n_layers; ++l) {
+        vdx[l] = w;
+        w += (size_t)mb * m;
+    }
 
     // forward of both nets; the minibatch gather (experience_buffer.py:82-87) is fused into the first layer's loads
     // The two networks are independent until the loss epilogue and again after it, so their launch chains run on
@@ -400,9 +416,9 @@ int rlppo_ppo_minibatch(void *stream, const rlppo_minibatch_args *a) {
         rc = order_after(side, st, g_ev_fork[slot]);
         if (rc) return rc;
     }
-    rc = backward(side, val, a->val_packed, a->states, a->ld_states, a->idx, mb, vact, d2, d3, a->val_grad);
+    rc = backward(side, val, a->val_packed, a->states, a->ld_states, a->idx, mb, vact, vdx, a->val_grad);
     if (rc) return rc;
-    rc = backward(st, pol, a->pol_packed, a->states, a->ld_states, a->idx, mb, pact, d0, d1, a->pol_grad);
+    rc = backward(st, pol, a->pol_packed, a->states, a->ld_states, a->idx, mb, pact, pdx, a->pol_grad);
     if (rc) return rc;
     if (side != st) rc = order_after(st, side, g_ev_join[slot]);
     return rc;
@@ -456,8 +472,19 @@ int rlppo_dbg_set(int32_t key, int32_t value) {
         set_nt_bk(value);
         return 0;
     }
+    if (key == 6) {
+        set_fused(value);
+        return 0;
+    }
+    if (key == 7) {
+        set_nt_stagger(value);
+        return 0;
+    }
     set_error("dbg_set: unknown key %d", key);
     return RLPPO_ERR_ARG;
+}
+int rlppo_dbg_probe2(void *stream, int32_t mode, int32_t threads, int32_t blocks, const float *W, float *out, int32_t chunks) {
+    return launch_probe2((hipStream_t)stream, mode, threads, blocks, W, out, chunks);
 }
 int rlppo_dbg_mfma_probe(void *stream, float *out, int32_t blocks, int32_t iters, uint64_t *clocks) {
     return launch_mfma_probe((hipStream_t)stream, out, blocks, iters, (unsigned long long *)clocks);

@@ -79,6 +79,14 @@ void set_gae_algo(int algo);
 void set_tn_rows(int rows);
 void set_nt_ws(int on);
 void set_nt_bk(int bk);
+void set_fused(int on);
+void set_nt_stagger(int sleep_units);
+int launch_probe2(hipStream_t st, int mode, int threads, int blocks, const float *W, float *out, int chunks);
+bool fused_eligible(const NetLayout &net, int64_t mb);
+int launch_fused_forward(hipStream_t st, const NetLayout &net, const float *packed, const float *obs, int64_t ld_obs,
+                         const int64_t *idx, int64_t mb, int out_tanh, float *const *acts);
+int launch_fused_backward(hipStream_t st, const NetLayout &net, const float *packed, int64_t mb, float *const *acts,
+                          float *const *dx);
 int launch_mfma_probe(hipStream_t st, float *out, int blocks, int iters, unsigned long long *clocks);
 int launch_gae(hipStream_t, const float *, const float *, const float *, const float *, int64_t, double, double, float,
                float *, float *, float *, void *, size_t);

@@ -44,7 +44,8 @@ __global__ __launch_bounds__(256, BKT == 16 ? 3 : 2) void gemm_nt_kernel(const f
                                                           const float *__restrict__ B, int64_t ldb,
                                                           const float *__restrict__ bias,
                                                           const float *__restrict__ mask_src, int64_t ld_mask,
-                                                          float *__restrict__ C, int64_t ldc, int64_t M, int K) {
+                                                          float *__restrict__ C, int64_t ldc, int64_t M, int K,
+                                                          int stagger) {
     constexpr int BN = NB * 16;
     constexpr int CPR = BKT / 4;          // 16-byte chunks per staged row
     constexpr int RPP = 256 / CPR;        // rows staged per pass of the 256 threads
@@ -82,6 +83,12 @@ __global__ __launch_bounds__(256, BKT == 16 ? 3 : 2) void gemm_nt_kernel(const f
     f32x4 ra[A_ITERS], rb[B_ITERS];
     const int nk = K / BKT;
 
+    // Two workgroups share a CU and run identical code, so they reach their barrier / staging phases together and the
+    // MFMA pipe idles in those phases.  Delaying every second wave of workgroups (blocks 256..511, 768..1023, ...: the
+    // ones that land as the SECOND workgroup of a CU under the observed round-robin dispatch; speed only, never
+    // correctness) by about half a K step puts the pair out of phase for its whole life.
+    if (stagger > 0 && (((blockIdx.y * gridDim.x + blockIdx.x) >> 8) & 1))
+        for (int i = 0; i < stagger; ++i) __builtin_amdgcn_s_sleep(8);  // 8 x 64 cycles per unit
     // prologue: tile 0 -> LDS buffer 0
 #pragma unroll
     for (int i = 0; i < A_ITERS; ++i) ra[i] = *reinterpret_cast<const f32x4 *>(a_ptr[i]);
@@ -162,7 +169,9 @@ __global__ __launch_bounds__(256, BKT == 16 ? 3 : 2) void gemm_nt_kernel(const f
 }
 
 static int g_nt_bk = 32;  // tuning: rlppo_dbg_set(5, 16 | 32): K step of the staged kernel
+static int g_nt_stagger = 0;  // tuning: rlppo_dbg_set(7, units of 512 cycles)
 void set_nt_bk(int v) { g_nt_bk = v; }
+void set_nt_stagger(int v) { g_nt_stagger = v; }
 
 template <int NB, int EPI>
 static int launch_nt_2(hipStream_t st, dim3 grid, const float *A, int64_t lda, const int64_t *row_idx, const float *B,
@@ -172,16 +181,16 @@ static int launch_nt_2(hipStream_t st, dim3 grid, const float *A, int64_t lda, c
     if (can16 && g_nt_bk == 16) {
         if (row_idx)
             hipLaunchKernelGGL((gemm_nt_kernel<NB, EPI, true, can16 ? 16 : 32>), grid, dim3(256), 0, st, A, lda, row_idx, B,
-                               ldb, bias, mask_src, ld_mask, C, ldc, M, K);
+                               ldb, bias, mask_src, ld_mask, C, ldc, M, K, g_nt_stagger);
         else
             hipLaunchKernelGGL((gemm_nt_kernel<NB, EPI, false, can16 ? 16 : 32>), grid, dim3(256), 0, st, A, lda, row_idx,
-                               B, ldb, bias, mask_src, ld_mask, C, ldc, M, K);
+                               B, ldb, bias, mask_src, ld_mask, C, ldc, M, K, g_nt_stagger);
     } else if (row_idx)
         hipLaunchKernelGGL((gemm_nt_kernel<NB, EPI, true, 32>), grid, dim3(256), 0, st, A, lda, row_idx, B, ldb, bias,
-                           mask_src, ld_mask, C, ldc, M, K);
+                           mask_src, ld_mask, C, ldc, M, K, g_nt_stagger);
     else
         hipLaunchKernelGGL((gemm_nt_kernel<NB, EPI, false, 32>), grid, dim3(256), 0, st, A, lda, row_idx, B, ldb, bias,
-                           mask_src, ld_mask, C, ldc, M, K);
+                           mask_src, ld_mask, C, ldc, M, K, g_nt_stagger);
     RLPPO_LAUNCH_CHECK();
     return 0;
 }

@@ -148,7 +148,7 @@ class PPOLearner(object):
         va.bind()
         self._stats = torch.zeros(N.N_STATS, dtype=torch.float64, device=self._dev)
         self._ws = Workspace(self._dev)
-        self.n_slots = int(os.environ.get("RLPPO_SLOTS", 4))  # minibatches of a batch kept in flight concurrently
+        self.n_slots = int(os.environ.get("RLPPO_SLOTS", 1))  # minibatches of a batch kept in flight concurrently
         self._idx_bufs = None
 
     # --------------------------------------------------------------------------------------------- learn

@@ -13,7 +13,9 @@ for path in glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=Tru
             continue
         out[name.replace("void ", "")][row["Counter_Name"]].append(float(row["Counter_Value"]))
 counters = sorted({c for k in out.values() for c in k})
-print("kernel," + ",".join(counters) + ",dispatches")
+import csv as _csv, sys as _sys
+w = _csv.writer(_sys.stdout)
+w.writerow(["kernel"] + counters + ["dispatches"])
 for k in sorted(out):
     n = max(len(v) for v in out[k].values())
-    print(k + "," + ",".join("%.6g" % (sum(out[k][c]) / len(out[k][c])) if out[k][c] else "" for c in counters) + f",{n}")
+    w.writerow([k] + ["%.6g" % (sum(out[k][c]) / len(out[k][c])) if out[k][c] else "" for c in counters] + [n])
