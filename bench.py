@@ -134,6 +134,26 @@ def kernel_breakdown(learner):
     return rows, dominant
 
 
+def pmc_traffic_for(kernel_label):
+    """HBM bytes per launch of the dominant kernel, from the committed PMC passes (bench.py cannot run rocprofv3 on itself)."""
+    path = os.path.join(ROOT, "profiles", "r01_traffic_v4.json")
+    key = {"gemm_tn dW hidden 256x256 (x4)": "rlppo::gemm_tn_kernel<false>",
+           "gemm_nt fwd hidden 256->256 (x4)": "rlppo::gemm_nt_kernel<8, 1, false, 32>",
+           "gemm_nt dX hidden 256->256 mask (x4)": "rlppo::gemm_nt_kernel<8, 3, false, 32>"}.get(kernel_label)
+    try:
+        t = json.load(open(path))
+        return round(t[key]["hbm_bytes"]), "profiles/r01_traffic_v4.json (tools/prof_kernels.py, same launch shape)"
+    except Exception:
+        return None, "no committed PMC pass for this kernel"
+
+
+def gae_traffic():
+    try:
+        return round(json.load(open(os.path.join(ROOT, "profiles", "r01_traffic_v4.json")))["rlppo::gae_lookback_kernel"]["hbm_bytes"])
+    except Exception:
+        return None
+
+
 def gae_bench():
     """BASELINE configs[2]: 8192 trajectories x 256 steps, gamma .99 lambda .95, return_std 1.7, fp32, seed 0."""
     from rlgym_ppo_amd.util import torch_functions
@@ -168,7 +188,7 @@ def gae_bench():
                steps_per_s=round(n / ms * 1e3), algorithm="single-pass decoupled look-back (memset node + 1 kernel)",
                ms_per_scan_two_launch=round(ms_two, 5),
                roofline=dict(bound="hbm", achieved=round(alg_bytes / ms / 1e6, 1), peak=HBM_PEAK_GBS, unit="GB/s",
-                             frac=round(alg_bytes / ms / 1e6 / HBM_PEAK_GBS, 4), traffic=None,
+                             frac=round(alg_bytes / ms / 1e6 / HBM_PEAK_GBS, 4), traffic=gae_traffic(), algorithmic_bytes=alg_bytes,
                              note="achieved = 28 algorithmic B/step x steps / time per scan (HIP events around 20 back-to-back scans, "
                                   "median of 5 rounds; includes the state memset node)"))
     # CPU side: the C port and the interpreter-bound Python form (the reference runs a Python loop) on bounded samples
@@ -315,9 +335,14 @@ def main():
         rows, dom = kernel_breakdown(learner)
         for r in rows:
             log("  %-44s x%d  %8.4f ms  %7.2f TFLOP/s" % (r["kernel"], r["launches_per_minibatch"], r["ms_per_launch"], r["tflops"]))
+        traffic, traffic_src = pmc_traffic_for(dom["kernel"])
         out["roofline"] = dict(bound="mfma", achieved=dom["tflops"], peak=MFMA_F32_PEAK_TF, unit="TFLOP/s",
-                               frac=round(dom["tflops"] / MFMA_F32_PEAK_TF, 4), traffic=None, kernel=dom["kernel"],
-                               note="algorithmic flop per launch / mean launch duration (HIP events, 10 launches)")
+                               frac=round(dom["tflops"] / MFMA_F32_PEAK_TF, 4), traffic=traffic, kernel=dom["kernel"],
+                               algorithmic_gflop_per_launch=dom["gflop_per_launch"], ms_per_launch=dom["ms_per_launch"],
+                               note="dominant kernel of the timed region by total time; achieved = algorithmic flop per "
+                                    "launch / mean launch duration (HIP events on the launch stream, 10 launches, same "
+                                    "shape as in the update: M=65,536); traffic = HBM bytes per launch from rocprofv3 PMC "
+                                    "(FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), " + traffic_src)
         out["update_flop_efficiency"] = dict(
             achieved=round(FLOP_PER_SAMPLE * value / 1e12, 2), peak=MFMA_F32_PEAK_TF, unit="TFLOP/s",
             frac=round(FLOP_PER_SAMPLE * value / 1e12 / MFMA_F32_PEAK_TF, 4),
