@@ -239,7 +239,9 @@ int rlppo_gae(void *stream, const float *rews, const float *dones, const float *
 // ------------------------------------------------------------------------------------------- PPO minibatch
 static int g_two_streams = 1;  // tuning: rlppo_dbg_set(4, 0/1)
 // Library-owned streams: slot s > 0 runs its policy chain on g_main[s]; every slot runs its critic chain on g_side[s].
-static hipStream_t g_main[RLPPO_MAX_SLOTS] = {}, g_side[RLPPO_MAX_SLOTS] = {};
+static hipStream_t g_main[RLPPO_MAX_SLOTS] = {}, g_side[RLPPO_MAX_SLOTS] = {}, g_dw[RLPPO_MAX_SLOTS][2] = {};
+static hipEvent_t g_ev_dw[RLPPO_MAX_SLOTS][2][RLPPO_MAX_LAYERS + 1] = {};
+static int g_dw_streams = 0;  // tuning: rlppo_dbg_set(8, 0/1); measured slower (14.4 vs 12.7 ms/epoch, tools/ab_update.py)
 static hipEvent_t g_ev_fork[RLPPO_MAX_SLOTS] = {}, g_ev_join[RLPPO_MAX_SLOTS] = {}, g_ev_slot[RLPPO_MAX_SLOTS] = {};
 static bool g_slot_pending[RLPPO_MAX_SLOTS] = {};
 
@@ -250,6 +252,10 @@ static int ensure_slot(int s) {
         RLPPO_HIP(hipEventCreateWithFlags(&g_ev_fork[s], hipEventDisableTiming));
         RLPPO_HIP(hipEventCreateWithFlags(&g_ev_join[s], hipEventDisableTiming));
         RLPPO_HIP(hipEventCreateWithFlags(&g_ev_slot[s], hipEventDisableTiming));
+        for (int n = 0; n < 2; ++n) {
+            RLPPO_HIP(hipStreamCreateWithFlags(&g_dw[s][n], hipStreamNonBlocking));
+            for (int l = 0; l <= RLPPO_MAX_LAYERS; ++l) RLPPO_HIP(hipEventCreateWithFlags(&g_ev_dw[s][n][l], hipEventDisableTiming));
+        }
     }
     return 0;
 }
@@ -277,8 +283,12 @@ size_t rlppo_minibatch_workspace_bytes(const int32_t *pol_dims, int32_t pol_laye
 }
 
 // backward of one net: acts[l] = saved output of layer l, acts[last] holds dL/d(out) on entry
-static int backward(hipStream_t st, const NetLayout &net, const float *packed, const float *states, int64_t ld_states,
-                    const int64_t *idx, int64_t mb, float *const *acts, float *const *dx, float *grad) {
+// Weight-gradient launches (gemm_tn) only depend on dY_l and the saved input of layer l, not on each other or on the rest
+// of the dX chain: with `dw` != `st` they go to a second stream so that a gemm_tn and a gemm_nt workgroup (different
+// kernels, 74 KB + 64 KB of LDS) share a CU instead of two copies of the same kernel running in lock step.
+static int backward(hipStream_t st, hipStream_t dw, hipEvent_t *ev, const NetLayout &net, const float *packed,
+                    const float *states, int64_t ld_states, const int64_t *idx, int64_t mb, float *const *acts,
+                    float *const *dx, float *grad) {
     // dx[l-1] receives dL/d(acts[l-1]) = dY of layer l-1 (one buffer per layer: the dW launches read them later)
     const int last = net.n_layers - 1;
     const bool fused = fused_eligible(net, mb);
@@ -292,7 +302,11 @@ static int backward(hipStream_t st, const NetLayout &net, const float *packed, c
         const float *dY = l == last ? acts[last] : dx[l];
         const float *X = l > 0 ? acts[l - 1] : states;
         const int64_t ldx = l > 0 ? net.L[l - 1].pout : ld_states;
-        rc = launch_gemm_tn(st, dY, L.pout, L.pout, X, ldx, l > 0 ? nullptr : idx, L.pin, grad + L.off_flat_w,
+        if (dw != st) {  // dY_l is complete at this point of `st`
+            rc = order_after(dw, st, ev[l]);
+            if (rc) return rc;
+        }
+        rc = launch_gemm_tn(dw, dY, L.pout, L.pout, X, ldx, l > 0 ? nullptr : idx, L.pin, grad + L.off_flat_w,
                             grad + L.off_flat_b, L.out, L.in, mb);
         if (rc) return rc;
         if (l > 0 && !fused) {
@@ -302,7 +316,8 @@ static int backward(hipStream_t st, const NetLayout &net, const float *packed, c
             if (rc) return rc;
         }
     }
-    return 0;
+    if (dw != st) rc = order_after(st, dw, ev[RLPPO_MAX_LAYERS]);
+    return rc;
 }
 
 int rlppo_ppo_minibatch(void *stream, const rlppo_minibatch_args *a) {
@@ -416,9 +431,9 @@ int rlppo_ppo_minibatch(void *stream, const rlppo_minibatch_args *a) {
         rc = order_after(side, st, g_ev_fork[slot]);
         if (rc) return rc;
     }
-    rc = backward(side, val, a->val_packed, a->states, a->ld_states, a->idx, mb, vact, vdx, a->val_grad);
+    rc = backward(side, g_dw_streams ? g_dw[slot][1] : side, g_ev_dw[slot][1], val, a->val_packed, a->states, a->ld_states, a->idx, mb, vact, vdx, a->val_grad);
     if (rc) return rc;
-    rc = backward(st, pol, a->pol_packed, a->states, a->ld_states, a->idx, mb, pact, pdx, a->pol_grad);
+    rc = backward(st, g_dw_streams ? g_dw[slot][0] : st, g_ev_dw[slot][0], pol, a->pol_packed, a->states, a->ld_states, a->idx, mb, pact, pdx, a->pol_grad);
     if (rc) return rc;
     if (side != st) rc = order_after(st, side, g_ev_join[slot]);
     return rc;
@@ -478,6 +493,10 @@ int rlppo_dbg_set(int32_t key, int32_t value) {
     }
     if (key == 7) {
         set_nt_stagger(value);
+        return 0;
+    }
+    if (key == 8) {
+        g_dw_streams = value;
         return 0;
     }
     set_error("dbg_set: unknown key %d", key);

@@ -213,6 +213,9 @@ class Learner(object):
 
     # ------------------------------------------------------------------------------------------ checkpoints
     def save(self, cumulative_timesteps):
+        from .dp import dist_info
+        if dist_info()[1] != 0:
+            return  # data-parallel replicas are bit-identical: rank 0 writes the checkpoint
         folder_path = os.path.join(self.checkpoints_save_folder, str(cumulative_timesteps))
         os.makedirs(folder_path, exist_ok=True)
         print(f"Saving checkpoint {cumulative_timesteps}...")

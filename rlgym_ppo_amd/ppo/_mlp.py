@@ -27,6 +27,11 @@ def build_body(input_shape, layer_sizes, n_out, final_activation=None):
 class ArenaModule(nn.Module):
     """nn.Module whose `self.model` Linear parameters live in a NetArena on the GPU."""
 
+    # "host": sampling noise is drawn with torch's CPU generator -- the stream the reference's CPU path consumes, so a
+    #         seeded run picks the reference's actions (costs ~1 us per drawn number on the host);
+    # "device": noise drawn on the GPU (what the reference does when it runs on cuda); no host work per step.
+    noise_mode = "host"
+
     def _finish(self, device):
         self.device = device
         dev = require_gpu(device)

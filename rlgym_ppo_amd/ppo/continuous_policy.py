@@ -36,7 +36,9 @@ class ContinuousPolicy(ArenaModule):
             return action.cpu(), self.logpdf(action, mean, std).cpu()
         rows = a.stage_obs(obs, standardize)
         n, k = rows.shape[0], self.n_out // 2
-        if noise is None:
+        if noise is None and self.noise_mode == "device":
+            noise = torch.empty(n, k, device=a.device).normal_(0, 1)  # fast mode: torch's HIP generator, not the reference's CPU stream
+        elif noise is None:
             noise = torch.empty(n, k).normal_(0, 1)  # what Normal.sample() draws on the reference's CPU path
         eps = torch.as_tensor(noise, dtype=torch.float32).to(a.device, non_blocking=True).contiguous()
         a.ensure_packed()

@@ -40,7 +40,9 @@ class DiscreteFF(ArenaModule):
         if deterministic:
             probs = torch.clamp(torch.softmax(a.forward(rows)[:, :self.n_actions], dim=-1), min=1e-11, max=1)
             return probs.cpu().numpy().argmax(), 0  # quirk Q11: flat argmax over the whole batch
-        if noise is None:
+        if noise is None and self.noise_mode == "device":
+            noise = torch.empty(n, self.n_actions, device=a.device).exponential_(1)  # fast mode: torch's HIP generator, not the reference's CPU stream
+        elif noise is None:
             noise = torch.empty(n, self.n_actions).exponential_(1)
         q = torch.as_tensor(noise, dtype=torch.float32).to(a.device, non_blocking=True).contiguous()
         a.ensure_packed()

@@ -35,7 +35,9 @@ class MultiDiscreteFF(ArenaModule):
             return torch.stack(action).cpu().numpy(), 0
         rows = a.stage_obs(obs, standardize)
         n = rows.shape[0]
-        if noise is None:
+        if noise is None and self.noise_mode == "device":
+            noise = torch.empty(n * 8, 3, device=a.device).exponential_(1)  # fast mode: torch's HIP generator, not the reference's CPU stream
+        elif noise is None:
             noise = torch.empty(n * 8, 3).exponential_(1)  # Categorical.sample -> multinomial on [n*8, 3]
         q = torch.as_tensor(noise, dtype=torch.float32).to(a.device, non_blocking=True).contiguous()
         a.ensure_packed()

@@ -150,6 +150,8 @@ class PPOLearner(object):
         self._ws = Workspace(self._dev)
         self.n_slots = int(os.environ.get("RLPPO_SLOTS", 1))  # minibatches of a batch kept in flight concurrently
         self._idx_bufs = None
+        from concurrent.futures import ThreadPoolExecutor
+        self._perm_pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="rlppo-shuffle")
 
     # --------------------------------------------------------------------------------------------- learn
     def _upload_indices(self, idx):
@@ -223,8 +225,14 @@ class PPOLearner(object):
                 raise ValueError("experience buffer action width does not match the policy head")
             args = self._minibatch_args(exp)
             st = stream_ptr()
-            indices = exp.epoch_indices()
+            # The legacy-MT19937 permutation is inherently serial host work (3 ms per 512k indices).  It is drawn by a
+            # helper thread (the C call releases the GIL) one epoch ahead, so it overlaps both the GPU and this
+            # thread's launch calls; with 8 ranks the GPU share of an epoch is ~1.5 ms and the shuffle is the critical path.
+            fut = self._perm_pool.submit(exp.epoch_indices)
             for epoch in range(self.n_epochs):
+                indices = fut.result()
+                if epoch + 1 < self.n_epochs:
+                    fut = self._perm_pool.submit(exp.epoch_indices)
                 idx_dev = self._upload_indices(indices)
                 for b in range(n_batches):
                     self._grad_all.zero_()
@@ -244,9 +252,6 @@ class PPOLearner(object):
                     self.value_optimizer.step(max_norm=MAX_GRAD_NORM)
                     self.policy_optimizer.step(max_norm=MAX_GRAD_NORM)
                     n_iterations += 1
-                if epoch + 1 < self.n_epochs:
-                    # drawn while the GPU is still working on this epoch's launches
-                    indices = exp.epoch_indices()
         else:
             for _ in range(self.n_epochs):
                 exp.epoch_indices()  # the reference consumes one permutation per epoch even if no batch fits

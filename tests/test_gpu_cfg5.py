@@ -1,0 +1,61 @@
+"""BASELINE configs[4] shape (continuous Gaussian policy, obs 231 = AdvancedObs, 512x4 MLPs, 8 action dims -> 16 outputs),
+in fp32 through the generic (non-256-wide) kernel path: K = 256/512, N = 512, 5 linear layers per net."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import nets, ppo  # noqa: E402
+from test_gpu_kernels import L, compare_minibatch, relerr, run_minibatch  # noqa: E402,F401
+
+
+def test_cfg5_shape_minibatch_and_sampling(L):
+    torch.manual_seed(5)
+    pol = nets.init_mlp(231, (512, 512, 512, 512), 16)
+    val = nets.init_mlp(231, (512, 512, 512, 512), 1)
+    rs = np.random.RandomState(5)
+    n = 6000
+    obs = np.clip(rs.randn(n, 231), -5, 5).astype(np.float32)
+    mean, std = nets.gauss_out(pol, obs)
+    eps = torch.as_tensor(rs.randn(n, 8).astype(np.float32))
+    act, logp = nets.gauss_sample(mean, std, eps)
+    old = (logp + torch.as_tensor(rs.randn(n).astype(np.float32) * 0.1)).numpy()
+    adv = rs.randn(n).astype(np.float32)
+    tgt = rs.randn(n).astype(np.float32)
+    # samples with a hidden pre-activation within GEMM rounding of 0 have an implementation-defined ReLU mask
+    amb = np.zeros(n, bool)
+    for params in (pol, val):
+        h = obs.astype(np.float64)
+        for w, b in params[:-1]:
+            pre = h @ w.double().numpy().T + b.double().numpy()
+            amb |= (np.abs(pre) < 2e-5).any(1)
+            h = np.maximum(pre, 0)
+    idx = np.flatnonzero(~amb)[:4096]
+    assert len(idx) == 4096
+    gp, gv, stats = run_minibatch(L, "gaussian", pol, val, obs, act.numpy(), old, tgt, adv, idx, 0.2, 0.005, 0.5)
+    ti = torch.as_tensor(idx)
+    ref = ppo.minibatch_autograd("gaussian", pol, val, torch.as_tensor(obs)[ti], act[ti], torch.as_tensor(old)[ti],
+                                 torch.as_tensor(adv)[ti], torch.as_tensor(tgt)[ti], 0.2, 0.005, 0.5)
+    compare_minibatch(gp, gv, stats, ref, tol=1e-4)  # (x-mu)^2/sd^3 terms amplify fp32 rounding
+
+
+def test_cfg5_policy_classes_round_trip():
+    from rlgym_ppo_amd.ppo import ContinuousPolicy, ValueEstimator
+    torch.manual_seed(9)
+    pol = ContinuousPolicy(231, 16, (512, 512, 512, 512), "cuda:0")
+    val = ValueEstimator(231, (512, 512, 512, 512), "cuda:0")
+    params = [(l.weight.detach().cpu(), l.bias.detach().cpu()) for l in pol.arena.linears]
+    vparams = [(l.weight.detach().cpu(), l.bias.detach().cpu()) for l in val.arena.linears]
+    rs = np.random.RandomState(1)
+    obs = np.clip(rs.randn(4096, 231), -5, 5).astype(np.float32)
+    eps = torch.as_tensor(rs.randn(4096, 8).astype(np.float32))
+    a, lp = pol.get_action(obs, noise=eps)
+    mean, std = nets.gauss_out(params, obs)
+    oa, olp = nets.gauss_sample(mean, std, eps)
+    np.testing.assert_allclose(a.numpy(), oa.numpy(), rtol=1e-5, atol=3e-6)
+    np.testing.assert_allclose(lp.numpy(), olp.numpy(), rtol=3e-5, atol=3e-4)
+    assert relerr(val(obs), nets.value_forward(vparams, obs)) < 1e-5
+    pol.noise_mode = "device"  # fast mode: same distribution, torch's HIP generator
+    a2, lp2 = pol.get_action(obs)
+    assert a2.shape == (4096, 8) and torch.isfinite(lp2).all() and (a2.abs() <= 1).all()

@@ -8,7 +8,7 @@ L = N.lib()
 with contextlib.redirect_stdout(sys.stderr):
     learner, buf = bench.build_workload("cuda:0")
 learner.n_epochs = 3
-configs = {"fused": (1, ((3, 0), (4, 1), (6, 1))), "layerwise": (1, ((3, 0), (4, 1), (6, 0))), "fused 1 stream": (1, ((3, 0), (4, 0), (6, 1)))}
+configs = {"dw streams": (1, ((4, 1), (6, 0), (8, 1))), "no dw streams": (1, ((4, 1), (6, 0), (8, 0))), "dw streams, 1 chain stream": (1, ((4, 0), (6, 0), (8, 1)))}
 res = {k: [] for k in configs}
 learner.learn(buf)
 for rnd in range(3):
