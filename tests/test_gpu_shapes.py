@@ -1,0 +1,95 @@
+"""Generality of the kernel paths: odd layer widths (padding to 32 / 64 / 96 / 128 / k*128), one hidden layer, wide
+discrete heads (EPL = 8 and 32 register variants of the wave-per-row kernels), tiny and ragged batches, empty calls."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import nets, ppo  # noqa: E402
+from test_gpu_kernels import L, Net, P, check, compare_minibatch, dev, relerr, run_minibatch, stream  # noqa: E402,F401
+
+
+def ambiguous(params_list, obs, thr=1e-5):
+    amb = np.zeros(len(obs), bool)
+    for params in params_list:
+        h = obs.astype(np.float64)
+        for w, b in params[:-1]:
+            pre = h @ w.double().numpy().T + b.double().numpy()
+            amb |= (np.abs(pre) < thr).any(1)
+            h = np.maximum(pre, 0)
+    return amb
+
+
+@pytest.mark.parametrize("d,hidden,A,n,mb", [(50, (100, 40), 300, 700, 333), (7, (33,), 5, 64, 64), (300, (130, 257, 64), 1500, 400, 129),
+                                             (107, (256, 256, 256), 90, 1300, 1100)])
+def test_discrete_odd_shapes(L, d, hidden, A, n, mb):
+    torch.manual_seed(d + A)
+    pol = nets.init_mlp(d, hidden, A)
+    val = nets.init_mlp(d, hidden[::-1], 1)
+    rs = np.random.RandomState(n)
+    obs = np.clip(rs.randn(n, d), -5, 5).astype(np.float32)
+    q = nets.draw_exp_noise(n, A)
+    oprobs = nets.discrete_probs(pol, obs)
+    oact, ologp = nets.discrete_sample(oprobs, q)
+    net = Net(L, pol)
+    rows = net.pad(obs)
+    act = torch.empty(n, dtype=torch.int64, device="cuda")
+    logp = torch.empty(n, device="cuda")
+    probs = torch.empty(n, A, device="cuda")
+    w = net.ws(n)
+    qd = dev(q)
+    check(L, L.rlppo_discrete_act(stream(), net.dims_c, net.nl, P(net.packed), P(rows), net.ld_in, n, P(qd), P(act), P(logp),
+                                  P(probs), P(w), w.numel()))
+    assert relerr(probs, oprobs) < 1e-5
+    assert (act.cpu() != oact).sum().item() <= max(1, n // 500)
+    old = (ologp + torch.as_tensor(rs.randn(n).astype(np.float32) * 0.2)).numpy()
+    adv, tgt = rs.randn(n).astype(np.float32), rs.randn(n).astype(np.float32)
+    idx = np.flatnonzero(~ambiguous([pol, val], obs))
+    idx = rs.permutation(idx)[:mb]
+    gp, gv, stats = run_minibatch(L, "discrete", pol, val, obs, oact.numpy(), old, tgt, adv, idx, 0.2, 0.005, 1.0)
+    ti = torch.as_tensor(idx)
+    ref = ppo.minibatch_autograd("discrete", pol, val, torch.as_tensor(obs)[ti], oact[ti].float(), torch.as_tensor(old)[ti],
+                                 torch.as_tensor(adv)[ti], torch.as_tensor(tgt)[ti], 0.2, 0.005, 1.0)
+    compare_minibatch(gp, gv, stats, ref, tol=3e-5)
+
+
+def test_single_row_and_empty_calls(L):
+    torch.manual_seed(3)
+    pol = nets.init_mlp(107, (64, 64), 90)
+    net = Net(L, pol)
+    obs = np.random.RandomState(0).randn(1, 107).astype(np.float32)
+    rows = net.pad(obs)
+    q = nets.draw_exp_noise(1, 90)
+    qd = dev(q)
+    act = torch.empty(1, dtype=torch.int64, device="cuda")
+    logp = torch.empty(1, device="cuda")
+    w = net.ws(1)
+    check(L, L.rlppo_discrete_act(stream(), net.dims_c, net.nl, P(net.packed), P(rows), net.ld_in, 1, P(qd), P(act), P(logp), None,
+                                  P(w), w.numel()))
+    oact, ologp = nets.discrete_sample(nets.discrete_probs(pol, obs), q)
+    assert act.item() == oact.item() and abs(logp.item() - ologp.item()) < 1e-5
+    # n == 0 is a no-op for every entry point that takes a row count
+    check(L, L.rlppo_discrete_act(stream(), net.dims_c, net.nl, P(net.packed), None, net.ld_in, 0, None, None, None, None, None, 0))
+    check(L, L.rlppo_mlp_forward(stream(), net.dims_c, net.nl, P(net.packed), None, net.ld_in, 0, 0, None, net.ld_out, None, 0))
+    check(L, L.rlppo_pad_rows(stream(), None, 0, 0, 107, 107, None, 128, 0, 0.0, 1.0))
+    check(L, L.rlppo_categorical_select(stream(), None, 90, 0, 90, None, None, None))
+    # argument errors are reported, not crashed on
+    assert L.rlppo_mlp_forward(stream(), net.dims_c, net.nl, P(net.packed), P(rows), 64, 1, 0, P(logp), net.ld_out, P(w), w.numel()) == 1001
+    assert b"ld_obs" in L.rlppo_last_error()
+    assert L.rlppo_mlp_forward(stream(), net.dims_c, net.nl, P(net.packed), P(rows), net.ld_in, 1, 0, P(logp), net.ld_out, P(w), 16) == 1002
+
+
+def test_obs_standardisation_fused_in_staging(L):
+    # rlppo_pad_rows with the reference's scalar statistics (quirk Q5) == np.clip((obs - mean0) / std0, -5, 5) in fp32
+    rs = np.random.RandomState(4)
+    obs = (rs.randn(300, 107) * 4 + 1).astype(np.float32)
+    mean0, std0 = np.float32(0.73), np.float32(2.9)
+    src = dev(obs)
+    out = torch.empty(300, 128, device="cuda")
+    check(L, L.rlppo_pad_rows(stream(), P(src), 0, 300, 107, 107, P(out), 128, 1, float(mean0), float(std0)))
+    ref = np.clip((obs - mean0) / std0, -5, 5)
+    got = out.cpu().numpy()
+    assert np.array_equal(got[:, :107], ref) and (got[:, 107:] == 0).all()
