@@ -204,7 +204,17 @@ int rlppo_dbg_set(int32_t key, int32_t value);
 /* Register-only fp32 MFMA loop: out[blocks*256] floats, clocks[2*blocks] = {shader cycles, 100 MHz ticks} per block. */
 /* GEMM inner-loop probe: 64 MFMAs per chunk + (mode&1) A fragments from LDS, (mode&2) B fragments from LDS, (mode&4) B
  * fragments from a 256x256 fp32 matrix W in global memory.  out: blocks*threads floats. */
+/* vector-memory path probe: every wave streams 8 KB per iteration with 8 dwordx4 loads; `pattern` picks the lane->address
+ * map (0: 8 rows x 128 B, 1: 1 KB contiguous, 2: 4 rows x 256 B, 3: 16 x 64 B); span = power-of-two bytes walked. */
+int rlppo_dbg_probe_ld(void *stream, int32_t pattern, int32_t blocks, const void *buf, size_t span, int32_t iters, float *out);
+/* co-issue probe: 512 workgroups, the first 256 stream MFMAs, the last 256 issue batches of 8 global loads and record the
+ * cycles each batch took to issue -> cycles[wave][2] = {issue, total}.  buf >= 16 MiB, out >= 512*256 floats. */
+int rlppo_dbg_probe_coissue(void *stream, const float *buf, int32_t flags, int32_t iters, uint64_t *cycles, float *out);
 int rlppo_dbg_probe2(void *stream, int32_t mode, int32_t threads, int32_t blocks, const float *W, float *out, int32_t chunks);
+/* Stamped copy of the staged forward GEMM (bias+ReLU, N % 128 == 0): stamps[wg][wave][8] cycles per phase (csrc/probe.hip). */
+int rlppo_dbg_gemm_nt_stamped(void *stream, const float *A, int64_t lda, const float *B, int64_t ldb, const float *bias,
+                                float *C, int64_t ldc, int64_t M, int32_t N, int32_t K, uint64_t *stamps, int32_t mode);
+/* mode: 0 real; 1 every workgroup reads the same 1024 A rows (A from L2); 2 output stores dropped; 3 both (diagnostic) */
 int rlppo_dbg_mfma_probe(void *stream, float *out, int32_t blocks, int32_t iters, uint64_t *clocks);
 int rlppo_dbg_gemm_nt(void *stream, const float *A, int64_t lda, const int64_t *row_idx, const float *B, int64_t ldb,
                       const float *bias, const float *mask_src, int64_t ld_mask, float *C, int64_t ldc, int64_t M,

@@ -499,8 +499,24 @@ int rlppo_dbg_set(int32_t key, int32_t value) {
         g_dw_streams = value;
         return 0;
     }
+    if (key == 9) {
+        set_nt_sa(value);
+        return 0;
+    }
     set_error("dbg_set: unknown key %d", key);
     return RLPPO_ERR_ARG;
+}
+int rlppo_dbg_gemm_nt_stamped(void *stream, const float *A, int64_t lda, const float *B, int64_t ldb, const float *bias,
+                                float *C, int64_t ldc, int64_t M, int32_t N, int32_t K, uint64_t *stamps, int32_t mode) {
+    if (mode & 64)  // the scalar-addressed product kernel (gemm_sa.hip) with stamps
+        return launch_gemm_nt_sa_stamped((hipStream_t)stream, A, lda, B, ldb, bias, C, ldc, M, N, K, (unsigned long long *)stamps);
+    return launch_gemm_nt_stamped((hipStream_t)stream, A, lda, B, ldb, bias, C, ldc, M, N, K, (unsigned long long *)stamps, mode);
+}
+int rlppo_dbg_probe_ld(void *stream, int32_t pattern, int32_t blocks, const void *buf, size_t span, int32_t iters, float *out) {
+    return launch_probe_ld((hipStream_t)stream, pattern, blocks, buf, span, iters, out);
+}
+int rlppo_dbg_probe_coissue(void *stream, const float *buf, int32_t flags, int32_t iters, uint64_t *cycles, float *out) {
+    return launch_probe_coissue((hipStream_t)stream, buf, flags, iters, (unsigned long long *)cycles, out);
 }
 int rlppo_dbg_probe2(void *stream, int32_t mode, int32_t threads, int32_t blocks, const float *W, float *out, int32_t chunks) {
     return launch_probe2((hipStream_t)stream, mode, threads, blocks, W, out, chunks);

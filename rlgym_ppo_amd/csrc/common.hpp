@@ -81,6 +81,17 @@ void set_nt_ws(int on);
 void set_nt_bk(int bk);
 void set_fused(int on);
 void set_nt_stagger(int sleep_units);
+int launch_gemm_nt_stamped(hipStream_t st, const float *A, int64_t lda, const float *B, int64_t ldb, const float *bias,
+                           float *C, int64_t ldc, int64_t M, int N, int K, unsigned long long *stamps, int mode);
+int launch_gemm_nt_sa(hipStream_t st, const float *A, int64_t lda, const float *B, int64_t ldb, const float *bias,
+                      const float *mask_src, int64_t ld_mask, float *C, int64_t ldc, int64_t M, int N, int nb, int K, int epi);
+void set_nt_sa(int v);
+int launch_gemm_tn_sa(hipStream_t st, dim3 grid, const float *dY, int64_t ldy, int ny_valid, const float *X, int64_t ldx,
+                      int kx_valid, float *dW, float *db, int out, int in, int64_t M, int rows_per_wg);
+int launch_gemm_nt_sa_stamped(hipStream_t st, const float *A, int64_t lda, const float *B, int64_t ldb, const float *bias,
+                              float *C, int64_t ldc, int64_t M, int N, int K, unsigned long long *stamps);
+int launch_probe_ld(hipStream_t st, int pat, int blocks, const void *buf, size_t span, int iters, float *out);
+int launch_probe_coissue(hipStream_t st, const float *buf, int flags, int iters, unsigned long long *cycles, float *out);
 int launch_probe2(hipStream_t st, int mode, int threads, int blocks, const float *W, float *out, int chunks);
 bool fused_eligible(const NetLayout &net, int64_t mb);
 int launch_fused_forward(hipStream_t st, const NetLayout &net, const float *packed, const float *obs, int64_t ld_obs,

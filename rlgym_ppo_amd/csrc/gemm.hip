@@ -415,6 +415,11 @@ int launch_gemm_nt(hipStream_t st, const float *A, int64_t lda, const int64_t *r
         set_error("gemm_nt: N=%d is not a padded output width", N);
         return RLPPO_ERR_ARG;
     }
+    if (!row_idx && !g_nt_ws) {
+        // default for ungathered operands: the scalar-addressed kernel (gemm_sa.hip); -1 = not applicable
+        const int rc = launch_gemm_nt_sa(st, A, lda, B, ldb, bias, mask_src, ld_mask, C, ldc, M, N, nb, K, epi);
+        if (rc != -1) return rc;
+    }
     if (g_nt_ws && K <= 256 && M >= 4 * WS_ROWS) {
         // one workgroup per CU: grid.x * (column tiles) ~ number of CUs, each workgroup walks several row tiles
         const int n_row_tiles = (int)cdiv(M, WS_ROWS);
@@ -585,6 +590,10 @@ int launch_gemm_tn(hipStream_t st, const float *dY, int64_t ldy, int ny_valid, c
     if (g_tn_rows_override > 0) rows = g_tn_rows_override;
     const int rows_per_wg = (int)rows;
     dim3 grid((unsigned)cdiv(out, 128), (unsigned)cdiv(in, 128), (unsigned)cdiv(M, rows_per_wg));
+    if (!row_idx) {  // default for ungathered X: the scalar-addressed kernel (gemm_sa.hip); -1 = not applicable
+        const int rc = launch_gemm_tn_sa(st, grid, dY, ldy, ny_valid, X, ldx, kx_valid, dW, db, out, in, M, rows_per_wg);
+        if (rc != -1) return rc;
+    }
     if (row_idx)
         hipLaunchKernelGGL((gemm_tn_kernel<true>), grid, dim3(256), 0, st, dY, ldy, ny_valid, X, ldx, row_idx, kx_valid,
                            dW, db, out, in, M, rows_per_wg);

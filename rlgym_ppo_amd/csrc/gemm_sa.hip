@@ -1,0 +1,422 @@
+// gemm_sa.hip -- gemm_nt with scalar addressing: the same 128 x (16 NB) x 32 staged tile as gemm.hip's gemm_nt_kernel, but
+// with NO vector-ALU instruction outside the MFMA stream's own wave slots.
+//
+// Why (measured, tools/stamps_nt.py + tools/probe_coissue.py): two workgroups share a CU, so every SIMD
+// holds two waves.  While one of them streams MFMAs, a VALU instruction of the OTHER wave takes ~400 cycles to issue
+// (a global_load or ds_write does not).  gemm_nt_kernel bumps seven 64-bit per-lane pointers per K step before it can
+// issue its 8 staging loads: 3.3k cycles per K step in which that wave does nothing else, 31 % of its lifetime.
+// Here every address is  SGPR base (tile origin + k advance, scalar ALU)  +  a 32-bit per-lane offset computed once,
+// which is the `global_load_dwordx4 v, v_off, s[base:base+1]` form; the bias is the accumulator's initial value instead of
+// 64 v_add in the epilogue, and the output rows use the same base + offset form.
+//
+// Applicability (host-checked in launch_gemm_nt_sa, otherwise gemm.hip's kernel runs): no row gather, and every operand
+// smaller than 4 GiB from its first to its last addressed byte.
+#include "common.hpp"
+
+namespace rlppo {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+
+namespace {
+constexpr int SBM = 128, SBK = 32;
+__device__ __forceinline__ unsigned long long stamp() {
+    unsigned long long t;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    return t;
+}
+__device__ __forceinline__ unsigned long long realtime() {  // constant 100 MHz reference clock
+    unsigned long long t;
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    return t;
+}
+__device__ __forceinline__ int sswz(int row, int chunk) { return row * 32 + ((chunk ^ (row & 7)) << 2); }
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+// 128-bit buffer descriptor over [base, base + bytes): base and bytes must be wave-uniform.  Loads past `bytes` return 0
+// and stores past it are dropped by the hardware range check (used for the ragged last row tile).
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *base, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, bytes, 0x00020000);
+}
+// buffer_load_dwordx4 v, voff, srsrc, soff offen: per-lane 32-bit offset + scalar offset, no vector address arithmetic
+__device__ __forceinline__ f32x4 ldb(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
+__device__ __forceinline__ void stb(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, f32x4 v) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, voff, soff, 0);
+}
+__device__ __forceinline__ float relu1(float x) {  // one v_max_f32 (x > 0 ? x : 0 compiles to two: NaN canonicalisation)
+    float y;
+    asm("v_max_f32 %0, 0, %1" : "=v"(y) : "v"(x));
+    return y;
+}
+}  // namespace
+
+// STAMP: diagnostic build (rlppo_dbg_gemm_nt_stamped mode 64) that accumulates s_memtime cycles per phase into
+// stamps[workgroup][wave][8]: 0 prologue, 1 issue of the staging loads, 2 fragment reads + MFMA, 3 wait for the staged
+// loads, 4 LDS writes, 5 barrier, 6 epilogue, 7 whole kernel.  PHASE() compiles to nothing in the product kernels.
+#define PHASE(k)                                                   \
+    if (STAMP) {                                                   \
+        __builtin_amdgcn_sched_barrier(0);                         \
+        const unsigned long long now_ = stamp();                   \
+        acc_t[k] += now_ - t_;                                     \
+        t_ = now_;                                                 \
+        __builtin_amdgcn_sched_barrier(0);                         \
+    }
+
+template <int NB, int EPI, bool STAMP = false>
+__global__ __launch_bounds__(256, 2) void gemm_nt_sa_kernel(const float *__restrict__ A, unsigned lda_b,
+                                                            const float *__restrict__ B, unsigned ldb_b,
+                                                            const float *__restrict__ bias,
+                                                            const float *__restrict__ mask_src, unsigned ldm_b,
+                                                            float *__restrict__ C, unsigned ldc_b, int64_t M, int K,
+                                                            unsigned long long *__restrict__ stamps) {
+    constexpr int BN = NB * 16;
+    unsigned long long acc_t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long t_ = STAMP ? stamp() : 0;
+    const unsigned long long t_begin = t_;
+    const unsigned long long rt_begin = STAMP ? realtime() : 0;
+    constexpr int B_ITERS = BN / 32;
+    __shared__ __attribute__((aligned(16))) float lds[2 * SBM * SBK + 2 * BN * SBK];
+    float *As = lds;
+    float *Bs = lds + 2 * SBM * SBK;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int r16 = lane & 15, q = lane >> 4;
+    const int64_t m0 = (int64_t)blockIdx.x * SBM;
+    const int n0 = blockIdx.y * BN;
+    const int rows_here = (int)((M - m0) < SBM ? (M - m0) : SBM);  // >= 1
+
+    // uniform descriptors (SGPRs) over this workgroup's tiles and per-lane byte offsets (one VGPR each, computed once)
+    const __amdgpu_buffer_rsrc_t a_rs = make_rsrc(reinterpret_cast<const char *>(A) + m0 * lda_b,
+                                                  (unsigned)(rows_here - 1) * lda_b + (unsigned)K * 4);
+    const __amdgpu_buffer_rsrc_t b_rs = make_rsrc(reinterpret_cast<const char *>(B) + (int64_t)n0 * ldb_b,
+                                                  (unsigned)(BN - 1) * ldb_b + (unsigned)K * 4);
+    const int ld_chunk = tid & 7, ld_row = tid >> 3;
+    // rows past M: offsets beyond the descriptor -> the loads return 0 (computed, never stored)
+    const unsigned a_off = (unsigned)ld_row * lda_b + ld_chunk * 16;
+    const unsigned b_off = (unsigned)ld_row * ldb_b + ld_chunk * 16;
+    const unsigned a_step = 32u * lda_b, b_step = 32u * ldb_b;  // uniform
+
+    f32x4 acc[2][NB];
+    if (EPI == EPI_MASK) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < NB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    } else {
+        // accumulate on top of the bias: b + sum_k x_k w_k (the reference's addmm also starts from the bias)
+        const __amdgpu_buffer_rsrc_t bias_rs = make_rsrc(bias + n0, BN * 4);
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            acc[0][j] = ldb(bias_rs, (unsigned)(q * 16), j * 64);
+            acc[1][j] = acc[0][j];
+        }
+    }
+
+    f32x4 ra[4], rb[B_ITERS];
+    const int nk = K / SBK;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) ra[i] = ldb(a_rs, a_off, i * a_step);
+#pragma unroll
+    for (int i = 0; i < B_ITERS; ++i) rb[i] = ldb(b_rs, b_off, i * b_step);
+    const int st_off = sswz(ld_row, ld_chunk);  // rows +32 i keep (row & 7): the swizzle is a constant offset per pass
+#pragma unroll
+    for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4 *>(&As[st_off + i * 32 * SBK]) = ra[i];
+#pragma unroll
+    for (int i = 0; i < B_ITERS; ++i) *reinterpret_cast<f32x4 *>(&Bs[st_off + i * 32 * SBK]) = rb[i];
+    __syncthreads();
+    PHASE(0)
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        const bool more = (kt + 1) < nk;
+        if (more) {
+            const unsigned kb = (unsigned)(kt + 1) * (SBK * 4);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) ra[i] = ldb(a_rs, a_off, kb + i * a_step);
+#pragma unroll
+            for (int i = 0; i < B_ITERS; ++i) rb[i] = ldb(b_rs, b_off, kb + i * b_step);
+        }
+        PHASE(1)
+        const float *Ac = As + cur * SBM * SBK + (wave * 32) * SBK;
+        const float *Bc = Bs + cur * BN * SBK;
+#pragma unroll
+        for (int kc = 0; kc < 2; ++kc) {
+            f32x4 fa[2], fb[NB];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) fa[i] = *reinterpret_cast<const f32x4 *>(&Ac[sswz(i * 16 + r16, kc * 4 + q)]);
+#pragma unroll
+            for (int j = 0; j < NB; ++j) fb[j] = *reinterpret_cast<const f32x4 *>(&Bc[sswz(j * 16 + r16, kc * 4 + q)]);
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < NB; ++j) acc[i][j] = MFMA16(fb[j][s], fa[i][s], acc[i][j]);
+        }
+        PHASE(2)
+        if (more) {
+            if (STAMP) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                PHASE(3)
+            }
+            float *An = As + (cur ^ 1) * SBM * SBK, *Bn = Bs + (cur ^ 1) * BN * SBK;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4 *>(&An[st_off + i * 32 * SBK]) = ra[i];
+#pragma unroll
+            for (int i = 0; i < B_ITERS; ++i) *reinterpret_cast<f32x4 *>(&Bn[st_off + i * 32 * SBK]) = rb[i];
+            PHASE(4)
+        }
+        __syncthreads();
+        PHASE(5)
+    }
+
+    // epilogue: lane owns C[m0 + wave*32 + 16 i + r16][n0 + 16 j + 4 q + (0..3)]; rows past M fall outside the descriptor
+    const int row_l = wave * 32 + r16;
+    const __amdgpu_buffer_rsrc_t c_rs = make_rsrc(reinterpret_cast<char *>(C) + m0 * ldc_b + (int64_t)n0 * 4,
+                                                  (unsigned)(rows_here - 1) * ldc_b + BN * 4);
+    const unsigned c_off = (unsigned)row_l * ldc_b + q * 16;
+    if (EPI == EPI_MASK) {
+        const __amdgpu_buffer_rsrc_t m_rs = make_rsrc(reinterpret_cast<const char *>(mask_src) + m0 * ldm_b + (int64_t)n0 * 4,
+                                                      (unsigned)(rows_here - 1) * ldm_b + BN * 4);
+        const unsigned m_off = (unsigned)row_l * ldm_b + q * 16;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                const f32x4 h = ldb(m_rs, m_off, 16 * i * ldm_b + j * 64);
+                f32x4 v = acc[i][j];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = h[e] > 0.f ? v[e] : 0.f;
+                stb(c_rs, c_off, 16 * i * ldc_b + j * 64, v);
+            }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                f32x4 v = acc[i][j];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (EPI == EPI_BIAS_RELU) v[e] = relu1(v[e]);
+                    if (EPI == EPI_BIAS_TANH) v[e] = tanhf(v[e]);
+                }
+                stb(c_rs, c_off, 16 * i * ldc_b + j * 64, v);
+            }
+    }
+    if (STAMP) {
+        PHASE(6)
+        acc_t[7] = t_ - t_begin;
+        if (lane == 0) {
+            unsigned long long *o = stamps + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave) * 8;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) o[k] = acc_t[k];
+            unsigned long long *abs_ = stamps + (size_t)gridDim.x * gridDim.y * 32 + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave) * 2;
+            abs_[0] = t_ - t_begin;              // s_memtime ticks and
+            abs_[1] = realtime() - rt_begin;     // 100 MHz reference ticks over the same span -> the clock s_memtime counts
+        }
+    }
+}
+#undef PHASE
+
+static int g_nt_sa = 1;  // tuning: rlppo_dbg_set(9, 0 | 1)
+void set_nt_sa(int v) { g_nt_sa = v; }
+
+template <int NB>
+static int launch_sa_1(hipStream_t st, dim3 grid, int epi, const float *A, unsigned lda_b, const float *B, unsigned ldb_b,
+                       const float *bias, const float *mask_src, unsigned ldm_b, float *C, unsigned ldc_b, int64_t M,
+                       int K) {
+#define SA(E)                                                                                                          \
+    case E:                                                                                                            \
+        hipLaunchKernelGGL((gemm_nt_sa_kernel<NB, E>), grid, dim3(256), 0, st, A, lda_b, B, ldb_b, bias, mask_src,     \
+                           ldm_b, C, ldc_b, M, K, nullptr);                                                            \
+        break;
+    switch (epi) {
+        SA(EPI_BIAS) SA(EPI_BIAS_RELU) SA(EPI_BIAS_TANH) SA(EPI_MASK)
+        default:
+            set_error("gemm_nt: bad epilogue %d", epi);
+            return RLPPO_ERR_ARG;
+    }
+#undef SA
+    RLPPO_LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_gemm_nt_sa_stamped(hipStream_t st, const float *A, int64_t lda, const float *B, int64_t ldb, const float *bias,
+                              float *C, int64_t ldc, int64_t M, int N, int K, unsigned long long *stamps) {
+    dim3 grid((unsigned)cdiv(M, SBM), (unsigned)(N / 128));
+    hipLaunchKernelGGL((gemm_nt_sa_kernel<8, EPI_BIAS_RELU, true>), grid, dim3(256), 0, st, A, (unsigned)(lda * 4), B,
+                       (unsigned)(ldb * 4), bias, nullptr, 0u, C, (unsigned)(ldc * 4), M, K, stamps);
+    RLPPO_LAUNCH_CHECK();
+    return 0;
+}
+
+// returns -1 when the scalar-addressed kernel does not apply (the caller falls through to gemm.hip's kernel).  Offsets
+// are relative to the workgroup's tile origin, so the 32-bit range only limits the leading dimensions.
+int launch_gemm_nt_sa(hipStream_t st, const float *A, int64_t lda, const float *B, int64_t ldb, const float *bias,
+                      const float *mask_src, int64_t ld_mask, float *C, int64_t ldc, int64_t M, int N, int nb, int K,
+                      int epi) {
+    if (!g_nt_sa) return -1;
+    const int64_t lim = (int64_t)1 << 31;
+    if (129 * lda * 4 >= lim || 129 * ldb * 4 >= lim || 129 * ldc * 4 >= lim || 129 * ld_mask * 4 >= lim) return -1;
+    dim3 grid((unsigned)cdiv(M, SBM), (unsigned)(N / (nb * 16)));
+    const unsigned la = (unsigned)(lda * 4), lb = (unsigned)(ldb * 4), lc = (unsigned)(ldc * 4), lm = (unsigned)(ld_mask * 4);
+    switch (nb) {
+        case 8: return launch_sa_1<8>(st, grid, epi, A, la, B, lb, bias, mask_src, lm, C, lc, M, K);
+        case 6: return launch_sa_1<6>(st, grid, epi, A, la, B, lb, bias, mask_src, lm, C, lc, M, K);
+        case 4: return launch_sa_1<4>(st, grid, epi, A, la, B, lb, bias, mask_src, lm, C, lc, M, K);
+        default: return launch_sa_1<2>(st, grid, epi, A, la, B, lb, bias, mask_src, lm, C, lc, M, K);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ gemm_tn, scalar-addressed
+// dW[out][in] += dY[M][out]^T . X[M][in], db[out] += colsum(dY): gemm.hip's gemm_tn_kernel (128 x 128 tile of dW per
+// workgroup, the sample axis split over blockIdx.z, fp32 atomics into the gradient arena) with buffer descriptors: the
+// staging loads, the range predicates (rows past the split, columns past the valid width) and the 64 accumulating
+// atomics per lane need no vector address arithmetic -- out-of-range lanes carry an offset beyond the descriptor and
+// the hardware drops them.
+namespace {
+constexpr int TM = 32;         // sample rows per LDS stage
+constexpr int TLD = 128 + 16;  // LDS row stride (floats): rows m and m+1 on opposite bank halves for ds_read_b32
+constexpr unsigned OOR = 0x80000000u;  // per-lane offset that fails every descriptor's range check
+}  // namespace
+
+__global__ __launch_bounds__(256, 2) void gemm_tn_sa_kernel(const float *__restrict__ dY, unsigned ldy_b, int ny_valid,
+                                                            const float *__restrict__ X, unsigned ldx_b, int kx_valid,
+                                                            float *__restrict__ dW, float *__restrict__ db, int out,
+                                                            int in, int64_t M, int rows_per_wg) {
+    __shared__ __attribute__((aligned(16))) float lds[2 * 2 * TM * TLD];
+    float *Ys = lds;                 // [2][TM][TLD]
+    float *Xs = lds + 2 * TM * TLD;  // [2][TM][TLD]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int r16 = lane & 15, q = lane >> 4;
+    const int wn = wave >> 1, wk = wave & 1;
+    const int n0 = blockIdx.x * 128, k0 = blockIdx.y * 128;
+    const int64_t mbeg = (int64_t)blockIdx.z * rows_per_wg;
+    const int rows = (int)((M - mbeg) < rows_per_wg ? (M - mbeg) : rows_per_wg);  // >= 1
+    const int steps = (rows + TM - 1) / TM;
+    const int ny_here = (ny_valid - n0) < 128 ? (ny_valid - n0) : 128;
+    const int kx_here = (kx_valid - k0) < 128 ? (kx_valid - k0) : 128;
+
+    const __amdgpu_buffer_rsrc_t y_rs = make_rsrc(reinterpret_cast<const char *>(dY) + mbeg * ldy_b + (int64_t)n0 * 4,
+                                                  (unsigned)(rows - 1) * ldy_b + (unsigned)ny_here * 4);
+    const __amdgpu_buffer_rsrc_t x_rs = make_rsrc(reinterpret_cast<const char *>(X) + mbeg * ldx_b + (int64_t)k0 * 4,
+                                                  (unsigned)(rows - 1) * ldx_b + (unsigned)kx_here * 4);
+    // staging: chunk = tid & 31 (16 B of a 128-float row), rows (tid >> 5) + 8 i
+    const int ld_chunk = tid & 31, ld_row = tid >> 5;
+    const unsigned y_off = (ld_chunk * 4 < ny_here) ? (unsigned)ld_row * ldy_b + ld_chunk * 16 : OOR;
+    const unsigned x_off = (ld_chunk * 4 < kx_here) ? (unsigned)ld_row * ldx_b + ld_chunk * 16 : OOR;
+    const unsigned y_row8 = 8u * ldy_b, x_row8 = 8u * ldx_b, y_stage = TM * ldy_b, x_stage = TM * ldx_b;  // uniform
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // db: every thread keeps the column sums of the dY rows IT stages (4 columns), straight from the staging registers
+    f32x4 bs4 = f32x4{0.f, 0.f, 0.f, 0.f};
+    const bool want_db = db != nullptr && blockIdx.y == 0;
+
+    f32x4 ry[4], rx[4];
+    const int st_off = ld_row * TLD + ld_chunk * 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        ry[i] = ldb(y_rs, y_off, i * y_row8);
+        rx[i] = ldb(x_rs, x_off, i * x_row8);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        *reinterpret_cast<f32x4 *>(&Ys[st_off + 8 * i * TLD]) = ry[i];
+        *reinterpret_cast<f32x4 *>(&Xs[st_off + 8 * i * TLD]) = rx[i];
+        if (want_db) bs4 += ry[i];
+    }
+    __syncthreads();
+    const int frag_y = q * TLD + wn * 64 + r16, frag_x = q * TLD + wk * 64 + r16;
+    for (int st = 0; st < steps; ++st) {
+        const int cur = st & 1;
+        const bool more = (st + 1) < steps;
+        if (more) {
+            const unsigned ys = (unsigned)(st + 1) * y_stage, xs = (unsigned)(st + 1) * x_stage;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                ry[i] = ldb(y_rs, y_off, ys + i * y_row8);
+                rx[i] = ldb(x_rs, x_off, xs + i * x_row8);
+            }
+        }
+        const float *Yc = Ys + cur * TM * TLD + frag_y;
+        const float *Xc = Xs + cur * TM * TLD + frag_x;
+#pragma unroll
+        for (int c = 0; c < TM / 16; ++c) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const int m = c * 16 + s * 4;  // + q: the row this lane's k-slot covers in step s
+                float fa[4], fb[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) fa[i] = Yc[m * TLD + i * 16];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) fb[j] = Xc[m * TLD + j * 16];
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[i][j] = MFMA16(fa[i], fb[j], acc[i][j]);
+            }
+        }
+        if (more) {
+            float *Yn = Ys + (cur ^ 1) * TM * TLD, *Xn = Xs + (cur ^ 1) * TM * TLD;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                *reinterpret_cast<f32x4 *>(&Yn[st_off + 8 * i * TLD]) = ry[i];
+                *reinterpret_cast<f32x4 *>(&Xn[st_off + 8 * i * TLD]) = rx[i];
+                if (want_db) bs4 += ry[i];
+            }
+        }
+        __syncthreads();
+    }
+
+    // D[n][k]: lane owns rows n = n0 + wn*64 + 16 i + 4 q + e, column k = k0 + wk*64 + 16 j + r16
+    const int out_here = (out - n0) < 128 ? (out - n0) : 128;
+    const int in_here = (in - k0) < 128 ? (in - k0) : 128;
+    if (out_here > 0 && in_here > 0) {
+        const unsigned in_b = (unsigned)in * 4;
+        const __amdgpu_buffer_rsrc_t w_rs = make_rsrc(dW + (int64_t)n0 * in + k0, (unsigned)(out_here - 1) * in_b + (unsigned)in_here * 4);
+        unsigned w_off[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            w_off[j] = (wk * 64 + j * 16 + r16 < in_here) ? (unsigned)(wn * 64 + q * 4) * in_b + (wk * 64 + j * 16 + r16) * 4 : OOR;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const unsigned row_s = (unsigned)(i * 16 + e) * in_b;  // uniform
+#pragma unroll
+                for (int j = 0; j < 4; ++j) __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(acc[i][j][e], w_rs, w_off[j], row_s, 0);
+            }
+    }
+    if (want_db) {  // 8 threads (tid >> 5) hold partial sums of the same 4 columns: fold them through LDS
+        float *red = lds;  // [8][128]; the staging buffers are dead (the loop ended with a barrier)
+        *reinterpret_cast<f32x4 *>(&red[ld_row * 128 + ld_chunk * 4]) = bs4;
+        __syncthreads();
+        if (tid < 128 && (n0 + tid) < out) {
+            float sum = 0.f;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) sum += red[r * 128 + tid];
+            atomicAdd(db + n0 + tid, sum);
+        }
+    }
+}
+
+// returns -1 when not applicable (gathered X, or a leading dimension too wide for 32-bit tile offsets)
+int launch_gemm_tn_sa(hipStream_t st, dim3 grid, const float *dY, int64_t ldy, int ny_valid, const float *X, int64_t ldx,
+                      int kx_valid, float *dW, float *db, int out, int in, int64_t M, int rows_per_wg) {
+    if (!g_nt_sa) return -1;
+    const int64_t lim = (int64_t)1 << 30;
+    if ((rows_per_wg + TM) * ldy * 4 >= lim || (rows_per_wg + TM) * ldx * 4 >= lim || (int64_t)129 * in * 4 >= lim) return -1;
+    hipLaunchKernelGGL(gemm_tn_sa_kernel, grid, dim3(256), 0, st, dY, (unsigned)(ldy * 4), ny_valid, X, (unsigned)(ldx * 4),
+                       kx_valid, dW, db, out, in, M, rows_per_wg);
+    RLPPO_LAUNCH_CHECK();
+    return 0;
+}
+}  // namespace rlppo

@@ -1,4 +1,4 @@
-"""A/B of the two gemm_nt forms (staged vs weights-stationary), interleaved in one process."""
+"""A/B of gemm_nt: per-lane 64-bit pointers (gemm.hip) vs scalar-addressed buffer loads (gemm_sa.hip), interleaved."""
 import ctypes, sys, os
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -23,7 +23,7 @@ for name,(A,lda,ri,ldb,C,ldc,n,k,epi,mask) in shapes.items():
     t = {0: [], 1: []}
     for _ in range(5):
         for v in (0, 1):
-            N.check(L.rlppo_dbg_set(3, v)); t[v].append(bench.time_region(fn, 10))
-    N.check(L.rlppo_dbg_set(3, 1))
+            N.check(L.rlppo_dbg_set(9, v)); t[v].append(bench.time_region(fn, 10))
+    N.check(L.rlppo_dbg_set(9, 1))
     fl = 2*M*n*k
-    print("%-26s staged %7.1f us %6.1f TF | stationary %7.1f us %6.1f TF" % (name, np.median(t[0])*1e3, fl/np.median(t[0])/1e9, np.median(t[1])*1e3, fl/np.median(t[1])/1e9))
+    print("%-26s vector-addressed %7.1f us %6.1f TF | scalar-addressed %7.1f us %6.1f TF" % (name, np.median(t[0])*1e3, fl/np.median(t[0])/1e9, np.median(t[1])*1e3, fl/np.median(t[1])/1e9))
