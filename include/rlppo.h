@@ -199,7 +199,13 @@ int rlppo_mt19937_permutation(uint32_t *state625, int64_t n, int64_t *out);
 /* ------------------------------------------------------------------------------------------ diagnostics */
 /* Single-kernel entry points used by tests/ to check each GEMM flavour in isolation against a CPU product.
  * epilogue: 0 bias, 1 bias+relu, 2 bias+tanh, 3 relu-mask (mask_src > 0).  Shapes as in csrc/gemm.hip. */
-/* Tuning switches for A/B measurements.  key 1: GAE algorithm (1 = single-pass look-back, default; 0 = two launches). */
+/* Tuning switches for A/B measurements (also RLPPO_TUNE="key=value,..." in the Python host).  Defaults in brackets.
+ *   1 GAE algorithm [1 single-pass look-back | 0 two launches]     2 gemm_tn rows per workgroup override [0 = table]
+ *   3 gemm.hip gemm_nt form [0 staged | 1 weights-stationary]      4 policy/critic chains on two streams [1]
+ *   5 gemm.hip gemm_nt K step [32 | 16]                            6 layer-fused chains [0]
+ *   7 gemm.hip gemm_nt stagger units [0]                           8 dW kernels on side streams [0]
+ *   9 gemm_nt kernel [3 LDS-DMA BK=16 | 2 LDS-DMA BK=32 | 1 scalar-addressed register staging | 0 gemm.hip]
+ *  10 gemm_tn kernel [2 LDS-DMA 32-row stages | 3 16-row stages | 1 scalar-addressed register staging | 0 gemm.hip] */
 int rlppo_dbg_set(int32_t key, int32_t value);
 /* Register-only fp32 MFMA loop: out[blocks*256] floats, clocks[2*blocks] = {shader cycles, 100 MHz ticks} per block. */
 /* GEMM inner-loop probe: 64 MFMAs per chunk + (mode&1) A fragments from LDS, (mode&2) B fragments from LDS, (mode&4) B

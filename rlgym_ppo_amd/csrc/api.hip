@@ -503,6 +503,10 @@ int rlppo_dbg_set(int32_t key, int32_t value) {
         set_nt_sa(value);
         return 0;
     }
+    if (key == 10) {
+        set_tn_sa(value);
+        return 0;
+    }
     set_error("dbg_set: unknown key %d", key);
     return RLPPO_ERR_ARG;
 }

@@ -51,6 +51,46 @@ __device__ __forceinline__ float relu1(float x) {  // one v_max_f32 (x > 0 ? x :
 }
 }  // namespace
 
+// epilogue shared by the nt kernels: lane owns C[m0 + wave*32 + 16 i + r16][n0 + 16 j + 4 q + (0..3)]; rows past M fall
+// outside the descriptor and are dropped by the range check
+template <int NB, int EPI>
+__device__ __forceinline__ void nt_epilogue(f32x4 (&acc)[2][NB], const float *mask_src, unsigned ldm_b, float *C, unsigned ldc_b,
+                                            int64_t m0, int n0, int rows_here, int wave, int r16, int q) {
+    constexpr int BN = NB * 16;
+    const int row_l = wave * 32 + r16;
+    const __amdgpu_buffer_rsrc_t c_rs = make_rsrc(reinterpret_cast<char *>(C) + m0 * ldc_b + (int64_t)n0 * 4,
+                                                  (unsigned)(rows_here - 1) * ldc_b + BN * 4);
+    const unsigned c_off = (unsigned)row_l * ldc_b + q * 16;
+    if (EPI == EPI_MASK) {
+        const __amdgpu_buffer_rsrc_t m_rs = make_rsrc(reinterpret_cast<const char *>(mask_src) + m0 * ldm_b + (int64_t)n0 * 4,
+                                                      (unsigned)(rows_here - 1) * ldm_b + BN * 4);
+        const unsigned m_off = (unsigned)row_l * ldm_b + q * 16;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                const f32x4 h = ldb(m_rs, m_off, 16 * i * ldm_b + j * 64);
+                f32x4 v = acc[i][j];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = h[e] > 0.f ? v[e] : 0.f;
+                stb(c_rs, c_off, 16 * i * ldc_b + j * 64, v);
+            }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                f32x4 v = acc[i][j];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (EPI == EPI_BIAS_RELU) v[e] = relu1(v[e]);
+                    if (EPI == EPI_BIAS_TANH) v[e] = tanhf(v[e]);
+                }
+                stb(c_rs, c_off, 16 * i * ldc_b + j * 64, v);
+            }
+    }
+}
+
 // STAMP: diagnostic build (rlppo_dbg_gemm_nt_stamped mode 64) that accumulates s_memtime cycles per phase into
 // stamps[workgroup][wave][8]: 0 prologue, 1 issue of the staging loads, 2 fragment reads + MFMA, 3 wait for the staged
 // loads, 4 LDS writes, 5 barrier, 6 epilogue, 7 whole kernel.  PHASE() compiles to nothing in the product kernels.
@@ -172,39 +212,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_sa_kernel(const float *__restr
         PHASE(5)
     }
 
-    // epilogue: lane owns C[m0 + wave*32 + 16 i + r16][n0 + 16 j + 4 q + (0..3)]; rows past M fall outside the descriptor
-    const int row_l = wave * 32 + r16;
-    const __amdgpu_buffer_rsrc_t c_rs = make_rsrc(reinterpret_cast<char *>(C) + m0 * ldc_b + (int64_t)n0 * 4,
-                                                  (unsigned)(rows_here - 1) * ldc_b + BN * 4);
-    const unsigned c_off = (unsigned)row_l * ldc_b + q * 16;
-    if (EPI == EPI_MASK) {
-        const __amdgpu_buffer_rsrc_t m_rs = make_rsrc(reinterpret_cast<const char *>(mask_src) + m0 * ldm_b + (int64_t)n0 * 4,
-                                                      (unsigned)(rows_here - 1) * ldm_b + BN * 4);
-        const unsigned m_off = (unsigned)row_l * ldm_b + q * 16;
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < NB; ++j) {
-                const f32x4 h = ldb(m_rs, m_off, 16 * i * ldm_b + j * 64);
-                f32x4 v = acc[i][j];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = h[e] > 0.f ? v[e] : 0.f;
-                stb(c_rs, c_off, 16 * i * ldc_b + j * 64, v);
-            }
-    } else {
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < NB; ++j) {
-                f32x4 v = acc[i][j];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    if (EPI == EPI_BIAS_RELU) v[e] = relu1(v[e]);
-                    if (EPI == EPI_BIAS_TANH) v[e] = tanhf(v[e]);
-                }
-                stb(c_rs, c_off, 16 * i * ldc_b + j * 64, v);
-            }
-    }
+    nt_epilogue<NB, EPI>(acc, mask_src, ldm_b, C, ldc_b, m0, n0, rows_here, wave, r16, q);
     if (STAMP) {
         PHASE(6)
         acc_t[7] = t_ - t_begin;
@@ -220,17 +228,131 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_sa_kernel(const float *__restr
 }
 #undef PHASE
 
-static int g_nt_sa = 1;  // tuning: rlppo_dbg_set(9, 0 | 1)
+// ------------------------------------------------------------------------------------------------ gemm_nt, LDS-DMA staging
+// Same tile, but the A/B tiles go global -> LDS directly (buffer_load_dwordx4 ... lds, 16 B per lane, 1 KiB per wave
+// instruction): no staging registers, no ds_write pass, no vector instruction at all between the MFMA streams.  One wave
+// instruction fills 64/CPR consecutive LDS rows; the XOR swizzle of the LDS image is applied to the SOURCE address (the LDS
+// side of an LDS-DMA is lane-linear).  BKT = 16 halves the LDS footprint (32 KiB) so that 4 workgroups share a CU.
+template <int BKT>
+__device__ __forceinline__ int dswz(int row, int chunk) {
+    if (BKT == 32) return row * 32 + ((chunk ^ (row & 7)) << 2);
+    return row * 16 + ((chunk ^ ((0 - (row >> 2)) & 3)) << 2);
+}
+
+template <int NB, int EPI, int BKT>
+__global__ __launch_bounds__(256, BKT == 16 ? 4 : 2) void gemm_nt_dma_kernel(const float *__restrict__ A, unsigned lda_b,
+                                                                              const float *__restrict__ B, unsigned ldb_b,
+                                                                              const float *__restrict__ bias,
+                                                                              const float *__restrict__ mask_src,
+                                                                              unsigned ldm_b, float *__restrict__ C,
+                                                                              unsigned ldc_b, int64_t M, int K) {
+    constexpr int BN = NB * 16;
+    constexpr int CPR = BKT / 4;     // 16-byte chunks per tile row
+    constexpr int RPW = 64 / CPR;    // tile rows one wave instruction fills
+    constexpr int RPP = 4 * RPW;     // rows per pass of the 4 waves
+    constexpr int A_IT = SBM / RPP, B_IT = BN / RPP;
+    static_assert(BN % RPP == 0, "column tile must be a whole number of staging passes");
+    __shared__ __attribute__((aligned(16))) float lds[2 * SBM * BKT + 2 * BN * BKT];
+    float *As = lds;
+    float *Bs = lds + 2 * SBM * BKT;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);  // provably uniform: it addresses the DMA destination (M0)
+    const int r16 = lane & 15, q = lane >> 4;
+    const int64_t m0 = (int64_t)blockIdx.x * SBM;
+    const int n0 = blockIdx.y * BN;
+    const int rows_here = (int)((M - m0) < SBM ? (M - m0) : SBM);
+
+    const __amdgpu_buffer_rsrc_t a_rs = make_rsrc(reinterpret_cast<const char *>(A) + m0 * lda_b,
+                                                  (unsigned)(rows_here - 1) * lda_b + (unsigned)K * 4);
+    const __amdgpu_buffer_rsrc_t b_rs = make_rsrc(reinterpret_cast<const char *>(B) + (int64_t)n0 * ldb_b,
+                                                  (unsigned)(BN - 1) * ldb_b + (unsigned)K * 4);
+    // lane -> (row, physical chunk) of the 1 KiB piece its wave instruction fills; it fetches the logical chunk that the
+    // swizzle maps there (rows of later passes keep the swizzle key, so one offset serves all passes)
+    const int row_p = wave * RPW + lane / CPR, pch = lane % CPR;
+    const int lch = BKT == 32 ? (pch ^ (row_p & 7)) : (pch ^ ((0 - (row_p >> 2)) & 3));
+    const unsigned a_off = (unsigned)row_p * lda_b + lch * 16;
+    const unsigned b_off = (unsigned)row_p * ldb_b + lch * 16;
+    const unsigned a_step = (unsigned)RPP * lda_b, b_step = (unsigned)RPP * ldb_b;
+
+    f32x4 acc[2][NB];
+    if (EPI == EPI_MASK) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < NB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    } else {
+        const __amdgpu_buffer_rsrc_t bias_rs = make_rsrc(bias + n0, BN * 4);
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            acc[0][j] = ldb(bias_rs, (unsigned)(q * 16), j * 64);
+            acc[1][j] = acc[0][j];
+        }
+    }
+
+    auto issue_tile = [&](int buf, unsigned kb) {
+        float *Ad = As + buf * SBM * BKT + wave_u * RPW * BKT;
+        float *Bd = Bs + buf * BN * BKT + wave_u * RPW * BKT;
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rs, Ad + i * RPP * BKT, 16, a_off, kb + i * a_step, 0, 0);
+#pragma unroll
+        for (int i = 0; i < B_IT; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(b_rs, Bd + i * RPP * BKT, 16, b_off, kb + i * b_step, 0, 0);
+    };
+
+    const int nk = K / BKT;
+    issue_tile(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if ((kt + 1) < nk) issue_tile(cur ^ 1, (unsigned)(kt + 1) * (BKT * 4));
+        const float *Ac = As + cur * SBM * BKT + (wave * 32) * BKT;
+        const float *Bc = Bs + cur * BN * BKT;
+#pragma unroll
+        for (int kc = 0; kc < BKT / 16; ++kc) {
+            f32x4 fa[2], fb[NB];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) fa[i] = *reinterpret_cast<const f32x4 *>(&Ac[dswz<BKT>(i * 16 + r16, kc * 4 + q)]);
+#pragma unroll
+            for (int j = 0; j < NB; ++j) fb[j] = *reinterpret_cast<const f32x4 *>(&Bc[dswz<BKT>(j * 16 + r16, kc * 4 + q)]);
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < NB; ++j) acc[i][j] = MFMA16(fb[j][s], fa[i][s], acc[i][j]);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of the next tile have landed in LDS
+        __syncthreads();
+    }
+    nt_epilogue<NB, EPI>(acc, mask_src, ldm_b, C, ldc_b, m0, n0, rows_here, wave, r16, q);
+}
+
+static int g_nt_sa = 3;  // tuning: rlppo_dbg_set(9, v): 0 gemm.hip kernel, 1 register-staged, 2 LDS-DMA BK=32, 3 LDS-DMA BK=16
+static int g_tn_sa = 2;  // tuning: rlppo_dbg_set(10, v): 0 gemm.hip kernel, 1 register-staged, 2 LDS-DMA 32-row stages, 3 16-row stages
 void set_nt_sa(int v) { g_nt_sa = v; }
+void set_tn_sa(int v) { g_tn_sa = v; }
 
 template <int NB>
 static int launch_sa_1(hipStream_t st, dim3 grid, int epi, const float *A, unsigned lda_b, const float *B, unsigned ldb_b,
                        const float *bias, const float *mask_src, unsigned ldm_b, float *C, unsigned ldc_b, int64_t M,
                        int K) {
+    constexpr bool can16 = (NB * 16) % 64 == 0;  // BK = 16 fills 64 tile rows per pass
+    const int variant = (g_nt_sa == 3 && !can16) ? 2 : g_nt_sa;
 #define SA(E)                                                                                                          \
     case E:                                                                                                            \
-        hipLaunchKernelGGL((gemm_nt_sa_kernel<NB, E>), grid, dim3(256), 0, st, A, lda_b, B, ldb_b, bias, mask_src,     \
-                           ldm_b, C, ldc_b, M, K, nullptr);                                                            \
+        if (variant == 3)                                                                                              \
+            hipLaunchKernelGGL((gemm_nt_dma_kernel<NB, E, can16 ? 16 : 32>), grid, dim3(256), 0, st, A, lda_b, B,      \
+                               ldb_b, bias, mask_src, ldm_b, C, ldc_b, M, K);                                          \
+        else if (variant == 2)                                                                                         \
+            hipLaunchKernelGGL((gemm_nt_dma_kernel<NB, E, 32>), grid, dim3(256), 0, st, A, lda_b, B, ldb_b, bias,      \
+                               mask_src, ldm_b, C, ldc_b, M, K);                                                       \
+        else                                                                                                           \
+            hipLaunchKernelGGL((gemm_nt_sa_kernel<NB, E>), grid, dim3(256), 0, st, A, lda_b, B, ldb_b, bias, mask_src, \
+                               ldm_b, C, ldc_b, M, K, nullptr);                                                        \
         break;
     switch (epi) {
         SA(EPI_BIAS) SA(EPI_BIAS_RELU) SA(EPI_BIAS_TANH) SA(EPI_MASK)
@@ -408,14 +530,163 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_sa_kernel(const float *__restr
     }
 }
 
+// ------------------------------------------------------------------------------------------------ gemm_tn, LDS-DMA staging
+// The dY / X stages go global -> LDS by buffer_load ... lds: a 1 KiB piece = 2 stage rows of 128 floats.  The LDS image is
+// unpadded; rows m..m+3 of one 16-float column group (what a ds_read_b32 fragment read touches) are spread over the banks
+// by XOR-ing the 16-byte chunk index with (m & 3) << 2, applied on the SOURCE address.  db column sums are read back from
+// the staged dY tile (only by the workgroups of the first k tile).  TMT = 16 halves the LDS footprint: 4 workgroups per CU.
+template <int TMT>
+__global__ __launch_bounds__(256, TMT == 16 ? 4 : 2) void gemm_tn_dma_kernel(const float *__restrict__ dY, unsigned ldy_b,
+                                                                              int ny_valid, const float *__restrict__ X,
+                                                                              unsigned ldx_b, int kx_valid,
+                                                                              float *__restrict__ dW, float *__restrict__ db,
+                                                                              int out, int in, int64_t M, int rows_per_wg) {
+    constexpr int PPW = TMT / 8;  // 1 KiB pieces per wave, per operand and stage
+    __shared__ __attribute__((aligned(16))) float lds[2 * 2 * TMT * 128 < 8 * 128 ? 8 * 128 : 2 * 2 * TMT * 128];
+    float *Ys = lds;                 // [2][TMT][128]
+    float *Xs = lds + 2 * TMT * 128;  // [2][TMT][128]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const int r16 = lane & 15, q = lane >> 4;
+    const int wn = wave >> 1, wk = wave & 1;
+    const int n0 = blockIdx.x * 128, k0 = blockIdx.y * 128;
+    const int64_t mbeg = (int64_t)blockIdx.z * rows_per_wg;
+    const int rows = (int)((M - mbeg) < rows_per_wg ? (M - mbeg) : rows_per_wg);  // >= 1
+    const int steps = (rows + TMT - 1) / TMT;
+    const int rem = rows - (steps - 1) * TMT;  // rows of the last stage, 1..TMT
+    const int ny_here = (ny_valid - n0) < 128 ? (ny_valid - n0) : 128;
+    const int kx_here = (kx_valid - k0) < 128 ? (kx_valid - k0) : 128;
+
+    const __amdgpu_buffer_rsrc_t y_rs = make_rsrc(reinterpret_cast<const char *>(dY) + mbeg * ldy_b + (int64_t)n0 * 4,
+                                                  (unsigned)(rows - 1) * ldy_b + (unsigned)ny_here * 4);
+    const __amdgpu_buffer_rsrc_t x_rs = make_rsrc(reinterpret_cast<const char *>(X) + mbeg * ldx_b + (int64_t)k0 * 4,
+                                                  (unsigned)(rows - 1) * ldx_b + (unsigned)kx_here * 4);
+    // DMA lane map: piece = rows 2 (wave + 4 i) + (lane >> 5); physical chunk lane & 31 holds logical chunk ^ ((row & 3) << 2)
+    const int row_l = 2 * wave + (lane >> 5);
+    const int lch = (lane & 31) ^ ((row_l & 3) << 2);
+    const unsigned y_off = (lch * 4 < ny_here) ? (unsigned)row_l * ldy_b + lch * 16 : OOR;
+    const unsigned x_off = (lch * 4 < kx_here) ? (unsigned)row_l * ldx_b + lch * 16 : OOR;
+    const unsigned y_row8 = 8u * ldy_b, x_row8 = 8u * ldx_b, y_stage = TMT * ldy_b, x_stage = TMT * ldx_b;  // uniform
+
+    auto issue_stage = [&](int buf, int stage) {
+        float *Yd = Ys + (buf * TMT + 2 * wave_u) * 128, *Xd = Xs + (buf * TMT + 2 * wave_u) * 128;
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(y_rs, Yd + 8 * i * 128, 16, y_off, (unsigned)stage * y_stage + i * y_row8, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rs, Xd + 8 * i * 128, 16, x_off, (unsigned)stage * x_stage + i * x_row8, 0, 0);
+        }
+    };
+    // a ragged last stage: the DMA drops the rows past the split, so their (stale) LDS rows are cleared by hand
+    const int zr = tid >> 5, zc = (tid & 31) * 4;
+    auto clear_tail = [&](int buf) {
+        const f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int r = rem + zr; r < TMT; r += 8) {
+            *reinterpret_cast<f32x4 *>(&Ys[(buf * TMT + r) * 128 + zc]) = z;
+            *reinterpret_cast<f32x4 *>(&Xs[(buf * TMT + r) * 128 + zc]) = z;
+        }
+    };
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 bs4 = f32x4{0.f, 0.f, 0.f, 0.f};
+    const bool want_db = db != nullptr && blockIdx.y == 0;
+
+    issue_stage(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (steps == 1 && rem < TMT) clear_tail(0);
+    __syncthreads();
+    // fragment addresses: element (m, col) lives at m*128 + (col ^ ((m & 3) << 4)); m & 3 == q for every fragment read
+    int fy[4], fx[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        fy[i] = q * 128 + wn * 64 + ((i ^ q) << 4) + r16;
+        fx[i] = q * 128 + wk * 64 + ((i ^ q) << 4) + r16;
+    }
+    const int db_off = zr * 128 + zc;  // db partial sums: rows zr + 8 i, physical chunk tid & 31
+    for (int st = 0; st < steps; ++st) {
+        const int cur = st & 1;
+        const bool more = (st + 1) < steps;
+        if (more) issue_stage(cur ^ 1, st + 1);
+        const float *Yc = Ys + cur * TMT * 128;
+        const float *Xc = Xs + cur * TMT * 128;
+        if (want_db) {
+#pragma unroll
+            for (int i = 0; i < PPW; ++i) bs4 += *reinterpret_cast<const f32x4 *>(&Yc[db_off + 8 * i * 128]);
+        }
+#pragma unroll
+        for (int c = 0; c < TMT / 16; ++c) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const int m = c * 16 + s * 4;  // + q
+                float fa[4], fb[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) fa[i] = Yc[m * 128 + fy[i]];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) fb[j] = Xc[m * 128 + fx[j]];
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[i][j] = MFMA16(fa[i], fb[j], acc[i][j]);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (more && (st + 2) == steps && rem < TMT) clear_tail(cur ^ 1);
+        __syncthreads();
+    }
+
+    // D[n][k]: lane owns rows n = n0 + wn*64 + 16 i + 4 q + e, column k = k0 + wk*64 + 16 j + r16
+    const int out_here = (out - n0) < 128 ? (out - n0) : 128;
+    const int in_here = (in - k0) < 128 ? (in - k0) : 128;
+    if (out_here > 0 && in_here > 0) {
+        const unsigned in_b = (unsigned)in * 4;
+        const __amdgpu_buffer_rsrc_t w_rs = make_rsrc(dW + (int64_t)n0 * in + k0, (unsigned)(out_here - 1) * in_b + (unsigned)in_here * 4);
+        unsigned w_off[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            w_off[j] = (wk * 64 + j * 16 + r16 < in_here) ? (unsigned)(wn * 64 + q * 4) * in_b + (wk * 64 + j * 16 + r16) * 4 : OOR;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const unsigned row_s = (unsigned)(i * 16 + e) * in_b;  // uniform
+#pragma unroll
+                for (int j = 0; j < 4; ++j) __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(acc[i][j][e], w_rs, w_off[j], row_s, 0);
+            }
+    }
+    if (want_db) {  // 8 threads (tid >> 5) hold partial sums of the same 4 columns: fold them through LDS
+        float *red = lds;  // [8][128]; the staging buffers are dead (the loop ended with a barrier)
+        const int lcol = ((tid & 31) ^ ((zr & 3) << 2)) * 4;  // the logical columns this thread's physical chunk holds
+        *reinterpret_cast<f32x4 *>(&red[zr * 128 + lcol]) = bs4;
+        __syncthreads();
+        if (tid < 128 && (n0 + tid) < out) {
+            float sum = 0.f;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) sum += red[r * 128 + tid];
+            atomicAdd(db + n0 + tid, sum);
+        }
+    }
+}
+
 // returns -1 when not applicable (gathered X, or a leading dimension too wide for 32-bit tile offsets)
 int launch_gemm_tn_sa(hipStream_t st, dim3 grid, const float *dY, int64_t ldy, int ny_valid, const float *X, int64_t ldx,
                       int kx_valid, float *dW, float *db, int out, int in, int64_t M, int rows_per_wg) {
-    if (!g_nt_sa) return -1;
+    if (!g_tn_sa) return -1;
     const int64_t lim = (int64_t)1 << 30;
     if ((rows_per_wg + TM) * ldy * 4 >= lim || (rows_per_wg + TM) * ldx * 4 >= lim || (int64_t)129 * in * 4 >= lim) return -1;
-    hipLaunchKernelGGL(gemm_tn_sa_kernel, grid, dim3(256), 0, st, dY, (unsigned)(ldy * 4), ny_valid, X, (unsigned)(ldx * 4),
-                       kx_valid, dW, db, out, in, M, rows_per_wg);
+    if (g_tn_sa == 3)
+        hipLaunchKernelGGL(gemm_tn_dma_kernel<16>, grid, dim3(256), 0, st, dY, (unsigned)(ldy * 4), ny_valid, X,
+                           (unsigned)(ldx * 4), kx_valid, dW, db, out, in, M, rows_per_wg);
+    else if (g_tn_sa == 2)
+        hipLaunchKernelGGL(gemm_tn_dma_kernel<32>, grid, dim3(256), 0, st, dY, (unsigned)(ldy * 4), ny_valid, X,
+                           (unsigned)(ldx * 4), kx_valid, dW, db, out, in, M, rows_per_wg);
+    else
+        hipLaunchKernelGGL(gemm_tn_sa_kernel, grid, dim3(256), 0, st, dY, (unsigned)(ldy * 4), ny_valid, X, (unsigned)(ldx * 4),
+                           kx_valid, dW, db, out, in, M, rows_per_wg);
     RLPPO_LAUNCH_CHECK();
     return 0;
 }

@@ -18,12 +18,13 @@ shapes = {
  "dX hidden mask": (A256,256,None,256,C256,256,256,256,3,A256),
  "dX head 96->256": (A96,96,None,96,C256,256,256,96,3,A256),
  "dX vhead 32->256": (A32,32,None,32,C256,256,256,32,3,A256)}
+variants = {0: "vector-addr", 1: "scalar-addr", 2: "LDS-DMA BK32", 3: "LDS-DMA BK16"}
 for name,(A,lda,ri,ldb,C,ldc,n,k,epi,mask) in shapes.items():
     fn = lambda: N.check(L.rlppo_dbg_gemm_nt(st(), P(A), lda, P(ri), P(W), ldb, P(bias), P(mask), n, P(C), ldc, M, n, k, epi))
-    t = {0: [], 1: []}
+    t = {v: [] for v in variants}
     for _ in range(5):
-        for v in (0, 1):
+        for v in variants:
             N.check(L.rlppo_dbg_set(9, v)); t[v].append(bench.time_region(fn, 10))
-    N.check(L.rlppo_dbg_set(9, 1))
+    N.check(L.rlppo_dbg_set(9, 3))
     fl = 2*M*n*k
-    print("%-26s vector-addressed %7.1f us %6.1f TF | scalar-addressed %7.1f us %6.1f TF" % (name, np.median(t[0])*1e3, fl/np.median(t[0])/1e9, np.median(t[1])*1e3, fl/np.median(t[1])/1e9))
+    print("%-24s" % name + " | ".join("%s %6.1f us %6.1f TF" % (variants[v], np.median(t[v])*1e3, fl/np.median(t[v])/1e9) for v in variants))

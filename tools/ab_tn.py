@@ -10,13 +10,13 @@ A128, A256, A96, A32 = (torch.randn(M, k, device=dev) for k in (128, 256, 96, 32
 dW = torch.zeros(256 * 256, device=dev); db = torch.zeros(256, device=dev)
 shapes = {"hidden 256x256": (A256, 256, A256, 256, 256, 256), "L0 256x107 (no gather)": (A256, 256, A128, 128, 256, 107),
           "head 90x256": (A96, 96, A256, 256, 90, 256), "vhead 1x256": (A32, 32, A256, 256, 1, 256)}
+variants = {0: "vector-addr", 1: "scalar-addr", 2: "LDS-DMA TM32", 3: "LDS-DMA TM16"}
 for name, (dY, ny, X, kx, out, in_) in shapes.items():
     fn = lambda: N.check(L.rlppo_dbg_gemm_tn(st(), P(dY), ny, ny, P(X), kx, None, kx, P(dW), P(db), out, in_, M))
-    t = {0: [], 1: []}
+    t = {v: [] for v in variants}
     for _ in range(5):
-        for v in (0, 1):
-            N.check(L.rlppo_dbg_set(9, v)); t[v].append(bench.time_region(fn, 10))
-    N.check(L.rlppo_dbg_set(9, 1))
+        for v in variants:
+            N.check(L.rlppo_dbg_set(10, v)); t[v].append(bench.time_region(fn, 10))
+    N.check(L.rlppo_dbg_set(10, 2))
     fl = 2 * M * ny * kx
-    print("%-24s vector-addressed %7.1f us %6.1f TF | scalar-addressed %7.1f us %6.1f TF" % (
-        name, np.median(t[0]) * 1e3, fl / np.median(t[0]) / 1e9, np.median(t[1]) * 1e3, fl / np.median(t[1]) / 1e9))
+    print("%-24s" % name + " | ".join("%s %6.1f us %6.1f TF" % (variants[v], np.median(t[v])*1e3, fl/np.median(t[v])/1e9) for v in variants))
