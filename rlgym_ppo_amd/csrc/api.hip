@@ -241,6 +241,7 @@ static int g_two_streams = 1;  // tuning: rlppo_dbg_set(4, 0/1)
 // Library-owned streams: slot s > 0 runs its policy chain on g_main[s]; every slot runs its critic chain on g_side[s].
 static hipStream_t g_main[RLPPO_MAX_SLOTS] = {}, g_side[RLPPO_MAX_SLOTS] = {}, g_dw[RLPPO_MAX_SLOTS][2] = {};
 static hipEvent_t g_ev_dw[RLPPO_MAX_SLOTS][2][RLPPO_MAX_LAYERS + 1] = {};
+static int g_pregather = 1;  // tuning: rlppo_dbg_set(11, 0/1): gather the minibatch's states once instead of in 4 GEMMs
 static int g_dw_streams = 0;  // tuning: rlppo_dbg_set(8, 0/1); measured slower (14.4 vs 12.7 ms/epoch, tools/ab_update.py)
 static hipEvent_t g_ev_fork[RLPPO_MAX_SLOTS] = {}, g_ev_join[RLPPO_MAX_SLOTS] = {}, g_ev_slot[RLPPO_MAX_SLOTS] = {};
 static bool g_slot_pending[RLPPO_MAX_SLOTS] = {};
@@ -272,6 +273,7 @@ static size_t train_ws_floats(const NetLayout &pol, const NetLayout &val, int64_
     for (int l = 0; l < val.n_layers; ++l) per_row += val.L[l].pout;
     int m = max_pout(pol) > max_pout(val) ? max_pout(pol) : max_pout(val);
     per_row += (size_t)(pol.n_layers - 1 + val.n_layers - 1) * (size_t)m;  // one dX buffer per layer and net
+    per_row += (size_t)pol.L[0].pin;                                         // the gathered minibatch states
     return per_row * (size_t)mb;
 }
 
@@ -336,6 +338,8 @@ int rlppo_ppo_minibatch(void *stream, const rlppo_minibatch_args *a) {
     RLPPO_CHECK_ARG(pol.L[0].in == val.L[0].in, "ppo_minibatch: policy and critic observe different sizes");
     RLPPO_CHECK_ARG(a->ld_states >= pol.L[0].pin && a->ld_states % 4 == 0, "ppo_minibatch: ld_states=%ld < %d",
                     (long)a->ld_states, pol.L[0].pin);
+    RLPPO_CHECK_ARG(pol.L[0].in == val.L[0].in, "ppo_minibatch: policy and critic read the same states (%d vs %d inputs)",
+                    pol.L[0].in, val.L[0].in);
     if (a->ws_bytes < train_ws_floats(pol, val, mb) * sizeof(float)) {
         set_error("ppo_minibatch: workspace %zu < %zu bytes", a->ws_bytes, train_ws_floats(pol, val, mb) * sizeof(float));
         return RLPPO_ERR_WORKSPACE;
@@ -380,7 +384,20 @@ int rlppo_ppo_minibatch(void *stream, const rlppo_minibatch_args *a) {
         w += (size_t)mb * m;
     }
 
-    // forward of both nets; the minibatch gather (experience_buffer.py:82-87) is fused into the first layer's loads
+    // the minibatch gather (experience_buffer.py:82-87): one pass into the workspace, shared by both nets
+    const float *states = a->states;
+    int64_t ld_states = a->ld_states;
+    const int64_t *gidx = a->idx;
+    if (g_pregather) {
+        float *xg = w;
+        w += (size_t)mb * pol.L[0].pin;
+        rc = launch_gather_rows(st, a->states, a->ld_states, a->idx, xg, pol.L[0].pin, mb);
+        if (rc) return rc;
+        states = xg;
+        ld_states = pol.L[0].pin;
+        gidx = nullptr;
+    }
+    // forward of both nets (with rlppo_dbg_set(11, 0) the gather is fused into the first layer's loads instead)
     // The two networks are independent until the loss epilogue and again after it, so their launch chains run on
     // two streams (the caller's + one library-owned side stream, forked/joined with events: capturable).  Each
     // launch is only 50-100 us long at K <= 256, so letting one chain's kernels fill the CUs that the other chain's
@@ -391,9 +408,9 @@ int rlppo_ppo_minibatch(void *stream, const rlppo_minibatch_args *a) {
         rc = order_after(side, st, g_ev_fork[slot]);
         if (rc) return rc;
     }
-    rc = forward(side, val, a->val_packed, a->states, a->ld_states, a->idx, mb, 0, vact);
+    rc = forward(side, val, a->val_packed, states, ld_states, gidx, mb, 0, vact);
     if (rc) return rc;
-    rc = forward(st, pol, a->pol_packed, a->states, a->ld_states, a->idx, mb, a->head == RLPPO_HEAD_GAUSSIAN, pact);
+    rc = forward(st, pol, a->pol_packed, states, ld_states, gidx, mb, a->head == RLPPO_HEAD_GAUSSIAN, pact);
     if (rc) return rc;
     if (side != st) {
         rc = order_after(st, side, g_ev_join[slot]);
@@ -431,9 +448,9 @@ int rlppo_ppo_minibatch(void *stream, const rlppo_minibatch_args *a) {
         rc = order_after(side, st, g_ev_fork[slot]);
         if (rc) return rc;
     }
-    rc = backward(side, g_dw_streams ? g_dw[slot][1] : side, g_ev_dw[slot][1], val, a->val_packed, a->states, a->ld_states, a->idx, mb, vact, vdx, a->val_grad);
+    rc = backward(side, g_dw_streams ? g_dw[slot][1] : side, g_ev_dw[slot][1], val, a->val_packed, states, ld_states, gidx, mb, vact, vdx, a->val_grad);
     if (rc) return rc;
-    rc = backward(st, g_dw_streams ? g_dw[slot][0] : st, g_ev_dw[slot][0], pol, a->pol_packed, a->states, a->ld_states, a->idx, mb, pact, pdx, a->pol_grad);
+    rc = backward(st, g_dw_streams ? g_dw[slot][0] : st, g_ev_dw[slot][0], pol, a->pol_packed, states, ld_states, gidx, mb, pact, pdx, a->pol_grad);
     if (rc) return rc;
     if (side != st) rc = order_after(st, side, g_ev_join[slot]);
     return rc;
@@ -505,6 +522,10 @@ int rlppo_dbg_set(int32_t key, int32_t value) {
     }
     if (key == 10) {
         set_tn_sa(value);
+        return 0;
+    }
+    if (key == 11) {
+        g_pregather = value;
         return 0;
     }
     set_error("dbg_set: unknown key %d", key);

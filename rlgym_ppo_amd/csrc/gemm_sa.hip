@@ -325,6 +325,7 @@ __global__ __launch_bounds__(256, BKT == 16 ? 4 : 2) void gemm_nt_dma_kernel(con
 #pragma unroll
                     for (int j = 0; j < NB; ++j) acc[i][j] = MFMA16(fb[j][s], fa[i][s], acc[i][j]);
         }
+        __builtin_amdgcn_sched_barrier(0);  // keep the MFMAs above the wait: they are what hides the DMA latency
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of the next tile have landed in LDS
         __syncthreads();
     }
@@ -634,6 +635,7 @@ __global__ __launch_bounds__(256, TMT == 16 ? 4 : 2) void gemm_tn_dma_kernel(con
                     for (int j = 0; j < 4; ++j) acc[i][j] = MFMA16(fa[i], fb[j], acc[i][j]);
             }
         }
+        __builtin_amdgcn_sched_barrier(0);  // keep the MFMAs above the wait: they are what hides the DMA latency
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (more && (st + 2) == steps && rem < TMT) clear_tail(cur ^ 1);
         __syncthreads();

@@ -65,6 +65,32 @@ __global__ __launch_bounds__(256) void pad_rows_kernel(const T *__restrict__ src
     }
 }
 
+// Minibatch gather (experience_buffer.py:82-87): dst[r][0..width) = src[idx[r]][0..width), 16 bytes per thread.  One pass
+// per minibatch, shared by the policy and the critic: the four first-layer GEMMs (two forwards, two dW) then read
+// contiguous rows through the LDS-DMA kernels instead of each chasing the index vector.
+__global__ __launch_bounds__(256) void gather_rows_kernel(const float *__restrict__ src, int64_t ld_src,
+                                                          const int64_t *__restrict__ idx, float *__restrict__ dst,
+                                                          int chunks_per_row, int64_t n) {
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t row = t / chunks_per_row;
+    const int c = (int)(t - row * chunks_per_row);
+    if (row >= n) return;
+    const f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(src + idx[row] * ld_src) + c);
+    reinterpret_cast<f32x4 *>(dst)[t] = v;
+}
+
+int launch_gather_rows(hipStream_t st, const float *src, int64_t ld_src, const int64_t *idx, float *dst, int width,
+                       int64_t n) {
+    if (n <= 0) return 0;
+    RLPPO_CHECK_ARG(width > 0 && width % 4 == 0 && ld_src >= width && ld_src % 4 == 0, "gather_rows: width=%d ld=%ld", width,
+                    (long)ld_src);
+    const int cpr = width / 4;
+    hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)cdiv(n * cpr, 256)), dim3(256), 0, st, src, ld_src, idx, dst, cpr, n);
+    RLPPO_LAUNCH_CHECK();
+    return 0;
+}
+
 int launch_pad_rows(hipStream_t st, const void *src, int is_f64, int64_t n, int64_t d, int64_t ld_src, float *dst,
                     int64_t ld_dst, int standardize, float mean0, float std0) {
     if (n <= 0) return 0;
