@@ -528,6 +528,14 @@ int rlppo_dbg_set(int32_t key, int32_t value) {
         g_pregather = value;
         return 0;
     }
+    if (key == 12) {
+        set_tn_rows_big(value);
+        return 0;
+    }
+    if (key == 13) {
+        set_loss16(value);
+        return 0;
+    }
     set_error("dbg_set: unknown key %d", key);
     return RLPPO_ERR_ARG;
 }

@@ -88,6 +88,8 @@ int launch_gemm_nt_sa(hipStream_t st, const float *A, int64_t lda, const float *
                       const float *mask_src, int64_t ld_mask, float *C, int64_t ldc, int64_t M, int N, int nb, int K, int epi);
 void set_nt_sa(int v);
 void set_tn_sa(int v);
+void set_loss16(int v);
+void set_tn_rows_big(int r);
 int launch_gemm_tn_sa(hipStream_t st, dim3 grid, const float *dY, int64_t ldy, int ny_valid, const float *X, int64_t ldx,
                       int kx_valid, float *dW, float *db, int out, int in, int64_t M, int rows_per_wg);
 int launch_gemm_nt_sa_stamped(hipStream_t st, const float *A, int64_t lda, const float *B, int64_t ldb, const float *bias,

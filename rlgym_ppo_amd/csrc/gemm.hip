@@ -446,6 +446,10 @@ int launch_gemm_nt(hipStream_t st, const float *A, int64_t lda, const int64_t *r
 // ------------------------------------------------------------------------------------------------- gemm_tn
 static int g_tn_rows_override = 0;  // tuning: rlppo_dbg_set(2, rows)
 void set_tn_rows(int r) { g_tn_rows_override = r; }
+// tuning: rlppo_dbg_set(12, rows): split of products with >= 4 output tiles.  With the LDS-DMA kernel and the two chains
+// overlapping (bench.py, M samples/s): 512 rows 49.2, 640 50.4, 768 50.7-50.9, 896 50.3, 1024 49.8
+static int g_tn_rows_big = 768;
+void set_tn_rows_big(int r) { g_tn_rows_big = r; }
 constexpr int TM = 32;        // sample rows per LDS stage
 constexpr int TLD = 128 + 16; // LDS row stride (floats): +16 puts rows m and m+1 on opposite bank halves (ds_read_b32)
 
@@ -586,6 +590,7 @@ int launch_gemm_tn(hipStream_t st, const float *dY, int64_t ldy, int ny_valid, c
     //   1x256        48.6   44.6   52.7   95.7  188.3
     const int64_t tiles = cdiv(out, 128) * cdiv(in, 128);
     int64_t rows = tiles >= 2 ? 512 : 256;
+    if (tiles >= 4 && g_tn_rows_big > 0) rows = g_tn_rows_big;
     if (M < 64 * rows) rows = round_up(cdiv(M, 64) > 32 ? cdiv(M, 64) : 32, TM);  // small M: still use the chip
     if (g_tn_rows_override > 0) rows = g_tn_rows_override;
     const int rows_per_wg = (int)rows;

@@ -44,11 +44,10 @@ __device__ __forceinline__ f32x4 ldb(__amdgpu_buffer_rsrc_t r, unsigned voff, un
 __device__ __forceinline__ void stb(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, f32x4 v) {
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, voff, soff, 0);
 }
-__device__ __forceinline__ float relu1(float x) {  // one v_max_f32 (x > 0 ? x : 0 compiles to two: NaN canonicalisation)
-    float y;
-    asm("v_max_f32 %0, 0, %1" : "=v"(y) : "v"(x));
-    return y;
-}
+// relu in ONE compiler-visible instruction: v_med3_f32(x, 0, +inf).  (x > 0 ? x : 0 compiles to two v_max because of NaN
+// canonicalisation; an inline-asm v_max is invisible to the MFMA -> VALU hazard recogniser and read accumulators early:
+// rare wrong activations under load, found by the 2-rank test.)  NaN -> 0 like the select form.
+__device__ __forceinline__ float relu1(float x) { return __builtin_amdgcn_fmed3f(x, 0.f, __builtin_inff()); }
 }  // namespace
 
 // epilogue shared by the nt kernels: lane owns C[m0 + wave*32 + 16 i + r16][n0 + 16 j + 4 q + (0..3)]; rows past M fall
@@ -61,6 +60,10 @@ __device__ __forceinline__ void nt_epilogue(f32x4 (&acc)[2][NB], const float *ma
     const __amdgpu_buffer_rsrc_t c_rs = make_rsrc(reinterpret_cast<char *>(C) + m0 * ldc_b + (int64_t)n0 * 4,
                                                   (unsigned)(rows_here - 1) * ldc_b + BN * 4);
     const unsigned c_off = (unsigned)row_l * ldc_b + q * 16;
+    // The activation is applied IN PLACE over the accumulators first and the stores are issued afterwards, from registers
+    // that nothing writes again.  With a shared temporary (store v[0:3]; next v_max overwrites v0..v3) the 16-byte buffer
+    // stores were seen to pick up the NEXT block's values when the memory pipeline is backed up by another process
+    // (scratch/stress_nt.py; the compiler's hazard table treats a buffer store with an SGPR soffset as safe to overwrite).
     if (EPI == EPI_MASK) {
         const __amdgpu_buffer_rsrc_t m_rs = make_rsrc(reinterpret_cast<const char *>(mask_src) + m0 * ldm_b + (int64_t)n0 * 4,
                                                       (unsigned)(rows_here - 1) * ldm_b + BN * 4);
@@ -70,25 +73,25 @@ __device__ __forceinline__ void nt_epilogue(f32x4 (&acc)[2][NB], const float *ma
 #pragma unroll
             for (int j = 0; j < NB; ++j) {
                 const f32x4 h = ldb(m_rs, m_off, 16 * i * ldm_b + j * 64);
-                f32x4 v = acc[i][j];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = h[e] > 0.f ? v[e] : 0.f;
-                stb(c_rs, c_off, 16 * i * ldc_b + j * 64, v);
+                for (int e = 0; e < 4; ++e) acc[i][j][e] = h[e] > 0.f ? acc[i][j][e] : 0.f;
             }
-    } else {
+    } else if (EPI != EPI_BIAS) {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int j = 0; j < NB; ++j) {
-                f32x4 v = acc[i][j];
+            for (int j = 0; j < NB; ++j)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    if (EPI == EPI_BIAS_RELU) v[e] = relu1(v[e]);
-                    if (EPI == EPI_BIAS_TANH) v[e] = tanhf(v[e]);
+                    if (EPI == EPI_BIAS_RELU) acc[i][j][e] = relu1(acc[i][j][e]);
+                    if (EPI == EPI_BIAS_TANH) acc[i][j][e] = tanhf(acc[i][j][e]);
                 }
-                stb(c_rs, c_off, 16 * i * ldc_b + j * 64, v);
-            }
     }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j) stb(c_rs, c_off, 16 * i * ldc_b + j * 64, acc[i][j]);
 }
 
 // STAMP: diagnostic build (rlppo_dbg_gemm_nt_stamped mode 64) that accumulates s_memtime cycles per phase into

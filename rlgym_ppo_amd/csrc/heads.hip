@@ -240,13 +240,144 @@ __global__ __launch_bounds__(256) void discrete_loss_kernel(float *__restrict__ 
     block_stats_add(stats, st, true);
 }
 
+// ---- 16 lanes per row (padded width <= 128): a wave works on 4 rows at once, a lane holds 8 CONSECUTIVE logits (two
+// 16-byte loads/stores) and the six per-row reductions are 4 DPP steps inside a 16-lane row instead of 6 cross-lane
+// shuffles of a whole wave.  Same arithmetic chain as discrete_loss_kernel; only the summation order inside a row differs.
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+// all-reduce over a 16-lane DPP row: xor 1, xor 2 (quad_perm), then half-row mirror and row mirror (every lane of a quad /
+// half row already holds the same partial, so a mirror is as good as an xor)
+__device__ __forceinline__ float row16_sum(float v) {
+    v += dpp_mov<0xB1>(v);
+    v += dpp_mov<0x4E>(v);
+    v += dpp_mov<0x141>(v);
+    v += dpp_mov<0x140>(v);
+    return v;
+}
+__device__ __forceinline__ float row16_max(float v) {
+    v = fmaxf(v, dpp_mov<0xB1>(v));
+    v = fmaxf(v, dpp_mov<0x4E>(v));
+    v = fmaxf(v, dpp_mov<0x141>(v));
+    v = fmaxf(v, dpp_mov<0x140>(v));
+    return v;
+}
+
+__global__ __launch_bounds__(256) void discrete_loss16_kernel(float *__restrict__ logits, int64_t ld, int A,
+                                                               float *__restrict__ vout, int64_t ldv,
+                                                               const int64_t *__restrict__ idx,
+                                                               const float *__restrict__ actions,
+                                                               const float *__restrict__ old_logp,
+                                                               const float *__restrict__ targets,
+                                                               const float *__restrict__ advantages, int64_t mb,
+                                                               LossCfg cfg, double *__restrict__ stats) {
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    const int l16 = threadIdx.x & 15, grp = threadIdx.x >> 4;
+    const int c0 = l16 * 8;
+    const bool in_row = c0 < ld;  // ld is a multiple of 32, so a lane's 8 columns are all inside or all outside
+    float st[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int64_t base = (int64_t)blockIdx.x * 16; base < mb; base += (int64_t)gridDim.x * 16) {
+        const bool live = base + grp < mb;
+        const int64_t row = live ? base + grp : mb - 1;  // idle groups of the last pass shadow the last row (no stores)
+        const int64_t src = idx[row];
+        float *z = logits + row * ld + c0;
+        float p[8], pc[8], lp[8];
+        if (in_row) {
+            const f32x4 z0 = *reinterpret_cast<const f32x4 *>(z), z1 = *reinterpret_cast<const f32x4 *>(z + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                p[e] = z0[e];
+                p[4 + e] = z1[e];
+            }
+        }
+        const float old = old_logp[src], adv = advantages[src];
+        const int a = (int)actions[src];  // acts.long() of a float-encoded index (discrete_policy.py:71)
+        float mx = -INFINITY;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            if (!(in_row && c0 + e < A)) p[e] = -INFINITY;
+            mx = fmaxf(mx, p[e]);
+        }
+        mx = row16_max(mx);
+        float s = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            p[e] = (c0 + e < A) ? expf(p[e] - mx) : 0.f;
+            s += p[e];
+        }
+        s = row16_sum(s);
+        float ent = 0.f, lpa = 0.f, pca = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int c = c0 + e;
+            p[e] = p[e] / s;
+            pc[e] = fminf(fmaxf(p[e], PROB_MIN), 1.0f);
+            lp[e] = c < A ? logf(pc[e]) : 0.f;
+            if (c < A) ent -= lp[e] * pc[e];
+            if (c == a) {
+                lpa = lp[e];
+                pca = pc[e];
+            }
+        }
+        ent = row16_sum(ent);
+        lpa = row16_sum(lpa);  // exactly one lane holds a non-zero term
+        pca = row16_sum(pca);
+        const float lr = lpa - old;
+        const float ratio = expf(lr);
+        float smin;
+        const float w = surrogate_weight(ratio, adv, cfg, smin);
+        const float g_logp = cfg.mb_ratio * (-(adv * w * ratio) * cfg.inv_mb);
+        const float g_ent = cfg.mb_ratio * (cfg.ent_coef * cfg.inv_mb);
+        float gp[8];
+        float dot = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int c = c0 + e;
+            float g = 0.f;
+            if (c < A) {
+                g = g_ent * (lp[e] + 1.f);
+                if (c == a) g += g_logp / pca;
+                if (!(p[e] >= PROB_MIN)) g = 0.f;  // clamp passes gradient on [1e-11, 1] only
+            }
+            gp[e] = g;
+            dot += g * p[e];
+        }
+        dot = row16_sum(dot);
+        if (live && in_row) {
+            f32x4 o0, o1;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                o0[e] = (c0 + e < A) ? p[e] * (gp[e] - dot) : 0.f;
+                o1[e] = (c0 + 4 + e < A) ? p[4 + e] * (gp[4 + e] - dot) : 0.f;
+            }
+            *reinterpret_cast<f32x4 *>(z) = o0;
+            *reinterpret_cast<f32x4 *>(z + 4) = o1;
+        }
+        if (live && l16 == 0) {
+            st[RLPPO_STAT_ENTROPY] += ent * cfg.inv_mb;
+            st[RLPPO_STAT_KL] += ((ratio - 1.f) - lr) * cfg.inv_mb;
+            st[RLPPO_STAT_CLIPFRAC] += (fabsf(ratio - 1.f) > cfg.clip ? 1.f : 0.f) * cfg.inv_mb;
+            st[RLPPO_STAT_PLOSS] += -smin * cfg.inv_mb;
+            st[RLPPO_STAT_VLOSS] += value_row(vout + row * ldv, targets[src], cfg) * cfg.inv_mb;
+        }
+    }
+    block_stats_add(stats, st, true);
+}
+
+static int g_loss16 = 1;  // tuning: rlppo_dbg_set(13, 0/1)
+void set_loss16(int v) { g_loss16 = v; }
+
 int launch_discrete_loss(hipStream_t st, float *logits, int64_t ld, int A, float *vout, int64_t ldv, const int64_t *idx,
                          const float *actions, const float *old_logp, const float *targets, const float *adv, int64_t mb,
                          const LossCfg &cfg, double *stats) {
     if (mb <= 0) return 0;
     dim3 grid((unsigned)(cdiv(mb, 4) < 2048 ? cdiv(mb, 4) : 2048)), block(256);
     RLPPO_CHECK_ARG(ld <= 64 * 32, "discrete head: padded width %ld too large", (long)ld);
-    if (ld <= 128)
+    if (ld <= 128 && g_loss16) {
+        dim3 grid16((unsigned)(cdiv(mb, 16) < 2048 ? cdiv(mb, 16) : 2048));
+        hipLaunchKernelGGL(discrete_loss16_kernel, grid16, block, 0, st, logits, ld, A, vout, ldv, idx, actions, old_logp, targets, adv, mb, cfg, stats);
+    } else if (ld <= 128)
         hipLaunchKernelGGL((discrete_loss_kernel<2>), grid, block, 0, st, logits, ld, A, vout, ldv, idx, actions, old_logp, targets, adv, mb, cfg, stats);
     else if (ld <= 512)
         hipLaunchKernelGGL((discrete_loss_kernel<8>), grid, block, 0, st, logits, ld, A, vout, ldv, idx, actions, old_logp, targets, adv, mb, cfg, stats);

@@ -1,0 +1,66 @@
+"""gemm_nt must be bitwise repeatable while another process keeps the GPU busy and no host sync separates the launches.
+
+Regression test for a store-data hazard found on MI355X: a 16-byte buffer store with an SGPR soffset whose data registers
+are overwritten by the next VALU instruction (the compiler's hazard table calls that safe) stored the NEXT block's values
+whenever the memory pipeline was backed up by a second process.  The epilogue of csrc/gemm_sa.hip now applies the
+activation in place and stores from registers nothing writes again.  gemm_nt has no atomics, so any difference between
+two runs of the same product is a bug."""
+import ctypes
+import os
+import subprocess
+import sys
+import time
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+LOAD = """
+import sys, time, torch
+a = torch.randn(4096, 4096, device="cuda")
+t0 = time.time()
+while time.time() - t0 < float(sys.argv[1]):
+    for _ in range(20):
+        b = a @ a
+    torch.cuda.synchronize()
+"""
+
+
+@pytest.mark.parametrize("variant", [1, 3])  # register-staged and LDS-DMA forms of csrc/gemm_sa.hip share the epilogue
+def test_gemm_nt_repeatable_under_gpu_sharing(variant):
+    from rlgym_ppo_amd import _native as N
+    L = N.lib()
+    N.check(L.rlppo_dbg_set(9, variant))
+    st = lambda: ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    P = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
+    torch.manual_seed(0)
+    bg = subprocess.Popen([sys.executable, "-c", LOAD, "25"])
+    try:
+        time.sleep(4.0)  # let the other process get going
+        # (M, N, K, epilogue): the shapes of a small learner's forward / backward and one cfg2 hidden layer
+        for (M, n, k, epi) in [(512, 64, 128, 1), (512, 64, 64, 1), (512, 64, 96, 3), (512, 96, 64, 0), (4096, 256, 256, 1)]:
+            A = torch.randn(M, k, device="cuda")
+            W = torch.randn(n, k, device="cuda") * 0.1
+            bias = torch.randn(n, device="cuda")
+            mask = torch.randn(M, n, device="cuda")
+            C = torch.empty(M, n, device="cuda")
+            run = lambda: N.check(L.rlppo_dbg_gemm_nt(st(), P(A), k, None, P(W), k, P(bias), P(mask) if epi == 3 else None, n,
+                                                       P(C), n, M, n, k, epi))
+            run()
+            ref = C.clone()
+            expect = A.double() @ W.double().T
+            expect = torch.where(mask > 0, expect, torch.zeros_like(expect)) if epi == 3 else expect + bias.double()
+            if epi == 1:
+                expect = expect.clamp_min(0)
+            assert (ref.double() - expect).abs().max().item() < 2e-5 * max(1.0, expect.abs().max().item())
+            differ = torch.zeros((), dtype=torch.int64, device="cuda")
+            for _ in range(1500):
+                C.fill_(-1.0)
+                run()
+                differ += (C != ref).any()
+            assert int(differ.item()) == 0, (M, n, k, epi, int(differ.item()))
+    finally:
+        N.check(L.rlppo_dbg_set(9, 3))
+        bg.wait()
