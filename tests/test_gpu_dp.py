@@ -60,8 +60,11 @@ def test_two_ranks_equal_one_rank():
     mp.spawn(_worker, args=(2, _free_port(), out), nprocs=2, join=True)
     for rank in (0, 1):
         p, v, report = out[rank]
-        assert ((p - ref_p).abs().max() / ref_p.abs().max()).item() < 1e-5   # summation order differs (atomics + all-reduce)
-        assert ((v - ref_v).abs().max() / ref_v.abs().max()).item() < 1e-5
+        # summation order differs (atomics + all-reduce); Adam turns 1e-7 gradient noise into up to ~1e-5 relative parameter
+        # noise after 4 steps (two identical single-process runs already differ by up to 9e-6: scratch/determinism.py), while
+        # a real defect shows up as O(lr / max|p|) ~ 2e-3
+        assert ((p - ref_p).abs().max() / ref_p.abs().max()).item() < 5e-5
+        assert ((v - ref_v).abs().max() / ref_v.abs().max()).item() < 5e-5
         for k in ("Policy Entropy", "Mean KL Divergence", "Value Function Loss", "SB3 Clip Fraction",
                   "Policy Update Magnitude", "Value Function Update Magnitude"):
             assert abs(report[k] - ref_report[k]) <= 2e-5 * max(abs(ref_report[k]), 1e-3) + 1e-7, (k, report[k], ref_report[k])
