@@ -241,6 +241,7 @@ static int g_two_streams = 1;  // tuning: rlppo_dbg_set(4, 0/1)
 // Library-owned streams: slot s > 0 runs its policy chain on g_main[s]; every slot runs its critic chain on g_side[s].
 static hipStream_t g_main[RLPPO_MAX_SLOTS] = {}, g_side[RLPPO_MAX_SLOTS] = {}, g_dw[RLPPO_MAX_SLOTS][2] = {};
 static hipEvent_t g_ev_dw[RLPPO_MAX_SLOTS][2][RLPPO_MAX_LAYERS + 1] = {};
+static int g_split_loss = 1;  // tuning: rlppo_dbg_set(14, 0/1): value loss in the critic's chain (no mid-minibatch join)
 static int g_pregather = 1;  // tuning: rlppo_dbg_set(11, 0/1): gather the minibatch's states once instead of in 4 GEMMs
 static int g_dw_streams = 0;  // tuning: rlppo_dbg_set(8, 0/1); measured slower (14.4 vs 12.7 ms/epoch, tools/ab_update.py)
 static hipEvent_t g_ev_fork[RLPPO_MAX_SLOTS] = {}, g_ev_join[RLPPO_MAX_SLOTS] = {}, g_ev_slot[RLPPO_MAX_SLOTS] = {};
@@ -412,12 +413,9 @@ int rlppo_ppo_minibatch(void *stream, const rlppo_minibatch_args *a) {
     if (rc) return rc;
     rc = forward(st, pol, a->pol_packed, states, ld_states, gidx, mb, a->head == RLPPO_HEAD_GAUSSIAN, pact);
     if (rc) return rc;
-    if (side != st) {
-        rc = order_after(st, side, g_ev_join[slot]);
-        if (rc) return rc;
-    }
-
-    // loss epilogue: outputs -> output gradients in place, report statistics accumulated on device
+    // loss epilogue: outputs -> output gradients in place, report statistics accumulated on device.  The value loss only
+    // needs the critic's output and the policy loss only the policy's, so with two streams each chain runs its own loss
+    // kernel and the chains do not meet until the end of the minibatch (rlppo_dbg_set(14, 0): one joint loss kernel).
     LossCfg cfg;
     cfg.clip = a->clip_range;
     cfg.clip_lo = (float)(1.0 - (double)a->clip_range);
@@ -429,14 +427,23 @@ int rlppo_ppo_minibatch(void *stream, const rlppo_minibatch_args *a) {
     cfg.var_b = a->var_b;
     float *pout = pact[pol.n_layers - 1], *vout = vact[val.n_layers - 1];
     const int64_t ldp = pol.L[pol.n_layers - 1].pout, ldv = val.L[val.n_layers - 1].pout;
+    const bool split_loss = side != st && g_split_loss;
+    if (split_loss) {
+        rc = launch_value_loss(side, vout, ldv, a->idx, a->targets, mb, cfg, a->stats);
+        if (rc) return rc;
+    } else if (side != st) {
+        rc = order_after(st, side, g_ev_join[slot]);
+        if (rc) return rc;
+    }
+    float *vjoint = split_loss ? nullptr : vout;
     if (a->head == RLPPO_HEAD_DISCRETE)
-        rc = launch_discrete_loss(st, pout, ldp, n_out, vout, ldv, a->idx, a->actions, a->old_logp, a->targets,
+        rc = launch_discrete_loss(st, pout, ldp, n_out, vjoint, ldv, a->idx, a->actions, a->old_logp, a->targets,
                                   a->advantages, mb, cfg, a->stats);
     else if (a->head == RLPPO_HEAD_GAUSSIAN)
-        rc = launch_gaussian_loss(st, pout, ldp, n_out / 2, vout, ldv, a->idx, a->actions, a->old_logp, a->targets,
+        rc = launch_gaussian_loss(st, pout, ldp, n_out / 2, vjoint, ldv, a->idx, a->actions, a->old_logp, a->targets,
                                   a->advantages, mb, cfg, a->stats);
     else if (a->head == RLPPO_HEAD_MULTIDISCRETE)
-        rc = launch_multidiscrete_loss(st, pout, ldp, vout, ldv, a->idx, a->actions, a->old_logp, a->targets, a->advantages,
+        rc = launch_multidiscrete_loss(st, pout, ldp, vjoint, ldv, a->idx, a->actions, a->old_logp, a->targets, a->advantages,
                                        mb, cfg, a->stats);
     else {
         set_error("ppo_minibatch: unknown head %d", a->head);
@@ -444,7 +451,7 @@ int rlppo_ppo_minibatch(void *stream, const rlppo_minibatch_args *a) {
     }
     if (rc) return rc;
 
-    if (g_two_streams) {
+    if (g_two_streams && !split_loss) {
         rc = order_after(side, st, g_ev_fork[slot]);
         if (rc) return rc;
     }
@@ -534,6 +541,10 @@ int rlppo_dbg_set(int32_t key, int32_t value) {
     }
     if (key == 13) {
         set_loss16(value);
+        return 0;
+    }
+    if (key == 14) {
+        g_split_loss = value;
         return 0;
     }
     set_error("dbg_set: unknown key %d", key);

@@ -109,6 +109,8 @@ int launch_discrete_sample_logits(hipStream_t, const float *, int64_t, int64_t, 
 int launch_categorical_select(hipStream_t, const float *, int64_t, int64_t, int, const float *, int64_t *, float *);
 int launch_gaussian_sample(hipStream_t, const float *, int64_t, int64_t, int, const float *, float, float, float *, float *);
 int launch_multidiscrete_sample(hipStream_t, const float *, int64_t, int64_t, const float *, int64_t *, float *);
+int launch_value_loss(hipStream_t st, float *vout, int64_t ldv, const int64_t *idx, const float *targets, int64_t mb,
+                      const LossCfg &cfg, double *stats);
 int launch_discrete_loss(hipStream_t, float *, int64_t, int, float *, int64_t, const int64_t *, const float *, const float *,
                          const float *, const float *, int64_t, const LossCfg &, double *);
 int launch_gaussian_loss(hipStream_t, float *, int64_t, int, float *, int64_t, const int64_t *, const float *, const float *,

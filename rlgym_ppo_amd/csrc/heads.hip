@@ -234,7 +234,7 @@ __global__ __launch_bounds__(256) void discrete_loss_kernel(float *__restrict__ 
             st[RLPPO_STAT_KL] += ((ratio - 1.f) - lr) * cfg.inv_mb;
             st[RLPPO_STAT_CLIPFRAC] += (fabsf(ratio - 1.f) > cfg.clip ? 1.f : 0.f) * cfg.inv_mb;
             st[RLPPO_STAT_PLOSS] += -smin * cfg.inv_mb;
-            st[RLPPO_STAT_VLOSS] += value_row(vout + row * ldv, targets[src], cfg) * cfg.inv_mb;
+            if (vout) st[RLPPO_STAT_VLOSS] += value_row(vout + row * ldv, targets[src], cfg) * cfg.inv_mb;
         }
     }
     block_stats_add(stats, st, true);
@@ -359,10 +359,31 @@ __global__ __launch_bounds__(256) void discrete_loss16_kernel(float *__restrict_
             st[RLPPO_STAT_KL] += ((ratio - 1.f) - lr) * cfg.inv_mb;
             st[RLPPO_STAT_CLIPFRAC] += (fabsf(ratio - 1.f) > cfg.clip ? 1.f : 0.f) * cfg.inv_mb;
             st[RLPPO_STAT_PLOSS] += -smin * cfg.inv_mb;
-            st[RLPPO_STAT_VLOSS] += value_row(vout + row * ldv, targets[src], cfg) * cfg.inv_mb;
+            if (vout) st[RLPPO_STAT_VLOSS] += value_row(vout + row * ldv, targets[src], cfg) * cfg.inv_mb;
         }
     }
     block_stats_add(stats, st, true);
+}
+
+// Value loss on its own (value_estimator + ppo_learner.py:163-166: MSE(vals, target_values)): v -> d loss / d v in place,
+// VLOSS statistic.  A separate launch so that the critic's launch chain never has to meet the policy's between the
+// forward and the backward pass: the two chains only join at the end of the minibatch.
+__global__ __launch_bounds__(256) void value_loss_kernel(float *__restrict__ vout, int64_t ldv, const int64_t *__restrict__ idx,
+                                                         const float *__restrict__ targets, int64_t mb, LossCfg cfg,
+                                                         double *__restrict__ stats) {
+    float st[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x; row < mb; row += (int64_t)gridDim.x * 256)
+        st[RLPPO_STAT_VLOSS] += value_row(vout + row * ldv, targets[idx[row]], cfg) * cfg.inv_mb;
+    block_stats_add(stats, st, true);
+}
+
+int launch_value_loss(hipStream_t st, float *vout, int64_t ldv, const int64_t *idx, const float *targets, int64_t mb,
+                      const LossCfg &cfg, double *stats) {
+    if (mb <= 0) return 0;
+    dim3 grid((unsigned)(cdiv(mb, 256) < 1024 ? cdiv(mb, 256) : 1024));
+    hipLaunchKernelGGL(value_loss_kernel, grid, dim3(256), 0, st, vout, ldv, idx, targets, mb, cfg, stats);
+    RLPPO_LAUNCH_CHECK();
+    return 0;
 }
 
 static int g_loss16 = 1;  // tuning: rlppo_dbg_set(13, 0/1)
@@ -474,7 +495,7 @@ __global__ __launch_bounds__(256) void gaussian_loss_kernel(float *__restrict__ 
         st[RLPPO_STAT_KL] = ((ratio - 1.f) - lr) * cfg.inv_mb;
         st[RLPPO_STAT_CLIPFRAC] = (fabsf(ratio - 1.f) > cfg.clip ? 1.f : 0.f) * cfg.inv_mb;
         st[RLPPO_STAT_PLOSS] = -smin * cfg.inv_mb;
-        st[RLPPO_STAT_VLOSS] = value_row(vout + row * ldv, targets[src], cfg) * cfg.inv_mb;
+        st[RLPPO_STAT_VLOSS] = vout ? value_row(vout + row * ldv, targets[src], cfg) * cfg.inv_mb : 0.f;
     }
     block_stats_add(stats, st, active);
 }
@@ -596,7 +617,7 @@ __global__ __launch_bounds__(256) void multidiscrete_loss_kernel(float *__restri
         st[RLPPO_STAT_KL] = ((ratio - 1.f) - lr) * cfg.inv_mb;
         st[RLPPO_STAT_CLIPFRAC] = (fabsf(ratio - 1.f) > cfg.clip ? 1.f : 0.f) * cfg.inv_mb;
         st[RLPPO_STAT_PLOSS] = -smin * cfg.inv_mb;
-        st[RLPPO_STAT_VLOSS] = value_row(vout + row * ldv, targets[src], cfg) * cfg.inv_mb;
+        st[RLPPO_STAT_VLOSS] = vout ? value_row(vout + row * ldv, targets[src], cfg) * cfg.inv_mb : 0.f;
     }
     block_stats_add(stats, st, active);
 }
