@@ -11,7 +11,9 @@ dW = torch.zeros(256 * 256, device=dev); db = torch.zeros(256, device=dev)
 shapes = {"hidden 256x256": (A256, 256, A256, 256, 256, 256), "L0 256x107 (no gather)": (A256, 256, A128, 128, 256, 107),
           "head 90x256": (A96, 96, A256, 256, 90, 256), "vhead 1x256": (A32, 32, A256, 256, 1, 256)}
 variants = {0: "vector-addr", 1: "scalar-addr", 2: "LDS-DMA TM32", 3: "LDS-DMA TM16"}
-for name, (dY, ny, X, kx, out, in_) in shapes.items():
+for rows in (512, 768, 1024):
+  N.check(L.rlppo_dbg_set(2, rows)); print('rows per workgroup', rows)
+  for name, (dY, ny, X, kx, out, in_) in shapes.items():
     fn = lambda: N.check(L.rlppo_dbg_gemm_tn(st(), P(dY), ny, ny, P(X), kx, None, kx, P(dW), P(db), out, in_, M))
     t = {v: [] for v in variants}
     for _ in range(5):
