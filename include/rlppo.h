@@ -209,7 +209,8 @@ int rlppo_mt19937_permutation(uint32_t *state625, int64_t n, int64_t *out);
  *  11 minibatch states gathered once into the workspace [1] | gather fused into the four first-layer GEMMs [0]
  *  12 gemm_tn rows per workgroup for products of >= 4 output tiles [768]
  *  13 discrete loss kernel with 16 lanes per row for widths <= 128 [1] | one wave per row [0]
- *  14 value loss launched in the critic's chain, no join between forward and backward [1] | one joint loss kernel [0] */
+ *  14 value loss launched in the critic's chain, no join between forward and backward [1] | one joint loss kernel [0]
+ *  15 one-output (critic) head as matrix-vector kernels [1] | through the padded GEMM kernels [0] */
 int rlppo_dbg_set(int32_t key, int32_t value);
 /* Register-only fp32 MFMA loop: out[blocks*256] floats, clocks[2*blocks] = {shader cycles, 100 MHz ticks} per block. */
 /* GEMM inner-loop probe: 64 MFMAs per chunk + (mode&1) A fragments from LDS, (mode&2) B fragments from LDS, (mode&4) B

@@ -74,7 +74,11 @@ static int forward(hipStream_t st, const NetLayout &net, const float *packed, co
         const LayerLayout &L = net.L[l];
         const bool last = l == net.n_layers - 1;
         const int epi = last ? (out_tanh ? EPI_BIAS_TANH : EPI_BIAS) : EPI_BIAS_RELU;
-        int rc = launch_gemm_nt(st, x, ldx, ridx, packed + L.off_w, L.pin, packed + L.off_b, nullptr, 0, acts[l], L.pout, n,
+        int rc;
+        if (last && !out_tanh && !ridx && gemv_head_ok(L.out, L.pin))  // one-output head: matrix-vector kernel (gemv.hip)
+            rc = launch_gemv_fwd(st, x, ldx, packed + L.off_w, packed + L.off_b, acts[l], L.pout, n, L.pin, L.pout);
+        else
+            rc = launch_gemm_nt(st, x, ldx, ridx, packed + L.off_w, L.pin, packed + L.off_b, nullptr, 0, acts[l], L.pout, n,
                                 L.pout, L.pin, epi);
         if (rc) return rc;
         x = acts[l];
@@ -309,10 +313,17 @@ static int backward(hipStream_t st, hipStream_t dw, hipEvent_t *ev, const NetLay
             rc = order_after(dw, st, ev[l]);
             if (rc) return rc;
         }
-        rc = launch_gemm_tn(dw, dY, L.pout, L.pout, X, ldx, l > 0 ? nullptr : idx, L.pin, grad + L.off_flat_w,
-                            grad + L.off_flat_b, L.out, L.in, mb);
+        const bool gemv = l == last && l > 0 && gemv_head_ok(L.out, L.pin);  // one-output head (gemv.hip)
+        if (gemv)
+            rc = launch_gemv_dw(dw, dY, L.pout, X, ldx, grad + L.off_flat_w, grad + L.off_flat_b, L.in, L.pin, mb);
+        else
+            rc = launch_gemm_tn(dw, dY, L.pout, L.pout, X, ldx, l > 0 ? nullptr : idx, L.pin, grad + L.off_flat_w,
+                                grad + L.off_flat_b, L.out, L.in, mb);
         if (rc) return rc;
-        if (l > 0 && !fused) {
+        if (gemv && !fused) {
+            rc = launch_gemv_dx(st, dY, L.pout, packed + L.off_w, acts[l - 1], L.pin, dx[l - 1], L.pin, L.pin, mb);
+            if (rc) return rc;
+        } else if (l > 0 && !fused) {
             // dX[mb][pin] = (dY[mb][pout] . W[pout][pin]) masked by relu'(acts[l-1]); B operand = W^T [pin][pout]
             rc = launch_gemm_nt(st, dY, L.pout, nullptr, packed + L.off_wt, L.pout, nullptr, acts[l - 1], L.pin, dx[l - 1],
                                 L.pin, mb, L.pin, L.pout, EPI_MASK);
@@ -339,8 +350,6 @@ int rlppo_ppo_minibatch(void *stream, const rlppo_minibatch_args *a) {
     RLPPO_CHECK_ARG(pol.L[0].in == val.L[0].in, "ppo_minibatch: policy and critic observe different sizes");
     RLPPO_CHECK_ARG(a->ld_states >= pol.L[0].pin && a->ld_states % 4 == 0, "ppo_minibatch: ld_states=%ld < %d",
                     (long)a->ld_states, pol.L[0].pin);
-    RLPPO_CHECK_ARG(pol.L[0].in == val.L[0].in, "ppo_minibatch: policy and critic read the same states (%d vs %d inputs)",
-                    pol.L[0].in, val.L[0].in);
     if (a->ws_bytes < train_ws_floats(pol, val, mb) * sizeof(float)) {
         set_error("ppo_minibatch: workspace %zu < %zu bytes", a->ws_bytes, train_ws_floats(pol, val, mb) * sizeof(float));
         return RLPPO_ERR_WORKSPACE;
@@ -545,6 +554,10 @@ int rlppo_dbg_set(int32_t key, int32_t value) {
     }
     if (key == 14) {
         g_split_loss = value;
+        return 0;
+    }
+    if (key == 15) {
+        set_gemv(value);
         return 0;
     }
     set_error("dbg_set: unknown key %d", key);

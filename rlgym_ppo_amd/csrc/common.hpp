@@ -88,6 +88,11 @@ int launch_gemm_nt_sa(hipStream_t st, const float *A, int64_t lda, const float *
                       const float *mask_src, int64_t ld_mask, float *C, int64_t ldc, int64_t M, int N, int nb, int K, int epi);
 void set_nt_sa(int v);
 void set_tn_sa(int v);
+void set_gemv(int v);
+bool gemv_head_ok(int out, int kp);
+int launch_gemv_fwd(hipStream_t st, const float *x, int64_t ldx, const float *w, const float *b, float *y, int64_t ldy, int64_t n, int kp, int pout);
+int launch_gemv_dx(hipStream_t st, const float *dy, int64_t ldy, const float *w, const float *mask, int64_t ldm, float *dx, int64_t ldc, int kp, int64_t n);
+int launch_gemv_dw(hipStream_t st, const float *dy, int64_t ldy, const float *x, int64_t ldx, float *dw, float *db, int in, int kp, int64_t n);
 void set_loss16(int v);
 void set_tn_rows_big(int r);
 int launch_gemm_tn_sa(hipStream_t st, dim3 grid, const float *dY, int64_t ldy, int ny_valid, const float *X, int64_t ldx,

@@ -1,0 +1,144 @@
+// gemv.hip -- the critic's one-output head (value_estimator.py: Linear(hidden, 1)) as three HBM-bound streaming kernels.
+//
+// Through the GEMM kernels the head is padded to 32 outputs: the forward, the masked dX and the dW launch then spend
+// 14 + 29 + 40 us per 65,536-row minibatch on products that are 1/32 real work.  As matrix-vector operations they only
+// have to stream the last hidden activation h[M][K] once each:
+//   forward : v[m]      = b + sum_k h[m][k] w[k]                      (read  M K 4 bytes)
+//   dX      : dx[m][k]  = dv[m] w[k] [h[m][k] > 0]                    (read + write M K 4 bytes; bit-identical to the GEMM:
+//                                                                      the other 31 padded terms of its sum are zeros)
+//   dW, db  : dw[k]    += sum_m dv[m] h[m][k],  db += sum_m dv[m]     (read  M K 4 bytes, one atomic per column and block)
+// v / dv live in column 0 of the critic's padded output buffer (row stride ldv), exactly where the GEMM path keeps them.
+#include "common.hpp"
+
+namespace rlppo {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+__device__ __forceinline__ float wave_sum64(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+}  // namespace
+
+// one wave per row, two rows in flight per wave
+__global__ __launch_bounds__(256) void gemv_fwd_kernel(const float *__restrict__ x, int64_t ldx, const float *__restrict__ w,
+                                                       const float *__restrict__ b, float *__restrict__ y, int64_t ldy,
+                                                       int64_t n, int kp, int pout) {
+    const int lane = threadIdx.x & 63;
+    const float bias = b[0];
+    for (int64_t row = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 2; row < n; row += (int64_t)gridDim.x * 8) {
+        const bool two = row + 1 < n;
+        const float *x0 = x + row * ldx, *x1 = x + (two ? row + 1 : row) * ldx;
+        float a0 = 0.f, a1 = 0.f;
+        for (int c = lane * 4; c < kp; c += 256) {
+            const f32x4 wv = *reinterpret_cast<const f32x4 *>(w + c);
+            const f32x4 u = *reinterpret_cast<const f32x4 *>(x0 + c), v = *reinterpret_cast<const f32x4 *>(x1 + c);
+            a0 += u[0] * wv[0] + u[1] * wv[1] + u[2] * wv[2] + u[3] * wv[3];
+            a1 += v[0] * wv[0] + v[1] * wv[1] + v[2] * wv[2] + v[3] * wv[3];
+        }
+        a0 = wave_sum64(a0);
+        a1 = wave_sum64(a1);
+        if (lane * 4 < pout) {  // the padded output columns are part of the layout contract: zeros
+            *reinterpret_cast<f32x4 *>(y + row * ldy + lane * 4) = f32x4{lane == 0 ? a0 + bias : 0.f, 0.f, 0.f, 0.f};
+            if (two) *reinterpret_cast<f32x4 *>(y + (row + 1) * ldy + lane * 4) = f32x4{lane == 0 ? a1 + bias : 0.f, 0.f, 0.f, 0.f};
+        }
+    }
+}
+
+// 16 bytes per thread
+__global__ __launch_bounds__(256) void gemv_dx_kernel(const float *__restrict__ dy, int64_t ldy, const float *__restrict__ w,
+                                                      const float *__restrict__ mask, int64_t ldm, float *__restrict__ dx,
+                                                      int64_t ldc, int cpr, int64_t n) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t row = t / cpr;
+    const int c = (int)(t - row * cpr) * 4;
+    if (row >= n) return;
+    const float d = dy[row * ldy];
+    const f32x4 h = *reinterpret_cast<const f32x4 *>(mask + row * ldm + c);
+    const f32x4 wv = *reinterpret_cast<const f32x4 *>(w + c);
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = h[e] > 0.f ? d * wv[e] : 0.f;
+    *reinterpret_cast<f32x4 *>(dx + row * ldc + c) = o;
+}
+
+// block = rows [r0, r0 + rows_per_block); thread = (row lane, 16-byte column chunk); cpr chunks per row, 256 / cpr row lanes
+__global__ __launch_bounds__(256) void gemv_dw_kernel(const float *__restrict__ dy, int64_t ldy, const float *__restrict__ x,
+                                                      int64_t ldx, float *__restrict__ dw, float *__restrict__ db, int in,
+                                                      int cpr, int64_t n, int rows_per_block) {
+    __shared__ __attribute__((aligned(16))) float red[256 * 4];
+    __shared__ float dsum_s[4];
+    const int chunk = threadIdx.x % cpr, rlane = threadIdx.x / cpr, RL = 256 / cpr;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    const int64_t r1 = (r0 + rows_per_block < n) ? r0 + rows_per_block : n;
+    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+    float dsum = 0.f;
+    int64_t m = r0 + rlane;
+    for (; m + 3 * RL < r1; m += 4 * RL) {  // four independent rows in flight per thread
+        float d[4];
+        f32x4 xv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            d[u] = dy[(m + u * RL) * ldy];
+            xv[u] = *reinterpret_cast<const f32x4 *>(x + (m + u * RL) * ldx + chunk * 4);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            acc += d[u] * xv[u];
+            dsum += d[u];
+        }
+    }
+    for (; m < r1; m += RL) {
+        const float d = dy[m * ldy];
+        acc += d * *reinterpret_cast<const f32x4 *>(x + m * ldx + chunk * 4);
+        dsum += d;
+    }
+    *reinterpret_cast<f32x4 *>(&red[(rlane * cpr + chunk) * 4]) = acc;
+    if (chunk != 0) dsum = 0.f;  // every row lane saw each dv once per chunk: count it once
+    dsum = wave_sum64(dsum);
+    if ((threadIdx.x & 63) == 0) dsum_s[threadIdx.x >> 6] = dsum;
+    __syncthreads();
+    for (int k = threadIdx.x; k < cpr * 4 && k < in; k += 256) {
+        float s = 0.f;
+        for (int r = 0; r < RL; ++r) s += red[r * cpr * 4 + k];
+        atomicAdd(dw + k, s);
+    }
+    if (threadIdx.x == 0 && db) atomicAdd(db, dsum_s[0] + dsum_s[1] + dsum_s[2] + dsum_s[3]);
+}
+
+static int g_gemv = 1;  // tuning: rlppo_dbg_set(15, 0/1)
+void set_gemv(int v) { g_gemv = v; }
+// the shapes the three kernels take: padded input width a power of two in [32, 1024] (one 16-byte chunk per thread column)
+bool gemv_head_ok(int out, int kp) { return g_gemv && out == 1 && kp >= 32 && kp <= 1024 && (kp & (kp - 1)) == 0; }
+
+int launch_gemv_fwd(hipStream_t st, const float *x, int64_t ldx, const float *w, const float *b, float *y, int64_t ldy,
+                    int64_t n, int kp, int pout) {
+    if (n <= 0) return 0;
+    const int64_t blocks = cdiv(n, 8);
+    hipLaunchKernelGGL(gemv_fwd_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, st, x, ldx, w, b, y, ldy, n, kp, pout);
+    RLPPO_LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_gemv_dx(hipStream_t st, const float *dy, int64_t ldy, const float *w, const float *mask, int64_t ldm, float *dx,
+                   int64_t ldc, int kp, int64_t n) {
+    if (n <= 0) return 0;
+    const int cpr = kp / 4;
+    hipLaunchKernelGGL(gemv_dx_kernel, dim3((unsigned)cdiv(n * cpr, 256)), dim3(256), 0, st, dy, ldy, w, mask, ldm, dx, ldc, cpr, n);
+    RLPPO_LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_gemv_dw(hipStream_t st, const float *dy, int64_t ldy, const float *x, int64_t ldx, float *dw, float *db, int in,
+                   int kp, int64_t n) {
+    if (n <= 0) return 0;
+    const int rows_per_block = 128;
+    hipLaunchKernelGGL(gemv_dw_kernel, dim3((unsigned)cdiv(n, rows_per_block)), dim3(256), 0, st, dy, ldy, x, ldx, dw, db, in,
+                       kp / 4, n, rows_per_block);
+    RLPPO_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace rlppo
