@@ -113,17 +113,14 @@ def kernel_breakdown(learner):
                                                     P(dW), P(db), out, in_, M))
 
     shapes = [
-        ("gemm_nt fwd L0 gather 128->256 (x2 nets)", 2, nt(A128, 128, idx, 128, C256, 256, 256, 128, 1), 2 * M * 256 * 128),
+        ("gemm_nt fwd L0 128->256 (x2 nets)", 2, nt(A128, 128, None, 128, C256, 256, 256, 128, 1), 2 * M * 256 * 128),
         ("gemm_nt fwd hidden 256->256 (x4)", 4, nt(A256, 256, None, 256, C256, 256, 256, 256, 1), 2 * M * 256 * 256),
         ("gemm_nt fwd head 256->96", 1, nt(A256, 256, None, 256, C96, 96, 96, 256, 0), 2 * M * 96 * 256),
-        ("gemm_nt fwd value head 256->32", 1, nt(A256, 256, None, 256, C32, 32, 32, 256, 0), 2 * M * 32 * 256),
         ("gemm_nt dX hidden 256->256 mask (x4)", 4, nt(A256, 256, None, 256, C256, 256, 256, 256, 3, A256), 2 * M * 256 * 256),
         ("gemm_nt dX head 96->256 mask", 1, nt(A96, 96, None, 96, C256, 256, 256, 96, 3, A256), 2 * M * 256 * 96),
-        ("gemm_nt dX value head 32->256 mask", 1, nt(A32, 32, None, 32, C256, 256, 256, 32, 3, A256), 2 * M * 256 * 32),
         ("gemm_tn dW hidden 256x256 (x4)", 4, tn(A256, 256, A256, 256, None, 256, 256), 2 * M * 256 * 256),
-        ("gemm_tn dW L0 gather 256x107 (x2)", 2, tn(A256, 256, A128, 128, idx, 256, 107), 2 * M * 256 * 128),
+        ("gemm_tn dW L0 256x107 (x2)", 2, tn(A256, 256, A128, 128, None, 256, 107), 2 * M * 256 * 128),
         ("gemm_tn dW head 90x256", 1, tn(A96, 96, A256, 256, None, 90, 256), 2 * M * 128 * 256),
-        ("gemm_tn dW value head 1x256", 1, tn(A32, 32, A256, 256, None, 1, 256), 2 * M * 128 * 256),
     ]
     rows = []
     for name, count, fn, flop in shapes:
@@ -134,22 +131,25 @@ def kernel_breakdown(learner):
     return rows, dominant
 
 
+TRAFFIC_JSON = "r01_traffic_v5.json"  # tools/pmc_traffic.py output of the committed PMC passes
+
+
 def pmc_traffic_for(kernel_label):
     """HBM bytes per launch of the dominant kernel, from the committed PMC passes (bench.py cannot run rocprofv3 on itself)."""
-    path = os.path.join(ROOT, "profiles", "r01_traffic_v4.json")
-    key = {"gemm_tn dW hidden 256x256 (x4)": "rlppo::gemm_tn_kernel<false>",
-           "gemm_nt fwd hidden 256->256 (x4)": "rlppo::gemm_nt_kernel<8, 1, false, 32>",
-           "gemm_nt dX hidden 256->256 mask (x4)": "rlppo::gemm_nt_kernel<8, 3, false, 32>"}.get(kernel_label)
+    path = os.path.join(ROOT, "profiles", TRAFFIC_JSON)
+    key = {"gemm_tn dW hidden 256x256 (x4)": "rlppo::gemm_tn_dma_kernel<32> [grid 88064]",
+           "gemm_nt fwd hidden 256->256 (x4)": "rlppo::gemm_nt_dma_kernel<8, 1, 16>",
+           "gemm_nt dX hidden 256->256 mask (x4)": "rlppo::gemm_nt_dma_kernel<8, 3, 16>"}.get(kernel_label)
     try:
         t = json.load(open(path))
-        return round(t[key]["hbm_bytes"]), "profiles/r01_traffic_v4.json (tools/prof_kernels.py, same launch shape)"
+        return round(t[key]["hbm_bytes"]), "profiles/" + TRAFFIC_JSON + " (tools/prof_kernels.py, same launch shape)"
     except Exception:
         return None, "no committed PMC pass for this kernel"
 
 
 def gae_traffic():
     try:
-        return round(json.load(open(os.path.join(ROOT, "profiles", "r01_traffic_v4.json")))["rlppo::gae_lookback_kernel"]["hbm_bytes"])
+        return round(json.load(open(os.path.join(ROOT, "profiles", TRAFFIC_JSON)))["rlppo::gae_lookback_kernel"]["hbm_bytes"])
     except Exception:
         return None
 

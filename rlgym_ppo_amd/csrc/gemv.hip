@@ -134,7 +134,7 @@ int launch_gemv_dx(hipStream_t st, const float *dy, int64_t ldy, const float *w,
 int launch_gemv_dw(hipStream_t st, const float *dy, int64_t ldy, const float *x, int64_t ldx, float *dw, float *db, int in,
                    int kp, int64_t n) {
     if (n <= 0) return 0;
-    const int rows_per_block = 128;
+    const int rows_per_block = 64;  // 1024 blocks at M = 65,536: enough loads in flight to stream h at HBM rate
     hipLaunchKernelGGL(gemv_dw_kernel, dim3((unsigned)cdiv(n, rows_per_block)), dim3(256), 0, st, dy, ldy, x, ldx, dw, db, in,
                        kp / 4, n, rows_per_block);
     RLPPO_LAUNCH_CHECK();

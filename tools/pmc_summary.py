@@ -5,13 +5,20 @@ import sys
 from collections import defaultdict
 
 out = defaultdict(lambda: defaultdict(list))
+rows_ = []
 for path in glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True):
     for row in csv.DictReader(open(path)):
         name = row["Kernel_Name"]
         name = name[:name.index("(")] if "(" in name else name
         if not name.startswith(("void rlppo", "rlppo")):
             continue
-        out[name.replace("void ", "")][row["Counter_Name"]].append(float(row["Counter_Value"]))
+        rows_.append((name.replace("void ", ""), row.get("Grid_Size", ""), row["Counter_Name"], float(row["Counter_Value"])))
+# one launch shape per line: a kernel launched with several grid sizes gets " [grid N]" appended (N = work-items)
+grids = defaultdict(set)
+for name, grid, _, _ in rows_:
+    grids[name].add(grid)
+for name, grid, counter, value in rows_:
+    out[name + (" [grid %s]" % grid if len(grids[name]) > 1 else "")][counter].append(value)
 counters = sorted({c for k in out.values() for c in k})
 import csv as _csv, sys as _sys
 w = _csv.writer(_sys.stdout)
