@@ -68,10 +68,18 @@ def build_workload(device, seed=123):
 
 
 # ------------------------------------------------------------------------------------------- kernel timing
-def time_region(fn, reps, warm=3):
-    """Average device time of fn() in ms, HIP events on torch's current stream (the stream librlppo launches on)."""
+def time_region(fn, reps, warm=3, warm_s=0.0):
+    """Average device time of fn() in ms, HIP events on torch's current stream (the stream librlppo launches on).
+    warm_s > 0 first keeps the GPU busy with fn() for that long: the shader clock needs a few hundred ms of load to
+    ramp from ~2.06 to ~2.35 GHz (tools/clock_under_load.py), and the timed region of the bench runs at the ramped clock."""
     for _ in range(warm):
         fn()
+    if warm_s > 0:
+        t0 = time.perf_counter()
+        while time.perf_counter() - t0 < warm_s:
+            for _ in range(20):
+                fn()
+            torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
     e0.record()
@@ -124,7 +132,7 @@ def kernel_breakdown(learner):
     ]
     rows = []
     for name, count, fn, flop in shapes:
-        ms = time_region(fn, 10)
+        ms = time_region(fn, 20, warm_s=0.3)
         rows.append(dict(kernel=name, launches_per_minibatch=count, ms_per_launch=round(ms, 4),
                          gflop_per_launch=round(flop / 1e9, 3), tflops=round(flop / ms / 1e9, 2)))
     dominant = max(rows, key=lambda r: r["launches_per_minibatch"] * r["ms_per_launch"])
@@ -172,7 +180,7 @@ def gae_bench():
     d = lambda x: torch.as_tensor(x).cuda()
     R, D, T, V = d(rews), d(dones), d(trunc), d(values)
     fn = lambda: torch_functions.gae_device(R, D, T, V, 0.99, 0.95, 1.7)
-    fn()
+    time_region(fn, 1, warm_s=0.3)  # clock ramp
     from rlgym_ppo_amd import _native as N
     # A/B of the two implementations, interleaved in one process (cdna_hip_programming.md rule 24)
     times = {0: [], 1: []}
