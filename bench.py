@@ -116,9 +116,11 @@ def kernel_breakdown(learner):
         return lambda: N.check(L.rlppo_dbg_gemm_nt(st(), P(A), lda, P(ridx) if ridx is not None else None, P(W), ldb, P(bias),
                                                     P(mask) if mask is not None else None, n, P(C), ldc, M, n, k, epi))
 
-    def tn(dY, ny, X, kx, ridx, out, in_):
-        return lambda: N.check(L.rlppo_dbg_gemm_tn(st(), P(dY), ny, ny, P(X), kx, P(ridx) if ridx is not None else None, kx,
-                                                    P(dW), P(db), out, in_, M))
+    tn_ws = torch.empty(max(int(L.rlppo_dbg_gemm_tn_workspace_bytes(256, 256, M)), 1), dtype=torch.uint8, device=dev)
+
+    def tn(dY, ny, X, kx, ridx, out, in_):  # the form the update uses: partial tiles + reduction kernel (both timed)
+        return lambda: N.check(L.rlppo_dbg_gemm_tn_ws(st(), P(dY), ny, ny, P(X), kx, kx, P(dW), P(db), out, in_, M, P(tn_ws),
+                                                       tn_ws.numel()))
 
     shapes = [
         ("gemm_nt fwd L0 128->256 (x2 nets)", 2, nt(A128, 128, None, 128, C256, 256, 256, 128, 1), 2 * M * 256 * 128),
@@ -145,7 +147,7 @@ TRAFFIC_JSON = "r01_traffic_v5.json"  # tools/pmc_traffic.py output of the commi
 def pmc_traffic_for(kernel_label):
     """HBM bytes per launch of the dominant kernel, from the committed PMC passes (bench.py cannot run rocprofv3 on itself)."""
     path = os.path.join(ROOT, "profiles", TRAFFIC_JSON)
-    key = {"gemm_tn dW hidden 256x256 (x4)": "rlppo::gemm_tn_dma_kernel<32> [grid 88064]",
+    key = {"gemm_tn dW hidden 256x256 (x4)": "rlppo::gemm_tn_dma_kernel<32, true> [grid 131072]",
            "gemm_nt fwd hidden 256->256 (x4)": "rlppo::gemm_nt_dma_kernel<8, 1, 16>",
            "gemm_nt dX hidden 256->256 mask (x4)": "rlppo::gemm_nt_dma_kernel<8, 3, 16>"}.get(kernel_label)
     try:

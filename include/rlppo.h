@@ -210,7 +210,8 @@ int rlppo_mt19937_permutation(uint32_t *state625, int64_t n, int64_t *out);
  *  12 gemm_tn rows per workgroup for products of >= 4 output tiles [768]
  *  13 discrete loss kernel with 16 lanes per row for widths <= 128 [1] | one wave per row [0]
  *  14 value loss launched in the critic's chain, no join between forward and backward [1] | one joint loss kernel [0]
- *  15 one-output (critic) head as matrix-vector kernels [1] | through the padded GEMM kernels [0] */
+ *  15 one-output (critic) head as matrix-vector kernels [1] | through the padded GEMM kernels [0]
+ *  16 dW through partial tiles + a reduction kernel [1] | fp32 atomics [0] */
 int rlppo_dbg_set(int32_t key, int32_t value);
 /* Register-only fp32 MFMA loop: out[blocks*256] floats, clocks[2*blocks] = {shader cycles, 100 MHz ticks} per block. */
 /* GEMM inner-loop probe: 64 MFMAs per chunk + (mode&1) A fragments from LDS, (mode&2) B fragments from LDS, (mode&4) B
@@ -232,6 +233,11 @@ int rlppo_dbg_gemm_nt(void *stream, const float *A, int64_t lda, const int64_t *
                       int32_t N, int32_t K, int32_t epilogue);
 int rlppo_dbg_gemm_tn(void *stream, const float *dY, int64_t ldy, int32_t ny_valid, const float *X, int64_t ldx,
                       const int64_t *row_idx, int32_t kx_valid, float *dW, float *db, int32_t out, int32_t in, int64_t M);
+/* gemm_tn without a row gather, accumulating through partial tiles in `ws` (rlppo_dbg_gemm_tn_workspace_bytes) and a
+ * reduction kernel instead of fp32 atomics: the form rlppo_ppo_minibatch uses. */
+size_t rlppo_dbg_gemm_tn_workspace_bytes(int32_t out, int32_t in, int64_t M);
+int rlppo_dbg_gemm_tn_ws(void *stream, const float *dY, int64_t ldy, int32_t ny_valid, const float *X, int64_t ldx,
+                         int32_t kx_valid, float *dW, float *db, int32_t out, int32_t in, int64_t M, void *ws, size_t ws_bytes);
 
 #ifdef __cplusplus
 }

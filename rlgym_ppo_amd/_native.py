@@ -79,6 +79,9 @@ SIGNATURES = {
                                     c_int64, c_void_p, c_int64, c_int64, c_int32, c_int32, c_int32]),
     "rlppo_dbg_gemm_tn": (c_int32, [c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_int64, c_void_p, c_int32,
                                     c_void_p, c_void_p, c_int32, c_int32, c_int64]),
+    "rlppo_dbg_gemm_tn_workspace_bytes": (c_size_t, [c_int32, c_int32, c_int64]),
+    "rlppo_dbg_gemm_tn_ws": (c_int32, [c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_int64, c_int32, c_void_p, c_void_p,
+                                       c_int32, c_int32, c_int64, c_void_p, c_size_t]),
 }
 
 _lib = None

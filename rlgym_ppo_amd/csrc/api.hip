@@ -272,6 +272,16 @@ static int order_after(hipStream_t to, hipStream_t from, hipEvent_t ev) {
     return 0;
 }
 
+// partial-tile workspace of a net's weight-gradient launches (they run one after the other on the net's stream)
+static size_t tn_ws_floats(const NetLayout &net, int64_t mb) {
+    size_t m = 0;
+    for (int l = 0; l < net.n_layers; ++l) {
+        const size_t f = tn_partial_floats(net.L[l].out, net.L[l].in, mb);
+        if (f > m) m = f;
+    }
+    return m;
+}
+
 static size_t train_ws_floats(const NetLayout &pol, const NetLayout &val, int64_t mb) {
     size_t per_row = 0;
     for (int l = 0; l < pol.n_layers; ++l) per_row += pol.L[l].pout;
@@ -279,7 +289,7 @@ static size_t train_ws_floats(const NetLayout &pol, const NetLayout &val, int64_
     int m = max_pout(pol) > max_pout(val) ? max_pout(pol) : max_pout(val);
     per_row += (size_t)(pol.n_layers - 1 + val.n_layers - 1) * (size_t)m;  // one dX buffer per layer and net
     per_row += (size_t)pol.L[0].pin;                                         // the gathered minibatch states
-    return per_row * (size_t)mb;
+    return per_row * (size_t)mb + tn_ws_floats(pol, mb) + tn_ws_floats(val, mb);  // + one partial-tile buffer per chain
 }
 
 size_t rlppo_minibatch_workspace_bytes(const int32_t *pol_dims, int32_t pol_layers, const int32_t *val_dims,
@@ -295,7 +305,7 @@ size_t rlppo_minibatch_workspace_bytes(const int32_t *pol_dims, int32_t pol_laye
 // kernels, 74 KB + 64 KB of LDS) share a CU instead of two copies of the same kernel running in lock step.
 static int backward(hipStream_t st, hipStream_t dw, hipEvent_t *ev, const NetLayout &net, const float *packed,
                     const float *states, int64_t ld_states, const int64_t *idx, int64_t mb, float *const *acts,
-                    float *const *dx, float *grad) {
+                    float *const *dx, float *grad, float *tn_ws, size_t tn_floats) {
     // dx[l-1] receives dL/d(acts[l-1]) = dY of layer l-1 (one buffer per layer: the dW launches read them later)
     const int last = net.n_layers - 1;
     const bool fused = fused_eligible(net, mb);
@@ -318,7 +328,7 @@ static int backward(hipStream_t st, hipStream_t dw, hipEvent_t *ev, const NetLay
             rc = launch_gemv_dw(dw, dY, L.pout, X, ldx, grad + L.off_flat_w, grad + L.off_flat_b, L.in, L.pin, mb);
         else
             rc = launch_gemm_tn(dw, dY, L.pout, L.pout, X, ldx, l > 0 ? nullptr : idx, L.pin, grad + L.off_flat_w,
-                                grad + L.off_flat_b, L.out, L.in, mb);
+                                grad + L.off_flat_b, L.out, L.in, mb, dw == st ? tn_ws : nullptr, tn_floats);
         if (rc) return rc;
         if (gemv && !fused) {
             rc = launch_gemv_dx(st, dY, L.pout, packed + L.off_w, acts[l - 1], L.pin, dx[l - 1], L.pin, L.pin, mb);
@@ -394,6 +404,10 @@ int rlppo_ppo_minibatch(void *stream, const rlppo_minibatch_args *a) {
         w += (size_t)mb * m;
     }
 
+    float *pol_tn_ws = w;  // partial dW tiles, one buffer per chain
+    w += tn_ws_floats(pol, mb);
+    float *val_tn_ws = w;
+    w += tn_ws_floats(val, mb);
     // the minibatch gather (experience_buffer.py:82-87): one pass into the workspace, shared by both nets
     const float *states = a->states;
     int64_t ld_states = a->ld_states;
@@ -464,9 +478,9 @@ int rlppo_ppo_minibatch(void *stream, const rlppo_minibatch_args *a) {
         rc = order_after(side, st, g_ev_fork[slot]);
         if (rc) return rc;
     }
-    rc = backward(side, g_dw_streams ? g_dw[slot][1] : side, g_ev_dw[slot][1], val, a->val_packed, states, ld_states, gidx, mb, vact, vdx, a->val_grad);
+    rc = backward(side, g_dw_streams ? g_dw[slot][1] : side, g_ev_dw[slot][1], val, a->val_packed, states, ld_states, gidx, mb, vact, vdx, a->val_grad, val_tn_ws, tn_ws_floats(val, mb));
     if (rc) return rc;
-    rc = backward(st, g_dw_streams ? g_dw[slot][0] : st, g_ev_dw[slot][0], pol, a->pol_packed, states, ld_states, gidx, mb, pact, pdx, a->pol_grad);
+    rc = backward(st, g_dw_streams ? g_dw[slot][0] : st, g_ev_dw[slot][0], pol, a->pol_packed, states, ld_states, gidx, mb, pact, pdx, a->pol_grad, pol_tn_ws, tn_ws_floats(pol, mb));
     if (rc) return rc;
     if (side != st) rc = order_after(st, side, g_ev_join[slot]);
     return rc;
@@ -560,6 +574,10 @@ int rlppo_dbg_set(int32_t key, int32_t value) {
         set_gemv(value);
         return 0;
     }
+    if (key == 16) {
+        set_tn_partial(value);
+        return 0;
+    }
     set_error("dbg_set: unknown key %d", key);
     return RLPPO_ERR_ARG;
 }
@@ -589,5 +607,11 @@ int rlppo_dbg_gemm_nt(void *stream, const float *A, int64_t lda, const int64_t *
 int rlppo_dbg_gemm_tn(void *stream, const float *dY, int64_t ldy, int32_t ny_valid, const float *X, int64_t ldx,
                       const int64_t *row_idx, int32_t kx_valid, float *dW, float *db, int32_t out, int32_t in, int64_t M) {
     return launch_gemm_tn((hipStream_t)stream, dY, ldy, ny_valid, X, ldx, row_idx, kx_valid, dW, db, out, in, M);
+}
+size_t rlppo_dbg_gemm_tn_workspace_bytes(int32_t out, int32_t in, int64_t M) { return tn_partial_floats(out, in, M) * sizeof(float); }
+int rlppo_dbg_gemm_tn_ws(void *stream, const float *dY, int64_t ldy, int32_t ny_valid, const float *X, int64_t ldx,
+                         int32_t kx_valid, float *dW, float *db, int32_t out, int32_t in, int64_t M, void *ws, size_t ws_bytes) {
+    return launch_gemm_tn((hipStream_t)stream, dY, ldy, ny_valid, X, ldx, nullptr, kx_valid, dW, db, out, in, M, (float *)ws,
+                          ws_bytes / sizeof(float));
 }
 }

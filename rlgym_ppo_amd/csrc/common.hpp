@@ -61,9 +61,11 @@ int launch_gemm_nt(hipStream_t st, const float *A, int64_t lda, const int64_t *r
                    const float *bias, const float *mask_src, int64_t ld_mask, float *C, int64_t ldc, int64_t M, int N,
                    int K, int epi);
 
-// dW[n][k] += sum_m dY[m][n] X[m][k] ; db[n] += sum_m dY[m][n]   (atomic accumulation into the flat arena)
+// dW[n][k] += sum_m dY[m][n] X[m][k] ; db[n] += sum_m dY[m][n]   (accumulation into the flat arena: through partial tiles
+// in `ws` (>= tn_partial_floats(out, in, M) floats) + a reduction, or with fp32 atomics when ws is null / too small)
 int launch_gemm_tn(hipStream_t st, const float *dY, int64_t ldy, int ny_valid, const float *X, int64_t ldx,
-                   const int64_t *row_idx, int kx_valid, float *dW, float *db, int out, int in, int64_t M);
+                   const int64_t *row_idx, int kx_valid, float *dW, float *db, int out, int in, int64_t M,
+                   float *ws = nullptr, size_t ws_floats = 0);
 
 struct LossCfg {
     float clip, clip_lo, clip_hi, ent_coef, mb_ratio, inv_mb;
@@ -88,6 +90,10 @@ int launch_gemm_nt_sa(hipStream_t st, const float *A, int64_t lda, const float *
                       const float *mask_src, int64_t ld_mask, float *C, int64_t ldc, int64_t M, int N, int nb, int K, int epi);
 void set_nt_sa(int v);
 void set_tn_sa(int v);
+void set_tn_partial(int v);
+size_t tn_partial_floats(int out, int in, int64_t M);
+int launch_gemm_tn_partial(hipStream_t st, const float *dY, int64_t ldy, int ny_valid, const float *X, int64_t ldx,
+                           int kx_valid, float *dW, float *db, int out, int in, int64_t M, float *ws, size_t ws_floats);
 void set_gemv(int v);
 bool gemv_head_ok(int out, int kp);
 int launch_gemv_fwd(hipStream_t st, const float *x, int64_t ldx, const float *w, const float *b, float *y, int64_t ldy, int64_t n, int kp, int pout);

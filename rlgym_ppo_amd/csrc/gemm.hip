@@ -576,12 +576,17 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const float *__restrict
 }
 
 int launch_gemm_tn(hipStream_t st, const float *dY, int64_t ldy, int ny_valid, const float *X, int64_t ldx,
-                   const int64_t *row_idx, int kx_valid, float *dW, float *db, int out, int in, int64_t M) {
+                   const int64_t *row_idx, int kx_valid, float *dW, float *db, int out, int in, int64_t M, float *ws,
+                   size_t ws_floats) {
     if (M <= 0) return 0;
     RLPPO_CHECK_ARG(ny_valid % 4 == 0 && kx_valid % 4 == 0 && ldy % 4 == 0 && ldx % 4 == 0 && ny_valid <= ldy &&
                         kx_valid <= ldx && out <= ny_valid && in <= kx_valid,
                     "gemm_tn: bad shapes ny=%d kx=%d ldy=%ld ldx=%ld out=%d in=%d", ny_valid, kx_valid, (long)ldy,
                     (long)ldx, out, in);
+    if (!row_idx && ws) {  // default with a workspace: partial tiles + reduction instead of atomics (gemm_sa.hip)
+        const int rc = launch_gemm_tn_partial(st, dY, ldy, ny_valid, X, ldx, kx_valid, dW, db, out, in, M, ws, ws_floats);
+        if (rc != -1) return rc;
+    }
     // Split over the sample axis.  Measured on MI355X at M = 65,536 (tools/sweep_tn.py, us per launch):
     //   rows/WG      128    256    512   1024   2048
     //   256x256     157.5  123.9  103.0  104.6  197.5      few splits -> idle CUs; many splits -> fp32 atomic traffic

@@ -539,12 +539,18 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_sa_kernel(const float *__restr
 // unpadded; rows m..m+3 of one 16-float column group (what a ds_read_b32 fragment read touches) are spread over the banks
 // by XOR-ing the 16-byte chunk index with (m & 3) << 2, applied on the SOURCE address.  db column sums are read back from
 // the staged dY tile (only by the workgroups of the first k tile).  TMT = 16 halves the LDS footprint: 4 workgroups per CU.
-template <int TMT>
+//
+// PARTIAL: instead of 64 fp32 atomics per lane into dW (measured: 20-50 us of an 86 us launch -- 128-256 workgroups add into
+// the same 110-256 KB, and the memory-side atomic units serialise them), the workgroup stores its 128 x 128 partial tile
+// with 16 coalesced 16-byte stores per lane into partial[split][tile][(i*4+j)*256 + tid] and tn_reduce_kernel sums the
+// splits afterwards.  The sum order is then fixed: the weight gradients are bit-reproducible from run to run.
+template <int TMT, bool PARTIAL>
 __global__ __launch_bounds__(256, TMT == 16 ? 4 : 2) void gemm_tn_dma_kernel(const float *__restrict__ dY, unsigned ldy_b,
                                                                               int ny_valid, const float *__restrict__ X,
                                                                               unsigned ldx_b, int kx_valid,
                                                                               float *__restrict__ dW, float *__restrict__ db,
-                                                                              int out, int in, int64_t M, int rows_per_wg) {
+                                                                              int out, int in, int64_t M, int rows_per_wg,
+                                                                              float *__restrict__ partial) {
     constexpr int PPW = TMT / 8;  // 1 KiB pieces per wave, per operand and stage
     __shared__ __attribute__((aligned(16))) float lds[2 * 2 * TMT * 128 < 8 * 128 ? 8 * 128 : 2 * 2 * TMT * 128];
     float *Ys = lds;                 // [2][TMT][128]
@@ -644,10 +650,18 @@ __global__ __launch_bounds__(256, TMT == 16 ? 4 : 2) void gemm_tn_dma_kernel(con
         __syncthreads();
     }
 
+    if (PARTIAL) {
+        const size_t tile_id = (size_t)blockIdx.z * (gridDim.x * gridDim.y) + (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+        const __amdgpu_buffer_rsrc_t p_rs = make_rsrc(partial + tile_id * (128 * 128), 128 * 128 * 4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) stb(p_rs, (unsigned)tid * 16, (unsigned)(i * 4 + j) * 4096, acc[i][j]);
+    }
     // D[n][k]: lane owns rows n = n0 + wn*64 + 16 i + 4 q + e, column k = k0 + wk*64 + 16 j + r16
     const int out_here = (out - n0) < 128 ? (out - n0) : 128;
     const int in_here = (in - k0) < 128 ? (in - k0) : 128;
-    if (out_here > 0 && in_here > 0) {
+    if (!PARTIAL && out_here > 0 && in_here > 0) {
         const unsigned in_b = (unsigned)in * 4;
         const __amdgpu_buffer_rsrc_t w_rs = make_rsrc(dW + (int64_t)n0 * in + k0, (unsigned)(out_here - 1) * in_b + (unsigned)in_here * 4);
         unsigned w_off[4];
@@ -677,6 +691,77 @@ __global__ __launch_bounds__(256, TMT == 16 ? 4 : 2) void gemm_tn_dma_kernel(con
     }
 }
 
+// Sums the partial tiles of gemm_tn_dma_kernel<.., true> over the splits and adds the result into dW[out][in].
+// Block = 64 consecutive 16-byte elements of one tile x 4 split lanes (one wave each: 1 KiB coalesced per load, 8 loads
+// in flight); the four partial sums meet in LDS.  The final add is an atomic only so that launches of different
+// minibatches that share dW stay safe; there is exactly one per element and launch.
+__global__ __launch_bounds__(256) void tn_reduce_kernel(const float *__restrict__ partial, int splits, int tiles_x, int tiles,
+                                                        float *__restrict__ dW, int out, int in) {
+    __shared__ __attribute__((aligned(16))) float red[3][64][4];
+    const int tile = blockIdx.y, e64 = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const int elem4 = blockIdx.x * 64 + e64;  // 16-byte element of the tile: (i*4+j)*256 + tid
+    const f32x4 *base = reinterpret_cast<const f32x4 *>(partial) + (size_t)tile * 4096 + elem4;
+    const size_t stride = (size_t)tiles * 4096;
+    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+    int sp = sl;
+    for (; sp + 28 < splits; sp += 32) {
+        f32x4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = __builtin_nontemporal_load(base + (size_t)(sp + 4 * u) * stride);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc += v[u];
+    }
+    for (; sp < splits; sp += 4) acc += __builtin_nontemporal_load(base + (size_t)sp * stride);
+    if (sl > 0) *reinterpret_cast<f32x4 *>(&red[sl - 1][e64][0]) = acc;
+    __syncthreads();
+    if (sl > 0) return;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) acc += *reinterpret_cast<const f32x4 *>(&red[r][e64][0]);
+    const int ij = elem4 >> 8, t = elem4 & 255;
+    const int i = ij >> 2, j = ij & 3, wave = t >> 6, lane = t & 63;
+    const int n0 = (tile % tiles_x) * 128, k0 = (tile / tiles_x) * 128;
+    const int k = k0 + (wave & 1) * 64 + j * 16 + (lane & 15);
+    const int nb = n0 + (wave >> 1) * 64 + i * 16 + (lane >> 4) * 4;
+    if (k < in) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (nb + e < out) atomicAdd(dW + (size_t)(nb + e) * in + k, acc[e]);
+    }
+}
+
+static int g_tn_partial = 1;  // tuning: rlppo_dbg_set(16, 0/1)
+void set_tn_partial(int v) { g_tn_partial = v; }
+
+// rows per workgroup of the partial-tile form: no atomic traffic to trade against, so simply two workgroups per CU
+static int64_t tn_partial_rows(int out, int in, int64_t M) {
+    const int64_t tiles = cdiv(out, 128) * cdiv(in, 128);
+    int64_t rows = tiles >= 2 ? 512 : 256;
+    if (M < 64 * rows) rows = round_up(cdiv(M, 64) > 32 ? cdiv(M, 64) : 32, 32);
+    return rows;
+}
+size_t tn_partial_floats(int out, int in, int64_t M) {
+    if (M <= 0) return 0;
+    return (size_t)cdiv(M, tn_partial_rows(out, in, M)) * (size_t)(cdiv(out, 128) * cdiv(in, 128)) * (128 * 128);
+}
+
+// dW through partial tiles + reduction; returns -1 when not applicable (switch off, workspace too small, wide operands)
+int launch_gemm_tn_partial(hipStream_t st, const float *dY, int64_t ldy, int ny_valid, const float *X, int64_t ldx,
+                           int kx_valid, float *dW, float *db, int out, int in, int64_t M, float *ws, size_t ws_floats) {
+    if (!g_tn_partial || !ws || ws_floats < tn_partial_floats(out, in, M)) return -1;
+    const int rows_per_wg = (int)tn_partial_rows(out, in, M);
+    const int64_t lim = (int64_t)1 << 30;
+    if ((rows_per_wg + TM) * ldy * 4 >= lim || (rows_per_wg + TM) * ldx * 4 >= lim) return -1;
+    const int tiles_x = (int)cdiv(out, 128), tiles_y = (int)cdiv(in, 128), splits = (int)cdiv(M, rows_per_wg);
+    dim3 grid((unsigned)tiles_x, (unsigned)tiles_y, (unsigned)splits);
+    hipLaunchKernelGGL((gemm_tn_dma_kernel<32, true>), grid, dim3(256), 0, st, dY, (unsigned)(ldy * 4), ny_valid, X,
+                       (unsigned)(ldx * 4), kx_valid, dW, db, out, in, M, rows_per_wg, ws);
+    RLPPO_LAUNCH_CHECK();
+    hipLaunchKernelGGL(tn_reduce_kernel, dim3(64, (unsigned)(tiles_x * tiles_y)), dim3(256), 0, st, ws, splits, tiles_x,
+                       tiles_x * tiles_y, dW, out, in);
+    RLPPO_LAUNCH_CHECK();
+    return 0;
+}
+
 // returns -1 when not applicable (gathered X, or a leading dimension too wide for 32-bit tile offsets)
 int launch_gemm_tn_sa(hipStream_t st, dim3 grid, const float *dY, int64_t ldy, int ny_valid, const float *X, int64_t ldx,
                       int kx_valid, float *dW, float *db, int out, int in, int64_t M, int rows_per_wg) {
@@ -684,11 +769,11 @@ int launch_gemm_tn_sa(hipStream_t st, dim3 grid, const float *dY, int64_t ldy, i
     const int64_t lim = (int64_t)1 << 30;
     if ((rows_per_wg + TM) * ldy * 4 >= lim || (rows_per_wg + TM) * ldx * 4 >= lim || (int64_t)129 * in * 4 >= lim) return -1;
     if (g_tn_sa == 3)
-        hipLaunchKernelGGL(gemm_tn_dma_kernel<16>, grid, dim3(256), 0, st, dY, (unsigned)(ldy * 4), ny_valid, X,
-                           (unsigned)(ldx * 4), kx_valid, dW, db, out, in, M, rows_per_wg);
+        hipLaunchKernelGGL((gemm_tn_dma_kernel<16, false>), grid, dim3(256), 0, st, dY, (unsigned)(ldy * 4), ny_valid, X,
+                           (unsigned)(ldx * 4), kx_valid, dW, db, out, in, M, rows_per_wg, nullptr);
     else if (g_tn_sa == 2)
-        hipLaunchKernelGGL(gemm_tn_dma_kernel<32>, grid, dim3(256), 0, st, dY, (unsigned)(ldy * 4), ny_valid, X,
-                           (unsigned)(ldx * 4), kx_valid, dW, db, out, in, M, rows_per_wg);
+        hipLaunchKernelGGL((gemm_tn_dma_kernel<32, false>), grid, dim3(256), 0, st, dY, (unsigned)(ldy * 4), ny_valid, X,
+                           (unsigned)(ldx * 4), kx_valid, dW, db, out, in, M, rows_per_wg, nullptr);
     else
         hipLaunchKernelGGL(gemm_tn_sa_kernel, grid, dim3(256), 0, st, dY, (unsigned)(ldy * 4), ny_valid, X, (unsigned)(ldx * 4),
                            kx_valid, dW, db, out, in, M, rows_per_wg);

@@ -99,6 +99,32 @@ def test_gemm_tn(L, M, out, in_, gather):
     assert relerr(dW, refW) < 2e-6 and relerr(db, refb) < 2e-6
 
 
+@pytest.mark.parametrize("M,out,in_", [(1000, 90, 256), (4096, 256, 107), (70000, 256, 256), (33, 1, 64), (5000, 300, 130)])
+def test_gemm_tn_partial_tiles(L, M, out, in_):
+    """The form rlppo_ppo_minibatch uses: partial 128x128 tiles per split + a reduction kernel instead of fp32 atomics.
+    Same product as test_gemm_tn, ragged last stage / tile included, and bit-identical from run to run."""
+    g = torch.Generator().manual_seed(M + out)
+    ny, kx = int(L.rlppo_padded_out(out)), int(L.rlppo_padded_out(in_))
+    dY = torch.zeros(M, ny)
+    dY[:, :out] = torch.randn(M, out, generator=g)
+    X = torch.zeros(M, kx)
+    X[:, :in_] = torch.randn(M, in_, generator=g)
+    dW0, db0 = torch.randn(out, in_, generator=g), torch.randn(out, generator=g)
+    dYd, Xd = dev(dY), dev(X)
+    ws = torch.empty(int(L.rlppo_dbg_gemm_tn_workspace_bytes(out, in_, M)), dtype=torch.uint8, device="cuda")
+    assert ws.numel() > 0
+    ws.fill_(0xFF)  # NaN patterns: slots the kernel does not write must not reach the sums
+    results = []
+    for _ in range(3):
+        dW, db = dev(dW0), dev(db0)
+        check(L, L.rlppo_dbg_gemm_tn_ws(stream(), P(dYd), ny, ny, P(Xd), kx, kx, P(dW), P(db), out, in_, M, P(ws), ws.numel()))
+        results.append(dW.clone())
+    refW = dW0.double() + dY[:, :out].double().T @ X[:, :in_].double()
+    refb = db0.double() + dY[:, :out].double().sum(0)
+    assert relerr(results[0], refW) < 2e-6 and relerr(db, refb) < 2e-6
+    assert torch.equal(results[0], results[1]) and torch.equal(results[0], results[2])
+
+
 # -------------------------------------------------------------------------------------------------- GAE
 def run_gae(L, rews, dones, trunc, values, gamma, lmbda, std):
     n = len(rews)

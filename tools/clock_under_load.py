@@ -22,3 +22,14 @@ for secs in (0.5, 1.0, 2.0, 4.0):
         for _ in range(50): gemm()
         torch.cuda.synchronize()
     print(f"after {secs:.1f} s more of back-to-back GEMMs: {clock():.0f} MHz, hidden fwd {bench.time_region(gemm, 10)*1e3:.1f} us")
+# clock while ANOTHER stream keeps the chip busy with a different GEMM flavour (the two-stream update's situation)
+side = torch.cuda.Stream()
+X2 = torch.randn(M, 256, device="cuda"); dW = torch.zeros(256 * 256, device="cuda"); db = torch.zeros(256, device="cuda")
+for _ in range(3):
+    with torch.cuda.stream(side):
+        for _ in range(300):
+            N.check(L.rlppo_dbg_gemm_tn(ctypes.c_void_p(side.cuda_stream), P(X2), 256, 256, P(A), 256, None, 256, P(dW), P(db), 256, 256, M))
+    for _ in range(100): gemm()
+    c = clock()
+    torch.cuda.synchronize()
+    print(f"with dW GEMMs running on a second stream: {c:.0f} MHz")

@@ -22,14 +22,15 @@ C256, C96, C32 = (torch.empty(M, k, device=dev) for k in (256, 96, 32))
 idx = torch.randperm(M, device=dev)
 dW = torch.zeros(256 * 256, device=dev)
 db = torch.zeros(256, device=dev)
+tn_ws = torch.empty(int(L.rlppo_dbg_gemm_tn_workspace_bytes(256, 256, M)), dtype=torch.uint8, device=dev)
 reps = int(os.environ.get("REPS", 3))
 for _ in range(reps):
     N.check(L.rlppo_dbg_gemm_nt(st(), P(A256), 256, None, P(W), 256, P(bias), None, 0, P(C256), 256, M, 256, 256, 1))
     N.check(L.rlppo_dbg_gemm_nt(st(), P(A256), 256, None, P(W), 256, P(bias), None, 0, P(C96), 96, M, 96, 256, 0))
     N.check(L.rlppo_dbg_gemm_nt(st(), P(A256), 256, None, P(W), 256, None, P(A256), 256, P(C256), 256, M, 256, 256, 3))
-    N.check(L.rlppo_dbg_gemm_tn(st(), P(A256), 256, 256, P(A256), 256, None, 256, P(dW), P(db), 256, 256, M))
-    N.check(L.rlppo_dbg_gemm_tn(st(), P(A256), 256, 256, P(A128), 128, None, 128, P(dW), P(db), 256, 107, M))
-    N.check(L.rlppo_dbg_gemm_tn(st(), P(A96), 96, 96, P(A256), 256, None, 256, P(dW), P(db), 90, 256, M))
+    N.check(L.rlppo_dbg_gemm_tn_ws(st(), P(A256), 256, 256, P(A256), 256, 256, P(dW), P(db), 256, 256, M, P(tn_ws), tn_ws.numel()))
+    N.check(L.rlppo_dbg_gemm_tn_ws(st(), P(A256), 256, 256, P(A128), 128, 128, P(dW), P(db), 256, 107, M, P(tn_ws), tn_ws.numel()))
+    N.check(L.rlppo_dbg_gemm_tn_ws(st(), P(A96), 96, 96, P(A256), 256, 256, P(dW), P(db), 90, 256, M, P(tn_ws), tn_ws.numel()))
 rs = np.random.RandomState(0)
 n = 8192 * 256
 d = lambda x: torch.as_tensor(x).cuda()
