@@ -487,6 +487,47 @@ def test_minibatch_gather_and_accumulate_cfg2_shape(L):
         compare_minibatch(gp, gv, stats, ref, tol=2e-5)
 
 
+def test_minibatch_full_size_cfg2(L):
+    """BASELINE configs[1] at its real minibatch size: 65,536 rows gathered from a 100,000-row buffer, 256x3 nets.
+    (a) additivity, the size-independent property of the update: the gradient of the whole minibatch equals the sum of
+        the gradients of its two halves (each scaled by mb_ratio/2) -- different row splits, tile counts and partial-tile
+        reductions must agree; the report statistics are means, so they average;
+    (b) the oracle itself (float32 autograd restatement) on the rows whose ReLU masks are not decided by the last bit."""
+    torch.manual_seed(321)
+    pol = nets.init_mlp(107, (256, 256, 256), 90)
+    val = nets.init_mlp(107, (256, 256, 256), 1)
+    rs = np.random.RandomState(7)
+    n = 100000
+    obs = np.clip(rs.randn(n, 107), -5, 5).astype(np.float32)
+    probs = nets.discrete_probs(pol, obs)
+    act, logp = nets.discrete_sample(probs, nets.draw_exp_noise(n, 90))
+    old = (logp + torch.as_tensor(rs.randn(n).astype(np.float32) * 0.2)).numpy()
+    adv = rs.randn(n).astype(np.float32)
+    tgt = rs.randn(n).astype(np.float32)
+    amb = np.zeros(n, bool)
+    for params in (pol, val):
+        h = obs.astype(np.float64)
+        for w, b in params[:-1]:
+            pre = h @ w.double().numpy().T + b.double().numpy()
+            amb |= (np.abs(pre) < 2e-5).any(1)
+            h = np.maximum(pre, 0)
+    perm = rs.permutation(n)
+    perm = perm[~amb[perm]]
+    assert len(perm) >= 65536
+    idx = perm[:65536]
+    gp, gv, st = run_minibatch(L, "discrete", pol, val, obs, act.numpy(), old, tgt, adv, idx, 0.2, 0.005, 1.0)
+    gp1, gv1, st1 = run_minibatch(L, "discrete", pol, val, obs, act.numpy(), old, tgt, adv, idx[:32768], 0.2, 0.005, 0.5)
+    gp2, gv2, st2 = run_minibatch(L, "discrete", pol, val, obs, act.numpy(), old, tgt, adv, idx[32768:], 0.2, 0.005, 0.5)
+    for whole, h1, h2 in zip(gp + gv, gp1 + gv1, gp2 + gv2):
+        for k in (0, 1):
+            assert relerr(whole[k], h1[k].double() + h2[k].double()) < 1e-5
+    np.testing.assert_allclose(st[:5], (st1[:5] + st2[:5]) / 2, rtol=1e-5, atol=1e-8)
+    ti = torch.as_tensor(idx)
+    ref = ppo.minibatch_autograd("discrete", pol, val, torch.as_tensor(obs)[ti], act[ti].float(), torch.as_tensor(old)[ti],
+                                 torch.as_tensor(adv)[ti], torch.as_tensor(tgt)[ti], 0.2, 0.005, 1.0)
+    compare_minibatch(gp, gv, st, ref, tol=2e-5)
+
+
 def test_clip_adam_matches_oracle(L):
     torch.manual_seed(0)
     params = nets.init_mlp(20, (16,), 5)
