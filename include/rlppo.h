@@ -196,6 +196,12 @@ int rlppo_clip_adam(void *stream, float *params, float *grads, float *exp_avg, f
 int rlppo_mt19937_seed(uint32_t *state625, uint32_t seed);
 int rlppo_mt19937_permutation(uint32_t *state625, int64_t n, int64_t *out);
 
+/* Precision of the ROLLOUT forward passes (rlppo_mlp_forward, rlppo_*_act): 0 = fp32 (default; the parity mode),
+ * 1 = activations and master weights rounded to bf16 as MFMA operands, fp32 accumulation / bias / activation
+ * (BASELINE configs[4] "bf16 fwd / fp32 master weights").  rlppo_ppo_minibatch always computes in fp32.  The reference
+ * has no such mode (it is fp32 throughout): outputs then agree with an fp32 forward to ~1e-2, not 1e-5. */
+int rlppo_set_inference_precision(int32_t mode);
+
 /* ------------------------------------------------------------------------------------------ diagnostics */
 /* Single-kernel entry points used by tests/ to check each GEMM flavour in isolation against a CPU product.
  * epilogue: 0 bias, 1 bias+relu, 2 bias+tanh, 3 relu-mask (mask_src > 0).  Shapes as in csrc/gemm.hip. */

@@ -76,6 +76,21 @@ def mlp(params, x, out_act=None):
     return h
 
 
+def mlp_bf16_operands(params, x, out_act=None):
+    """The build's optional rollout precision (BASELINE configs[4] "bf16 fwd / fp32 master weights"; the reference has no
+    such mode): activations and weights rounded to bf16 (round-to-nearest-even) as they enter each product, fp32
+    accumulation, fp32 bias and activation.  Products of two bf16 values are exact in fp32, so only the summation order
+    separates this restatement from the MFMA kernel."""
+    h = as_obs(x)
+    for i, (w, b) in enumerate(params):
+        h = torch.nn.functional.linear(h.bfloat16().float(), w.bfloat16().float(), b)
+        if i < len(params) - 1:
+            h = torch.relu(h)
+    if out_act == "tanh":
+        h = torch.tanh(h)
+    return h
+
+
 def value_forward(params, obs):
     return mlp(params, obs)  # [n, 1]
 

@@ -65,7 +65,7 @@ static int max_pout(const NetLayout &net) {
 // Forward pass.  acts[l] receives the output of layer l ([n][pout_l]); for inference the caller passes two
 // ping-pong buffers, for training one buffer per layer (they are the saved activations of the backward pass).
 static int forward(hipStream_t st, const NetLayout &net, const float *packed, const float *obs, int64_t ld_obs,
-                   const int64_t *row_idx, int64_t n, int out_tanh, float *const *acts) {
+                   const int64_t *row_idx, int64_t n, int out_tanh, float *const *acts, int bf16_operands = 0) {
     if (fused_eligible(net, n)) return launch_fused_forward(st, net, packed, obs, ld_obs, row_idx, n, out_tanh, acts);
     const float *x = obs;
     int64_t ldx = ld_obs;
@@ -79,7 +79,7 @@ static int forward(hipStream_t st, const NetLayout &net, const float *packed, co
             rc = launch_gemv_fwd(st, x, ldx, packed + L.off_w, packed + L.off_b, acts[l], L.pout, n, L.pin, L.pout);
         else
             rc = launch_gemm_nt(st, x, ldx, ridx, packed + L.off_w, L.pin, packed + L.off_b, nullptr, 0, acts[l], L.pout, n,
-                                L.pout, L.pin, epi);
+                                L.pout, L.pin, epi, bf16_operands);
         if (rc) return rc;
         x = acts[l];
         ldx = L.pout;
@@ -107,7 +107,7 @@ static int forward_pingpong(hipStream_t st, const NetLayout &net, const float *p
     if (final_out) acts[net.n_layers - 1] = final_out;
     if (fused_eligible(net, n))  // the fused chain keeps hidden activations on chip: nothing to store for inference
         for (int l = 0; l + 1 < net.n_layers; ++l) acts[l] = nullptr;
-    int rc = forward(st, net, packed, obs, ld_obs, nullptr, n, out_tanh, acts);
+    int rc = forward(st, net, packed, obs, ld_obs, nullptr, n, out_tanh, acts, get_infer_bf16());  // inference only
     if (rc) return rc;
     *out = acts[net.n_layers - 1];
     *ld_out = net.L[net.n_layers - 1].pout;
@@ -513,6 +513,11 @@ int rlppo_clip_adam(void *stream, float *params, float *grads, float *exp_avg, f
 
 // ------------------------------------------------------------------------------------------ diagnostics
 extern "C" {
+int rlppo_set_inference_precision(int32_t mode) {
+    RLPPO_CHECK_ARG(mode == 0 || mode == 1, "set_inference_precision: mode %d (0 = fp32, 1 = bf16 operands)", mode);
+    set_infer_bf16(mode);
+    return 0;
+}
 int rlppo_dbg_set(int32_t key, int32_t value) {
     if (key == 1) {
         set_gae_algo(value);

@@ -59,7 +59,7 @@ enum Epilogue { EPI_BIAS = 0, EPI_BIAS_RELU = 1, EPI_BIAS_TANH = 2, EPI_MASK = 3
 // C[m][0:N] = epi(A[m][0:K] . B[n][0:K]^T)   (K % 32 == 0, N = padded out in {32,64,96,128,k*128})
 int launch_gemm_nt(hipStream_t st, const float *A, int64_t lda, const int64_t *row_idx, const float *B, int64_t ldb,
                    const float *bias, const float *mask_src, int64_t ld_mask, float *C, int64_t ldc, int64_t M, int N,
-                   int K, int epi);
+                   int K, int epi, int bf16_operands = 0);
 
 // dW[n][k] += sum_m dY[m][n] X[m][k] ; db[n] += sum_m dY[m][n]   (accumulation into the flat arena: through partial tiles
 // in `ws` (>= tn_partial_floats(out, in, M) floats) + a reduction, or with fp32 atomics when ws is null / too small)
@@ -90,6 +90,10 @@ int launch_gemm_nt_sa(hipStream_t st, const float *A, int64_t lda, const float *
                       const float *mask_src, int64_t ld_mask, float *C, int64_t ldc, int64_t M, int N, int nb, int K, int epi);
 void set_nt_sa(int v);
 void set_tn_sa(int v);
+void set_infer_bf16(int v);
+int get_infer_bf16();
+int launch_gemm_nt_bf16(hipStream_t st, const float *A, int64_t lda, const float *B, int64_t ldb, const float *bias, float *C,
+                        int64_t ldc, int64_t M, int N, int nb, int K, int epi);
 void set_tn_partial(int v);
 size_t tn_partial_floats(int out, int in, int64_t M);
 int launch_gemm_tn_partial(hipStream_t st, const float *dY, int64_t ldy, int ny_valid, const float *X, int64_t ldx,

@@ -398,7 +398,7 @@ static int launch_ws_1(hipStream_t st, dim3 grid, int epi, const float *A, int64
 
 int launch_gemm_nt(hipStream_t st, const float *A, int64_t lda, const int64_t *row_idx, const float *B, int64_t ldb,
                    const float *bias, const float *mask_src, int64_t ld_mask, float *C, int64_t ldc, int64_t M, int N,
-                   int K, int epi) {
+                   int K, int epi, int bf16_operands) {
     if (M <= 0) return 0;
     RLPPO_CHECK_ARG(K > 0 && K % 32 == 0, "gemm_nt: K=%d must be a positive multiple of 32", K);
     RLPPO_CHECK_ARG(lda % 4 == 0 && ldb % 4 == 0 && ldc % 4 == 0 && lda >= K && ldb >= K && ldc >= N,
@@ -415,6 +415,8 @@ int launch_gemm_nt(hipStream_t st, const float *A, int64_t lda, const int64_t *r
         set_error("gemm_nt: N=%d is not a padded output width", N);
         return RLPPO_ERR_ARG;
     }
+    if (bf16_operands && !row_idx && epi != EPI_MASK && 129 * lda * 4 < ((int64_t)1 << 31) && 129 * ldc * 4 < ((int64_t)1 << 31))
+        return launch_gemm_nt_bf16(st, A, lda, B, ldb, bias, C, ldc, M, N, nb, K, epi);  // inference-only forward (gemm_sa.hip)
     if (!row_idx && !g_nt_ws) {
         // default for ungathered operands: the scalar-addressed kernel (gemm_sa.hip); -1 = not applicable
         const int rc = launch_gemm_nt_sa(st, A, lda, B, ldb, bias, mask_src, ld_mask, C, ldc, M, N, nb, K, epi);

@@ -335,6 +335,114 @@ __global__ __launch_bounds__(256, BKT == 16 ? 4 : 2) void gemm_nt_dma_kernel(con
     nt_epilogue<NB, EPI>(acc, mask_src, ldm_b, C, ldc_b, m0, n0, rows_here, wave, r16, q);
 }
 
+// ------------------------------------------------------------------------------------------------ gemm_nt, bf16 operands
+// Inference-only forward (BASELINE configs[4]: "bf16 fwd / fp32 master weights"): the fp32 activations and the fp32 master
+// weights are staged exactly as in gemm_nt_dma_kernel (fp32 tiles in LDS), rounded to bf16 when a lane builds its MFMA
+// operands, multiplied by v_mfma_f32_16x16x32_bf16 and accumulated / biased / activated in fp32.  Selected by
+// rlppo_set_inference_precision(1) for the rollout entry points only; rlppo_ppo_minibatch never uses it.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ bf16x8 to_bf16x8(const float *lo, const float *hi) {
+    const f32x4 a = *reinterpret_cast<const f32x4 *>(lo), b = *reinterpret_cast<const f32x4 *>(hi);
+    bf16x8 r;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        r[e] = (__bf16)a[e];
+        r[4 + e] = (__bf16)b[e];
+    }
+    return r;
+}
+
+template <int NB, int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_nt_bf16_kernel(const float *__restrict__ A, unsigned lda_b,
+                                                                              const float *__restrict__ B, unsigned ldb_b,
+                                                                              const float *__restrict__ bias,
+                                                                              const float *__restrict__ mask_src,
+                                                                              unsigned ldm_b, float *__restrict__ C,
+                                                                              unsigned ldc_b, int64_t M, int K) {
+    constexpr int BN = NB * 16;
+    constexpr int BKT = 32;  // one v_mfma_f32_16x16x32_bf16 step per LDS tile
+    constexpr int CPR = BKT / 4;     // 16-byte chunks per tile row
+    constexpr int RPW = 64 / CPR;    // tile rows one wave instruction fills
+    constexpr int RPP = 4 * RPW;     // rows per pass of the 4 waves
+    constexpr int A_IT = SBM / RPP, B_IT = BN / RPP;
+    static_assert(BN % RPP == 0, "column tile must be a whole number of staging passes");
+    __shared__ __attribute__((aligned(16))) float lds[2 * SBM * BKT + 2 * BN * BKT];
+    float *As = lds;
+    float *Bs = lds + 2 * SBM * BKT;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);  // provably uniform: it addresses the DMA destination (M0)
+    const int r16 = lane & 15, q = lane >> 4;
+    const int64_t m0 = (int64_t)blockIdx.x * SBM;
+    const int n0 = blockIdx.y * BN;
+    const int rows_here = (int)((M - m0) < SBM ? (M - m0) : SBM);
+
+    const __amdgpu_buffer_rsrc_t a_rs = make_rsrc(reinterpret_cast<const char *>(A) + m0 * lda_b,
+                                                  (unsigned)(rows_here - 1) * lda_b + (unsigned)K * 4);
+    const __amdgpu_buffer_rsrc_t b_rs = make_rsrc(reinterpret_cast<const char *>(B) + (int64_t)n0 * ldb_b,
+                                                  (unsigned)(BN - 1) * ldb_b + (unsigned)K * 4);
+    // lane -> (row, physical chunk) of the 1 KiB piece its wave instruction fills; it fetches the logical chunk that the
+    // swizzle maps there (rows of later passes keep the swizzle key, so one offset serves all passes)
+    const int row_p = wave * RPW + lane / CPR, pch = lane % CPR;
+    const int lch = BKT == 32 ? (pch ^ (row_p & 7)) : (pch ^ ((0 - (row_p >> 2)) & 3));
+    const unsigned a_off = (unsigned)row_p * lda_b + lch * 16;
+    const unsigned b_off = (unsigned)row_p * ldb_b + lch * 16;
+    const unsigned a_step = (unsigned)RPP * lda_b, b_step = (unsigned)RPP * ldb_b;
+
+    f32x4 acc[2][NB];
+    if (EPI == EPI_MASK) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < NB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    } else {
+        const __amdgpu_buffer_rsrc_t bias_rs = make_rsrc(bias + n0, BN * 4);
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            acc[0][j] = ldb(bias_rs, (unsigned)(q * 16), j * 64);
+            acc[1][j] = acc[0][j];
+        }
+    }
+
+    auto issue_tile = [&](int buf, unsigned kb) {
+        float *Ad = As + buf * SBM * BKT + wave_u * RPW * BKT;
+        float *Bd = Bs + buf * BN * BKT + wave_u * RPW * BKT;
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rs, Ad + i * RPP * BKT, 16, a_off, kb + i * a_step, 0, 0);
+#pragma unroll
+        for (int i = 0; i < B_IT; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(b_rs, Bd + i * RPP * BKT, 16, b_off, kb + i * b_step, 0, 0);
+    };
+
+    const int nk = K / BKT;
+    issue_tile(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if ((kt + 1) < nk) issue_tile(cur ^ 1, (unsigned)(kt + 1) * (BKT * 4));
+        const float *Ac = As + cur * SBM * BKT + (wave * 32) * BKT;
+        const float *Bc = Bs + cur * BN * BKT;
+        // lane (r16, q) holds k = 8 q .. 8 q + 7 of its row: chunks 2 q and 2 q + 1 of the swizzled fp32 image, rounded to
+        // bf16 (round-to-nearest-even, v_cvt_pk_bf16_f32) as they become MFMA operands
+        bf16x8 fa[2], fb[NB];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) fa[i] = to_bf16x8(&Ac[dswz<32>(i * 16 + r16, 2 * q)], &Ac[dswz<32>(i * 16 + r16, 2 * q + 1)]);
+#pragma unroll
+        for (int j = 0; j < NB; ++j) fb[j] = to_bf16x8(&Bc[dswz<32>(j * 16 + r16, 2 * q)], &Bc[dswz<32>(j * 16 + r16, 2 * q + 1)]);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < NB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);  // keep the MFMAs above the wait: they are what hides the DMA latency
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of the next tile have landed in LDS
+        __syncthreads();
+    }
+    nt_epilogue<NB, EPI>(acc, mask_src, ldm_b, C, ldc_b, m0, n0, rows_here, wave, r16, q);
+}
+
 static int g_nt_sa = 3;  // tuning: rlppo_dbg_set(9, v): 0 gemm.hip kernel, 1 register-staged, 2 LDS-DMA BK=32, 3 LDS-DMA BK=16
 static int g_tn_sa = 2;  // tuning: rlppo_dbg_set(10, v): 0 gemm.hip kernel, 1 register-staged, 2 LDS-DMA 32-row stages, 3 16-row stages
 void set_nt_sa(int v) { g_nt_sa = v; }
@@ -367,6 +475,42 @@ static int launch_sa_1(hipStream_t st, dim3 grid, int epi, const float *A, unsig
 #undef SA
     RLPPO_LAUNCH_CHECK();
     return 0;
+}
+
+static int g_infer_bf16 = 0;  // rlppo_set_inference_precision
+void set_infer_bf16(int v) { g_infer_bf16 = v; }
+int get_infer_bf16() { return g_infer_bf16; }
+
+template <int NB>
+static int launch_bf16_1(hipStream_t st, dim3 grid, int epi, const float *A, unsigned lda_b, const float *B, unsigned ldb_b,
+                         const float *bias, float *C, unsigned ldc_b, int64_t M, int K) {
+#define BF(E)                                                                                                          \
+    case E:                                                                                                            \
+        hipLaunchKernelGGL((gemm_nt_bf16_kernel<NB, E>), grid, dim3(256), 0, st, A, lda_b, B, ldb_b, bias, nullptr, 0u, C, \
+                           ldc_b, M, K);                                                                               \
+        break;
+    switch (epi) {
+        BF(EPI_BIAS) BF(EPI_BIAS_RELU) BF(EPI_BIAS_TANH)
+        default:
+            set_error("gemm_nt (bf16 operands): epilogue %d is not a forward epilogue", epi);
+            return RLPPO_ERR_ARG;
+    }
+#undef BF
+    RLPPO_LAUNCH_CHECK();
+    return 0;
+}
+
+// forward product with bf16-rounded operands; same argument checks as launch_gemm_nt (done by the caller)
+int launch_gemm_nt_bf16(hipStream_t st, const float *A, int64_t lda, const float *B, int64_t ldb, const float *bias, float *C,
+                        int64_t ldc, int64_t M, int N, int nb, int K, int epi) {
+    dim3 grid((unsigned)cdiv(M, SBM), (unsigned)(N / (nb * 16)));
+    const unsigned la = (unsigned)(lda * 4), lb = (unsigned)(ldb * 4), lc = (unsigned)(ldc * 4);
+    switch (nb) {
+        case 8: return launch_bf16_1<8>(st, grid, epi, A, la, B, lb, bias, C, lc, M, K);
+        case 6: return launch_bf16_1<6>(st, grid, epi, A, la, B, lb, bias, C, lc, M, K);
+        case 4: return launch_bf16_1<4>(st, grid, epi, A, la, B, lb, bias, C, lc, M, K);
+        default: return launch_bf16_1<2>(st, grid, epi, A, la, B, lb, bias, C, lc, M, K);
+    }
 }
 
 int launch_gemm_nt_sa_stamped(hipStream_t st, const float *A, int64_t lda, const float *B, int64_t ldb, const float *bias,

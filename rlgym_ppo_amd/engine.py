@@ -172,3 +172,11 @@ class LegacyPermutation:
                                                   ctypes.c_void_p(out.ctypes.data)))
         self.rng.set_state((kind, st[:624].copy(), int(st[624]), has_gauss, cached))
         return out
+
+
+def set_inference_precision(mode):
+    """Precision of the rollout forward passes (get_action / value predictions): "fp32" (default: the reference's
+    arithmetic, bit-exact action indices) or "bf16" (activations and master weights rounded to bf16 as MFMA operands,
+    fp32 accumulation; BASELINE configs[4]).  The PPO update always runs in fp32."""
+    from . import _native as N
+    N.check(N.lib().rlppo_set_inference_precision({"fp32": 0, "bf16": 1}[mode]))
