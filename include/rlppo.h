@@ -196,6 +196,12 @@ int rlppo_clip_adam(void *stream, float *params, float *grads, float *exp_avg, f
 int rlppo_mt19937_seed(uint32_t *state625, uint32_t seed);
 int rlppo_mt19937_permutation(uint32_t *state625, int64_t n, int64_t *out);
 
+/* dst[r][0..width) = src[idx[r]][0..width), fp32 rows, 16 bytes per thread (width, ld_src multiples of 4; dst rows are
+ * `width` floats apart).  The minibatch gather of experience_buffer.py:82-87 (used inside rlppo_ppo_minibatch) and the
+ * step-major -> trajectory-major flatten of a device-resident rollout (batched_agent_manager.py:154-172 builds the same
+ * order with Python lists). */
+int rlppo_gather_rows(void *stream, const float *src, int64_t ld_src, const int64_t *idx, float *dst, int32_t width, int64_t n);
+
 /* Precision of the ROLLOUT forward passes (rlppo_mlp_forward, rlppo_*_act): 0 = fp32 (default; the parity mode),
  * 1 = activations and master weights rounded to bf16 as MFMA operands, fp32 accumulation / bias / activation
  * (BASELINE configs[4] "bf16 fwd / fp32 master weights").  rlppo_ppo_minibatch always computes in fp32.  The reference

@@ -1,0 +1,142 @@
+"""Rollout collection for ONE vectorised environment that steps all of its agents in lockstep, with the rollout kept on
+the GPU (device-resident rollout storage, vector-env fast path).
+
+The reference collects through one OS process per environment, a UDP datagram per step and Python lists per agent
+(batched_agent_manager.py:126-299, batched_trajectory.py:58-105); at 4096 agents that is 4096 datagrams per step and,
+per iteration, seven `np.asarray` flattens plus a 224 MB upload of the states.  Here the policy's padded input rows of
+step t are written straight into their final, trajectory-major position on the device (row a*T + t of agent a), so
+`Learner.add_new_experience` runs the value pass, the GAE scan and the buffer submit on them without a copy through the host.
+
+What comes out is exactly what the reference's assembler would produce for the same interaction sequence when every agent
+is its own trajectory stream (oracle/host.py::flatten_lockstep_rollout is the restatement the tests compare with):
+  * trajectories are concatenated agent by agent, steps in order (batched_trajectory.py:58-105);
+  * the last collected step of every agent is force-marked truncated unless it is terminal (quirk Q4, the flush at
+    batched_agent_manager.py:154-172), and the episode continues in the next collect;
+  * observations are standardised with the SCALAR statistics of feature 0 and clipped to +-5 (quirk Q5, :303-315), the
+    running statistics are advanced every `steps_per_obs_stats_increment` steps with the raw observations (:233-235);
+  * `next_states[i]` is the observation the environment returned for step i (after its auto-reset at episode ends).
+
+Environment interface: `reset() -> obs [n, d]`; `step(actions [n, k]) -> (obs [n, d], rewards [n], dones [n],
+truncated [n], info)` with auto-reset of finished agents; `observation_space.shape`, `action_space` as in the reference.
+"""
+import time
+
+import numpy as np
+import torch
+
+from ..util.running_stats import WelfordRunningStat
+from .batched_agent import describe_action_space
+
+
+class VectorAgentManager(object):
+    def __init__(self, policy, min_inference_size=8, seed=123, standardize_obs=True, steps_per_obs_stats_increment=5):
+        self.policy = policy
+        self.seed = seed
+        self.standardize_obs = standardize_obs
+        self.steps_per_obs_stats_increment = steps_per_obs_stats_increment
+        self.steps_since_obs_stats_update = 0
+        self.obs_stats = None
+        self.cumulative_timesteps = 0
+        self.average_reward = None
+        self.env = None
+        self.collect_metrics_fn = None
+        self.n_agents = 0
+        self.value_input_rows = None  # [N + 1, ld] device rows of the last collect: states ++ the last next_state
+        self._next_rows = None        # padded device rows of the observation the agents act on next
+        self._ep_rews = None
+
+    # same signature as BatchedAgentManager.init_processes (learner.py:140-150); n_processes is ignored
+    def init_processes(self, n_processes, build_env_fn, collect_metrics_fn=None, spawn_delay=None, render=False,
+                       render_delay=None, shm_buffer_size=8192):
+        self.env = build_env_fn()
+        self.collect_metrics_fn = collect_metrics_fn
+        if hasattr(self.env.action_space, "seed"):
+            self.env.action_space.seed(self.seed)
+        obs = np.asarray(self.env.reset(), dtype=np.float32)
+        self.n_agents, d = obs.shape
+        self._ep_rews = np.zeros(self.n_agents, np.float64)
+        self.obs_stats = None
+        if self.standardize_obs:  # the reset observations enter the statistics and are acted on RAW
+            self.obs_stats = WelfordRunningStat(shape=d)                      # (batched_agent_manager.py:366-384)
+            self.obs_stats.increment(obs, obs.shape[0])
+        self._initial_obs = obs
+        n_acts, code = describe_action_space(self.env.action_space)
+        return int(np.prod(self.env.observation_space.shape)), int(n_acts), int(code)
+
+    def _standardize_scalars(self):
+        if not self.standardize_obs:
+            return None
+        return float(self.obs_stats.mean[0]), float(self.obs_stats.std[0])
+
+    @torch.no_grad()
+    def collect_timesteps(self, n):
+        """-> ((states, actions, log_probs, rewards, next_states, dones, truncated), metrics, n_collected, seconds):
+        device tensors in trajectory-major order; `self.value_input_rows` holds states ++ last next_state contiguously."""
+        t1 = time.perf_counter()
+        arena = self.policy.arena
+        dev, ld, na = arena.device, arena.ld_in, self.n_agents
+        T = max(1, -(-int(n) // na))
+        N_ = na * T
+        flat = torch.empty((N_ + 1, ld), dtype=torch.float32, device=dev)
+        nxt_flat = torch.empty((N_, ld), dtype=torch.float32, device=dev)
+        s3, n3 = flat[:N_].view(na, T, ld), nxt_flat.view(na, T, ld)
+        acts = logp = None
+        rews = np.empty((na, T), np.float32)
+        dones = np.empty((na, T), np.float32)
+        trunc = np.empty((na, T), np.float32)
+        metrics = []
+        if self._next_rows is None:
+            self._next_rows = arena.stage_obs(self._initial_obs)
+        rows = self._next_rows
+        for t in range(T):
+            a_dev, lp_dev = self.policy.act_padded(rows)
+            if acts is None:
+                k = 1 if a_dev.dim() == 1 else a_dev.shape[1]
+                acts = torch.empty((na, T, k), dtype=torch.float32, device=dev)
+                logp = torch.empty((na, T), dtype=torch.float32, device=dev)
+            s3[:, t].copy_(rows)
+            acts[:, t].copy_(a_dev.view(na, -1))
+            logp[:, t].copy_(lp_dev)
+            step = self.env.step(a_dev.cpu().numpy().astype(np.float32).reshape(na, -1))
+            if len(step) == 4:
+                obs, r, d, info = step
+                tr = np.zeros(na, np.float32)
+            else:
+                obs, r, d, tr, info = step
+            obs = np.asarray(obs, dtype=np.float32)
+            rews[:, t], dones[:, t], trunc[:, t] = r, d, tr
+            if self.collect_metrics_fn is not None:
+                metrics.append(self.collect_metrics_fn(info["state"]))
+            scalars = self._standardize_scalars()  # fetched BEFORE this step's increment (batched_agent_manager.py:230-235)
+            if self.standardize_obs:  # same cadence as one worker response per step
+                if self.steps_since_obs_stats_update > self.steps_per_obs_stats_increment:
+                    self.obs_stats.increment(obs, obs.shape[0])
+                    self.steps_since_obs_stats_update = 0
+                else:
+                    self.steps_since_obs_stats_update += 1
+            self._track_rewards(rews[:, t], (dones[:, t] + trunc[:, t]) > 0)
+            rows = arena.stage_obs(obs, scalars)
+            n3[:, t].copy_(rows)
+        flat[N_].copy_(rows[na - 1])                      # next_states[-1]: what add_new_experience appends (learner.py:347)
+        trunc[:, T - 1] = np.where(dones[:, T - 1] == 0, 1.0, 0.0)   # flush rule (quirk Q4)
+        up = lambda x: torch.from_numpy(np.ascontiguousarray(x.reshape(-1))).to(dev)
+        self.value_input_rows = flat
+        self._next_rows = rows
+        self.cumulative_timesteps += N_
+        experience = (flat[:N_], acts.view(N_, -1), logp.view(N_), up(rews), nxt_flat, up(dones), up(trunc))
+        return experience, metrics, N_, time.perf_counter() - t1
+
+    def _track_rewards(self, r, ended):
+        """Episode-reward average as batched_agent_manager.py:377-399 keeps it, one agent = one stream."""
+        self._ep_rews += r
+        for a in np.flatnonzero(ended):
+            if self.average_reward is None:
+                self.average_reward = float(self._ep_rews[a])
+            else:
+                self.average_reward = self.average_reward * 0.9 + float(self._ep_rews[a]) * 0.1
+            self._ep_rews[a] = 0.0
+
+    def cleanup(self):
+        if self.env is not None and hasattr(self.env, "close"):
+            self.env.close()
+        self.env = None

@@ -513,6 +513,11 @@ int rlppo_clip_adam(void *stream, float *params, float *grads, float *exp_avg, f
 
 // ------------------------------------------------------------------------------------------ diagnostics
 extern "C" {
+int rlppo_gather_rows(void *stream, const float *src, int64_t ld_src, const int64_t *idx, float *dst, int32_t width, int64_t n) {
+    if (n == 0) return 0;
+    RLPPO_CHECK_ARG(n > 0 && src && idx && dst, "gather_rows: null pointer");
+    return launch_gather_rows((hipStream_t)stream, src, ld_src, idx, dst, width, n);
+}
 int rlppo_set_inference_precision(int32_t mode) {
     RLPPO_CHECK_ARG(mode == 0 || mode == 1, "set_inference_precision: mode %d (0 = fp32, 1 = bf16 operands)", mode);
     set_infer_bf16(mode);

@@ -108,8 +108,9 @@ class NetArena:
             self._packed_key = key
 
     # ------------------------------------------------------------------------------------------ inference
-    def stage_obs(self, obs, standardize=None):
-        """numpy / tensor observations of any float dtype -> zero-padded fp32 device rows [n, ld_in]."""
+    def stage_obs(self, obs, standardize=None, out=None):
+        """numpy / tensor observations of any float dtype -> zero-padded fp32 device rows [n, ld_in]
+        (written into `out` when given: the rollout storage's slot of the current step)."""
         if isinstance(obs, torch.Tensor):
             t = obs.detach()
             if t.dtype not in (torch.float32, torch.float64):
@@ -126,7 +127,10 @@ class NetArena:
         n, d = t.shape
         if d != self.d_in:
             raise ValueError(f"observation width {d} != network input {self.d_in}")
-        out = torch.empty((n, self.ld_in), dtype=torch.float32, device=self.device)
+        if out is None:
+            out = torch.empty((n, self.ld_in), dtype=torch.float32, device=self.device)
+        elif out.shape != (n, self.ld_in) or not out.is_contiguous() or out.dtype != torch.float32:
+            raise ValueError("stage_obs: out must be a contiguous fp32 [n, ld_in] device tensor")
         mean0, std0, flag = 0.0, 1.0, 0
         if standardize is not None:
             mean0, std0, flag = float(standardize[0]), float(standardize[1]), 1

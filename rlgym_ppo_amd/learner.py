@@ -14,7 +14,7 @@ import time
 import numpy as np
 import torch
 
-from .batched_agents import BatchedAgentManager
+from .batched_agents import BatchedAgentManager, VectorAgentManager
 from .ppo import ExperienceBuffer, PPOLearner
 from .util import KBHit, WelfordRunningStat, reporting, torch_functions
 
@@ -39,7 +39,8 @@ class Learner(object):
             wandb_group_name=None, wandb_run_name=None,
             checkpoints_save_folder=None, add_unix_timestamp: bool = True, checkpoint_load_folder="latest",
             save_every_ts: int = 1_000_000, instance_launch_delay=None, random_seed: int = 123,
-            n_checkpoints_to_keep: int = 5, shm_buffer_size: int = 8192, device: str = "auto"):
+            n_checkpoints_to_keep: int = 5, shm_buffer_size: int = 8192, device: str = "auto",
+            vector_env: bool = False):
         assert env_create_function is not None, "MUST PROVIDE A FUNCTION TO CREATE RLGYM FUNCTIONS TO INITIALIZE RLGYM-PPO"
         if checkpoints_save_folder is None:
             checkpoints_save_folder = os.path.join("data", "checkpoints", "rlgym-ppo-run")
@@ -80,9 +81,12 @@ class Learner(object):
 
         print("Initializing processes...")
         collect_metrics_fn = None if metrics_logger is None else self.metrics_logger.collect_metrics
-        self.agent = BatchedAgentManager(None, min_inference_size=min_inference_size, seed=random_seed,
-                                         standardize_obs=standardize_obs,
-                                         steps_per_obs_stats_increment=steps_per_obs_stats_increment)
+        # vector_env=True (not in the reference): env_create_function builds ONE vectorised environment whose agents step in
+        # lockstep; the rollout then stays on the GPU (batched_agents/vector_agent_manager.py)
+        manager_cls = VectorAgentManager if vector_env else BatchedAgentManager
+        self.agent = manager_cls(None, min_inference_size=min_inference_size, seed=random_seed,
+                                 standardize_obs=standardize_obs,
+                                 steps_per_obs_stats_increment=steps_per_obs_stats_increment)
         obs_space_size, act_space_size, action_space_type = self.agent.init_processes(
             n_processes=n_proc, build_env_fn=env_create_function, collect_metrics_fn=collect_metrics_fn,
             spawn_delay=instance_launch_delay, render=render, render_delay=render_delay, shm_buffer_size=shm_buffer_size)
@@ -192,12 +196,20 @@ class Learner(object):
         states, actions, log_probs, rewards, next_states, dones, truncated = experience
         value_net = self.ppo_learner.value_net
         n = states.shape[0]
-        val_inp = np.concatenate([np.asarray(states).reshape(n, -1), np.asarray(next_states[-1]).reshape(1, -1)], axis=0)
-        rows = value_net.arena.stage_obs(val_inp)            # zero-padded fp32 device rows [N+1, ld]
+        on_device = isinstance(states, torch.Tensor) and states.is_cuda   # VectorAgentManager: rollout already in HBM
+        if on_device:
+            rows = self.agent.value_input_rows               # [N+1, ld]: states ++ the last next_state, padded
+            assert rows.shape[0] == n + 1 and rows.data_ptr() == states.data_ptr()
+            d_logical = int(self.ppo_learner.policy.arena.d_in)
+        else:
+            val_inp = np.concatenate([np.asarray(states).reshape(n, -1), np.asarray(next_states[-1]).reshape(1, -1)], axis=0)
+            rows = value_net.arena.stage_obs(val_inp)        # zero-padded fp32 device rows [N+1, ld]
+            d_logical = int(np.asarray(states).reshape(n, -1).shape[1])
         val_preds = value_net.forward_padded(rows).contiguous()
 
         dev = rows.device
-        up = lambda x: torch.as_tensor(np.ascontiguousarray(np.asarray(x, dtype=np.float32))).to(dev)
+        up = lambda x: x.to(dev, torch.float32) if isinstance(x, torch.Tensor) else \
+            torch.as_tensor(np.ascontiguousarray(np.asarray(x, dtype=np.float32))).to(dev)
         rews_d, dones_d, trunc_d = up(rewards), up(dones), up(truncated)
         ret_std = self.return_stats.std[0] if self.standardize_returns else None
         value_targets, advantages, returns = torch_functions.gae_device(
@@ -207,7 +219,7 @@ class Learner(object):
             n_to_increment = min(self.max_returns_per_stats_increment, n)
             self.return_stats.increment(returns[:n_to_increment].cpu().numpy(), n_to_increment)
 
-        self.experience_buffer._d = int(np.asarray(states).reshape(n, -1).shape[1])  # logical width of the padded rows
+        self.experience_buffer._d = d_logical  # logical width of the padded rows
         self.experience_buffer.submit_experience(rows[:n], actions, log_probs, rews_d, next_states, dones_d, trunc_d,
                                                  value_targets, advantages)
 
@@ -299,6 +311,6 @@ class Learner(object):
     def cleanup(self):
         if self.wandb_run is not None:
             self.wandb_run.finish()
-        if type(self.agent) == BatchedAgentManager:
+        if type(self.agent) in (BatchedAgentManager, VectorAgentManager):
             self.agent.cleanup()
         self.experience_buffer.clear()

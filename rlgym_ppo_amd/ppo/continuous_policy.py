@@ -35,6 +35,12 @@ class ContinuousPolicy(ArenaModule):
             action = (eps * std + mean).clamp(min=-1, max=1)
             return action.cpu(), self.logpdf(action, mean, std).cpu()
         rows = a.stage_obs(obs, standardize)
+        actions, logp = self.act_padded(rows, noise)
+        return actions.cpu(), logp.cpu()
+
+    def act_padded(self, rows, noise=None):
+        """Padded device rows -> (actions fp32 [n, k], summed log_probs fp32 [n]) on the device (see DiscreteFF.act_padded)."""
+        a = self.arena
         n, k = rows.shape[0], self.n_out // 2
         if noise is None and self.noise_mode == "device":
             noise = torch.empty(n, k, device=a.device).normal_(0, 1)  # fast mode: torch's HIP generator, not the reference's CPU stream
@@ -48,7 +54,7 @@ class ContinuousPolicy(ArenaModule):
         N.check(N.lib().rlppo_gaussian_act(stream_ptr(), a.dims_c, a.n_layers, ptr(a.packed), ptr(rows), rows.shape[1], n,
                                            ptr(eps), float(self.affine_map.m), float(self.affine_map.b), ptr(actions),
                                            ptr(logp), ptr(ws), ws.numel()))
-        return actions.cpu(), logp.cpu()
+        return actions, logp
 
     @staticmethod
     def logpdf(x, mean, std):

@@ -40,6 +40,14 @@ class DiscreteFF(ArenaModule):
         if deterministic:
             probs = torch.clamp(torch.softmax(a.forward(rows)[:, :self.n_actions], dim=-1), min=1e-11, max=1)
             return probs.cpu().numpy().argmax(), 0  # quirk Q11: flat argmax over the whole batch
+        actions, logp = self.act_padded(rows, noise)
+        return actions.cpu(), logp.cpu()
+
+    def act_padded(self, rows, noise=None):
+        """Padded device rows [n, ld_in] -> (actions int64 [n], log_probs fp32 [n]) ON THE DEVICE: the part of get_action
+        after staging, for callers that keep the rollout on the GPU (VectorAgentManager)."""
+        a = self.arena
+        n = rows.shape[0]
         if noise is None and self.noise_mode == "device":
             noise = torch.empty(n, self.n_actions, device=a.device).exponential_(1)  # fast mode: torch's HIP generator, not the reference's CPU stream
         elif noise is None:
@@ -51,7 +59,7 @@ class DiscreteFF(ArenaModule):
         ws = a.forward_ws(n)
         N.check(N.lib().rlppo_discrete_act(stream_ptr(), a.dims_c, a.n_layers, ptr(a.packed), ptr(rows), rows.shape[1], n,
                                            ptr(q), ptr(actions), ptr(logp), None, ptr(ws), ws.numel()))
-        return actions.cpu(), logp.cpu()
+        return actions, logp
 
     def get_backprop_data(self, obs, acts):
         """Compatibility accessor with an autograd graph (discrete_policy.py:64-80), evaluated by stock PyTorch

@@ -34,6 +34,12 @@ class MultiDiscreteFF(ArenaModule):
                 start += split
             return torch.stack(action).cpu().numpy(), 0
         rows = a.stage_obs(obs, standardize)
+        actions, logp = self.act_padded(rows, noise)
+        return actions.cpu(), logp.cpu()
+
+    def act_padded(self, rows, noise=None):
+        """Padded device rows -> (actions int64 [n, 8], log_probs fp32 [n]) on the device (see DiscreteFF.act_padded)."""
+        a = self.arena
         n = rows.shape[0]
         if noise is None and self.noise_mode == "device":
             noise = torch.empty(n * 8, 3, device=a.device).exponential_(1)  # fast mode: torch's HIP generator, not the reference's CPU stream
@@ -46,7 +52,7 @@ class MultiDiscreteFF(ArenaModule):
         ws = a.forward_ws(n)
         N.check(N.lib().rlppo_multidiscrete_act(stream_ptr(), a.dims_c, a.n_layers, ptr(a.packed), ptr(rows), rows.shape[1],
                                                 n, ptr(q), ptr(actions), ptr(logp), ptr(ws), ws.numel()))
-        return actions.cpu(), logp.cpu()
+        return actions, logp
 
     def get_backprop_data(self, obs, acts):
         """Compatibility accessor with an autograd graph (multi_discrete_policy.py:76-89); unused by PPOLearner."""

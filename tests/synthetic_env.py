@@ -71,3 +71,40 @@ def make_continuous_env():
 
 def make_multidiscrete_env():
     return SyntheticEnv(kind="multidiscrete", new_gym_api=False)
+
+
+class SyntheticVectorEnv:
+    """n agents stepping in lockstep with auto-reset: observations are drawn independently of the actions (so two
+    implementations of the policy that disagree on a near-tie still see the same observation stream), rewards depend on
+    the actions, episode lengths differ per agent."""
+
+    def __init__(self, obs_dim=107, n_actions=90, n_agents=16, seed=0, kind="discrete"):
+        self.obs_dim, self.n_agents, self.kind = obs_dim, n_agents, kind
+        self.rs = np.random.RandomState(seed)
+        self.observation_space = _Space(shape=(obs_dim,))
+        self.action_space = Discrete(n=n_actions) if kind == "discrete" else Box(shape=(n_actions,))
+        self.ep_len = 5 + (np.arange(n_agents) * 7) % 13
+        self.t = np.zeros(n_agents, np.int64)
+
+    def _obs(self):
+        return (self.rs.randn(self.n_agents, self.obs_dim) * 2 + 0.5).astype(np.float32)
+
+    def reset(self):
+        self.t[:] = 0
+        return self._obs()
+
+    def step(self, actions):
+        actions = np.asarray(actions, np.float32).reshape(self.n_agents, -1)
+        self.t += 1
+        rew = (np.tanh(actions.sum(1) * 0.01) + self.rs.randn(self.n_agents) * 0.1).astype(np.float32)
+        done = self.t >= self.ep_len
+        trunc = (~done) & (self.t % 4 == 0) & (np.arange(self.n_agents) % 3 == 0)
+        self.t[done | trunc] = 0
+        return self._obs(), rew, done.astype(np.float32), trunc.astype(np.float32), {"state": None}
+
+    def close(self):
+        pass
+
+
+def make_vector_env():
+    return SyntheticVectorEnv()

@@ -1,0 +1,77 @@
+"""Device-resident rollout of a vectorised environment: VectorAgentManager against the
+numpy restatement of the reference's trajectory assembly (oracle/host.py::lockstep_rollout), and the whole Learner loop
+running on it."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+import synthetic_env  # noqa: E402
+from oracle import host, nets  # noqa: E402
+
+
+@pytest.mark.parametrize("standardize", [True, False])
+def test_vector_rollout_matches_trajectory_assembly(standardize):
+    from rlgym_ppo_amd.batched_agents import VectorAgentManager
+    from rlgym_ppo_amd.ppo import DiscreteFF
+    torch.manual_seed(11)
+    pol = DiscreteFF(107, 90, (32, 32), "cuda:0")
+    params = [(l.weight.detach().cpu(), l.bias.detach().cpu()) for l in pol.arena.linears]
+    mgr = VectorAgentManager(pol, seed=5, standardize_obs=standardize)
+    d, n_act, code = mgr.init_processes(0, lambda: synthetic_env.SyntheticVectorEnv(seed=3))
+    assert (d, n_act, code) == (107, 90, 0)
+
+    env = synthetic_env.SyntheticVectorEnv(seed=3)           # the oracle's own copy of the environment
+
+    def act_fn(obs):                                         # the reference's sampling chain on the CPU
+        probs = nets.discrete_probs(params, obs)
+        a, lp = nets.discrete_sample(probs, nets.draw_exp_noise(obs.shape[0], 90))
+        return a.numpy().astype(np.float32).reshape(-1, 1), lp.numpy()
+
+    step_fn = lambda a: env.step(a)[:4]
+    state = None
+    reset_obs = env.reset()
+    for n_req in (16 * 9, 16 * 5 - 3):                       # second request is rounded up to whole steps: 5 per agent
+        torch.manual_seed(100 + n_req)
+        exp, _, n_col, _ = mgr.collect_timesteps(n_req)
+        torch.manual_seed(100 + n_req)
+        T = -(-n_req // 16)
+        ref, state = host.lockstep_rollout(reset_obs, step_fn, act_fn, T, standardize=standardize, state=state)
+        assert n_col == 16 * T and mgr.value_input_rows.shape[0] == n_col + 1
+        states, actions, logp, rews, nxt, dones, trunc = [x.cpu().numpy() for x in exp]
+        assert np.array_equal(actions, ref[1])                                  # action indices: exact
+        np.testing.assert_allclose(states[:, :107], ref[0], rtol=1e-6, atol=1e-7)
+        assert (states[:, 107:] == 0).all()
+        np.testing.assert_allclose(logp, ref[2], rtol=1e-5, atol=1e-6)
+        assert np.array_equal(rews, ref[3]) and np.array_equal(dones, ref[5]) and np.array_equal(trunc, ref[6])
+        np.testing.assert_allclose(nxt[:, :107], ref[4], rtol=1e-6, atol=1e-7)
+        np.testing.assert_allclose(mgr.value_input_rows[n_col, :107].cpu().numpy(), ref[4][-1], rtol=1e-6, atol=1e-7)
+        assert trunc.reshape(16, T)[:, -1].tolist() == [1.0 - x for x in dones.reshape(16, T)[:, -1].tolist()]
+    assert mgr.cumulative_timesteps == 16 * 9 + 16 * 5
+    mgr.cleanup()
+
+
+def test_learner_loop_on_vector_env(tmp_path, capsys):
+    from rlgym_ppo_amd import Learner
+    learner = Learner(synthetic_env.make_vector_env, vector_env=True, n_proc=1, timestep_limit=1500, exp_buffer_size=1024,
+                      ts_per_iteration=512, ppo_epochs=2, ppo_batch_size=512, ppo_minibatch_size=256,
+                      policy_layer_sizes=(64, 64), critic_layer_sizes=(64, 64), checkpoints_save_folder=str(tmp_path / "ck"),
+                      add_unix_timestamp=False, save_every_ts=1000, checkpoint_load_folder=None, random_seed=3)
+    try:
+        learner._learn()
+    finally:
+        learner.agent.cleanup()
+    out = capsys.readouterr().out
+    assert out.count("BEGIN ITERATION REPORT") == 3 and "Policy Entropy" in out
+    assert learner.agent.cumulative_timesteps == 3 * 512 and learner.epoch == 3
+    assert len(learner.experience_buffer) == 1024
+    assert learner.ppo_learner.cumulative_model_updates == 2 * (1 + 2 + 2)
+    assert learner.agent.average_reward is not None and np.isfinite(learner.agent.average_reward)
+    b = learner.experience_buffer
+    assert b.states.shape == (1024, 107) and b.next_states.shape == (1024, 107) and b.actions.shape[0] == 1024
+    assert torch.isfinite(b.advantages).all() and torch.isfinite(b.values).all()
