@@ -8,7 +8,7 @@ step t are written straight into their final, trajectory-major position on the d
 `Learner.add_new_experience` runs the value pass, the GAE scan and the buffer submit on them without a copy through the host.
 
 What comes out is exactly what the reference's assembler would produce for the same interaction sequence when every agent
-is its own trajectory stream (oracle/host.py::flatten_lockstep_rollout is the restatement the tests compare with):
+is its own trajectory stream (tests/test_gpu_vector_rollout.py compares with a numpy restatement of these rules):
   * trajectories are concatenated agent by agent, steps in order (batched_trajectory.py:58-105);
   * the last collected step of every agent is force-marked truncated unless it is terminal (quirk Q4, the flush at
     batched_agent_manager.py:154-172), and the episode continues in the next collect;
