@@ -202,6 +202,12 @@ int rlppo_mt19937_permutation(uint32_t *state625, int64_t n, int64_t *out);
  * order with Python lists). */
 int rlppo_gather_rows(void *stream, const float *src, int64_t ld_src, const int64_t *idx, float *dst, int32_t width, int64_t n);
 
+/* WelfordRunningStat.increment(samples, n) (running_stats.py:28-46) on the device, bit-exact with the reference's sample-by-
+ * sample float32 update: mean[d], m2[d] (= running_mean, running_variance) are updated in place with the n rows of
+ * `samples` (row stride ld floats); `count` is the number of samples already absorbed (the caller adds n afterwards). */
+int rlppo_welford_increment(void *stream, const float *samples, int64_t ld, int64_t n, int32_t d, float *mean, float *m2,
+                            int64_t count);
+
 /* Precision of the ROLLOUT forward passes (rlppo_mlp_forward, rlppo_*_act): 0 = fp32 (default; the parity mode),
  * 1 = activations and master weights rounded to bf16 as MFMA operands, fp32 accumulation / bias / activation
  * (BASELINE configs[4] "bf16 fwd / fp32 master weights").  rlppo_ppo_minibatch always computes in fp32.  The reference

@@ -104,18 +104,19 @@ class VectorAgentManager(object):
             else:
                 obs, r, d, tr, info = step
             obs = np.asarray(obs, dtype=np.float32)
+            obs_dev = torch.from_numpy(np.ascontiguousarray(obs)).to(dev)   # raw observations: one upload per step
             rews[:, t], dones[:, t], trunc[:, t] = r, d, tr
             if self.collect_metrics_fn is not None:
                 metrics.append(self.collect_metrics_fn(info["state"]))
             scalars = self._standardize_scalars()  # fetched BEFORE this step's increment (batched_agent_manager.py:230-235)
             if self.standardize_obs:  # same cadence as one worker response per step
                 if self.steps_since_obs_stats_update > self.steps_per_obs_stats_increment:
-                    self.obs_stats.increment(obs, obs.shape[0])
+                    self._increment_obs_stats(obs_dev)
                     self.steps_since_obs_stats_update = 0
                 else:
                     self.steps_since_obs_stats_update += 1
             self._track_rewards(rews[:, t], (dones[:, t] + trunc[:, t]) > 0)
-            rows = arena.stage_obs(obs, scalars)
+            rows = arena.stage_obs(obs_dev, scalars)
             n3[:, t].copy_(rows)
         flat[N_].copy_(rows[na - 1])                      # next_states[-1]: what add_new_experience appends (learner.py:347)
         trunc[:, T - 1] = np.where(dones[:, T - 1] == 0, 1.0, 0.0)   # flush rule (quirk Q4)
@@ -125,6 +126,20 @@ class VectorAgentManager(object):
         self.cumulative_timesteps += N_
         experience = (flat[:N_], acts.view(N_, -1), logp.view(N_), up(rews), nxt_flat, up(dones), up(trunc))
         return experience, metrics, N_, time.perf_counter() - t1
+
+    def _increment_obs_stats(self, obs_dev):
+        """WelfordRunningStat.increment(obs, n) on the device (bit-exact with the host class's sample-by-sample float32
+        update, which costs ~10 ms of Python per 4096 samples); the host object stays the owner of the state (checkpoints)."""
+        from .. import _native as N
+        from ..engine import ptr, stream_ptr
+        st = self.obs_stats
+        n, d = obs_dev.shape
+        mean = torch.from_numpy(st.running_mean.reshape(-1).copy()).to(obs_dev.device)
+        m2 = torch.from_numpy(st.running_variance.reshape(-1).copy()).to(obs_dev.device)
+        N.check(N.lib().rlppo_welford_increment(stream_ptr(), ptr(obs_dev), d, n, d, ptr(mean), ptr(m2), int(st.count)))
+        st.running_mean[...] = mean.cpu().numpy().reshape(st.running_mean.shape)
+        st.running_variance[...] = m2.cpu().numpy().reshape(st.running_variance.shape)
+        st.count += n
 
     def _track_rewards(self, r, ended):
         """Episode-reward average as batched_agent_manager.py:377-399 keeps it, one agent = one stream."""

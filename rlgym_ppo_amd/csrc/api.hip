@@ -518,6 +518,12 @@ int rlppo_gather_rows(void *stream, const float *src, int64_t ld_src, const int6
     RLPPO_CHECK_ARG(n > 0 && src && idx && dst, "gather_rows: null pointer");
     return launch_gather_rows((hipStream_t)stream, src, ld_src, idx, dst, width, n);
 }
+int rlppo_welford_increment(void *stream, const float *samples, int64_t ld, int64_t n, int32_t d, float *mean, float *m2,
+                            int64_t count) {
+    if (n == 0) return 0;
+    RLPPO_CHECK_ARG(n > 0 && d > 0 && ld >= d && count >= 0 && samples && mean && m2, "welford_increment: bad argument");
+    return launch_welford((hipStream_t)stream, samples, ld, n, d, mean, m2, (long long)count);
+}
 int rlppo_set_inference_precision(int32_t mode) {
     RLPPO_CHECK_ARG(mode == 0 || mode == 1, "set_inference_precision: mode %d (0 = fp32, 1 = bf16 operands)", mode);
     set_infer_bf16(mode);

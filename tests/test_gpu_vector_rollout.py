@@ -75,3 +75,26 @@ def test_learner_loop_on_vector_env(tmp_path, capsys):
     b = learner.experience_buffer
     assert b.states.shape == (1024, 107) and b.next_states.shape == (1024, 107) and b.actions.shape[0] == 1024
     assert torch.isfinite(b.advantages).all() and torch.isfinite(b.values).all()
+
+
+def test_welford_increment_bit_exact():
+    """rlppo_welford_increment == WelfordRunningStat.increment (sample-by-sample float32), bit for bit, from a non-trivial
+    state, for the observation statistics (d = 107, 4096 samples) and the return statistics (d = 1)."""
+    import ctypes
+    from rlgym_ppo_amd import _native as N
+    L = N.lib()
+    P = lambda t: ctypes.c_void_p(t.data_ptr())
+    st = lambda: ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    rs = np.random.RandomState(0)
+    for d, n, ld in ((107, 4096, 107), (1, 150, 1), (231, 700, 256)):
+        w = host.Welford(d)
+        warm = (rs.randn(37, d) * 3 + 1).astype(np.float32)
+        w.increment(warm, 37)
+        x = (rs.randn(n, d) * 2 + 0.5).astype(np.float32)
+        mean, m2 = torch.from_numpy(w.mean_.copy()).cuda(), torch.from_numpy(w.m2.copy()).cuda()
+        xp = np.zeros((n, ld), np.float32)
+        xp[:, :d] = x
+        xd = torch.from_numpy(xp).cuda()
+        N.check(L.rlppo_welford_increment(st(), P(xd), ld, n, d, P(mean), P(m2), w.count))
+        w.increment(x, n)
+        assert np.array_equal(mean.cpu().numpy(), w.mean_) and np.array_equal(m2.cpu().numpy(), w.m2)
