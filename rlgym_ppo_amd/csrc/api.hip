@@ -276,7 +276,11 @@ static int order_after(hipStream_t to, hipStream_t from, hipEvent_t ev) {
 static size_t tn_ws_floats(const NetLayout &net, int64_t mb) {
     size_t m = 0;
     for (int l = 0; l < net.n_layers; ++l) {
-        const size_t f = tn_partial_floats(net.L[l].out, net.L[l].in, mb);
+        size_t f = tn_partial_floats(net.L[l].out, net.L[l].in, mb);
+        if (net.L[l].out == 1) {  // one-output head: block partials of gemv_dw_kernel (64 rows per block)
+            const size_t g = (size_t)cdiv(mb, 64) * (size_t)(net.L[l].pin + 4);
+            if (g > f) f = g;
+        }
         if (f > m) m = f;
     }
     return m;
@@ -325,7 +329,8 @@ static int backward(hipStream_t st, hipStream_t dw, hipEvent_t *ev, const NetLay
         }
         const bool gemv = l == last && l > 0 && gemv_head_ok(L.out, L.pin);  // one-output head (gemv.hip)
         if (gemv)
-            rc = launch_gemv_dw(dw, dY, L.pout, X, ldx, grad + L.off_flat_w, grad + L.off_flat_b, L.in, L.pin, mb);
+            rc = launch_gemv_dw(dw, dY, L.pout, X, ldx, grad + L.off_flat_w, grad + L.off_flat_b, L.in, L.pin, mb,
+                                dw == st ? tn_ws : nullptr, tn_floats);
         else
             rc = launch_gemm_tn(dw, dY, L.pout, L.pout, X, ldx, l > 0 ? nullptr : idx, L.pin, grad + L.off_flat_w,
                                 grad + L.off_flat_b, L.out, L.in, mb, dw == st ? tn_ws : nullptr, tn_floats);

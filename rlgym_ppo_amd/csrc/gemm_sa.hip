@@ -830,7 +830,10 @@ __global__ __launch_bounds__(256, TMT == 16 ? 4 : 2) void gemm_tn_dma_kernel(con
             float sum = 0.f;
 #pragma unroll
             for (int r = 0; r < 8; ++r) sum += red[r * 128 + tid];
-            atomicAdd(db + n0 + tid, sum);
+            if (PARTIAL)  // column sums of this split: partial_db[split][n tile][128], behind the tile partials
+                partial[(size_t)gridDim.z * gridDim.y * gridDim.x * (128 * 128) + ((size_t)blockIdx.z * gridDim.x + blockIdx.x) * 128 + tid] = sum;
+            else
+                atomicAdd(db + n0 + tid, sum);
         }
     }
 }
@@ -840,7 +843,7 @@ __global__ __launch_bounds__(256, TMT == 16 ? 4 : 2) void gemm_tn_dma_kernel(con
 // in flight); the four partial sums meet in LDS.  The final add is an atomic only so that launches of different
 // minibatches that share dW stay safe; there is exactly one per element and launch.
 __global__ __launch_bounds__(256) void tn_reduce_kernel(const float *__restrict__ partial, int splits, int tiles_x, int tiles,
-                                                        float *__restrict__ dW, int out, int in) {
+                                                        float *__restrict__ dW, float *__restrict__ db, int out, int in) {
     __shared__ __attribute__((aligned(16))) float red[3][64][4];
     const int tile = blockIdx.y, e64 = threadIdx.x & 63, sl = threadIdx.x >> 6;
     const int elem4 = blockIdx.x * 64 + e64;  // 16-byte element of the tile: (i*4+j)*256 + tid
@@ -857,7 +860,34 @@ __global__ __launch_bounds__(256) void tn_reduce_kernel(const float *__restrict_
     }
     for (; sp < splits; sp += 4) acc += __builtin_nontemporal_load(base + (size_t)sp * stride);
     if (sl > 0) *reinterpret_cast<f32x4 *>(&red[sl - 1][e64][0]) = acc;
+    // bias gradient (one block per n tile): 128 columns x 2 halves of the splits, 16 loads in flight per thread, every
+    // partial combined in a fixed order
+    __shared__ float dbh[128];
+    const bool db_block = db && blockIdx.x == 63 && tile < tiles_x;
+    float sdb = 0.f;
+    if (db_block) {
+        const int c = threadIdx.x & 127, half = threadIdx.x >> 7;
+        const float *pdb = partial + (size_t)splits * tiles * (128 * 128) + (size_t)tile * 128 + c;
+        const size_t dstride = (size_t)tiles_x * 128;
+        const int s_lo = half ? (splits + 1) / 2 : 0, s_hi = half ? splits : (splits + 1) / 2;
+        float a16[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) a16[u] = 0.f;
+        int s2 = s_lo;
+        for (; s2 + 15 < s_hi; s2 += 16) {
+            float v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) v[u] = pdb[(size_t)(s2 + u) * dstride];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) a16[u] += v[u];
+        }
+        for (int u = 0; s2 < s_hi; ++s2, ++u) a16[u] += pdb[(size_t)s2 * dstride];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) sdb += a16[u];
+        if (half) dbh[c] = sdb;
+    }
     __syncthreads();
+    if (db_block && threadIdx.x < 128 && tile * 128 + (int)threadIdx.x < out) atomicAdd(db + tile * 128 + threadIdx.x, sdb + dbh[threadIdx.x]);
     if (sl > 0) return;
 #pragma unroll
     for (int r = 0; r < 3; ++r) acc += *reinterpret_cast<const f32x4 *>(&red[r][e64][0]);
@@ -885,7 +915,8 @@ static int64_t tn_partial_rows(int out, int in, int64_t M) {
 }
 size_t tn_partial_floats(int out, int in, int64_t M) {
     if (M <= 0) return 0;
-    return (size_t)cdiv(M, tn_partial_rows(out, in, M)) * (size_t)(cdiv(out, 128) * cdiv(in, 128)) * (128 * 128);
+    const size_t splits = (size_t)cdiv(M, tn_partial_rows(out, in, M));
+    return splits * (size_t)(cdiv(out, 128) * cdiv(in, 128)) * (128 * 128) + splits * (size_t)cdiv(out, 128) * 128;  // tiles + db
 }
 
 // dW through partial tiles + reduction; returns -1 when not applicable (switch off, workspace too small, wide operands)
@@ -901,7 +932,7 @@ int launch_gemm_tn_partial(hipStream_t st, const float *dY, int64_t ldy, int ny_
                        (unsigned)(ldx * 4), kx_valid, dW, db, out, in, M, rows_per_wg, ws);
     RLPPO_LAUNCH_CHECK();
     hipLaunchKernelGGL(tn_reduce_kernel, dim3(64, (unsigned)(tiles_x * tiles_y)), dim3(256), 0, st, ws, splits, tiles_x,
-                       tiles_x * tiles_y, dW, out, in);
+                       tiles_x * tiles_y, dW, db, out, in);
     RLPPO_LAUNCH_CHECK();
     return 0;
 }

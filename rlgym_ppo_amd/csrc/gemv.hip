@@ -67,7 +67,7 @@ __global__ __launch_bounds__(256) void gemv_dx_kernel(const float *__restrict__ 
 // block = rows [r0, r0 + rows_per_block); thread = (row lane, 16-byte column chunk); cpr chunks per row, 256 / cpr row lanes
 __global__ __launch_bounds__(256) void gemv_dw_kernel(const float *__restrict__ dy, int64_t ldy, const float *__restrict__ x,
                                                       int64_t ldx, float *__restrict__ dw, float *__restrict__ db, int in,
-                                                      int cpr, int64_t n, int rows_per_block) {
+                                                      int cpr, int64_t n, int rows_per_block, float *__restrict__ part) {
     __shared__ __attribute__((aligned(16))) float red[256 * 4];
     __shared__ float dsum_s[4];
     const int chunk = threadIdx.x % cpr, rlane = threadIdx.x / cpr, RL = 256 / cpr;
@@ -100,12 +100,59 @@ __global__ __launch_bounds__(256) void gemv_dw_kernel(const float *__restrict__ 
     dsum = wave_sum64(dsum);
     if ((threadIdx.x & 63) == 0) dsum_s[threadIdx.x >> 6] = dsum;
     __syncthreads();
+    // with a workspace the block's sums go to part[block][4 cpr + 4] and gemv_dw_reduce_kernel adds the blocks in order
+    // (bit-reproducible); without one they are added atomically
+    float *mine = part ? part + (size_t)blockIdx.x * (cpr * 4 + 4) : nullptr;
     for (int k = threadIdx.x; k < cpr * 4 && k < in; k += 256) {
         float s = 0.f;
         for (int r = 0; r < RL; ++r) s += red[r * cpr * 4 + k];
-        atomicAdd(dw + k, s);
+        if (mine) mine[k] = s;
+        else atomicAdd(dw + k, s);
     }
-    if (threadIdx.x == 0 && db) atomicAdd(db, dsum_s[0] + dsum_s[1] + dsum_s[2] + dsum_s[3]);
+    if (threadIdx.x == 0) {
+        const float ds = dsum_s[0] + dsum_s[1] + dsum_s[2] + dsum_s[3];
+        if (mine) mine[cpr * 4] = ds;
+        else if (db) atomicAdd(db, ds);
+    }
+}
+
+// block = 16 columns x 16 row lanes; a thread adds every 16th block partial with 16 loads in flight, the 16 lanes of a column
+// meet in LDS and are added in lane order: a fixed summation order
+__global__ __launch_bounds__(256) void gemv_dw_reduce_kernel(const float *__restrict__ part, int blocks, int kp,
+                                                             float *__restrict__ dw, float *__restrict__ db, int in) {
+    __shared__ float red[16][17];
+    const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    const int k = blockIdx.x * 16 + cl;  // columns 0..in-1, and column kp = the bias gradient
+    const bool live = k < in || k == kp;
+    const int stride = kp + 4;
+    float a16[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) a16[u] = 0.f;
+    if (live) {
+        int b = rl;
+        for (; b + 15 * 16 < blocks; b += 16 * 16) {
+            float v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) v[u] = part[(size_t)(b + 16 * u) * stride + k];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) a16[u] += v[u];
+        }
+        for (int u = 0; b < blocks; b += 16, ++u) a16[u] += part[(size_t)b * stride + k];
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int u = 0; u < 16; ++u) s += a16[u];
+    red[rl][cl] = s;
+    __syncthreads();
+    if (rl == 0 && live) {
+        float t = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) t += red[r][cl];
+        if (k == kp) {
+            if (db) atomicAdd(db, t);
+        } else
+            atomicAdd(dw + k, t);
+    }
 }
 
 static int g_gemv = 1;  // tuning: rlppo_dbg_set(15, 0/1)
@@ -132,12 +179,18 @@ int launch_gemv_dx(hipStream_t st, const float *dy, int64_t ldy, const float *w,
 }
 
 int launch_gemv_dw(hipStream_t st, const float *dy, int64_t ldy, const float *x, int64_t ldx, float *dw, float *db, int in,
-                   int kp, int64_t n) {
+                   int kp, int64_t n, float *ws, size_t ws_floats) {
     if (n <= 0) return 0;
     const int rows_per_block = 64;  // 1024 blocks at M = 65,536: enough loads in flight to stream h at HBM rate
-    hipLaunchKernelGGL(gemv_dw_kernel, dim3((unsigned)cdiv(n, rows_per_block)), dim3(256), 0, st, dy, ldy, x, ldx, dw, db, in,
-                       kp / 4, n, rows_per_block);
+    const int blocks = (int)cdiv(n, rows_per_block);
+    float *part = (ws && ws_floats >= (size_t)blocks * (kp + 4)) ? ws : nullptr;
+    hipLaunchKernelGGL(gemv_dw_kernel, dim3((unsigned)blocks), dim3(256), 0, st, dy, ldy, x, ldx, dw, db, in, kp / 4, n,
+                       rows_per_block, part);
     RLPPO_LAUNCH_CHECK();
+    if (part) {
+        hipLaunchKernelGGL(gemv_dw_reduce_kernel, dim3((unsigned)cdiv(kp + 1, 16)), dim3(256), 0, st, part, blocks, kp, dw, db, in);
+        RLPPO_LAUNCH_CHECK();
+    }
     return 0;
 }
 

@@ -64,3 +64,20 @@ def test_gemm_nt_repeatable_under_gpu_sharing(variant):
     finally:
         N.check(L.rlppo_dbg_set(9, 3))
         bg.wait()
+
+
+def test_update_is_bit_reproducible():
+    """Weight and bias gradients go through partial tiles / block partials summed in a fixed order (no fp32 atomics whose
+    arrival order would leak into the sums), so two runs of the same update from the same state end in bit-identical
+    parameters -- with the policy and critic chains racing on two streams and at a size where every launch splits."""
+    import contextlib
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_gpu_dp import _build
+    finals = []
+    for _ in range(3):
+        with contextlib.redirect_stdout(open(os.devnull, "w")):
+            learner, buf = _build()
+        learner.learn(buf)
+        finals.append((learner.policy.arena.flat.clone(), learner.value_net.arena.flat.clone()))
+    for p, v in finals[1:]:
+        assert torch.equal(p, finals[0][0]) and torch.equal(v, finals[0][1])
