@@ -141,7 +141,7 @@ def kernel_breakdown(learner):
     return rows, dominant
 
 
-TRAFFIC_JSON = "r01_traffic_v5.json"  # tools/pmc_traffic.py output of the committed PMC passes
+TRAFFIC_JSON = "r01_traffic_v6.json"  # tools/pmc_traffic.py output of the committed PMC passes
 
 
 def pmc_traffic_for(kernel_label):
@@ -242,13 +242,13 @@ def rollout_bench(learner):
 
 def cpu_baseline(seed=123):
     """The oracle's learn() (torch-CPU eager, the reference's op sequence; kind "port") on a BOUNDED sample of the same
-    workload: a 131,072-sample slice of the cfg2 buffer = one optimiser step of 2 minibatches of 65,536 (same nets, same
+    workload: one optimiser step over the whole 524,288-sample cfg2 buffer = 8 minibatches of 65,536, 1 epoch (same nets, same
     minibatch size, same per-sample work as the GPU run).  Thread count: the better of 16 and min(cores, 64) -- on the
     256-thread GPU-box host, torch-CPU with all hardware threads is ~20x SLOWER than with 16-64 (oversubscribed MKL/OpenMP),
     which would misrepresent the reference."""
     from oracle import nets, ppo
     cores = os.cpu_count() or 1
-    n, B = 131072, 131072
+    n, B = N_SAMPLES, BATCH
     torch.manual_seed(seed)
     g = torch.Generator().manual_seed(seed)
     states = torch.randn(n, OBS, generator=g).clamp_(-5, 5)
@@ -257,7 +257,7 @@ def cpu_baseline(seed=123):
     with torch.no_grad():
         probs = nets.discrete_probs(pol0, states[:65536])
         a, lp = nets.discrete_sample(probs, torch.empty(65536, ACT).exponential_(1, generator=g))
-    buf = dict(states=states, actions=a.float().repeat(2), log_probs=lp.repeat(2),
+    buf = dict(states=states, actions=a.float().repeat(n // 65536), log_probs=lp.repeat(n // 65536),
                values=torch.randn(n, generator=g), advantages=torch.randn(n, generator=g))
     best = None
     for threads in sorted({min(cores, 16), min(cores, 64)}):
@@ -271,8 +271,8 @@ def cpu_baseline(seed=123):
             best = (dt, threads)
     dt, threads = best
     return dict(value=round(n / dt), unit="samples/s", cores=threads, kind="port",
-                sample="1 optimiser step over 131,072 samples (2 minibatches of 65,536) of the cfg2 workload, torch-CPU eager "
-                       "oracle, %d threads (best of 16 / min(cores,64); host has %d), %.1f s" % (threads, cores, dt))
+                sample="1 optimiser step (1 epoch) over the 524,288-sample cfg2 buffer = 8 minibatches of 65,536, torch-CPU eager "
+                       "oracle, %d threads (best of 16 / min(cores,64), both timed; host has %d), %.1f s" % (threads, cores, dt))
 
 
 # ---------------------------------------------------------------------------------------------------- main
