@@ -599,6 +599,10 @@ int rlppo_dbg_set(int32_t key, int32_t value) {
         set_tn_partial(value);
         return 0;
     }
+    if (key == 18) {
+        set_gae_grid_div(value);
+        return 0;
+    }
     set_error("dbg_set: unknown key %d", key);
     return RLPPO_ERR_ARG;
 }

@@ -36,6 +36,42 @@ __device__ __forceinline__ Aff2 shfl_down_aff(const Aff2 &v, int off) {
     return Aff2{__shfl_down(v.a, off), __shfl_down(v.b, off), __shfl_down(v.c, off), __shfl_down(v.d, off)};
 }
 
+// ---- wave-wide inclusive SUFFIX scan of composites: lane l <- f_l o f_{l+1} o ... o f_63 (lane 0 = the wave total).
+// The shuffle form (6 steps x 8 ds_bpermute per composite) took ~2.5k cycles per scan and there are two scans on every
+// workgroup's critical path (in-kernel stamps: DESIGN.md section 5, GAE history).  Here the four steps inside a 16-lane
+// DPP row use row_shl moves (lanes without a source take the identity) and the three row totals to the right of a row
+// are fetched with v_readlane: ~56 cheap cross-lane moves instead of 48 LDS-crossbar round trips.
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v, double ident) {
+    const long long b = __double_as_longlong(v), ib = __double_as_longlong(ident);
+    const int lo = __builtin_amdgcn_update_dpp((int)ib, (int)b, CTRL, 0xF, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp((int)(ib >> 32), (int)(b >> 32), CTRL, 0xF, 0xF, false);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+template <int CTRL>
+__device__ __forceinline__ Aff2 dpp_aff(const Aff2 &v) {  // the composite CTRL lanes to the right in the row, or identity
+    return Aff2{dpp_f64<CTRL>(v.a, 1.0), dpp_f64<CTRL>(v.b, 0.0), dpp_f64<CTRL>(v.c, 1.0), dpp_f64<CTRL>(v.d, 0.0)};
+}
+__device__ __forceinline__ double readlane_f64(double v, int lane) {
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_readlane((int)b, lane), hi = __builtin_amdgcn_readlane((int)(b >> 32), lane);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+__device__ __forceinline__ Aff2 readlane_aff(const Aff2 &v, int lane) {
+    return Aff2{readlane_f64(v.a, lane), readlane_f64(v.b, lane), readlane_f64(v.c, lane), readlane_f64(v.d, lane)};
+}
+__device__ __forceinline__ Aff2 wave_suffix_scan(Aff2 v, int lane) {
+    v = compose(v, dpp_aff<0x101>(v));  // row_shl:1
+    v = compose(v, dpp_aff<0x102>(v));  // row_shl:2
+    v = compose(v, dpp_aff<0x104>(v));  // row_shl:4
+    v = compose(v, dpp_aff<0x108>(v));  // row_shl:8 -> lane 16 r holds the total of row r
+    const Aff2 t1 = readlane_aff(v, 16), t2 = readlane_aff(v, 32), t3 = readlane_aff(v, 48);
+    const Aff2 t23 = compose(t2, t3), t123 = compose(t1, t23);
+    const int row = lane >> 4;
+    const Aff2 right = row == 0 ? t123 : (row == 1 ? t23 : (row == 2 ? t3 : aff_identity()));
+    return compose(v, right);
+}
+
 struct GaeParams {
     double gamma, gl;  // gamma, gamma*lambda
     float ret_std;
@@ -49,10 +85,15 @@ struct Steps {
     float r[GAE_EPT], v[GAE_EPT];
 };
 
-__device__ __forceinline__ void load_steps(const float *__restrict__ rews, const float *__restrict__ dones,
-                                           const float *__restrict__ trunc, const float *__restrict__ values,
-                                           int64_t t0, int64_t n, const GaeParams &p, Steps &s) {
+struct RawSteps {
     float r[GAE_EPT], d[GAE_EPT], tr[GAE_EPT], v[GAE_EPT + 1];
+};
+
+// the loads only (so that a caller can put independent work between issuing them and consuming them)
+__device__ __forceinline__ void load_raw(const float *__restrict__ rews, const float *__restrict__ dones,
+                                         const float *__restrict__ trunc, const float *__restrict__ values, int64_t t0,
+                                         int64_t n, RawSteps &w) {
+    float *r = w.r, *d = w.d, *tr = w.tr, *v = w.v;
     if (t0 + GAE_EPT <= n) {
         typedef float f4 __attribute__((ext_vector_type(4)));
 #pragma unroll
@@ -79,10 +120,15 @@ __device__ __forceinline__ void load_steps(const float *__restrict__ rews, const
             tr[e] = ok ? trunc[t0 + e] : 0.f;
             v[e] = ok ? values[t0 + e] : 0.f;
         }
+        v[GAE_EPT] = 0.f;
 #pragma unroll
         for (int e = 0; e < GAE_EPT; ++e)
             if (t0 + e + 1 <= n) v[e + 1] = values[t0 + e + 1];
     }
+}
+
+__device__ __forceinline__ void make_steps(const RawSteps &w, int64_t t0, int64_t n, const GaeParams &p, Steps &s) {
+    const float *r = w.r, *d = w.d, *tr = w.tr, *v = w.v;
 #pragma unroll
     for (int e = 0; e < GAE_EPT; ++e) {
         if (t0 + e < n) {
@@ -92,14 +138,22 @@ __device__ __forceinline__ void load_steps(const float *__restrict__ rews, const
             if (p.use_std) rn = fminf(fmaxf(r[e] / p.ret_std, -10.f), 10.f);
             s.b_adv[e] = ((double)rn + p.gamma * (double)v[e + 1] * nd) - (double)v[e];
             s.m[e] = (float)(nd * nt);
+            s.r[e] = r[e];
         } else {  // past the end: identity, so partial blocks need no special casing downstream
             s.b_adv[e] = 0.0;
             s.m[e] = -1.f;  // marker: a_adv = a_ret = 1
-            r[e] = 0.f;
+            s.r[e] = 0.f;
         }
-        s.r[e] = r[e];
         s.v[e] = v[e];
     }
+}
+
+__device__ __forceinline__ void load_steps(const float *__restrict__ rews, const float *__restrict__ dones,
+                                           const float *__restrict__ trunc, const float *__restrict__ values,
+                                           int64_t t0, int64_t n, const GaeParams &p, Steps &s) {
+    RawSteps w;
+    load_raw(rews, dones, trunc, values, t0, n, w);
+    make_steps(w, t0, n, p, s);
 }
 
 __device__ __forceinline__ double coef_adv(const Steps &s, int e, const GaeParams &p) {
@@ -257,31 +311,60 @@ __global__ __launch_bounds__(GAE_THREADS, 4) void gae_lookback_kernel(const floa
                                                                     float *__restrict__ adv_out,
                                                                     float *__restrict__ ret_out) {
     __shared__ Aff2 wave_tot[4];
+    __shared__ Aff2 wave_la[4];  // look-ahead window of the next chunk: per-wave composites (64 steps each)
     __shared__ double s_carry[2];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // Tags are unique per launch without a memset: tag = (epoch word left by the previous launch on this workspace)
     // + 1, and the workgroup that owns chunk 0 -- the end of the dependency chain, so every other workgroup has read
     // the word by then -- stores the new value on its way out.  Whatever the word holds on first use, records of
     // earlier launches (or never-written memory) carry a different tag in all 8 / 4 granules of a record.
-    const unsigned TAG_AGG = __hip_atomic_load(epoch_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
-    const unsigned TAG_INC = TAG_AGG;
+    // (read after the first chunk's loads have been issued: the compiler waits for an agent-scope load right away, and
+    // placed first it cost every workgroup a memory round trip before its step loads even started)
+    unsigned TAG_AGG = 0, TAG_INC = 0;
+    bool have_tag = false;
     // Chunks are taken right-to-left, grid-strided.  A chunk waits only on chunks to its right, i.e. on work of this
     // same round owned by lower block ids or on earlier rounds; the launcher sizes the grid to the number of
     // co-resident workgroups, so every awaited chunk belongs to a running workgroup whatever the dispatch order.
     for (int chunk = n_blocks - 1 - (int)blockIdx.x; chunk >= 0; chunk -= (int)gridDim.x) {
     const int64_t t0 = ((int64_t)chunk * GAE_THREADS + threadIdx.x) * GAE_EPT;
 
+    // Look-ahead window = the first LOOKAHEAD (= 256) raw steps of the next chunk, ONE per thread, requested together
+    // with the chunk's own steps: its memory round trip overlaps theirs instead of following the chunk scan, and the
+    // window costs 5 registers per thread instead of 17 in wave 0 (which forced a second, serialised load wave there).
+    const int64_t lt0 = (int64_t)(chunk + 1) * GAE_BLOCK + threadIdx.x;
+    const bool l_ok = chunk + 1 < n_blocks && lt0 < n;
+    float l_r = 0.f, l_d = 0.f, l_t = 0.f, l_v = 0.f, l_v1 = 0.f;
+    if (l_ok) {
+        l_r = rews[lt0];
+        l_d = dones[lt0];
+        l_t = trunc[lt0];
+        l_v = values[lt0];
+        l_v1 = values[lt0 + 1];
+    }
+    RawSteps raw;
+    load_raw(rews, dones, trunc, values, t0, n, raw);
+    {   // the window's composite while the chunk's own loads are still in flight (the window's were issued first)
+        Aff2 l1 = aff_identity();  // steps past the end: identity (x = 0 there is handled by covers_all below)
+        if (l_ok) {
+            const double nd = (double)(1.0f - l_d), nt = (double)(1.0f - l_t);
+            const float rn = p.use_std ? fminf(fmaxf(l_r / p.ret_std, -10.f), 10.f) : l_r;
+            const double m = (double)(float)(nd * nt);
+            l1 = Aff2{p.gl * m, ((double)rn + p.gamma * (double)l_v1 * nd) - (double)l_v, p.gamma * m, (double)l_r};
+        }
+        const Aff2 ls = wave_suffix_scan(l1, lane);
+        if (lane == 0) wave_la[wave] = ls;
+    }
+    __builtin_amdgcn_sched_barrier(0);
     Steps s;
-    load_steps(rews, dones, trunc, values, t0, n, p, s);
+    make_steps(raw, t0, n, p, s);
+    if (!have_tag) {
+        TAG_AGG = TAG_INC = __hip_atomic_load(epoch_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+        have_tag = true;
+    }
     const Aff2 mine = thread_composite(s, p);
     // one shuffle scan serves both purposes: lane l gets the composite of lanes l..63 (needed for the outputs) and
     // lane 0's value is the wave total (needed for the chunk aggregate)
-    Aff2 inc = mine;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const Aff2 o = shfl_down_aff(inc, off);
-        if (lane + off < 64) inc = compose(inc, o);
-    }
+    const Aff2 inc = wave_suffix_scan(mine, lane);
     if (lane == 0) wave_tot[wave] = inc;
     __syncthreads();
     const Aff2 agg = compose(compose(wave_tot[0], wave_tot[1]), compose(wave_tot[2], wave_tot[3]));
@@ -301,50 +384,7 @@ __global__ __launch_bounds__(GAE_THREADS, 4) void gae_lookback_kernel(const floa
             Aff2 acc = aff_identity();
             bool done = false;
             {
-                const int64_t tb = (int64_t)(chunk + 1) * GAE_BLOCK + 4 * lane;
-                Aff2 la = aff_identity();
-                float lr[4], ld[4], lt[4], lv[5];
-                if (tb + 4 <= n) {  // 16-byte aligned: one dwordx4 per array
-                    typedef float f4 __attribute__((ext_vector_type(4)));
-                    const f4 r4 = *reinterpret_cast<const f4 *>(rews + tb), d4 = *reinterpret_cast<const f4 *>(dones + tb);
-                    const f4 t4 = *reinterpret_cast<const f4 *>(trunc + tb), v4 = *reinterpret_cast<const f4 *>(values + tb);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        lr[e] = r4[e];
-                        ld[e] = d4[e];
-                        lt[e] = t4[e];
-                        lv[e] = v4[e];
-                    }
-                    lv[4] = values[tb + 4];
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const bool ok = tb + e < n;
-                        lr[e] = ok ? rews[tb + e] : 0.f;
-                        ld[e] = ok ? dones[tb + e] : 0.f;
-                        lt[e] = ok ? trunc[tb + e] : 0.f;
-                        lv[e] = ok ? values[tb + e] : 0.f;
-                    }
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        if (tb + e + 1 <= n) lv[e + 1] = values[tb + e + 1];
-                }
-#pragma unroll
-                for (int e = 3; e >= 0; --e) {
-                    if (tb + e < n) {
-                        const double nd = (double)(1.0f - ld[e]), nt = (double)(1.0f - lt[e]);
-                        const float rn = p.use_std ? fminf(fmaxf(lr[e] / p.ret_std, -10.f), 10.f) : lr[e];
-                        const double b = ((double)rn + p.gamma * (double)lv[e + 1] * nd) - (double)lv[e];
-                        const double aa = p.gl * (double)(float)(nd * nt), ar = p.gamma * (double)(float)(nd * nt);
-                        la = Aff2{aa * la.a, b + aa * la.b, ar * la.c, (double)lr[e] + ar * la.d};
-                    }
-                }
-#pragma unroll
-                for (int off = 1; off < 64; off <<= 1) {
-                    const Aff2 o = shfl_down_aff(la, off);
-                    if (lane + off < 64) la = compose(la, o);
-                }
-                la = Aff2{__shfl(la.a, 0), __shfl(la.b, 0), __shfl(la.c, 0), __shfl(la.d, 0)};
+                const Aff2 la = compose(compose(wave_la[0], wave_la[1]), compose(wave_la[2], wave_la[3]));
                 const bool covers_all = (int64_t)(chunk + 1) * GAE_BLOCK + LOOKAHEAD >= n;  // ran off the end: x = 0 there
                 if ((la.a == 0.0 && la.c == 0.0) || covers_all) {
                     carry_adv = la.b;
@@ -439,6 +479,8 @@ __global__ __launch_bounds__(GAE_THREADS, 4) void gae_lookback_kernel(const floa
     }
 }
 
+static int g_gae_grid_div = 1;  // tuning: rlppo_dbg_set(18, k): k chunks per workgroup (measured slower: the chunk is latency-bound)
+void set_gae_grid_div(int v) { g_gae_grid_div = v; }
 static int g_gae_algo = 1;  // 1 = single-pass look-back (default), 0 = two launches (summary + apply)
 void set_gae_algo(int a) { g_gae_algo = a; }
 
@@ -478,7 +520,8 @@ int launch_gae(hipStream_t st, const float *rews, const float *dones, const floa
             per_cu = per_cu > 6 ? 6 : (per_cu < 1 ? 1 : per_cu);
             resident = per_cu * prop.multiProcessorCount;
         }
-        const int grid = nb < resident ? nb : resident;
+        int grid = nb < resident ? nb : resident;
+        if (g_gae_grid_div > 1 && grid / g_gae_grid_div >= 256) grid = (int)cdiv(nb, cdiv(nb, grid / g_gae_grid_div));  // whole rounds
         hipLaunchKernelGGL(gae_lookback_kernel, dim3(grid), dim3(GAE_THREADS), 0, st, rews, dones, trunc, values, n, p, state,
                            hdr, hdr + 1, nb, vt, adv, ret);
         RLPPO_LAUNCH_CHECK();
