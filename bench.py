@@ -141,7 +141,7 @@ def kernel_breakdown(learner):
     return rows, dominant
 
 
-TRAFFIC_JSON = "r01_traffic_v6.json"  # tools/pmc_traffic.py output of the committed PMC passes
+TRAFFIC_JSON = "r01_traffic_v7.json"  # tools/pmc_traffic.py output of the committed PMC passes
 
 
 def pmc_traffic_for(kernel_label):
