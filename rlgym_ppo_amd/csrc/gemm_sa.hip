@@ -794,14 +794,6 @@ __global__ __launch_bounds__(256, TMT == 16 ? 4 : 2) void gemm_tn_dma_kernel(con
         __syncthreads();
     }
 
-    if (PARTIAL) {
-        const size_t tile_id = (size_t)blockIdx.z * (gridDim.x * gridDim.y) + (size_t)blockIdx.y * gridDim.x + blockIdx.x;
-        const __amdgpu_buffer_rsrc_t p_rs = make_rsrc(partial + tile_id * (128 * 128), 128 * 128 * 4);
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) stb(p_rs, (unsigned)tid * 16, (unsigned)(i * 4 + j) * 4096, acc[i][j]);
-    }
     // D[n][k]: lane owns rows n = n0 + wn*64 + 16 i + 4 q + e, column k = k0 + wk*64 + 16 j + r16
     const int out_here = (out - n0) < 128 ? (out - n0) : 128;
     const int in_here = (in - k0) < 128 ? (in - k0) : 128;
@@ -835,6 +827,17 @@ __global__ __launch_bounds__(256, TMT == 16 ? 4 : 2) void gemm_tn_dma_kernel(con
             else
                 atomicAdd(db + n0 + tid, sum);
         }
+    }
+    // The partial-tile stores are the LAST instructions of the wave: 16-byte buffer stores whose data registers are written
+    // again soon afterwards can pick up the new values (the hazard of section 5 / tests/test_gpu_stress.py); here the
+    // accumulators are never touched after them.
+    if (PARTIAL) {
+        const size_t tile_id = (size_t)blockIdx.z * (gridDim.x * gridDim.y) + (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+        const __amdgpu_buffer_rsrc_t p_rs = make_rsrc(partial + tile_id * (128 * 128), 128 * 128 * 4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) stb(p_rs, (unsigned)tid * 16, (unsigned)(i * 4 + j) * 4096, acc[i][j]);
     }
 }
 

@@ -81,3 +81,36 @@ def test_update_is_bit_reproducible():
         finals.append((learner.policy.arena.flat.clone(), learner.value_net.arena.flat.clone()))
     for p, v in finals[1:]:
         assert torch.equal(p, finals[0][0]) and torch.equal(v, finals[0][1])
+
+
+def test_gemm_tn_partial_tiles_repeatable_under_gpu_sharing():
+    """Same screen for the weight-gradient path: partial tiles are written with 16-byte buffer stores (the last
+    instructions of every wave) and reduced in a fixed order, so repeated launches must agree bit for bit."""
+    from rlgym_ppo_amd import _native as N
+    L = N.lib()
+    st = lambda: ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    P = lambda t: ctypes.c_void_p(t.data_ptr())
+    torch.manual_seed(1)
+    bg = subprocess.Popen([sys.executable, "-c", LOAD, "14"])
+    try:
+        time.sleep(4.0)
+        for (M, out, in_) in [(4096, 256, 256), (4096, 90, 256), (65536, 256, 107)]:
+            ny, kx = int(L.rlppo_padded_out(out)), int(L.rlppo_padded_out(in_))
+            dY = torch.zeros(M, ny, device="cuda")
+            dY[:, :out] = torch.randn(M, out, device="cuda")
+            X = torch.zeros(M, kx, device="cuda")
+            X[:, :in_] = torch.randn(M, in_, device="cuda")
+            ws = torch.empty(int(L.rlppo_dbg_gemm_tn_workspace_bytes(out, in_, M)), dtype=torch.uint8, device="cuda")
+            dW, db = torch.zeros(out * in_, device="cuda"), torch.zeros(out, device="cuda")
+            run = lambda: N.check(L.rlppo_dbg_gemm_tn_ws(st(), P(dY), ny, ny, P(X), kx, kx, P(dW), P(db), out, in_, M, P(ws), ws.numel()))
+            run()
+            ref_w, ref_b = dW.clone(), db.clone()
+            differ = torch.zeros((), dtype=torch.int64, device="cuda")
+            for _ in range(600 if M <= 4096 else 100):
+                dW.zero_()
+                db.zero_()
+                run()
+                differ += (dW != ref_w).any() | (db != ref_b).any()
+            assert int(differ.item()) == 0, (M, out, in_, int(differ.item()))
+    finally:
+        bg.wait()
