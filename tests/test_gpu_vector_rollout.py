@@ -98,3 +98,36 @@ def test_welford_increment_bit_exact():
         N.check(L.rlppo_welford_increment(st(), P(xd), ld, n, d, P(mean), P(m2), w.count))
         w.increment(x, n)
         assert np.array_equal(mean.cpu().numpy(), w.mean_) and np.array_equal(m2.cpu().numpy(), w.m2)
+
+
+def test_vector_rollout_gaussian_policy():
+    """Same comparison for the continuous head (actions [n, k] fp32, summed log-probs)."""
+    from rlgym_ppo_amd.batched_agents import VectorAgentManager
+    from rlgym_ppo_amd.ppo import ContinuousPolicy
+    torch.manual_seed(21)
+    pol = ContinuousPolicy(107, 8, (32, 32), "cuda:0")
+    params = [(l.weight.detach().cpu(), l.bias.detach().cpu()) for l in pol.arena.linears]
+    mgr = VectorAgentManager(pol, seed=5, standardize_obs=True)
+    make = lambda: synthetic_env.SyntheticVectorEnv(n_actions=4, n_agents=12, seed=8, kind="continuous")
+    d, n_act, code = mgr.init_processes(0, make)
+    assert (d, n_act, code) == (107, 4, 2)
+    env = make()
+
+    def act_fn(obs):
+        mean, std = nets.gauss_out(params, obs)
+        a, lp = nets.gauss_sample(mean, std, torch.empty(obs.shape[0], 4).normal_(0, 1))
+        return a.numpy(), lp.numpy()
+
+    state, reset_obs = None, env.reset()
+    for n_req in (12 * 7, 12 * 3):
+        torch.manual_seed(7 + n_req)
+        exp, _, n_col, _ = mgr.collect_timesteps(n_req)
+        torch.manual_seed(7 + n_req)
+        ref, state = host.lockstep_rollout(reset_obs, lambda a: env.step(a)[:4], act_fn, n_req // 12, state=state)
+        states, actions, logp, rews, nxt, dones, trunc = [x.cpu().numpy() for x in exp]
+        np.testing.assert_allclose(actions, ref[1], rtol=1e-5, atol=2e-6)
+        np.testing.assert_allclose(states[:, :107], ref[0], rtol=1e-6, atol=1e-7)
+        np.testing.assert_allclose(logp, ref[2], rtol=1e-4, atol=1e-4)
+        np.testing.assert_allclose(rews, ref[3], rtol=1e-5, atol=1e-6)   # rewards depend on the (fp32-close) actions
+        assert np.array_equal(dones, ref[5]) and np.array_equal(trunc, ref[6])
+    mgr.cleanup()
