@@ -228,12 +228,13 @@ class PPOLearner(object):
             # The legacy-MT19937 permutation is inherently serial host work (3 ms per 512k indices).  It is drawn by a
             # helper thread (the C call releases the GIL) one epoch ahead, so it overlaps both the GPU and this
             # thread's launch calls; with 8 ranks the GPU share of an epoch is ~1.5 ms and the shuffle is the critical path.
+            # ... and its upload (4 MB through pinned memory) is issued while the GPU still has the minibatches of the
+            # current epoch's first batch queued: done at the epoch boundary it left the GPU idle for ~100 us per epoch.
             fut = self._perm_pool.submit(exp.epoch_indices)
+            idx_next = self._upload_indices(fut.result())
+            fut = self._perm_pool.submit(exp.epoch_indices) if self.n_epochs > 1 else None
             for epoch in range(self.n_epochs):
-                indices = fut.result()
-                if epoch + 1 < self.n_epochs:
-                    fut = self._perm_pool.submit(exp.epoch_indices)
-                idx_dev = self._upload_indices(indices)
+                idx_dev = idx_next
                 for b in range(n_batches):
                     self._grad_all.zero_()
                     pa.ensure_packed()
@@ -246,6 +247,9 @@ class PPOLearner(object):
                         args.mb = MB
                         N.check(L.rlppo_ppo_minibatch(st, ctypes.byref(args)))
                     N.check(L.rlppo_ppo_join(st))
+                    if b == 0 and fut is not None:  # next epoch's indices, behind this batch's launches in the stream
+                        idx_next = self._upload_indices(fut.result())
+                        fut = self._perm_pool.submit(exp.epoch_indices) if epoch + 2 < self.n_epochs else None
                     n_minibatch_iterations += n_slices
                     if dist is not None:
                         all_reduce_sum(self._grad_all, dist)  # RCCL over xGMI, before clipping
