@@ -330,10 +330,10 @@ static int backward(hipStream_t st, hipStream_t dw, hipEvent_t *ev, const NetLay
         const bool gemv = l == last && l > 0 && gemv_head_ok(L.out, L.pin);  // one-output head (gemv.hip)
         if (gemv)
             rc = launch_gemv_dw(dw, dY, L.pout, X, ldx, grad + L.off_flat_w, grad + L.off_flat_b, L.in, L.pin, mb,
-                                dw == st ? tn_ws : nullptr, tn_floats);
+                                tn_ws, tn_floats);
         else
             rc = launch_gemm_tn(dw, dY, L.pout, L.pout, X, ldx, l > 0 ? nullptr : idx, L.pin, grad + L.off_flat_w,
-                                grad + L.off_flat_b, L.out, L.in, mb, dw == st ? tn_ws : nullptr, tn_floats);
+                                grad + L.off_flat_b, L.out, L.in, mb, tn_ws, tn_floats);  // all dW launches of a net share one stream
         if (rc) return rc;
         if (gemv && !fused) {
             rc = launch_gemv_dx(st, dY, L.pout, packed + L.off_w, acts[l - 1], L.pin, dx[l - 1], L.pin, L.pin, mb);
