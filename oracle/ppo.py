@@ -209,7 +209,8 @@ def learn(head, pol, val, buf, batch_size, mini_batch_size, n_epochs, clip, ent_
           rng, adam_pol=None, adam_val=None, var_range=(0.1, 1.0), on_step=None, rank=0, world=1, allreduce=None):
     """`pol`/`val` are updated in place.  `buf` = dict(states, actions, log_probs, values, advantages) of CPU
     tensors; `rng` a numpy RandomState (persistent across calls, experience_buffer.py:52).  With world > 1 the
-    minibatch slices of a batch are dealt round-robin to ranks and `allreduce(flat_tensor)` sums across ranks
+    minibatch slices of a batch are dealt to ranks (contiguous blocks when they divide evenly, round-robin otherwise:
+    the sum is the same either way) and `allreduce(flat_tensor)` sums across ranks
     (SURVEY.md section 8(e)); world == 1 is the reference loop verbatim."""
     assert batch_size % mini_batch_size == 0
     adam_pol = adam_pol or AdamState(pol)
@@ -233,7 +234,9 @@ def learn(head, pol, val, buf, batch_size, mini_batch_size, n_epochs, clip, ent_
             gv = [(torch.zeros_like(w), torch.zeros_like(b)) for w, b in val]
             stats = torch.zeros(4, dtype=torch.float64)
             for j, s in enumerate(range(0, batch_size, mini_batch_size)):
-                if j % world != rank:
+                n_sl = batch_size // mini_batch_size
+                mine = (j // (n_sl // world) == rank) if n_sl % world == 0 else (j % world == rank)
+                if not mine:
                     continue
                 e = s + mini_batch_size
                 acts = b_acts[s:e]

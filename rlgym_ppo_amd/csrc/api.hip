@@ -278,7 +278,7 @@ static size_t tn_ws_floats(const NetLayout &net, int64_t mb) {
     for (int l = 0; l < net.n_layers; ++l) {
         size_t f = tn_partial_floats(net.L[l].out, net.L[l].in, mb);
         if (net.L[l].out == 1) {  // one-output head: block partials of gemv_dw_kernel (64 rows per block)
-            const size_t g = (size_t)cdiv(mb, 64) * (size_t)(net.L[l].pin + 4);
+            const size_t g = (size_t)cdiv(mb, 64) * (size_t)(net.L[l].pin + 4);  // upper bound: at least 64 rows per block
             if (g > f) f = g;
         }
         if (f > m) m = f;
@@ -541,6 +541,7 @@ int rlppo_dbg_set(int32_t key, int32_t value) {
     }
     if (key == 2) {
         set_tn_rows(value);
+        set_tn_partial_rows(value);
         return 0;
     }
     if (key == 3) {

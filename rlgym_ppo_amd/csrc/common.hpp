@@ -97,6 +97,7 @@ int get_infer_bf16();
 int launch_gemm_nt_bf16(hipStream_t st, const float *A, int64_t lda, const float *B, int64_t ldb, const float *bias, float *C,
                         int64_t ldc, int64_t M, int N, int nb, int K, int epi);
 void set_tn_partial(int v);
+void set_tn_partial_rows(int v);
 size_t tn_partial_floats(int out, int in, int64_t M);
 int launch_gemm_tn_partial(hipStream_t st, const float *dY, int64_t ldy, int ny_valid, const float *X, int64_t ldx,
                            int kx_valid, float *dW, float *db, int out, int in, int64_t M, float *ws, size_t ws_floats);

@@ -94,6 +94,22 @@ __device__ __forceinline__ void nt_epilogue(f32x4 (&acc)[2][NB], const float *ma
         for (int j = 0; j < NB; ++j) stb(c_rs, c_off, 16 * i * ldc_b + j * 64, acc[i][j]);
 }
 
+// XCD-aware tile order.  Workgroups are dispatched in linear id order (x fastest) and id i runs on XCD i % 8, each XCD with
+// its own L2.  The column tiles of one row tile read the same A rows, so they should run on the same XCD at about the same
+// time: ids are taken in groups of 8 * (column tiles); within a group, id g -> row tile 8*group + g % 8, column tile g / 8.
+// With row tiles as the fast index instead, the second reader of an A tile came 512-4096 workgroups later and, once A no
+// longer fitted the 256 MB memory-side cache (fused minibatches), from HBM again.
+__device__ __forceinline__ void xcd_tile(int &row_tile, int &col_tile) {
+    const int nr = gridDim.x, nc = gridDim.y;
+    row_tile = blockIdx.x;
+    col_tile = blockIdx.y;
+    if ((nr & 7) == 0 && nc > 1) {
+        const int id = blockIdx.y * nr + blockIdx.x, g = id % (8 * nc);
+        row_tile = (id / (8 * nc)) * 8 + (g & 7);
+        col_tile = g >> 3;
+    }
+}
+
 // STAMP: diagnostic build (rlppo_dbg_gemm_nt_stamped mode 64) that accumulates s_memtime cycles per phase into
 // stamps[workgroup][wave][8]: 0 prologue, 1 issue of the staging loads, 2 fragment reads + MFMA, 3 wait for the staged
 // loads, 4 LDS writes, 5 barrier, 6 epilogue, 7 whole kernel.  PHASE() compiles to nothing in the product kernels.
@@ -263,8 +279,10 @@ __global__ __launch_bounds__(256, BKT == 16 ? 4 : 2) void gemm_nt_dma_kernel(con
     const int lane = tid & 63, wave = tid >> 6;
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);  // provably uniform: it addresses the DMA destination (M0)
     const int r16 = lane & 15, q = lane >> 4;
-    const int64_t m0 = (int64_t)blockIdx.x * SBM;
-    const int n0 = blockIdx.y * BN;
+    int row_tile, col_tile;
+    xcd_tile(row_tile, col_tile);
+    const int64_t m0 = (int64_t)row_tile * SBM;
+    const int n0 = col_tile * BN;
     const int rows_here = (int)((M - m0) < SBM ? (M - m0) : SBM);
 
     const __amdgpu_buffer_rsrc_t a_rs = make_rsrc(reinterpret_cast<const char *>(A) + m0 * lda_b,
@@ -374,8 +392,10 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf16_kernel(const float *__res
     const int lane = tid & 63, wave = tid >> 6;
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);  // provably uniform: it addresses the DMA destination (M0)
     const int r16 = lane & 15, q = lane >> 4;
-    const int64_t m0 = (int64_t)blockIdx.x * SBM;
-    const int n0 = blockIdx.y * BN;
+    int row_tile, col_tile;
+    xcd_tile(row_tile, col_tile);
+    const int64_t m0 = (int64_t)row_tile * SBM;
+    const int n0 = col_tile * BN;
     const int rows_here = (int)((M - m0) < SBM ? (M - m0) : SBM);
 
     const __amdgpu_buffer_rsrc_t a_rs = make_rsrc(reinterpret_cast<const char *>(A) + m0 * lda_b,
@@ -705,8 +725,21 @@ __global__ __launch_bounds__(256, TMT == 16 ? 4 : 2) void gemm_tn_dma_kernel(con
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     const int r16 = lane & 15, q = lane >> 4;
     const int wn = wave >> 1, wk = wave & 1;
-    const int n0 = blockIdx.x * 128, k0 = blockIdx.y * 128;
-    const int64_t mbeg = (int64_t)blockIdx.z * rows_per_wg;
+    // XCD-aware order (see xcd_tile): the output tiles of one row split read the same dY / X rows, so they are given ids
+    // that land on the same XCD back to back: id -> tile = (id % (8 T)) / 8, split = 8 (id / (8 T)) + id % 8
+    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    {
+        const int T = gridDim.x * gridDim.y;
+        if ((gridDim.z & 7) == 0 && T > 1) {
+            const int id = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x, g = id % (8 * T);
+            const int tile = g >> 3;
+            bz = (id / (8 * T)) * 8 + (g & 7);
+            bx = tile % gridDim.x;
+            by = tile / gridDim.x;
+        }
+    }
+    const int n0 = bx * 128, k0 = by * 128;
+    const int64_t mbeg = (int64_t)bz * rows_per_wg;
     const int rows = (int)((M - mbeg) < rows_per_wg ? (M - mbeg) : rows_per_wg);  // >= 1
     const int steps = (rows + TMT - 1) / TMT;
     const int rem = rows - (steps - 1) * TMT;  // rows of the last stage, 1..TMT
@@ -748,7 +781,7 @@ __global__ __launch_bounds__(256, TMT == 16 ? 4 : 2) void gemm_tn_dma_kernel(con
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     f32x4 bs4 = f32x4{0.f, 0.f, 0.f, 0.f};
-    const bool want_db = db != nullptr && blockIdx.y == 0;
+    const bool want_db = db != nullptr && by == 0;
 
     issue_stage(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -823,7 +856,7 @@ __global__ __launch_bounds__(256, TMT == 16 ? 4 : 2) void gemm_tn_dma_kernel(con
 #pragma unroll
             for (int r = 0; r < 8; ++r) sum += red[r * 128 + tid];
             if (PARTIAL)  // column sums of this split: partial_db[split][n tile][128], behind the tile partials
-                partial[(size_t)gridDim.z * gridDim.y * gridDim.x * (128 * 128) + ((size_t)blockIdx.z * gridDim.x + blockIdx.x) * 128 + tid] = sum;
+                partial[(size_t)gridDim.z * gridDim.y * gridDim.x * (128 * 128) + ((size_t)bz * gridDim.x + bx) * 128 + tid] = sum;
             else
                 atomicAdd(db + n0 + tid, sum);
         }
@@ -832,7 +865,7 @@ __global__ __launch_bounds__(256, TMT == 16 ? 4 : 2) void gemm_tn_dma_kernel(con
     // again soon afterwards can pick up the new values (the hazard of section 5 / tests/test_gpu_stress.py); here the
     // accumulators are never touched after them.
     if (PARTIAL) {
-        const size_t tile_id = (size_t)blockIdx.z * (gridDim.x * gridDim.y) + (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+        const size_t tile_id = (size_t)bz * (gridDim.x * gridDim.y) + (size_t)by * gridDim.x + bx;
         const __amdgpu_buffer_rsrc_t p_rs = make_rsrc(partial + tile_id * (128 * 128), 128 * 128 * 4);
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -910,11 +943,18 @@ static int g_tn_partial = 1;  // tuning: rlppo_dbg_set(16, 0/1)
 void set_tn_partial(int v) { g_tn_partial = v; }
 
 // rows per workgroup of the partial-tile form: no atomic traffic to trade against, so simply two workgroups per CU
+static int g_tn_partial_rows = 0;  // tuning: rlppo_dbg_set(2, rows) also overrides the split of the partial-tile form
+void set_tn_partial_rows(int v) { g_tn_partial_rows = v; }
 static int64_t tn_partial_rows(int out, int in, int64_t M) {
+    if (g_tn_partial_rows > 0) return g_tn_partial_rows;
     const int64_t tiles = cdiv(out, 128) * cdiv(in, 128);
     int64_t rows = tiles >= 2 ? 512 : 256;
     if (M < 64 * rows) rows = round_up(cdiv(M, 64) > 32 ? cdiv(M, 64) : 32, 32);
-    return rows;
+    // large M (fused minibatches): one round of workgroups (2 per CU) instead of more and more splits -- fewer partial tiles
+    // to write and to reduce.  M = 524,288, us per launch at 512 / 1024 / 2048 / 4096 rows: hidden 567 / 527 / 505 / 494,
+    // first layer 313 / 284 / 267 / 287, policy head 305 / 277 / 262 / 284
+    const int64_t few = round_up(cdiv(M * tiles, 512), 32);
+    return few > rows ? few : rows;
 }
 size_t tn_partial_floats(int out, int in, int64_t M) {
     if (M <= 0) return 0;

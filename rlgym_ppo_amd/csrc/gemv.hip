@@ -181,7 +181,8 @@ int launch_gemv_dx(hipStream_t st, const float *dy, int64_t ldy, const float *w,
 int launch_gemv_dw(hipStream_t st, const float *dy, int64_t ldy, const float *x, int64_t ldx, float *dw, float *db, int in,
                    int kp, int64_t n, float *ws, size_t ws_floats) {
     if (n <= 0) return 0;
-    const int rows_per_block = 64;  // 1024 blocks at M = 65,536: enough loads in flight to stream h at HBM rate
+    // 1024 blocks at M = 65,536: enough loads in flight to stream h at HBM rate; larger M keeps about 2048 blocks
+    const int rows_per_block = n > 131072 ? (int)round_up(cdiv(n, 2048), 64) : 64;
     const int blocks = (int)cdiv(n, rows_per_block);
     float *part = (ws && ws_floats >= (size_t)blocks * (kp + 4)) ? ws : nullptr;
     hipLaunchKernelGGL(gemv_dw_kernel, dim3((unsigned)blocks), dim3(256), 0, st, dy, ldy, x, ldx, dw, db, in, kp / 4, n,

@@ -18,8 +18,24 @@ def dist_info():
 
 
 def slices_for_rank(n_slices, rank, world):
-    """Minibatch slice numbers of one batch that `rank` computes (round-robin)."""
+    """Minibatch slice numbers of one batch that `rank` computes: a contiguous block when the slices divide evenly over the
+    ranks (so that a rank can evaluate its share in one fused pass over consecutive rows of the permutation), round-robin
+    otherwise.  Either dealing gives the same gradient sum."""
+    if n_slices % world == 0:
+        per = n_slices // world
+        return list(range(rank * per, (rank + 1) * per))
     return list(range(rank, n_slices, world))
+
+
+def fuse_runs(slices, max_fused):
+    """Consecutive slice numbers grouped into EQUAL runs of at most `max_fused` slices: [(first_slice, count), ...].
+    Equal counts keep "mean over passes of the per-pass mean" identical to the reference's mean over minibatches."""
+    n = len(slices)
+    contiguous = all(slices[i] + 1 == slices[i + 1] for i in range(n - 1))
+    k = 1
+    if contiguous:
+        k = max(d for d in range(1, max(1, min(max_fused, n)) + 1) if n % d == 0)
+    return [(slices[i], k) for i in range(0, n, k)]
 
 
 def all_reduce_sum(tensor, dist=None):

@@ -21,7 +21,7 @@ import numpy as np
 import torch
 
 from .. import _native as N
-from ..dp import all_reduce_sum, dist_info, slices_for_rank
+from ..dp import all_reduce_sum, dist_info, fuse_runs, slices_for_rank
 from ..engine import Workspace, ptr, require_gpu, stream_ptr
 from .continuous_policy import ContinuousPolicy
 from .discrete_policy import DiscreteFF
@@ -149,6 +149,13 @@ class PPOLearner(object):
         self._stats = torch.zeros(N.N_STATS, dtype=torch.float64, device=self._dev)
         self._ws = Workspace(self._dev)
         self.n_slots = int(os.environ.get("RLPPO_SLOTS", 1))  # minibatches of a batch kept in flight concurrently
+        # Minibatch fusion.  The reference sums the gradients of a batch's minibatches, each the MB/B-scaled mean over its
+        # rows, before ONE clip + Adam (ppo_learner.py:134-193): the minibatches are independent given the parameters and
+        # their sum is the 1/B-scaled sum over all their rows.  They only exist to bound activation memory; with 288 GB of
+        # HBM a rank evaluates up to `max_fused_minibatches` CONSECUTIVE minibatches in one pass of rlppo_ppo_minibatch
+        # (mb = k MB rows, mb_ratio = k MB / B): the same gradient and the same report means up to fp32 summation order,
+        # in launches that are k times larger.  RLPPO_FUSE=1 keeps one pass per minibatch.
+        self.max_fused_minibatches = max(1, int(os.environ.get("RLPPO_FUSE", 8)))
         self._idx_bufs = None
         from concurrent.futures import ThreadPoolExecutor
         self._perm_pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="rlppo-shuffle")
@@ -195,7 +202,9 @@ class PPOLearner(object):
             a.var_m, a.var_b = float(self.policy.affine_map.m), float(self.policy.affine_map.b)
         a.stats = self._stats.data_ptr()
         # one activation workspace per slot: minibatches in different slots overlap on the GPU (rlppo_ppo_join)
-        nbytes = int(N.lib().rlppo_minibatch_workspace_bytes(pa.dims_c, pa.n_layers, va.dims_c, va.n_layers, self.mini_batch_size))
+        n_slices = self.batch_size // self.mini_batch_size
+        self._fused_rows = self.mini_batch_size * min(self.max_fused_minibatches, max(1, n_slices))
+        nbytes = int(N.lib().rlppo_minibatch_workspace_bytes(pa.dims_c, pa.n_layers, va.dims_c, va.n_layers, self._fused_rows))
         nbytes = (nbytes + 255) // 256 * 256
         ws = self._ws.get(nbytes * self.n_slots)
         self._slot_ws = [ws.data_ptr() + i * nbytes for i in range(self.n_slots)]
@@ -216,6 +225,7 @@ class PPOLearner(object):
         self._stats.zero_()
         n_iterations = 0
         n_minibatch_iterations = 0
+        n_passes = 0  # launches of rlppo_ppo_minibatch on this rank (each adds one mean to every report statistic)
         total = len(exp)
         n_batches = total // B if B > 0 else 0
 
@@ -239,13 +249,15 @@ class PPOLearner(object):
                     self._grad_all.zero_()
                     pa.ensure_packed()
                     va.ensure_packed()
-                    for k, j in enumerate(slices_for_rank(n_slices, rank, world)):
+                    for k, (j, cnt) in enumerate(fuse_runs(slices_for_rank(n_slices, rank, world), self.max_fused_minibatches)):
                         args.slot = k % self.n_slots
                         args.workspace = self._slot_ws[args.slot]
                         off = b * B + j * MB
                         args.idx = idx_dev.data_ptr() + 8 * off
-                        args.mb = MB
+                        args.mb = cnt * MB                      # cnt consecutive minibatches in one pass
+                        args.mb_ratio = float(cnt * MB / B)
                         N.check(L.rlppo_ppo_minibatch(st, ctypes.byref(args)))
+                        n_passes += 1
                     N.check(L.rlppo_ppo_join(st))
                     if b == 0 and fut is not None:  # next epoch's indices, behind this batch's launches in the stream
                         idx_next = self._upload_indices(fut.result())
@@ -264,7 +276,7 @@ class PPOLearner(object):
         stats = self._stats.cpu().numpy()  # the only device->host sync of learn()
         elapsed = time.time() - t1
         n_iter_r = max(n_iterations, 1)
-        n_mb_r = max(n_minibatch_iterations, 1)
+        n_mb_r = max(n_passes * world, 1)  # the statistics were summed over ranks: passes of all ranks
         policy_update_magnitude = (policy_before - pa.flat).norm().item()
         critic_update_magnitude = (critic_before - va.flat).norm().item()
         self.cumulative_model_updates += n_iter_r

@@ -45,7 +45,11 @@ def _worker(rank, world, port, out):
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
     d, r, w = dp.dist_info()
     assert (r, w) == (rank, world)
-    assert dp.slices_for_rank(8, rank, world) == list(range(rank, 8, world))
+    per = 8 // world
+    assert dp.slices_for_rank(8, rank, world) == list(range(rank * per, (rank + 1) * per))   # contiguous blocks
+    assert dp.slices_for_rank(7, rank, world) == list(range(rank, 7, world))                   # uneven: round-robin
+    assert dp.fuse_runs(dp.slices_for_rank(8, rank, world), 8) == [(rank * per, per)]
+    assert dp.fuse_runs([0, 1, 2, 3, 4, 5], 4) == [(0, 3), (3, 3)] and dp.fuse_runs([0, 2, 4], 8) == [(0, 1), (2, 1), (4, 1)]
     pol, val, buf = _make_problem()
 
     class DealtLearn:  # the oracle's loop with the PRODUCT's dealing + collective plugged in
@@ -53,9 +57,9 @@ def _worker(rank, world, port, out):
 
     report, _, _ = ppo.learn("discrete", pol, val, buf, 128, 32, 2, 0.2, 0.005, 3e-4, 3e-4, np.random.RandomState(9),
                              rank=rank, world=world, allreduce=lambda t: dp.all_reduce_sum(t, d))
-    # ppo.learn deals slices with `j % world != rank` -- assert that this is the product's dealing
+    # ppo.learn deals slices in contiguous blocks when they divide evenly -- assert that this is the product's dealing
     for j in range(4):
-        assert (j % world == rank) == (j in dp.slices_for_rank(4, rank, world))
+        assert (j // (4 // world) == rank) == (j in dp.slices_for_rank(4, rank, world))
     out[rank] = (nets.flatten(pol).clone(), nets.flatten(val).clone(), report)
     dist.barrier()
     dist.destroy_process_group()
