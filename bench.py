@@ -9,8 +9,10 @@ Workload = BASELINE.json configs[1] ("1xMI355X: 4096 parallel agents, obs=107 f3
 weights.  One *step* = one PPOLearner.learn() call = `--epochs` (default 10, the reference's ppo_epochs default,
 learner.py:51) shuffled passes over the whole buffer, i.e. epochs x 524,288 samples through forward + loss + backward
 + clip + Adam, including the host-side legacy-MT19937 shuffle and the index upload.  value = samples / wall time,
-whole job (all ranks).  With N ranks the 8 minibatch slices of every batch are dealt round-robin to the ranks and one
-RCCL all-reduce of the flat gradient arena precedes the optimiser step (total work fixed: strong scaling).
+whole job (all ranks).  With N ranks the 8 minibatch slices of every batch are dealt to the ranks in contiguous blocks (a rank
+evaluates its consecutive slices in one fused pass: the minibatches of a batch are independent and their gradients are summed
+before the one optimiser step, ppo_learner.py:134-193) and one RCCL all-reduce of the flat gradient arena precedes the optimiser
+step (total work fixed: strong scaling).
 
 Extra objects on the same JSON line (N=1 only): `roofline` for the dominant kernel of the timed region, `gae` =
 the GAE scan (BASELINE configs[2]: 8192 x 256, HBM-bound) with its own roofline, `rollout` = policy inference
@@ -91,12 +93,14 @@ def time_region(fn, reps, warm=3, warm_s=0.0):
 
 
 def kernel_breakdown(learner):
-    """Times every GEMM launch shape of one cfg2 minibatch through the diagnostic entry points and returns
-    (rows, dominant) where rows = [(name, launches per minibatch, ms per launch, flop per launch)]."""
+    """Times every GEMM launch shape of one pass of the update through the diagnostic entry points, at the row count the
+    update really launches (learner._fused_rows: at one GPU the 8 minibatches of a batch are evaluated in ONE pass of
+    524,288 rows, PPOLearner.max_fused_minibatches; with 8 ranks a pass is one 65,536-row minibatch), and returns
+    (rows, dominant) where rows = [(name, launches per pass, ms per launch, flop per launch)]."""
     from rlgym_ppo_amd import _native as N
     L = N.lib()
     dev = learner._dev
-    M = MINIBATCH
+    M = int(getattr(learner, "_fused_rows", MINIBATCH))
     st = lambda: ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     P = lambda t: ctypes.c_void_p(t.data_ptr())
     A128 = torch.randn(M, 128, device=dev)
@@ -135,24 +139,27 @@ def kernel_breakdown(learner):
     rows = []
     for name, count, fn, flop in shapes:
         ms = time_region(fn, 20, warm_s=0.3)
-        rows.append(dict(kernel=name, launches_per_minibatch=count, ms_per_launch=round(ms, 4),
+        rows.append(dict(kernel=name, rows_per_launch=M, launches_per_minibatch=count, ms_per_launch=round(ms, 4),
                          gflop_per_launch=round(flop / 1e9, 3), tflops=round(flop / ms / 1e9, 2)))
     dominant = max(rows, key=lambda r: r["launches_per_minibatch"] * r["ms_per_launch"])
     return rows, dominant
 
 
-TRAFFIC_JSON = "r01_traffic_v7.json"  # tools/pmc_traffic.py output of the committed PMC passes
+TRAFFIC_JSON = "r01_traffic_v8.json"  # tools/pmc_traffic.py output of the committed PMC passes
 
 
 def pmc_traffic_for(kernel_label):
     """HBM bytes per launch of the dominant kernel, from the committed PMC passes (bench.py cannot run rocprofv3 on itself)."""
     path = os.path.join(ROOT, "profiles", TRAFFIC_JSON)
-    key = {"gemm_tn dW hidden 256x256 (x4)": "rlppo::gemm_tn_dma_kernel<32, true> [grid 131072]",
-           "gemm_nt fwd hidden 256->256 (x4)": "rlppo::gemm_nt_dma_kernel<8, 1, 16>",
-           "gemm_nt dX hidden 256->256 mask (x4)": "rlppo::gemm_nt_dma_kernel<8, 3, 16>"}.get(kernel_label)
+    prefix = {"gemm_tn dW hidden 256x256 (x4)": "rlppo::gemm_tn_dma_kernel<32, true>",
+              "gemm_nt fwd hidden 256->256 (x4)": "rlppo::gemm_nt_dma_kernel<8, 1, 16>",
+              "gemm_nt dX hidden 256->256 mask (x4)": "rlppo::gemm_nt_dma_kernel<8, 3, 16>"}.get(kernel_label)
     try:
         t = json.load(open(path))
-        return round(t[key]["hbm_bytes"]), "profiles/" + TRAFFIC_JSON + " (tools/prof_kernels.py, same launch shape)"
+        # tools/pmc_summary.py keys a kernel that ran with several grids as "name [grid N]": of one template, the hidden-layer
+        # launch is the one with the most traffic (tools/prof_kernels.py runs the same shapes as kernel_breakdown)
+        cand = [v["hbm_bytes"] for k, v in t.items() if k.startswith(prefix)]
+        return round(max(cand)), "profiles/" + TRAFFIC_JSON + " (tools/prof_kernels.py, same launch shape)"
     except Exception:
         return None, "no committed PMC pass for this kernel"
 
@@ -338,7 +345,7 @@ def main():
         "config": {"workload": "BASELINE configs[1]: 4096 agents x 128 steps = 524,288-sample buffer, obs 107 f32, "
                                "90 discrete actions, 256x3 policy + 256x3 critic; ppo_batch 524,288, minibatch 65,536",
                    "epochs_per_step": args.epochs, "samples_per_step": args.epochs * BATCH,
-                   "parallelism": f"dp{world}: minibatch slices round-robin over ranks, 1 RCCL all-reduce/optimiser step",
+                   "parallelism": f"dp{world}: {8 // world if 8 % world == 0 else 1} consecutive minibatch slice(s) per rank and pass, 1 RCCL all-reduce/optimiser step",
                    "last_report": {k: (round(v, 6) if isinstance(v, float) else v) for k, v in report.items()}},
     }
     if rank == 0 and world == 1 and not args.no_extras:
@@ -349,10 +356,10 @@ def main():
         out["roofline"] = dict(bound="mfma", achieved=dom["tflops"], peak=MFMA_F32_PEAK_TF, unit="TFLOP/s",
                                frac=round(dom["tflops"] / MFMA_F32_PEAK_TF, 4), traffic=traffic, kernel=dom["kernel"],
                                algorithmic_gflop_per_launch=dom["gflop_per_launch"], ms_per_launch=dom["ms_per_launch"],
-                               note="dominant kernel of the timed region by total time; achieved = algorithmic flop per "
-                                    "launch / mean launch duration (HIP events on the launch stream, 10 launches, same "
-                                    "shape as in the update: M=65,536); traffic = HBM bytes per launch from rocprofv3 PMC "
-                                    "(FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), " + traffic_src)
+                               note=("dominant kernel of the timed region by total time; achieved = algorithmic flop per "
+                                    "launch / mean launch duration (HIP events on the launch stream, 20 launches, same "
+                                    "shape as in the update: M=%d rows per pass); traffic = HBM bytes per launch from rocprofv3 PMC "
+                                    "(FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), ") % dom["rows_per_launch"] + traffic_src)
         out["update_flop_efficiency"] = dict(
             achieved=round(FLOP_PER_SAMPLE * value / 1e12, 2), peak=MFMA_F32_PEAK_TF, unit="TFLOP/s",
             frac=round(FLOP_PER_SAMPLE * value / 1e12 / MFMA_F32_PEAK_TF, 4),

@@ -195,6 +195,13 @@ int rlppo_clip_adam(void *stream, float *params, float *grads, float *exp_avg, f
  * state: 625 uint32 (624 words of key + position), as numpy's get_state() exposes it. */
 int rlppo_mt19937_seed(uint32_t *state625, uint32_t seed);
 int rlppo_mt19937_permutation(uint32_t *state625, int64_t n, int64_t *out);
+/* The same permutation in two phases (same stream consumption, same result).  draw_targets: the serial phase -- advances
+ * the generator exactly as rlppo_mt19937_permutation(n) does and records the n-1 swap targets of numpy's reverse
+ * Fisher-Yates loop (mtrand.pyx _shuffle_raw) in draw order: targets[t] = j_i for i = n-1-t.  apply_swap_targets: applies
+ * those swaps to arange(n); no generator state, so it can run on another thread while the next epoch is being drawn
+ * (the shuffle of experience_buffer.py:97-98 is the serial host work of an epoch once 8 ranks share the GPU work). */
+int rlppo_mt19937_draw_targets(uint32_t *state625, int64_t n, uint32_t *targets);
+int rlppo_apply_swap_targets(int64_t n, const uint32_t *targets, int64_t *out);
 
 /* dst[r][0..width) = src[idx[r]][0..width), fp32 rows, 16 bytes per thread (width, ld_src multiples of 4; dst rows are
  * `width` floats apart).  The minibatch gather of experience_buffer.py:82-87 (used inside rlppo_ppo_minibatch) and the

@@ -68,6 +68,8 @@ SIGNATURES = {
                                   c_double, c_double, c_double, c_int64, c_void_p]),
     "rlppo_mt19937_seed": (c_int32, [POINTER(c_uint32), c_uint32]),
     "rlppo_mt19937_permutation": (c_int32, [POINTER(c_uint32), c_int64, c_void_p]),
+    "rlppo_mt19937_draw_targets": (c_int32, [POINTER(c_uint32), c_int64, c_void_p]),
+    "rlppo_apply_swap_targets": (c_int32, [c_int64, c_void_p, c_void_p]),
     "rlppo_gather_rows": (c_int32, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int32, c_int64]),
     "rlppo_welford_increment": (c_int32, [c_void_p, c_void_p, c_int64, c_int64, c_int32, c_void_p, c_void_p, c_int64]),
     "rlppo_set_inference_precision": (c_int32, [c_int32]),

@@ -6,6 +6,7 @@
 // mtrand.pyx (_shuffle_raw), pinned by tests against numpy itself and by fixture tests/golden/g6_shuffle.npz.
 // It exists so that the permutation of a 512k-sample buffer takes ~3 ms instead of numpy's ~12 ms and can run
 // outside the GIL while the GPU works on the previous epoch.
+#include <immintrin.h>
 #include <stdint.h>
 #include <string.h>
 
@@ -17,19 +18,30 @@ namespace {
 constexpr int N = 624, M = 397;
 constexpr uint32_t MATRIX_A = 0x9908b0dfu, UPPER = 0x80000000u, LOWER = 0x7fffffffu;
 
+inline uint32_t twist(uint32_t cur, uint32_t nxt, uint32_t far) {
+    const uint32_t y = (cur & UPPER) | (nxt & LOWER);
+    return far ^ (y >> 1) ^ (-(int32_t)(y & 1) & MATRIX_A);
+}
+
+// One 624-word regeneration, eight words per step: word kk needs the OLD kk+1 (loaded before kk..kk+7 are stored) and
+// either the old kk+397 (first 227 words) or the NEW kk-227 (written at least 220 words earlier).
 inline void regen(uint32_t *mt) {
-    int kk;
-    uint32_t y;
-    for (kk = 0; kk < N - M; kk++) {
-        y = (mt[kk] & UPPER) | (mt[kk + 1] & LOWER);
-        mt[kk] = mt[kk + M] ^ (y >> 1) ^ (-(int32_t)(y & 1) & MATRIX_A);
-    }
-    for (; kk < N - 1; kk++) {
-        y = (mt[kk] & UPPER) | (mt[kk + 1] & LOWER);
-        mt[kk] = mt[kk + (M - N)] ^ (y >> 1) ^ (-(int32_t)(y & 1) & MATRIX_A);
-    }
-    y = (mt[N - 1] & UPPER) | (mt[0] & LOWER);
-    mt[N - 1] = mt[M - 1] ^ (y >> 1) ^ (-(int32_t)(y & 1) & MATRIX_A);
+    const __m256i upper = _mm256_set1_epi32((int)UPPER), lower = _mm256_set1_epi32((int)LOWER);
+    const __m256i mat = _mm256_set1_epi32((int)MATRIX_A), one = _mm256_set1_epi32(1);
+    auto twist8 = [&](int kk, int far) {
+        const __m256i cur = _mm256_loadu_si256((const __m256i *)(mt + kk)), nxt = _mm256_loadu_si256((const __m256i *)(mt + kk + 1));
+        const __m256i y = _mm256_or_si256(_mm256_and_si256(cur, upper), _mm256_and_si256(nxt, lower));
+        const __m256i odd = _mm256_sub_epi32(_mm256_setzero_si256(), _mm256_and_si256(y, one));  // 0 or ~0
+        const __m256i r = _mm256_xor_si256(_mm256_xor_si256(_mm256_loadu_si256((const __m256i *)(mt + far)), _mm256_srli_epi32(y, 1)),
+                                           _mm256_and_si256(odd, mat));
+        _mm256_storeu_si256((__m256i *)(mt + kk), r);
+    };
+    int kk = 0;
+    for (; kk + 8 <= N - M; kk += 8) twist8(kk, kk + M);
+    for (; kk < N - M; kk++) mt[kk] = twist(mt[kk], mt[kk + 1], mt[kk + M]);
+    for (; kk + 8 <= N - 1; kk += 8) twist8(kk, kk + (M - N));
+    for (; kk < N - 1; kk++) mt[kk] = twist(mt[kk], mt[kk + 1], mt[kk + (M - N)]);
+    mt[N - 1] = twist(mt[N - 1], mt[0], mt[M - 1]);
 }
 
 inline uint32_t next32(uint32_t *st) {
@@ -44,6 +56,23 @@ inline uint32_t next32(uint32_t *st) {
     y ^= (y << 15) & 0xefc60000u;
     y ^= (y >> 18);
     return y;
+}
+
+// permutevar8x32 index vectors that move the lanes selected by an 8-bit mask to the front, in order
+struct CompressLut {
+    alignas(32) uint32_t idx[256][8];
+    CompressLut() {
+        for (int m = 0; m < 256; m++) {
+            int c = 0;
+            for (int k = 0; k < 8; k++)
+                if (m >> k & 1) idx[m][c++] = (uint32_t)k;
+            for (; c < 8; c++) idx[m][c] = 0;
+        }
+    }
+};
+inline const CompressLut &compress_lut() {
+    static const CompressLut lut;
+    return lut;
 }
 }  // namespace
 
@@ -117,6 +146,93 @@ int rlppo_mt19937_permutation(uint32_t *st, int64_t n, int64_t *out) {
         i -= want;
     }
     st[N] = pos;
+    for (int64_t k = 0; k < n; k++) out[k] = w[k];
+    return 0;
+}
+
+// ---- the same permutation in two phases --------------------------------------------------------------------------
+// The swap targets j_i of the reverse Fisher-Yates loop depend on the generator only, not on the array being shuffled.
+// Phase 1 (rlppo_mt19937_draw_targets) is the inherently serial part: it consumes the stream exactly as
+// rlppo_mt19937_permutation does and records targets[t] = j_i for i = n-1-t (draw order).  Phase 2
+// (rlppo_apply_swap_targets) applies the swaps; it touches no generator state, so the swaps of epoch e can run on another
+// thread while phase 1 already draws epoch e+1 (engine.ShufflePipeline).  With 8 data-parallel ranks the GPU share of an
+// epoch (~1.1 ms) is shorter than the fused permutation (~3 ms); the serial critical path is then phase 1 alone.
+int rlppo_mt19937_draw_targets(uint32_t *st, int64_t n, uint32_t *targets) {
+    if (!st || n < 0 || (n > 1 && !targets) || n > 0x7fffffffLL) return RLPPO_ERR_ARG;
+    if (n < 2) return 0;
+    alignas(32) uint32_t cache[N + 8];
+    uint32_t pos = st[N] > (uint32_t)N ? (uint32_t)N : st[N];
+    auto temper_block = [&](uint32_t from) {
+        for (uint32_t k = from; k < (uint32_t)N; k++) {
+            uint32_t y = st[k];
+            y ^= (y >> 11);
+            y ^= (y << 7) & 0x9d2c5680u;
+            y ^= (y << 15) & 0xefc60000u;
+            y ^= (y >> 18);
+            cache[k] = y;
+        }
+    };
+    temper_block(pos);
+    const CompressLut &lut = compress_lut();
+    uint32_t *out = targets;
+    uint32_t ii = (uint32_t)(n - 1);
+    while (ii >= 1) {
+        const uint32_t mask = 0xffffffffu >> __builtin_clz(ii);  // smallest all-ones mask >= ii
+        const uint32_t lo = mask >> 1;                             // the run ends when ii drops to lo
+        const __m256i vmask = _mm256_set1_epi32((int)mask);
+        while (ii > lo) {
+            if (pos >= (uint32_t)N) {
+                regen(st);
+                temper_block(0);
+                pos = 0;
+            }
+            // Eight stream words at a time.  Word k of a group is accepted iff (w & mask) <= ii - (accepted before it), so
+            // (w & mask) <= ii - 8 is accepted and (w & mask) > ii is rejected whatever the words before it did; a group in
+            // which every word is one or the other (all but ~64/ii of them) is compacted with one permute and stored in
+            // draw order (the 8 written slots always lie inside the caller's n entries: at least 8 targets remain).  masks
+            // are < 2^31 (n <= INT32_MAX), so signed compares are exact.
+            while (pos + 8 <= (uint32_t)N && ii > lo + 8) {
+                const __m256i w = _mm256_and_si256(_mm256_loadu_si256((const __m256i *)(cache + pos)), vmask);
+                const __m256i rej = _mm256_cmpgt_epi32(w, _mm256_set1_epi32((int)ii));
+                const __m256i acc = _mm256_cmpgt_epi32(_mm256_set1_epi32((int)(ii - 8 + 1)), w);
+                const int macc = _mm256_movemask_ps(_mm256_castsi256_ps(acc));
+                const int mrej = _mm256_movemask_ps(_mm256_castsi256_ps(rej));
+                if ((macc | mrej) != 0xff) break;  // an undecided word: this group goes through the scalar loop
+                _mm256_storeu_si256((__m256i *)out, _mm256_permutevar8x32_epi32(w, _mm256_load_si256((const __m256i *)lut.idx[macc])));
+                const uint32_t c = (uint32_t)__builtin_popcount((unsigned)macc);
+                out += c;
+                ii -= c;
+                pos += 8;
+            }
+            for (int k = 0; k < 8 && pos < (uint32_t)N && ii > lo; k++) {
+                const uint32_t v = cache[pos++] & mask;
+                const uint32_t a = v <= ii;
+                *out = v;
+                out += a;
+                ii -= a;
+            }
+        }
+    }
+    st[N] = pos;
+    return 0;
+}
+
+int rlppo_apply_swap_targets(int64_t n, const uint32_t *targets, int64_t *out) {
+    if (n < 0 || (n > 0 && !out) || (n > 1 && !targets) || n > 0x7fffffffLL) return RLPPO_ERR_ARG;
+    static thread_local std::vector<int32_t> work;
+    work.resize((size_t)n);
+    int32_t *w = work.data();
+    for (int64_t i = 0; i < n; i++) w[i] = (int32_t)i;
+    constexpr int64_t AHEAD = 32;  // the targets are known in advance: their cache lines are requested 32 swaps early
+    for (int64_t t = 0; t + 1 < n; t++) {
+        if (t + AHEAD < n - 1) __builtin_prefetch(&w[targets[t + AHEAD]], 1, 1);
+        const int64_t i = n - 1 - t;
+        const uint32_t j = targets[t];
+        if ((int64_t)j > i) return RLPPO_ERR_ARG;  // not a target vector of rlppo_mt19937_draw_targets
+        const int32_t v = w[j];
+        w[j] = w[i];
+        w[i] = v;
+    }
     for (int64_t k = 0; k < n; k++) out[k] = w[k];
     return 0;
 }

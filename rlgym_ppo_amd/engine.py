@@ -4,7 +4,9 @@ PyTorch is used for what the task allows it for -- device memory, streams, H2D/D
 torch.distributed -- never for the arithmetic of the hot path.  Everything numeric is a call into the C ABI
 (include/rlppo.h) on torch's current HIP stream.
 """
+import collections
 import ctypes
+import threading
 
 import numpy as np
 import torch
@@ -157,25 +159,190 @@ def linears_of(sequential):
 
 
 # ----------------------------------------------------------------------------------------------- shuffle
+_POOLS = {}
+
+
+def _pool(name, workers):
+    """Process-wide helper threads of the shuffle pipeline (the C calls release the GIL)."""
+    if name not in _POOLS:
+        from concurrent.futures import ThreadPoolExecutor
+        _POOLS[name] = ThreadPoolExecutor(max_workers=workers, thread_name_prefix="rlppo-" + name)
+    return _POOLS[name]
+
+
+class _ShuffleEntry:
+    __slots__ = ("n", "after", "out", "slot", "done", "error")
+
+    def __init__(self, n):
+        self.n, self.after, self.out, self.slot, self.error = n, None, None, None, None
+        self.done = threading.Event()
+
+
 class LegacyPermutation:
-    """numpy.random.RandomState(seed).permutation(n) through the library's host implementation (bit-identical
-    stream, ~4x faster, releases the GIL), keeping the numpy generator object in sync so that user code that
-    touches `buffer.rng` still sees the reference's state."""
+    """numpy.random.RandomState(seed).permutation(n) through the library's host implementation (bit-identical stream),
+    keeping the numpy generator object in sync so that user code that touches `buffer.rng` still sees the reference's
+    state (experience_buffer.py:52,97-98).
 
-    def __init__(self, rng):
+    The permutation is produced in two phases on helper threads: the serial stream phase (rlppo_mt19937_draw_targets,
+    one thread, epochs in order) and the swap phase (rlppo_apply_swap_targets, any thread).  With `lookahead` > 0 the
+    pipeline also draws that many permutations of the same size AHEAD of the request (an epoch loop asks for the same n
+    again and again); they are speculative: a request is served from the queue only if n matches and the numpy generator
+    is still in exactly the state the queue was drawn from -- otherwise the queue is dropped and the draw restarts from the
+    generator's current state, so the observable stream never differs from the reference's.
+
+    `ring` (optional, see DeviceIndexRing) supplies the output arrays and is told when one is complete."""
+
+    def __init__(self, rng, lookahead=0, ring=None):
         self.rng = rng
+        self.lookahead = int(lookahead)
+        self._ring = ring
+        self._q = collections.deque()
+        self._chain = None      # {"st": uint32[625] owned by the draw thread, "dead": bool}
+        self._expected = None   # generator state the head of the queue was drawn from
+        self._seq = 0
 
-    def permutation(self, n):
+    def _rng_state(self):
         kind, key, pos, has_gauss, cached = self.rng.get_state()
         assert kind == "MT19937"
         st = np.empty(625, dtype=np.uint32)
         st[:624] = key
         st[624] = pos
-        out = np.empty(int(n), dtype=np.int64)
-        N.check(N.lib().rlppo_mt19937_permutation(st.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)), int(n),
-                                                  ctypes.c_void_p(out.ctypes.data)))
-        self.rng.set_state((kind, st[:624].copy(), int(st[624]), has_gauss, cached))
-        return out
+        return st, (kind, has_gauss, cached)
+
+    def _enqueue(self, n):
+        e = _ShuffleEntry(n)
+        ring, chain = self._ring, self._chain
+        if ring is not None:
+            e.slot = self._seq % ring.slots
+            e.out = ring.host_array(e.slot, n)
+        else:
+            e.out = np.empty(n, dtype=np.int64)
+        self._seq += 1
+        targets = np.empty(max(n - 1, 0) + 8, dtype=np.uint32)
+        L = N.lib()
+
+        def apply():
+            try:
+                N.check(L.rlppo_apply_swap_targets(n, ctypes.c_void_p(targets.ctypes.data), ctypes.c_void_p(e.out.ctypes.data)))
+                if ring is not None:
+                    ring.after_write(e.slot, n)
+            except BaseException as ex:  # noqa: BLE001 -- handed to the consumer
+                e.error = ex
+            finally:
+                e.done.set()
+
+        def draw():
+            try:
+                if chain.get("dead"):
+                    raise RuntimeError("shuffle pipeline: entry dropped")
+                if ring is not None:
+                    ring.before_write(e.slot)
+                st = chain["st"]
+                N.check(L.rlppo_mt19937_draw_targets(st.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)), n,
+                                                     ctypes.c_void_p(targets.ctypes.data)))
+                e.after = st.copy()
+                _pool("swap", 2).submit(apply)
+            except BaseException as ex:  # noqa: BLE001
+                e.error = ex
+                e.done.set()
+
+        self._q.append(e)
+        _pool("draw", 1).submit(draw)
+
+    def _flush(self):
+        if self._chain is not None:
+            self._chain["dead"] = True
+        for e in self._q:
+            e.done.wait()
+        self._q.clear()
+        self._chain = None
+
+    close = _flush
+
+    def take(self, n):
+        """The next permutation of arange(n) as a completed pipeline entry (`.out`: int64 host array, `.slot`)."""
+        n = int(n)
+        st, extra = self._rng_state()
+        if not (self._q and self._q[0].n == n and self._expected is not None and np.array_equal(st, self._expected)):
+            self._flush()
+            if self._ring is not None:
+                self._ring.ensure(n)
+            self._chain = {"st": st.copy()}
+        while len(self._q) < 1 + self.lookahead:
+            self._enqueue(n)
+        e = self._q.popleft()
+        e.done.wait()
+        if e.error is not None:
+            self._flush()
+            raise e.error
+        self.rng.set_state((extra[0], e.after[:624].copy(), int(e.after[624]), extra[1], extra[2]))
+        self._expected = e.after
+        while len(self._q) < self.lookahead:
+            self._enqueue(n)
+        return e
+
+    def permutation(self, n):
+        return self.take(n).out
+
+
+class DeviceIndexRing:
+    """Output side of the shuffle pipeline for the PPO update: every permutation is written by the swap thread straight into
+    a pinned host vector and copied to HBM from that thread on a dedicated upload stream, so an epoch's index vector is
+    already resident when the epoch starts and the learner thread only orders its stream after the copy's event.
+
+    Slot life cycle (ring of `slots` >= lookahead + 2 vectors): swap thread writes pinned[slot] -> H2D on the upload stream,
+    `copied[slot]` recorded -> learner takes it (its stream waits for `copied`) -> before the learner asks for the NEXT vector
+    `released[slot]` is recorded on its stream -> the slot's next H2D waits for `released` (the kernels of that epoch are done
+    reading) and the next host write waits for `copied` (the previous H2D no longer reads the pinned vector).  A host view
+    returned by LegacyPermutation.permutation() therefore stays valid until the next-but-one request."""
+
+    def __init__(self, device, slots):
+        self.device = torch.device(device)
+        self.slots = int(slots)
+        self.cap = 0
+        self.pinned = self.dev = None
+        self.stream = None
+        self.copied = [torch.cuda.Event() for _ in range(self.slots)]
+        self.released = [torch.cuda.Event() for _ in range(self.slots)]
+        self._held = None
+
+    def ensure(self, n):
+        """Called with no pipeline entry outstanding (the queue was just dropped)."""
+        if self.stream is None:
+            self.stream = torch.cuda.Stream(self.device)
+        n = max(int(n), 1)
+        if n > self.cap:
+            torch.cuda.synchronize(self.device)  # rare: the buffer grew; nothing may still read the old vectors
+            self.cap = int(n)
+            self.pinned = [torch.empty(self.cap, dtype=torch.int64).pin_memory() for _ in range(self.slots)]
+            self.dev = [torch.empty(self.cap, dtype=torch.int64, device=self.device) for _ in range(self.slots)]
+
+    def host_array(self, slot, n):
+        return self.pinned[slot][:n].numpy()
+
+    def before_write(self, slot):
+        self.copied[slot].synchronize()
+
+    def after_write(self, slot, n):
+        with torch.cuda.device(self.device):
+            self.stream.wait_event(self.released[slot])
+            with torch.cuda.stream(self.stream):
+                self.dev[slot][:n].copy_(self.pinned[slot][:n], non_blocking=True)
+            self.copied[slot].record(self.stream)
+
+    def release_held(self):
+        """Learner thread, before asking the pipeline for the next vector: everything that reads the vector handed out last
+        has been enqueued on the current stream; its slot may be refilled once that work is done."""
+        if self._held is not None:
+            self.released[self._held].record(torch.cuda.current_stream(self.device))
+            self._held = None
+
+    def take(self, entry):
+        """Learner thread: device view of a completed entry, ordered on the current stream."""
+        self.release_held()
+        torch.cuda.current_stream(self.device).wait_event(self.copied[entry.slot])
+        self._held = entry.slot
+        return self.dev[entry.slot][:entry.n]
 
 
 def set_inference_precision(mode):

@@ -6,11 +6,13 @@ only: the buffer lives on the GPU (the reference keeps it on the CPU and re-uplo
 ppo_learner.py:139-143), `states` rows are zero-padded to the kernels' leading dimension, and PPOLearner reads
 the buffer through index vectors (`epoch_indices`) instead of materialised gathers.
 """
+import os
+
 import numpy as np
 import torch
 
 from .. import _native as N
-from ..engine import LegacyPermutation, ptr, require_gpu, stream_ptr
+from ..engine import DeviceIndexRing, LegacyPermutation, ptr, require_gpu, stream_ptr
 
 _FIELDS = ("states", "actions", "log_probs", "rewards", "next_states", "dones", "truncated", "values", "advantages")
 
@@ -25,7 +27,13 @@ class ExperienceBuffer(object):
         self.seed = seed
         self.max_size = max_size
         self.rng = np.random.RandomState(seed)
-        self._perm = LegacyPermutation(self.rng)
+        # epochs drawn ahead of the request by the shuffle pipeline (speculative, transparent: engine.LegacyPermutation)
+        lookahead = max(0, int(os.environ.get("RLPPO_SHUFFLE_LOOKAHEAD", 3)))
+        ring = getattr(self, "_ring", None)  # clear() re-runs __init__: the pinned / device index vectors are kept
+        if ring is None or ring.slots != lookahead + 2:
+            ring = DeviceIndexRing(self._dev, lookahead + 2)
+        self._ring = ring
+        self._perm = LegacyPermutation(self.rng, lookahead=lookahead, ring=ring)
         self._store = {k: None for k in _FIELDS}
         self._d = None  # logical observation width
 
@@ -94,6 +102,12 @@ class ExperienceBuffer(object):
         per epoch from the persistent generator (experience_buffer.py:97-98)."""
         return self._perm.permutation(len(self))
 
+    def epoch_indices_device(self):
+        """The same permutation as a device int64 vector, ordered on the current stream (uploaded by the shuffle pipeline
+        on its own stream, normally long before it is asked for).  It stays valid until the next call."""
+        self._ring.release_held()
+        return self._ring.take(self._perm.take(len(self)))
+
     def _get_samples(self, indices):
         idx = torch.as_tensor(np.asarray(indices), device=self._dev)
         return (self.actions[idx], self.log_probs[idx], self.states[idx], self.values[idx], self.advantages[idx])
@@ -109,4 +123,5 @@ class ExperienceBuffer(object):
             start += batch_size
 
     def clear(self):
+        self._perm.close()
         self.__init__(self.max_size, self.seed, self.device)

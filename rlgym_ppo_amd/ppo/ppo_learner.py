@@ -156,30 +156,8 @@ class PPOLearner(object):
         # (mb = k MB rows, mb_ratio = k MB / B): the same gradient and the same report means up to fp32 summation order,
         # in launches that are k times larger.  RLPPO_FUSE=1 keeps one pass per minibatch.
         self.max_fused_minibatches = max(1, int(os.environ.get("RLPPO_FUSE", 8)))
-        self._idx_bufs = None
-        from concurrent.futures import ThreadPoolExecutor
-        self._perm_pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="rlppo-shuffle")
 
     # --------------------------------------------------------------------------------------------- learn
-    def _upload_indices(self, idx):
-        """Host permutation -> device, double buffered: slot s is rewritten two epochs later, after the event that
-        follows its H2D copy has completed, so neither the pinned staging memory nor the device vector is ever
-        overwritten while in use and learn() never synchronises the stream."""
-        n = idx.shape[0]
-        s = self._idx_slot = 1 - getattr(self, "_idx_slot", 1)
-        if self._idx_bufs is None or self._idx_bufs[0][0].numel() < n:
-            self._idx_bufs = [(torch.empty(n, dtype=torch.int64).pin_memory(),
-                               torch.empty(n, dtype=torch.int64, device=self._dev), torch.cuda.Event()) for _ in range(2)]
-            self._idx_used = [False, False]
-        pinned, dev, ev = self._idx_bufs[s]
-        if self._idx_used[s]:
-            ev.synchronize()
-        pinned[:n].numpy()[:] = idx
-        dev[:n].copy_(pinned[:n], non_blocking=True)
-        ev.record()
-        self._idx_used[s] = True
-        return dev[:n]
-
     def _minibatch_args(self, exp):
         pa, va = self.policy.arena, self.value_net.arena
         a = N.MinibatchArgs()
@@ -235,16 +213,13 @@ class PPOLearner(object):
                 raise ValueError("experience buffer action width does not match the policy head")
             args = self._minibatch_args(exp)
             st = stream_ptr()
-            # The legacy-MT19937 permutation is inherently serial host work (3 ms per 512k indices).  It is drawn by a
-            # helper thread (the C call releases the GIL) one epoch ahead, so it overlaps both the GPU and this
-            # thread's launch calls; with 8 ranks the GPU share of an epoch is ~1.5 ms and the shuffle is the critical path.
-            # ... and its upload (4 MB through pinned memory) is issued while the GPU still has the minibatches of the
-            # current epoch's first batch queued: done at the epoch boundary it left the GPU idle for ~100 us per epoch.
-            fut = self._perm_pool.submit(exp.epoch_indices)
-            idx_next = self._upload_indices(fut.result())
-            fut = self._perm_pool.submit(exp.epoch_indices) if self.n_epochs > 1 else None
+            # The legacy-MT19937 permutation is inherently serial host work.  The buffer's shuffle pipeline draws it on
+            # helper threads several epochs ahead (also across learn() calls) and uploads every index vector on its own
+            # stream (engine.LegacyPermutation / DeviceIndexRing): here an epoch only orders the stream after that copy.
+            # With 8 ranks the GPU share of an epoch is ~1.1 ms; the serial stream phase (~0.8 ms per 512k indices) is
+            # the only part of the shuffle that cannot be spread over threads.
             for epoch in range(self.n_epochs):
-                idx_dev = idx_next
+                idx_dev = exp.epoch_indices_device()
                 for b in range(n_batches):
                     self._grad_all.zero_()
                     pa.ensure_packed()
@@ -259,9 +234,6 @@ class PPOLearner(object):
                         N.check(L.rlppo_ppo_minibatch(st, ctypes.byref(args)))
                         n_passes += 1
                     N.check(L.rlppo_ppo_join(st))
-                    if b == 0 and fut is not None:  # next epoch's indices, behind this batch's launches in the stream
-                        idx_next = self._upload_indices(fut.result())
-                        fut = self._perm_pool.submit(exp.epoch_indices) if epoch + 2 < self.n_epochs else None
                     n_minibatch_iterations += n_slices
                     if dist is not None:
                         all_reduce_sum(self._grad_all, dist)  # RCCL over xGMI, before clipping

@@ -86,6 +86,45 @@ def test_mt19937_permutation_is_numpys_legacy_stream(golden):
     assert np.array_equal(st[:624], np.random.RandomState(123).get_state()[1]) and st[624] == 624
 
 
+def test_two_phase_permutation_and_speculative_pipeline():
+    """rlppo_mt19937_draw_targets + rlppo_apply_swap_targets == RandomState.permutation (stream and result), and the
+    look-ahead pipeline never changes the observable stream: requests of another size, foreign draws from the generator
+    and re-seeding between requests all fall back to the generator's current state."""
+    from rlgym_ppo_amd import _native as N
+    from rlgym_ppo_amd.engine import LegacyPermutation
+    L = N.lib()
+    ref = np.random.RandomState(11)
+    st = np.empty(625, np.uint32)
+    st[:624], st[624] = ref.get_state()[1], ref.get_state()[2]
+    for n in (0, 1, 2, 3, 8, 9, 10, 17, 255, 256, 257, 1000, 4097, 70000, 524288):
+        targets = np.full(max(n - 1, 0) + 8, 0xDEADBEEF, np.uint32)
+        out = np.empty(n, np.int64)
+        N.check(L.rlppo_mt19937_draw_targets(st.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)), n, ctypes.c_void_p(targets.ctypes.data)))
+        N.check(L.rlppo_apply_swap_targets(n, ctypes.c_void_p(targets.ctypes.data), ctypes.c_void_p(out.ctypes.data)))
+        assert np.array_equal(out, ref.permutation(n)), n
+        assert (targets[max(n - 1, 0):] == 0xDEADBEEF).all()                       # nothing written past the n-1 targets
+        assert (targets[:max(n - 1, 0)] <= np.arange(n - 1, 0, -1)).all()          # j_i <= i
+        assert np.array_equal(st[:624], ref.get_state()[1]) and st[624] == ref.get_state()[2], n
+    bad = np.array([5, 0, 0], np.uint32)                                            # j > i is rejected, not applied
+    assert L.rlppo_apply_swap_targets(4, ctypes.c_void_p(bad.ctypes.data), ctypes.c_void_p(np.empty(4, np.int64).ctypes.data)) != 0
+
+    for lookahead in (0, 1, 3):
+        ref = np.random.RandomState(5)
+        rng = np.random.RandomState(5)
+        mine = LegacyPermutation(rng, lookahead=lookahead)
+        for n in (1000, 1000, 1000, 1000, 1000, 1000, 777, 777, 1000):              # size changes drop the speculation
+            assert np.array_equal(mine.permutation(n), ref.permutation(n)), (lookahead, n)
+        assert rng.randint(1 << 30) == ref.randint(1 << 30)                         # a foreign draw ...
+        assert np.array_equal(mine.permutation(1000), ref.permutation(1000))        # ... is seen by the next request
+        assert np.array_equal(mine.permutation(1000), ref.permutation(1000))
+        rng.seed(99), ref.seed(99)                                                  # re-seeding as well
+        for _ in range(4):
+            assert np.array_equal(mine.permutation(4096), ref.permutation(4096))
+        assert np.array_equal(rng.get_state()[1], ref.get_state()[1]) and rng.get_state()[2] == ref.get_state()[2]
+        assert rng.standard_normal() == ref.standard_normal()
+        mine.close()
+
+
 def test_oracle_is_only_imported_where_allowed():
     allowed = {"bench.py", "__graft_entry__.py"}
     pat = re.compile(r"^\s*(from|import)\s+oracle\b", re.M)

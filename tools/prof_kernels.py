@@ -1,4 +1,5 @@
-"""Runs every kernel flavour of one cfg2 minibatch + the GAE scan a few times (for rocprofv3 --pmc / --kernel-trace)."""
+"""Runs every kernel flavour of one pass of the cfg2 update (M rows) + the GAE scan a few times (for rocprofv3 --pmc /
+--kernel-trace)."""
 import ctypes
 import os
 import sys
@@ -11,7 +12,7 @@ from rlgym_ppo_amd import _native as N  # noqa: E402
 from rlgym_ppo_amd.util import torch_functions  # noqa: E402
 
 L = N.lib()
-M = 65536
+M = int(os.environ.get("M", 524288))  # rows per launch: one GPU evaluates the 8 minibatches of a batch in one pass
 st = lambda: ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 P = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
 dev = "cuda"
