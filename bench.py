@@ -46,16 +46,25 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def build_workload(device, seed=123):
+CFG5 = dict(obs=231, act=8, hid=(512, 512, 512, 512), flop_per_sample=10_435_584)  # BASELINE configs[4], SURVEY 8(d)
+
+
+def build_workload(device, seed=123, config="cfg2"):
     from rlgym_ppo_amd.ppo import ExperienceBuffer, PPOLearner
     torch.manual_seed(seed)
     np.random.seed(seed)
-    learner = PPOLearner(OBS, ACT, 0, HID, HID, (0.1, 1.0), BATCH, 10, 3e-4, 3e-4, 0.2, 0.005, MINIBATCH, device)
+    gauss = config == "cfg5"
+    obs_d, hid = (CFG5["obs"], CFG5["hid"]) if gauss else (OBS, HID)
+    learner = PPOLearner(obs_d, CFG5["act"] if gauss else ACT, 2 if gauss else 0, hid, hid, (0.1, 1.0), BATCH, 10, 3e-4, 3e-4, 0.2,
+                         0.005, MINIBATCH, device)
     g = torch.Generator(device=device).manual_seed(seed)
-    states = torch.randn(N_SAMPLES, OBS, device=device, generator=g).clamp_(-5, 5)
+    states = torch.randn(N_SAMPLES, obs_d, device=device, generator=g).clamp_(-5, 5)
     acts, logps = [], []
     for s in range(0, N_SAMPLES, 65536):  # actions sampled by the policy itself at init weights -> ratio ~ 1 at step 0
-        noise = torch.empty(65536, ACT, device=device).exponential_(1, generator=g)
+        if gauss:
+            noise = torch.empty(65536, CFG5["act"], device=device).normal_(0, 1, generator=g)
+        else:
+            noise = torch.empty(65536, ACT, device=device).exponential_(1, generator=g)
         a, lp = learner.policy.get_action(states[s:s + 65536], noise=noise)
         acts.append(a)
         logps.append(lp)
@@ -65,7 +74,7 @@ def build_workload(device, seed=123):
     tgt = torch.randn(N_SAMPLES, device=device, generator=g)
     z = torch.zeros(N_SAMPLES, device=device)
     buf = ExperienceBuffer(N_SAMPLES, seed, "cpu")
-    buf.submit_experience(states, actions, log_probs, z, states[:1].expand(N_SAMPLES, OBS), z, z, tgt, adv)
+    buf.submit_experience(states, actions, log_probs, z, states[:1].expand(N_SAMPLES, obs_d), z, z, tgt, adv)
     return learner, buf
 
 
@@ -120,7 +129,8 @@ def kernel_breakdown(learner):
         return lambda: N.check(L.rlppo_dbg_gemm_nt(st(), P(A), lda, P(ridx) if ridx is not None else None, P(W), ldb, P(bias),
                                                     P(mask) if mask is not None else None, n, P(C), ldc, M, n, k, epi))
 
-    tn_ws = torch.empty(max(int(L.rlppo_dbg_gemm_tn_workspace_bytes(256, 256, M)), 1), dtype=torch.uint8, device=dev)
+    tn_ws = torch.empty(max(max(int(L.rlppo_dbg_gemm_tn_workspace_bytes(o, i, M)) for o, i in ((256, 256), (256, 107), (90, 256))), 1),
+                        dtype=torch.uint8, device=dev)  # too small a workspace silently selects the atomic form
 
     def tn(dY, ny, X, kx, ridx, out, in_):  # the form the update uses: partial tiles + reduction kernel (both timed)
         return lambda: N.check(L.rlppo_dbg_gemm_tn_ws(st(), P(dY), ny, ny, P(X), kx, kx, P(dW), P(db), out, in_, M, P(tn_ws),
@@ -290,6 +300,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--epochs", type=int, default=10)
     ap.add_argument("--no-extras", action="store_true", help="skip roofline / gae / rollout / cpu_baseline legs")
+    ap.add_argument("--config", choices=("cfg2", "cfg5"), default="cfg2",
+                    help="cfg2 = BASELINE configs[1] (the headline metric); cfg5 = configs[4] shape (Gaussian policy, obs 231, "
+                         "512x4 nets, fp32 update) -- update throughput only, no extra legs")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
@@ -314,7 +327,7 @@ def main():
 
     import contextlib
     with contextlib.redirect_stdout(sys.stderr):
-        learner, buf = build_workload(device)
+        learner, buf = build_workload(device, config=args.config)
     learner.n_epochs = args.epochs
 
     def barrier():
@@ -342,13 +355,21 @@ def main():
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
         "data": "synthetic" + (" (DRY RUN: all ranks on one GPU over gloo, not a measurement)" if dryrun else ""),
-        "config": {"workload": "BASELINE configs[1]: 4096 agents x 128 steps = 524,288-sample buffer, obs 107 f32, "
-                               "90 discrete actions, 256x3 policy + 256x3 critic; ppo_batch 524,288, minibatch 65,536",
+        "config": {"workload": ("BASELINE configs[1]: 4096 agents x 128 steps = 524,288-sample buffer, obs 107 f32, "
+                                "90 discrete actions, 256x3 policy + 256x3 critic; ppo_batch 524,288, minibatch 65,536")
+                   if args.config == "cfg2" else
+                   ("BASELINE configs[4] shape: 524,288-sample buffer, obs 231 f32, Gaussian policy with 8 actions, 512x4 policy + "
+                    "512x4 critic, fp32 update (the bf16 forward is a rollout option); ppo_batch 524,288, minibatch 65,536"),
                    "epochs_per_step": args.epochs, "samples_per_step": args.epochs * BATCH,
                    "parallelism": f"dp{world}: {8 // world if 8 % world == 0 else 1} consecutive minibatch slice(s) per rank and pass, 1 RCCL all-reduce/optimiser step",
                    "last_report": {k: (round(v, 6) if isinstance(v, float) else v) for k, v in report.items()}},
     }
-    if rank == 0 and world == 1 and not args.no_extras:
+    if args.config == "cfg5":
+        fps = CFG5["flop_per_sample"]
+        out["update_flop_efficiency"] = dict(achieved=round(fps * value / 1e12, 2), peak=MFMA_F32_PEAK_TF, unit="TFLOP/s",
+                                             frac=round(fps * value / 1e12 / MFMA_F32_PEAK_TF, 4),
+                                             note="10,435,584 algorithmic flop/sample (SURVEY 8(d)) x measured samples/s")
+    if rank == 0 and world == 1 and not args.no_extras and args.config == "cfg2":
         rows, dom = kernel_breakdown(learner)
         for r in rows:
             log("  %-44s x%d  %8.4f ms  %7.2f TFLOP/s" % (r["kernel"], r["launches_per_minibatch"], r["ms_per_launch"], r["tflops"]))

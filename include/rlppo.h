@@ -68,6 +68,11 @@ int rlppo_net_pack(void *stream, const int32_t *dims, int32_t n_layers, const fl
  * if standardize != 0, dst = clip((src - mean0) / std0, -5, 5). */
 int rlppo_pad_rows(void *stream, const void *src, int32_t src_is_f64, int64_t n, int64_t d, int64_t ld_src,
                    float *dst, int64_t ld_dst, int32_t standardize, float mean0, float std0);
+/* The same copy with per-feature statistics (device vectors of d floats): dst = clip((src - mean[c]) / std[c], -5, 5).
+ * Not the reference's behaviour (it applies the scalars of feature 0 to every feature, batched_agent_manager.py:230-235,
+ * 313-315): the corrected form SURVEY.md section 8(f) row 4 asks for, selected by per_feature_obs_standardization=True. */
+int rlppo_pad_rows_per_feature(void *stream, const void *src, int32_t src_is_f64, int64_t n, int64_t d, int64_t ld_src,
+                               float *dst, int64_t ld_dst, const float *mean, const float *stdv);
 
 /* ------------------------------------------------------------------------------------ rollout inference */
 

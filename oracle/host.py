@@ -70,7 +70,7 @@ class Welford:
         return np.sqrt(np.where(var == 0, 1.0, var))
 
 
-def lockstep_rollout(reset_obs, step_fn, act_fn, n_steps, standardize=True, stats_every=5, state=None):
+def lockstep_rollout(reset_obs, step_fn, act_fn, n_steps, standardize=True, stats_every=5, state=None, per_feature=False):
     """-> ((states, actions, log_probs, rewards, next_states, dones, truncated), state).
 
     reset_obs [n, d]: observations returned by the reset (first call only); step_fn(actions [n, k]) ->
@@ -91,6 +91,8 @@ def lockstep_rollout(reset_obs, step_fn, act_fn, n_steps, standardize=True, stat
         obs = np.asarray(obs, np.float32)
         if standardize:
             mean0, std0 = stats.mean[0], stats.std[0]          # fetched before this step's increment
+            if per_feature:                                     # the corrected form (not the reference's): own statistics
+                mean0, std0 = stats.mean.reshape(-1).copy(), stats.std.reshape(-1).copy()
             if state["since"] > stats_every:
                 stats.increment(obs, obs.shape[0])
                 state["since"] = 0

@@ -48,6 +48,8 @@ SIGNATURES = {
     "rlppo_net_pack": (c_int32, [c_void_p, _P32, c_int32, c_void_p, c_void_p]),
     "rlppo_pad_rows": (c_int32, [c_void_p, c_void_p, c_int32, c_int64, c_int64, c_int64, c_void_p, c_int64, c_int32,
                                  c_float, c_float]),
+    "rlppo_pad_rows_per_feature": (c_int32, [c_void_p, c_void_p, c_int32, c_int64, c_int64, c_int64, c_void_p, c_int64, c_void_p,
+                                             c_void_p]),
     "rlppo_forward_workspace_bytes": (c_size_t, [_P32, c_int32, c_int64]),
     "rlppo_mlp_forward": (c_int32, [c_void_p, _P32, c_int32, c_void_p, c_void_p, c_int64, c_int64, c_int32, c_void_p,
                                     c_int64, c_void_p, c_size_t]),

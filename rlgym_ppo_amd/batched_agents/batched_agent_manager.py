@@ -67,6 +67,7 @@ class BatchedAgentManager(object):
         self.standardize_obs = standardize_obs
         self.steps_per_obs_stats_increment = steps_per_obs_stats_increment
         self.steps_since_obs_stats_update = 0
+        self.per_feature_obs_standardization = False  # True: every feature with its own statistics (not the reference's Q5)
         self.obs_stats = None
         self.ep_rews = []
         self.trajectory_map = []
@@ -147,6 +148,8 @@ class BatchedAgentManager(object):
         mean0 = std0 = None
         if self.standardize_obs:
             mean0, std0 = self.obs_stats.mean[0], self.obs_stats.std[0]   # scalars of feature 0 (quirk Q5)
+            if self.per_feature_obs_standardization:
+                mean0, std0 = self.obs_stats.mean.reshape(-1), self.obs_stats.std.reshape(-1)  # broadcast over the rows
         conns = {conn: pid for pid, (_, conn) in enumerate(self.processes)}
         local = isinstance(self.processes[0][1], _LocalWorker)
         while n_collected < n_obs_per_inference:

@@ -35,6 +35,7 @@ class VectorAgentManager(object):
         self.standardize_obs = standardize_obs
         self.steps_per_obs_stats_increment = steps_per_obs_stats_increment
         self.steps_since_obs_stats_update = 0
+        self.per_feature_obs_standardization = False  # True: every feature with its own statistics (not the reference's Q5)
         self.obs_stats = None
         self.cumulative_timesteps = 0
         self.average_reward = None
@@ -66,6 +67,9 @@ class VectorAgentManager(object):
     def _standardize_scalars(self):
         if not self.standardize_obs:
             return None
+        if self.per_feature_obs_standardization:  # device vectors -> rlppo_pad_rows_per_feature
+            return (torch.from_numpy(np.asarray(self.obs_stats.mean, np.float32).reshape(-1).copy()),
+                    torch.from_numpy(np.asarray(self.obs_stats.std, np.float32).reshape(-1).copy()))
         return float(self.obs_stats.mean[0]), float(self.obs_stats.std[0])
 
     @torch.no_grad()

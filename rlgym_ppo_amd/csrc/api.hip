@@ -153,6 +153,14 @@ int rlppo_pad_rows(void *stream, const void *src, int32_t src_is_f64, int64_t n,
     return launch_pad_rows((hipStream_t)stream, src, src_is_f64, n, d, ld_src, dst, ld_dst, standardize, mean0, std0);
 }
 
+int rlppo_pad_rows_per_feature(void *stream, const void *src, int32_t src_is_f64, int64_t n, int64_t d, int64_t ld_src,
+                               float *dst, int64_t ld_dst, const float *mean, const float *stdv) {
+    RLPPO_CHECK_ARG(n >= 0 && d >= 1 && ld_src >= d && ld_dst >= d, "pad_rows_per_feature: n=%ld d=%ld ld_src=%ld ld_dst=%ld",
+                    (long)n, (long)d, (long)ld_src, (long)ld_dst);
+    RLPPO_CHECK_ARG(n == 0 || (src && dst && mean && stdv), "pad_rows_per_feature: null pointer");
+    return launch_pad_rows_vec((hipStream_t)stream, src, src_is_f64, n, d, ld_src, dst, ld_dst, mean, stdv);
+}
+
 size_t rlppo_forward_workspace_bytes(const int32_t *dims, int32_t n_layers, int64_t n) {
     NetLayout net;
     if (make_layout(dims, n_layers, &net)) return 0;

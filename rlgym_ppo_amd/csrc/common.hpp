@@ -76,6 +76,7 @@ int launch_pack(hipStream_t, const NetLayout &, const float *, float *);
 int launch_welford(hipStream_t st, const float *x, int64_t ld, int64_t n, int d, float *mean, float *m2, long long count0);
 int launch_gather_rows(hipStream_t st, const float *src, int64_t ld_src, const int64_t *idx, float *dst, int width, int64_t n);
 int launch_pad_rows(hipStream_t, const void *, int, int64_t, int64_t, int64_t, float *, int64_t, int, float, float);
+int launch_pad_rows_vec(hipStream_t, const void *, int, int64_t, int64_t, int64_t, float *, int64_t, const float *, const float *);
 int launch_clip_adam(hipStream_t, float *p, float *g, float *m, float *v, int64_t n, float max_norm, float step_size,
                      float bc2_sqrt, float one_minus_beta1, float beta2, float one_minus_beta2, float eps, double *gnorm2);
 size_t gae_workspace_bytes(int64_t n);

@@ -65,6 +65,21 @@ __global__ __launch_bounds__(256) void pad_rows_kernel(const T *__restrict__ src
     }
 }
 
+// The same copy with PER-FEATURE statistics: dst = clip((src - mean[c]) / std[c], -5, 5).  The reference standardises every
+// feature with the scalars of feature 0 (quirk Q5, above); this is the form its obs_stats were meant for, behind a flag.
+template <typename T>
+__global__ __launch_bounds__(256) void pad_rows_vec_kernel(const T *__restrict__ src, int64_t n, int64_t d, int64_t ld_src,
+                                                            float *__restrict__ dst, int64_t ld_dst,
+                                                            const float *__restrict__ mean, const float *__restrict__ stdv) {
+    const int64_t total = n * ld_dst;
+    for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = g / ld_dst, c = g % ld_dst;
+        float v = 0.f;
+        if (c < d) v = fminf(fmaxf(((float)src[r * ld_src + c] - mean[c]) / stdv[c], -5.f), 5.f);
+        dst[g] = v;
+    }
+}
+
 // Minibatch gather (experience_buffer.py:82-87): dst[r][0..width) = src[idx[r]][0..width), 16 bytes per thread.  One pass
 // per minibatch, shared by the policy and the critic: the four first-layer GEMMs (two forwards, two dW) then read
 // contiguous rows through the LDS-DMA kernels instead of each chasing the index vector.
@@ -130,6 +145,21 @@ int launch_pad_rows(hipStream_t st, const void *src, int is_f64, int64_t n, int6
     else
         hipLaunchKernelGGL(pad_rows_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float *)src, n, d, ld_src, dst,
                            ld_dst, standardize, mean0, std0);
+    RLPPO_LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_pad_rows_vec(hipStream_t st, const void *src, int is_f64, int64_t n, int64_t d, int64_t ld_src, float *dst,
+                        int64_t ld_dst, const float *mean, const float *stdv) {
+    if (n <= 0) return 0;
+    const int64_t total = n * ld_dst;
+    const int blocks = (int)(cdiv(total, 256) < 4096 ? cdiv(total, 256) : 4096);
+    if (is_f64)
+        hipLaunchKernelGGL(pad_rows_vec_kernel<double>, dim3(blocks), dim3(256), 0, st, (const double *)src, n, d, ld_src, dst,
+                           ld_dst, mean, stdv);
+    else
+        hipLaunchKernelGGL(pad_rows_vec_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float *)src, n, d, ld_src, dst,
+                           ld_dst, mean, stdv);
     RLPPO_LAUNCH_CHECK();
     return 0;
 }

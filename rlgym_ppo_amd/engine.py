@@ -112,7 +112,8 @@ class NetArena:
     # ------------------------------------------------------------------------------------------ inference
     def stage_obs(self, obs, standardize=None, out=None):
         """numpy / tensor observations of any float dtype -> zero-padded fp32 device rows [n, ld_in]
-        (written into `out` when given: the rollout storage's slot of the current step)."""
+        (written into `out` when given: the rollout storage's slot of the current step).  `standardize`: None, the
+        reference's scalar pair (mean0, std0) or a pair of per-feature tensors (mean[d], std[d])."""
         if isinstance(obs, torch.Tensor):
             t = obs.detach()
             if t.dtype not in (torch.float32, torch.float64):
@@ -135,6 +136,13 @@ class NetArena:
             raise ValueError("stage_obs: out must be a contiguous fp32 [n, ld_in] device tensor")
         mean0, std0, flag = 0.0, 1.0, 0
         if standardize is not None:
+            if isinstance(standardize[0], torch.Tensor):  # per-feature statistics: device vectors (mean[d], std[d])
+                mean_v, std_v = (x.to(self.device, dtype=torch.float32).contiguous() for x in standardize)
+                if mean_v.numel() != d or std_v.numel() != d:
+                    raise ValueError("stage_obs: per-feature statistics must have one entry per observation feature")
+                N.check(N.lib().rlppo_pad_rows_per_feature(stream_ptr(), ptr(t), int(t.dtype == torch.float64), n, d, d, ptr(out),
+                                                           self.ld_in, ptr(mean_v), ptr(std_v)))
+                return out
             mean0, std0, flag = float(standardize[0]), float(standardize[1]), 1
         N.check(N.lib().rlppo_pad_rows(stream_ptr(), ptr(t), int(t.dtype == torch.float64), n, d, d, ptr(out), self.ld_in,
                                        flag, mean0, std0))

@@ -40,7 +40,7 @@ class Learner(object):
             checkpoints_save_folder=None, add_unix_timestamp: bool = True, checkpoint_load_folder="latest",
             save_every_ts: int = 1_000_000, instance_launch_delay=None, random_seed: int = 123,
             n_checkpoints_to_keep: int = 5, shm_buffer_size: int = 8192, device: str = "auto",
-            vector_env: bool = False):
+            vector_env: bool = False, per_feature_obs_standardization: bool = False):
         assert env_create_function is not None, "MUST PROVIDE A FUNCTION TO CREATE RLGYM FUNCTIONS TO INITIALIZE RLGYM-PPO"
         if checkpoints_save_folder is None:
             checkpoints_save_folder = os.path.join("data", "checkpoints", "rlgym-ppo-run")
@@ -87,6 +87,9 @@ class Learner(object):
         self.agent = manager_cls(None, min_inference_size=min_inference_size, seed=random_seed,
                                  standardize_obs=standardize_obs,
                                  steps_per_obs_stats_increment=steps_per_obs_stats_increment)
+        # not in the reference (which standardises every feature with the statistics of feature 0, quirk Q5): every feature
+        # with its own running mean / std
+        self.agent.per_feature_obs_standardization = bool(per_feature_obs_standardization)
         obs_space_size, act_space_size, action_space_type = self.agent.init_processes(
             n_processes=n_proc, build_env_fn=env_create_function, collect_metrics_fn=collect_metrics_fn,
             spawn_delay=instance_launch_delay, render=render, render_delay=render_delay, shm_buffer_size=shm_buffer_size)

@@ -9,7 +9,7 @@ for M in (65536, 131072, 524288):
     A256 = torch.randn(M, 256, device="cuda"); A128 = torch.randn(M, 128, device="cuda"); A96 = torch.randn(M, 96, device="cuda")
     W = torch.randn(256, 256, device="cuda") * 0.05; b = torch.zeros(256, device="cuda"); C = torch.empty(M, 256, device="cuda"); C96 = torch.empty(M, 96, device="cuda")
     dW = torch.zeros(256 * 256, device="cuda"); db = torch.zeros(256, device="cuda")
-    ws = torch.empty(int(L.rlppo_dbg_gemm_tn_workspace_bytes(256, 256, M)), dtype=torch.uint8, device="cuda")
+    ws = torch.empty(max(int(L.rlppo_dbg_gemm_tn_workspace_bytes(o, i, M)) for o, i in ((256, 256), (256, 107), (90, 256))), dtype=torch.uint8, device="cuda")
     kern = {
         "fwd hidden": (lambda: N.check(L.rlppo_dbg_gemm_nt(st(), P(A256), 256, None, P(W), 256, P(b), None, 0, P(C), 256, M, 256, 256, 1)), 2 * M * 256 * 256),
         "fwd L0": (lambda: N.check(L.rlppo_dbg_gemm_nt(st(), P(A128), 128, None, P(W), 128, P(b), None, 0, P(C), 256, M, 256, 128, 1)), 2 * M * 256 * 128),

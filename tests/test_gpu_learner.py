@@ -223,3 +223,49 @@ def test_checkpoint_round_trip(tmp_path, golden):
     # and the reference's own optimiser class can read the file
     ref_opt = torch.optim.Adam([torch.nn.Parameter(torch.zeros_like(p)) for p in learner.policy.parameters()], lr=1.0)
     ref_opt.load_state_dict(osd)
+
+
+def test_shuffle_pipeline_is_transparent_on_the_device(golden, monkeypatch):
+    """The look-ahead shuffle pipeline (helper threads, own upload stream, ring of index vectors) must not change anything
+    observable: device index vectors == numpy's stream epoch by epoch, and learn() with look-ahead 3 ends in bit-identical
+    parameters to learn() with look-ahead 0, including across a buffer that grows between learn() calls (the speculation is
+    dropped) and a host-side epoch_indices() call in between."""
+    from rlgym_ppo_amd.ppo import ExperienceBuffer
+    g = golden("g5_learn_discrete")
+    cfg = json.loads(str(g["cfg"]))
+    names = ["states", "actions", "log_probs", "rewards", "next_states", "dones", "truncated", "values", "advantages"]
+    exp = [g["exp." + k] for k in names]
+
+    # 1. the device vectors are numpy's stream; a vector stays intact while later epochs are drawn and uploaded
+    monkeypatch.setenv("RLPPO_SHUFFLE_LOOKAHEAD", "3")
+    buf = ExperienceBuffer(1 << 20, 7, "cpu")
+    n = 300000
+    z = torch.zeros(n, device="cuda")
+    buf.submit_experience(torch.zeros(n, 4, device="cuda"), z, z, z, torch.zeros(n, 4, device="cuda"), z, z, z, z)
+    ref = np.random.RandomState(7)
+    for epoch in range(12):
+        dev = buf.epoch_indices_device()
+        got = dev.cpu().numpy()
+        assert np.array_equal(got, ref.permutation(n)), epoch
+    assert np.array_equal(buf.epoch_indices(), ref.permutation(n))       # host view of the same stream
+    assert buf.rng.randint(1 << 30) == ref.randint(1 << 30)              # foreign draw: speculation dropped
+    assert np.array_equal(buf.epoch_indices_device().cpu().numpy(), ref.permutation(n))
+
+    # 2. learn() is bit-identical with and without look-ahead
+    finals = []
+    for lookahead in ("0", "3"):
+        monkeypatch.setenv("RLPPO_SHUFFLE_LOOKAHEAD", lookahead)
+        learner = make_learner(cfg)
+        learner.n_epochs = 5
+        b = ExperienceBuffer(4 * cfg["n"], cfg["seed"], "cpu")
+        b.submit_experience(*exp)
+        learner.learn(b)
+        learner.learn(b)
+        b.submit_experience(*exp)                                        # the buffer grows: n changes
+        learner.learn(b)
+        b.epoch_indices()                                                # somebody else consumes an epoch
+        learner.learn(b)
+        torch.cuda.synchronize()
+        finals.append((learner.policy.arena.flat.clone(), learner.value_net.arena.flat.clone(), b.rng.get_state()[1].copy()))
+    assert torch.equal(finals[0][0], finals[1][0]) and torch.equal(finals[0][1], finals[1][1])
+    assert np.array_equal(finals[0][2], finals[1][2])

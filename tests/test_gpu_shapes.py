@@ -93,3 +93,23 @@ def test_obs_standardisation_fused_in_staging(L):
     ref = np.clip((obs - mean0) / std0, -5, 5)
     got = out.cpu().numpy()
     assert np.array_equal(got[:, :107], ref) and (got[:, 107:] == 0).all()
+
+
+def test_obs_standardisation_per_feature(L):
+    # rlppo_pad_rows_per_feature == np.clip((obs - mean) / std, -5, 5) with one (mean, std) per feature, f32 and f64 sources;
+    # through NetArena.stage_obs as the managers call it
+    rs = np.random.RandomState(5)
+    obs = (rs.randn(300, 107) * 4 + 1).astype(np.float32)
+    mean = rs.randn(107).astype(np.float32)
+    std = (rs.rand(107) * 3 + 0.1).astype(np.float32)
+    ref = np.clip((obs - mean) / std, -5, 5)
+    for is64, src in ((0, dev(obs)), (1, torch.as_tensor(obs.astype(np.float64)).cuda())):
+        out = torch.empty(300, 128, device="cuda")
+        check(L, L.rlppo_pad_rows_per_feature(stream(), P(src), is64, 300, 107, 107, P(out), 128, P(dev(mean)), P(dev(std))))
+        got = out.cpu().numpy()
+        assert np.array_equal(got[:, :107], ref) and (got[:, 107:] == 0).all()
+    assert L.rlppo_pad_rows_per_feature(stream(), P(src), 0, 300, 107, 107, P(out), 128, None, P(dev(std))) != 0
+    from rlgym_ppo_amd.ppo import ValueEstimator
+    arena = ValueEstimator(107, (32,), "cuda:0").arena
+    rows = arena.stage_obs(obs, (torch.from_numpy(mean), torch.from_numpy(std)))
+    assert np.array_equal(rows.cpu().numpy()[:, :107], ref)

@@ -15,14 +15,17 @@ import synthetic_env  # noqa: E402
 from oracle import host, nets  # noqa: E402
 
 
-@pytest.mark.parametrize("standardize", [True, False])
+@pytest.mark.parametrize("standardize", [True, False, "per_feature"])
 def test_vector_rollout_matches_trajectory_assembly(standardize):
+    per_feature = standardize == "per_feature"   # every feature with its own statistics (not the reference)
+    standardize = bool(standardize)
     from rlgym_ppo_amd.batched_agents import VectorAgentManager
     from rlgym_ppo_amd.ppo import DiscreteFF
     torch.manual_seed(11)
     pol = DiscreteFF(107, 90, (32, 32), "cuda:0")
     params = [(l.weight.detach().cpu(), l.bias.detach().cpu()) for l in pol.arena.linears]
     mgr = VectorAgentManager(pol, seed=5, standardize_obs=standardize)
+    mgr.per_feature_obs_standardization = per_feature
     d, n_act, code = mgr.init_processes(0, lambda: synthetic_env.SyntheticVectorEnv(seed=3))
     assert (d, n_act, code) == (107, 90, 0)
 
@@ -41,7 +44,7 @@ def test_vector_rollout_matches_trajectory_assembly(standardize):
         exp, _, n_col, _ = mgr.collect_timesteps(n_req)
         torch.manual_seed(100 + n_req)
         T = -(-n_req // 16)
-        ref, state = host.lockstep_rollout(reset_obs, step_fn, act_fn, T, standardize=standardize, state=state)
+        ref, state = host.lockstep_rollout(reset_obs, step_fn, act_fn, T, standardize=standardize, state=state, per_feature=per_feature)
         assert n_col == 16 * T and mgr.value_input_rows.shape[0] == n_col + 1
         states, actions, logp, rews, nxt, dones, trunc = [x.cpu().numpy() for x in exp]
         assert np.array_equal(actions, ref[1])                                  # action indices: exact

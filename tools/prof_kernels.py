@@ -23,7 +23,8 @@ C256, C96, C32 = (torch.empty(M, k, device=dev) for k in (256, 96, 32))
 idx = torch.randperm(M, device=dev)
 dW = torch.zeros(256 * 256, device=dev)
 db = torch.zeros(256, device=dev)
-tn_ws = torch.empty(int(L.rlppo_dbg_gemm_tn_workspace_bytes(256, 256, M)), dtype=torch.uint8, device=dev)
+tn_ws = torch.empty(max(int(L.rlppo_dbg_gemm_tn_workspace_bytes(o, i, M)) for o, i in ((256, 256), (256, 107), (90, 256))),
+                    dtype=torch.uint8, device=dev)  # too small a workspace silently selects the atomic form
 reps = int(os.environ.get("REPS", 3))
 for _ in range(reps):
     N.check(L.rlppo_dbg_gemm_nt(st(), P(A256), 256, None, P(W), 256, P(bias), None, 0, P(C256), 256, M, 256, 256, 1))
