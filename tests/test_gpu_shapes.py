@@ -103,12 +103,13 @@ def test_obs_standardisation_per_feature(L):
     mean = rs.randn(107).astype(np.float32)
     std = (rs.rand(107) * 3 + 0.1).astype(np.float32)
     ref = np.clip((obs - mean) / std, -5, 5)
+    mean_d, std_d = dev(mean), dev(std)   # kept alive: the library borrows the pointers
     for is64, src in ((0, dev(obs)), (1, torch.as_tensor(obs.astype(np.float64)).cuda())):
         out = torch.empty(300, 128, device="cuda")
-        check(L, L.rlppo_pad_rows_per_feature(stream(), P(src), is64, 300, 107, 107, P(out), 128, P(dev(mean)), P(dev(std))))
+        check(L, L.rlppo_pad_rows_per_feature(stream(), P(src), is64, 300, 107, 107, P(out), 128, P(mean_d), P(std_d)))
         got = out.cpu().numpy()
         assert np.array_equal(got[:, :107], ref) and (got[:, 107:] == 0).all()
-    assert L.rlppo_pad_rows_per_feature(stream(), P(src), 0, 300, 107, 107, P(out), 128, None, P(dev(std))) != 0
+    assert L.rlppo_pad_rows_per_feature(stream(), P(src), 0, 300, 107, 107, P(out), 128, None, P(std_d)) != 0
     from rlgym_ppo_amd.ppo import ValueEstimator
     arena = ValueEstimator(107, (32,), "cuda:0").arena
     rows = arena.stage_obs(obs, (torch.from_numpy(mean), torch.from_numpy(std)))
