@@ -269,3 +269,39 @@ def test_shuffle_pipeline_is_transparent_on_the_device(golden, monkeypatch):
         finals.append((learner.policy.arena.flat.clone(), learner.value_net.arena.flat.clone(), b.rng.get_state()[1].copy()))
     assert torch.equal(finals[0][0], finals[1][0]) and torch.equal(finals[0][1], finals[1][1])
     assert np.array_equal(finals[0][2], finals[1][2])
+
+
+def test_fused_minibatches_equal_separate_passes():
+    """PPOLearner evaluates consecutive minibatches of a batch in one pass (max_fused_minibatches): the reference sums the
+    MB/B-scaled minibatch gradients before one clip + Adam (ppo_learner.py:134-193), so the fused pass must give the same
+    gradient norm, the same parameters and the same report as eight separate passes, up to fp32 summation order."""
+    from rlgym_ppo_amd.ppo import ExperienceBuffer, PPOLearner
+    n, d, A, B, MB = 65536, 107, 90, 65536, 8192
+    rs = np.random.RandomState(3)
+    obs = np.clip(rs.randn(n, d), -5, 5).astype(np.float32)
+    res = []
+    for fused in (1, 8):
+        torch.manual_seed(3)
+        learner = PPOLearner(d, A, 0, (256, 256, 256), (256, 256, 256), (0.1, 1.0), B, 3, 3e-4, 3e-4, 0.2, 0.005, MB, "cuda:0")
+        learner.max_fused_minibatches = fused
+        if fused == 1:
+            noise = torch.as_tensor(np.random.RandomState(4).exponential(size=(n, A)).astype(np.float32))
+            act, logp = learner.policy.get_action(obs, noise=noise)
+            exp = (obs, act.numpy().astype(np.float32), logp.numpy() + 0.05 * rs.randn(n).astype(np.float32), np.zeros(n, np.float32),
+                   obs, np.zeros(n, np.float32), np.zeros(n, np.float32), rs.randn(n).astype(np.float32), rs.randn(n).astype(np.float32))
+        buf = ExperienceBuffer(n, 9, "cpu")
+        buf.submit_experience(*exp)
+        learner.n_epochs = 1
+        learner.learn(buf)                      # first optimiser step: identical parameters going in
+        gp, gv = learner.policy_optimizer.gnorm2.item(), learner.value_optimizer.gnorm2.item()
+        learner.n_epochs = 2
+        report = learner.learn(buf)
+        torch.cuda.synchronize()
+        res.append((learner.policy.arena.flat.clone(), learner.value_net.arena.flat.clone(), report, gp, gv))
+    (p1, v1, r1, gp1, gv1), (p8, v8, r8, gp8, gv8) = res
+    assert abs(gp8 - gp1) <= 1e-5 * gp1 and abs(gv8 - gv1) <= 1e-5 * gv1          # squared gradient norms of the first step
+    assert relerr(p8, p1) < 5e-5 and relerr(v8, v1) < 5e-5                        # 3 Adam steps amplify 1e-7 gradient noise
+    for k in ("Policy Entropy", "Mean KL Divergence", "Value Function Loss", "SB3 Clip Fraction", "Policy Update Magnitude",
+              "Value Function Update Magnitude"):
+        assert abs(r8[k] - r1[k]) <= 5e-5 * max(abs(r1[k]), 1e-3) + 1e-7, (k, r8[k], r1[k])
+    assert r8["Cumulative Model Updates"] == r1["Cumulative Model Updates"] == 3
