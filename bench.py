@@ -114,6 +114,7 @@ def kernel_breakdown(learner):
     P = lambda t: ctypes.c_void_p(t.data_ptr())
     A128 = torch.randn(M, 128, device=dev)
     A256 = torch.randn(M, 256, device=dev)
+    A256b = torch.randn(M, 256, device=dev)  # second operand of dW / mask of dX: distinct memory, as in the update
     A96 = torch.randn(M, 96, device=dev)
     A32 = torch.randn(M, 32, device=dev)
     W = torch.randn(256, 256, device=dev) * 0.05
@@ -140,9 +141,9 @@ def kernel_breakdown(learner):
         ("gemm_nt fwd L0 128->256 (x2 nets)", 2, nt(A128, 128, None, 128, C256, 256, 256, 128, 1), 2 * M * 256 * 128),
         ("gemm_nt fwd hidden 256->256 (x4)", 4, nt(A256, 256, None, 256, C256, 256, 256, 256, 1), 2 * M * 256 * 256),
         ("gemm_nt fwd head 256->96", 1, nt(A256, 256, None, 256, C96, 96, 96, 256, 0), 2 * M * 96 * 256),
-        ("gemm_nt dX hidden 256->256 mask (x4)", 4, nt(A256, 256, None, 256, C256, 256, 256, 256, 3, A256), 2 * M * 256 * 256),
-        ("gemm_nt dX head 96->256 mask", 1, nt(A96, 96, None, 96, C256, 256, 256, 96, 3, A256), 2 * M * 256 * 96),
-        ("gemm_tn dW hidden 256x256 (x4)", 4, tn(A256, 256, A256, 256, None, 256, 256), 2 * M * 256 * 256),
+        ("gemm_nt dX hidden 256->256 mask (x4)", 4, nt(A256, 256, None, 256, C256, 256, 256, 256, 3, A256b), 2 * M * 256 * 256),
+        ("gemm_nt dX head 96->256 mask", 1, nt(A96, 96, None, 96, C256, 256, 256, 96, 3, A256b), 2 * M * 256 * 96),
+        ("gemm_tn dW hidden 256x256 (x4)", 4, tn(A256, 256, A256b, 256, None, 256, 256), 2 * M * 256 * 256),
         ("gemm_tn dW L0 256x107 (x2)", 2, tn(A256, 256, A128, 128, None, 256, 107), 2 * M * 256 * 128),
         ("gemm_tn dW head 90x256", 1, tn(A96, 96, A256, 256, None, 90, 256), 2 * M * 128 * 256),
     ]
@@ -161,15 +162,17 @@ TRAFFIC_JSON = "r01_traffic_v8.json"  # tools/pmc_traffic.py output of the commi
 def pmc_traffic_for(kernel_label):
     """HBM bytes per launch of the dominant kernel, from the committed PMC passes (bench.py cannot run rocprofv3 on itself)."""
     path = os.path.join(ROOT, "profiles", TRAFFIC_JSON)
-    prefix = {"gemm_tn dW hidden 256x256 (x4)": "rlppo::gemm_tn_dma_kernel<32, true>",
-              "gemm_nt fwd hidden 256->256 (x4)": "rlppo::gemm_nt_dma_kernel<8, 1, 16>",
-              "gemm_nt dX hidden 256->256 mask (x4)": "rlppo::gemm_nt_dma_kernel<8, 3, 16>"}.get(kernel_label)
+    key = {"gemm_tn dW hidden 256x256 (x4)": "rlppo::gemm_tn_dma_kernel<32, true> {dW hidden 256x256}",
+           "gemm_tn dW L0 256x107 (x2)": "rlppo::gemm_tn_dma_kernel<32, true> {dW L0 256x107}",
+           "gemm_tn dW head 90x256": "rlppo::gemm_tn_dma_kernel<32, true> {dW head 90x256}",
+           "gemm_nt fwd hidden 256->256 (x4)": "rlppo::gemm_nt_dma_kernel<8, 1, 16>",
+           "gemm_nt fwd head 256->96": "rlppo::gemm_nt_dma_kernel<6, 0, 32>",
+           "gemm_nt dX hidden 256->256 mask (x4)": "rlppo::gemm_nt_dma_kernel<8, 3, 16>"}.get(kernel_label)
     try:
+        # tools/prof_kernels.py launches the same shapes as kernel_breakdown (M = 524,288 rows); tools/pmc_summary.py tells the
+        # three dW shapes (same kernel, same grid) apart by their position in the launch cycle
         t = json.load(open(path))
-        # tools/pmc_summary.py keys a kernel that ran with several grids as "name [grid N]": of one template, the hidden-layer
-        # launch is the one with the most traffic (tools/prof_kernels.py runs the same shapes as kernel_breakdown)
-        cand = [v["hbm_bytes"] for k, v in t.items() if k.startswith(prefix)]
-        return round(max(cand)), "profiles/" + TRAFFIC_JSON + " (tools/prof_kernels.py, same launch shape)"
+        return round(t[key]["hbm_bytes"]), "profiles/" + TRAFFIC_JSON + " (tools/prof_kernels.py, same launch shape)"
     except Exception:
         return None, "no committed PMC pass for this kernel"
 

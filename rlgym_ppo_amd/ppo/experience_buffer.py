@@ -100,7 +100,7 @@ class ExperienceBuffer(object):
     def epoch_indices(self):
         """The permutation of one epoch (host int64 array): RandomState.permutation(total_samples), consumed once
         per epoch from the persistent generator (experience_buffer.py:97-98)."""
-        return self._perm.permutation(len(self))
+        return self._perm.permutation(len(self)).copy()  # the pipeline's own vector is recycled two requests later
 
     def epoch_indices_device(self):
         """The same permutation as a device int64 vector, ordered on the current stream (uploaded by the shuffle pipeline
