@@ -368,6 +368,11 @@ def main():
                    "parallelism": f"dp{world}: {8 // world if 8 % world == 0 else 1} consecutive minibatch slice(s) per rank and pass, 1 RCCL all-reduce/optimiser step",
                    "last_report": {k: (round(v, 6) if isinstance(v, float) else v) for k, v in report.items()}},
     }
+    if world > 1 and args.config == "cfg2":  # achieved fraction of the MFMA roofline of the whole job (N x peak)
+        out["update_flop_efficiency"] = dict(
+            achieved=round(FLOP_PER_SAMPLE * value / 1e12, 2), peak=round(MFMA_F32_PEAK_TF * world, 1), unit="TFLOP/s",
+            frac=round(FLOP_PER_SAMPLE * value / 1e12 / (MFMA_F32_PEAK_TF * world), 4),
+            note="1,931,776 algorithmic flop/sample x measured whole-job samples/s against %d x the fp32 MFMA peak" % world)
     if args.config == "cfg5":
         fps = CFG5["flop_per_sample"]
         out["update_flop_efficiency"] = dict(achieved=round(fps * value / 1e12, 2), peak=MFMA_F32_PEAK_TF, unit="TFLOP/s",

@@ -528,6 +528,39 @@ def test_minibatch_full_size_cfg2(L):
     compare_minibatch(gp, gv, st, ref, tol=2e-5)
 
 
+def test_fused_pass_full_size_cfg2(L):
+    """The launch shape of the update at one GPU: ONE pass over the 8 minibatches of a batch = 524,288 rows (BASELINE configs[1]:
+    B = 524,288, MB = 65,536; PPOLearner.max_fused_minibatches).  Additivity at that size: the gradient and the report sums of
+    the fused pass equal those of its eight 65,536-row minibatches (mb_ratio 1/8 each) -- different row splits, XCD tile
+    orders, dW split sizes and partial-tile reductions must agree."""
+    torch.manual_seed(99)
+    pol = nets.init_mlp(107, (256, 256, 256), 90)
+    val = nets.init_mlp(107, (256, 256, 256), 1)
+    rs = np.random.RandomState(17)
+    n = 524288
+    obs = np.clip(rs.randn(n, 107), -5, 5).astype(np.float32)
+    with torch.no_grad():
+        act, logp = nets.discrete_sample(nets.discrete_probs(pol, obs), nets.draw_exp_noise(n, 90))
+    old = (logp + torch.as_tensor(rs.randn(n).astype(np.float32) * 0.2)).numpy()
+    adv = rs.randn(n).astype(np.float32)
+    tgt = rs.randn(n).astype(np.float32)
+    idx = rs.permutation(n)
+    gp, gv, st = run_minibatch(L, "discrete", pol, val, obs, act.numpy(), old, tgt, adv, idx, 0.2, 0.005, 1.0)
+    acc = [[torch.zeros_like(w, dtype=torch.float64), torch.zeros_like(b, dtype=torch.float64)] for w, b in gp + gv]
+    st_sum = np.zeros(5)
+    for j in range(8):
+        gpj, gvj, stj = run_minibatch(L, "discrete", pol, val, obs, act.numpy(), old, tgt, adv, idx[j * 65536:(j + 1) * 65536], 0.2,
+                                      0.005, 0.125)
+        for a, g in zip(acc, gpj + gvj):
+            a[0] += g[0].double()
+            a[1] += g[1].double()
+        st_sum += stj[:5]
+    for whole, parts in zip(gp + gv, acc):
+        for k in (0, 1):
+            assert relerr(whole[k], parts[k]) < 1e-5
+    np.testing.assert_allclose(st[:5], st_sum / 8, rtol=1e-5, atol=1e-8)
+
+
 def test_clip_adam_matches_oracle(L):
     torch.manual_seed(0)
     params = nets.init_mlp(20, (16,), 5)

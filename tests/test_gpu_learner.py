@@ -291,6 +291,7 @@ def test_fused_minibatches_equal_separate_passes():
                    obs, np.zeros(n, np.float32), np.zeros(n, np.float32), rs.randn(n).astype(np.float32), rs.randn(n).astype(np.float32))
         buf = ExperienceBuffer(n, 9, "cpu")
         buf.submit_experience(*exp)
+        p0, v0 = learner.policy.arena.flat.clone(), learner.value_net.arena.flat.clone()
         learner.n_epochs = 1
         learner.learn(buf)                      # first optimiser step: identical parameters going in
         gp, gv = learner.policy_optimizer.gnorm2.item(), learner.value_optimizer.gnorm2.item()
@@ -300,7 +301,12 @@ def test_fused_minibatches_equal_separate_passes():
         res.append((learner.policy.arena.flat.clone(), learner.value_net.arena.flat.clone(), report, gp, gv))
     (p1, v1, r1, gp1, gv1), (p8, v8, r8, gp8, gv8) = res
     assert abs(gp8 - gp1) <= 1e-5 * gp1 and abs(gv8 - gv1) <= 1e-5 * gv1          # squared gradient norms of the first step
-    assert relerr(p8, p1) < 5e-5 and relerr(v8, v1) < 5e-5                        # 3 Adam steps amplify 1e-7 gradient noise
+    # Adam's first steps are sign-like (m/sqrt(v) = g/|g|): an element whose gradient is within summation noise of zero can
+    # move by up to 2 lr either way, so the parameters are compared through the L2 distance of the three-step updates (a lost
+    # or double-counted slice changes the update by O(1) of its norm)
+    for a, b, o in ((p8, p1, p0), (v8, v1, v0)):
+        assert ((a - b).double().norm() / (b - o).double().norm()).item() < 2e-3
+        assert relerr(a, b) < 3 * 2 * 3e-4 / b.abs().max().item()
     for k in ("Policy Entropy", "Mean KL Divergence", "Value Function Loss", "SB3 Clip Fraction", "Policy Update Magnitude",
               "Value Function Update Magnitude"):
         assert abs(r8[k] - r1[k]) <= 5e-5 * max(abs(r1[k]), 1e-3) + 1e-7, (k, r8[k], r1[k])
