@@ -201,9 +201,20 @@ def gae_bench():
     trunc[ends[~is_done]] = 1
     d = lambda x: torch.as_tensor(x).cuda()
     R, D, T, V = d(rews), d(dones), d(trunc), d(values)
-    fn = lambda: torch_functions.gae_device(R, D, T, V, 0.99, 0.95, 1.7)
-    time_region(fn, 1, warm_s=0.3)  # clock ramp
     from rlgym_ppo_amd import _native as N
+    # the timed region is the entry point itself on preallocated outputs: torch_functions.gae_device allocates three output
+    # tensors per call (~15 us of Python on the host, about the duration of the scan it launches -- a host-bound measurement)
+    L = N.lib()
+    vt, adv, ret = (torch.empty(n, device="cuda") for _ in range(3))
+    ws = torch.empty(int(L.rlppo_gae_workspace_bytes(n)), dtype=torch.uint8, device="cuda")
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    cargs = [ctypes.c_void_p(t.data_ptr()) for t in (R, D, T, V)] + [n, 0.99, 0.95, float(np.float32(1.7))] + \
+            [ctypes.c_void_p(t.data_ptr()) for t in (vt, adv, ret, ws)] + [ws.numel()]
+    fn = lambda: N.check(L.rlppo_gae(st, *cargs))
+    fn()
+    chk = torch_functions.gae_device(R, D, T, V, 0.99, 0.95, 1.7)
+    assert all(torch.equal(a, b) for a, b in zip((vt, adv, ret), chk))
+    time_region(fn, 1, warm_s=0.3)  # clock ramp
     # A/B of the two implementations, interleaved in one process (cdna_hip_programming.md rule 24)
     times = {0: [], 1: []}
     for _ in range(5):

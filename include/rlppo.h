@@ -193,6 +193,41 @@ int rlppo_clip_adam(void *stream, float *params, float *grads, float *exp_avg, f
                     double max_norm, double lr, double beta1, double beta2, double eps, int64_t step,
                     double *gnorm2);
 
+/* The optimiser tail of one batch for BOTH networks in two launches (ppo_learner.py:187-193: clip_grad_norm_ x2,
+ * value_optimizer.step(), policy_optimizer.step()) + the re-packing rlppo_net_pack would do + the zero_grad of the next batch
+ * (ppo_learner.py:135-136): squared norms of both gradient arenas, then clip + Adam on both, every updated parameter written
+ * straight into its W / W^T / b slots of `packed` (which must already hold a full rlppo_net_pack image: the zero padding is not
+ * rewritten), gradients left ZERO.  Element for element the arithmetic of rlppo_clip_adam + rlppo_net_pack.  Used by
+ * PPOLearner.learn; FusedAdam.step() (the public optimiser API, gradients scaled in place) stays on rlppo_clip_adam. */
+typedef struct rlppo_opt_net {
+    const int32_t *dims;  /* layer widths, n_layers + 1 entries */
+    int32_t n_layers;
+    float *params, *grads, *exp_avg, *exp_avg_sq; /* flat arenas, rlppo_flat_floats entries */
+    float *packed;        /* rlppo_packed_floats entries */
+    double *gnorm2;       /* receives the squared gradient norm before clipping */
+    double max_norm, lr, beta1, beta2, eps;
+    int64_t step;         /* 1-based Adam step count of THIS update */
+} rlppo_opt_net;
+int rlppo_clip_adam_pack2(void *stream, const rlppo_opt_net *a, const rlppo_opt_net *b);
+
+/* ------------------------------------------------------------------------------------- data-parallel exchange */
+
+/* The one exchange step of the path: an in-place sum over the ranks of the flat
+ * [grad_policy | grad_value] arena, after a rank's last backward of a batch and before clip_grad_norm_ / Adam, which then
+ * run replicated (ppo_learner.py:187-193 sees the reduced gradients).  The reference is single-device and has no
+ * counterpart.  RCCL is loaded at run time (rlppo_comm_set_library(path) to name a particular librccl.so, e.g. PyTorch's
+ * own copy; default: the loader's "librccl.so").  One communicator per process (one process per GPU): rank 0 obtains
+ * the 128-byte id with rlppo_comm_unique_id and hands it to the other ranks by any host channel; every rank then calls
+ * rlppo_comm_init on the thread whose current device is its GPU.  rlppo_allreduce enqueues ncclAllReduce(sum) on the
+ * caller's stream (fp32, or fp64 for the report statistics) and returns without synchronising.  Errors: 2000 + ncclResult_t.
+ * rlgym_ppo_amd/dp.py uses these when RLPPO_RCCL_DIRECT=1 and torch.distributed's all_reduce otherwise. */
+#define RLPPO_COMM_ID_BYTES 128
+int rlppo_comm_set_library(const char *path);
+int rlppo_comm_unique_id(void *id128);
+int rlppo_comm_init(int32_t rank, int32_t world, const void *id128);
+int rlppo_allreduce(void *stream, void *buf, int64_t n, int32_t is_f64);
+int rlppo_comm_destroy(void);
+
 /* ----------------------------------------------------------------------------------------- host helpers */
 
 /* numpy.random.RandomState legacy stream (MT19937 + masked rejection + reverse Fisher-Yates): the index stream

@@ -12,6 +12,7 @@ from ctypes import POINTER, c_char_p, c_double, c_float, c_int32, c_int64, c_siz
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "librlppo.so")
 ABI_VERSION = 1
+COMM_ID_BYTES = 128  # RLPPO_COMM_ID_BYTES
 MAX_LAYERS = 16
 N_STATS = 8
 MAX_SLOTS = 8
@@ -21,6 +22,17 @@ HEAD_DISCRETE, HEAD_MULTIDISCRETE, HEAD_GAUSSIAN = 0, 1, 2
 
 class NativeLibraryMissing(RuntimeError):
     pass
+
+
+class OptNet(ctypes.Structure):
+    """struct rlppo_opt_net (include/rlppo.h)."""
+    _fields_ = [
+        ("dims", POINTER(c_int32)), ("n_layers", c_int32),
+        ("params", c_void_p), ("grads", c_void_p), ("exp_avg", c_void_p), ("exp_avg_sq", c_void_p),
+        ("packed", c_void_p), ("gnorm2", c_void_p),
+        ("max_norm", c_double), ("lr", c_double), ("beta1", c_double), ("beta2", c_double), ("eps", c_double),
+        ("step", c_int64),
+    ]
 
 
 class MinibatchArgs(ctypes.Structure):
@@ -68,6 +80,12 @@ SIGNATURES = {
     "rlppo_ppo_join": (c_int32, [c_void_p]),
     "rlppo_clip_adam": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_double, c_double,
                                   c_double, c_double, c_double, c_int64, c_void_p]),
+    "rlppo_clip_adam_pack2": (c_int32, [c_void_p, POINTER(OptNet), POINTER(OptNet)]),
+    "rlppo_comm_set_library": (c_int32, [ctypes.c_char_p]),
+    "rlppo_comm_unique_id": (c_int32, [c_void_p]),
+    "rlppo_comm_init": (c_int32, [c_int32, c_int32, c_void_p]),
+    "rlppo_allreduce": (c_int32, [c_void_p, c_void_p, c_int64, c_int32]),
+    "rlppo_comm_destroy": (c_int32, []),
     "rlppo_mt19937_seed": (c_int32, [POINTER(c_uint32), c_uint32]),
     "rlppo_mt19937_permutation": (c_int32, [POINTER(c_uint32), c_int64, c_void_p]),
     "rlppo_mt19937_draw_targets": (c_int32, [POINTER(c_uint32), c_int64, c_void_p]),
@@ -101,6 +119,16 @@ def lib():
             raise NativeLibraryMissing(
                 f"{LIB_PATH} not found. rlgym_ppo_amd has no CPU/PyTorch fallback: build the HIP library first "
                 f"(python -c 'import __graft_entry__ as g; g.build()' or make -C rlgym_ppo_amd/csrc).")
+        # Load order: PyTorch's HIP runtime first.  Seen on the GPU box: with librlppo.so loaded into a process before the
+        # first torch.cuda call (build() followed by smoke() in one process), every launch of this library failed with
+        # hipErrorNoDevice although torch itself worked; with the runtime initialised first it never does.  On a box without
+        # a GPU (the build check) there is nothing to initialise.
+        try:
+            import torch
+            if torch.cuda.is_available():
+                torch.cuda.init()
+        except Exception:  # noqa: BLE001 -- a CPU-only box: symbols and layouts can still be checked
+            pass
         L = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)  # AttributeError here == symbol missing == broken build

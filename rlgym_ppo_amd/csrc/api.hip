@@ -522,6 +522,34 @@ int rlppo_clip_adam(void *stream, float *params, float *grads, float *exp_avg, f
                             (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps, gnorm2);
 }
 
+int rlppo_clip_adam_pack2(void *stream, const rlppo_opt_net *a, const rlppo_opt_net *b) {
+    RLPPO_CHECK_ARG(a && b, "clip_adam_pack2: null descriptor");
+    const rlppo_opt_net *d[2] = {a, b};
+    NetLayout nets[2];
+    float *p[2], *g[2], *m[2], *v[2], *packed[2];
+    double *gn[2];
+    int64_t n[2];
+    float max_norm[2], step_size[2], bc2_sqrt[2], omb1[2], beta2[2], omb2[2], eps[2];
+    for (int k = 0; k < 2; ++k) {
+        int rc = make_layout(d[k]->dims, d[k]->n_layers, &nets[k]);
+        if (rc) return rc;
+        RLPPO_CHECK_ARG(d[k]->params && d[k]->grads && d[k]->exp_avg && d[k]->exp_avg_sq && d[k]->packed && d[k]->gnorm2 &&
+                            d[k]->step >= 1, "clip_adam_pack2: bad argument (net %d)", k);
+        // torch/optim/adam.py (_single_tensor_adam): python-double scalars, cast to fp32 where they meet a tensor
+        const double bc1 = 1.0 - pow(d[k]->beta1, (double)d[k]->step);
+        const double bc2 = 1.0 - pow(d[k]->beta2, (double)d[k]->step);
+        p[k] = d[k]->params; g[k] = d[k]->grads; m[k] = d[k]->exp_avg; v[k] = d[k]->exp_avg_sq; packed[k] = d[k]->packed;
+        gn[k] = d[k]->gnorm2;
+        const LayerLayout &last = nets[k].L[nets[k].n_layers - 1];
+        n[k] = last.off_flat_b + last.out;  // = rlppo_flat_floats
+        max_norm[k] = (float)d[k]->max_norm; step_size[k] = (float)(d[k]->lr / bc1); bc2_sqrt[k] = (float)sqrt(bc2);
+        omb1[k] = (float)(1.0 - d[k]->beta1); beta2[k] = (float)d[k]->beta2; omb2[k] = (float)(1.0 - d[k]->beta2);
+        eps[k] = (float)d[k]->eps;
+    }
+    return launch_clip_adam_pack2((hipStream_t)stream, nets, p, g, m, v, packed, gn, n, max_norm, step_size, bc2_sqrt, omb1, beta2,
+                                  omb2, eps);
+}
+
 }  // extern "C"
 
 // ------------------------------------------------------------------------------------------ diagnostics

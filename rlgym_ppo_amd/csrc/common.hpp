@@ -28,6 +28,16 @@ void set_error(const char *fmt, ...);
     } while (0)
 
 #define RLPPO_LAUNCH_CHECK() RLPPO_HIP(hipGetLastError())
+// hipGetLastError() is per thread and sticky across libraries: an error another library left unread on this thread (seen on
+// the GPU box: PyTorch's device probing leaves hipErrorNoDevice behind when this library was loaded before the first
+// torch.cuda call) would be reported by the check after our next launch.  Every launch therefore clears the thread's
+// error state first, so RLPPO_LAUNCH_CHECK only ever sees the result of the launch in front of it.
+#undef hipLaunchKernelGGL
+#define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...)        \
+    do {                                                                   \
+        (void)hipGetLastError();                                           \
+        kernel<<<(grid), (block), (shmem), (stream)>>>(__VA_ARGS__);       \
+    } while (0)
 
 static inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
 static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
@@ -73,6 +83,10 @@ struct LossCfg {
 };
 
 int launch_pack(hipStream_t, const NetLayout &, const float *, float *);
+int launch_clip_adam_pack2(hipStream_t st, const NetLayout *nets, float *const *p, float *const *g, float *const *m, float *const *v,
+                           float *const *packed, double *const *gnorm2, const int64_t *n, const float *max_norm,
+                           const float *step_size, const float *bc2_sqrt, const float *omb1, const float *beta2, const float *omb2,
+                           const float *eps);
 int launch_welford(hipStream_t st, const float *x, int64_t ld, int64_t n, int d, float *mean, float *m2, long long count0);
 int launch_gather_rows(hipStream_t st, const float *src, int64_t ld_src, const int64_t *idx, float *dst, int width, int64_t n);
 int launch_pad_rows(hipStream_t, const void *, int, int64_t, int64_t, int64_t, float *, int64_t, int, float, float);

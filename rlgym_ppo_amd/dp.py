@@ -38,11 +38,45 @@ def fuse_runs(slices, max_fused):
     return [(slices[i], k) for i in range(0, n, k)]
 
 
+_direct = {"state": None}  # None = undecided, False = torch.distributed, True = librlppo's own RCCL communicator
+
+
+def _direct_comm(dist):
+    """RLPPO_RCCL_DIRECT=1: sum through rlppo_allreduce (RCCL enqueued on the caller's stream by librlppo itself, include/rlppo.h)
+    instead of torch.distributed's all_reduce.  Opt-in: the default keeps the collective in torch.distributed, which is what
+    the multi-process tests cover (gloo on the CPU; RCCL refuses two ranks on one GPU, so a one-GPU box can only exercise the
+    one-rank communicator)."""
+    if _direct["state"] is None:
+        import os
+        on = os.environ.get("RLPPO_RCCL_DIRECT") == "1" and dist.get_backend() == "nccl"
+        if on:
+            import ctypes
+            from . import _native as N
+            L = N.lib()
+            rccl = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+            if os.path.exists(rccl):  # the copy PyTorch already holds: one RCCL instance per process
+                N.check(L.rlppo_comm_set_library(rccl.encode()))
+            ident = ctypes.create_string_buffer(N.COMM_ID_BYTES)
+            if dist.get_rank() == 0:
+                N.check(L.rlppo_comm_unique_id(ident))
+            box = [ident.raw]
+            dist.broadcast_object_list(box, src=0)
+            N.check(L.rlppo_comm_init(dist.get_rank(), dist.get_world_size(), ctypes.c_char_p(box[0])))
+        _direct["state"] = on
+    return _direct["state"]
+
+
 def all_reduce_sum(tensor, dist=None):
     """In-place sum over ranks of one flat buffer ([grad_policy | grad_value]: 1.37 MB for the 256x3 nets -- latency
     bound, so exactly one collective per optimiser step)."""
     if dist is None:
         dist, _, _ = dist_info()
     if dist is not None:
-        dist.all_reduce(tensor, op=dist.ReduceOp.SUM)
+        if _direct_comm(dist) and tensor.is_cuda and tensor.is_contiguous() and tensor.dtype in (torch.float32, torch.float64):
+            import ctypes
+            from . import _native as N
+            N.check(N.lib().rlppo_allreduce(ctypes.c_void_p(torch.cuda.current_stream().cuda_stream), ctypes.c_void_p(tensor.data_ptr()),
+                                            tensor.numel(), int(tensor.dtype == torch.float64)))
+        else:
+            dist.all_reduce(tensor, op=dist.ReduceOp.SUM)
     return tensor

@@ -109,6 +109,11 @@ class NetArena:
             N.check(N.lib().rlppo_net_pack(stream_ptr(), self.dims_c, self.n_layers, ptr(self.flat), ptr(self.packed)))
             self._packed_key = key
 
+    def mark_repacked(self):
+        """A kernel has just updated `flat` AND written the new values into `packed` (rlppo_clip_adam_pack2)."""
+        self.native_epoch += 1
+        self._packed_key = (self.flat._version, self.native_epoch)
+
     # ------------------------------------------------------------------------------------------ inference
     def stage_obs(self, obs, standardize=None, out=None):
         """numpy / tensor observations of any float dtype -> zero-padded fp32 device rows [n, ld_in]

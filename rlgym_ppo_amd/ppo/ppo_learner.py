@@ -70,6 +70,23 @@ class FusedAdam(torch.optim.Adam):
                                         float(b2), float(g["eps"]), self.step_count, ptr(self.gnorm2)))
         self.arena.native_epoch += 1
 
+    def fused_descriptor(self, max_norm):
+        """rlppo_opt_net of THIS update (advances the step count): one half of rlppo_clip_adam_pack2."""
+        g = self.param_groups[0]
+        a = self.arena
+        if not a.is_bound():
+            a.bind()
+        self.step_count += 1
+        b1, b2 = g["betas"]
+        d = N.OptNet()
+        d.dims, d.n_layers = ctypes.cast(a.dims_c, ctypes.POINTER(ctypes.c_int32)), a.n_layers
+        d.params, d.grads = a.flat.data_ptr(), a.grad.data_ptr()
+        d.exp_avg, d.exp_avg_sq = self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr()
+        d.packed, d.gnorm2 = a.packed.data_ptr(), self.gnorm2.data_ptr()
+        d.max_norm = float("inf") if max_norm is None else float(max_norm)
+        d.lr, d.beta1, d.beta2, d.eps, d.step = float(g["lr"]), float(b1), float(b2), float(g["eps"]), self.step_count
+        return d
+
     def state_dict(self):
         if self.step_count > 0:
             self._expose_state()
@@ -156,6 +173,7 @@ class PPOLearner(object):
         # (mb = k MB rows, mb_ratio = k MB / B): the same gradient and the same report means up to fp32 summation order,
         # in launches that are k times larger.  RLPPO_FUSE=1 keeps one pass per minibatch.
         self.max_fused_minibatches = max(1, int(os.environ.get("RLPPO_FUSE", 8)))
+        self.fused_optimizer_step = os.environ.get("RLPPO_FUSED_OPT", "1") != "0"  # rlppo_clip_adam_pack2 (False: FusedAdam.step x2)
 
     # --------------------------------------------------------------------------------------------- learn
     def _minibatch_args(self, exp):
@@ -218,10 +236,13 @@ class PPOLearner(object):
             # stream (engine.LegacyPermutation / DeviceIndexRing): here an epoch only orders the stream after that copy.
             # With 8 ranks the GPU share of an epoch is ~1.1 ms; the serial stream phase (~0.8 ms per 512k indices) is
             # the only part of the shuffle that cannot be spread over threads.
+            grads_zero = False
             for epoch in range(self.n_epochs):
                 idx_dev = exp.epoch_indices_device()
                 for b in range(n_batches):
-                    self._grad_all.zero_()
+                    if not grads_zero:
+                        self._grad_all.zero_()
+                    grads_zero = False
                     pa.ensure_packed()
                     va.ensure_packed()
                     for k, (j, cnt) in enumerate(fuse_runs(slices_for_rank(n_slices, rank, world), self.max_fused_minibatches)):
@@ -237,8 +258,18 @@ class PPOLearner(object):
                     n_minibatch_iterations += n_slices
                     if dist is not None:
                         all_reduce_sum(self._grad_all, dist)  # RCCL over xGMI, before clipping
-                    self.value_optimizer.step(max_norm=MAX_GRAD_NORM)
-                    self.policy_optimizer.step(max_norm=MAX_GRAD_NORM)
+                    if self.fused_optimizer_step:
+                        # both clip + Adam steps, the re-pack of both weight copies and the next batch's zero_grad: 3 stream
+                        # operations instead of 9 (csrc/optim.hip)
+                        dv = self.value_optimizer.fused_descriptor(MAX_GRAD_NORM)
+                        dp_ = self.policy_optimizer.fused_descriptor(MAX_GRAD_NORM)
+                        N.check(L.rlppo_clip_adam_pack2(st, ctypes.byref(dv), ctypes.byref(dp_)))
+                        va.mark_repacked()
+                        pa.mark_repacked()
+                        grads_zero = True
+                    else:
+                        self.value_optimizer.step(max_norm=MAX_GRAD_NORM)
+                        self.policy_optimizer.step(max_norm=MAX_GRAD_NORM)
                     n_iterations += 1
         else:
             for _ in range(self.n_epochs):

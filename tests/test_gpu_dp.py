@@ -70,3 +70,33 @@ def test_two_ranks_equal_one_rank():
             assert abs(report[k] - ref_report[k]) <= 2e-5 * max(abs(ref_report[k]), 1e-3) + 1e-7, (k, report[k], ref_report[k])
         assert report["Cumulative Model Updates"] == ref_report["Cumulative Model Updates"] == 4
     assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1])  # replicas stay bit-identical
+
+
+def test_direct_rccl_entry_points_one_rank():
+    """rlppo_comm_unique_id / rlppo_comm_init / rlppo_allreduce / rlppo_comm_destroy with a one-rank communicator
+    (RCCL refuses two ranks on one GPU): fp32 and fp64 buffers come back unchanged, stream-ordered behind the kernel that wrote
+    them; errors are reported through the status code."""
+    import ctypes
+    from rlgym_ppo_amd import _native as N
+    L = N.lib()
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    buf = torch.zeros(8, device="cuda")
+    assert L.rlppo_allreduce(st, ctypes.c_void_p(buf.data_ptr()), 8, 0) != 0          # no communicator yet
+    rccl = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+    if os.path.exists(rccl):
+        N.check(L.rlppo_comm_set_library(rccl.encode()))
+    ident = ctypes.create_string_buffer(N.COMM_ID_BYTES)
+    N.check(L.rlppo_comm_unique_id(ident))
+    assert L.rlppo_comm_init(1, 1, ident) != 0                                         # rank out of range
+    N.check(L.rlppo_comm_init(0, 1, ident))
+    assert L.rlppo_comm_init(0, 1, ident) != 0                                         # one communicator per process
+    g = torch.randn(341851, device="cuda")
+    ref = g.clone()
+    g.mul_(2.0)
+    N.check(L.rlppo_allreduce(st, ctypes.c_void_p(g.data_ptr()), g.numel(), 0))
+    s = torch.arange(8, dtype=torch.float64, device="cuda")
+    N.check(L.rlppo_allreduce(st, ctypes.c_void_p(s.data_ptr()), 8, 1))
+    torch.cuda.synchronize()
+    assert torch.equal(g, ref * 2.0) and torch.equal(s.cpu(), torch.arange(8, dtype=torch.float64))
+    N.check(L.rlppo_comm_destroy())
+    N.check(L.rlppo_comm_destroy())                                                    # idempotent
