@@ -277,6 +277,7 @@ int rlppo_set_inference_precision(int32_t mode);
  *  14 value loss launched in the critic's chain, no join between forward and backward [1] | one joint loss kernel [0]
  *  15 one-output (critic) head as matrix-vector kernels [1] | through the padded GEMM kernels [0]
  *  16 dW through partial tiles + a reduction kernel [1] | fp32 atomics [0]
+ *  17 gemm_nt with persistent workgroups when a launch has more tiles than resident slots [0]
  *  18 GAE chunks per workgroup [1] */
 int rlppo_dbg_set(int32_t key, int32_t value);
 /* Register-only fp32 MFMA loop: out[blocks*256] floats, clocks[2*blocks] = {shader cycles, 100 MHz ticks} per block. */

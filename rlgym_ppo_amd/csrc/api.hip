@@ -636,6 +636,10 @@ int rlppo_dbg_set(int32_t key, int32_t value) {
         set_tn_partial(value);
         return 0;
     }
+    if (key == 17) {
+        set_nt_persist(value);
+        return 0;
+    }
     if (key == 18) {
         set_gae_grid_div(value);
         return 0;

@@ -353,6 +353,149 @@ __global__ __launch_bounds__(256, BKT == 16 ? 4 : 2) void gemm_nt_dma_kernel(con
     nt_epilogue<NB, EPI>(acc, mask_src, ldm_b, C, ldc_b, m0, n0, rows_here, wave, r16, q);
 }
 
+// ------------------------------------------------------------------------------------------------ gemm_nt, persistent form
+// The same tile loop as gemm_nt_dma_kernel, but a workgroup walks over several output tiles (ids w, w + G, w + 2G, ... with
+// G = the number of resident workgroup slots) instead of being re-dispatched for each: at M = 524,288 a launch is 8 rounds of
+// 1024 workgroups, and each turnover costs a dispatch, the descriptor set-up and an exposed first DMA (the difference between
+// the 54.6 us of MFMA work a tile has at a quarter of a CU and the 66 us a workgroup actually lives).  Here the first K tile
+// of the NEXT output tile is requested during the last K step of the current one, so the epilogue (activation + 16-byte
+// stores) overlaps that DMA; the only per-tile serialisation left is the wait for the stores to be acknowledged before the
+// accumulators are re-initialised (the store-data hazard of section 5 -- the registers must not be rewritten while a store
+// may still read them).  Tile ids keep the XCD-aware order of xcd_tile: ids are congruent mod 8 with the workgroup id, so a
+// workgroup's tiles stay on its XCD and the column tiles of a row tile are worked on in the same round.
+template <int NB, int EPI, int BKT>
+__global__ __launch_bounds__(256, BKT == 16 ? 4 : 2) void gemm_nt_dma_persist_kernel(const float *__restrict__ A, unsigned lda_b,
+                                                                                      const float *__restrict__ B, unsigned ldb_b,
+                                                                                      const float *__restrict__ bias,
+                                                                                      const float *__restrict__ mask_src,
+                                                                                      unsigned ldm_b, float *__restrict__ C,
+                                                                                      unsigned ldc_b, int64_t M, int K,
+                                                                                      int row_tiles, int col_tiles) {
+    constexpr int BN = NB * 16;
+    constexpr int CPR = BKT / 4;
+    constexpr int RPW = 64 / CPR;
+    constexpr int RPP = 4 * RPW;
+    constexpr int A_IT = SBM / RPP, B_IT = BN / RPP;
+    static_assert(BN % RPP == 0, "column tile must be a whole number of staging passes");
+    __shared__ __attribute__((aligned(16))) float lds[2 * SBM * BKT + 2 * BN * BKT];
+    float *As = lds;
+    float *Bs = lds + 2 * SBM * BKT;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const int r16 = lane & 15, q = lane >> 4;
+    const int tiles = row_tiles * col_tiles;
+    const bool xcd = (row_tiles & 7) == 0 && col_tiles > 1;
+    auto tile_of = [&](int id, int &rt, int &ct) {
+        if (xcd) {
+            const int g = id % (8 * col_tiles);
+            rt = (id / (8 * col_tiles)) * 8 + (g & 7);
+            ct = g >> 3;
+        } else {
+            rt = id % row_tiles;
+            ct = id / row_tiles;
+        }
+    };
+    const int row_p = wave * RPW + lane / CPR, pch = lane % CPR;
+    const int lch = BKT == 32 ? (pch ^ (row_p & 7)) : (pch ^ ((0 - (row_p >> 2)) & 3));
+    const unsigned a_off = (unsigned)row_p * lda_b + lch * 16;
+    const unsigned b_off = (unsigned)row_p * ldb_b + lch * 16;
+    const unsigned a_step = (unsigned)RPP * lda_b, b_step = (unsigned)RPP * ldb_b;
+
+    auto issue_tile = [&](__amdgpu_buffer_rsrc_t a_rs, __amdgpu_buffer_rsrc_t b_rs, int buf, unsigned kb) {
+        float *Ad = As + buf * SBM * BKT + wave_u * RPW * BKT;
+        float *Bd = Bs + buf * BN * BKT + wave_u * RPW * BKT;
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rs, Ad + i * RPP * BKT, 16, a_off, kb + i * a_step, 0, 0);
+#pragma unroll
+        for (int i = 0; i < B_IT; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(b_rs, Bd + i * RPP * BKT, 16, b_off, kb + i * b_step, 0, 0);
+    };
+    auto a_desc = [&](int64_t m0, int rows_here) {
+        return make_rsrc(reinterpret_cast<const char *>(A) + m0 * lda_b, (unsigned)(rows_here - 1) * lda_b + (unsigned)K * 4);
+    };
+    auto b_desc = [&](int n0) {
+        return make_rsrc(reinterpret_cast<const char *>(B) + (int64_t)n0 * ldb_b, (unsigned)(BN - 1) * ldb_b + (unsigned)K * 4);
+    };
+
+    const int nk = K / BKT;
+    int t = blockIdx.x;  // < tiles (host)
+    int rt, ct;
+    tile_of(t, rt, ct);
+    int64_t m0 = (int64_t)rt * SBM;
+    int n0 = ct * BN;
+    int rows_here = (int)((M - m0) < SBM ? (M - m0) : SBM);
+    __amdgpu_buffer_rsrc_t a_rs = a_desc(m0, rows_here), b_rs = b_desc(n0);
+    issue_tile(a_rs, b_rs, 0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int par = 0;  // LDS buffer that holds the current K tile
+    for (;;) {
+        f32x4 acc[2][NB];
+        if (EPI == EPI_MASK) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < NB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        } else {
+            const __amdgpu_buffer_rsrc_t bias_rs = make_rsrc(bias + n0, BN * 4);
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                acc[0][j] = ldb(bias_rs, (unsigned)(q * 16), j * 64);
+                acc[1][j] = acc[0][j];
+            }
+        }
+        const int tn = t + (int)gridDim.x;
+        const bool has_next = tn < tiles;
+        int rt2 = rt, ct2 = ct;
+        if (has_next) tile_of(tn, rt2, ct2);
+        const int64_t m0n = (int64_t)rt2 * SBM;
+        const int n0n = ct2 * BN;
+        const int rows_n = (int)((M - m0n) < SBM ? (M - m0n) : SBM);
+        const __amdgpu_buffer_rsrc_t a_nx = a_desc(m0n, rows_n), b_nx = b_desc(n0n);
+        for (int kt = 0; kt < nk; ++kt) {
+            if ((kt + 1) < nk)
+                issue_tile(a_rs, b_rs, par ^ 1, (unsigned)(kt + 1) * (BKT * 4));
+            else if (has_next)
+                issue_tile(a_nx, b_nx, par ^ 1, 0);  // the next output tile's first K tile, behind this tile's last MFMAs
+            const float *Ac = As + par * SBM * BKT + (wave * 32) * BKT;
+            const float *Bc = Bs + par * BN * BKT;
+#pragma unroll
+            for (int kc = 0; kc < BKT / 16; ++kc) {
+                f32x4 fa[2], fb[NB];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) fa[i] = *reinterpret_cast<const f32x4 *>(&Ac[dswz<BKT>(i * 16 + r16, kc * 4 + q)]);
+#pragma unroll
+                for (int j = 0; j < NB; ++j) fb[j] = *reinterpret_cast<const f32x4 *>(&Bc[dswz<BKT>(j * 16 + r16, kc * 4 + q)]);
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < NB; ++j) acc[i][j] = MFMA16(fb[j][s], fa[i][s], acc[i][j]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            par ^= 1;
+        }
+        nt_epilogue<NB, EPI>(acc, mask_src, ldm_b, C, ldc_b, m0, n0, rows_here, wave, r16, q);
+        if (!has_next) break;
+        // the accumulators are rewritten next: every store that reads them must have left the registers
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        t = tn;
+        rt = rt2;
+        ct = ct2;
+        m0 = m0n;
+        n0 = n0n;
+        rows_here = rows_n;
+        a_rs = a_nx;
+        b_rs = b_nx;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ gemm_nt, bf16 operands
 // Inference-only forward (BASELINE configs[4]: "bf16 fwd / fp32 master weights"): the fp32 activations and the fp32 master
 // weights are staged exactly as in gemm_nt_dma_kernel (fp32 tiles in LDS), rounded to bf16 when a lane builds its MFMA
@@ -463,6 +606,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf16_kernel(const float *__res
     nt_epilogue<NB, EPI>(acc, mask_src, ldm_b, C, ldc_b, m0, n0, rows_here, wave, r16, q);
 }
 
+static int g_nt_persist = 0;  // tuning: rlppo_dbg_set(17, 0/1): persistent workgroups when a launch has more tiles than slots
+void set_nt_persist(int v) { g_nt_persist = v; }
 static int g_nt_sa = 3;  // tuning: rlppo_dbg_set(9, v): 0 gemm.hip kernel, 1 register-staged, 2 LDS-DMA BK=32, 3 LDS-DMA BK=16
 static int g_tn_sa = 2;  // tuning: rlppo_dbg_set(10, v): 0 gemm.hip kernel, 1 register-staged, 2 LDS-DMA 32-row stages, 3 16-row stages
 void set_nt_sa(int v) { g_nt_sa = v; }
@@ -474,9 +619,15 @@ static int launch_sa_1(hipStream_t st, dim3 grid, int epi, const float *A, unsig
                        int K) {
     constexpr bool can16 = (NB * 16) % 64 == 0;  // BK = 16 fills 64 tile rows per pass
     const int variant = (g_nt_sa == 3 && !can16) ? 2 : g_nt_sa;
+    // persistent form: one workgroup per resident slot (256 CUs x 4 or 2 per CU), only when a launch has more tiles than that
+    const unsigned slots = 256u * (can16 ? 4u : 2u);
+    const bool persist = g_nt_persist && (uint64_t)grid.x * grid.y > slots && (uint64_t)grid.x * grid.y < (1u << 30);
 #define SA(E)                                                                                                          \
     case E:                                                                                                            \
-        if (variant == 3)                                                                                              \
+        if (variant == 3 && persist && E != EPI_BIAS_TANH) /* the tanh epilogue spills in the persistent form */       \
+            hipLaunchKernelGGL((gemm_nt_dma_persist_kernel<NB, E, can16 ? 16 : 32>), dim3(slots), dim3(256), 0, st, A,  \
+                               lda_b, B, ldb_b, bias, mask_src, ldm_b, C, ldc_b, M, K, (int)grid.x, (int)grid.y);      \
+        else if (variant == 3)                                                                                         \
             hipLaunchKernelGGL((gemm_nt_dma_kernel<NB, E, can16 ? 16 : 32>), grid, dim3(256), 0, st, A, lda_b, B,      \
                                ldb_b, bias, mask_src, ldm_b, C, ldc_b, M, K);                                          \
         else if (variant == 2)                                                                                         \

@@ -76,6 +76,31 @@ def test_gemm_nt(L, M, N, K, epi, gather):
     assert relerr(C, ref) < (5e-6 if epi == 2 else 2e-6)
 
 
+def test_gemm_nt_persistent_form_is_bitwise_equal(L):
+    """RLPPO_TUNE key 17: workgroups that walk over several output tiles (launches with more tiles than resident slots) run
+    the same arithmetic in the same order as the one-tile-per-workgroup kernel: outputs must be bit-identical, including the
+    ragged last row tile, for the forward (bias + ReLU), head (bias, 96 columns) and masked (dX) epilogues."""
+    torch.manual_seed(5)
+    M = 131072 + 5
+    A256, Mk, A96 = (torch.randn(M, k, device="cuda") for k in (256, 256, 96))
+    W = torch.randn(256, 256, device="cuda") * 0.05
+    b = torch.randn(256, device="cuda")
+    try:
+        for Am, K, n, epi in ((A256, 256, 256, 1), (A256, 256, 96, 0), (A256, 256, 256, 3), (A96, 96, 256, 3)):
+            outs = []
+            for persist in (0, 1):
+                check(L, L.rlppo_dbg_set(17, persist))
+                C = torch.full((M, n), -7.0, device="cuda")
+                check(L, L.rlppo_dbg_gemm_nt(stream(), P(Am), K, None, P(W), K, P(b) if epi != 3 else None,
+                                             P(Mk) if epi == 3 else None, 256 if epi == 3 else 0, P(C), n, M, n, K, epi))
+                outs.append(C)
+            torch.cuda.synchronize()
+            assert torch.equal(outs[0], outs[1]), (K, n, epi)
+            assert not (outs[1] == -7.0).any()
+    finally:
+        check(L, L.rlppo_dbg_set(17, 0))
+
+
 @pytest.mark.parametrize("M,out,in_,gather", [(1000, 256, 107, True), (4096, 256, 256, False), (33, 90, 256, False),
                                               (2500, 1, 256, False), (1, 21, 32, False), (3000, 512, 231, True)])
 def test_gemm_tn(L, M, out, in_, gather):
