@@ -278,7 +278,8 @@ int rlppo_set_inference_precision(int32_t mode);
  *  15 one-output (critic) head as matrix-vector kernels [1] | through the padded GEMM kernels [0]
  *  16 dW through partial tiles + a reduction kernel [1] | fp32 atomics [0]
  *  17 gemm_nt with persistent workgroups when a launch has more tiles than resident slots [0]
- *  18 GAE chunks per workgroup [1] */
+ *  18 GAE chunks per workgroup [1]
+ *  19 ReLU bitmask written by the hidden-layer forward and read by the masked dX product [1] | dX re-reads the activation [0] */
 int rlppo_dbg_set(int32_t key, int32_t value);
 /* Register-only fp32 MFMA loop: out[blocks*256] floats, clocks[2*blocks] = {shader cycles, 100 MHz ticks} per block. */
 /* GEMM inner-loop probe: 64 MFMAs per chunk + (mode&1) A fragments from LDS, (mode&2) B fragments from LDS, (mode&4) B
@@ -290,6 +291,11 @@ int rlppo_dbg_probe_ld(void *stream, int32_t pattern, int32_t blocks, const void
  * cycles each batch took to issue -> cycles[wave][2] = {issue, total}.  buf >= 16 MiB, out >= 512*256 floats. */
 int rlppo_dbg_probe_coissue(void *stream, const float *buf, int32_t flags, int32_t iters, uint64_t *cycles, float *out);
 int rlppo_dbg_probe2(void *stream, int32_t mode, int32_t threads, int32_t blocks, const float *W, float *out, int32_t chunks);
+/* The bitmask form of the hidden-layer forward (epilogue 1: C = relu(A.B^T + bias), bits <- [C > 0], 8 bytes per lane and
+ * 128 x 128 tile) and of the masked dX product (epilogue 3: C = (A.B^T) masked by bits).  N % 128 == 0. */
+size_t rlppo_dbg_gemm_nt_bits_bytes(int64_t M, int32_t N);
+int rlppo_dbg_gemm_nt_bits(void *stream, const float *A, int64_t lda, const float *B, int64_t ldb, const float *bias, float *C,
+                           int64_t ldc, int64_t M, int32_t N, int32_t K, int32_t epilogue, void *bits);
 /* Stamped copy of the staged forward GEMM (bias+ReLU, N % 128 == 0): stamps[wg][wave][8] cycles per phase (csrc/probe.hip). */
 int rlppo_dbg_gemm_nt_stamped(void *stream, const float *A, int64_t lda, const float *B, int64_t ldb, const float *bias,
                                 float *C, int64_t ldc, int64_t M, int32_t N, int32_t K, uint64_t *stamps, int32_t mode);

@@ -102,6 +102,9 @@ SIGNATURES = {
     "rlppo_dbg_mfma_probe": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_void_p]),
     "rlppo_dbg_gemm_nt": (c_int32, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_void_p,
                                     c_int64, c_void_p, c_int64, c_int64, c_int32, c_int32, c_int32]),
+    "rlppo_dbg_gemm_nt_bits_bytes": (c_size_t, [c_int64, c_int32]),
+    "rlppo_dbg_gemm_nt_bits": (c_int32, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int64,
+                                         c_int32, c_int32, c_int32, c_void_p]),
     "rlppo_dbg_gemm_tn": (c_int32, [c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_int64, c_void_p, c_int32,
                                     c_void_p, c_void_p, c_int32, c_int32, c_int64]),
     "rlppo_dbg_gemm_tn_workspace_bytes": (c_size_t, [c_int32, c_int32, c_int64]),

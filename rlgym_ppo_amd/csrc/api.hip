@@ -64,8 +64,13 @@ static int max_pout(const NetLayout &net) {
 
 // Forward pass.  acts[l] receives the output of layer l ([n][pout_l]); for inference the caller passes two
 // ping-pong buffers, for training one buffer per layer (they are the saved activations of the backward pass).
+// Training only: bits[l] (may be null) receives the ReLU bitmask of hidden layer l and have_bits[l] says whether it was
+// written (csrc/gemm_sa.hip, launch_gemm_nt_bits); backward() then masks dX with it instead of re-reading acts[l].
 static int forward(hipStream_t st, const NetLayout &net, const float *packed, const float *obs, int64_t ld_obs,
-                   const int64_t *row_idx, int64_t n, int out_tanh, float *const *acts, int bf16_operands = 0) {
+                   const int64_t *row_idx, int64_t n, int out_tanh, float *const *acts, int bf16_operands = 0,
+                   unsigned long long *const *bits = nullptr, bool *have_bits = nullptr) {
+    if (have_bits)
+        for (int l = 0; l < net.n_layers; ++l) have_bits[l] = false;
     if (fused_eligible(net, n)) return launch_fused_forward(st, net, packed, obs, ld_obs, row_idx, n, out_tanh, acts);
     const float *x = obs;
     int64_t ldx = ld_obs;
@@ -77,9 +82,17 @@ static int forward(hipStream_t st, const NetLayout &net, const float *packed, co
         int rc;
         if (last && !out_tanh && !ridx && gemv_head_ok(L.out, L.pin))  // one-output head: matrix-vector kernel (gemv.hip)
             rc = launch_gemv_fwd(st, x, ldx, packed + L.off_w, packed + L.off_b, acts[l], L.pout, n, L.pin, L.pout);
-        else
-            rc = launch_gemm_nt(st, x, ldx, ridx, packed + L.off_w, L.pin, packed + L.off_b, nullptr, 0, acts[l], L.pout, n,
-                                L.pout, L.pin, epi, bf16_operands);
+        else {
+            rc = -1;
+            if (!last && bits && bits[l] && !ridx && !bf16_operands) {
+                rc = launch_gemm_nt_bits(st, x, ldx, packed + L.off_w, L.pin, packed + L.off_b, acts[l], L.pout, n, L.pout, L.pin,
+                                         EPI_BIAS_RELU, bits[l]);
+                if (rc == 0) have_bits[l] = true;
+            }
+            if (rc == -1)
+                rc = launch_gemm_nt(st, x, ldx, ridx, packed + L.off_w, L.pin, packed + L.off_b, nullptr, 0, acts[l], L.pout, n,
+                                    L.pout, L.pin, epi, bf16_operands);
+        }
         if (rc) return rc;
         x = acts[l];
         ldx = L.pout;
@@ -301,7 +314,10 @@ static size_t train_ws_floats(const NetLayout &pol, const NetLayout &val, int64_
     int m = max_pout(pol) > max_pout(val) ? max_pout(pol) : max_pout(val);
     per_row += (size_t)(pol.n_layers - 1 + val.n_layers - 1) * (size_t)m;  // one dX buffer per layer and net
     per_row += (size_t)pol.L[0].pin;                                         // the gathered minibatch states
-    return per_row * (size_t)mb + tn_ws_floats(pol, mb) + tn_ws_floats(val, mb);  // + one partial-tile buffer per chain
+    size_t bits = 0;                                                         // ReLU bitmasks of the hidden layers (1/32 of h)
+    for (int l = 0; l + 1 < pol.n_layers; ++l) bits += nt_bits_floats(mb, pol.L[l].pout);
+    for (int l = 0; l + 1 < val.n_layers; ++l) bits += nt_bits_floats(mb, val.L[l].pout);
+    return per_row * (size_t)mb + tn_ws_floats(pol, mb) + tn_ws_floats(val, mb) + bits + 2;  // + one partial-tile buffer per chain
 }
 
 size_t rlppo_minibatch_workspace_bytes(const int32_t *pol_dims, int32_t pol_layers, const int32_t *val_dims,
@@ -317,7 +333,8 @@ size_t rlppo_minibatch_workspace_bytes(const int32_t *pol_dims, int32_t pol_laye
 // kernels, 74 KB + 64 KB of LDS) share a CU instead of two copies of the same kernel running in lock step.
 static int backward(hipStream_t st, hipStream_t dw, hipEvent_t *ev, const NetLayout &net, const float *packed,
                     const float *states, int64_t ld_states, const int64_t *idx, int64_t mb, float *const *acts,
-                    float *const *dx, float *grad, float *tn_ws, size_t tn_floats) {
+                    float *const *dx, float *grad, float *tn_ws, size_t tn_floats, unsigned long long *const *bits = nullptr,
+                    const bool *have_bits = nullptr) {
     // dx[l-1] receives dL/d(acts[l-1]) = dY of layer l-1 (one buffer per layer: the dW launches read them later)
     const int last = net.n_layers - 1;
     const bool fused = fused_eligible(net, mb);
@@ -348,8 +365,13 @@ static int backward(hipStream_t st, hipStream_t dw, hipEvent_t *ev, const NetLay
             if (rc) return rc;
         } else if (l > 0 && !fused) {
             // dX[mb][pin] = (dY[mb][pout] . W[pout][pin]) masked by relu'(acts[l-1]); B operand = W^T [pin][pout]
-            rc = launch_gemm_nt(st, dY, L.pout, nullptr, packed + L.off_wt, L.pout, nullptr, acts[l - 1], L.pin, dx[l - 1],
-                                L.pin, mb, L.pin, L.pout, EPI_MASK);
+            rc = -1;
+            if (have_bits && have_bits[l - 1])  // the forward left the ReLU bitmask of acts[l-1]: no re-read of the activation
+                rc = launch_gemm_nt_bits(st, dY, L.pout, packed + L.off_wt, L.pout, nullptr, dx[l - 1], L.pin, mb, L.pin, L.pout,
+                                         EPI_MASK, bits[l - 1]);
+            if (rc == -1)
+                rc = launch_gemm_nt(st, dY, L.pout, nullptr, packed + L.off_wt, L.pout, nullptr, acts[l - 1], L.pin, dx[l - 1],
+                                    L.pin, mb, L.pin, L.pout, EPI_MASK);
             if (rc) return rc;
         }
     }
@@ -421,6 +443,20 @@ int rlppo_ppo_minibatch(void *stream, const rlppo_minibatch_args *a) {
     w += tn_ws_floats(pol, mb);
     float *val_tn_ws = w;
     w += tn_ws_floats(val, mb);
+    // ReLU bitmasks of the hidden layers, 8-byte aligned (the workspace base is 256-byte aligned by contract of the host)
+    if ((reinterpret_cast<uintptr_t>(w) & 7) != 0) ++w;
+    unsigned long long *pbits[RLPPO_MAX_LAYERS] = {}, *vbits[RLPPO_MAX_LAYERS] = {};
+    bool phave[RLPPO_MAX_LAYERS] = {}, vhave[RLPPO_MAX_LAYERS] = {};
+    for (int l = 0; l + 1 < pol.n_layers; ++l) {
+        const size_t f = nt_bits_floats(mb, pol.L[l].pout);
+        pbits[l] = f ? reinterpret_cast<unsigned long long *>(w) : nullptr;
+        w += f;
+    }
+    for (int l = 0; l + 1 < val.n_layers; ++l) {
+        const size_t f = nt_bits_floats(mb, val.L[l].pout);
+        vbits[l] = f ? reinterpret_cast<unsigned long long *>(w) : nullptr;
+        w += f;
+    }
     // the minibatch gather (experience_buffer.py:82-87): one pass into the workspace, shared by both nets
     const float *states = a->states;
     int64_t ld_states = a->ld_states;
@@ -445,9 +481,9 @@ int rlppo_ppo_minibatch(void *stream, const rlppo_minibatch_args *a) {
         rc = order_after(side, st, g_ev_fork[slot]);
         if (rc) return rc;
     }
-    rc = forward(side, val, a->val_packed, states, ld_states, gidx, mb, 0, vact);
+    rc = forward(side, val, a->val_packed, states, ld_states, gidx, mb, 0, vact, 0, vbits, vhave);
     if (rc) return rc;
-    rc = forward(st, pol, a->pol_packed, states, ld_states, gidx, mb, a->head == RLPPO_HEAD_GAUSSIAN, pact);
+    rc = forward(st, pol, a->pol_packed, states, ld_states, gidx, mb, a->head == RLPPO_HEAD_GAUSSIAN, pact, 0, pbits, phave);
     if (rc) return rc;
     // loss epilogue: outputs -> output gradients in place, report statistics accumulated on device.  The value loss only
     // needs the critic's output and the policy loss only the policy's, so with two streams each chain runs its own loss
@@ -491,9 +527,9 @@ int rlppo_ppo_minibatch(void *stream, const rlppo_minibatch_args *a) {
         rc = order_after(side, st, g_ev_fork[slot]);
         if (rc) return rc;
     }
-    rc = backward(side, g_dw_streams ? g_dw[slot][1] : side, g_ev_dw[slot][1], val, a->val_packed, states, ld_states, gidx, mb, vact, vdx, a->val_grad, val_tn_ws, tn_ws_floats(val, mb));
+    rc = backward(side, g_dw_streams ? g_dw[slot][1] : side, g_ev_dw[slot][1], val, a->val_packed, states, ld_states, gidx, mb, vact, vdx, a->val_grad, val_tn_ws, tn_ws_floats(val, mb), vbits, vhave);
     if (rc) return rc;
-    rc = backward(st, g_dw_streams ? g_dw[slot][0] : st, g_ev_dw[slot][0], pol, a->pol_packed, states, ld_states, gidx, mb, pact, pdx, a->pol_grad, pol_tn_ws, tn_ws_floats(pol, mb));
+    rc = backward(st, g_dw_streams ? g_dw[slot][0] : st, g_ev_dw[slot][0], pol, a->pol_packed, states, ld_states, gidx, mb, pact, pdx, a->pol_grad, pol_tn_ws, tn_ws_floats(pol, mb), pbits, phave);
     if (rc) return rc;
     if (side != st) rc = order_after(st, side, g_ev_join[slot]);
     return rc;
@@ -640,12 +676,27 @@ int rlppo_dbg_set(int32_t key, int32_t value) {
         set_nt_persist(value);
         return 0;
     }
+    if (key == 19) {
+        set_mask_bits(value);
+        return 0;
+    }
     if (key == 18) {
         set_gae_grid_div(value);
         return 0;
     }
     set_error("dbg_set: unknown key %d", key);
     return RLPPO_ERR_ARG;
+}
+size_t rlppo_dbg_gemm_nt_bits_bytes(int64_t M, int32_t N) { return nt_bits_floats(M, N) * sizeof(float); }
+int rlppo_dbg_gemm_nt_bits(void *stream, const float *A, int64_t lda, const float *B, int64_t ldb, const float *bias, float *C,
+                           int64_t ldc, int64_t M, int32_t N, int32_t K, int32_t epilogue, void *bits) {
+    const int rc = launch_gemm_nt_bits((hipStream_t)stream, A, lda, B, ldb, bias, C, ldc, M, N, K, epilogue,
+                                       reinterpret_cast<unsigned long long *>(bits));
+    if (rc == -1) {
+        set_error("dbg_gemm_nt_bits: the bitmask form does not apply to this call");
+        return RLPPO_ERR_ARG;
+    }
+    return rc;
 }
 int rlppo_dbg_gemm_nt_stamped(void *stream, const float *A, int64_t lda, const float *B, int64_t ldb, const float *bias,
                                 float *C, int64_t ldc, int64_t M, int32_t N, int32_t K, uint64_t *stamps, int32_t mode) {

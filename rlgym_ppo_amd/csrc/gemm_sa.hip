@@ -20,6 +20,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 constexpr int SBM = 128, SBK = 32;
+constexpr int EPI_NONE = 99;  // nt_epilogue: store the accumulators as they are
 __device__ __forceinline__ unsigned long long stamp() {
     unsigned long long t;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
@@ -76,7 +77,7 @@ __device__ __forceinline__ void nt_epilogue(f32x4 (&acc)[2][NB], const float *ma
 #pragma unroll
                 for (int e = 0; e < 4; ++e) acc[i][j][e] = h[e] > 0.f ? acc[i][j][e] : 0.f;
             }
-    } else if (EPI != EPI_BIAS) {
+    } else if (EPI != EPI_BIAS && EPI != EPI_NONE) {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -92,6 +93,45 @@ __device__ __forceinline__ void nt_epilogue(f32x4 (&acc)[2][NB], const float *ma
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < NB; ++j) stb(c_rs, c_off, 16 * i * ldc_b + j * 64, acc[i][j]);
+}
+
+// ReLU bitmask (rlppo_dbg_set(19)).  dX = (dY . W) masked by [h > 0] needs one BIT of the forward activation per element,
+// but re-reading h costs a 64 KB tile per workgroup whose latency nothing hides (the accumulators occupy the registers the
+// tile would have to be prefetched into): the masked epilogue is 11 % of a dX launch (scratch/epi_cost.py).  Instead the
+// forward epilogue of a hidden layer also emits, per lane, the 64 bits [acc > 0] of the 64 outputs the lane owns --
+// bit (i * NB + j) * 4 + e for C[.. + 16 i + r16][.. + 16 j + 4 q + e] -- as one 8-byte word at
+// bits[(row_tile * col_tiles + col_tile) * 256 + tid]; the dX kernel of the same tile geometry loads its word before the
+// K loop (2 VGPRs) and the epilogue is 2 VALU instructions per element with no memory access.  1/32 of the bytes of h.
+template <int NB>
+__device__ __forceinline__ unsigned long long relu_bits(const f32x4 (&acc)[2][NB]) {
+    unsigned lo = 0, hi = 0;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int b = (i * NB + j) * 4 + e;
+                const unsigned v = acc[i][j][e] > 0.f ? 1u : 0u;
+                if (b < 32) lo |= v << b;
+                else hi |= v << (b - 32);
+            }
+    return ((unsigned long long)hi << 32) | lo;
+}
+template <int NB>
+__device__ __forceinline__ void apply_bits(f32x4 (&acc)[2][NB], unsigned long long w) {
+    const unsigned lo = (unsigned)w, hi = (unsigned)(w >> 32);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int b = (i * NB + j) * 4 + e;
+                const unsigned m = 0u - (((b < 32 ? lo : hi) >> (b & 31)) & 1u);  // 0 or ~0
+                const float x = acc[i][j][e];  // a scalar copy: bit-casting the vector ELEMENT expression reads element 0
+                acc[i][j][e] = __uint_as_float(__float_as_uint(x) & m);
+            }
 }
 
 // XCD-aware tile order.  Workgroups are dispatched in linear id order (x fastest) and id i runs on XCD i % 8, each XCD with
@@ -258,13 +298,14 @@ __device__ __forceinline__ int dswz(int row, int chunk) {
     return row * 16 + ((chunk ^ ((0 - (row >> 2)) & 3)) << 2);
 }
 
-template <int NB, int EPI, int BKT>
+template <int NB, int EPI, int BKT, bool BITS = false>
 __global__ __launch_bounds__(256, BKT == 16 ? 4 : 2) void gemm_nt_dma_kernel(const float *__restrict__ A, unsigned lda_b,
                                                                               const float *__restrict__ B, unsigned ldb_b,
                                                                               const float *__restrict__ bias,
                                                                               const float *__restrict__ mask_src,
                                                                               unsigned ldm_b, float *__restrict__ C,
-                                                                              unsigned ldc_b, int64_t M, int K) {
+                                                                              unsigned ldc_b, int64_t M, int K,
+                                                                              unsigned long long *__restrict__ bits = nullptr) {
     constexpr int BN = NB * 16;
     constexpr int CPR = BKT / 4;     // 16-byte chunks per tile row
     constexpr int RPW = 64 / CPR;    // tile rows one wave instruction fills
@@ -284,6 +325,9 @@ __global__ __launch_bounds__(256, BKT == 16 ? 4 : 2) void gemm_nt_dma_kernel(con
     const int64_t m0 = (int64_t)row_tile * SBM;
     const int n0 = col_tile * BN;
     const int rows_here = (int)((M - m0) < SBM ? (M - m0) : SBM);
+    unsigned long long *const bit_word = BITS ? bits + ((size_t)row_tile * gridDim.y + col_tile) * 256 + tid : nullptr;
+    unsigned long long mask_word = 0;
+    if (BITS && EPI == EPI_MASK) mask_word = *bit_word;  // requested before the K loop: long arrived when the epilogue needs it
 
     const __amdgpu_buffer_rsrc_t a_rs = make_rsrc(reinterpret_cast<const char *>(A) + m0 * lda_b,
                                                   (unsigned)(rows_here - 1) * lda_b + (unsigned)K * 4);
@@ -350,7 +394,21 @@ __global__ __launch_bounds__(256, BKT == 16 ? 4 : 2) void gemm_nt_dma_kernel(con
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of the next tile have landed in LDS
         __syncthreads();
     }
-    nt_epilogue<NB, EPI>(acc, mask_src, ldm_b, C, ldc_b, m0, n0, rows_here, wave, r16, q);
+    if (BITS && EPI == EPI_MASK) {
+        apply_bits<NB>(acc, mask_word);
+        nt_epilogue<NB, EPI_NONE>(acc, nullptr, 0, C, ldc_b, m0, n0, rows_here, wave, r16, q);
+    } else if (BITS && EPI == EPI_BIAS_RELU) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < NB; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[i][j][e] = relu1(acc[i][j][e]);
+        *bit_word = relu_bits<NB>(acc);
+        nt_epilogue<NB, EPI_NONE>(acc, nullptr, 0, C, ldc_b, m0, n0, rows_here, wave, r16, q);
+    } else {
+        nt_epilogue<NB, EPI>(acc, mask_src, ldm_b, C, ldc_b, m0, n0, rows_here, wave, r16, q);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ gemm_nt, persistent form
@@ -689,6 +747,35 @@ int launch_gemm_nt_sa_stamped(hipStream_t st, const float *A, int64_t lda, const
     dim3 grid((unsigned)cdiv(M, SBM), (unsigned)(N / 128));
     hipLaunchKernelGGL((gemm_nt_sa_kernel<8, EPI_BIAS_RELU, true>), grid, dim3(256), 0, st, A, (unsigned)(lda * 4), B,
                        (unsigned)(ldb * 4), bias, nullptr, 0u, C, (unsigned)(ldc * 4), M, K, stamps);
+    RLPPO_LAUNCH_CHECK();
+    return 0;
+}
+
+static int g_mask_bits = 1;  // tuning: rlppo_dbg_set(19, 0/1)
+void set_mask_bits(int v) { g_mask_bits = v; }
+// floats of workspace one hidden layer's ReLU bitmask needs (8 bytes per lane and 128 x 128 tile); 0 = width not supported
+size_t nt_bits_floats(int64_t M, int N) {
+    if (N % 128 != 0 || M <= 0) return 0;
+    return (size_t)cdiv(M, SBM) * (size_t)(N / 128) * 256 * 2;
+}
+// The hidden-layer forward (epi = EPI_BIAS_RELU: writes `bits`) or the masked dX product (epi = EPI_MASK: reads `bits`
+// instead of the activation) through gemm_nt_dma_kernel<8, ., 16, true>.  Returns -1 when that form does not apply
+// (switch off, width not a multiple of 128, operands too wide for 32-bit tile offsets): the caller then uses launch_gemm_nt
+// and, for the forward, must not hand the bitmask to the backward pass.
+int launch_gemm_nt_bits(hipStream_t st, const float *A, int64_t lda, const float *B, int64_t ldb, const float *bias, float *C,
+                        int64_t ldc, int64_t M, int N, int K, int epi, unsigned long long *bits) {
+    if (!g_mask_bits || g_nt_sa != 3 || !bits || N % 128 != 0 || K % 16 != 0 || M <= 0) return -1;
+    if (epi != EPI_BIAS_RELU && epi != EPI_MASK) return -1;
+    const int64_t lim = (int64_t)1 << 31;
+    if (129 * lda * 4 >= lim || 129 * ldb * 4 >= lim || 129 * ldc * 4 >= lim) return -1;
+    dim3 grid((unsigned)cdiv(M, SBM), (unsigned)(N / 128));
+    const unsigned la = (unsigned)(lda * 4), lb = (unsigned)(ldb * 4), lc = (unsigned)(ldc * 4);
+    if (epi == EPI_BIAS_RELU)
+        hipLaunchKernelGGL((gemm_nt_dma_kernel<8, EPI_BIAS_RELU, 16, true>), grid, dim3(256), 0, st, A, la, B, lb, bias, nullptr,
+                           0u, C, lc, M, K, bits);
+    else
+        hipLaunchKernelGGL((gemm_nt_dma_kernel<8, EPI_MASK, 16, true>), grid, dim3(256), 0, st, A, la, B, lb, nullptr, nullptr, 0u,
+                           C, lc, M, K, bits);
     RLPPO_LAUNCH_CHECK();
     return 0;
 }

@@ -76,6 +76,34 @@ def test_gemm_nt(L, M, N, K, epi, gather):
     assert relerr(C, ref) < (5e-6 if epi == 2 else 2e-6)
 
 
+def test_relu_bitmask_forms_are_bitwise_equal(L):
+    """RLPPO_TUNE key 19: the hidden-layer forward that also writes the ReLU bitmask gives the same activations as the plain
+    forward, and the dX product masked by that bitmask gives the same result as the one masked by re-reading the activation
+    (ragged last row tile, exact zeros and negative pre-activations in the mask)."""
+    torch.manual_seed(6)
+    M = 4096 * 3 + 77
+    A = torch.randn(M, 256, device="cuda")
+    W = torch.randn(256, 256, device="cuda") * 0.05
+    b = torch.randn(256, device="cuda") * 0.1
+    dY = torch.randn(M, 128, device="cuda")
+    Wt = torch.randn(256, 128, device="cuda") * 0.05
+    bits = torch.zeros(int(L.rlppo_dbg_gemm_nt_bits_bytes(M, 256)), dtype=torch.uint8, device="cuda")
+    assert bits.numel() == ((M + 127) // 128) * 2 * 256 * 8
+    H0 = torch.empty(M, 256, device="cuda")
+    H1 = torch.full((M, 256), -7.0, device="cuda")
+    check(L, L.rlppo_dbg_gemm_nt(stream(), P(A), 256, None, P(W), 256, P(b), None, 0, P(H0), 256, M, 256, 256, 1))
+    check(L, L.rlppo_dbg_gemm_nt_bits(stream(), P(A), 256, P(W), 256, P(b), P(H1), 256, M, 256, 256, 1, P(bits)))
+    assert torch.equal(H0, H1) and (H0 == 0).float().mean().item() > 0.3
+    D0 = torch.empty(M, 256, device="cuda")
+    D1 = torch.full((M, 256), -7.0, device="cuda")
+    check(L, L.rlppo_dbg_gemm_nt(stream(), P(dY), 128, None, P(Wt), 128, None, P(H0), 256, P(D0), 256, M, 256, 128, 3))
+    check(L, L.rlppo_dbg_gemm_nt_bits(stream(), P(dY), 128, P(Wt), 128, None, P(D1), 256, M, 256, 128, 3, P(bits)))
+    torch.cuda.synchronize()
+    assert torch.equal(D0, D1)
+    assert ((D1 == 0) == (H0 == 0)).all()      # zero exactly where the unit was off (N(0,1) products are never exactly 0)
+    assert L.rlppo_dbg_gemm_nt_bits(stream(), P(A), 256, P(W), 256, P(b), P(H1), 96, M, 96, 256, 1, P(bits)) != 0   # width not 128 k
+
+
 def test_gemm_nt_persistent_form_is_bitwise_equal(L):
     """RLPPO_TUNE key 17: workgroups that walk over several output tiles (launches with more tiles than resident slots) run
     the same arithmetic in the same order as the one-tile-per-workgroup kernel: outputs must be bit-identical, including the
