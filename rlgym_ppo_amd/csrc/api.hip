@@ -361,7 +361,10 @@ static int backward(hipStream_t st, hipStream_t dw, hipEvent_t *ev, const NetLay
                                 grad + L.off_flat_b, L.out, L.in, mb, tn_ws, tn_floats);  // all dW launches of a net share one stream
         if (rc) return rc;
         if (gemv && !fused) {
-            rc = launch_gemv_dx(st, dY, L.pout, packed + L.off_w, acts[l - 1], L.pin, dx[l - 1], L.pin, L.pin, mb);
+            rc = -1;
+            if (have_bits && have_bits[l - 1])
+                rc = launch_gemv_dx_bits(st, dY, L.pout, packed + L.off_w, bits[l - 1], dx[l - 1], L.pin, L.pin, mb);
+            if (rc == -1) rc = launch_gemv_dx(st, dY, L.pout, packed + L.off_w, acts[l - 1], L.pin, dx[l - 1], L.pin, L.pin, mb);
             if (rc) return rc;
         } else if (l > 0 && !fused) {
             // dX[mb][pin] = (dY[mb][pout] . W[pout][pin]) masked by relu'(acts[l-1]); B operand = W^T [pin][pout]

@@ -125,6 +125,8 @@ void set_gemv(int v);
 bool gemv_head_ok(int out, int kp);
 int launch_gemv_fwd(hipStream_t st, const float *x, int64_t ldx, const float *w, const float *b, float *y, int64_t ldy, int64_t n, int kp, int pout);
 int launch_gemv_dx(hipStream_t st, const float *dy, int64_t ldy, const float *w, const float *mask, int64_t ldm, float *dx, int64_t ldc, int kp, int64_t n);
+int launch_gemv_dx_bits(hipStream_t st, const float *dy, int64_t ldy, const float *w, const unsigned long long *bits, float *dx,
+                        int64_t ldc, int kp, int64_t n);
 int launch_gemv_dw(hipStream_t st, const float *dy, int64_t ldy, const float *x, int64_t ldx, float *dw, float *db, int in, int kp, int64_t n,
                    float *ws = nullptr, size_t ws_floats = 0);
 void set_loss16(int v);

@@ -64,6 +64,36 @@ __global__ __launch_bounds__(256) void gemv_dx_kernel(const float *__restrict__ 
     *reinterpret_cast<f32x4 *>(dx + row * ldc + c) = o;
 }
 
+// The same product with the ReLU mask taken from the bitmask the hidden layer's forward GEMM wrote (csrc/gemm_sa.hip,
+// relu_bits): no read of the activation at all.  A block is one 128 x 128 tile of dx and a thread is the lane that owned the
+// same 64 elements in the forward epilogue: wave w, lane (q, r16) -> rows m0 + 32 w + 16 i + r16, columns n0 + 16 j + 4 q + e,
+// bit (8 i + j) * 4 + e of the word at bits[tile * 256 + tid] (512 contiguous bytes per wave).
+__global__ __launch_bounds__(256) void gemv_dx_bits_kernel(const float *__restrict__ dy, int64_t ldy, const float *__restrict__ w,
+                                                           const unsigned long long *__restrict__ bits, float *__restrict__ dx,
+                                                           int64_t ldc, int64_t n) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r16 = lane & 15, q = lane >> 4;
+    const int64_t m0 = (int64_t)blockIdx.x * 128;
+    const int n0 = blockIdx.y * 128;
+    const unsigned long long word = bits[((size_t)blockIdx.x * gridDim.y + blockIdx.y) * 256 + tid];
+    f32x4 wv[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) wv[j] = *reinterpret_cast<const f32x4 *>(w + n0 + 16 * j + 4 * q);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int64_t row = m0 + wave * 32 + 16 * i + r16;
+        if (row >= n) continue;
+        const float d = dy[row * ldy];
+        const unsigned half = (unsigned)(word >> (32 * i));
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = ((half >> (j * 4 + e)) & 1u) ? d * wv[j][e] : 0.f;
+            *reinterpret_cast<f32x4 *>(dx + row * ldc + n0 + 16 * j + 4 * q) = o;
+        }
+    }
+}
+
 // block = rows [r0, r0 + rows_per_block); thread = (row lane, 16-byte column chunk); cpr chunks per row, 256 / cpr row lanes
 __global__ __launch_bounds__(256) void gemv_dw_kernel(const float *__restrict__ dy, int64_t ldy, const float *__restrict__ x,
                                                       int64_t ldx, float *__restrict__ dw, float *__restrict__ db, int in,
@@ -174,6 +204,17 @@ int launch_gemv_dx(hipStream_t st, const float *dy, int64_t ldy, const float *w,
     if (n <= 0) return 0;
     const int cpr = kp / 4;
     hipLaunchKernelGGL(gemv_dx_kernel, dim3((unsigned)cdiv(n * cpr, 256)), dim3(256), 0, st, dy, ldy, w, mask, ldm, dx, ldc, cpr, n);
+    RLPPO_LAUNCH_CHECK();
+    return 0;
+}
+
+// returns -1 when the bitmask form does not apply (width not a multiple of 128)
+int launch_gemv_dx_bits(hipStream_t st, const float *dy, int64_t ldy, const float *w, const unsigned long long *bits, float *dx,
+                        int64_t ldc, int kp, int64_t n) {
+    if (n <= 0) return 0;
+    if (!bits || kp % 128 != 0) return -1;
+    hipLaunchKernelGGL(gemv_dx_bits_kernel, dim3((unsigned)cdiv(n, 128), (unsigned)(kp / 128)), dim3(256), 0, st, dy, ldy, w, bits,
+                       dx, ldc, n);
     RLPPO_LAUNCH_CHECK();
     return 0;
 }

@@ -581,6 +581,34 @@ def test_minibatch_full_size_cfg2(L):
     compare_minibatch(gp, gv, st, ref, tol=2e-5)
 
 
+def test_minibatch_identical_with_and_without_relu_bitmask(L):
+    """RLPPO_TUNE key 19 only changes WHERE the ReLU mask of the backward pass comes from (the bitmask the forward wrote vs the
+    saved activation): the gradients and the statistics of a cfg2-shape minibatch must be bit-identical either way (256-wide
+    nets: every masked dX GEMM and the critic's matrix-vector dX take the bitmask path)."""
+    torch.manual_seed(12)
+    pol = nets.init_mlp(107, (256, 256, 256), 90)
+    val = nets.init_mlp(107, (256, 256, 256), 1)
+    rs = np.random.RandomState(12)
+    n = 9000
+    obs = np.clip(rs.randn(n, 107), -5, 5).astype(np.float32)
+    with torch.no_grad():
+        act, logp = nets.discrete_sample(nets.discrete_probs(pol, obs), nets.draw_exp_noise(n, 90))
+    old = (logp + torch.as_tensor(rs.randn(n).astype(np.float32) * 0.2)).numpy()
+    adv, tgt = rs.randn(n).astype(np.float32), rs.randn(n).astype(np.float32)
+    idx = rs.permutation(n)[:8192 + 77]
+    res = []
+    try:
+        for v in (0, 1):
+            check(L, L.rlppo_dbg_set(19, v))
+            res.append(run_minibatch(L, "discrete", pol, val, obs, act.numpy(), old, tgt, adv, idx, 0.2, 0.005, 1.0))
+    finally:
+        check(L, L.rlppo_dbg_set(19, 1))
+    (gp0, gv0, st0), (gp1, gv1, st1) = res
+    for a, b in zip(gp0 + gv0, gp1 + gv1):
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    assert np.array_equal(st0[:5], st1[:5])
+
+
 def test_fused_pass_full_size_cfg2(L):
     """The launch shape of the update at one GPU: ONE pass over the 8 minibatches of a batch = 524,288 rows (BASELINE configs[1]:
     B = 524,288, MB = 65,536; PPOLearner.max_fused_minibatches).  Additivity at that size: the gradient and the report sums of
