@@ -133,16 +133,24 @@ def kernel_breakdown(learner):
     tn_ws = torch.empty(max(max(int(L.rlppo_dbg_gemm_tn_workspace_bytes(o, i, M)) for o, i in ((256, 256), (256, 107), (90, 256))), 1),
                         dtype=torch.uint8, device=dev)  # too small a workspace silently selects the atomic form
 
+    # the forms the update launches for 128-multiple widths: the hidden-layer forward also writes the ReLU bitmask, the masked
+    # dX product reads it (csrc/gemm_sa.hip); the bitmask buffer here is written by the forward launches timed first
+    bits = torch.zeros(max(int(L.rlppo_dbg_gemm_nt_bits_bytes(M, 256)), 8), dtype=torch.uint8, device=dev)
+
+    def ntb(A, lda, C, ldc, n, k, epi):
+        return lambda: N.check(L.rlppo_dbg_gemm_nt_bits(st(), P(A), lda, P(W), lda, P(bias) if epi == 1 else None, P(C), ldc, M, n, k,
+                                                        epi, P(bits)))
+
     def tn(dY, ny, X, kx, ridx, out, in_):  # the form the update uses: partial tiles + reduction kernel (both timed)
         return lambda: N.check(L.rlppo_dbg_gemm_tn_ws(st(), P(dY), ny, ny, P(X), kx, kx, P(dW), P(db), out, in_, M, P(tn_ws),
                                                        tn_ws.numel()))
 
     shapes = [
-        ("gemm_nt fwd L0 128->256 (x2 nets)", 2, nt(A128, 128, None, 128, C256, 256, 256, 128, 1), 2 * M * 256 * 128),
-        ("gemm_nt fwd hidden 256->256 (x4)", 4, nt(A256, 256, None, 256, C256, 256, 256, 256, 1), 2 * M * 256 * 256),
+        ("gemm_nt fwd L0 128->256 +bitmask (x2 nets)", 2, ntb(A128, 128, C256, 256, 256, 128, 1), 2 * M * 256 * 128),
+        ("gemm_nt fwd hidden 256->256 +bitmask (x4)", 4, ntb(A256, 256, C256, 256, 256, 256, 1), 2 * M * 256 * 256),
         ("gemm_nt fwd head 256->96", 1, nt(A256, 256, None, 256, C96, 96, 96, 256, 0), 2 * M * 96 * 256),
-        ("gemm_nt dX hidden 256->256 mask (x4)", 4, nt(A256, 256, None, 256, C256, 256, 256, 256, 3, A256b), 2 * M * 256 * 256),
-        ("gemm_nt dX head 96->256 mask", 1, nt(A96, 96, None, 96, C256, 256, 256, 96, 3, A256b), 2 * M * 256 * 96),
+        ("gemm_nt dX hidden 256->256 bitmask (x4)", 4, ntb(A256, 256, C256, 256, 256, 256, 3), 2 * M * 256 * 256),
+        ("gemm_nt dX head 96->256 bitmask", 1, ntb(A96, 96, C256, 256, 256, 96, 3), 2 * M * 256 * 96),
         ("gemm_tn dW hidden 256x256 (x4)", 4, tn(A256, 256, A256b, 256, None, 256, 256), 2 * M * 256 * 256),
         ("gemm_tn dW L0 256x107 (x2)", 2, tn(A256, 256, A128, 128, None, 256, 107), 2 * M * 256 * 128),
         ("gemm_tn dW head 90x256", 1, tn(A96, 96, A256, 256, None, 90, 256), 2 * M * 128 * 256),
@@ -156,7 +164,7 @@ def kernel_breakdown(learner):
     return rows, dominant
 
 
-TRAFFIC_JSON = "r01_traffic_v8.json"  # tools/pmc_traffic.py output of the committed PMC passes
+TRAFFIC_JSON = "r01_traffic_v9.json"  # tools/pmc_traffic.py output of the committed PMC passes
 
 
 def pmc_traffic_for(kernel_label):
@@ -165,9 +173,9 @@ def pmc_traffic_for(kernel_label):
     key = {"gemm_tn dW hidden 256x256 (x4)": "rlppo::gemm_tn_dma_kernel<32, true> {dW hidden 256x256}",
            "gemm_tn dW L0 256x107 (x2)": "rlppo::gemm_tn_dma_kernel<32, true> {dW L0 256x107}",
            "gemm_tn dW head 90x256": "rlppo::gemm_tn_dma_kernel<32, true> {dW head 90x256}",
-           "gemm_nt fwd hidden 256->256 (x4)": "rlppo::gemm_nt_dma_kernel<8, 1, 16>",
-           "gemm_nt fwd head 256->96": "rlppo::gemm_nt_dma_kernel<6, 0, 32>",
-           "gemm_nt dX hidden 256->256 mask (x4)": "rlppo::gemm_nt_dma_kernel<8, 3, 16>"}.get(kernel_label)
+           "gemm_nt fwd hidden 256->256 +bitmask (x4)": "rlppo::gemm_nt_dma_kernel<8, 1, 16, true>",
+           "gemm_nt fwd head 256->96": "rlppo::gemm_nt_dma_kernel<6, 0, 32, false>",
+           "gemm_nt dX hidden 256->256 bitmask (x4)": "rlppo::gemm_nt_dma_kernel<8, 3, 16, true>"}.get(kernel_label)
     try:
         # tools/prof_kernels.py launches the same shapes as kernel_breakdown (M = 524,288 rows); tools/pmc_summary.py tells the
         # three dW shapes (same kernel, same grid) apart by their position in the launch cycle
