@@ -279,6 +279,7 @@ int rlppo_set_inference_precision(int32_t mode);
  *  16 dW through partial tiles + a reduction kernel [1] | fp32 atomics [0]
  *  17 gemm_nt with persistent workgroups when a launch has more tiles than resident slots [0]
  *  18 GAE chunks per workgroup [1]
+ *  20 gemm_nt with three K tiles in flight, three workgroups per CU [0]
  *  19 ReLU bitmask written by the hidden-layer forward and read by the masked dX product [1] | dX re-reads the activation [0] */
 int rlppo_dbg_set(int32_t key, int32_t value);
 /* Register-only fp32 MFMA loop: out[blocks*256] floats, clocks[2*blocks] = {shader cycles, 100 MHz ticks} per block. */

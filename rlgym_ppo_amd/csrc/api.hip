@@ -679,6 +679,10 @@ int rlppo_dbg_set(int32_t key, int32_t value) {
         set_nt_persist(value);
         return 0;
     }
+    if (key == 20) {
+        set_nt_nbuf3(value);
+        return 0;
+    }
     if (key == 19) {
         set_mask_bits(value);
         return 0;

@@ -106,6 +106,7 @@ int launch_gemm_nt_sa(hipStream_t st, const float *A, int64_t lda, const float *
                       const float *mask_src, int64_t ld_mask, float *C, int64_t ldc, int64_t M, int N, int nb, int K, int epi);
 void set_nt_sa(int v);
 void set_nt_persist(int v);
+void set_nt_nbuf3(int v);
 void set_mask_bits(int v);
 size_t nt_bits_floats(int64_t M, int N);
 int launch_gemm_nt_bits(hipStream_t st, const float *A, int64_t lda, const float *B, int64_t ldb, const float *bias, float *C,

@@ -411,6 +411,102 @@ __global__ __launch_bounds__(256, BKT == 16 ? 4 : 2) void gemm_nt_dma_kernel(con
     }
 }
 
+// ------------------------------------------------------------------------------------------------ gemm_nt, three K tiles in flight
+// Experiment (rlppo_dbg_set(20, 1)): the two-buffer kernel requests K tile k+1 at the start of step k and needs it at the end
+// of the same step -- a window of one step (~3.5 us with four workgroups per CU).  Here the request runs two steps ahead
+// (three LDS buffers, 48 KB -> three workgroups per CU) and the wait is a counted one: buffer loads complete in order, so
+// vmcnt(A_IT + B_IT) at the end of step k means "everything but the tile requested in this step has landed".
+template <int NB, int EPI>
+__global__ __launch_bounds__(256, 3) void gemm_nt_dma3_kernel(const float *__restrict__ A, unsigned lda_b,
+                                                              const float *__restrict__ B, unsigned ldb_b,
+                                                              const float *__restrict__ bias, const float *__restrict__ mask_src,
+                                                              unsigned ldm_b, float *__restrict__ C, unsigned ldc_b, int64_t M, int K) {
+    constexpr int BKT = 16, NBUF = 3;
+    constexpr int BN = NB * 16;
+    constexpr int CPR = BKT / 4, RPW = 64 / CPR, RPP = 4 * RPW;
+    constexpr int A_IT = SBM / RPP, B_IT = BN / RPP;
+    static_assert(BN % RPP == 0 && A_IT + B_IT == 4, "wait count below assumes four DMA instructions per tile");
+    __shared__ __attribute__((aligned(16))) float lds[NBUF * SBM * BKT + NBUF * BN * BKT];
+    float *As = lds;
+    float *Bs = lds + NBUF * SBM * BKT;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const int r16 = lane & 15, q = lane >> 4;
+    int row_tile, col_tile;
+    xcd_tile(row_tile, col_tile);
+    const int64_t m0 = (int64_t)row_tile * SBM;
+    const int n0 = col_tile * BN;
+    const int rows_here = (int)((M - m0) < SBM ? (M - m0) : SBM);
+    const __amdgpu_buffer_rsrc_t a_rs = make_rsrc(reinterpret_cast<const char *>(A) + m0 * lda_b,
+                                                  (unsigned)(rows_here - 1) * lda_b + (unsigned)K * 4);
+    const __amdgpu_buffer_rsrc_t b_rs = make_rsrc(reinterpret_cast<const char *>(B) + (int64_t)n0 * ldb_b,
+                                                  (unsigned)(BN - 1) * ldb_b + (unsigned)K * 4);
+    const int row_p = wave * RPW + lane / CPR, pch = lane % CPR;
+    const int lch = pch ^ ((0 - (row_p >> 2)) & 3);
+    const unsigned a_off = (unsigned)row_p * lda_b + lch * 16;
+    const unsigned b_off = (unsigned)row_p * ldb_b + lch * 16;
+    const unsigned a_step = (unsigned)RPP * lda_b, b_step = (unsigned)RPP * ldb_b;
+    f32x4 acc[2][NB];
+    if (EPI == EPI_MASK) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < NB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    } else {
+        const __amdgpu_buffer_rsrc_t bias_rs = make_rsrc(bias + n0, BN * 4);
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            acc[0][j] = ldb(bias_rs, (unsigned)(q * 16), j * 64);
+            acc[1][j] = acc[0][j];
+        }
+    }
+    auto issue_tile = [&](int buf, unsigned kb) {
+        float *Ad = As + buf * SBM * BKT + wave_u * RPW * BKT;
+        float *Bd = Bs + buf * BN * BKT + wave_u * RPW * BKT;
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rs, Ad + i * RPP * BKT, 16, a_off, kb + i * a_step, 0, 0);
+#pragma unroll
+        for (int i = 0; i < B_IT; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(b_rs, Bd + i * RPP * BKT, 16, b_off, kb + i * b_step, 0, 0);
+    };
+    const int nk = K / BKT;
+    issue_tile(0, 0);
+    if (nk > 1) {
+        issue_tile(1, BKT * 4);
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // tile 0 (and the bias loads before it) have landed
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+    int cur = 0, nxt2 = 2;  // buffer of tile kt, buffer tile kt + 2 goes to
+    for (int kt = 0; kt < nk; ++kt) {
+        const bool more2 = (kt + 2) < nk;
+        if (more2) issue_tile(nxt2, (unsigned)(kt + 2) * (BKT * 4));
+        const float *Ac = As + cur * SBM * BKT + (wave * 32) * BKT;
+        const float *Bc = Bs + cur * BN * BKT;
+        f32x4 fa[2], fb[NB];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) fa[i] = *reinterpret_cast<const f32x4 *>(&Ac[dswz<BKT>(i * 16 + r16, q)]);
+#pragma unroll
+        for (int j = 0; j < NB; ++j) fb[j] = *reinterpret_cast<const f32x4 *>(&Bc[dswz<BKT>(j * 16 + r16, q)]);
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < NB; ++j) acc[i][j] = MFMA16(fb[j][s], fa[i][s], acc[i][j]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (more2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // tile kt + 1 has landed; kt + 2 may still be in flight
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        cur = cur == 2 ? 0 : cur + 1;
+        nxt2 = nxt2 == 2 ? 0 : nxt2 + 1;
+    }
+    nt_epilogue<NB, EPI>(acc, mask_src, ldm_b, C, ldc_b, m0, n0, rows_here, wave, r16, q);
+}
+
 // ------------------------------------------------------------------------------------------------ gemm_nt, persistent form
 // The same tile loop as gemm_nt_dma_kernel, but a workgroup walks over several output tiles (ids w, w + G, w + 2G, ... with
 // G = the number of resident workgroup slots) instead of being re-dispatched for each: at M = 524,288 a launch is 8 rounds of
@@ -664,6 +760,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf16_kernel(const float *__res
     nt_epilogue<NB, EPI>(acc, mask_src, ldm_b, C, ldc_b, m0, n0, rows_here, wave, r16, q);
 }
 
+static int g_nt_nbuf3 = 0;  // tuning: rlppo_dbg_set(20, 0/1): three K tiles in flight, three workgroups per CU (NB = 8 only)
+void set_nt_nbuf3(int v) { g_nt_nbuf3 = v; }
 static int g_nt_persist = 0;  // tuning: rlppo_dbg_set(17, 0/1): persistent workgroups when a launch has more tiles than slots
 void set_nt_persist(int v) { g_nt_persist = v; }
 static int g_nt_sa = 3;  // tuning: rlppo_dbg_set(9, v): 0 gemm.hip kernel, 1 register-staged, 2 LDS-DMA BK=32, 3 LDS-DMA BK=16
@@ -682,7 +780,10 @@ static int launch_sa_1(hipStream_t st, dim3 grid, int epi, const float *A, unsig
     const bool persist = g_nt_persist && (uint64_t)grid.x * grid.y > slots && (uint64_t)grid.x * grid.y < (1u << 30);
 #define SA(E)                                                                                                          \
     case E:                                                                                                            \
-        if (variant == 3 && persist && E != EPI_BIAS_TANH) /* the tanh epilogue spills in the persistent form */       \
+        if (variant == 3 && g_nt_nbuf3 && NB == 8 && (E == EPI_BIAS_RELU || E == EPI_MASK))                            \
+            hipLaunchKernelGGL((gemm_nt_dma3_kernel<8, E>), grid, dim3(256), 0, st, A, lda_b, B, ldb_b, bias, mask_src,   \
+                               ldm_b, C, ldc_b, M, K);                                                                 \
+        else if (variant == 3 && persist && E != EPI_BIAS_TANH) /* the tanh epilogue spills in the persistent form */  \
             hipLaunchKernelGGL((gemm_nt_dma_persist_kernel<NB, E, can16 ? 16 : 32>), dim3(slots), dim3(256), 0, st, A,  \
                                lda_b, B, ldb_b, bias, mask_src, ldm_b, C, ldc_b, M, K, (int)grid.x, (int)grid.y);      \
         else if (variant == 3)                                                                                         \
