@@ -660,3 +660,48 @@ def test_clip_adam_matches_oracle(L):
         assert relerr(flat, nets.flatten(params)) < 1e-6
         assert relerr(m, nets.flatten(st.m)) < 1e-5 and relerr(v, nets.flatten(st.v)) < 1e-5
         assert relerr(gflat, nets.flatten([(w * coef, b * coef) for w, b in grads])) < 1e-6  # grads scaled in place
+
+
+def test_clip_adam_pack2_equals_separate_launches(L):
+    """rlppo_clip_adam_pack2 (both nets' clip + Adam + re-pack + zero_grad in two launches) against rlppo_clip_adam x2 +
+    rlppo_net_pack x2: parameters, both Adam moments and the packed copies bit-identical over several steps (large and tiny
+    gradients: clipped and unclipped), gradients left zero, squared norms equal; odd layer widths exercise the padding."""
+    from rlgym_ppo_amd import _native as N
+    torch.manual_seed(3)
+    shapes = [[107, 256, 256, 90], [107, 64, 1]]
+    state = []
+    for dims in shapes:
+        dc = N.dims_array(dims)
+        nl = len(dims) - 1
+        nf, npk = int(L.rlppo_flat_floats(dc, nl)), int(L.rlppo_packed_floats(dc, nl))
+        flat = torch.randn(nf, device="cuda") * 0.1
+        st = dict(dc=dc, nl=nl, nf=nf)
+        for tag in ("a", "b"):  # a: separate launches, b: fused
+            st[tag] = dict(p=flat.clone(), m=torch.zeros(nf, device="cuda"), v=torch.zeros(nf, device="cuda"),
+                           packed=torch.zeros(npk, device="cuda"), gn=torch.zeros(1, dtype=torch.float64, device="cuda"))
+            check(L, L.rlppo_net_pack(stream(), dc, nl, P(st[tag]["p"]), P(st[tag]["packed"])))
+        state.append(st)
+    for step in range(1, 6):
+        descs = []
+        for st in state:
+            g = torch.randn(st["nf"], device="cuda") * (5.0 if step % 2 else 1e-4)
+            ga, gb = g.clone(), g.clone()
+            a, b = st["a"], st["b"]
+            check(L, L.rlppo_clip_adam(stream(), P(a["p"]), P(ga), P(a["m"]), P(a["v"]), st["nf"], 0.5, 3e-4, 0.9, 0.999, 1e-8, step, P(a["gn"])))
+            check(L, L.rlppo_net_pack(stream(), st["dc"], st["nl"], P(a["p"]), P(a["packed"])))
+            d = N.OptNet()
+            d.dims, d.n_layers = ctypes.cast(st["dc"], ctypes.POINTER(ctypes.c_int32)), st["nl"]
+            d.params, d.grads, d.exp_avg, d.exp_avg_sq = b["p"].data_ptr(), gb.data_ptr(), b["m"].data_ptr(), b["v"].data_ptr()
+            d.packed, d.gnorm2 = b["packed"].data_ptr(), b["gn"].data_ptr()
+            d.max_norm, d.lr, d.beta1, d.beta2, d.eps, d.step = 0.5, 3e-4, 0.9, 0.999, 1e-8, step
+            descs.append((d, gb))
+        check(L, L.rlppo_clip_adam_pack2(stream(), ctypes.byref(descs[0][0]), ctypes.byref(descs[1][0])))
+        torch.cuda.synchronize()
+        for st, (_, gb) in zip(state, descs):
+            a, b = st["a"], st["b"]
+            for k in ("p", "m", "v", "packed"):
+                assert torch.equal(a[k], b[k]), (step, k)
+            assert (gb == 0).all()
+            assert abs(a["gn"].item() - b["gn"].item()) <= 1e-12 * a["gn"].item()
+    bad = N.OptNet()
+    assert L.rlppo_clip_adam_pack2(stream(), ctypes.byref(bad), ctypes.byref(descs[1][0])) != 0
