@@ -311,3 +311,41 @@ def test_fused_minibatches_equal_separate_passes():
               "Value Function Update Magnitude"):
         assert abs(r8[k] - r1[k]) <= 5e-5 * max(abs(r1[k]), 1e-3) + 1e-7, (k, r8[k], r1[k])
     assert r8["Cumulative Model Updates"] == r1["Cumulative Model Updates"] == 3
+
+
+def test_get_action_graph_replay_equals_eager_path():
+    """DiscreteFF.get_action replays one hipGraph per batch-size bucket (copies + staging + forward + sampling + read-back):
+    same actions and log-probabilities, bit for bit, as the eager path; the graph reads the CURRENT weights (the packed copy
+    is refreshed in place after an optimiser step), serves every n of its bucket and float64 observations."""
+    from rlgym_ppo_amd.ppo import DiscreteFF
+    torch.manual_seed(21)
+    pol = DiscreteFF(107, 90, (64, 64), "cuda:0")
+    rs = np.random.RandomState(2)
+    for round_ in range(2):
+        for n in (1, 8, 17, 80, 129, 700):
+            obs = np.clip(rs.randn(n, 107), -5, 5).astype(np.float32 if n % 2 else np.float64)
+            q = torch.empty(n, 90).exponential_(1)
+            pol.act_graphs = True
+            a1, l1 = pol.get_action(obs, noise=q)
+            pol.act_graphs = False
+            a0, l0 = pol.get_action(obs, noise=q)
+            assert a1.dtype == torch.int64 and a1.device.type == "cpu" and a1.shape == (n,)
+            assert torch.equal(a0, a1) and torch.equal(l0, l1), (round_, n)
+        # default noise: the same CPU generator stream either way
+        obs = np.clip(rs.randn(33, 107), -5, 5).astype(np.float32)
+        pol.act_graphs = True
+        torch.manual_seed(5)
+        a1, l1 = pol.get_action(obs)
+        pol.act_graphs = False
+        torch.manual_seed(5)
+        a0, l0 = pol.get_action(obs)
+        assert torch.equal(a0, a1) and torch.equal(l0, l1)
+        with torch.no_grad():  # new weights: the next round must see them through the same graphs
+            for p in pol.parameters():
+                p.add_(torch.randn_like(p) * 0.05)
+        pol.arena.native_epoch += 1
+    assert set(pol._graphs) == {16, 32, 80, 256, 1024, 48}
+    pol.act_graphs = True
+    big = np.clip(rs.randn(1500, 107), -5, 5).astype(np.float32)      # above act_graph_max: the eager path, no new graph
+    pol.get_action(big)
+    assert set(pol._graphs) == {16, 32, 80, 256, 1024, 48}
