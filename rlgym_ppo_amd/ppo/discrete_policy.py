@@ -21,8 +21,7 @@ class _ActGraph:
     host memory (hipHostMalloc memory is mapped into the GPU's address space), and the actions / log-probabilities are written
     straight into pinned host memory.  At the reference's rollout scale (8-80 observations per call,
     batched_agent_manager.py:202-204) a call is nothing but latency -- ~7 launches, three copies and two blocking read-backs,
-    ~140-250 us; one replay + one synchronisation does the same work.  (Copy NODES inside a graph were measured at ~40 MB/s
-    on this stack, hence zero-copy.)  Same kernels, same arguments: results are those of the eager path bit for bit.  Rows past
+    ~140-250 us; one replay + one synchronisation does the same work, with no copy node at all.  Same kernels, same arguments: results are those of the eager path bit for bit.  Rows past
     the caller's n hold stale data and are ignored."""
 
     def __init__(self, pol, cap):
