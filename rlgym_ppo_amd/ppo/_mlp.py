@@ -5,9 +5,14 @@ constructors (rlgym_ppo/ppo/discrete_policy.py:21-31, continuous_policy.py:29-41
 multi_discrete_policy.py:22-32, value_estimator.py:18-28): layers are built on the CPU first (so a seeded run
 starts from the reference's weights bit for bit) and only then moved to the GPU arena.
 """
+import os
+
+import numpy as np
+import torch
 import torch.nn as nn
 
-from ..engine import NetArena, linears_of, require_gpu
+from .. import _native as N
+from ..engine import NetArena, linears_of, ptr, require_gpu, stream_ptr
 
 
 def build_body(input_shape, layer_sizes, n_out, final_activation=None):
@@ -24,6 +29,59 @@ def build_body(input_shape, layer_sizes, n_out, final_activation=None):
     return nn.Sequential(*layers)
 
 
+class ActGraph:
+    """One hipGraph of the whole rollout step of a policy head for up to `cap` observations, with no copy in it:
+    rlppo_pad_rows reads the observations and the head's act entry point (forward + sampling) reads its noise straight from
+    pinned host memory (hipHostMalloc memory is mapped into the GPU's address space), and the actions / log-probabilities are
+    written straight into pinned host memory.  At the reference's rollout scale (8-80 observations per call,
+    batched_agent_manager.py:202-204) a call is nothing but latency -- ~7 launches, three copies and two blocking read-backs,
+    ~140-250 us; one replay + one synchronisation does the same work, with no copy node at all.  Same kernels, same
+    arguments: results are those of the eager path bit for bit.  Rows past the caller's n hold stale data and are ignored."""
+
+    def __init__(self, pol, cap):
+        a = pol.arena
+        dev, d = a.device, a.d_in
+        self.cap = cap
+        self.obs_pin = torch.zeros(cap, d).pin_memory()
+        self.q_pin = torch.ones(pol._noise_shape(cap)).pin_memory()
+        self.rows = torch.zeros(cap, a.ld_in, device=dev)
+        self.act_pin = pol._action_buffer(cap).pin_memory()
+        self.logp_pin = torch.zeros(cap, dtype=torch.float32).pin_memory()
+        self.ws = torch.empty(int(N.lib().rlppo_forward_workspace_bytes(a.dims_c, a.n_layers, cap)), dtype=torch.uint8, device=dev)
+        L = N.lib()
+
+        def body():
+            N.check(L.rlppo_pad_rows(stream_ptr(), ptr(self.obs_pin), 0, cap, d, d, ptr(self.rows), a.ld_in, 0, 0.0, 1.0))
+            pol._act_launch(self.rows, cap, self.q_pin, self.act_pin, self.logp_pin, self.ws)
+
+        side = torch.cuda.Stream(dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            body()
+        side.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            body()
+
+    def run(self, obs, q, n):
+        self.obs_pin[:n].numpy()[...] = obs
+        # plain memcpy: Tensor.copy_ fans out to an OpenMP team above 32k elements (10 ms on a 256-thread host)
+        self.q_pin.view(-1)[:q.numel()].numpy()[...] = q.reshape(-1).numpy()
+        self.graph.replay()
+        torch.cuda.current_stream().synchronize()
+        return self.act_pin[:n].clone(), self.logp_pin[:n].clone()
+
+
+def _bucket(n):
+    """Capacity of the graph that serves n observations: multiples of 16 up to 128, then powers of two."""
+    if n <= 128:
+        return (n + 15) // 16 * 16
+    c = 256
+    while c < n:
+        c *= 2
+    return c
+
+
 class ArenaModule(nn.Module):
     """nn.Module whose `self.model` Linear parameters live in a NetArena on the GPU."""
 
@@ -37,6 +95,32 @@ class ArenaModule(nn.Module):
         dev = require_gpu(device)
         self.model = self.model.to(dev)
         self.arena = NetArena(linears_of(self.model), dev)
+        self.act_graphs = os.environ.get("RLPPO_ACT_GRAPH", "1") != "0"  # get_action through a hipGraph per batch-size bucket
+        self.act_graph_max = 1024  # beyond that the explicit copies of the eager path are the better transport for the noise
+        self._graphs = {}
+
+    def _graph_act(self, obs, noise, standardize):
+        """get_action for a small HOST batch as one graph replay, or None when that form does not apply (device inputs, fused
+        standardisation, device-drawn noise, more than act_graph_max rows): the caller then takes the eager path."""
+        if not self.act_graphs or standardize is not None or self.noise_mode != "host":
+            return None
+        if (isinstance(obs, torch.Tensor) and obs.is_cuda) or (isinstance(noise, torch.Tensor) and noise.is_cuda):
+            return None
+        a = self.arena
+        o = np.asarray(obs.detach().numpy() if isinstance(obs, torch.Tensor) else obs)
+        if o.ndim == 1:
+            o = o.reshape(1, -1)
+        if o.ndim != 2 or o.shape[1] != a.d_in or not (0 < o.shape[0] <= self.act_graph_max):
+            return None
+        n = o.shape[0]
+        q = self._draw_noise(n) if noise is None else torch.as_tensor(noise, dtype=torch.float32)
+        if tuple(q.shape) != tuple(self._noise_shape(n)):
+            return None
+        g = self._graphs.get(_bucket(n))
+        if g is None:
+            g = self._graphs[_bucket(n)] = ActGraph(self, _bucket(n))
+        a.ensure_packed()
+        return g.run(o.astype(np.float32, copy=False), q.contiguous(), n)
 
     def _apply(self, fn, *a, **k):  # .to()/.float()/... : re-bind afterwards so the kernels keep seeing the params
         out = super()._apply(fn, *a, **k)

@@ -34,9 +34,28 @@ class ContinuousPolicy(ArenaModule):
             eps = torch.empty(mean.shape).normal_(0, 1).to(a.device) if noise is None else torch.as_tensor(noise).to(a.device)
             action = (eps * std + mean).clamp(min=-1, max=1)
             return action.cpu(), self.logpdf(action, mean, std).cpu()
+        out = self._graph_act(obs, noise, standardize)  # small host batches: one hipGraph replay (ppo/_mlp.py)
+        if out is not None:
+            return out
         rows = a.stage_obs(obs, standardize)
         actions, logp = self.act_padded(rows, noise)
         return actions.cpu(), logp.cpu()
+
+    # ---- hooks of the graph-replayed rollout step (ppo/_mlp.py::ActGraph)
+    def _noise_shape(self, n):
+        return (n, self.n_out // 2)
+
+    def _draw_noise(self, n):
+        return torch.empty(n, self.n_out // 2).normal_(0, 1)  # what Normal.sample() draws on the reference's CPU path
+
+    def _action_buffer(self, cap):
+        return torch.zeros((cap, self.n_out // 2), dtype=torch.float32)
+
+    def _act_launch(self, rows, n, noise, actions, logp, ws):
+        a = self.arena
+        N.check(N.lib().rlppo_gaussian_act(stream_ptr(), a.dims_c, a.n_layers, ptr(a.packed), ptr(rows), rows.shape[1], n,
+                                           ptr(noise), float(self.affine_map.m), float(self.affine_map.b), ptr(actions),
+                                           ptr(logp), ptr(ws), ws.numel()))
 
     def act_padded(self, rows, noise=None):
         """Padded device rows -> (actions fp32 [n, k], summed log_probs fp32 [n]) on the device (see DiscreteFF.act_padded)."""

@@ -33,9 +33,27 @@ class MultiDiscreteFF(ArenaModule):
                 action.append(logits[..., start:start + split].argmax(dim=-1))
                 start += split
             return torch.stack(action).cpu().numpy(), 0
+        out = self._graph_act(obs, noise, standardize)  # small host batches: one hipGraph replay (ppo/_mlp.py)
+        if out is not None:
+            return out
         rows = a.stage_obs(obs, standardize)
         actions, logp = self.act_padded(rows, noise)
         return actions.cpu(), logp.cpu()
+
+    # ---- hooks of the graph-replayed rollout step (ppo/_mlp.py::ActGraph)
+    def _noise_shape(self, n):
+        return (n * 8, 3)
+
+    def _draw_noise(self, n):
+        return torch.empty(n * 8, 3).exponential_(1)  # Categorical.sample -> multinomial on [n*8, 3]
+
+    def _action_buffer(self, cap):
+        return torch.zeros((cap, 8), dtype=torch.int64)
+
+    def _act_launch(self, rows, n, noise, actions, logp, ws):
+        a = self.arena
+        N.check(N.lib().rlppo_multidiscrete_act(stream_ptr(), a.dims_c, a.n_layers, ptr(a.packed), ptr(rows), rows.shape[1],
+                                                n, ptr(noise), ptr(actions), ptr(logp), ptr(ws), ws.numel()))
 
     def act_padded(self, rows, noise=None):
         """Padded device rows -> (actions int64 [n, 8], log_probs fp32 [n]) on the device (see DiscreteFF.act_padded)."""

@@ -349,3 +349,30 @@ def test_get_action_graph_replay_equals_eager_path():
     big = np.clip(rs.randn(1500, 107), -5, 5).astype(np.float32)      # above act_graph_max: the eager path, no new graph
     pol.get_action(big)
     assert set(pol._graphs) == {16, 32, 80, 256, 1024, 48}
+
+
+def test_get_action_graph_replay_other_heads():
+    """The graph-replayed rollout step of the Gaussian and the multi-discrete heads: bit-identical to their eager paths, with
+    given noise and with the default CPU-generator draw."""
+    from rlgym_ppo_amd.ppo import ContinuousPolicy, MultiDiscreteFF
+    torch.manual_seed(22)
+    rs = np.random.RandomState(3)
+    heads = [(ContinuousPolicy(231, 16, (64, 64), "cuda:0"), 231, lambda n: torch.empty(n, 8).normal_(0, 1)),
+             (MultiDiscreteFF(107, (64, 64), "cuda:0"), 107, lambda n: torch.empty(n * 8, 3).exponential_(1))]
+    for pol, d, draw in heads:
+        for n in (3, 40, 300):
+            obs = np.clip(rs.randn(n, d), -5, 5).astype(np.float32)
+            q = draw(n)
+            pol.act_graphs = True
+            a1, l1 = pol.get_action(obs, noise=q)
+            pol.act_graphs = False
+            a0, l0 = pol.get_action(obs, noise=q)
+            assert a1.shape == a0.shape and a1.dtype == a0.dtype and torch.equal(a0, a1) and torch.equal(l0, l1), (type(pol).__name__, n)
+            pol.act_graphs = True
+            torch.manual_seed(9)
+            a1, l1 = pol.get_action(obs)
+            pol.act_graphs = False
+            torch.manual_seed(9)
+            a0, l0 = pol.get_action(obs)
+            assert torch.equal(a0, a1) and torch.equal(l0, l1)
+        assert set(pol._graphs) == {16, 48, 512}
