@@ -60,7 +60,8 @@ class ActGraph:
             body()
         side.synchronize()
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        # thread_local: the shuffle pipeline's helper threads may be issuing copies / events on their own stream right now
+        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
             body()
 
     def run(self, obs, q, n):
