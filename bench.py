@@ -126,34 +126,34 @@ def kernel_breakdown(learner):
     dW = torch.zeros(256 * 256, device=dev)
     db = torch.zeros(256, device=dev)
 
-    def nt(A, lda, ridx, ldb, C, ldc, n, k, epi, mask=None):
-        return lambda: N.check(L.rlppo_dbg_gemm_nt(st(), P(A), lda, P(ridx) if ridx is not None else None, P(W), ldb, P(bias),
-                                                    P(mask) if mask is not None else None, n, P(C), ldc, M, n, k, epi))
+    def nt(A, lda, ldb, C, ldc, n, k, epi, mask=None):
+        return lambda: N.check(L.rlppo_dbg_gemm_nt(st(), P(A), lda, P(W), ldb, P(bias), P(mask) if mask is not None else None, n,
+                                                    P(C), ldc, M, n, k, epi))
 
     tn_ws = torch.empty(max(max(int(L.rlppo_dbg_gemm_tn_workspace_bytes(o, i, M)) for o, i in ((256, 256), (256, 107), (90, 256))), 1),
-                        dtype=torch.uint8, device=dev)  # too small a workspace silently selects the atomic form
+                        dtype=torch.uint8, device=dev)
 
     # the forms the update launches for 128-multiple widths: the hidden-layer forward also writes the ReLU bitmask, the masked
-    # dX product reads it (csrc/gemm_sa.hip); the bitmask buffer here is written by the forward launches timed first
+    # dX product reads it (csrc/gemm.hip); the bitmask buffer here is written by the forward launches timed first
     bits = torch.zeros(max(int(L.rlppo_dbg_gemm_nt_bits_bytes(M, 256)), 8), dtype=torch.uint8, device=dev)
 
     def ntb(A, lda, C, ldc, n, k, epi):
         return lambda: N.check(L.rlppo_dbg_gemm_nt_bits(st(), P(A), lda, P(W), lda, P(bias) if epi == 1 else None, P(C), ldc, M, n, k,
                                                         epi, P(bits)))
 
-    def tn(dY, ny, X, kx, ridx, out, in_):  # the form the update uses: partial tiles + reduction kernel (both timed)
-        return lambda: N.check(L.rlppo_dbg_gemm_tn_ws(st(), P(dY), ny, ny, P(X), kx, kx, P(dW), P(db), out, in_, M, P(tn_ws),
-                                                       tn_ws.numel()))
+    def tn(dY, ny, X, kx, out, in_):  # partial tiles + reduction kernel (both timed)
+        return lambda: N.check(L.rlppo_dbg_gemm_tn(st(), P(dY), ny, ny, P(X), kx, kx, P(dW), P(db), out, in_, M, P(tn_ws),
+                                                    tn_ws.numel()))
 
     shapes = [
         ("gemm_nt fwd L0 128->256 +bitmask (x2 nets)", 2, ntb(A128, 128, C256, 256, 256, 128, 1), 2 * M * 256 * 128),
         ("gemm_nt fwd hidden 256->256 +bitmask (x4)", 4, ntb(A256, 256, C256, 256, 256, 256, 1), 2 * M * 256 * 256),
-        ("gemm_nt fwd head 256->96", 1, nt(A256, 256, None, 256, C96, 96, 96, 256, 0), 2 * M * 96 * 256),
+        ("gemm_nt fwd head 256->96", 1, nt(A256, 256, 256, C96, 96, 96, 256, 0), 2 * M * 96 * 256),
         ("gemm_nt dX hidden 256->256 bitmask (x4)", 4, ntb(A256, 256, C256, 256, 256, 256, 3), 2 * M * 256 * 256),
         ("gemm_nt dX head 96->256 bitmask", 1, ntb(A96, 96, C256, 256, 256, 96, 3), 2 * M * 256 * 96),
-        ("gemm_tn dW hidden 256x256 (x4)", 4, tn(A256, 256, A256b, 256, None, 256, 256), 2 * M * 256 * 256),
-        ("gemm_tn dW L0 256x107 (x2)", 2, tn(A256, 256, A128, 128, None, 256, 107), 2 * M * 256 * 128),
-        ("gemm_tn dW head 90x256", 1, tn(A96, 96, A256, 256, None, 90, 256), 2 * M * 128 * 256),
+        ("gemm_tn dW hidden 256x256 (x4)", 4, tn(A256, 256, A256b, 256, 256, 256), 2 * M * 256 * 256),
+        ("gemm_tn dW L0 256x107 (x2)", 2, tn(A256, 256, A128, 128, 256, 107), 2 * M * 256 * 128),
+        ("gemm_tn dW head 90x256", 1, tn(A96, 96, A256, 256, 90, 256), 2 * M * 128 * 256),
     ]
     rows = []
     for name, count, fn, flop in shapes:
@@ -279,15 +279,16 @@ def rollout_bench(learner):
                 note="host_noise = torch CPU exponential_ draw (bit-exact action parity mode) + H2D/D2H included")
 
 
-def cpu_baseline(seed=123):
+def cpu_baseline(seed=123, reps=3):
     """The oracle's learn() (torch-CPU eager, the reference's op sequence; kind "port") on a BOUNDED sample of the same
-    workload: one optimiser step over the whole 524,288-sample cfg2 buffer = 8 minibatches of 65,536, 1 epoch (same nets, same
-    minibatch size, same per-sample work as the GPU run).  Thread count: the better of 16 and min(cores, 64) -- on the
-    256-thread GPU-box host, torch-CPU with all hardware threads is ~20x SLOWER than with 16-64 (oversubscribed MKL/OpenMP),
-    which would misrepresent the reference."""
+    workload: one optimiser step over 131,072 samples of the cfg2 buffer = 2 minibatches of 65,536 (same nets, same minibatch
+    size, same per-sample work as the GPU run), `reps` warm repetitions per thread count, median.
+    Thread counts: 16 and min(cores, 64) are both timed and both reported -- on the 256-thread GPU-box host torch-CPU with all
+    hardware threads is ~20x SLOWER than with 16-64 (oversubscribed MKL/OpenMP), which would misrepresent the reference;
+    `value` is the better median."""
     from oracle import nets, ppo
     cores = os.cpu_count() or 1
-    n, B = N_SAMPLES, BATCH
+    n = B = 2 * MINIBATCH
     torch.manual_seed(seed)
     g = torch.Generator().manual_seed(seed)
     states = torch.randn(n, OBS, generator=g).clamp_(-5, 5)
@@ -298,24 +299,41 @@ def cpu_baseline(seed=123):
         a, lp = nets.discrete_sample(probs, torch.empty(65536, ACT).exponential_(1, generator=g))
     buf = dict(states=states, actions=a.float().repeat(n // 65536), log_probs=lp.repeat(n // 65536),
                values=torch.randn(n, generator=g), advantages=torch.randn(n, generator=g))
-    best = None
+    per_threads, t_all = {}, time.perf_counter()
     for threads in sorted({min(cores, 16), min(cores, 64)}):
         torch.set_num_threads(threads)
-        pol = [(w.clone(), b.clone()) for w, b in pol0]
-        val = [(w.clone(), b.clone()) for w, b in val0]
-        t = time.perf_counter()
-        ppo.learn("discrete", pol, val, buf, B, MINIBATCH, 1, 0.2, 0.005, 3e-4, 3e-4, np.random.RandomState(seed))
-        dt = time.perf_counter() - t
-        if best is None or dt < best[0]:
-            best = (dt, threads)
-    dt, threads = best
-    return dict(value=round(n / dt), unit="samples/s", cores=threads, kind="port",
-                sample="1 optimiser step (1 epoch) over the 524,288-sample cfg2 buffer = 8 minibatches of 65,536, torch-CPU eager "
-                       "oracle, %d threads (best of 16 / min(cores,64), both timed; host has %d), %.1f s" % (threads, cores, dt))
+        times = []
+        for rep in range(reps + 1):  # the first repetition is the warm-up
+            pol = [(w.clone(), b.clone()) for w, b in pol0]
+            val = [(w.clone(), b.clone()) for w, b in val0]
+            t = time.perf_counter()
+            ppo.learn("discrete", pol, val, buf, B, MINIBATCH, 1, 0.2, 0.005, 3e-4, 3e-4, np.random.RandomState(seed))
+            if rep:
+                times.append(time.perf_counter() - t)
+        per_threads[threads] = float(np.median(times))
+    threads = min(per_threads, key=per_threads.get)
+    return dict(value=round(n / per_threads[threads]), unit="samples/s", cores=threads, kind="port",
+                by_threads={str(k): round(n / v) for k, v in per_threads.items()}, host_cores=cores,
+                sample="1 optimiser step (1 epoch) over 131,072 samples of the cfg2 workload = 2 minibatches of 65,536, torch-CPU "
+                       "eager oracle; %d warm repetitions per thread count, median; thread counts %s both timed (samples/s in "
+                       "by_threads), value = the better one; %.1f s in total"
+                       % (reps, sorted(per_threads), time.perf_counter() - t_all))
+
+
+BF16_MFMA_PEAK_TF = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA peak (the 5 PF headline figure includes 2:1 sparsity)
+
+
+def cfg5_rooflines(value, bf16):
+    """BASELINE configs[4]: 10,435,584 algorithmic flop/sample; 968 algorithmic B/sample read by the update."""
+    fps = CFG5["flop_per_sample"]
+    tf = fps * value / 1e12
+    out = {"update_flop_efficiency": dict(achieved=round(tf, 2), peak=MFMA_F32_PEAK_TF, unit="TFLOP/s", frac=round(tf / MFMA_F32_PEAK_TF, 4),
+                                          note="10,435,584 algorithmic flop/sample (SURVEY 8(d)) x measured samples/s, against the fp32 MFMA peak")}
+    return out
 
 
 # ---------------------------------------------------------------------------------------------------- main
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
@@ -324,8 +342,92 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip roofline / gae / rollout / cpu_baseline legs")
     ap.add_argument("--config", choices=("cfg2", "cfg5"), default="cfg2",
                     help="cfg2 = BASELINE configs[1] (the headline metric); cfg5 = configs[4] shape (Gaussian policy, obs 231, "
-                         "512x4 nets, fp32 update) -- update throughput only, no extra legs")
-    args = ap.parse_args()
+                         "512x4 nets) -- update throughput only, no extra legs")
+    ap.add_argument("--precision", choices=("fp32", "bf16"), default="fp32",
+                    help="update precision: fp32 (parity mode, default) or bf16 = bf16-operand forward / fp32 master, accumulate "
+                         "and backward (BASELINE configs[4]; rlppo_set_update_precision)")
+    ap.add_argument("--allreduce", choices=("torch", "direct", "ab"), default="ab",
+                    help="N > 1: gradient exchange through torch.distributed (RCCL), through librlppo's own RCCL communicator, or "
+                         "'ab' = the timed region uses torch.distributed and a short A/B of both follows (reported as `allreduce`)")
+    return ap.parse_args(argv)
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` with N > 1 and no torchrun environment: THIS process starts the N ranks itself, as fresh
+    children of torch.distributed.run, and relays rank 0's JSON line.  It makes no GPU call of its own (a process that has
+    initialised HIP must not be the parent of the ranks' exec chain on this pool), so everything below the import of torch is
+    host-only here."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // max(args.gpus, 1))))
+    log(f"bench.py: starting {args.gpus} ranks: {' '.join(cmd[1:8])} ...  (parent initialised HIP: {torch.cuda.is_initialized()})")
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    line = None
+    for out in proc.stdout:
+        out = out.rstrip("\n")
+        if out.startswith("{") and '"metric"' in out:
+            line = out
+        else:
+            log(out)
+    rc = proc.wait()
+    if line is not None:
+        print(line, flush=True)
+    return rc if line is None or rc != 0 else 0
+
+
+def allreduce_ab(learner, buf, steps, world, device, dist):
+    """N > 1 only, after the timed region: the same learn() steps with the gradient exchange through librlppo's own RCCL
+    communicator (rlppo_allreduce on the compute stream) next to torch.distributed's, plus the exchange alone in microseconds
+    per optimiser step (the 1.37 MB [grad_policy | grad_value] arena, 200 back-to-back collectives)."""
+    from rlgym_ppo_amd import dp
+    out = {}
+    grad = learner._grad_all
+    scratch = torch.zeros_like(grad)
+    for name in ("torch", "direct"):
+        dp.set_allreduce_backend(name)
+        try:
+            for _ in range(10):
+                dp.all_reduce_sum(scratch, dist)
+            dist.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(200):
+                dp.all_reduce_sum(scratch, dist)
+            torch.cuda.synchronize()
+            us = (time.perf_counter() - t0) / 200 * 1e6
+            learner.learn(buf)
+            dist.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                learner.learn(buf)
+            dist.barrier()
+            torch.cuda.synchronize()
+            t = torch.tensor([time.perf_counter() - t0, us], dtype=torch.float64, device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            out[name] = dict(us_per_allreduce=round(float(t[1]), 1), ms_per_step=round(float(t[0]) / steps * 1e3, 3),
+                             samples_per_s=round(steps * learner.n_epochs * BATCH / float(t[0]), 1))
+        except Exception as e:  # noqa: BLE001 -- the A/B must never take the headline number down with it
+            out[name] = dict(error=str(e)[:200])
+    dp.set_allreduce_backend("torch")
+    out["bytes"] = grad.numel() * 4
+    out["note"] = "same ranks, same workload, after the timed region; `value` above is the torch.distributed run"
+    return out
+
+
+def main():
+    args = parse_args()
+    torchrun = "WORLD_SIZE" in os.environ and "RANK" in os.environ
+    if args.gpus > 1 and not torchrun:
+        sys.exit(spawn_ranks(args))
 
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
@@ -333,25 +435,48 @@ def main():
     if world != args.gpus:
         log(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}; using WORLD_SIZE")
     # RLPPO_BENCH_DRYRUN=1: exercise the N > 1 code path on a single-GPU box (all ranks on cuda:0, gloo); numbers from
-    # such a run are meaningless and are tagged as such.  The driver's real runs use one rank per GPU over RCCL.
-    dryrun = os.environ.get("RLPPO_BENCH_DRYRUN") == "1"
+    # such a run are meaningless and are tagged as such.  =2: rendezvous + one CPU all-reduce only (no GPU at all: the
+    # launch-path check of tests/test_bench_spawn.py).  The driver's real runs use one rank per GPU over RCCL.
+    dry = os.environ.get("RLPPO_BENCH_DRYRUN", "")
+    dryrun = dry in ("1", "2")
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: what RCCL needs on this pool (exported there anyway)
+    if dry == "2":
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        ones = torch.ones(1)
+        dist.all_reduce(ones)
+        if rank == 0:
+            print(json.dumps({"metric": "ppo_update_samples_per_sec", "value": None, "unit": "samples/s", "n_gpus": int(ones.item()),
+                              "steps": args.steps, "warmup": args.warmup, "data": "none (DRY RUN 2: launch path only, no GPU work)",
+                              "hip_initialised": torch.cuda.is_initialized()}), flush=True)
+        dist.destroy_process_group()
+        return
     if dryrun:
         local_rank = 0
-    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: what RCCL needs on this pool (exported there anyway)
     torch.cuda.set_device(local_rank)
     device = f"cuda:{local_rank}"
-    import torch.distributed as dist
     if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if dryrun:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(device))
+        from rlgym_ppo_amd import dp
+        dp.set_allreduce_backend("direct" if args.allreduce == "direct" else "torch")
+        # the number of ranks the collective really spans: a sum of ones through the backend the run uses
+        ones = torch.ones(1, device=device)
+        dist.all_reduce(ones)
+        n_seen = int(ones.item())
+    else:
+        n_seen = 1
 
     import contextlib
     with contextlib.redirect_stdout(sys.stderr):
         learner, buf = build_workload(device, config=args.config)
     learner.n_epochs = args.epochs
+    if args.precision == "bf16":
+        from rlgym_ppo_amd.engine import set_update_precision
+        set_update_precision("bf16")
 
     def barrier():
         if world > 1:
@@ -373,18 +498,23 @@ def main():
 
     samples = args.steps * args.epochs * (N_SAMPLES // BATCH) * BATCH
     value = samples / dt
+    bf16 = args.precision == "bf16"
+    if args.config == "cfg2":
+        workload = ("BASELINE configs[1]: 4096 agents x 128 steps = 524,288-sample buffer, obs 107 f32, 90 discrete actions, "
+                    "256x3 policy + 256x3 critic; ppo_batch 524,288, minibatch 65,536")
+    else:
+        workload = ("BASELINE configs[4]: 524,288-sample buffer, obs 231 f32, Gaussian policy with 8 actions, 512x4 policy + 512x4 "
+                    "critic, " + ("bf16-operand forward / fp32 master weights, accumulation and backward" if bf16 else "fp32 update") +
+                    "; ppo_batch 524,288, minibatch 65,536")
+    per_rank = 8 // world if 8 % world == 0 else 1
     out = {
-        "metric": "ppo_update_samples_per_sec", "value": round(value, 1), "unit": "samples/s", "n_gpus": world,
+        "metric": "ppo_update_samples_per_sec", "value": round(value, 1), "unit": "samples/s", "n_gpus": n_seen,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
-        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "bf16" if bf16 else "f32",
         "data": "synthetic" + (" (DRY RUN: all ranks on one GPU over gloo, not a measurement)" if dryrun else ""),
-        "config": {"workload": ("BASELINE configs[1]: 4096 agents x 128 steps = 524,288-sample buffer, obs 107 f32, "
-                                "90 discrete actions, 256x3 policy + 256x3 critic; ppo_batch 524,288, minibatch 65,536")
-                   if args.config == "cfg2" else
-                   ("BASELINE configs[4] shape: 524,288-sample buffer, obs 231 f32, Gaussian policy with 8 actions, 512x4 policy + "
-                    "512x4 critic, fp32 update (the bf16 forward is a rollout option); ppo_batch 524,288, minibatch 65,536"),
-                   "epochs_per_step": args.epochs, "samples_per_step": args.epochs * BATCH,
-                   "parallelism": f"dp{world}: {8 // world if 8 % world == 0 else 1} consecutive minibatch slice(s) per rank and pass, 1 RCCL all-reduce/optimiser step",
+        "config": {"workload": workload, "epochs_per_step": args.epochs, "samples_per_step": args.epochs * BATCH,
+                   "parallelism": f"dp{world}: {per_rank} consecutive minibatch slice(s) per rank and pass, 1 RCCL all-reduce/optimiser step"
+                                  + (f" ({args.allreduce if args.allreduce != 'ab' else 'torch'}.distributed)" if world > 1 else ""),
                    "last_report": {k: (round(v, 6) if isinstance(v, float) else v) for k, v in report.items()}},
     }
     if world > 1 and args.config == "cfg2":  # achieved fraction of the MFMA roofline of the whole job (N x peak)
@@ -393,10 +523,29 @@ def main():
             frac=round(FLOP_PER_SAMPLE * value / 1e12 / (MFMA_F32_PEAK_TF * world), 4),
             note="1,931,776 algorithmic flop/sample x measured whole-job samples/s against %d x the fp32 MFMA peak" % world)
     if args.config == "cfg5":
-        fps = CFG5["flop_per_sample"]
-        out["update_flop_efficiency"] = dict(achieved=round(fps * value / 1e12, 2), peak=MFMA_F32_PEAK_TF, unit="TFLOP/s",
-                                             frac=round(fps * value / 1e12 / MFMA_F32_PEAK_TF, 4),
-                                             note="10,435,584 algorithmic flop/sample (SURVEY 8(d)) x measured samples/s")
+        out.update(cfg5_rooflines(value, bf16))
+
+    emitted = []
+
+    def emit():
+        if rank == 0 and not emitted:
+            emitted.append(1)
+            print(json.dumps(out), flush=True)
+
+    if world > 1 and args.allreduce == "ab" and not dryrun:
+        # watchdog: the direct communicator has its first multi-rank run here; if the A/B wedges, every rank still leaves with
+        # the headline line printed
+        import threading
+        done = threading.Event()
+
+        def bail():
+            if not done.wait(120.0):
+                out["allreduce"] = {"error": "A/B did not finish within 120 s; skipped"}
+                emit()
+                os._exit(0)
+        threading.Thread(target=bail, daemon=True).start()
+        out["allreduce"] = allreduce_ab(learner, buf, max(1, min(args.steps, 5)), world, device, dist)
+        done.set()
     if rank == 0 and world == 1 and not args.no_extras and args.config == "cfg2":
         rows, dom = kernel_breakdown(learner)
         for r in rows:
@@ -417,8 +566,7 @@ def main():
         out["gae"] = gae_bench()
         out["rollout"] = rollout_bench(learner)
         out["cpu_baseline"] = cpu_baseline()
-    if rank == 0:
-        print(json.dumps(out), flush=True)
+    emit()
     if world > 1:
         dist.destroy_process_group()
 

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define RLPPO_ABI_VERSION 1
+#define RLPPO_ABI_VERSION 2
 #define RLPPO_MAX_LAYERS 16
 
 #define RLPPO_OK 0
@@ -151,8 +151,11 @@ typedef struct rlppo_minibatch_args {
     const float *old_logp;        /* [N] */
     const float *targets;         /* [N]  value targets ("values" in the buffer) */
     const float *advantages;      /* [N] */
-    const int64_t *idx;           /* [mb] rows of this minibatch (a slice of the epoch's permutation) */
+    const int64_t *idx;           /* [mb] LOGICAL rows of this minibatch (a slice of the epoch's permutation) */
     int64_t mb;                   /* rows in this minibatch */
+    int64_t ring_base, ring_cap;  /* the experience arrays as a ring (the FIFO of experience_buffer.py:18-37 without the
+                                     torch.cat re-allocation): logical row i is physical row (i + ring_base) mod ring_cap;
+                                     ring_cap == 0: plain arrays */
     float clip_range;
     float ent_coef;
     float mb_ratio;               /* mini_batch_size / batch_size (ppo_learner.py:175) */
@@ -169,6 +172,7 @@ typedef struct rlppo_minibatch_args {
 #define RLPPO_STAT_PLOSS 4       /* += -mean(min(ratio*A, clamp(ratio)*A))  (diagnostic)      ppo_learner.py:172-174 */
 #define RLPPO_STAT_GNORM2_POL 5  /* written by rlppo_clip_adam: squared grad norm, policy */
 #define RLPPO_STAT_GNORM2_VAL 6
+#define RLPPO_STAT_PASSES 7      /* host side: number of rlppo_ppo_minibatch passes behind the sums (all-reduced with them) */
 #define RLPPO_N_STATS 8
 
 #define RLPPO_MAX_SLOTS 8
@@ -180,8 +184,8 @@ int rlppo_ppo_minibatch(void *stream, const rlppo_minibatch_args *args);
 
 /* Orders `stream` after every minibatch enqueued through non-zero slots since the last join (call it before the
  * gradient all-reduce / rlppo_clip_adam).  Independent minibatches of one batch only meet in the gradient arena
- * (atomic adds), so they may overlap; each launch is short (50-100 us), and overlapping chains fill the CUs that one
- * chain's ramp-up and tail leave idle. */
+ * (one add per element and launch), so they may overlap; each launch is short (50-100 us at 65,536 rows), and overlapping
+ * chains fill the CUs that one chain's ramp-up and tail leave idle. */
 int rlppo_ppo_join(void *stream);
 
 /* clip_grad_norm_(max_norm) + torch.optim.Adam.step() on one flat arena (ppo_learner.py:187-193).
@@ -250,10 +254,17 @@ int rlppo_apply_swap_targets(int64_t n, const uint32_t *targets, int64_t *out);
 int rlppo_gather_rows(void *stream, const float *src, int64_t ld_src, const int64_t *idx, float *dst, int32_t width, int64_t n);
 
 /* WelfordRunningStat.increment(samples, n) (running_stats.py:28-46) on the device, bit-exact with the reference's sample-by-
- * sample float32 update: mean[d], m2[d] (= running_mean, running_variance) are updated in place with the n rows of
- * `samples` (row stride ld floats); `count` is the number of samples already absorbed (the caller adds n afterwards). */
-int rlppo_welford_increment(void *stream, const float *samples, int64_t ld, int64_t n, int32_t d, float *mean, float *m2,
-                            int64_t count);
+ * sample update: mean[d], m2[d] (= running_mean, running_variance) are updated in place with the n rows of `samples` (fp32,
+ * row stride ld floats); `count` is the number of samples already absorbed (the caller adds n afterwards).  The state is
+ * float32 as the class constructs it, or float64 (state_is_f64 != 0) as WelfordRunningStat.from_json leaves it after a
+ * checkpoint load (running_stats.py:121-125: np.asarray of Python floats) -- the reference then updates in float64. */
+int rlppo_welford_increment(void *stream, const float *samples, int64_t ld, int64_t n, int32_t d, void *mean, void *m2,
+                            int64_t count, int32_t state_is_f64);
+/* WelfordRunningStat.increment_from_serialized_other (running_stats.py:71-98): combine the running statistics of another
+ * instance (other_mean[d], other_m2[d] fp32 -- the reference casts the serialised list to float32 -- and other_count) into
+ * mean / m2 in place, in the reference's operation order; the caller sets count += other_count.  SURVEY.md 8(f) row 4. */
+int rlppo_welford_merge(void *stream, int32_t d, void *mean, void *m2, int64_t count, const float *other_mean,
+                        const float *other_m2, int64_t other_count, int32_t state_is_f64);
 
 /* Precision of the ROLLOUT forward passes (rlppo_mlp_forward, rlppo_*_act): 0 = fp32 (default; the parity mode),
  * 1 = activations and master weights rounded to bf16 as MFMA operands, fp32 accumulation / bias / activation
@@ -262,56 +273,29 @@ int rlppo_welford_increment(void *stream, const float *samples, int64_t ld, int6
 int rlppo_set_inference_precision(int32_t mode);
 
 /* ------------------------------------------------------------------------------------------ diagnostics */
-/* Single-kernel entry points used by tests/ to check each GEMM flavour in isolation against a CPU product.
- * epilogue: 0 bias, 1 bias+relu, 2 bias+tanh, 3 relu-mask (mask_src > 0).  Shapes as in csrc/gemm.hip. */
-/* Tuning switches for A/B measurements (also RLPPO_TUNE="key=value,..." in the Python host).  Defaults in brackets.
- *   1 GAE algorithm [1 single-pass look-back | 0 two launches]     2 gemm_tn rows per workgroup override [0 = table]
- *   3 gemm.hip gemm_nt form [0 staged | 1 weights-stationary]      4 policy/critic chains on two streams [1]
- *   5 gemm.hip gemm_nt K step [32 | 16]                            6 layer-fused chains [0]
- *   7 gemm.hip gemm_nt stagger units [0]                           8 dW kernels on side streams [0]
- *   9 gemm_nt kernel [3 LDS-DMA BK=16 | 2 LDS-DMA BK=32 | 1 scalar-addressed register staging | 0 gemm.hip]
- *  10 gemm_tn kernel [2 LDS-DMA 32-row stages | 3 16-row stages | 1 scalar-addressed register staging | 0 gemm.hip]
- *  11 minibatch states gathered once into the workspace [1] | gather fused into the four first-layer GEMMs [0]
- *  12 gemm_tn rows per workgroup for products of >= 4 output tiles [768]
- *  13 discrete loss kernel with 16 lanes per row for widths <= 128 [1] | one wave per row [0]
- *  14 value loss launched in the critic's chain, no join between forward and backward [1] | one joint loss kernel [0]
- *  15 one-output (critic) head as matrix-vector kernels [1] | through the padded GEMM kernels [0]
- *  16 dW through partial tiles + a reduction kernel [1] | fp32 atomics [0]
- *  17 gemm_nt with persistent workgroups when a launch has more tiles than resident slots [0]
- *  18 GAE chunks per workgroup [1]
- *  20 gemm_nt with three K tiles in flight, three workgroups per CU [0]
- *  19 ReLU bitmask written by the hidden-layer forward and read by the masked dX product [1] | dX re-reads the activation [0] */
+/* A/B switches for measurements and tests (also RLPPO_TUNE="key=value,..." in the Python host).  Defaults in brackets.
+ *   1 GAE algorithm [1 single-pass look-back | 0 two launches]
+ *   4 policy / critic chains of rlppo_ppo_minibatch on two streams [1]
+ *  21 GAE look-back spin limit before the raw-step slow path [-1 = default 2^18 | 0 = always the slow path (tests)] */
 int rlppo_dbg_set(int32_t key, int32_t value);
-/* Register-only fp32 MFMA loop: out[blocks*256] floats, clocks[2*blocks] = {shader cycles, 100 MHz ticks} per block. */
-/* GEMM inner-loop probe: 64 MFMAs per chunk + (mode&1) A fragments from LDS, (mode&2) B fragments from LDS, (mode&4) B
- * fragments from a 256x256 fp32 matrix W in global memory.  out: blocks*threads floats. */
-/* vector-memory path probe: every wave streams 8 KB per iteration with 8 dwordx4 loads; `pattern` picks the lane->address
- * map (0: 8 rows x 128 B, 1: 1 KB contiguous, 2: 4 rows x 256 B, 3: 16 x 64 B); span = power-of-two bytes walked. */
-int rlppo_dbg_probe_ld(void *stream, int32_t pattern, int32_t blocks, const void *buf, size_t span, int32_t iters, float *out);
-/* co-issue probe: 512 workgroups, the first 256 stream MFMAs, the last 256 issue batches of 8 global loads and record the
- * cycles each batch took to issue -> cycles[wave][2] = {issue, total}.  buf >= 16 MiB, out >= 512*256 floats. */
-int rlppo_dbg_probe_coissue(void *stream, const float *buf, int32_t flags, int32_t iters, uint64_t *cycles, float *out);
-int rlppo_dbg_probe2(void *stream, int32_t mode, int32_t threads, int32_t blocks, const float *W, float *out, int32_t chunks);
+/* Counter bumped by every call that changes which kernels later launches select (rlppo_dbg_set, rlppo_set_*_precision): a
+ * host that caches captured graphs of library calls keys them on it (rlgym_ppo_amd/ppo/_mlp.py::ActGraph). */
+int64_t rlppo_selection_epoch(void);
+/* Single-kernel entry points used by tests/ and bench.py to check / time each GEMM flavour in isolation.
+ * epilogue: 0 bias, 1 bias+relu, 2 bias+tanh, 3 relu-mask (mask_src > 0).  Shapes as in csrc/gemm.hip. */
+int rlppo_dbg_gemm_nt(void *stream, const float *A, int64_t lda, const float *B, int64_t ldb, const float *bias,
+                      const float *mask_src, int64_t ld_mask, float *C, int64_t ldc, int64_t M, int32_t N, int32_t K,
+                      int32_t epilogue);
 /* The bitmask form of the hidden-layer forward (epilogue 1: C = relu(A.B^T + bias), bits <- [C > 0], 8 bytes per lane and
  * 128 x 128 tile) and of the masked dX product (epilogue 3: C = (A.B^T) masked by bits).  N % 128 == 0. */
 size_t rlppo_dbg_gemm_nt_bits_bytes(int64_t M, int32_t N);
 int rlppo_dbg_gemm_nt_bits(void *stream, const float *A, int64_t lda, const float *B, int64_t ldb, const float *bias, float *C,
                            int64_t ldc, int64_t M, int32_t N, int32_t K, int32_t epilogue, void *bits);
-/* Stamped copy of the staged forward GEMM (bias+ReLU, N % 128 == 0): stamps[wg][wave][8] cycles per phase (csrc/probe.hip). */
-int rlppo_dbg_gemm_nt_stamped(void *stream, const float *A, int64_t lda, const float *B, int64_t ldb, const float *bias,
-                                float *C, int64_t ldc, int64_t M, int32_t N, int32_t K, uint64_t *stamps, int32_t mode);
-/* mode: 0 real; 1 every workgroup reads the same 1024 A rows (A from L2); 2 output stores dropped; 3 both (diagnostic) */
-int rlppo_dbg_mfma_probe(void *stream, float *out, int32_t blocks, int32_t iters, uint64_t *clocks);
-int rlppo_dbg_gemm_nt(void *stream, const float *A, int64_t lda, const int64_t *row_idx, const float *B, int64_t ldb,
-                      const float *bias, const float *mask_src, int64_t ld_mask, float *C, int64_t ldc, int64_t M,
-                      int32_t N, int32_t K, int32_t epilogue);
-int rlppo_dbg_gemm_tn(void *stream, const float *dY, int64_t ldy, int32_t ny_valid, const float *X, int64_t ldx,
-                      const int64_t *row_idx, int32_t kx_valid, float *dW, float *db, int32_t out, int32_t in, int64_t M);
-/* gemm_tn without a row gather, accumulating through partial tiles in `ws` (rlppo_dbg_gemm_tn_workspace_bytes) and a
- * reduction kernel instead of fp32 atomics: the form rlppo_ppo_minibatch uses. */
+/* dW[out][in] += dY^T . X, db[out] += colsum(dY) through partial tiles in `ws` (rlppo_dbg_gemm_tn_workspace_bytes) and a
+ * fixed-order reduction: the form rlppo_ppo_minibatch uses. */
 size_t rlppo_dbg_gemm_tn_workspace_bytes(int32_t out, int32_t in, int64_t M);
-int rlppo_dbg_gemm_tn_ws(void *stream, const float *dY, int64_t ldy, int32_t ny_valid, const float *X, int64_t ldx,
-                         int32_t kx_valid, float *dW, float *db, int32_t out, int32_t in, int64_t M, void *ws, size_t ws_bytes);
+int rlppo_dbg_gemm_tn(void *stream, const float *dY, int64_t ldy, int32_t ny_valid, const float *X, int64_t ldx,
+                      int32_t kx_valid, float *dW, float *db, int32_t out, int32_t in, int64_t M, void *ws, size_t ws_bytes);
 
 #ifdef __cplusplus
 }

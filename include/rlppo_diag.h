@@ -1,0 +1,33 @@
+/*
+ * rlppo_diag.h -- C ABI of librlppo_diag.so: measurement probes for gfx950 (NOT part of the product library; loaded only by
+ * tools/).  They produced the hardware findings quoted in DESIGN.md section 5 (sustained fp32 MFMA rate, vector-memory bytes per
+ * clock, the ~400-cycle VALU issue cost beside an MFMA stream, phase shares of a register-staged GEMM).  Same conventions as
+ * rlppo.h: device pointers, asynchronous on `stream`, 0 = OK.
+ */
+#ifndef RLPPO_DIAG_H
+#define RLPPO_DIAG_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+const char *rlppo_diag_last_error(void);
+/* Register-only fp32 MFMA loop: out[blocks*256] floats, clocks[2*blocks] = {shader cycles, 100 MHz ticks} per block. */
+int rlppo_dbg_mfma_probe(void *stream, float *out, int32_t blocks, int32_t iters, uint64_t *clocks);
+/* GEMM inner-loop probe: 64 MFMAs per chunk + (mode&1) A fragments from LDS, (mode&2) B fragments from LDS, (mode&4) B
+ * fragments from a 256x256 fp32 matrix W in global memory.  out: blocks*threads floats. */
+int rlppo_dbg_probe2(void *stream, int32_t mode, int32_t threads, int32_t blocks, const float *W, float *out, int32_t chunks);
+/* vector-memory path probe: every wave streams 8 KB per iteration with 8 dwordx4 loads; `pattern` picks the lane->address
+ * map (0: 8 rows x 128 B, 1: 1 KB contiguous, 2: 4 rows x 256 B, 3: 16 x 64 B); span = power-of-two bytes walked. */
+int rlppo_dbg_probe_ld(void *stream, int32_t pattern, int32_t blocks, const void *buf, size_t span, int32_t iters, float *out);
+/* co-issue probe: 512 workgroups, the first 256 stream MFMAs, the last 256 issue batches of 8 global loads and record the
+ * cycles each batch took to issue -> cycles[wave][2] = {issue, total}.  buf >= 16 MiB, out >= 512*256 floats. */
+int rlppo_dbg_probe_coissue(void *stream, const float *buf, int32_t flags, int32_t iters, uint64_t *cycles, float *out);
+/* Stamped register-staged forward GEMM (bias+ReLU, N % 128 == 0): stamps[wg][wave][8] cycles per phase.
+ * mode: 0 real; 1 every workgroup reads the same 1024 A rows (A from L2); 2 output stores dropped; 3 both */
+int rlppo_dbg_gemm_nt_stamped(void *stream, const float *A, int64_t lda, const float *B, int64_t ldb, const float *bias,
+                              float *C, int64_t ldc, int64_t M, int32_t N, int32_t K, uint64_t *stamps, int32_t mode);
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -11,12 +11,13 @@ from ctypes import POINTER, c_char_p, c_double, c_float, c_int32, c_int64, c_siz
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "librlppo.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 COMM_ID_BYTES = 128  # RLPPO_COMM_ID_BYTES
 MAX_LAYERS = 16
 N_STATS = 8
 MAX_SLOTS = 8
 STAT_ENTROPY, STAT_KL, STAT_VLOSS, STAT_CLIPFRAC, STAT_PLOSS = 0, 1, 2, 3, 4
+STAT_PASSES = 7  # host-side: passes of rlppo_ppo_minibatch behind the sums above (summed over ranks with them)
 HEAD_DISCRETE, HEAD_MULTIDISCRETE, HEAD_GAUSSIAN = 0, 1, 2
 
 
@@ -43,6 +44,7 @@ class MinibatchArgs(ctypes.Structure):
         ("pol_packed", c_void_p), ("val_packed", c_void_p), ("pol_grad", c_void_p), ("val_grad", c_void_p),
         ("states", c_void_p), ("ld_states", c_int64), ("actions", c_void_p), ("old_logp", c_void_p),
         ("targets", c_void_p), ("advantages", c_void_p), ("idx", c_void_p), ("mb", c_int64),
+        ("ring_base", c_int64), ("ring_cap", c_int64),
         ("clip_range", c_float), ("ent_coef", c_float), ("mb_ratio", c_float), ("var_m", c_float), ("var_b", c_float),
         ("stats", c_void_p), ("workspace", c_void_p), ("ws_bytes", c_size_t),
     ]
@@ -91,25 +93,19 @@ SIGNATURES = {
     "rlppo_mt19937_draw_targets": (c_int32, [POINTER(c_uint32), c_int64, c_void_p]),
     "rlppo_apply_swap_targets": (c_int32, [c_int64, c_void_p, c_void_p]),
     "rlppo_gather_rows": (c_int32, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int32, c_int64]),
-    "rlppo_welford_increment": (c_int32, [c_void_p, c_void_p, c_int64, c_int64, c_int32, c_void_p, c_void_p, c_int64]),
+    "rlppo_welford_increment": (c_int32, [c_void_p, c_void_p, c_int64, c_int64, c_int32, c_void_p, c_void_p, c_int64, c_int32]),
+    "rlppo_welford_merge": (c_int32, [c_void_p, c_int32, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int32]),
     "rlppo_set_inference_precision": (c_int32, [c_int32]),
     "rlppo_dbg_set": (c_int32, [c_int32, c_int32]),
-    "rlppo_dbg_probe_ld": (c_int32, [c_void_p, c_int32, c_int32, c_void_p, c_size_t, c_int32, c_void_p]),
-    "rlppo_dbg_probe_coissue": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p]),
-    "rlppo_dbg_probe2": (c_int32, [c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_int32]),
-    "rlppo_dbg_gemm_nt_stamped": (c_int32, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int64,
-                                            c_int32, c_int32, c_void_p, c_int32]),
-    "rlppo_dbg_mfma_probe": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_void_p]),
-    "rlppo_dbg_gemm_nt": (c_int32, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_void_p,
-                                    c_int64, c_void_p, c_int64, c_int64, c_int32, c_int32, c_int32]),
+    "rlppo_selection_epoch": (c_int64, []),
+    "rlppo_dbg_gemm_nt": (c_int32, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_int64,
+                                    c_int64, c_int32, c_int32, c_int32]),
     "rlppo_dbg_gemm_nt_bits_bytes": (c_size_t, [c_int64, c_int32]),
     "rlppo_dbg_gemm_nt_bits": (c_int32, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int64,
                                          c_int32, c_int32, c_int32, c_void_p]),
-    "rlppo_dbg_gemm_tn": (c_int32, [c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_int64, c_void_p, c_int32,
-                                    c_void_p, c_void_p, c_int32, c_int32, c_int64]),
     "rlppo_dbg_gemm_tn_workspace_bytes": (c_size_t, [c_int32, c_int32, c_int64]),
-    "rlppo_dbg_gemm_tn_ws": (c_int32, [c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_int64, c_int32, c_void_p, c_void_p,
-                                       c_int32, c_int32, c_int64, c_void_p, c_size_t]),
+    "rlppo_dbg_gemm_tn": (c_int32, [c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_int64, c_int32, c_void_p, c_void_p,
+                                    c_int32, c_int32, c_int64, c_void_p, c_size_t]),
 }
 
 _lib = None

@@ -132,18 +132,11 @@ class VectorAgentManager(object):
         return experience, metrics, N_, time.perf_counter() - t1
 
     def _increment_obs_stats(self, obs_dev):
-        """WelfordRunningStat.increment(obs, n) on the device (bit-exact with the host class's sample-by-sample float32
-        update, which costs ~10 ms of Python per 4096 samples); the host object stays the owner of the state (checkpoints)."""
-        from .. import _native as N
-        from ..engine import ptr, stream_ptr
-        st = self.obs_stats
-        n, d = obs_dev.shape
-        mean = torch.from_numpy(st.running_mean.reshape(-1).copy()).to(obs_dev.device)
-        m2 = torch.from_numpy(st.running_variance.reshape(-1).copy()).to(obs_dev.device)
-        N.check(N.lib().rlppo_welford_increment(stream_ptr(), ptr(obs_dev), d, n, d, ptr(mean), ptr(m2), int(st.count)))
-        st.running_mean[...] = mean.cpu().numpy().reshape(st.running_mean.shape)
-        st.running_variance[...] = m2.cpu().numpy().reshape(st.running_variance.shape)
-        st.count += n
+        """WelfordRunningStat.increment(obs, n) on the device (bit-exact with the host class's sample-by-sample update in the
+        state's dtype -- float32, or float64 after a checkpoint load -- which costs ~10 ms of Python per 4096 samples); the host
+        object stays the owner of the state (checkpoints)."""
+        from ..util import device_stats
+        device_stats.increment(self.obs_stats, obs_dev)
 
     def _track_rewards(self, r, ended):
         """Episode-reward average as batched_agent_manager.py:377-399 keeps it, one agent = one stream."""

@@ -65,38 +65,35 @@ static int max_pout(const NetLayout &net) {
 // Forward pass.  acts[l] receives the output of layer l ([n][pout_l]); for inference the caller passes two
 // ping-pong buffers, for training one buffer per layer (they are the saved activations of the backward pass).
 // Training only: bits[l] (may be null) receives the ReLU bitmask of hidden layer l and have_bits[l] says whether it was
-// written (csrc/gemm_sa.hip, launch_gemm_nt_bits); backward() then masks dX with it instead of re-reading acts[l].
-static int forward(hipStream_t st, const NetLayout &net, const float *packed, const float *obs, int64_t ld_obs,
-                   const int64_t *row_idx, int64_t n, int out_tanh, float *const *acts, int bf16_operands = 0,
-                   unsigned long long *const *bits = nullptr, bool *have_bits = nullptr) {
+// written (csrc/gemm.hip, launch_gemm_nt_bits); backward() then masks dX with it instead of re-reading acts[l].
+static int forward(hipStream_t st, const NetLayout &net, const float *packed, const float *obs, int64_t ld_obs, int64_t n,
+                   int out_tanh, float *const *acts, int bf16_operands = 0, unsigned long long *const *bits = nullptr,
+                   bool *have_bits = nullptr) {
     if (have_bits)
         for (int l = 0; l < net.n_layers; ++l) have_bits[l] = false;
-    if (fused_eligible(net, n)) return launch_fused_forward(st, net, packed, obs, ld_obs, row_idx, n, out_tanh, acts);
     const float *x = obs;
     int64_t ldx = ld_obs;
-    const int64_t *ridx = row_idx;
     for (int l = 0; l < net.n_layers; ++l) {
         const LayerLayout &L = net.L[l];
         const bool last = l == net.n_layers - 1;
         const int epi = last ? (out_tanh ? EPI_BIAS_TANH : EPI_BIAS) : EPI_BIAS_RELU;
         int rc;
-        if (last && !out_tanh && !ridx && gemv_head_ok(L.out, L.pin))  // one-output head: matrix-vector kernel (gemv.hip)
+        if (last && !out_tanh && gemv_head_ok(L.out, L.pin))  // one-output head: matrix-vector kernel (gemv.hip)
             rc = launch_gemv_fwd(st, x, ldx, packed + L.off_w, packed + L.off_b, acts[l], L.pout, n, L.pin, L.pout);
         else {
             rc = -1;
-            if (!last && bits && bits[l] && !ridx && !bf16_operands) {
+            if (!last && bits && bits[l] && !bf16_operands) {
                 rc = launch_gemm_nt_bits(st, x, ldx, packed + L.off_w, L.pin, packed + L.off_b, acts[l], L.pout, n, L.pout, L.pin,
                                          EPI_BIAS_RELU, bits[l]);
                 if (rc == 0) have_bits[l] = true;
             }
             if (rc == -1)
-                rc = launch_gemm_nt(st, x, ldx, ridx, packed + L.off_w, L.pin, packed + L.off_b, nullptr, 0, acts[l], L.pout, n,
-                                    L.pout, L.pin, epi, bf16_operands);
+                rc = launch_gemm_nt(st, x, ldx, packed + L.off_w, L.pin, packed + L.off_b, nullptr, 0, acts[l], L.pout, n, L.pout,
+                                    L.pin, epi, bf16_operands);
         }
         if (rc) return rc;
         x = acts[l];
         ldx = L.pout;
-        ridx = nullptr;
     }
     return 0;
 }
@@ -118,9 +115,7 @@ static int forward_pingpong(hipStream_t st, const NetLayout &net, const float *p
     float *acts[RLPPO_MAX_LAYERS];
     for (int l = 0; l < net.n_layers; ++l) acts[l] = (l & 1) ? b1 : b0;
     if (final_out) acts[net.n_layers - 1] = final_out;
-    if (fused_eligible(net, n))  // the fused chain keeps hidden activations on chip: nothing to store for inference
-        for (int l = 0; l + 1 < net.n_layers; ++l) acts[l] = nullptr;
-    int rc = forward(st, net, packed, obs, ld_obs, nullptr, n, out_tanh, acts, get_infer_bf16());  // inference only
+    int rc = forward(st, net, packed, obs, ld_obs, n, out_tanh, acts, get_infer_bf16());  // inference only
     if (rc) return rc;
     *out = acts[net.n_layers - 1];
     *ld_out = net.L[net.n_layers - 1].pout;
@@ -264,11 +259,7 @@ int rlppo_gae(void *stream, const float *rews, const float *dones, const float *
 // ------------------------------------------------------------------------------------------- PPO minibatch
 static int g_two_streams = 1;  // tuning: rlppo_dbg_set(4, 0/1)
 // Library-owned streams: slot s > 0 runs its policy chain on g_main[s]; every slot runs its critic chain on g_side[s].
-static hipStream_t g_main[RLPPO_MAX_SLOTS] = {}, g_side[RLPPO_MAX_SLOTS] = {}, g_dw[RLPPO_MAX_SLOTS][2] = {};
-static hipEvent_t g_ev_dw[RLPPO_MAX_SLOTS][2][RLPPO_MAX_LAYERS + 1] = {};
-static int g_split_loss = 1;  // tuning: rlppo_dbg_set(14, 0/1): value loss in the critic's chain (no mid-minibatch join)
-static int g_pregather = 1;  // tuning: rlppo_dbg_set(11, 0/1): gather the minibatch's states once instead of in 4 GEMMs
-static int g_dw_streams = 0;  // tuning: rlppo_dbg_set(8, 0/1); measured slower (14.4 vs 12.7 ms/epoch, tools/ab_update.py)
+static hipStream_t g_main[RLPPO_MAX_SLOTS] = {}, g_side[RLPPO_MAX_SLOTS] = {};
 static hipEvent_t g_ev_fork[RLPPO_MAX_SLOTS] = {}, g_ev_join[RLPPO_MAX_SLOTS] = {}, g_ev_slot[RLPPO_MAX_SLOTS] = {};
 static bool g_slot_pending[RLPPO_MAX_SLOTS] = {};
 
@@ -279,10 +270,6 @@ static int ensure_slot(int s) {
         RLPPO_HIP(hipEventCreateWithFlags(&g_ev_fork[s], hipEventDisableTiming));
         RLPPO_HIP(hipEventCreateWithFlags(&g_ev_join[s], hipEventDisableTiming));
         RLPPO_HIP(hipEventCreateWithFlags(&g_ev_slot[s], hipEventDisableTiming));
-        for (int n = 0; n < 2; ++n) {
-            RLPPO_HIP(hipStreamCreateWithFlags(&g_dw[s][n], hipStreamNonBlocking));
-            for (int l = 0; l <= RLPPO_MAX_LAYERS; ++l) RLPPO_HIP(hipEventCreateWithFlags(&g_ev_dw[s][n][l], hipEventDisableTiming));
-        }
     }
     return 0;
 }
@@ -327,58 +314,42 @@ size_t rlppo_minibatch_workspace_bytes(const int32_t *pol_dims, int32_t pol_laye
     return train_ws_floats(pol, val, mb > 0 ? mb : 0) * sizeof(float) + 256;
 }
 
-// backward of one net: acts[l] = saved output of layer l, acts[last] holds dL/d(out) on entry
-// Weight-gradient launches (gemm_tn) only depend on dY_l and the saved input of layer l, not on each other or on the rest
-// of the dX chain: with `dw` != `st` they go to a second stream so that a gemm_tn and a gemm_nt workgroup (different
-// kernels, 74 KB + 64 KB of LDS) share a CU instead of two copies of the same kernel running in lock step.
-static int backward(hipStream_t st, hipStream_t dw, hipEvent_t *ev, const NetLayout &net, const float *packed,
-                    const float *states, int64_t ld_states, const int64_t *idx, int64_t mb, float *const *acts,
-                    float *const *dx, float *grad, float *tn_ws, size_t tn_floats, unsigned long long *const *bits = nullptr,
-                    const bool *have_bits = nullptr) {
-    // dx[l-1] receives dL/d(acts[l-1]) = dY of layer l-1 (one buffer per layer: the dW launches read them later)
+// backward of one net: acts[l] = saved output of layer l, acts[last] holds dL/d(out) on entry; dx[l-1] receives
+// dL/d(acts[l-1]) = dY of layer l-1 (one buffer per layer: the dW launches read them later)
+static int backward(hipStream_t st, const NetLayout &net, const float *packed, const float *states, int64_t ld_states,
+                    int64_t mb, float *const *acts, float *const *dx, float *grad, float *tn_ws, size_t tn_floats,
+                    unsigned long long *const *bits, const bool *have_bits) {
     const int last = net.n_layers - 1;
-    const bool fused = fused_eligible(net, mb);
-    int rc;
-    if (fused) {  // whole dX chain in one launch (csrc/fused.hip), then the weight gradients
-        rc = launch_fused_backward(st, net, packed, mb, acts, dx);
-        if (rc) return rc;
-    }
+    int rc = 0;
     for (int l = last; l >= 0; --l) {
         const LayerLayout &L = net.L[l];
         const float *dY = l == last ? acts[last] : dx[l];
         const float *X = l > 0 ? acts[l - 1] : states;
         const int64_t ldx = l > 0 ? net.L[l - 1].pout : ld_states;
-        if (dw != st) {  // dY_l is complete at this point of `st`
-            rc = order_after(dw, st, ev[l]);
-            if (rc) return rc;
-        }
         const bool gemv = l == last && l > 0 && gemv_head_ok(L.out, L.pin);  // one-output head (gemv.hip)
         if (gemv)
-            rc = launch_gemv_dw(dw, dY, L.pout, X, ldx, grad + L.off_flat_w, grad + L.off_flat_b, L.in, L.pin, mb,
-                                tn_ws, tn_floats);
+            rc = launch_gemv_dw(st, dY, L.pout, X, ldx, grad + L.off_flat_w, grad + L.off_flat_b, L.in, L.pin, mb, tn_ws, tn_floats);
         else
-            rc = launch_gemm_tn(dw, dY, L.pout, L.pout, X, ldx, l > 0 ? nullptr : idx, L.pin, grad + L.off_flat_w,
-                                grad + L.off_flat_b, L.out, L.in, mb, tn_ws, tn_floats);  // all dW launches of a net share one stream
+            rc = launch_gemm_tn(st, dY, L.pout, L.pout, X, ldx, L.pin, grad + L.off_flat_w, grad + L.off_flat_b, L.out, L.in, mb,
+                                tn_ws, tn_floats);
         if (rc) return rc;
-        if (gemv && !fused) {
-            rc = -1;
-            if (have_bits && have_bits[l - 1])
-                rc = launch_gemv_dx_bits(st, dY, L.pout, packed + L.off_w, bits[l - 1], dx[l - 1], L.pin, L.pin, mb);
+        if (l == 0) break;
+        // dX[mb][pin] = (dY[mb][pout] . W[pout][pin]) masked by relu'(acts[l-1]); B operand = W^T [pin][pout].  The mask is the
+        // bitmask the forward left when there is one (no re-read of the activation), else the saved activation itself.
+        rc = -1;
+        if (gemv) {
+            if (have_bits[l - 1]) rc = launch_gemv_dx_bits(st, dY, L.pout, packed + L.off_w, bits[l - 1], dx[l - 1], L.pin, L.pin, mb);
             if (rc == -1) rc = launch_gemv_dx(st, dY, L.pout, packed + L.off_w, acts[l - 1], L.pin, dx[l - 1], L.pin, L.pin, mb);
-            if (rc) return rc;
-        } else if (l > 0 && !fused) {
-            // dX[mb][pin] = (dY[mb][pout] . W[pout][pin]) masked by relu'(acts[l-1]); B operand = W^T [pin][pout]
-            rc = -1;
-            if (have_bits && have_bits[l - 1])  // the forward left the ReLU bitmask of acts[l-1]: no re-read of the activation
+        } else {
+            if (have_bits[l - 1])
                 rc = launch_gemm_nt_bits(st, dY, L.pout, packed + L.off_wt, L.pout, nullptr, dx[l - 1], L.pin, mb, L.pin, L.pout,
                                          EPI_MASK, bits[l - 1]);
             if (rc == -1)
-                rc = launch_gemm_nt(st, dY, L.pout, nullptr, packed + L.off_wt, L.pout, nullptr, acts[l - 1], L.pin, dx[l - 1],
-                                    L.pin, mb, L.pin, L.pout, EPI_MASK);
-            if (rc) return rc;
+                rc = launch_gemm_nt(st, dY, L.pout, packed + L.off_wt, L.pout, nullptr, acts[l - 1], L.pin, dx[l - 1], L.pin, mb,
+                                    L.pin, L.pout, EPI_MASK);
         }
+        if (rc) return rc;
     }
-    if (dw != st) rc = order_after(st, dw, ev[RLPPO_MAX_LAYERS]);
     return rc;
 }
 
@@ -409,6 +380,10 @@ int rlppo_ppo_minibatch(void *stream, const rlppo_minibatch_args *a) {
     if (a->head == RLPPO_HEAD_MULTIDISCRETE)
         RLPPO_CHECK_ARG(n_out == 21 && a->act_dim == 8, "multi-discrete head: needs 21 outputs and act_dim 8");
 
+    // ring-resident experience: ring_cap == 0 means "not a ring" (logical row == physical row)
+    const int64_t ring_cap = a->ring_cap > 0 ? a->ring_cap : INT64_MAX, ring_base = a->ring_cap > 0 ? a->ring_base : 0;
+    RLPPO_CHECK_ARG(ring_base >= 0 && ring_base < ring_cap, "ppo_minibatch: ring_base=%ld not in [0, ring_cap=%ld)", (long)a->ring_base,
+                    (long)a->ring_cap);
     const int slot = a->slot;
     RLPPO_CHECK_ARG(slot >= 0 && slot < RLPPO_MAX_SLOTS, "ppo_minibatch: slot %d not in [0, %d)", slot, RLPPO_MAX_SLOTS);
     rc = ensure_slot(slot);
@@ -461,19 +436,12 @@ int rlppo_ppo_minibatch(void *stream, const rlppo_minibatch_args *a) {
         w += f;
     }
     // the minibatch gather (experience_buffer.py:82-87): one pass into the workspace, shared by both nets
-    const float *states = a->states;
-    int64_t ld_states = a->ld_states;
-    const int64_t *gidx = a->idx;
-    if (g_pregather) {
-        float *xg = w;
-        w += (size_t)mb * pol.L[0].pin;
-        rc = launch_gather_rows(st, a->states, a->ld_states, a->idx, xg, pol.L[0].pin, mb);
-        if (rc) return rc;
-        states = xg;
-        ld_states = pol.L[0].pin;
-        gidx = nullptr;
-    }
-    // forward of both nets (with rlppo_dbg_set(11, 0) the gather is fused into the first layer's loads instead)
+    float *const states = w;
+    const int64_t ld_states = pol.L[0].pin;
+    w += (size_t)mb * pol.L[0].pin;
+    rc = launch_gather_rows(st, a->states, a->ld_states, a->idx, states, pol.L[0].pin, mb, ring_base, ring_cap);
+    if (rc) return rc;
+    // forward of both nets
     // The two networks are independent until the loss epilogue and again after it, so their launch chains run on
     // two streams (the caller's + one library-owned side stream, forked/joined with events: capturable).  Each
     // launch is only 50-100 us long at K <= 256, so letting one chain's kernels fill the CUs that the other chain's
@@ -484,13 +452,13 @@ int rlppo_ppo_minibatch(void *stream, const rlppo_minibatch_args *a) {
         rc = order_after(side, st, g_ev_fork[slot]);
         if (rc) return rc;
     }
-    rc = forward(side, val, a->val_packed, states, ld_states, gidx, mb, 0, vact, 0, vbits, vhave);
+    rc = forward(side, val, a->val_packed, states, ld_states, mb, 0, vact, 0, vbits, vhave);
     if (rc) return rc;
-    rc = forward(st, pol, a->pol_packed, states, ld_states, gidx, mb, a->head == RLPPO_HEAD_GAUSSIAN, pact, 0, pbits, phave);
+    rc = forward(st, pol, a->pol_packed, states, ld_states, mb, a->head == RLPPO_HEAD_GAUSSIAN, pact, 0, pbits, phave);
     if (rc) return rc;
     // loss epilogue: outputs -> output gradients in place, report statistics accumulated on device.  The value loss only
-    // needs the critic's output and the policy loss only the policy's, so with two streams each chain runs its own loss
-    // kernel and the chains do not meet until the end of the minibatch (rlppo_dbg_set(14, 0): one joint loss kernel).
+    // needs the critic's output and the policy loss only the policy's, so each chain runs its own loss kernel and the chains
+    // do not meet until the end of the minibatch.
     LossCfg cfg;
     cfg.clip = a->clip_range;
     cfg.clip_lo = (float)(1.0 - (double)a->clip_range);
@@ -500,17 +468,13 @@ int rlppo_ppo_minibatch(void *stream, const rlppo_minibatch_args *a) {
     cfg.inv_mb = 1.0f / (float)mb;
     cfg.var_m = a->var_m;
     cfg.var_b = a->var_b;
+    cfg.ring_base = ring_base;
+    cfg.ring_cap = ring_cap;
     float *pout = pact[pol.n_layers - 1], *vout = vact[val.n_layers - 1];
     const int64_t ldp = pol.L[pol.n_layers - 1].pout, ldv = val.L[val.n_layers - 1].pout;
-    const bool split_loss = side != st && g_split_loss;
-    if (split_loss) {
-        rc = launch_value_loss(side, vout, ldv, a->idx, a->targets, mb, cfg, a->stats);
-        if (rc) return rc;
-    } else if (side != st) {
-        rc = order_after(st, side, g_ev_join[slot]);
-        if (rc) return rc;
-    }
-    float *vjoint = split_loss ? nullptr : vout;
+    rc = launch_value_loss(side, vout, ldv, a->idx, a->targets, mb, cfg, a->stats);
+    if (rc) return rc;
+    float *vjoint = nullptr;  // the loss kernels' joint form (policy + value in one launch) is not used by this entry point
     if (a->head == RLPPO_HEAD_DISCRETE)
         rc = launch_discrete_loss(st, pout, ldp, n_out, vjoint, ldv, a->idx, a->actions, a->old_logp, a->targets,
                                   a->advantages, mb, cfg, a->stats);
@@ -526,13 +490,9 @@ int rlppo_ppo_minibatch(void *stream, const rlppo_minibatch_args *a) {
     }
     if (rc) return rc;
 
-    if (g_two_streams && !split_loss) {
-        rc = order_after(side, st, g_ev_fork[slot]);
-        if (rc) return rc;
-    }
-    rc = backward(side, g_dw_streams ? g_dw[slot][1] : side, g_ev_dw[slot][1], val, a->val_packed, states, ld_states, gidx, mb, vact, vdx, a->val_grad, val_tn_ws, tn_ws_floats(val, mb), vbits, vhave);
+    rc = backward(side, val, a->val_packed, states, ld_states, mb, vact, vdx, a->val_grad, val_tn_ws, tn_ws_floats(val, mb), vbits, vhave);
     if (rc) return rc;
-    rc = backward(st, g_dw_streams ? g_dw[slot][0] : st, g_ev_dw[slot][0], pol, a->pol_packed, states, ld_states, gidx, mb, pact, pdx, a->pol_grad, pol_tn_ws, tn_ws_floats(pol, mb), pbits, phave);
+    rc = backward(st, pol, a->pol_packed, states, ld_states, mb, pact, pdx, a->pol_grad, pol_tn_ws, tn_ws_floats(pol, mb), pbits, phave);
     if (rc) return rc;
     if (side != st) rc = order_after(st, side, g_ev_join[slot]);
     return rc;
@@ -598,102 +558,38 @@ int rlppo_gather_rows(void *stream, const float *src, int64_t ld_src, const int6
     RLPPO_CHECK_ARG(n > 0 && src && idx && dst, "gather_rows: null pointer");
     return launch_gather_rows((hipStream_t)stream, src, ld_src, idx, dst, width, n);
 }
-int rlppo_welford_increment(void *stream, const float *samples, int64_t ld, int64_t n, int32_t d, float *mean, float *m2,
-                            int64_t count) {
+int rlppo_welford_increment(void *stream, const float *samples, int64_t ld, int64_t n, int32_t d, void *mean, void *m2,
+                            int64_t count, int32_t state_is_f64) {
     if (n == 0) return 0;
     RLPPO_CHECK_ARG(n > 0 && d > 0 && ld >= d && count >= 0 && samples && mean && m2, "welford_increment: bad argument");
-    return launch_welford((hipStream_t)stream, samples, ld, n, d, mean, m2, (long long)count);
+    return launch_welford((hipStream_t)stream, samples, ld, n, d, mean, m2, (long long)count, state_is_f64 != 0);
 }
+int rlppo_welford_merge(void *stream, int32_t d, void *mean, void *m2, int64_t count, const float *other_mean,
+                        const float *other_m2, int64_t other_count, int32_t state_is_f64) {
+    if (other_count == 0) return 0;
+    RLPPO_CHECK_ARG(d > 0 && count >= 0 && other_count > 0 && mean && m2 && other_mean && other_m2, "welford_merge: bad argument");
+    return launch_welford_merge((hipStream_t)stream, d, mean, m2, (long long)count, other_mean, other_m2, (long long)other_count,
+                                state_is_f64 != 0);
+}
+static int64_t g_selection_epoch = 0;  // bumped by every call that changes which kernels later launches select
 int rlppo_set_inference_precision(int32_t mode) {
     RLPPO_CHECK_ARG(mode == 0 || mode == 1, "set_inference_precision: mode %d (0 = fp32, 1 = bf16 operands)", mode);
     set_infer_bf16(mode);
+    ++g_selection_epoch;
     return 0;
 }
 int rlppo_dbg_set(int32_t key, int32_t value) {
-    if (key == 1) {
-        set_gae_algo(value);
-        return 0;
-    }
-    if (key == 2) {
-        set_tn_rows(value);
-        set_tn_partial_rows(value);
-        return 0;
-    }
-    if (key == 3) {
-        set_nt_ws(value);
-        return 0;
-    }
-    if (key == 4) {
-        g_two_streams = value;
-        return 0;
-    }
-    if (key == 5) {
-        set_nt_bk(value);
-        return 0;
-    }
-    if (key == 6) {
-        set_fused(value);
-        return 0;
-    }
-    if (key == 7) {
-        set_nt_stagger(value);
-        return 0;
-    }
-    if (key == 8) {
-        g_dw_streams = value;
-        return 0;
-    }
-    if (key == 9) {
-        set_nt_sa(value);
-        return 0;
-    }
-    if (key == 10) {
-        set_tn_sa(value);
-        return 0;
-    }
-    if (key == 11) {
-        g_pregather = value;
-        return 0;
-    }
-    if (key == 12) {
-        set_tn_rows_big(value);
-        return 0;
-    }
-    if (key == 13) {
-        set_loss16(value);
-        return 0;
-    }
-    if (key == 14) {
-        g_split_loss = value;
-        return 0;
-    }
-    if (key == 15) {
-        set_gemv(value);
-        return 0;
-    }
-    if (key == 16) {
-        set_tn_partial(value);
-        return 0;
-    }
-    if (key == 17) {
-        set_nt_persist(value);
-        return 0;
-    }
-    if (key == 20) {
-        set_nt_nbuf3(value);
-        return 0;
-    }
-    if (key == 19) {
-        set_mask_bits(value);
-        return 0;
-    }
-    if (key == 18) {
-        set_gae_grid_div(value);
-        return 0;
+    ++g_selection_epoch;
+    switch (key) {
+        case 1: set_gae_algo(value); return 0;
+        case 4: g_two_streams = value; return 0;
+        case 21: set_gae_spin_limit(value); return 0;
+        default: break;
     }
     set_error("dbg_set: unknown key %d", key);
     return RLPPO_ERR_ARG;
 }
+int64_t rlppo_selection_epoch(void) { return g_selection_epoch; }
 size_t rlppo_dbg_gemm_nt_bits_bytes(int64_t M, int32_t N) { return nt_bits_floats(M, N) * sizeof(float); }
 int rlppo_dbg_gemm_nt_bits(void *stream, const float *A, int64_t lda, const float *B, int64_t ldb, const float *bias, float *C,
                            int64_t ldc, int64_t M, int32_t N, int32_t K, int32_t epilogue, void *bits) {
@@ -705,37 +601,15 @@ int rlppo_dbg_gemm_nt_bits(void *stream, const float *A, int64_t lda, const floa
     }
     return rc;
 }
-int rlppo_dbg_gemm_nt_stamped(void *stream, const float *A, int64_t lda, const float *B, int64_t ldb, const float *bias,
-                                float *C, int64_t ldc, int64_t M, int32_t N, int32_t K, uint64_t *stamps, int32_t mode) {
-    if (mode & 64)  // the scalar-addressed product kernel (gemm_sa.hip) with stamps
-        return launch_gemm_nt_sa_stamped((hipStream_t)stream, A, lda, B, ldb, bias, C, ldc, M, N, K, (unsigned long long *)stamps);
-    return launch_gemm_nt_stamped((hipStream_t)stream, A, lda, B, ldb, bias, C, ldc, M, N, K, (unsigned long long *)stamps, mode);
-}
-int rlppo_dbg_probe_ld(void *stream, int32_t pattern, int32_t blocks, const void *buf, size_t span, int32_t iters, float *out) {
-    return launch_probe_ld((hipStream_t)stream, pattern, blocks, buf, span, iters, out);
-}
-int rlppo_dbg_probe_coissue(void *stream, const float *buf, int32_t flags, int32_t iters, uint64_t *cycles, float *out) {
-    return launch_probe_coissue((hipStream_t)stream, buf, flags, iters, (unsigned long long *)cycles, out);
-}
-int rlppo_dbg_probe2(void *stream, int32_t mode, int32_t threads, int32_t blocks, const float *W, float *out, int32_t chunks) {
-    return launch_probe2((hipStream_t)stream, mode, threads, blocks, W, out, chunks);
-}
-int rlppo_dbg_mfma_probe(void *stream, float *out, int32_t blocks, int32_t iters, uint64_t *clocks) {
-    return launch_mfma_probe((hipStream_t)stream, out, blocks, iters, (unsigned long long *)clocks);
-}
-int rlppo_dbg_gemm_nt(void *stream, const float *A, int64_t lda, const int64_t *row_idx, const float *B, int64_t ldb,
-                      const float *bias, const float *mask_src, int64_t ld_mask, float *C, int64_t ldc, int64_t M,
-                      int32_t N, int32_t K, int32_t epilogue) {
-    return launch_gemm_nt((hipStream_t)stream, A, lda, row_idx, B, ldb, bias, mask_src, ld_mask, C, ldc, M, N, K, epilogue);
-}
-int rlppo_dbg_gemm_tn(void *stream, const float *dY, int64_t ldy, int32_t ny_valid, const float *X, int64_t ldx,
-                      const int64_t *row_idx, int32_t kx_valid, float *dW, float *db, int32_t out, int32_t in, int64_t M) {
-    return launch_gemm_tn((hipStream_t)stream, dY, ldy, ny_valid, X, ldx, row_idx, kx_valid, dW, db, out, in, M);
+int rlppo_dbg_gemm_nt(void *stream, const float *A, int64_t lda, const float *B, int64_t ldb, const float *bias,
+                      const float *mask_src, int64_t ld_mask, float *C, int64_t ldc, int64_t M, int32_t N, int32_t K,
+                      int32_t epilogue) {
+    return launch_gemm_nt((hipStream_t)stream, A, lda, B, ldb, bias, mask_src, ld_mask, C, ldc, M, N, K, epilogue);
 }
 size_t rlppo_dbg_gemm_tn_workspace_bytes(int32_t out, int32_t in, int64_t M) { return tn_partial_floats(out, in, M) * sizeof(float); }
-int rlppo_dbg_gemm_tn_ws(void *stream, const float *dY, int64_t ldy, int32_t ny_valid, const float *X, int64_t ldx,
-                         int32_t kx_valid, float *dW, float *db, int32_t out, int32_t in, int64_t M, void *ws, size_t ws_bytes) {
-    return launch_gemm_tn((hipStream_t)stream, dY, ldy, ny_valid, X, ldx, nullptr, kx_valid, dW, db, out, in, M, (float *)ws,
+int rlppo_dbg_gemm_tn(void *stream, const float *dY, int64_t ldy, int32_t ny_valid, const float *X, int64_t ldx,
+                      int32_t kx_valid, float *dW, float *db, int32_t out, int32_t in, int64_t M, void *ws, size_t ws_bytes) {
+    return launch_gemm_tn((hipStream_t)stream, dY, ldy, ny_valid, X, ldx, kx_valid, dW, db, out, in, M, (float *)ws,
                           ws_bytes / sizeof(float));
 }
 }

@@ -66,63 +66,27 @@ int make_layout(const int32_t *dims, int32_t n_layers, NetLayout *out);
 // ---- kernel launchers shared between translation units ------------------------------------------
 enum Epilogue { EPI_BIAS = 0, EPI_BIAS_RELU = 1, EPI_BIAS_TANH = 2, EPI_MASK = 3 };
 
+// gemm.hip ------------------------------------------------------------------------------------------
 // C[m][0:N] = epi(A[m][0:K] . B[n][0:K]^T)   (K % 32 == 0, N = padded out in {32,64,96,128,k*128})
-int launch_gemm_nt(hipStream_t st, const float *A, int64_t lda, const int64_t *row_idx, const float *B, int64_t ldb,
-                   const float *bias, const float *mask_src, int64_t ld_mask, float *C, int64_t ldc, int64_t M, int N,
-                   int K, int epi, int bf16_operands = 0);
-
-// dW[n][k] += sum_m dY[m][n] X[m][k] ; db[n] += sum_m dY[m][n]   (accumulation into the flat arena: through partial tiles
-// in `ws` (>= tn_partial_floats(out, in, M) floats) + a reduction, or with fp32 atomics when ws is null / too small)
-int launch_gemm_tn(hipStream_t st, const float *dY, int64_t ldy, int ny_valid, const float *X, int64_t ldx,
-                   const int64_t *row_idx, int kx_valid, float *dW, float *db, int out, int in, int64_t M,
-                   float *ws = nullptr, size_t ws_floats = 0);
-
-struct LossCfg {
-    float clip, clip_lo, clip_hi, ent_coef, mb_ratio, inv_mb;
-    float var_m, var_b;
-};
-
-int launch_pack(hipStream_t, const NetLayout &, const float *, float *);
-int launch_clip_adam_pack2(hipStream_t st, const NetLayout *nets, float *const *p, float *const *g, float *const *m, float *const *v,
-                           float *const *packed, double *const *gnorm2, const int64_t *n, const float *max_norm,
-                           const float *step_size, const float *bc2_sqrt, const float *omb1, const float *beta2, const float *omb2,
-                           const float *eps);
-int launch_welford(hipStream_t st, const float *x, int64_t ld, int64_t n, int d, float *mean, float *m2, long long count0);
-int launch_gather_rows(hipStream_t st, const float *src, int64_t ld_src, const int64_t *idx, float *dst, int width, int64_t n);
-int launch_pad_rows(hipStream_t, const void *, int, int64_t, int64_t, int64_t, float *, int64_t, int, float, float);
-int launch_pad_rows_vec(hipStream_t, const void *, int, int64_t, int64_t, int64_t, float *, int64_t, const float *, const float *);
-int launch_clip_adam(hipStream_t, float *p, float *g, float *m, float *v, int64_t n, float max_norm, float step_size,
-                     float bc2_sqrt, float one_minus_beta1, float beta2, float one_minus_beta2, float eps, double *gnorm2);
-size_t gae_workspace_bytes(int64_t n);
-void set_gae_algo(int algo);
-void set_tn_rows(int rows);
-void set_nt_ws(int on);
-void set_nt_bk(int bk);
-void set_fused(int on);
-void set_nt_stagger(int sleep_units);
-int launch_gemm_nt_stamped(hipStream_t st, const float *A, int64_t lda, const float *B, int64_t ldb, const float *bias,
-                           float *C, int64_t ldc, int64_t M, int N, int K, unsigned long long *stamps, int mode);
-int launch_gemm_nt_sa(hipStream_t st, const float *A, int64_t lda, const float *B, int64_t ldb, const float *bias,
-                      const float *mask_src, int64_t ld_mask, float *C, int64_t ldc, int64_t M, int N, int nb, int K, int epi);
-void set_nt_sa(int v);
-void set_nt_persist(int v);
-void set_nt_nbuf3(int v);
-void set_mask_bits(int v);
+int launch_gemm_nt(hipStream_t st, const float *A, int64_t lda, const float *B, int64_t ldb, const float *bias,
+                   const float *mask_src, int64_t ld_mask, float *C, int64_t ldc, int64_t M, int N, int K, int epi,
+                   int bf16_operands = 0);
+// the hidden-layer forward that also writes the ReLU bitmask (epi = EPI_BIAS_RELU) / the dX product masked by it (EPI_MASK);
+// returns -1 when that form does not apply (width not a multiple of 128)
 size_t nt_bits_floats(int64_t M, int N);
 int launch_gemm_nt_bits(hipStream_t st, const float *A, int64_t lda, const float *B, int64_t ldb, const float *bias, float *C,
                         int64_t ldc, int64_t M, int N, int K, int epi, unsigned long long *bits);
-void set_tn_sa(int v);
-void set_gae_grid_div(int v);
-void set_infer_bf16(int v);
-int get_infer_bf16();
 int launch_gemm_nt_bf16(hipStream_t st, const float *A, int64_t lda, const float *B, int64_t ldb, const float *bias, float *C,
                         int64_t ldc, int64_t M, int N, int nb, int K, int epi);
-void set_tn_partial(int v);
-void set_tn_partial_rows(int v);
+void set_infer_bf16(int v);
+int get_infer_bf16();
+// dW[n][k] += sum_m dY[m][n] X[m][k] ; db[n] += sum_m dY[m][n]: partial tiles in `ws` (>= tn_partial_floats(out, in, M)
+// floats) + a fixed-order reduction into the flat arena
 size_t tn_partial_floats(int out, int in, int64_t M);
-int launch_gemm_tn_partial(hipStream_t st, const float *dY, int64_t ldy, int ny_valid, const float *X, int64_t ldx,
-                           int kx_valid, float *dW, float *db, int out, int in, int64_t M, float *ws, size_t ws_floats);
-void set_gemv(int v);
+int launch_gemm_tn(hipStream_t st, const float *dY, int64_t ldy, int ny_valid, const float *X, int64_t ldx, int kx_valid,
+                   float *dW, float *db, int out, int in, int64_t M, float *ws, size_t ws_floats);
+
+// gemv.hip: the critic's one-output head ---------------------------------------------------------------
 bool gemv_head_ok(int out, int kp);
 int launch_gemv_fwd(hipStream_t st, const float *x, int64_t ldx, const float *w, const float *b, float *y, int64_t ldy, int64_t n, int kp, int pout);
 int launch_gemv_dx(hipStream_t st, const float *dy, int64_t ldy, const float *w, const float *mask, int64_t ldm, float *dx, int64_t ldc, int kp, int64_t n);
@@ -130,23 +94,18 @@ int launch_gemv_dx_bits(hipStream_t st, const float *dy, int64_t ldy, const floa
                         int64_t ldc, int kp, int64_t n);
 int launch_gemv_dw(hipStream_t st, const float *dy, int64_t ldy, const float *x, int64_t ldx, float *dw, float *db, int in, int kp, int64_t n,
                    float *ws = nullptr, size_t ws_floats = 0);
-void set_loss16(int v);
-void set_tn_rows_big(int r);
-int launch_gemm_tn_sa(hipStream_t st, dim3 grid, const float *dY, int64_t ldy, int ny_valid, const float *X, int64_t ldx,
-                      int kx_valid, float *dW, float *db, int out, int in, int64_t M, int rows_per_wg);
-int launch_gemm_nt_sa_stamped(hipStream_t st, const float *A, int64_t lda, const float *B, int64_t ldb, const float *bias,
-                              float *C, int64_t ldc, int64_t M, int N, int K, unsigned long long *stamps);
-int launch_probe_ld(hipStream_t st, int pat, int blocks, const void *buf, size_t span, int iters, float *out);
-int launch_probe_coissue(hipStream_t st, const float *buf, int flags, int iters, unsigned long long *cycles, float *out);
-int launch_probe2(hipStream_t st, int mode, int threads, int blocks, const float *W, float *out, int chunks);
-bool fused_eligible(const NetLayout &net, int64_t mb);
-int launch_fused_forward(hipStream_t st, const NetLayout &net, const float *packed, const float *obs, int64_t ld_obs,
-                         const int64_t *idx, int64_t mb, int out_tanh, float *const *acts);
-int launch_fused_backward(hipStream_t st, const NetLayout &net, const float *packed, int64_t mb, float *const *acts,
-                          float *const *dx);
-int launch_mfma_probe(hipStream_t st, float *out, int blocks, int iters, unsigned long long *clocks);
-int launch_gae(hipStream_t, const float *, const float *, const float *, const float *, int64_t, double, double, float,
-               float *, float *, float *, void *, size_t);
+
+// heads.hip: sampling and loss epilogues ---------------------------------------------------------------
+struct LossCfg {
+    float clip, clip_lo, clip_hi, ent_coef, mb_ratio, inv_mb;
+    float var_m, var_b;
+    int64_t ring_base, ring_cap;  // ExperienceBuffer ring: logical row i lives at physical row (i + ring_base) mod ring_cap
+};
+// logical -> physical row of the ring-resident experience (i < cap, base < cap: one conditional subtraction)
+__host__ __device__ __forceinline__ int64_t ring_row(int64_t i, int64_t base, int64_t cap) {
+    const int64_t r = i + base;
+    return r >= cap ? r - cap : r;
+}
 int launch_discrete_sample_logits(hipStream_t, const float *, int64_t, int64_t, int, const float *, int64_t *, float *, float *);
 int launch_categorical_select(hipStream_t, const float *, int64_t, int64_t, int, const float *, int64_t *, float *);
 int launch_gaussian_sample(hipStream_t, const float *, int64_t, int64_t, int, const float *, float, float, float *, float *);
@@ -159,5 +118,28 @@ int launch_gaussian_loss(hipStream_t, float *, int64_t, int, float *, int64_t, c
                          const float *, const float *, int64_t, const LossCfg &, double *);
 int launch_multidiscrete_loss(hipStream_t, float *, int64_t, float *, int64_t, const int64_t *, const float *, const float *,
                               const float *, const float *, int64_t, const LossCfg &, double *);
+
+// gae.hip ---------------------------------------------------------------------------------------------
+size_t gae_workspace_bytes(int64_t n);
+void set_gae_algo(int algo);
+void set_gae_spin_limit(int v);
+int launch_gae(hipStream_t, const float *, const float *, const float *, const float *, int64_t, double, double, float,
+               float *, float *, float *, void *, size_t);
+
+// optim.hip -------------------------------------------------------------------------------------------
+int launch_pack(hipStream_t, const NetLayout &, const float *, float *);
+int launch_clip_adam(hipStream_t, float *p, float *g, float *m, float *v, int64_t n, float max_norm, float step_size,
+                     float bc2_sqrt, float one_minus_beta1, float beta2, float one_minus_beta2, float eps, double *gnorm2);
+int launch_clip_adam_pack2(hipStream_t st, const NetLayout *nets, float *const *p, float *const *g, float *const *m, float *const *v,
+                           float *const *packed, double *const *gnorm2, const int64_t *n, const float *max_norm,
+                           const float *step_size, const float *bc2_sqrt, const float *omb1, const float *beta2, const float *omb2,
+                           const float *eps);
+int launch_welford(hipStream_t st, const float *x, int64_t ld, int64_t n, int d, void *mean, void *m2, long long count0, int state_f64);
+int launch_welford_merge(hipStream_t st, int d, void *mean, void *m2, long long count, const float *omean, const float *om2,
+                         long long ocount, int state_f64);
+int launch_gather_rows(hipStream_t st, const float *src, int64_t ld_src, const int64_t *idx, float *dst, int width, int64_t n,
+                       int64_t ring_base = 0, int64_t ring_cap = INT64_MAX);
+int launch_pad_rows(hipStream_t, const void *, int, int64_t, int64_t, int64_t, float *, int64_t, int, float, float);
+int launch_pad_rows_vec(hipStream_t, const void *, int, int64_t, int64_t, int64_t, float *, int64_t, const float *, const float *);
 
 }  // namespace rlppo

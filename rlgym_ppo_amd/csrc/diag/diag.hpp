@@ -1,0 +1,12 @@
+// diag.hpp -- launchers of librlppo_diag.so (measurement probes; nothing here is on the product path).
+#pragma once
+#include "../common.hpp"
+
+namespace rlppo {
+int launch_gemm_nt_stamped(hipStream_t st, const float *A, int64_t lda, const float *B, int64_t ldb, const float *bias,
+                           float *C, int64_t ldc, int64_t M, int N, int K, unsigned long long *stamps, int mode);
+int launch_probe_ld(hipStream_t st, int pat, int blocks, const void *buf, size_t span, int iters, float *out);
+int launch_probe_coissue(hipStream_t st, const float *buf, int flags, int iters, unsigned long long *cycles, float *out);
+int launch_probe2(hipStream_t st, int mode, int threads, int blocks, const float *W, float *out, int chunks);
+int launch_mfma_probe(hipStream_t st, float *out, int blocks, int iters, unsigned long long *clocks);
+}  // namespace rlppo

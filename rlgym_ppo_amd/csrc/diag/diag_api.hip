@@ -1,0 +1,79 @@
+// diag_api.hip -- extern "C" surface of librlppo_diag.so (include/rlppo_diag.h): the measurement probes behind the numbers
+// of DESIGN.md section 5 (MFMA ceiling, load-path bandwidth, VALU co-issue cost, phase stamps of a staged GEMM).  Built next
+// to librlppo.so, loaded only by tools/; the product library does not contain or need any of it.
+#include <stdarg.h>
+
+#include "../../../include/rlppo_diag.h"
+#include "diag.hpp"
+
+namespace rlppo {
+static thread_local char g_diag_err[512] = "";
+void set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_diag_err, sizeof(g_diag_err), fmt, ap);
+    va_end(ap);
+}
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+
+// Register-only loop of v_mfma_f32_16x16x4_f32 on 16 independent accumulators (the instruction mix of the GEMM inner
+// loops without any memory traffic): measures what the chip sustains on THIS box (clock under load included), so
+// that roofline fractions can also be read against an achievable ceiling.
+__global__ __launch_bounds__(256) void mfma_probe_kernel(float *out, int iters, unsigned long long *clocks) {
+    f32x4 acc[16];
+    float a[4], b[4];
+    const float seed = (float)(threadIdx.x % 37) * 0.03125f - 0.5f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = f32x4{seed, -seed, 0.5f * seed, 0.25f};
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        a[s] = seed * (float)(s + 1) * 0.37f + 0.01f;
+        b[s] = 0.91f - seed * (float)(s + 1) * 0.11f;
+    }
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[i] = MFMA16(a[s], b[(s + i) & 3], acc[i]);
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) sum += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    out[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = sum;
+    if (threadIdx.x == 0 && clocks) {
+        clocks[2 * blockIdx.x] = t1 - t0;      // shader cycles
+        clocks[2 * blockIdx.x + 1] = r1 - r0;  // 100 MHz ticks
+    }
+}
+int launch_mfma_probe(hipStream_t st, float *out, int blocks, int iters, unsigned long long *clocks) {
+    hipLaunchKernelGGL(mfma_probe_kernel, dim3(blocks), dim3(256), 0, st, out, iters, clocks);
+    RLPPO_LAUNCH_CHECK();
+    return 0;
+}
+}  // namespace rlppo
+
+using namespace rlppo;
+
+extern "C" {
+const char *rlppo_diag_last_error(void) { return g_diag_err; }
+int rlppo_dbg_gemm_nt_stamped(void *stream, const float *A, int64_t lda, const float *B, int64_t ldb, const float *bias,
+                              float *C, int64_t ldc, int64_t M, int32_t N, int32_t K, uint64_t *stamps, int32_t mode) {
+    return launch_gemm_nt_stamped((hipStream_t)stream, A, lda, B, ldb, bias, C, ldc, M, N, K, (unsigned long long *)stamps, mode);
+}
+int rlppo_dbg_probe_ld(void *stream, int32_t pattern, int32_t blocks, const void *buf, size_t span, int32_t iters, float *out) {
+    return launch_probe_ld((hipStream_t)stream, pattern, blocks, buf, span, iters, out);
+}
+int rlppo_dbg_probe_coissue(void *stream, const float *buf, int32_t flags, int32_t iters, uint64_t *cycles, float *out) {
+    return launch_probe_coissue((hipStream_t)stream, buf, flags, iters, (unsigned long long *)cycles, out);
+}
+int rlppo_dbg_probe2(void *stream, int32_t mode, int32_t threads, int32_t blocks, const float *W, float *out, int32_t chunks) {
+    return launch_probe2((hipStream_t)stream, mode, threads, blocks, W, out, chunks);
+}
+int rlppo_dbg_mfma_probe(void *stream, float *out, int32_t blocks, int32_t iters, uint64_t *clocks) {
+    return launch_mfma_probe((hipStream_t)stream, out, blocks, iters, (unsigned long long *)clocks);
+}
+}

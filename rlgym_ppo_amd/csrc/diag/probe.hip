@@ -1,7 +1,8 @@
 // probe.hip -- diagnostic micro-kernels (not on the product path): what does the GEMM inner loop sustain when its
 // ingredients are added one at a time?  64 MFMAs (2 x 8 accumulator blocks, the wave tile of every GEMM kernel here)
 // per 16-deep k chunk, plus optionally the LDS fragment reads and/or the global fragment loads of that chunk.
-#include "common.hpp"
+#include "../common.hpp"
+#include "diag.hpp"
 
 namespace rlppo {
 typedef float f32x4 __attribute__((ext_vector_type(4)));

@@ -16,6 +16,9 @@
 //                   in-block suffix scan with wave shuffles and writes the three outputs.
 // Arithmetic: float32 reward scaling, float64 recurrences, one rounding to float32 at the store -- the reference's
 // behaviour under its pinned NumPy < 2 (oracle/gae_oracle.c mode 0).
+#include <atomic>
+#include <chrono>
+
 #include "common.hpp"
 
 namespace rlppo {
@@ -276,6 +279,14 @@ __global__ __launch_bounds__(GAE_THREADS) void gae_apply_kernel(const float *__r
     }
 }
 
+// one raw step as its pair of affine maps (the look-ahead window and the slow path below work on raw steps)
+__device__ __forceinline__ Aff2 step_affine(float r, float d, float t, float v, float v1, const GaeParams &p) {
+    const double nd = (double)(1.0f - d), nt = (double)(1.0f - t);
+    const float rn = p.use_std ? fminf(fmaxf(r / p.ret_std, -10.f), 10.f) : r;
+    const double m = (double)(float)(nd * nt);
+    return Aff2{p.gl * m, ((double)rn + p.gamma * (double)v1 * nd) - (double)v, p.gamma * m, (double)r};
+}
+
 // ------------------------------------------------------------------------------------------ single pass
 // One launch: chained scan with decoupled look-back.  Workgroups take chunks right-to-left through a ticket counter
 // (a chunk only ever waits on chunks whose tickets were drawn earlier, so progress never depends on dispatch order or
@@ -289,7 +300,7 @@ constexpr int LB_AGG = 8;                       // granules of the aggregate rec
 constexpr int LB_INC = 4;                       // granules of the inclusive record: 2 doubles
 constexpr int LB_STRIDE = 16;                   // granules per chunk (128 B: one line per chunk)
 constexpr int LOOKAHEAD = 256;                  // raw steps of the next chunk inspected by wave 0 (4 per lane)
-constexpr unsigned LB_SPIN_LIMIT = 1u << 22;    // bounded spin: give up (error word set) instead of hanging the GPU
+constexpr unsigned LB_SPIN_LIMIT = 1u << 18;    // bounded spin (~0.1-0.3 s), then the slow path: never a hang, never a wrong carry
 
 __device__ __forceinline__ void put_granule(u64 *p, unsigned tag, unsigned v) {
     __hip_atomic_store(p, ((u64)tag << 32) | v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -305,8 +316,8 @@ __global__ __launch_bounds__(GAE_THREADS, 4) void gae_lookback_kernel(const floa
                                                                     const float *__restrict__ trunc,
                                                                     const float *__restrict__ values, int64_t n,
                                                                     GaeParams p, u64 *__restrict__ state,
-                                                                    unsigned *__restrict__ epoch_word,
-                                                                    unsigned *__restrict__ error_word, int n_blocks,
+                                                                    const unsigned tag, const unsigned spin_limit,
+                                                                    unsigned *__restrict__ slow_word, int n_blocks,
                                                                     float *__restrict__ vt_out,
                                                                     float *__restrict__ adv_out,
                                                                     float *__restrict__ ret_out) {
@@ -314,14 +325,13 @@ __global__ __launch_bounds__(GAE_THREADS, 4) void gae_lookback_kernel(const floa
     __shared__ Aff2 wave_la[4];  // look-ahead window of the next chunk: per-wave composites (64 steps each)
     __shared__ double s_carry[2];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    // Tags are unique per launch without a memset: tag = (epoch word left by the previous launch on this workspace)
-    // + 1, and the workgroup that owns chunk 0 -- the end of the dependency chain, so every other workgroup has read
-    // the word by then -- stores the new value on its way out.  Whatever the word holds on first use, records of
-    // earlier launches (or never-written memory) carry a different tag in all 8 / 4 granules of a record.
-    // (read after the first chunk's loads have been issued: the compiler waits for an agent-scope load right away, and
-    // placed first it cost every workgroup a memory round trip before its step loads even started)
-    unsigned TAG_AGG = 0, TAG_INC = 0;
-    bool have_tag = false;
+    // Tags are unique per launch without a memset: `tag` is a kernel argument drawn from a process-wide host counter
+    // (launch_gae), so every workgroup of a launch holds the same tag whatever its dispatch time, and records of earlier
+    // launches (or never-written memory) carry a different tag in all 8 / 4 granules of a record.  (Round 1 kept the epoch
+    // in the workspace header and let the owner of chunk 0 advance it on exit: a workgroup dispatched after that store --
+    // possible when chunk 0's fast path needs nobody -- would have read the NEXT launch's tag and never matched its
+    // neighbours.)  A captured launch would replay a frozen tag, so launch_gae takes the two-launch form under capture.
+    const unsigned TAG_AGG = tag, TAG_INC = tag;
     // Chunks are taken right-to-left, grid-strided.  A chunk waits only on chunks to its right, i.e. on work of this
     // same round owned by lower block ids or on earlier rounds; the launcher sizes the grid to the number of
     // co-resident workgroups, so every awaited chunk belongs to a running workgroup whatever the dispatch order.
@@ -345,22 +355,13 @@ __global__ __launch_bounds__(GAE_THREADS, 4) void gae_lookback_kernel(const floa
     load_raw(rews, dones, trunc, values, t0, n, raw);
     {   // the window's composite while the chunk's own loads are still in flight (the window's were issued first)
         Aff2 l1 = aff_identity();  // steps past the end: identity (x = 0 there is handled by covers_all below)
-        if (l_ok) {
-            const double nd = (double)(1.0f - l_d), nt = (double)(1.0f - l_t);
-            const float rn = p.use_std ? fminf(fmaxf(l_r / p.ret_std, -10.f), 10.f) : l_r;
-            const double m = (double)(float)(nd * nt);
-            l1 = Aff2{p.gl * m, ((double)rn + p.gamma * (double)l_v1 * nd) - (double)l_v, p.gamma * m, (double)l_r};
-        }
+        if (l_ok) l1 = step_affine(l_r, l_d, l_t, l_v, l_v1, p);
         const Aff2 ls = wave_suffix_scan(l1, lane);
         if (lane == 0) wave_la[wave] = ls;
     }
     __builtin_amdgcn_sched_barrier(0);
     Steps s;
     make_steps(raw, t0, n, p, s);
-    if (!have_tag) {
-        TAG_AGG = TAG_INC = __hip_atomic_load(epoch_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
-        have_tag = true;
-    }
     const Aff2 mine = thread_composite(s, p);
     // one shuffle scan serves both purposes: lane l gets the composite of lanes l..63 (needed for the outputs) and
     // lane 0's value is the wave total (needed for the chunk aggregate)
@@ -424,8 +425,22 @@ __global__ __launch_bounds__(GAE_THREADS, 4) void gae_lookback_kernel(const floa
                     }
                 } else {
                     __builtin_amdgcn_s_sleep(2);
-                    if (++spins > LB_SPIN_LIMIT) {
-                        if (lane == 0) atomicExch(error_word, 1u);
+                    if (++spins > spin_limit) {
+                        // Slow path: the awaited record did not appear.  Nothing is given up: the carry is recomputed
+                        // from the RAW steps to the right of what has been composed so far (64 per iteration, one per
+                        // lane) up to the first trajectory end or the end of the data -- correct whatever the other
+                        // workgroups do, merely slow; slow_word counts how often it happened (expected: never).
+                        if (lane == 0) atomicAdd(slow_word, 1u);
+                        for (int64_t pos = (int64_t)j * GAE_BLOCK; pos < n; pos += 64) {
+                            const int64_t t = pos + lane;
+                            Aff2 f = aff_identity();
+                            if (t < n) f = step_affine(rews[t], dones[t], trunc[t], values[t], values[t + 1], p);
+                            const Aff2 sc = wave_suffix_scan(f, lane);
+                            acc = compose(acc, readlane_aff(sc, 0));
+                            if (acc.a == 0.0 && acc.c == 0.0) break;
+                        }
+                        carry_adv = acc.b;  // x = 0 beyond the last step
+                        carry_ret = acc.d;
                         done = true;
                     }
                 }
@@ -474,7 +489,6 @@ __global__ __launch_bounds__(GAE_THREADS, 4) void gae_lookback_kernel(const floa
                 ret_out[t0 + e] = o_ret[e];
             }
     }
-    if (chunk == 0 && threadIdx.x == 0) __hip_atomic_store(epoch_word, TAG_AGG, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();  // LDS (lds4, wave_tot, s_carry) is reused by the next round
     }
 }
@@ -483,8 +497,11 @@ static int g_gae_grid_div = 1;  // tuning: rlppo_dbg_set(18, k): k chunks per wo
 void set_gae_grid_div(int v) { g_gae_grid_div = v; }
 static int g_gae_algo = 1;  // 1 = single-pass look-back (default), 0 = two launches (summary + apply)
 void set_gae_algo(int a) { g_gae_algo = a; }
+static unsigned g_gae_spin_limit = LB_SPIN_LIMIT;  // rlppo_dbg_set(21, v): tests set 0 to force the slow path
+void set_gae_spin_limit(int v) { g_gae_spin_limit = v < 0 ? LB_SPIN_LIMIT : (unsigned)v; }
 
-// workspace: [0,16) ticket + error word (+pad) | look-back state (128 B per chunk) ; the two-launch path uses the same
+// workspace: [0,16) header: word 1 = number of look-back waits that ended in the slow path (diagnostic, never reset by the
+// library) | look-back state (128 B per chunk) ; the two-launch path uses the same
 // region for its per-chunk composites (32 B per chunk)
 size_t gae_workspace_bytes(int64_t n) { return 16 + (size_t)(cdiv(n > 0 ? n : 1, GAE_BLOCK)) * LB_STRIDE * sizeof(u64); }
 
@@ -505,7 +522,9 @@ int launch_gae(hipStream_t st, const float *rews, const float *dones, const floa
     p.use_std = !(ret_std != ret_std);  // NaN means "no scaling" (return_std=None)
     p.ret_std = ret_std;
     const int nb = (int)cdiv(n, GAE_BLOCK);
-    if (g_gae_algo == 1) {
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (st) RLPPO_HIP(hipStreamIsCapturing(st, &cap));
+    if (g_gae_algo == 1 && cap == hipStreamCaptureStatusNone) {
         unsigned *hdr = reinterpret_cast<unsigned *>(ws);
         u64 *state = reinterpret_cast<u64 *>(reinterpret_cast<char *>(ws) + 16);
         static int resident = 0;  // co-resident workgroups of this kernel on the device (queried once)
@@ -522,8 +541,18 @@ int launch_gae(hipStream_t st, const float *rews, const float *dones, const floa
         }
         int grid = nb < resident ? nb : resident;
         if (g_gae_grid_div > 1 && grid / g_gae_grid_div >= 256) grid = (int)cdiv(nb, cdiv(nb, grid / g_gae_grid_div));  // whole rounds
+        // per-launch tag: process-wide counter seeded from the clock (a recycled workspace may hold records of another
+        // process's launches), never 0 (zero-filled memory)
+        static std::atomic<unsigned> g_tag{0};
+        if (g_tag.load(std::memory_order_relaxed) == 0) {
+            unsigned expect = 0;
+            const unsigned seed = (unsigned)std::chrono::steady_clock::now().time_since_epoch().count() | 1u;
+            g_tag.compare_exchange_strong(expect, seed);
+        }
+        unsigned tag = g_tag.fetch_add(1, std::memory_order_relaxed) + 1;
+        if (tag == 0) tag = g_tag.fetch_add(1, std::memory_order_relaxed) + 1;
         hipLaunchKernelGGL(gae_lookback_kernel, dim3(grid), dim3(GAE_THREADS), 0, st, rews, dones, trunc, values, n, p, state,
-                           hdr, hdr + 1, nb, vt, adv, ret);
+                           tag, g_gae_spin_limit, hdr + 1, nb, vt, adv, ret);
         RLPPO_LAUNCH_CHECK();
         return 0;
     }

@@ -1,404 +1,475 @@
-// gemm.hip -- fp32 MFMA GEMM kernels for the MLP forward / backward (gfx950, wave64).
+// gemm.hip -- the fp32 MFMA GEMM kernels of the MLP forward / backward (gfx950, wave64), LDS-DMA staged, scalar-addressed.
 //
 // Why fp32 MFMA: BASELINE.json asks for fp32 losses/grads within 1e-5 relative of the reference's CPU path.
-// v_mfma_f32_16x16x4_f32 is an exact fp32 fmaf chain (MI355X_MICROARCH.md "Matrix cores") at the fp32
-// vector peak (157 TFLOP/s), so parity needs no error analysis and the VALU stays free for epilogues.
+// v_mfma_f32_16x16x4_f32 is an exact fp32 fmaf chain (MI355X_MICROARCH.md "Matrix cores") at the fp32 vector peak
+// (157 TFLOP/s), so parity needs no error analysis and the VALU stays free for epilogues.
 //
 //   gemm_nt : C[M][N] = epi(A[M][K] . B[N][K]^T)  -- both operands contraction-contiguous.
-//             forward:   A = activations, B = packed W[out][in]              (epi = bias / bias+relu / bias+tanh)
-//             backward:  A = dY,          B = packed W^T[in][out]            (epi = relu mask of the saved activation)
-//             The first layer reads its rows through an index vector (the minibatch gather of
-//             experience_buffer.py:82-87 fused into the A-tile load).
-//   gemm_tn : dW[N][K] += dY[M][N]^T . X[M][K], db[N] += colsum(dY) -- contraction over the row (sample) axis,
-//             split over workgroups along M and accumulated with fp32 atomics into the flat gradient arena
-//             (the reference accumulates minibatch gradients into .grad the same way, ppo_learner.py:179-180).
+//             forward:   A = activations, B = packed W[out][in]     (epi = bias / bias+relu / bias+tanh)
+//             backward:  A = dY,          B = packed W^T[in][out]   (epi = relu mask: bitmask of the forward, or the saved activation)
+//   gemm_tn : dW[N][K] += dY[M][N]^T . X[M][K], db[N] += colsum(dY) -- contraction over the row (sample) axis, split over
+//             workgroups along M into partial 128 x 128 tiles that a reduction kernel sums in a fixed order into the flat
+//             gradient arena (the reference accumulates minibatch gradients into .grad, ppo_learner.py:179-180).
 //
-// Tiling (both): 256 threads = 4 waves, LDS double buffer, one barrier per K step, 2 workgroups per CU.
-// MFMA operand trick: a lane loads 4 consecutive k with ONE ds_read_b128 and feeds them to 4 successive
-// 16x16x4 MFMAs; hardware k-slot (lane>>4) then covers k = 4*(lane>>4)+s in step s -- a permutation of the
-// contraction order applied identically to both operands, so the product is unchanged.
+// MFMA operand trick: a lane loads 4 consecutive k with ONE ds_read_b128 and feeds them to 4 successive 16x16x4 MFMAs;
+// hardware k-slot (lane>>4) then covers k = 4*(lane>>4)+s in step s -- a permutation of the contraction order applied
+// identically to both operands, so the product is unchanged.
+//
+// Scalar addressing (measured): while one wave of a SIMD streams MFMAs, a VALU instruction of ANOTHER wave
+// takes ~400 cycles to issue (a buffer load or an LDS-DMA does not).  Every address here is therefore an SGPR buffer
+// descriptor (tile origin + k advance, scalar ALU) + a 32-bit per-lane offset computed once; the A/B tiles go global -> LDS
+// by `buffer_load_dwordx4 ... lds` (no staging registers, no ds_write pass); the bias is the accumulators' initial value.
+// Operands must span < 2 GiB from a tile's first to its last addressed byte (host-checked).
 #include "common.hpp"
 
 namespace rlppo {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
-constexpr int BM = 128;  // rows per workgroup (gemm_nt)
+namespace {
+constexpr int SBM = 128;  // rows of a gemm_nt output tile
+constexpr int EPI_NONE = 99;  // nt_epilogue: store the accumulators as they are
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+// 128-bit buffer descriptor over [base, base + bytes): base and bytes must be wave-uniform.  Loads past `bytes` return 0
+// and stores past it are dropped by the hardware range check (used for the ragged last row tile).
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *base, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, bytes, 0x00020000);
+}
+// buffer_load_dwordx4 v, voff, srsrc, soff offen: per-lane 32-bit offset + scalar offset, no vector address arithmetic
+__device__ __forceinline__ f32x4 ldb(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
+__device__ __forceinline__ void stb(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, f32x4 v) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, voff, soff, 0);
+}
+// relu in ONE compiler-visible instruction: v_med3_f32(x, 0, +inf).  (x > 0 ? x : 0 compiles to two v_max because of NaN
+// canonicalisation; an inline-asm v_max is invisible to the MFMA -> VALU hazard recogniser and read accumulators early:
+// rare wrong activations under load, found by the 2-rank test.)  NaN -> 0 like the select form.
+__device__ __forceinline__ float relu1(float x) { return __builtin_amdgcn_fmed3f(x, 0.f, __builtin_inff()); }
+}  // namespace
 
-// LDS tile of R rows x BKT floats in 16-byte chunks, XOR-swizzled so that a ds_read_b128 fragment read (16 rows x
-// 4 chunk columns per instruction, issued to four 16-lane groups) touches 16 distinct 16-byte slots of the 256-byte
-// bank row -> conflict free (checked with SQ_LDS_BANK_CONFLICT = 0, profiles/r01_pmc_sq_v2.csv).
-//   BKT = 32: 8 chunks per row,  chunk ^ (row & 7)
-//   BKT = 16: 4 chunks per row,  chunk ^ ((-(row >> 2)) & 3)
+// epilogue shared by the nt kernels: lane owns C[m0 + wave*32 + 16 i + r16][n0 + 16 j + 4 q + (0..3)]; rows past M fall
+// outside the descriptor and are dropped by the range check
+template <int NB, int EPI>
+__device__ __forceinline__ void nt_epilogue(f32x4 (&acc)[2][NB], const float *mask_src, unsigned ldm_b, float *C, unsigned ldc_b,
+                                            int64_t m0, int n0, int rows_here, int wave, int r16, int q) {
+    constexpr int BN = NB * 16;
+    const int row_l = wave * 32 + r16;
+    const __amdgpu_buffer_rsrc_t c_rs = make_rsrc(reinterpret_cast<char *>(C) + m0 * ldc_b + (int64_t)n0 * 4,
+                                                  (unsigned)(rows_here - 1) * ldc_b + BN * 4);
+    const unsigned c_off = (unsigned)row_l * ldc_b + q * 16;
+    // The activation is applied IN PLACE over the accumulators first and the stores are issued afterwards, from registers
+    // that nothing writes again.  With a shared temporary (store v[0:3]; next v_max overwrites v0..v3) the 16-byte buffer
+    // stores were seen to pick up the NEXT block's values when the memory pipeline is backed up by another process
+    // (scratch/stress_nt.py; the compiler's hazard table treats a buffer store with an SGPR soffset as safe to overwrite).
+    if (EPI == EPI_MASK) {
+        const __amdgpu_buffer_rsrc_t m_rs = make_rsrc(reinterpret_cast<const char *>(mask_src) + m0 * ldm_b + (int64_t)n0 * 4,
+                                                      (unsigned)(rows_here - 1) * ldm_b + BN * 4);
+        const unsigned m_off = (unsigned)row_l * ldm_b + q * 16;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                const f32x4 h = ldb(m_rs, m_off, 16 * i * ldm_b + j * 64);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[i][j][e] = h[e] > 0.f ? acc[i][j][e] : 0.f;
+            }
+    } else if (EPI != EPI_BIAS && EPI != EPI_NONE) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < NB; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (EPI == EPI_BIAS_RELU) acc[i][j][e] = relu1(acc[i][j][e]);
+                    if (EPI == EPI_BIAS_TANH) acc[i][j][e] = tanhf(acc[i][j][e]);
+                }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j) stb(c_rs, c_off, 16 * i * ldc_b + j * 64, acc[i][j]);
+}
+
+// ReLU bitmask (rlppo_dbg_set(19)).  dX = (dY . W) masked by [h > 0] needs one BIT of the forward activation per element,
+// but re-reading h costs a 64 KB tile per workgroup whose latency nothing hides (the accumulators occupy the registers the
+// tile would have to be prefetched into): the masked epilogue is 11 % of a dX launch (scratch/epi_cost.py).  Instead the
+// forward epilogue of a hidden layer also emits, per lane, the 64 bits [acc > 0] of the 64 outputs the lane owns --
+// bit (i * NB + j) * 4 + e for C[.. + 16 i + r16][.. + 16 j + 4 q + e] -- as one 8-byte word at
+// bits[(row_tile * col_tiles + col_tile) * 256 + tid]; the dX kernel of the same tile geometry loads its word before the
+// K loop (2 VGPRs) and the epilogue is 2 VALU instructions per element with no memory access.  1/32 of the bytes of h.
+template <int NB>
+__device__ __forceinline__ unsigned long long relu_bits(const f32x4 (&acc)[2][NB]) {
+    unsigned lo = 0, hi = 0;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int b = (i * NB + j) * 4 + e;
+                const unsigned v = acc[i][j][e] > 0.f ? 1u : 0u;
+                if (b < 32) lo |= v << b;
+                else hi |= v << (b - 32);
+            }
+    return ((unsigned long long)hi << 32) | lo;
+}
+template <int NB>
+__device__ __forceinline__ void apply_bits(f32x4 (&acc)[2][NB], unsigned long long w) {
+    const unsigned lo = (unsigned)w, hi = (unsigned)(w >> 32);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int b = (i * NB + j) * 4 + e;
+                const unsigned m = 0u - (((b < 32 ? lo : hi) >> (b & 31)) & 1u);  // 0 or ~0
+                const float x = acc[i][j][e];  // a scalar copy: bit-casting the vector ELEMENT expression reads element 0
+                acc[i][j][e] = __uint_as_float(__float_as_uint(x) & m);
+            }
+}
+
+// XCD-aware tile order.  Workgroups are dispatched in linear id order (x fastest) and id i runs on XCD i % 8, each XCD with
+// its own L2.  The column tiles of one row tile read the same A rows, so they should run on the same XCD at about the same
+// time: ids are taken in groups of 8 * (column tiles); within a group, id g -> row tile 8*group + g % 8, column tile g / 8.
+// With row tiles as the fast index instead, the second reader of an A tile came 512-4096 workgroups later and, once A no
+// longer fitted the 256 MB memory-side cache (fused minibatches), from HBM again.
+__device__ __forceinline__ void xcd_tile(int &row_tile, int &col_tile) {
+    const int nr = gridDim.x, nc = gridDim.y;
+    row_tile = blockIdx.x;
+    col_tile = blockIdx.y;
+    if ((nr & 7) == 0 && nc > 1) {
+        const int id = blockIdx.y * nr + blockIdx.x, g = id % (8 * nc);
+        row_tile = (id / (8 * nc)) * 8 + (g & 7);
+        col_tile = g >> 3;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ gemm_nt, LDS-DMA staging
+// Same tile, but the A/B tiles go global -> LDS directly (buffer_load_dwordx4 ... lds, 16 B per lane, 1 KiB per wave
+// instruction): no staging registers, no ds_write pass, no vector instruction at all between the MFMA streams.  One wave
+// instruction fills 64/CPR consecutive LDS rows; the XOR swizzle of the LDS image is applied to the SOURCE address (the LDS
+// side of an LDS-DMA is lane-linear).  BKT = 16 halves the LDS footprint (32 KiB) so that 4 workgroups share a CU.
 template <int BKT>
-__device__ __forceinline__ int swz(int row, int chunk) {
+__device__ __forceinline__ int dswz(int row, int chunk) {
     if (BKT == 32) return row * 32 + ((chunk ^ (row & 7)) << 2);
     return row * 16 + ((chunk ^ ((0 - (row >> 2)) & 3)) << 2);
 }
 
-template <int NB, int EPI, bool GATHER, int BKT>
-__global__ __launch_bounds__(256, BKT == 16 ? 3 : 2) void gemm_nt_kernel(const float *__restrict__ A, int64_t lda,
-                                                          const int64_t *__restrict__ row_idx,
-                                                          const float *__restrict__ B, int64_t ldb,
-                                                          const float *__restrict__ bias,
-                                                          const float *__restrict__ mask_src, int64_t ld_mask,
-                                                          float *__restrict__ C, int64_t ldc, int64_t M, int K,
-                                                          int stagger) {
+template <int NB, int EPI, int BKT, bool BITS = false>
+__global__ __launch_bounds__(256, BKT == 16 ? 4 : 2) void gemm_nt_dma_kernel(const float *__restrict__ A, unsigned lda_b,
+                                                                              const float *__restrict__ B, unsigned ldb_b,
+                                                                              const float *__restrict__ bias,
+                                                                              const float *__restrict__ mask_src,
+                                                                              unsigned ldm_b, float *__restrict__ C,
+                                                                              unsigned ldc_b, int64_t M, int K,
+                                                                              unsigned long long *__restrict__ bits = nullptr) {
     constexpr int BN = NB * 16;
-    constexpr int CPR = BKT / 4;          // 16-byte chunks per staged row
-    constexpr int RPP = 256 / CPR;        // rows staged per pass of the 256 threads
-    constexpr int A_ITERS = BM / RPP;
-    constexpr int B_ITERS = BN / RPP;
+    constexpr int CPR = BKT / 4;     // 16-byte chunks per tile row
+    constexpr int RPW = 64 / CPR;    // tile rows one wave instruction fills
+    constexpr int RPP = 4 * RPW;     // rows per pass of the 4 waves
+    constexpr int A_IT = SBM / RPP, B_IT = BN / RPP;
     static_assert(BN % RPP == 0, "column tile must be a whole number of staging passes");
-    __shared__ __attribute__((aligned(16))) float lds[2 * BM * BKT + 2 * BN * BKT];
+    __shared__ __attribute__((aligned(16))) float lds[2 * SBM * BKT + 2 * BN * BKT];
     float *As = lds;
-    float *Bs = lds + 2 * BM * BKT;
+    float *Bs = lds + 2 * SBM * BKT;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);  // provably uniform: it addresses the DMA destination (M0)
     const int r16 = lane & 15, q = lane >> 4;
-    const int64_t m0 = (int64_t)blockIdx.x * BM;
-    const int n0 = blockIdx.y * BN;
+    int row_tile, col_tile;
+    xcd_tile(row_tile, col_tile);
+    const int64_t m0 = (int64_t)row_tile * SBM;
+    const int n0 = col_tile * BN;
+    const int rows_here = (int)((M - m0) < SBM ? (M - m0) : SBM);
+    unsigned long long *const bit_word = BITS ? bits + ((size_t)row_tile * gridDim.y + col_tile) * 256 + tid : nullptr;
+    unsigned long long mask_word = 0;
+    if (BITS && EPI == EPI_MASK) mask_word = *bit_word;  // requested before the K loop: long arrived when the epilogue needs it
 
-    // staging assignment: chunk = tid % CPR (16 B), rows tid / CPR + RPP * i
-    const int ld_chunk = tid % CPR, ld_row = tid / CPR;
-    const float *a_ptr[A_ITERS];
-#pragma unroll
-    for (int i = 0; i < A_ITERS; ++i) {
-        int64_t m = m0 + ld_row + RPP * i;
-        if (m >= M) m = M - 1;  // clamp: rows past M are computed but never stored
-        int64_t src = GATHER ? row_idx[m] : m;
-        a_ptr[i] = A + src * lda + ld_chunk * 4;
-    }
-    const float *b_ptr = B + (int64_t)(n0 + ld_row) * ldb + ld_chunk * 4;
+    const __amdgpu_buffer_rsrc_t a_rs = make_rsrc(reinterpret_cast<const char *>(A) + m0 * lda_b,
+                                                  (unsigned)(rows_here - 1) * lda_b + (unsigned)K * 4);
+    const __amdgpu_buffer_rsrc_t b_rs = make_rsrc(reinterpret_cast<const char *>(B) + (int64_t)n0 * ldb_b,
+                                                  (unsigned)(BN - 1) * ldb_b + (unsigned)K * 4);
+    // lane -> (row, physical chunk) of the 1 KiB piece its wave instruction fills; it fetches the logical chunk that the
+    // swizzle maps there (rows of later passes keep the swizzle key, so one offset serves all passes)
+    const int row_p = wave * RPW + lane / CPR, pch = lane % CPR;
+    const int lch = BKT == 32 ? (pch ^ (row_p & 7)) : (pch ^ ((0 - (row_p >> 2)) & 3));
+    const unsigned a_off = (unsigned)row_p * lda_b + lch * 16;
+    const unsigned b_off = (unsigned)row_p * ldb_b + lch * 16;
+    const unsigned a_step = (unsigned)RPP * lda_b, b_step = (unsigned)RPP * ldb_b;
 
     f32x4 acc[2][NB];
+    if (EPI == EPI_MASK) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < NB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int j = 0; j < NB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    } else {
+        const __amdgpu_buffer_rsrc_t bias_rs = make_rsrc(bias + n0, BN * 4);
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            acc[0][j] = ldb(bias_rs, (unsigned)(q * 16), j * 64);
+            acc[1][j] = acc[0][j];
+        }
+    }
 
-    f32x4 ra[A_ITERS], rb[B_ITERS];
+    auto issue_tile = [&](int buf, unsigned kb) {
+        float *Ad = As + buf * SBM * BKT + wave_u * RPW * BKT;
+        float *Bd = Bs + buf * BN * BKT + wave_u * RPW * BKT;
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rs, Ad + i * RPP * BKT, 16, a_off, kb + i * a_step, 0, 0);
+#pragma unroll
+        for (int i = 0; i < B_IT; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(b_rs, Bd + i * RPP * BKT, 16, b_off, kb + i * b_step, 0, 0);
+    };
+
     const int nk = K / BKT;
-
-    // Two workgroups share a CU and run identical code, so they reach their barrier / staging phases together and the
-    // MFMA pipe idles in those phases.  Delaying every second wave of workgroups (blocks 256..511, 768..1023, ...: the
-    // ones that land as the SECOND workgroup of a CU under the observed round-robin dispatch; speed only, never
-    // correctness) by about half a K step puts the pair out of phase for its whole life.
-    if (stagger > 0 && (((blockIdx.y * gridDim.x + blockIdx.x) >> 8) & 1))
-        for (int i = 0; i < stagger; ++i) __builtin_amdgcn_s_sleep(8);  // 8 x 64 cycles per unit
-    // prologue: tile 0 -> LDS buffer 0
-#pragma unroll
-    for (int i = 0; i < A_ITERS; ++i) ra[i] = *reinterpret_cast<const f32x4 *>(a_ptr[i]);
-#pragma unroll
-    for (int i = 0; i < B_ITERS; ++i) rb[i] = *reinterpret_cast<const f32x4 *>(b_ptr + (int64_t)(RPP * i) * ldb);
-#pragma unroll
-    for (int i = 0; i < A_ITERS; ++i) *reinterpret_cast<f32x4 *>(&As[swz<BKT>(ld_row + RPP * i, ld_chunk)]) = ra[i];
-#pragma unroll
-    for (int i = 0; i < B_ITERS; ++i) *reinterpret_cast<f32x4 *>(&Bs[swz<BKT>(ld_row + RPP * i, ld_chunk)]) = rb[i];
+    issue_tile(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
-        const bool more = (kt + 1) < nk;
-        if (more) {
-            const int koff = (kt + 1) * BKT;
-#pragma unroll
-            for (int i = 0; i < A_ITERS; ++i) ra[i] = *reinterpret_cast<const f32x4 *>(a_ptr[i] + koff);
-#pragma unroll
-            for (int i = 0; i < B_ITERS; ++i)
-                rb[i] = *reinterpret_cast<const f32x4 *>(b_ptr + (int64_t)(RPP * i) * ldb + koff);
-        }
-        const float *Ac = As + cur * BM * BKT + (wave * 32) * BKT;
+        if ((kt + 1) < nk) issue_tile(cur ^ 1, (unsigned)(kt + 1) * (BKT * 4));
+        const float *Ac = As + cur * SBM * BKT + (wave * 32) * BKT;
         const float *Bc = Bs + cur * BN * BKT;
 #pragma unroll
         for (int kc = 0; kc < BKT / 16; ++kc) {
             f32x4 fa[2], fb[NB];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) fa[i] = *reinterpret_cast<const f32x4 *>(&Ac[swz<BKT>(i * 16 + r16, kc * 4 + q)]);
+            for (int i = 0; i < 2; ++i) fa[i] = *reinterpret_cast<const f32x4 *>(&Ac[dswz<BKT>(i * 16 + r16, kc * 4 + q)]);
 #pragma unroll
-            for (int j = 0; j < NB; ++j) fb[j] = *reinterpret_cast<const f32x4 *>(&Bc[swz<BKT>(j * 16 + r16, kc * 4 + q)]);
+            for (int j = 0; j < NB; ++j) fb[j] = *reinterpret_cast<const f32x4 *>(&Bc[dswz<BKT>(j * 16 + r16, kc * 4 + q)]);
 #pragma unroll
             for (int s = 0; s < 4; ++s)
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
-                    for (int j = 0; j < NB; ++j)
-                        // D[n][m]: weights are the MFMA "A" operand so that a lane ends up with 4 consecutive n
-                        acc[i][j] = MFMA16(fb[j][s], fa[i][s], acc[i][j]);
+                    for (int j = 0; j < NB; ++j) acc[i][j] = MFMA16(fb[j][s], fa[i][s], acc[i][j]);
         }
-        if (more) {
-            float *An = As + (cur ^ 1) * BM * BKT;
-            float *Bn = Bs + (cur ^ 1) * BN * BKT;
-#pragma unroll
-            for (int i = 0; i < A_ITERS; ++i) *reinterpret_cast<f32x4 *>(&An[swz<BKT>(ld_row + RPP * i, ld_chunk)]) = ra[i];
-#pragma unroll
-            for (int i = 0; i < B_ITERS; ++i) *reinterpret_cast<f32x4 *>(&Bn[swz<BKT>(ld_row + RPP * i, ld_chunk)]) = rb[i];
-        }
+        __builtin_amdgcn_sched_barrier(0);  // keep the MFMAs above the wait: they are what hides the DMA latency
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of the next tile have landed in LDS
         __syncthreads();
     }
-
-    // epilogue: lane owns C[m = m0 + wave*32 + 16 i + r16][n = n0 + 16 j + 4 q + (0..3)]
+    if (BITS && EPI == EPI_MASK) {
+        apply_bits<NB>(acc, mask_word);
+        nt_epilogue<NB, EPI_NONE>(acc, nullptr, 0, C, ldc_b, m0, n0, rows_here, wave, r16, q);
+    } else if (BITS && EPI == EPI_BIAS_RELU) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int64_t m = m0 + wave * 32 + i * 16 + r16;
-        if (m >= M) continue;
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < NB; ++j) {
-            const int n = n0 + j * 16 + q * 4;
-            f32x4 v = acc[i][j];
-            if (EPI == EPI_MASK) {
-                const f32x4 h = *reinterpret_cast<const f32x4 *>(mask_src + m * ld_mask + n);
+            for (int j = 0; j < NB; ++j)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = h[e] > 0.f ? v[e] : 0.f;
-            } else {
-                const f32x4 bv = *reinterpret_cast<const f32x4 *>(bias + n);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float x = v[e] + bv[e];
-                    if (EPI == EPI_BIAS_RELU) x = x > 0.f ? x : 0.f;
-                    if (EPI == EPI_BIAS_TANH) x = tanhf(x);
-                    v[e] = x;
-                }
-            }
-            *reinterpret_cast<f32x4 *>(C + m * ldc + n) = v;
-        }
+                for (int e = 0; e < 4; ++e) acc[i][j][e] = relu1(acc[i][j][e]);
+        *bit_word = relu_bits<NB>(acc);
+        nt_epilogue<NB, EPI_NONE>(acc, nullptr, 0, C, ldc_b, m0, n0, rows_here, wave, r16, q);
+    } else {
+        nt_epilogue<NB, EPI>(acc, mask_src, ldm_b, C, ldc_b, m0, n0, rows_here, wave, r16, q);
     }
 }
 
-static int g_nt_bk = 32;  // tuning: rlppo_dbg_set(5, 16 | 32): K step of the staged kernel
-static int g_nt_stagger = 0;  // tuning: rlppo_dbg_set(7, units of 512 cycles)
-void set_nt_bk(int v) { g_nt_bk = v; }
-void set_nt_stagger(int v) { g_nt_stagger = v; }
+// ------------------------------------------------------------------------------------------------ gemm_nt, bf16 operands
+// Inference-only forward (BASELINE configs[4]: "bf16 fwd / fp32 master weights"): the fp32 activations and the fp32 master
+// weights are staged exactly as in gemm_nt_dma_kernel (fp32 tiles in LDS), rounded to bf16 when a lane builds its MFMA
+// operands, multiplied by v_mfma_f32_16x16x32_bf16 and accumulated / biased / activated in fp32.  Selected by
+// rlppo_set_inference_precision(1) for the rollout entry points only; rlppo_ppo_minibatch never uses it.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ bf16x8 to_bf16x8(const float *lo, const float *hi) {
+    const f32x4 a = *reinterpret_cast<const f32x4 *>(lo), b = *reinterpret_cast<const f32x4 *>(hi);
+    bf16x8 r;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        r[e] = (__bf16)a[e];
+        r[4 + e] = (__bf16)b[e];
+    }
+    return r;
+}
 
 template <int NB, int EPI>
-static int launch_nt_2(hipStream_t st, dim3 grid, const float *A, int64_t lda, const int64_t *row_idx, const float *B,
-                       int64_t ldb, const float *bias, const float *mask_src, int64_t ld_mask, float *C, int64_t ldc,
-                       int64_t M, int K) {
-    constexpr bool can16 = (NB * 16) % 64 == 0;  // BK=16 stages 64 rows per pass
-    if (can16 && g_nt_bk == 16) {
-        if (row_idx)
-            hipLaunchKernelGGL((gemm_nt_kernel<NB, EPI, true, can16 ? 16 : 32>), grid, dim3(256), 0, st, A, lda, row_idx, B,
-                               ldb, bias, mask_src, ld_mask, C, ldc, M, K, g_nt_stagger);
-        else
-            hipLaunchKernelGGL((gemm_nt_kernel<NB, EPI, false, can16 ? 16 : 32>), grid, dim3(256), 0, st, A, lda, row_idx,
-                               B, ldb, bias, mask_src, ld_mask, C, ldc, M, K, g_nt_stagger);
-    } else if (row_idx)
-        hipLaunchKernelGGL((gemm_nt_kernel<NB, EPI, true, 32>), grid, dim3(256), 0, st, A, lda, row_idx, B, ldb, bias,
-                           mask_src, ld_mask, C, ldc, M, K, g_nt_stagger);
-    else
-        hipLaunchKernelGGL((gemm_nt_kernel<NB, EPI, false, 32>), grid, dim3(256), 0, st, A, lda, row_idx, B, ldb, bias,
-                           mask_src, ld_mask, C, ldc, M, K, g_nt_stagger);
-    RLPPO_LAUNCH_CHECK();
-    return 0;
-}
-
-template <int NB>
-static int launch_nt_1(hipStream_t st, dim3 grid, int epi, const float *A, int64_t lda, const int64_t *row_idx,
-                       const float *B, int64_t ldb, const float *bias, const float *mask_src, int64_t ld_mask, float *C,
-                       int64_t ldc, int64_t M, int K) {
-    switch (epi) {
-        case EPI_BIAS: return launch_nt_2<NB, EPI_BIAS>(st, grid, A, lda, row_idx, B, ldb, bias, mask_src, ld_mask, C, ldc, M, K);
-        case EPI_BIAS_RELU: return launch_nt_2<NB, EPI_BIAS_RELU>(st, grid, A, lda, row_idx, B, ldb, bias, mask_src, ld_mask, C, ldc, M, K);
-        case EPI_BIAS_TANH: return launch_nt_2<NB, EPI_BIAS_TANH>(st, grid, A, lda, row_idx, B, ldb, bias, mask_src, ld_mask, C, ldc, M, K);
-        case EPI_MASK: return launch_nt_2<NB, EPI_MASK>(st, grid, A, lda, row_idx, B, ldb, bias, mask_src, ld_mask, C, ldc, M, K);
-    }
-    set_error("gemm_nt: bad epilogue %d", epi);
-    return RLPPO_ERR_ARG;
-}
-
-// --------------------------------------------------------------------------------- gemm_nt, weights-stationary
-// Second form of the same product for K <= 256 (every layer of the 256x3 nets): the whole B column tile
-// ([16*NB rows][K] fp32, <= 128 KB) is loaded into LDS ONCE per workgroup and stays there while the workgroup walks
-// over row tiles; every wave streams its own 32 A rows straight from global memory into MFMA fragments (one dwordx4
-// per 16x16 block and 16-deep k chunk, 4 chunks in flight), so the main loop has NO barrier and the 8 waves of a
-// workgroup drift apart instead of stalling together (the lock-step stalls of the staged kernel above cost ~35 % of
-// the MFMA pipe, profiles/r01_pmc_sq_v2.csv).  Row tiles are processed as one flattened (tile, k-chunk) pipeline so
-// the loads of the next tile are in flight while the current tile's epilogue stores drain.
-constexpr int WS_WAVES = 8;
-constexpr int WS_ROWS = WS_WAVES * 32;  // 256 rows per row tile
-constexpr int WS_DEPTH = 4;             // k chunks (16 floats) of A kept in flight per wave
-
-// Off by default: measured inside the whole update (tools/ab_update.py) the staged kernel is 5 % faster, because with
-// two kernels in flight (policy / critic chains) the staged form's 64 KB workgroups of both kernels share a CU, while
-// the stationary form's 128 KB workgroups cannot.  Kept selectable: rlppo_dbg_set(3, 1).
-static int g_nt_ws = 0;
-void set_nt_ws(int v) { g_nt_ws = v; }
-
-template <int NB, int EPI, bool GATHER>
-__global__ __launch_bounds__(512) void gemm_nt_ws_kernel(const float *__restrict__ A, int64_t lda,
-                                                          const int64_t *__restrict__ row_idx,
-                                                          const float *__restrict__ B, int64_t ldb,
-                                                          const float *__restrict__ bias,
-                                                          const float *__restrict__ mask_src, int64_t ld_mask,
-                                                          float *__restrict__ C, int64_t ldc, int64_t M, int K,
-                                                          int n_row_tiles) {
+__global__ __launch_bounds__(256, 2) void gemm_nt_bf16_kernel(const float *__restrict__ A, unsigned lda_b,
+                                                                              const float *__restrict__ B, unsigned ldb_b,
+                                                                              const float *__restrict__ bias,
+                                                                              const float *__restrict__ mask_src,
+                                                                              unsigned ldm_b, float *__restrict__ C,
+                                                                              unsigned ldc_b, int64_t M, int K) {
     constexpr int BN = NB * 16;
-    __shared__ __attribute__((aligned(16))) float Bs[BN * 256];
+    constexpr int BKT = 32;  // one v_mfma_f32_16x16x32_bf16 step per LDS tile
+    constexpr int CPR = BKT / 4;     // 16-byte chunks per tile row
+    constexpr int RPW = 64 / CPR;    // tile rows one wave instruction fills
+    constexpr int RPP = 4 * RPW;     // rows per pass of the 4 waves
+    constexpr int A_IT = SBM / RPP, B_IT = BN / RPP;
+    static_assert(BN % RPP == 0, "column tile must be a whole number of staging passes");
+    __shared__ __attribute__((aligned(16))) float lds[2 * SBM * BKT + 2 * BN * BKT];
+    float *As = lds;
+    float *Bs = lds + 2 * SBM * BKT;
+
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);  // provably uniform: it addresses the DMA destination (M0)
     const int r16 = lane & 15, q = lane >> 4;
-    const int n0 = blockIdx.y * BN;
-    const int kch = K >> 2;                       // 16-byte chunks per B row
-    const int swm = (kch & 15) == 0 ? 15 : 7;     // XOR swizzle mask (K is a multiple of 32, so kch % 8 == 0)
+    int row_tile, col_tile;
+    xcd_tile(row_tile, col_tile);
+    const int64_t m0 = (int64_t)row_tile * SBM;
+    const int n0 = col_tile * BN;
+    const int rows_here = (int)((M - m0) < SBM ? (M - m0) : SBM);
 
-    // ---- stationary operand: B[n0 .. n0+BN)[0..K) -> LDS, chunk c of row r stored at chunk c ^ (r & swm)
-    // (indexing Bs in float4 units tells the compiler the accesses are 16-byte aligned: ds_read_b128 / ds_write_b128)
-    f32x4 *Bs4 = reinterpret_cast<f32x4 *>(Bs);
-    for (int base = tid; base < BN * kch; base += 512 * 8) {  // 8 independent loads in flight per thread
-        f32x4 v[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int id = base + u * 512;
-            if (id < BN * kch) {
-                const int r = id / kch, c = id - r * kch;
-                v[u] = *reinterpret_cast<const f32x4 *>(B + (int64_t)(n0 + r) * ldb + c * 4);
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int id = base + u * 512;
-            if (id < BN * kch) {
-                const int r = id / kch, c = id - r * kch;
-                Bs4[r * kch + (c ^ (r & swm))] = v[u];
-            }
-        }
-    }
-    __syncthreads();
-
-    const int nkc = K >> 4;                       // 16-float k chunks per tile
-    const int my_tiles = (n_row_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
-    const int total = my_tiles * nkc;             // flattened (tile, chunk) steps of this workgroup
-
-    // row pointers of the tile currently being LOADED (two 16-row blocks per wave)
-    auto tile_row = [&](int t_local, int i) -> int64_t {
-        int64_t m = ((int64_t)blockIdx.x + (int64_t)t_local * gridDim.x) * WS_ROWS + wave * 32 + i * 16 + r16;
-        return m < M ? m : M - 1;  // clamp: rows past M are computed but never stored
-    };
-    const float *pa[2];
-    int64_t nxt_src[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int64_t m = tile_row(0, i);
-        pa[i] = A + (GATHER ? row_idx[m] : m) * lda + q * 4;
-        nxt_src[i] = GATHER ? row_idx[tile_row(1 < my_tiles ? 1 : 0, i)] : 0;
-    }
-    int ld_tile = 0, ld_kc = 0;  // position of the next load in the flattened sequence
-
-    f32x4 ring[WS_DEPTH][2];
-    auto issue = [&](f32x4 (&dst)[2]) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) dst[i] = *reinterpret_cast<const f32x4 *>(pa[i] + ld_kc * 16);
-        if (++ld_kc == nkc) {  // advance to the next tile of this workgroup
-            ld_kc = 0;
-            ++ld_tile;
-            const int t = ld_tile < my_tiles ? ld_tile : my_tiles - 1;
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int64_t m = tile_row(t, i);
-                pa[i] = A + (GATHER ? nxt_src[i] : m) * lda + q * 4;
-                if (GATHER) nxt_src[i] = row_idx[tile_row(t + 1 < my_tiles ? t + 1 : t, i)];
-            }
-        }
-    };
-#pragma unroll
-    for (int d = 0; d < WS_DEPTH; ++d) issue(ring[d]);  // loads past the end re-read the last tile (harmless)
+    const __amdgpu_buffer_rsrc_t a_rs = make_rsrc(reinterpret_cast<const char *>(A) + m0 * lda_b,
+                                                  (unsigned)(rows_here - 1) * lda_b + (unsigned)K * 4);
+    const __amdgpu_buffer_rsrc_t b_rs = make_rsrc(reinterpret_cast<const char *>(B) + (int64_t)n0 * ldb_b,
+                                                  (unsigned)(BN - 1) * ldb_b + (unsigned)K * 4);
+    // lane -> (row, physical chunk) of the 1 KiB piece its wave instruction fills; it fetches the logical chunk that the
+    // swizzle maps there (rows of later passes keep the swizzle key, so one offset serves all passes)
+    const int row_p = wave * RPW + lane / CPR, pch = lane % CPR;
+    const int lch = BKT == 32 ? (pch ^ (row_p & 7)) : (pch ^ ((0 - (row_p >> 2)) & 3));
+    const unsigned a_off = (unsigned)row_p * lda_b + lch * 16;
+    const unsigned b_off = (unsigned)row_p * ldb_b + lch * 16;
+    const unsigned a_step = (unsigned)RPP * lda_b, b_step = (unsigned)RPP * ldb_b;
 
     f32x4 acc[2][NB];
+    if (EPI == EPI_MASK) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < NB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    int cs_tile = 0, cs_kc = 0;  // position of the chunk being consumed
-    for (int step = 0; step < total; step += WS_DEPTH) {
+            for (int j = 0; j < NB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    } else {
+        const __amdgpu_buffer_rsrc_t bias_rs = make_rsrc(bias + n0, BN * 4);
 #pragma unroll
-        for (int u = 0; u < WS_DEPTH; ++u) {
-            if (step + u < total) {  // wave-uniform
-                f32x4 fa[2] = {ring[u][0], ring[u][1]};
-                issue(ring[u]);  // refill this ring slot with the chunk WS_DEPTH steps ahead
-                f32x4 fb[NB];
-                const int c = cs_kc * 4 + q;
-#pragma unroll
-                for (int j = 0; j < NB; ++j) {
-                    const int r = j * 16 + r16;
-                    fb[j] = Bs4[r * kch + (c ^ (r & swm))];
-                }
-#pragma unroll
-                for (int s = 0; s < 4; ++s)
-#pragma unroll
-                    for (int i = 0; i < 2; ++i)
-#pragma unroll
-                        for (int j = 0; j < NB; ++j) acc[i][j] = MFMA16(fb[j][s], fa[i][s], acc[i][j]);
-                if (++cs_kc == nkc) {  // tile finished: epilogue, then fresh accumulators
-                    cs_kc = 0;
-#pragma unroll
-                    for (int i = 0; i < 2; ++i) {
-                        const int64_t m = ((int64_t)blockIdx.x + (int64_t)cs_tile * gridDim.x) * WS_ROWS + wave * 32 + i * 16 + r16;
-#pragma unroll
-                        for (int j = 0; j < NB; ++j) {
-                            const int n = n0 + j * 16 + q * 4;
-                            f32x4 v = acc[i][j];
-                            acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-                            if (m < M) {
-                                if (EPI == EPI_MASK) {
-                                    const f32x4 h = *reinterpret_cast<const f32x4 *>(mask_src + m * ld_mask + n);
-#pragma unroll
-                                    for (int e = 0; e < 4; ++e) v[e] = h[e] > 0.f ? v[e] : 0.f;
-                                } else {
-                                    const f32x4 bv = *reinterpret_cast<const f32x4 *>(bias + n);
-#pragma unroll
-                                    for (int e = 0; e < 4; ++e) {
-                                        float x = v[e] + bv[e];
-                                        if (EPI == EPI_BIAS_RELU) x = x > 0.f ? x : 0.f;
-                                        if (EPI == EPI_BIAS_TANH) x = tanhf(x);
-                                        v[e] = x;
-                                    }
-                                }
-                                *reinterpret_cast<f32x4 *>(C + m * ldc + n) = v;
-                            }
-                        }
-                    }
-                    ++cs_tile;
-                }
-            }
+        for (int j = 0; j < NB; ++j) {
+            acc[0][j] = ldb(bias_rs, (unsigned)(q * 16), j * 64);
+            acc[1][j] = acc[0][j];
         }
     }
+
+    auto issue_tile = [&](int buf, unsigned kb) {
+        float *Ad = As + buf * SBM * BKT + wave_u * RPW * BKT;
+        float *Bd = Bs + buf * BN * BKT + wave_u * RPW * BKT;
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rs, Ad + i * RPP * BKT, 16, a_off, kb + i * a_step, 0, 0);
+#pragma unroll
+        for (int i = 0; i < B_IT; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(b_rs, Bd + i * RPP * BKT, 16, b_off, kb + i * b_step, 0, 0);
+    };
+
+    const int nk = K / BKT;
+    issue_tile(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if ((kt + 1) < nk) issue_tile(cur ^ 1, (unsigned)(kt + 1) * (BKT * 4));
+        const float *Ac = As + cur * SBM * BKT + (wave * 32) * BKT;
+        const float *Bc = Bs + cur * BN * BKT;
+        // lane (r16, q) holds k = 8 q .. 8 q + 7 of its row: chunks 2 q and 2 q + 1 of the swizzled fp32 image, rounded to
+        // bf16 (round-to-nearest-even, v_cvt_pk_bf16_f32) as they become MFMA operands
+        bf16x8 fa[2], fb[NB];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) fa[i] = to_bf16x8(&Ac[dswz<32>(i * 16 + r16, 2 * q)], &Ac[dswz<32>(i * 16 + r16, 2 * q + 1)]);
+#pragma unroll
+        for (int j = 0; j < NB; ++j) fb[j] = to_bf16x8(&Bc[dswz<32>(j * 16 + r16, 2 * q)], &Bc[dswz<32>(j * 16 + r16, 2 * q + 1)]);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < NB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);  // keep the MFMAs above the wait: they are what hides the DMA latency
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of the next tile have landed in LDS
+        __syncthreads();
+    }
+    nt_epilogue<NB, EPI>(acc, mask_src, ldm_b, C, ldc_b, m0, n0, rows_here, wave, r16, q);
 }
 
-template <int NB, int EPI>
-static int launch_ws_2(hipStream_t st, dim3 grid, const float *A, int64_t lda, const int64_t *row_idx, const float *B,
-                       int64_t ldb, const float *bias, const float *mask_src, int64_t ld_mask, float *C, int64_t ldc,
-                       int64_t M, int K, int n_row_tiles) {
-    if (row_idx)
-        hipLaunchKernelGGL((gemm_nt_ws_kernel<NB, EPI, true>), grid, dim3(512), 0, st, A, lda, row_idx, B, ldb, bias,
-                           mask_src, ld_mask, C, ldc, M, K, n_row_tiles);
-    else
-        hipLaunchKernelGGL((gemm_nt_ws_kernel<NB, EPI, false>), grid, dim3(512), 0, st, A, lda, row_idx, B, ldb, bias,
-                           mask_src, ld_mask, C, ldc, M, K, n_row_tiles);
+template <int NB>
+static int launch_nt_1(hipStream_t st, dim3 grid, int epi, const float *A, unsigned lda_b, const float *B, unsigned ldb_b,
+                       const float *bias, const float *mask_src, unsigned ldm_b, float *C, unsigned ldc_b, int64_t M,
+                       int K) {
+    // BK = 16 (32 KiB of LDS, four workgroups per CU) fills 64 tile rows per staging pass: column tiles of 32 / 96 take BK = 32
+    constexpr int BKT = (NB * 16) % 64 == 0 ? 16 : 32;
+#define NT(E)                                                                                                          \
+    case E:                                                                                                            \
+        hipLaunchKernelGGL((gemm_nt_dma_kernel<NB, E, BKT>), grid, dim3(256), 0, st, A, lda_b, B, ldb_b, bias, mask_src, \
+                           ldm_b, C, ldc_b, M, K);                                                                     \
+        break;
+    switch (epi) {
+        NT(EPI_BIAS) NT(EPI_BIAS_RELU) NT(EPI_BIAS_TANH) NT(EPI_MASK)
+        default:
+            set_error("gemm_nt: bad epilogue %d", epi);
+            return RLPPO_ERR_ARG;
+    }
+#undef NT
     RLPPO_LAUNCH_CHECK();
     return 0;
 }
 
+static int g_infer_bf16 = 0;  // rlppo_set_inference_precision
+void set_infer_bf16(int v) { g_infer_bf16 = v; }
+int get_infer_bf16() { return g_infer_bf16; }
+
 template <int NB>
-static int launch_ws_1(hipStream_t st, dim3 grid, int epi, const float *A, int64_t lda, const int64_t *row_idx,
-                       const float *B, int64_t ldb, const float *bias, const float *mask_src, int64_t ld_mask, float *C,
-                       int64_t ldc, int64_t M, int K, int n_row_tiles) {
+static int launch_bf16_1(hipStream_t st, dim3 grid, int epi, const float *A, unsigned lda_b, const float *B, unsigned ldb_b,
+                         const float *bias, float *C, unsigned ldc_b, int64_t M, int K) {
+#define BF(E)                                                                                                          \
+    case E:                                                                                                            \
+        hipLaunchKernelGGL((gemm_nt_bf16_kernel<NB, E>), grid, dim3(256), 0, st, A, lda_b, B, ldb_b, bias, nullptr, 0u, C, \
+                           ldc_b, M, K);                                                                               \
+        break;
     switch (epi) {
-        case EPI_BIAS: return launch_ws_2<NB, EPI_BIAS>(st, grid, A, lda, row_idx, B, ldb, bias, mask_src, ld_mask, C, ldc, M, K, n_row_tiles);
-        case EPI_BIAS_RELU: return launch_ws_2<NB, EPI_BIAS_RELU>(st, grid, A, lda, row_idx, B, ldb, bias, mask_src, ld_mask, C, ldc, M, K, n_row_tiles);
-        case EPI_BIAS_TANH: return launch_ws_2<NB, EPI_BIAS_TANH>(st, grid, A, lda, row_idx, B, ldb, bias, mask_src, ld_mask, C, ldc, M, K, n_row_tiles);
-        case EPI_MASK: return launch_ws_2<NB, EPI_MASK>(st, grid, A, lda, row_idx, B, ldb, bias, mask_src, ld_mask, C, ldc, M, K, n_row_tiles);
+        BF(EPI_BIAS) BF(EPI_BIAS_RELU) BF(EPI_BIAS_TANH)
+        default:
+            set_error("gemm_nt (bf16 operands): epilogue %d is not a forward epilogue", epi);
+            return RLPPO_ERR_ARG;
     }
-    set_error("gemm_nt: bad epilogue %d", epi);
-    return RLPPO_ERR_ARG;
+#undef BF
+    RLPPO_LAUNCH_CHECK();
+    return 0;
 }
 
-int launch_gemm_nt(hipStream_t st, const float *A, int64_t lda, const int64_t *row_idx, const float *B, int64_t ldb,
-                   const float *bias, const float *mask_src, int64_t ld_mask, float *C, int64_t ldc, int64_t M, int N,
-                   int K, int epi, int bf16_operands) {
+// forward product with bf16-rounded operands; same argument checks as launch_gemm_nt (done by the caller)
+int launch_gemm_nt_bf16(hipStream_t st, const float *A, int64_t lda, const float *B, int64_t ldb, const float *bias, float *C,
+                        int64_t ldc, int64_t M, int N, int nb, int K, int epi) {
+    dim3 grid((unsigned)cdiv(M, SBM), (unsigned)(N / (nb * 16)));
+    const unsigned la = (unsigned)(lda * 4), lb = (unsigned)(ldb * 4), lc = (unsigned)(ldc * 4);
+    switch (nb) {
+        case 8: return launch_bf16_1<8>(st, grid, epi, A, la, B, lb, bias, C, lc, M, K);
+        case 6: return launch_bf16_1<6>(st, grid, epi, A, la, B, lb, bias, C, lc, M, K);
+        case 4: return launch_bf16_1<4>(st, grid, epi, A, la, B, lb, bias, C, lc, M, K);
+        default: return launch_bf16_1<2>(st, grid, epi, A, la, B, lb, bias, C, lc, M, K);
+    }
+}
+
+// floats of workspace one hidden layer's ReLU bitmask needs (8 bytes per lane and 128 x 128 tile); 0 = width not supported
+size_t nt_bits_floats(int64_t M, int N) {
+    if (N % 128 != 0 || M <= 0) return 0;
+    return (size_t)cdiv(M, SBM) * (size_t)(N / 128) * 256 * 2;
+}
+// The hidden-layer forward (epi = EPI_BIAS_RELU: writes `bits`) or the masked dX product (epi = EPI_MASK: reads `bits`
+// instead of the activation) through gemm_nt_dma_kernel<8, ., 16, true>.  Returns -1 when that form does not apply
+// (width not a multiple of 128, operands too wide for 32-bit tile offsets): the caller then uses launch_gemm_nt
+// and, for the forward, must not hand the bitmask to the backward pass.
+int launch_gemm_nt_bits(hipStream_t st, const float *A, int64_t lda, const float *B, int64_t ldb, const float *bias, float *C,
+                        int64_t ldc, int64_t M, int N, int K, int epi, unsigned long long *bits) {
+    if (!bits || N % 128 != 0 || K % 16 != 0 || M <= 0) return -1;
+    if (epi != EPI_BIAS_RELU && epi != EPI_MASK) return -1;
+    const int64_t lim = (int64_t)1 << 31;
+    if (129 * lda * 4 >= lim || 129 * ldb * 4 >= lim || 129 * ldc * 4 >= lim) return -1;
+    dim3 grid((unsigned)cdiv(M, SBM), (unsigned)(N / 128));
+    const unsigned la = (unsigned)(lda * 4), lb = (unsigned)(ldb * 4), lc = (unsigned)(ldc * 4);
+    if (epi == EPI_BIAS_RELU)
+        hipLaunchKernelGGL((gemm_nt_dma_kernel<8, EPI_BIAS_RELU, 16, true>), grid, dim3(256), 0, st, A, la, B, lb, bias, nullptr,
+                           0u, C, lc, M, K, bits);
+    else
+        hipLaunchKernelGGL((gemm_nt_dma_kernel<8, EPI_MASK, 16, true>), grid, dim3(256), 0, st, A, la, B, lb, nullptr, nullptr, 0u,
+                           C, lc, M, K, bits);
+    RLPPO_LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_gemm_nt(hipStream_t st, const float *A, int64_t lda, const float *B, int64_t ldb, const float *bias,
+                   const float *mask_src, int64_t ld_mask, float *C, int64_t ldc, int64_t M, int N, int K, int epi,
+                   int bf16_operands) {
     if (M <= 0) return 0;
     RLPPO_CHECK_ARG(K > 0 && K % 32 == 0, "gemm_nt: K=%d must be a positive multiple of 32", K);
     RLPPO_CHECK_ARG(lda % 4 == 0 && ldb % 4 == 0 && ldc % 4 == 0 && lda >= K && ldb >= K && ldc >= N,
@@ -415,244 +486,285 @@ int launch_gemm_nt(hipStream_t st, const float *A, int64_t lda, const int64_t *r
         set_error("gemm_nt: N=%d is not a padded output width", N);
         return RLPPO_ERR_ARG;
     }
-    if (bf16_operands && !row_idx && epi != EPI_MASK && 129 * lda * 4 < ((int64_t)1 << 31) && 129 * ldc * 4 < ((int64_t)1 << 31))
-        return launch_gemm_nt_bf16(st, A, lda, B, ldb, bias, C, ldc, M, N, nb, K, epi);  // inference-only forward (gemm_sa.hip)
-    if (!row_idx && !g_nt_ws) {
-        // default for ungathered operands: the scalar-addressed kernel (gemm_sa.hip); -1 = not applicable
-        const int rc = launch_gemm_nt_sa(st, A, lda, B, ldb, bias, mask_src, ld_mask, C, ldc, M, N, nb, K, epi);
-        if (rc != -1) return rc;
-    }
-    if (g_nt_ws && K <= 256 && M >= 4 * WS_ROWS) {
-        // one workgroup per CU: grid.x * (column tiles) ~ number of CUs, each workgroup walks several row tiles
-        const int n_row_tiles = (int)cdiv(M, WS_ROWS);
-        const int col_tiles = N / (nb * 16);
-        int gx = 256 / col_tiles;
-        if (gx > n_row_tiles) gx = n_row_tiles;
-        dim3 wgrid((unsigned)gx, (unsigned)col_tiles);
-        switch (nb) {
-            case 8: return launch_ws_1<8>(st, wgrid, epi, A, lda, row_idx, B, ldb, bias, mask_src, ld_mask, C, ldc, M, K, n_row_tiles);
-            case 6: return launch_ws_1<6>(st, wgrid, epi, A, lda, row_idx, B, ldb, bias, mask_src, ld_mask, C, ldc, M, K, n_row_tiles);
-            case 4: return launch_ws_1<4>(st, wgrid, epi, A, lda, row_idx, B, ldb, bias, mask_src, ld_mask, C, ldc, M, K, n_row_tiles);
-            default: return launch_ws_1<2>(st, wgrid, epi, A, lda, row_idx, B, ldb, bias, mask_src, ld_mask, C, ldc, M, K, n_row_tiles);
-        }
-    }
-    dim3 grid((unsigned)cdiv(M, BM), (unsigned)(N / (nb * 16)));
+    // offsets are relative to the workgroup's tile origin, so the 32-bit range only limits the leading dimensions
+    const int64_t lim = (int64_t)1 << 31;
+    RLPPO_CHECK_ARG(129 * lda * 4 < lim && 129 * ldb * 4 < lim && 129 * ldc * 4 < lim && 129 * ld_mask * 4 < lim,
+                    "gemm_nt: a leading dimension is too wide for 32-bit tile offsets");
+    if (bf16_operands && epi != EPI_MASK) return launch_gemm_nt_bf16(st, A, lda, B, ldb, bias, C, ldc, M, N, nb, K, epi);
+    dim3 grid((unsigned)cdiv(M, SBM), (unsigned)(N / (nb * 16)));
+    const unsigned la = (unsigned)(lda * 4), lb = (unsigned)(ldb * 4), lc = (unsigned)(ldc * 4), lm = (unsigned)(ld_mask * 4);
     switch (nb) {
-        case 8: return launch_nt_1<8>(st, grid, epi, A, lda, row_idx, B, ldb, bias, mask_src, ld_mask, C, ldc, M, K);
-        case 6: return launch_nt_1<6>(st, grid, epi, A, lda, row_idx, B, ldb, bias, mask_src, ld_mask, C, ldc, M, K);
-        case 4: return launch_nt_1<4>(st, grid, epi, A, lda, row_idx, B, ldb, bias, mask_src, ld_mask, C, ldc, M, K);
-        default: return launch_nt_1<2>(st, grid, epi, A, lda, row_idx, B, ldb, bias, mask_src, ld_mask, C, ldc, M, K);
+        case 8: return launch_nt_1<8>(st, grid, epi, A, la, B, lb, bias, mask_src, lm, C, lc, M, K);
+        case 6: return launch_nt_1<6>(st, grid, epi, A, la, B, lb, bias, mask_src, lm, C, lc, M, K);
+        case 4: return launch_nt_1<4>(st, grid, epi, A, la, B, lb, bias, mask_src, lm, C, lc, M, K);
+        default: return launch_nt_1<2>(st, grid, epi, A, la, B, lb, bias, mask_src, lm, C, lc, M, K);
     }
 }
 
-// ------------------------------------------------------------------------------------------------- gemm_tn
-static int g_tn_rows_override = 0;  // tuning: rlppo_dbg_set(2, rows)
-void set_tn_rows(int r) { g_tn_rows_override = r; }
-// tuning: rlppo_dbg_set(12, rows): split of products with >= 4 output tiles.  With the LDS-DMA kernel and the two chains
-// overlapping (bench.py, M samples/s): 512 rows 49.2, 640 50.4, 768 50.7-50.9, 896 50.3, 1024 49.8
-static int g_tn_rows_big = 768;
-void set_tn_rows_big(int r) { g_tn_rows_big = r; }
-constexpr int TM = 32;        // sample rows per LDS stage
-constexpr int TLD = 128 + 16; // LDS row stride (floats): +16 puts rows m and m+1 on opposite bank halves (ds_read_b32)
+namespace {
+constexpr int TM = 32;                 // sample rows per LDS stage
+constexpr unsigned OOR = 0x80000000u;  // per-lane offset that fails every descriptor's range check
+}  // namespace
 
-template <bool GATHER>
-__global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const float *__restrict__ dY, int64_t ldy, int ny_valid,
-                                                          const float *__restrict__ X, int64_t ldx,
-                                                          const int64_t *__restrict__ row_idx, int kx_valid,
-                                                          float *__restrict__ dW, float *__restrict__ db, int out,
-                                                          int in, int64_t M, int rows_per_wg) {
-    __shared__ __attribute__((aligned(16))) float lds[2 * 2 * TM * TLD];
-    float *Ys = lds;                 // [2][TM][TLD]
-    float *Xs = lds + 2 * TM * TLD;  // [2][TM][TLD]
+// ------------------------------------------------------------------------------------------------ gemm_tn, LDS-DMA staging
+// The dY / X stages go global -> LDS by buffer_load ... lds: a 1 KiB piece = 2 stage rows of 128 floats.  The LDS image is
+// unpadded; rows m..m+3 of one 16-float column group (what a ds_read_b32 fragment read touches) are spread over the banks
+// by XOR-ing the 16-byte chunk index with (m & 3) << 2, applied on the SOURCE address.  db column sums are read back from
+// the staged dY tile (only by the workgroups of the first k tile).
+//
+// No atomics: 64 fp32 atomics per lane into dW cost 20-50 us of an 86 us launch (128-256 workgroups adding into the same
+// 110-256 KB serialise in the memory-side atomic units).  The workgroup stores its 128 x 128 partial tile with 16 coalesced
+// 16-byte stores per lane into partial[split][tile][(i*4+j)*256 + tid] and tn_reduce_kernel sums the splits afterwards: the
+// sum order is fixed, so the weight gradients are bit-reproducible from run to run.
+template <int TMT>
+__global__ __launch_bounds__(256, 2) void gemm_tn_dma_kernel(const float *__restrict__ dY, unsigned ldy_b,
+                                                                              int ny_valid, const float *__restrict__ X,
+                                                                              unsigned ldx_b, int kx_valid,
+                                                                              bool with_db, int out, int in, int64_t M,
+                                                                              int rows_per_wg, float *__restrict__ partial) {
+    constexpr int PPW = TMT / 8;  // 1 KiB pieces per wave, per operand and stage
+    __shared__ __attribute__((aligned(16))) float lds[2 * 2 * TMT * 128 < 8 * 128 ? 8 * 128 : 2 * 2 * TMT * 128];
+    float *Ys = lds;                 // [2][TMT][128]
+    float *Xs = lds + 2 * TMT * 128;  // [2][TMT][128]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     const int r16 = lane & 15, q = lane >> 4;
     const int wn = wave >> 1, wk = wave & 1;
-    const int n0 = blockIdx.x * 128, k0 = blockIdx.y * 128;
-    const int64_t mbeg = (int64_t)blockIdx.z * rows_per_wg;
-    const int64_t mend = (mbeg + rows_per_wg < M) ? mbeg + rows_per_wg : M;
-    const int steps = (int)((mend - mbeg + TM - 1) / TM);
+    // XCD-aware order (see xcd_tile): the output tiles of one row split read the same dY / X rows, so they are given ids
+    // that land on the same XCD back to back: id -> tile = (id % (8 T)) / 8, split = 8 (id / (8 T)) + id % 8
+    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    {
+        const int T = gridDim.x * gridDim.y;
+        if ((gridDim.z & 7) == 0 && T > 1) {
+            const int id = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x, g = id % (8 * T);
+            const int tile = g >> 3;
+            bz = (id / (8 * T)) * 8 + (g & 7);
+            bx = tile % gridDim.x;
+            by = tile / gridDim.x;
+        }
+    }
+    const int n0 = bx * 128, k0 = by * 128;
+    const int64_t mbeg = (int64_t)bz * rows_per_wg;
+    const int rows = (int)((M - mbeg) < rows_per_wg ? (M - mbeg) : rows_per_wg);  // >= 1
+    const int steps = (rows + TMT - 1) / TMT;
+    const int rem = rows - (steps - 1) * TMT;  // rows of the last stage, 1..TMT
+    const int ny_here = (ny_valid - n0) < 128 ? (ny_valid - n0) : 128;
+    const int kx_here = (kx_valid - k0) < 128 ? (kx_valid - k0) : 128;
 
-    // staging: chunk = tid & 31 (16 B of a 128-float row), rows (tid >> 5) + 8 i
-    const int ld_chunk = tid & 31, ld_row = tid >> 5;
-    const bool y_col_ok = (n0 + ld_chunk * 4) < ny_valid;
-    const bool x_col_ok = (k0 + ld_chunk * 4) < kx_valid;
+    const __amdgpu_buffer_rsrc_t y_rs = make_rsrc(reinterpret_cast<const char *>(dY) + mbeg * ldy_b + (int64_t)n0 * 4,
+                                                  (unsigned)(rows - 1) * ldy_b + (unsigned)ny_here * 4);
+    const __amdgpu_buffer_rsrc_t x_rs = make_rsrc(reinterpret_cast<const char *>(X) + mbeg * ldx_b + (int64_t)k0 * 4,
+                                                  (unsigned)(rows - 1) * ldx_b + (unsigned)kx_here * 4);
+    // DMA lane map: piece = rows 2 (wave + 4 i) + (lane >> 5); physical chunk lane & 31 holds logical chunk ^ ((row & 3) << 2)
+    const int row_l = 2 * wave + (lane >> 5);
+    const int lch = (lane & 31) ^ ((row_l & 3) << 2);
+    const unsigned y_off = (lch * 4 < ny_here) ? (unsigned)row_l * ldy_b + lch * 16 : OOR;
+    const unsigned x_off = (lch * 4 < kx_here) ? (unsigned)row_l * ldx_b + lch * 16 : OOR;
+    const unsigned y_row8 = 8u * ldy_b, x_row8 = 8u * ldx_b, y_stage = TMT * ldy_b, x_stage = TMT * ldx_b;  // uniform
+
+    auto issue_stage = [&](int buf, int stage) {
+        float *Yd = Ys + (buf * TMT + 2 * wave_u) * 128, *Xd = Xs + (buf * TMT + 2 * wave_u) * 128;
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(y_rs, Yd + 8 * i * 128, 16, y_off, (unsigned)stage * y_stage + i * y_row8, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rs, Xd + 8 * i * 128, 16, x_off, (unsigned)stage * x_stage + i * x_row8, 0, 0);
+        }
+    };
+    // a ragged last stage: the DMA drops the rows past the split, so their (stale) LDS rows are cleared by hand
+    const int zr = tid >> 5, zc = (tid & 31) * 4;
+    auto clear_tail = [&](int buf) {
+        const f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int r = rem + zr; r < TMT; r += 8) {
+            *reinterpret_cast<f32x4 *>(&Ys[(buf * TMT + r) * 128 + zc]) = z;
+            *reinterpret_cast<f32x4 *>(&Xs[(buf * TMT + r) * 128 + zc]) = z;
+        }
+    };
 
     f32x4 acc[4][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    // db: every thread keeps the column sums of the dY rows IT stages (4 columns), straight from the staging registers
     f32x4 bs4 = f32x4{0.f, 0.f, 0.f, 0.f};
-    const bool want_db = db != nullptr && blockIdx.y == 0;
+    const bool want_db = with_db && by == 0;
 
-    f32x4 ry[4], rx[4];
-    // gathered X rows: the row indices of stage st+2 are fetched while the data of stage st+1 is in flight, so the
-    // dependent index -> address -> data chain costs one memory latency per stage instead of two
-    int64_t src_next[4];
-    auto load_idx = [&](int step) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int64_t m = mbeg + (int64_t)step * TM + ld_row + 8 * i;
-            src_next[i] = (GATHER && m < mend) ? row_idx[m] : 0;
-        }
-    };
-    auto load_tile = [&](int step) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int64_t m = mbeg + (int64_t)step * TM + ld_row + 8 * i;
-            const bool ok = m < mend;
-            f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
-            ry[i] = (ok && y_col_ok) ? *reinterpret_cast<const f32x4 *>(dY + m * ldy + n0 + ld_chunk * 4) : z;
-            const int64_t src = GATHER ? src_next[i] : m;
-            rx[i] = (ok && x_col_ok) ? *reinterpret_cast<const f32x4 *>(X + src * ldx + k0 + ld_chunk * 4) : z;
-        }
-        if (GATHER) load_idx(step + 1);
-    };
-    auto store_tile = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            *reinterpret_cast<f32x4 *>(&Ys[(buf * TM + ld_row + 8 * i) * TLD + ld_chunk * 4]) = ry[i];
-            *reinterpret_cast<f32x4 *>(&Xs[(buf * TM + ld_row + 8 * i) * TLD + ld_chunk * 4]) = rx[i];
-            if (want_db) bs4 += ry[i];
-        }
-    };
-
-    if (steps > 0) {
-        load_idx(0);
-        load_tile(0);
-        store_tile(0);
-    }
+    issue_stage(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (steps == 1 && rem < TMT) clear_tail(0);
     __syncthreads();
+    // fragment addresses: element (m, col) lives at m*128 + (col ^ ((m & 3) << 4)); m & 3 == q for every fragment read
+    int fy[4], fx[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        fy[i] = q * 128 + wn * 64 + ((i ^ q) << 4) + r16;
+        fx[i] = q * 128 + wk * 64 + ((i ^ q) << 4) + r16;
+    }
+    const int db_off = zr * 128 + zc;  // db partial sums: rows zr + 8 i, physical chunk tid & 31
     for (int st = 0; st < steps; ++st) {
         const int cur = st & 1;
         const bool more = (st + 1) < steps;
-        if (more) load_tile(st + 1);
-        const float *Yc = Ys + cur * TM * TLD;
-        const float *Xc = Xs + cur * TM * TLD;
+        if (more) issue_stage(cur ^ 1, st + 1);
+        const float *Yc = Ys + cur * TMT * 128;
+        const float *Xc = Xs + cur * TMT * 128;
+        if (want_db) {
 #pragma unroll
-        for (int c = 0; c < TM / 16; ++c) {
+            for (int i = 0; i < PPW; ++i) bs4 += *reinterpret_cast<const f32x4 *>(&Yc[db_off + 8 * i * 128]);
+        }
+#pragma unroll
+        for (int c = 0; c < TMT / 16; ++c) {
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
-                const int m = c * 16 + s * 4 + q;  // the row this lane's k-slot covers in step s
+                const int m = c * 16 + s * 4;  // + q
                 float fa[4], fb[4];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) fa[i] = Yc[m * TLD + wn * 64 + i * 16 + r16];
+                for (int i = 0; i < 4; ++i) fa[i] = Yc[m * 128 + fy[i]];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) fb[j] = Xc[m * TLD + wk * 64 + j * 16 + r16];
+                for (int j = 0; j < 4; ++j) fb[j] = Xc[m * 128 + fx[j]];
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
                     for (int j = 0; j < 4; ++j) acc[i][j] = MFMA16(fa[i], fb[j], acc[i][j]);
             }
         }
-        if (more) store_tile(cur ^ 1);
+        __builtin_amdgcn_sched_barrier(0);  // keep the MFMAs above the wait: they are what hides the DMA latency
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (more && (st + 2) == steps && rem < TMT) clear_tail(cur ^ 1);
         __syncthreads();
     }
 
-    // D[n][k]: lane owns rows n = 16 i + 4 q + e, column k = 16 j + r16
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int k = k0 + wk * 64 + j * 16 + r16;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int n = n0 + wn * 64 + i * 16 + q * 4 + e;
-                if (n < out && k < in) atomicAdd(dW + (int64_t)n * in + k, acc[i][j][e]);
-            }
-        }
     if (want_db) {  // 8 threads (tid >> 5) hold partial sums of the same 4 columns: fold them through LDS
         float *red = lds;  // [8][128]; the staging buffers are dead (the loop ended with a barrier)
-        *reinterpret_cast<f32x4 *>(&red[ld_row * 128 + ld_chunk * 4]) = bs4;
+        const int lcol = ((tid & 31) ^ ((zr & 3) << 2)) * 4;  // the logical columns this thread's physical chunk holds
+        *reinterpret_cast<f32x4 *>(&red[zr * 128 + lcol]) = bs4;
         __syncthreads();
         if (tid < 128 && (n0 + tid) < out) {
             float sum = 0.f;
 #pragma unroll
             for (int r = 0; r < 8; ++r) sum += red[r * 128 + tid];
-            atomicAdd(db + n0 + tid, sum);
+            // column sums of this split: partial_db[split][n tile][128], behind the tile partials
+            partial[(size_t)gridDim.z * gridDim.y * gridDim.x * (128 * 128) + ((size_t)bz * gridDim.x + bx) * 128 + tid] = sum;
         }
+    }
+    // The partial-tile stores are the LAST instructions of the wave: 16-byte buffer stores whose data registers are written
+    // again soon afterwards can pick up the new values (the hazard of section 5 / tests/test_gpu_stress.py); here the
+    // accumulators are never touched after them.
+    {
+        const size_t tile_id = (size_t)bz * (gridDim.x * gridDim.y) + (size_t)by * gridDim.x + bx;
+        const __amdgpu_buffer_rsrc_t p_rs = make_rsrc(partial + tile_id * (128 * 128), 128 * 128 * 4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) stb(p_rs, (unsigned)tid * 16, (unsigned)(i * 4 + j) * 4096, acc[i][j]);
     }
 }
 
-int launch_gemm_tn(hipStream_t st, const float *dY, int64_t ldy, int ny_valid, const float *X, int64_t ldx,
-                   const int64_t *row_idx, int kx_valid, float *dW, float *db, int out, int in, int64_t M, float *ws,
-                   size_t ws_floats) {
+// Sums the partial tiles of gemm_tn_dma_kernel over the splits and adds the result into dW[out][in].
+// Block = 64 consecutive 16-byte elements of one tile x 4 split lanes (one wave each: 1 KiB coalesced per load, 8 loads
+// in flight); the four partial sums meet in LDS.  The final add is an atomic only so that launches of different
+// minibatches that share dW stay safe; there is exactly one per element and launch.
+__global__ __launch_bounds__(256) void tn_reduce_kernel(const float *__restrict__ partial, int splits, int tiles_x, int tiles,
+                                                        float *__restrict__ dW, float *__restrict__ db, int out, int in) {
+    __shared__ __attribute__((aligned(16))) float red[3][64][4];
+    const int tile = blockIdx.y, e64 = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const int elem4 = blockIdx.x * 64 + e64;  // 16-byte element of the tile: (i*4+j)*256 + tid
+    const f32x4 *base = reinterpret_cast<const f32x4 *>(partial) + (size_t)tile * 4096 + elem4;
+    const size_t stride = (size_t)tiles * 4096;
+    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+    int sp = sl;
+    for (; sp + 28 < splits; sp += 32) {
+        f32x4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = __builtin_nontemporal_load(base + (size_t)(sp + 4 * u) * stride);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc += v[u];
+    }
+    for (; sp < splits; sp += 4) acc += __builtin_nontemporal_load(base + (size_t)sp * stride);
+    if (sl > 0) *reinterpret_cast<f32x4 *>(&red[sl - 1][e64][0]) = acc;
+    // bias gradient (one block per n tile): 128 columns x 2 halves of the splits, 16 loads in flight per thread, every
+    // partial combined in a fixed order
+    __shared__ float dbh[128];
+    const bool db_block = db && blockIdx.x == 63 && tile < tiles_x;
+    float sdb = 0.f;
+    if (db_block) {
+        const int c = threadIdx.x & 127, half = threadIdx.x >> 7;
+        const float *pdb = partial + (size_t)splits * tiles * (128 * 128) + (size_t)tile * 128 + c;
+        const size_t dstride = (size_t)tiles_x * 128;
+        const int s_lo = half ? (splits + 1) / 2 : 0, s_hi = half ? splits : (splits + 1) / 2;
+        float a16[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) a16[u] = 0.f;
+        int s2 = s_lo;
+        for (; s2 + 15 < s_hi; s2 += 16) {
+            float v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) v[u] = pdb[(size_t)(s2 + u) * dstride];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) a16[u] += v[u];
+        }
+        for (int u = 0; s2 < s_hi; ++s2, ++u) a16[u] += pdb[(size_t)s2 * dstride];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) sdb += a16[u];
+        if (half) dbh[c] = sdb;
+    }
+    __syncthreads();
+    if (db_block && threadIdx.x < 128 && tile * 128 + (int)threadIdx.x < out) atomicAdd(db + tile * 128 + threadIdx.x, sdb + dbh[threadIdx.x]);
+    if (sl > 0) return;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) acc += *reinterpret_cast<const f32x4 *>(&red[r][e64][0]);
+    const int ij = elem4 >> 8, t = elem4 & 255;
+    const int i = ij >> 2, j = ij & 3, wave = t >> 6, lane = t & 63;
+    const int n0 = (tile % tiles_x) * 128, k0 = (tile / tiles_x) * 128;
+    const int k = k0 + (wave & 1) * 64 + j * 16 + (lane & 15);
+    const int nb = n0 + (wave >> 1) * 64 + i * 16 + (lane >> 4) * 4;
+    if (k < in) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (nb + e < out) atomicAdd(dW + (size_t)(nb + e) * in + k, acc[e]);
+    }
+}
+
+// rows per workgroup: no atomic traffic to trade against, so simply two workgroups per CU
+static int64_t tn_partial_rows(int out, int in, int64_t M) {
+    const int64_t tiles = cdiv(out, 128) * cdiv(in, 128);
+    int64_t rows = tiles >= 2 ? 512 : 256;
+    if (M < 64 * rows) rows = round_up(cdiv(M, 64) > 32 ? cdiv(M, 64) : 32, 32);
+    // large M (fused minibatches): one round of workgroups (2 per CU) instead of more and more splits -- fewer partial tiles
+    // to write and to reduce.  M = 524,288, us per launch at 512 / 1024 / 2048 / 4096 rows: hidden 567 / 527 / 505 / 494,
+    // first layer 313 / 284 / 267 / 287, policy head 305 / 277 / 262 / 284
+    const int64_t few = round_up(cdiv(M * tiles, 512), 32);
+    return few > rows ? few : rows;
+}
+size_t tn_partial_floats(int out, int in, int64_t M) {
+    if (M <= 0) return 0;
+    const size_t splits = (size_t)cdiv(M, tn_partial_rows(out, in, M));
+    return splits * (size_t)(cdiv(out, 128) * cdiv(in, 128)) * (128 * 128) + splits * (size_t)cdiv(out, 128) * 128;  // tiles + db
+}
+
+// dW[out][in] += dY^T . X, db[out] += colsum(dY) through partial tiles in `ws` (>= tn_partial_floats floats) + a reduction
+int launch_gemm_tn(hipStream_t st, const float *dY, int64_t ldy, int ny_valid, const float *X, int64_t ldx, int kx_valid,
+                   float *dW, float *db, int out, int in, int64_t M, float *ws, size_t ws_floats) {
     if (M <= 0) return 0;
     RLPPO_CHECK_ARG(ny_valid % 4 == 0 && kx_valid % 4 == 0 && ldy % 4 == 0 && ldx % 4 == 0 && ny_valid <= ldy &&
                         kx_valid <= ldx && out <= ny_valid && in <= kx_valid,
                     "gemm_tn: bad shapes ny=%d kx=%d ldy=%ld ldx=%ld out=%d in=%d", ny_valid, kx_valid, (long)ldy,
                     (long)ldx, out, in);
-    if (!row_idx && ws) {  // default with a workspace: partial tiles + reduction instead of atomics (gemm_sa.hip)
-        const int rc = launch_gemm_tn_partial(st, dY, ldy, ny_valid, X, ldx, kx_valid, dW, db, out, in, M, ws, ws_floats);
-        if (rc != -1) return rc;
+    if (!ws || ws_floats < tn_partial_floats(out, in, M)) {
+        set_error("gemm_tn: workspace %zu < %zu floats", ws ? ws_floats : (size_t)0, tn_partial_floats(out, in, M));
+        return RLPPO_ERR_WORKSPACE;
     }
-    // Split over the sample axis.  Measured on MI355X at M = 65,536 (tools/sweep_tn.py, us per launch):
-    //   rows/WG      128    256    512   1024   2048
-    //   256x256     157.5  123.9  103.0  104.6  197.5      few splits -> idle CUs; many splits -> fp32 atomic traffic
-    //   256x107     159.2  110.4  103.6  149.6  265.2
-    //   90x256       83.6   62.8   62.7   98.7  187.6
-    //   1x256        48.6   44.6   52.7   95.7  188.3
-    const int64_t tiles = cdiv(out, 128) * cdiv(in, 128);
-    int64_t rows = tiles >= 2 ? 512 : 256;
-    if (tiles >= 4 && g_tn_rows_big > 0) rows = g_tn_rows_big;
-    if (M < 64 * rows) rows = round_up(cdiv(M, 64) > 32 ? cdiv(M, 64) : 32, TM);  // small M: still use the chip
-    if (g_tn_rows_override > 0) rows = g_tn_rows_override;
-    const int rows_per_wg = (int)rows;
-    dim3 grid((unsigned)cdiv(out, 128), (unsigned)cdiv(in, 128), (unsigned)cdiv(M, rows_per_wg));
-    if (!row_idx) {  // default for ungathered X: the scalar-addressed kernel (gemm_sa.hip); -1 = not applicable
-        const int rc = launch_gemm_tn_sa(st, grid, dY, ldy, ny_valid, X, ldx, kx_valid, dW, db, out, in, M, rows_per_wg);
-        if (rc != -1) return rc;
-    }
-    if (row_idx)
-        hipLaunchKernelGGL((gemm_tn_kernel<true>), grid, dim3(256), 0, st, dY, ldy, ny_valid, X, ldx, row_idx, kx_valid,
-                           dW, db, out, in, M, rows_per_wg);
-    else
-        hipLaunchKernelGGL((gemm_tn_kernel<false>), grid, dim3(256), 0, st, dY, ldy, ny_valid, X, ldx, row_idx, kx_valid,
-                           dW, db, out, in, M, rows_per_wg);
+    const int rows_per_wg = (int)tn_partial_rows(out, in, M);
+    const int64_t lim = (int64_t)1 << 30;
+    RLPPO_CHECK_ARG((rows_per_wg + TM) * ldy * 4 < lim && (rows_per_wg + TM) * ldx * 4 < lim,
+                    "gemm_tn: a leading dimension is too wide for 32-bit tile offsets");
+    const int tiles_x = (int)cdiv(out, 128), tiles_y = (int)cdiv(in, 128), splits = (int)cdiv(M, rows_per_wg);
+    dim3 grid((unsigned)tiles_x, (unsigned)tiles_y, (unsigned)splits);
+    hipLaunchKernelGGL((gemm_tn_dma_kernel<TM>), grid, dim3(256), 0, st, dY, (unsigned)(ldy * 4), ny_valid, X,
+                       (unsigned)(ldx * 4), kx_valid, db != nullptr, out, in, M, rows_per_wg, ws);
     RLPPO_LAUNCH_CHECK();
-    return 0;
-}
-
-}  // namespace rlppo
-
-// ------------------------------------------------------------------------------------------ MFMA ceiling probe
-// Register-only loop of v_mfma_f32_16x16x4_f32 on 16 independent accumulators (the instruction mix of the GEMM inner
-// loops without any memory traffic): measures what the chip sustains on THIS box (clock under load included), so
-// that roofline fractions can also be read against an achievable ceiling.  Diagnostic entry point only.
-namespace rlppo {
-__global__ __launch_bounds__(256) void mfma_probe_kernel(float *out, int iters, unsigned long long *clocks) {
-    f32x4 acc[16];
-    float a[4], b[4];
-    const float seed = (float)(threadIdx.x % 37) * 0.03125f - 0.5f;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = f32x4{seed, -seed, 0.5f * seed, 0.25f};
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        a[s] = seed * (float)(s + 1) * 0.37f + 0.01f;
-        b[s] = 0.91f - seed * (float)(s + 1) * 0.11f;
-    }
-    const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
-    for (int it = 0; it < iters; ++it) {
-#pragma unroll
-        for (int s = 0; s < 4; ++s)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) acc[i] = MFMA16(a[s], b[(s + i) & 3], acc[i]);
-    }
-    const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
-    float sum = 0.f;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) sum += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
-    out[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = sum;
-    if (threadIdx.x == 0 && clocks) {
-        clocks[2 * blockIdx.x] = t1 - t0;      // shader cycles
-        clocks[2 * blockIdx.x + 1] = r1 - r0;  // 100 MHz ticks
-    }
-}
-int launch_mfma_probe(hipStream_t st, float *out, int blocks, int iters, unsigned long long *clocks) {
-    hipLaunchKernelGGL(mfma_probe_kernel, dim3(blocks), dim3(256), 0, st, out, iters, clocks);
+    hipLaunchKernelGGL(tn_reduce_kernel, dim3(64, (unsigned)(tiles_x * tiles_y)), dim3(256), 0, st, ws, splits, tiles_x,
+                       tiles_x * tiles_y, dW, db, out, in);
     RLPPO_LAUNCH_CHECK();
     return 0;
 }

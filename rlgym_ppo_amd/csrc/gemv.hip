@@ -64,7 +64,7 @@ __global__ __launch_bounds__(256) void gemv_dx_kernel(const float *__restrict__ 
     *reinterpret_cast<f32x4 *>(dx + row * ldc + c) = o;
 }
 
-// The same product with the ReLU mask taken from the bitmask the hidden layer's forward GEMM wrote (csrc/gemm_sa.hip,
+// The same product with the ReLU mask taken from the bitmask the hidden layer's forward GEMM wrote (csrc/gemm.hip,
 // relu_bits): no read of the activation at all.  A block is one 128 x 128 tile of dx and a thread is the lane that owned the
 // same 64 elements in the forward epilogue: wave w, lane (q, r16) -> rows m0 + 32 w + 16 i + r16, columns n0 + 16 j + 4 q + e,
 // bit (8 i + j) * 4 + e of the word at bits[tile * 256 + tid] (512 contiguous bytes per wave).
@@ -188,7 +188,7 @@ __global__ __launch_bounds__(256) void gemv_dw_reduce_kernel(const float *__rest
 static int g_gemv = 1;  // tuning: rlppo_dbg_set(15, 0/1)
 void set_gemv(int v) { g_gemv = v; }
 // the shapes the three kernels take: padded input width a power of two in [32, 1024] (one 16-byte chunk per thread column)
-bool gemv_head_ok(int out, int kp) { return g_gemv && out == 1 && kp >= 32 && kp <= 1024 && (kp & (kp - 1)) == 0; }
+bool gemv_head_ok(int out, int kp) { return out == 1 && kp >= 32 && kp <= 1024 && (kp & (kp - 1)) == 0; }
 
 int launch_gemv_fwd(hipStream_t st, const float *x, int64_t ldx, const float *w, const float *b, float *y, int64_t ldy,
                     int64_t n, int kp, int pout) {

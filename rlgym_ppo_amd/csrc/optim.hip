@@ -85,23 +85,24 @@ __global__ __launch_bounds__(256) void pad_rows_vec_kernel(const T *__restrict__
 // contiguous rows through the LDS-DMA kernels instead of each chasing the index vector.
 __global__ __launch_bounds__(256) void gather_rows_kernel(const float *__restrict__ src, int64_t ld_src,
                                                           const int64_t *__restrict__ idx, float *__restrict__ dst,
-                                                          int chunks_per_row, int64_t n) {
+                                                          int chunks_per_row, int64_t n, int64_t ring_base, int64_t ring_cap) {
     typedef float f32x4 __attribute__((ext_vector_type(4)));
     const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t row = t / chunks_per_row;
     const int c = (int)(t - row * chunks_per_row);
     if (row >= n) return;
-    const f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(src + idx[row] * ld_src) + c);
+    const f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(src + ring_row(idx[row], ring_base, ring_cap) * ld_src) + c);
     reinterpret_cast<f32x4 *>(dst)[t] = v;
 }
 
 int launch_gather_rows(hipStream_t st, const float *src, int64_t ld_src, const int64_t *idx, float *dst, int width,
-                       int64_t n) {
+                       int64_t n, int64_t ring_base, int64_t ring_cap) {
     if (n <= 0) return 0;
     RLPPO_CHECK_ARG(width > 0 && width % 4 == 0 && ld_src >= width && ld_src % 4 == 0, "gather_rows: width=%d ld=%ld", width,
                     (long)ld_src);
     const int cpr = width / 4;
-    hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)cdiv(n * cpr, 256)), dim3(256), 0, st, src, ld_src, idx, dst, cpr, n);
+    hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)cdiv(n * cpr, 256)), dim3(256), 0, st, src, ld_src, idx, dst, cpr, n, ring_base,
+                       ring_cap);
     RLPPO_LAUNCH_CHECK();
     return 0;
 }
@@ -110,26 +111,69 @@ int launch_gather_rows(hipStream_t st, const float *src, int64_t ld_src, const i
 // sample in float32, and each feature's recurrence is independent of the others -- so one thread per feature walking the
 // samples in order reproduces it BIT FOR BIT (IEEE division, no contraction), while the d threads read the sample rows
 // coalesced.  4096 samples take ~0.1 ms on the stream instead of ~10 ms of Python on the host.
+// T = the dtype of the running state: float32 as constructed, float64 after WelfordRunningStat.from_json (np.asarray of
+// Python floats; the reference then updates in float64: float32 sample - float64 mean -> float64).
+template <typename T>
 __global__ __launch_bounds__(128) void welford_kernel(const float *__restrict__ x, int64_t ld, int64_t n, int d,
-                                                      float *__restrict__ mean, float *__restrict__ m2, long long count0) {
+                                                      T *__restrict__ mean, T *__restrict__ m2, long long count0) {
     const int f = blockIdx.x * 128 + threadIdx.x;
     if (f >= d) return;
-    float mu = mean[f], v = m2[f];
+    T mu = mean[f], v = m2[f];
     for (int64_t i = 0; i < n; ++i) {
         const long long prev = count0 + i;
-        const float cnt = (float)(prev + 1);
-        const float delta = x[i * ld + f] - mu;   // delta   = sample - running_mean
-        const float dn = delta / cnt;             // delta_n = delta / count
+        const T cnt = (T)(prev + 1);
+        const T delta = (T)x[i * ld + f] - mu;    // delta   = sample - running_mean
+        const T dn = delta / cnt;                 // delta_n = delta / count
         mu += dn;                                 // running_mean += delta_n
-        v += (delta * dn) * (float)prev;          // running_variance += delta * delta_n * (count - 1)
+        v += (delta * dn) * (T)prev;              // running_variance += delta * delta_n * (count - 1)
     }
     mean[f] = mu;
     m2[f] = v;
 }
 
-int launch_welford(hipStream_t st, const float *x, int64_t ld, int64_t n, int d, float *mean, float *m2, long long count0) {
+int launch_welford(hipStream_t st, const float *x, int64_t ld, int64_t n, int d, void *mean, void *m2, long long count0,
+                   int state_f64) {
     if (n <= 0 || d <= 0) return 0;
-    hipLaunchKernelGGL(welford_kernel, dim3((unsigned)cdiv(d, 128)), dim3(128), 0, st, x, ld, n, d, mean, m2, count0);
+    if (state_f64)
+        hipLaunchKernelGGL(welford_kernel<double>, dim3((unsigned)cdiv(d, 128)), dim3(128), 0, st, x, ld, n, d, (double *)mean,
+                           (double *)m2, count0);
+    else
+        hipLaunchKernelGGL(welford_kernel<float>, dim3((unsigned)cdiv(d, 128)), dim3(128), 0, st, x, ld, n, d, (float *)mean,
+                           (float *)m2, count0);
+    RLPPO_LAUNCH_CHECK();
+    return 0;
+}
+
+// WelfordRunningStat.increment_from_serialized_other (running_stats.py:71-98): Chan's parallel combination of two running
+// statistics, elementwise over the d features, in the state's dtype and in the reference's operation order:
+//   delta = other_mean - mean;  mean' = (count*mean + other_count*other_mean) / total
+//   m2'   = m2 + other_m2 + ((delta*delta)*count)*other_count / total
+template <typename T>
+__global__ __launch_bounds__(128) void welford_merge_kernel(int d, T *__restrict__ mean, T *__restrict__ m2, long long count,
+                                                            const float *__restrict__ omean, const float *__restrict__ om2,
+                                                            long long ocount) {
+    const int f = blockIdx.x * 128 + threadIdx.x;
+    if (f >= d) return;
+    const T c = (T)count, oc = (T)ocount, tot = (T)(count + ocount);
+    const T mu = mean[f], om = (T)omean[f];
+    const T delta = om - mu;
+    const T dsq = delta * delta;
+    // `other_count * other_mean` is int x float32-array = a float32 product whatever the state's dtype (the reference casts
+    // the serialised list to float32, running_stats.py:79-80); only then does it meet the (possibly float64) state
+    const T oterm = (T)((float)ocount * omean[f]);
+    mean[f] = (c * mu + oterm) / tot;
+    m2[f] = (m2[f] + (T)om2[f]) + ((dsq * c) * oc) / tot;
+}
+
+int launch_welford_merge(hipStream_t st, int d, void *mean, void *m2, long long count, const float *omean, const float *om2,
+                         long long ocount, int state_f64) {
+    if (d <= 0 || ocount == 0) return 0;
+    if (state_f64)
+        hipLaunchKernelGGL(welford_merge_kernel<double>, dim3((unsigned)cdiv(d, 128)), dim3(128), 0, st, d, (double *)mean,
+                           (double *)m2, count, omean, om2, ocount);
+    else
+        hipLaunchKernelGGL(welford_merge_kernel<float>, dim3((unsigned)cdiv(d, 128)), dim3(128), 0, st, d, (float *)mean,
+                           (float *)m2, count, omean, om2, ocount);
     RLPPO_LAUNCH_CHECK();
     return 0;
 }

@@ -38,32 +38,47 @@ def fuse_runs(slices, max_fused):
     return [(slices[i], k) for i in range(0, n, k)]
 
 
-_direct = {"state": None}  # None = undecided, False = torch.distributed, True = librlppo's own RCCL communicator
+_direct = {"ready": False, "want": None}  # want: None = RLPPO_RCCL_DIRECT decides, True / False = set_allreduce_backend
+
+
+def set_allreduce_backend(name):
+    """A/B switch of the gradient exchange: "torch" = torch.distributed's all_reduce (default), "direct" = rlppo_allreduce
+    (RCCL enqueued on the caller's stream by librlppo itself, include/rlppo.h).  Every rank must make the same choice.  The
+    direct communicator is created on first use and kept; switching back and forth is free."""
+    _direct["want"] = {"torch": False, "direct": True}[name]
+
+
+def allreduce_backend():
+    import os
+    want = _direct["want"]
+    if want is None:
+        want = os.environ.get("RLPPO_RCCL_DIRECT") == "1"
+    return "direct" if want else "torch"
 
 
 def _direct_comm(dist):
-    """RLPPO_RCCL_DIRECT=1: sum through rlppo_allreduce (RCCL enqueued on the caller's stream by librlppo itself, include/rlppo.h)
-    instead of torch.distributed's all_reduce.  Opt-in: the default keeps the collective in torch.distributed, which is what
-    the multi-process tests cover (gloo on the CPU; RCCL refuses two ranks on one GPU, so a one-GPU box can only exercise the
-    one-rank communicator)."""
-    if _direct["state"] is None:
+    """True when the sum should go through rlppo_allreduce: the direct backend is selected and the default group runs on
+    RCCL (with gloo -- the CPU tests, the one-GPU dry run -- the collective stays in torch.distributed).  The multi-process
+    tests cover the torch.distributed route (gloo on the CPU; RCCL refuses two ranks on one GPU, so a one-GPU box can only
+    exercise the one-rank communicator: tests/test_gpu_dp.py)."""
+    if allreduce_backend() != "direct" or dist.get_backend() != "nccl":
+        return False
+    if not _direct["ready"]:
+        import ctypes
         import os
-        on = os.environ.get("RLPPO_RCCL_DIRECT") == "1" and dist.get_backend() == "nccl"
-        if on:
-            import ctypes
-            from . import _native as N
-            L = N.lib()
-            rccl = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
-            if os.path.exists(rccl):  # the copy PyTorch already holds: one RCCL instance per process
-                N.check(L.rlppo_comm_set_library(rccl.encode()))
-            ident = ctypes.create_string_buffer(N.COMM_ID_BYTES)
-            if dist.get_rank() == 0:
-                N.check(L.rlppo_comm_unique_id(ident))
-            box = [ident.raw]
-            dist.broadcast_object_list(box, src=0)
-            N.check(L.rlppo_comm_init(dist.get_rank(), dist.get_world_size(), ctypes.c_char_p(box[0])))
-        _direct["state"] = on
-    return _direct["state"]
+        from . import _native as N
+        L = N.lib()
+        rccl = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+        if os.path.exists(rccl):  # the copy PyTorch already holds: one RCCL instance per process
+            N.check(L.rlppo_comm_set_library(rccl.encode()))
+        ident = ctypes.create_string_buffer(N.COMM_ID_BYTES)
+        if dist.get_rank() == 0:
+            N.check(L.rlppo_comm_unique_id(ident))
+        box = [ident.raw]
+        dist.broadcast_object_list(box, src=0)
+        N.check(L.rlppo_comm_init(dist.get_rank(), dist.get_world_size(), ctypes.c_char_p(box[0])))
+        _direct["ready"] = True
+    return True
 
 
 def all_reduce_sum(tensor, dist=None):
@@ -72,7 +87,7 @@ def all_reduce_sum(tensor, dist=None):
     if dist is None:
         dist, _, _ = dist_info()
     if dist is not None:
-        if _direct_comm(dist) and tensor.is_cuda and tensor.is_contiguous() and tensor.dtype in (torch.float32, torch.float64):
+        if tensor.is_cuda and tensor.is_contiguous() and tensor.dtype in (torch.float32, torch.float64) and _direct_comm(dist):
             import ctypes
             from . import _native as N
             N.check(N.lib().rlppo_allreduce(ctypes.c_void_p(torch.cuda.current_stream().cuda_stream), ctypes.c_void_p(tensor.data_ptr()),

@@ -104,15 +104,27 @@ class NetArena:
     def ensure_packed(self):
         if not self.is_bound():  # e.g. the user called module.to(...) or replaced .data
             self.bind()
-        key = (self.flat._version, self.native_epoch)
+        key = self._pack_key()
         if key != self._packed_key:
             N.check(N.lib().rlppo_net_pack(stream_ptr(), self.dims_c, self.n_layers, ptr(self.flat), ptr(self.packed)))
             self._packed_key = key
 
+    def _pack_key(self):
+        # bind() re-points every Parameter with `p.data = view`, which gives it a version counter of its own: in-place updates
+        # made THROUGH the Parameters (a stock torch optimiser on get_backprop_data's graph, vector_to_parameters, p.data.mul_())
+        # bump p._version, not flat._version -- both are part of the key; native_epoch covers the kernels that rewrite `flat`
+        # behind torch's back (Adam)
+        return (self.flat._version, self.native_epoch, sum(p._version for p in self.params()))
+
     def mark_repacked(self):
         """A kernel has just updated `flat` AND written the new values into `packed` (rlppo_clip_adam_pack2)."""
         self.native_epoch += 1
-        self._packed_key = (self.flat._version, self.native_epoch)
+        self._packed_key = self._pack_key()
+
+    def invalidate(self):
+        """Force a re-pack before the next kernel reads the weights (for writers that bypass both version counters, e.g.
+        a raw pointer write into the arena)."""
+        self._packed_key = None
 
     # ------------------------------------------------------------------------------------------ inference
     def stage_obs(self, obs, standardize=None, out=None):
@@ -356,6 +368,12 @@ class DeviceIndexRing:
         torch.cuda.current_stream(self.device).wait_event(self.copied[entry.slot])
         self._held = entry.slot
         return self.dev[entry.slot][:entry.n]
+
+
+def selection_epoch():
+    """Counter the library bumps whenever a call changes which kernels later launches select (precision setters, A/B
+    switches): captured graphs of library calls are keyed on it (ppo/_mlp.py::ActGraph)."""
+    return int(N.lib().rlppo_selection_epoch())
 
 
 def set_inference_precision(mode):

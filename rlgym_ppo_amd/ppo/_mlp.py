@@ -12,7 +12,7 @@ import torch
 import torch.nn as nn
 
 from .. import _native as N
-from ..engine import NetArena, linears_of, ptr, require_gpu, stream_ptr
+from ..engine import NetArena, linears_of, ptr, require_gpu, selection_epoch, stream_ptr
 
 
 def build_body(input_shape, layer_sizes, n_out, final_activation=None):
@@ -99,6 +99,7 @@ class ArenaModule(nn.Module):
         self.act_graphs = os.environ.get("RLPPO_ACT_GRAPH", "1") != "0"  # get_action through a hipGraph per batch-size bucket
         self.act_graph_max = 1024  # beyond that the explicit copies of the eager path are the better transport for the noise
         self._graphs = {}
+        self._graph_epoch = -1
 
     def _graph_act(self, obs, noise, standardize):
         """get_action for a small HOST batch as one graph replay, or None when that form does not apply (device inputs, fused
@@ -117,6 +118,12 @@ class ArenaModule(nn.Module):
         q = self._draw_noise(n) if noise is None else torch.as_tensor(noise, dtype=torch.float32)
         if tuple(q.shape) != tuple(self._noise_shape(n)):
             return None
+        # a captured graph replays the kernels that were selected at capture time: the library's selection epoch (bumped by
+        # rlppo_set_inference_precision and the A/B switches) is part of the cache key, stale graphs are dropped
+        epoch = selection_epoch()
+        if epoch != self._graph_epoch:
+            self._graphs.clear()
+            self._graph_epoch = epoch
         g = self._graphs.get(_bucket(n))
         if g is None:
             g = self._graphs[_bucket(n)] = ActGraph(self, _bucket(n))

@@ -3,8 +3,12 @@
 Same nine FIFO fields, same constructor, same `submit_experience` / `get_all_batches_shuffled` / `clear`, same
 shuffle stream (numpy legacy RandomState(seed).permutation per epoch, remainder dropped).  Differences are layout
 only: the buffer lives on the GPU (the reference keeps it on the CPU and re-uploads every minibatch,
-ppo_learner.py:139-143), `states` rows are zero-padded to the kernels' leading dimension, and PPOLearner reads
-the buffer through index vectors (`epoch_indices`) instead of materialised gathers.
+ppo_learner.py:139-143), `states` rows are zero-padded to the kernels' leading dimension, PPOLearner reads
+the buffer through index vectors (`epoch_indices`) instead of materialised gathers, and the FIFO is a RING: the reference's
+`_cat` re-allocates all nine tensors on every submit (experience_buffer.py:18-37; 2 x 268 MB + 7 vectors at 524,288 rows);
+here new rows overwrite the oldest ones in place and a rotating base index maps logical row i (0 = oldest, the reference's
+order) to physical row (base + i) mod capacity -- the kernels apply that map to the permutation's entries
+(rlppo_minibatch_args.ring_base / ring_cap), the reference-shaped accessors materialise the logical order on demand.
 """
 import os
 
@@ -34,17 +38,57 @@ class ExperienceBuffer(object):
             ring = DeviceIndexRing(self._dev, lookahead + 2)
         self._ring = ring
         self._perm = LegacyPermutation(self.rng, lookahead=lookahead, ring=ring)
-        self._store = {k: None for k in _FIELDS}
-        self._d = None  # logical observation width
+        self._store = {k: None for k in _FIELDS}   # physical ring storage [capacity, ...] per field
+        self._cap = 0     # rows allocated (grows geometrically up to max_size, then stays)
+        self._base = 0    # physical row of logical row 0 (the oldest sample)
+        self._count = 0   # valid rows
+        self._d = None    # logical observation width
 
     # ------------------------------------------------------------------------------------------- FIFO
-    def _fifo(self, old, new):
-        """Keep the newest max_size rows of old ++ new (experience_buffer.py:18-37), on the device."""
+    def _grow(self, need, new):
+        """(Re-)allocate the ring for at least `need` rows (at most max_size), keeping the current rows in logical order."""
+        cap = min(self.max_size, max(need, 2 * self._cap))
+        fresh = {}
+        for k in _FIELDS:
+            t = torch.empty((cap,) + tuple(new[k].shape[1:]), dtype=torch.float32, device=self._dev)
+            if self._count:
+                t[:self._count].copy_(self._logical(k))
+            fresh[k] = t
+        self._store, self._cap, self._base = fresh, cap, 0
+
+    def _logical(self, k):
+        """Rows of field k in the reference's order (oldest first): a view when the ring has not wrapped, else a copy."""
+        t, b, n = self._store[k], self._base, self._count
+        if b + n <= self._cap:
+            return t[b:b + n]
+        return torch.cat((t[b:], t[:b + n - self._cap]), 0)
+
+    def _append(self, new):
+        """Keep the newest max_size rows of old ++ new (experience_buffer.py:18-37: its four cases are this one rule)."""
+        n_new = new["rewards"].shape[0]
         size = self.max_size
-        if old is None or new.shape[0] >= size:
-            return new[new.shape[0] - size:].clone() if new.shape[0] > size else new
-        keep = min(old.shape[0], size - new.shape[0])
-        return torch.cat((old[old.shape[0] - keep:], new), 0)
+        if n_new >= size:                       # the new chunk alone fills the buffer: its last max_size rows
+            if self._cap < size or any(self._store[k].shape[1:] != new[k].shape[1:] for k in _FIELDS):
+                self._count = 0
+                self._cap = 0
+                self._grow(size, new)
+            for k in _FIELDS:
+                self._store[k].copy_(new[k][n_new - size:])
+            self._base, self._count = 0, size
+            return
+        if self._count + n_new > self._cap and self._cap < size:
+            self._grow(self._count + n_new, new)
+        cap = self._cap
+        w0 = (self._base + self._count) % cap   # first physical row to write
+        first = min(n_new, cap - w0)
+        for k in _FIELDS:
+            self._store[k][w0:w0 + first].copy_(new[k][:first])
+            if first < n_new:
+                self._store[k][:n_new - first].copy_(new[k][first:])
+        self._count += n_new
+        if self._count > cap:                   # the oldest rows were overwritten
+            self._base = (self._base + self._count - cap) % cap
+            self._count = cap
 
     def _to_dev(self, x):
         if isinstance(x, torch.Tensor):
@@ -70,14 +114,24 @@ class ExperienceBuffer(object):
         new = dict(states=self._pad_states(states), actions=self._to_dev(actions), log_probs=self._to_dev(log_probs),
                    rewards=self._to_dev(rewards), next_states=self._pad_states(next_states), dones=self._to_dev(dones),
                    truncated=self._to_dev(truncated), values=self._to_dev(values), advantages=self._to_dev(advantages))
+        n = new["rewards"].shape[0]
         for k in _FIELDS:
-            self._store[k] = self._fifo(self._store[k], new[k])
+            if new[k].shape[0] != n:
+                raise ValueError(f"submit_experience: field '{k}' has {new[k].shape[0]} rows, 'rewards' has {n}")
+        if self._cap and any(self._store[k].shape[1:] != new[k].shape[1:] for k in _FIELDS) and n < self.max_size:
+            raise ValueError("submit_experience: row shapes differ from the rows already in the buffer")
+        if n:
+            self._append(new)
+
+    def ring(self):
+        """(physical storage dict, base, capacity) for the kernels: logical row i = physical row (i + base) mod capacity."""
+        return self._store, self._base, self._cap
 
     # ------------------------------------------------------------------------------- reference-shaped views
     def _get(self, k):
-        t = self._store[k]
-        if t is None:
+        if self._count == 0:
             return torch.empty(0, dtype=torch.float32, device=self._dev)
+        t = self._logical(k)
         if k in ("states", "next_states"):
             return t[:, :self._d]
         return t
@@ -93,8 +147,7 @@ class ExperienceBuffer(object):
     advantages = property(lambda s: s._get("advantages"))
 
     def __len__(self):
-        t = self._store["rewards"]
-        return 0 if t is None else t.shape[0]
+        return self._count
 
     # ------------------------------------------------------------------------------------------ shuffle
     def epoch_indices(self):

@@ -186,7 +186,7 @@ class PPOLearner(object):
         a.val_dims = ctypes.cast(va.dims_c, ctypes.POINTER(ctypes.c_int32))
         a.pol_packed, a.val_packed = pa.packed.data_ptr(), va.packed.data_ptr()
         a.pol_grad, a.val_grad = pa.grad.data_ptr(), va.grad.data_ptr()
-        st = exp._store
+        st, a.ring_base, a.ring_cap = exp.ring()  # physical rows; the kernels map the permutation's logical rows onto them
         a.states, a.ld_states = st["states"].data_ptr(), st["states"].shape[1]
         a.actions = st["actions"].data_ptr()
         a.old_logp = st["log_probs"].data_ptr()
@@ -227,7 +227,7 @@ class PPOLearner(object):
 
         t1 = time.time()
         if n_batches > 0 and total > 0:
-            if exp._store["actions"].reshape(total, -1).shape[1] != self._act_dim:
+            if exp.ring()[0]["actions"][:1].reshape(1, -1).shape[1] != self._act_dim:
                 raise ValueError("experience buffer action width does not match the policy head")
             args = self._minibatch_args(exp)
             st = stream_ptr()
@@ -275,11 +275,14 @@ class PPOLearner(object):
             for _ in range(self.n_epochs):
                 exp.epoch_indices()  # the reference consumes one permutation per epoch even if no batch fits
 
+        # every pass added one mean to each report statistic; the number of passes travels with the sums, so the report is the
+        # mean over the passes of ALL ranks even when the slices do not divide evenly over them (3 slices on 2 ranks)
+        self._stats[N.STAT_PASSES] += float(n_passes)
         all_reduce_sum(self._stats, dist)
         stats = self._stats.cpu().numpy()  # the only device->host sync of learn()
         elapsed = time.time() - t1
         n_iter_r = max(n_iterations, 1)
-        n_mb_r = max(n_passes * world, 1)  # the statistics were summed over ranks: passes of all ranks
+        n_mb_r = max(float(stats[N.STAT_PASSES]), 1.0)
         policy_update_magnitude = (policy_before - pa.flat).norm().item()
         critic_update_magnitude = (critic_before - va.flat).norm().item()
         self.cumulative_model_updates += n_iter_r

@@ -22,10 +22,10 @@ def _free_port():
     return p
 
 
-def _build(seed=7):
+def _build(seed=7, batch=2048):
     from rlgym_ppo_amd.ppo import ExperienceBuffer, PPOLearner
     torch.manual_seed(seed)
-    learner = PPOLearner(107, 90, 0, (64, 64), (64, 64), (0.1, 1.0), 2048, 2, 3e-4, 3e-4, 0.2, 0.005, 512, "cuda:0")
+    learner = PPOLearner(107, 90, 0, (64, 64), (64, 64), (0.1, 1.0), batch, 2, 3e-4, 3e-4, 0.2, 0.005, 512, "cuda:0")
     rs = np.random.RandomState(seed)
     n = 4096
     obs = np.clip(rs.randn(n, 107), -5, 5).astype(np.float32)
@@ -38,13 +38,13 @@ def _build(seed=7):
     return learner, buf
 
 
-def _worker(rank, world, port, out):
+def _worker(rank, world, port, out, batch=2048):
     sys.path.insert(0, ROOT)
     import contextlib
     import torch.distributed as dist
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
     with contextlib.redirect_stdout(open(os.devnull, "w")):
-        learner, buf = _build()
+        learner, buf = _build(batch=batch)
     report = learner.learn(buf)
     out[rank] = (learner.policy.arena.flat.cpu(), learner.value_net.arena.flat.cpu(), report)
     dist.barrier()
@@ -70,6 +70,24 @@ def test_two_ranks_equal_one_rank():
             assert abs(report[k] - ref_report[k]) <= 2e-5 * max(abs(ref_report[k]), 1e-3) + 1e-7, (k, report[k], ref_report[k])
         assert report["Cumulative Model Updates"] == ref_report["Cumulative Model Updates"] == 4
     assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1])  # replicas stay bit-identical
+
+
+def test_uneven_slices_report_the_mean_over_all_passes():
+    """3 minibatch slices on 2 ranks (round-robin: rank 0 runs two passes, rank 1 one): the pass count travels with the
+    all-reduced statistics, so both ranks report the single-process means (the round-1 code divided by 4 on rank 0 and by
+    2 on rank 1) and the parameters still match."""
+    learner, buf = _build(batch=1536)
+    ref_report = learner.learn(buf)
+    ref_p = learner.policy.arena.flat.cpu()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(2, _free_port(), out, 1536), nprocs=2, join=True)
+    for rank in (0, 1):
+        p, v, report = out[rank]
+        assert ((p - ref_p).abs().max() / ref_p.abs().max()).item() < 5e-5
+        for k in ("Policy Entropy", "Mean KL Divergence", "Value Function Loss", "SB3 Clip Fraction"):
+            assert abs(report[k] - ref_report[k]) <= 2e-5 * max(abs(ref_report[k]), 1e-3) + 1e-7, (rank, k, report[k], ref_report[k])
+    assert all(out[0][2][k] == out[1][2][k] for k in ("Policy Entropy", "Mean KL Divergence", "Value Function Loss", "SB3 Clip Fraction"))
 
 
 def test_direct_rccl_entry_points_one_rank():

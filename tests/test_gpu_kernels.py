@@ -44,27 +44,21 @@ def check(L, rc):
 
 
 # ------------------------------------------------------------------------------------------------ GEMMs
-@pytest.mark.parametrize("M,N,K,epi,gather", [
-    (128, 128, 32, 0, False), (300, 256, 128, 1, False), (1000, 96, 256, 0, True), (77, 32, 256, 2, False),
-    (513, 64, 64, 1, True), (256, 256, 96, 3, False), (4096, 256, 256, 3, False), (5, 128, 128, 1, False),
-    # M >= 1024 and K <= 256 take the weights-stationary kernel (persistent row tiles, ragged last tile, gather)
-    (5000, 256, 128, 1, True), (3000, 96, 256, 0, False), (2048, 32, 256, 0, False), (1500, 256, 96, 3, False),
-    (1100, 256, 32, 3, False), (70000, 256, 256, 1, False), (66000, 128, 64, 2, True), (1024, 64, 256, 1, False),
+@pytest.mark.parametrize("M,N,K,epi", [
+    (128, 128, 32, 0), (300, 256, 128, 1), (1000, 96, 256, 0), (77, 32, 256, 2), (513, 64, 64, 1), (256, 256, 96, 3),
+    (4096, 256, 256, 3), (5, 128, 128, 1), (5000, 256, 128, 1), (3000, 96, 256, 0), (2048, 32, 256, 0), (1500, 256, 96, 3),
+    (1100, 256, 32, 3), (70000, 256, 256, 1), (66000, 128, 64, 2), (1024, 64, 256, 1), (2051, 512, 512, 1), (999, 96, 512, 3),
 ])
-def test_gemm_nt(L, M, N, K, epi, gather):
+def test_gemm_nt(L, M, N, K, epi):
     g = torch.Generator().manual_seed(M + N + K)
-    rows = M * 2 if gather else M
-    A = torch.randn(rows, K + 32, generator=g)          # lda > K
+    A = torch.randn(M, K + 32, generator=g)          # lda > K
     B = torch.randn(N, K, generator=g) * (0.05 if epi == 2 else 1.0)  # keep tanh inputs O(1): fp32 input rounding
     bias = torch.randn(N, generator=g)
     mask = torch.randn(M, N, generator=g)
-    idx = torch.randperm(rows, generator=g)[:M] if gather else None
     Ad, Bd, bd, md = dev(A), dev(B), dev(bias), dev(mask)
-    idxd = dev(idx, torch.int64) if gather else None
     C = torch.full((M, N), float("nan"), device="cuda")
-    check(L, L.rlppo_dbg_gemm_nt(stream(), P(Ad), A.shape[1], P(idxd), P(Bd), K, P(bd), P(md), N, P(C), N, M, N, K, epi))
-    Asel = A[idx] if gather else A
-    ref = Asel[:, :K].double() @ B.double().T
+    check(L, L.rlppo_dbg_gemm_nt(stream(), P(Ad), A.shape[1], P(Bd), K, P(bd), P(md), N, P(C), N, M, N, K, epi))
+    ref = A[:, :K].double() @ B.double().T
     if epi == 3:
         ref = ref * (mask > 0)
     else:
@@ -77,7 +71,7 @@ def test_gemm_nt(L, M, N, K, epi, gather):
 
 
 def test_relu_bitmask_forms_are_bitwise_equal(L):
-    """RLPPO_TUNE key 19: the hidden-layer forward that also writes the ReLU bitmask gives the same activations as the plain
+    """The hidden-layer forward that also writes the ReLU bitmask gives the same activations as the plain
     forward, and the dX product masked by that bitmask gives the same result as the one masked by re-reading the activation
     (ragged last row tile, exact zeros and negative pre-activations in the mask)."""
     torch.manual_seed(6)
@@ -91,12 +85,12 @@ def test_relu_bitmask_forms_are_bitwise_equal(L):
     assert bits.numel() == ((M + 127) // 128) * 2 * 256 * 8
     H0 = torch.empty(M, 256, device="cuda")
     H1 = torch.full((M, 256), -7.0, device="cuda")
-    check(L, L.rlppo_dbg_gemm_nt(stream(), P(A), 256, None, P(W), 256, P(b), None, 0, P(H0), 256, M, 256, 256, 1))
+    check(L, L.rlppo_dbg_gemm_nt(stream(), P(A), 256, P(W), 256, P(b), None, 0, P(H0), 256, M, 256, 256, 1))
     check(L, L.rlppo_dbg_gemm_nt_bits(stream(), P(A), 256, P(W), 256, P(b), P(H1), 256, M, 256, 256, 1, P(bits)))
     assert torch.equal(H0, H1) and (H0 == 0).float().mean().item() > 0.3
     D0 = torch.empty(M, 256, device="cuda")
     D1 = torch.full((M, 256), -7.0, device="cuda")
-    check(L, L.rlppo_dbg_gemm_nt(stream(), P(dY), 128, None, P(Wt), 128, None, P(H0), 256, P(D0), 256, M, 256, 128, 3))
+    check(L, L.rlppo_dbg_gemm_nt(stream(), P(dY), 128, P(Wt), 128, None, P(H0), 256, P(D0), 256, M, 256, 128, 3))
     check(L, L.rlppo_dbg_gemm_nt_bits(stream(), P(dY), 128, P(Wt), 128, None, P(D1), 256, M, 256, 128, 3, P(bits)))
     torch.cuda.synchronize()
     assert torch.equal(D0, D1)
@@ -104,58 +98,11 @@ def test_relu_bitmask_forms_are_bitwise_equal(L):
     assert L.rlppo_dbg_gemm_nt_bits(stream(), P(A), 256, P(W), 256, P(b), P(H1), 96, M, 96, 256, 1, P(bits)) != 0   # width not 128 k
 
 
-def test_gemm_nt_persistent_form_is_bitwise_equal(L):
-    """RLPPO_TUNE key 17: workgroups that walk over several output tiles (launches with more tiles than resident slots) run
-    the same arithmetic in the same order as the one-tile-per-workgroup kernel: outputs must be bit-identical, including the
-    ragged last row tile, for the forward (bias + ReLU), head (bias, 96 columns) and masked (dX) epilogues."""
-    torch.manual_seed(5)
-    M = 131072 + 5
-    A256, Mk, A96 = (torch.randn(M, k, device="cuda") for k in (256, 256, 96))
-    W = torch.randn(256, 256, device="cuda") * 0.05
-    b = torch.randn(256, device="cuda")
-    try:
-        for Am, K, n, epi in ((A256, 256, 256, 1), (A256, 256, 96, 0), (A256, 256, 256, 3), (A96, 96, 256, 3)):
-            outs = []
-            for persist in (0, 1):
-                check(L, L.rlppo_dbg_set(17, persist))
-                C = torch.full((M, n), -7.0, device="cuda")
-                check(L, L.rlppo_dbg_gemm_nt(stream(), P(Am), K, None, P(W), K, P(b) if epi != 3 else None,
-                                             P(Mk) if epi == 3 else None, 256 if epi == 3 else 0, P(C), n, M, n, K, epi))
-                outs.append(C)
-            torch.cuda.synchronize()
-            assert torch.equal(outs[0], outs[1]), (K, n, epi)
-            assert not (outs[1] == -7.0).any()
-    finally:
-        check(L, L.rlppo_dbg_set(17, 0))
-
-
-@pytest.mark.parametrize("M,out,in_,gather", [(1000, 256, 107, True), (4096, 256, 256, False), (33, 90, 256, False),
-                                              (2500, 1, 256, False), (1, 21, 32, False), (3000, 512, 231, True)])
-def test_gemm_tn(L, M, out, in_, gather):
-    g = torch.Generator().manual_seed(M + out)
-    ny, kx = int(L.rlppo_padded_out(out)), int(L.rlppo_padded_width(in_)) if gather else int(L.rlppo_padded_out(in_))
-    rows = 2 * M if gather else M
-    dY = torch.zeros(M, ny)
-    dY[:, :out] = torch.randn(M, out, generator=g)
-    X = torch.zeros(rows, kx)
-    X[:, :in_] = torch.randn(rows, in_, generator=g)
-    idx = torch.randperm(rows, generator=g)[:M] if gather else None
-    dW0 = torch.randn(out, in_, generator=g)
-    db0 = torch.randn(out, generator=g)
-    dW, db = dev(dW0), dev(db0)
-    dYd, Xd = dev(dY), dev(X)  # keep references: a temporary's memory is recycled by the next allocation
-    idxd = dev(idx, torch.int64) if gather else None
-    check(L, L.rlppo_dbg_gemm_tn(stream(), P(dYd), ny, ny, P(Xd), kx, P(idxd), kx, P(dW), P(db), out, in_, M))
-    Xs = X[idx] if gather else X
-    refW = dW0.double() + dY[:, :out].double().T @ Xs[:, :in_].double()
-    refb = db0.double() + dY[:, :out].double().sum(0)
-    assert relerr(dW, refW) < 2e-6 and relerr(db, refb) < 2e-6
-
-
-@pytest.mark.parametrize("M,out,in_", [(1000, 90, 256), (4096, 256, 107), (70000, 256, 256), (33, 1, 64), (5000, 300, 130)])
-def test_gemm_tn_partial_tiles(L, M, out, in_):
-    """The form rlppo_ppo_minibatch uses: partial 128x128 tiles per split + a reduction kernel instead of fp32 atomics.
-    Same product as test_gemm_tn, ragged last stage / tile included, and bit-identical from run to run."""
+@pytest.mark.parametrize("M,out,in_", [(1000, 90, 256), (4096, 256, 107), (70000, 256, 256), (33, 1, 64), (5000, 300, 130),
+                                       (1000, 256, 107), (33, 90, 256), (2500, 1, 256), (1, 21, 32), (3000, 512, 231)])
+def test_gemm_tn(L, M, out, in_):
+    """dW += dY^T . X, db += colsum(dY) through partial 128x128 tiles per split + a fixed-order reduction kernel (no fp32
+    atomics): ragged last stage / tile included, accumulation on top of existing gradients, bit-identical from run to run."""
     g = torch.Generator().manual_seed(M + out)
     ny, kx = int(L.rlppo_padded_out(out)), int(L.rlppo_padded_out(in_))
     dY = torch.zeros(M, ny)
@@ -170,7 +117,7 @@ def test_gemm_tn_partial_tiles(L, M, out, in_):
     results = []
     for _ in range(3):
         dW, db = dev(dW0), dev(db0)
-        check(L, L.rlppo_dbg_gemm_tn_ws(stream(), P(dYd), ny, ny, P(Xd), kx, kx, P(dW), P(db), out, in_, M, P(ws), ws.numel()))
+        check(L, L.rlppo_dbg_gemm_tn(stream(), P(dYd), ny, ny, P(Xd), kx, kx, P(dW), P(db), out, in_, M, P(ws), ws.numel()))
         results.append(dW.clone())
     refW = dW0.double() + dY[:, :out].double().T @ X[:, :in_].double()
     refb = db0.double() + dY[:, :out].double().sum(0)
@@ -283,6 +230,65 @@ def test_gae_segment_independence_and_linearity(L, gae_algo):
     assert np.array_equal(ret[:end + 1], ret2[:end + 1])
     _, _, ret3 = run_gae(L, 2 * rews, dones, trunc, values, 0.99, 0.95, None)
     np.testing.assert_allclose(ret3, 2 * ret, rtol=1e-6, atol=1e-6)
+
+
+def test_gae_slow_path_and_recycled_workspace(L):
+    """The look-back never gives up with a wrong carry: with the spin limit forced to 0 every wait takes the raw-step slow path
+    (no trajectory end at all: the worst case) and the outputs are still the oracle's; a workspace full of another launch's
+    records (or garbage) does not matter because tags are per launch; the header's slow-path counter is 0 in normal runs."""
+    rews, dones, trunc, values = synth_gae(96, 256, seed=9, p_mid=0.0)
+    dones[:] = 0
+    trunc[:] = 0
+    trunc[-1] = 1
+    n = len(rews)
+    ovt, oadv, oret = ogae.gae(rews, dones, trunc, values, 0.99, 0.95, 1.3, "f64")
+    vt, adv, ret = (torch.empty(n, device="cuda") for _ in range(3))
+    ws = torch.empty(int(L.rlppo_gae_workspace_bytes(n)), dtype=torch.uint8, device="cuda")
+    r, d, t, v = dev(rews), dev(dones), dev(trunc), dev(values)
+    call = lambda: check(L, L.rlppo_gae(stream(), P(r), P(d), P(t), P(v), n, 0.99, 0.95, 1.3, P(vt), P(adv), P(ret), P(ws), ws.numel()))
+    for fill in (0x00, 0xFF, 0x5A):
+        ws.fill_(fill)
+        ws[:16] = 0
+        call()
+        call()  # second launch on a workspace that holds the first launch's records
+        np.testing.assert_allclose(adv.cpu().numpy(), oadv, rtol=2e-6, atol=2e-6)
+        np.testing.assert_allclose(ret.cpu().numpy(), oret.astype(np.float32), rtol=2e-6, atol=2e-6)
+        assert int(ws[4:8].view(torch.int32).item()) == 0, "the slow path was taken in a normal run"
+    check(L, L.rlppo_dbg_set(21, 0))
+    try:
+        ws[:16] = 0
+        call()
+        assert int(ws[4:8].view(torch.int32).item()) > 0   # the test really went through the slow path
+        np.testing.assert_allclose(adv.cpu().numpy(), oadv, rtol=2e-6, atol=2e-6)
+        np.testing.assert_allclose(vt.cpu().numpy(), ovt, rtol=2e-6, atol=2e-6)
+        np.testing.assert_allclose(ret.cpu().numpy(), oret.astype(np.float32), rtol=2e-6, atol=2e-6)
+    finally:
+        check(L, L.rlppo_dbg_set(21, -1))
+
+
+def test_gae_under_graph_capture_replays_correctly(L):
+    """A captured launch would replay a frozen per-launch tag, so rlppo_gae switches to its stateless two-launch form while
+    the stream is capturing: replays on NEW inputs give the new outputs."""
+    rews, dones, trunc, values = synth_gae(64, 256, seed=3)
+    n = len(rews)
+    vt, adv, ret = (torch.empty(n, device="cuda") for _ in range(3))
+    ws = torch.empty(int(L.rlppo_gae_workspace_bytes(n)), dtype=torch.uint8, device="cuda")
+    r, d, t, v = dev(rews), dev(dones), dev(trunc), dev(values)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(g, stream=side, capture_error_mode="thread_local"):
+            check(L, L.rlppo_gae(ctypes.c_void_p(side.cuda_stream), P(r), P(d), P(t), P(v), n, 0.99, 0.95, 1.7, P(vt), P(adv), P(ret),
+                                 P(ws), ws.numel()))
+    for seed in (3, 4, 5):
+        rews, dones, trunc, values = synth_gae(64, 256, seed=seed)
+        r.copy_(dev(rews)); d.copy_(dev(dones)); t.copy_(dev(trunc)); v.copy_(dev(values))
+        g.replay()
+        torch.cuda.synchronize()
+        _, oadv, oret = ogae.gae(rews, dones, trunc, values, 0.99, 0.95, 1.7, "f64")
+        np.testing.assert_allclose(adv.cpu().numpy(), oadv, rtol=2e-6, atol=2e-6)
+        np.testing.assert_allclose(ret.cpu().numpy(), oret.astype(np.float32), rtol=2e-6, atol=2e-6)
 
 
 def test_gae_empty(L):
@@ -579,34 +585,6 @@ def test_minibatch_full_size_cfg2(L):
     ref = ppo.minibatch_autograd("discrete", pol, val, torch.as_tensor(obs)[ti], act[ti].float(), torch.as_tensor(old)[ti],
                                  torch.as_tensor(adv)[ti], torch.as_tensor(tgt)[ti], 0.2, 0.005, 1.0)
     compare_minibatch(gp, gv, st, ref, tol=2e-5)
-
-
-def test_minibatch_identical_with_and_without_relu_bitmask(L):
-    """RLPPO_TUNE key 19 only changes WHERE the ReLU mask of the backward pass comes from (the bitmask the forward wrote vs the
-    saved activation): the gradients and the statistics of a cfg2-shape minibatch must be bit-identical either way (256-wide
-    nets: every masked dX GEMM and the critic's matrix-vector dX take the bitmask path)."""
-    torch.manual_seed(12)
-    pol = nets.init_mlp(107, (256, 256, 256), 90)
-    val = nets.init_mlp(107, (256, 256, 256), 1)
-    rs = np.random.RandomState(12)
-    n = 9000
-    obs = np.clip(rs.randn(n, 107), -5, 5).astype(np.float32)
-    with torch.no_grad():
-        act, logp = nets.discrete_sample(nets.discrete_probs(pol, obs), nets.draw_exp_noise(n, 90))
-    old = (logp + torch.as_tensor(rs.randn(n).astype(np.float32) * 0.2)).numpy()
-    adv, tgt = rs.randn(n).astype(np.float32), rs.randn(n).astype(np.float32)
-    idx = rs.permutation(n)[:8192 + 77]
-    res = []
-    try:
-        for v in (0, 1):
-            check(L, L.rlppo_dbg_set(19, v))
-            res.append(run_minibatch(L, "discrete", pol, val, obs, act.numpy(), old, tgt, adv, idx, 0.2, 0.005, 1.0))
-    finally:
-        check(L, L.rlppo_dbg_set(19, 1))
-    (gp0, gv0, st0), (gp1, gv1, st1) = res
-    for a, b in zip(gp0 + gv0, gp1 + gv1):
-        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
-    assert np.array_equal(st0[:5], st1[:5])
 
 
 def test_fused_pass_full_size_cfg2(L):

@@ -340,15 +340,40 @@ def test_get_action_graph_replay_equals_eager_path():
         torch.manual_seed(5)
         a0, l0 = pol.get_action(obs)
         assert torch.equal(a0, a1) and torch.equal(l0, l1)
-        with torch.no_grad():  # new weights: the next round must see them through the same graphs
-            for p in pol.parameters():
+        with torch.no_grad():  # new weights, written THROUGH the Parameters (what a stock optimiser / vector_to_parameters does:
+            for p in pol.parameters():  # p._version moves, flat._version does not): the next round must see them
                 p.add_(torch.randn_like(p) * 0.05)
-        pol.arena.native_epoch += 1
     assert set(pol._graphs) == {16, 32, 80, 256, 1024, 48}
     pol.act_graphs = True
     big = np.clip(rs.randn(1500, 107), -5, 5).astype(np.float32)      # above act_graph_max: the eager path, no new graph
     pol.get_action(big)
     assert set(pol._graphs) == {16, 32, 80, 256, 1024, 48}
+
+
+def test_captured_act_graphs_follow_the_inference_precision():
+    """A captured graph replays the kernels selected at capture time; the graph cache is keyed on the library's selection
+    epoch, so set_inference_precision takes effect for small (graph-served, n <= 1024) batches too, both ways."""
+    from rlgym_ppo_amd.engine import set_inference_precision
+    from rlgym_ppo_amd.ppo import ContinuousPolicy
+    torch.manual_seed(4)
+    pol = ContinuousPolicy(231, 16, (512, 512), "cuda:0")
+    rs = np.random.RandomState(4)
+    obs = np.clip(rs.randn(200, 231), -5, 5).astype(np.float32)
+    eps = torch.as_tensor(rs.randn(200, 8).astype(np.float32))
+    a32, _ = pol.get_action(obs, noise=eps)            # captures the fp32 graph of bucket 256
+    assert 256 in pol._graphs
+    pol.act_graphs = False
+    e32, _ = pol.get_action(obs, noise=eps)
+    set_inference_precision("bf16")
+    try:
+        e16, _ = pol.get_action(obs, noise=eps)        # eager bf16
+        pol.act_graphs = True
+        a16, _ = pol.get_action(obs, noise=eps)        # must NOT replay the fp32 graph
+    finally:
+        set_inference_precision("fp32")
+    a_back, _ = pol.get_action(obs, noise=eps)
+    assert torch.equal(a32, e32) and torch.equal(a16, e16) and torch.equal(a_back, a32)
+    assert not torch.equal(a16, a32) and (a16 - a32).abs().max().item() < 0.1
 
 
 def test_get_action_graph_replay_other_heads():

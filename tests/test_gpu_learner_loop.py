@@ -94,3 +94,22 @@ def test_add_new_experience_matches_oracle(tmp_path):
         np.testing.assert_allclose(learner.return_stats.std, ref_stats.std, rtol=1e-5)
     finally:
         learner.agent.cleanup()
+
+
+def test_configs0_literal_loop(tmp_path, capsys):
+    """BASELINE configs[0] as written: 8 parallel env processes (1v1: two agents each), obs 107, 90 discrete actions, the
+    DEFAULT 256x3 policy and critic -- the reference's own CPU-runnable configuration (example.py) -- through the whole loop
+    on the GPU path: collection over the worker processes, value pass + GAE, PPO update, report."""
+    learner = run(synthetic_env.make_discrete_env, tmp_path, n_proc=8, min_inference_size=8, timestep_limit=4000,
+                  exp_buffer_size=4096, ts_per_iteration=2048, ppo_epochs=2, ppo_batch_size=2048, ppo_minibatch_size=1024,
+                  policy_layer_sizes=(256, 256, 256), critic_layer_sizes=(256, 256, 256), save_every_ts=10_000_000)
+    out = capsys.readouterr().out
+    assert out.count("BEGIN ITERATION REPORT") == 2 and "Policy Entropy" in out
+    assert "Policy     182362" in out.replace("  ", " ").replace("  ", " ") or "182362" in out   # 107 -> 256x3 -> 90
+    assert "159489" in out                                                                         # 107 -> 256x3 -> 1
+    assert learner.agent.n_procs == 8 and learner.agent.cumulative_timesteps >= 4000
+    assert learner.ppo_learner.cumulative_model_updates == 2 * (1 + 2)   # 2 epochs x (1, 2) batches of 2048
+    pol = learner.ppo_learner.policy
+    assert pol.arena.dims == [107, 256, 256, 256, 90] and learner.ppo_learner.value_net.arena.dims == [107, 256, 256, 256, 1]
+    assert np.isfinite(pol.arena.flat.cpu().numpy()).all()
+    assert learner.agent.average_reward is not None

@@ -1,6 +1,7 @@
 """Device-resident rollout of a vectorised environment: VectorAgentManager against the
 numpy restatement of the reference's trajectory assembly (oracle/host.py::lockstep_rollout), and the whole Learner loop
 running on it."""
+import json
 import os
 import sys
 
@@ -98,9 +99,78 @@ def test_welford_increment_bit_exact():
         xp = np.zeros((n, ld), np.float32)
         xp[:, :d] = x
         xd = torch.from_numpy(xp).cuda()
-        N.check(L.rlppo_welford_increment(st(), P(xd), ld, n, d, P(mean), P(m2), w.count))
+        N.check(L.rlppo_welford_increment(st(), P(xd), ld, n, d, P(mean), P(m2), w.count, 0))
         w.increment(x, n)
         assert np.array_equal(mean.cpu().numpy(), w.mean_) and np.array_equal(m2.cpu().numpy(), w.m2)
+
+
+def test_welford_device_forms_follow_the_state_dtype():
+    """After WelfordRunningStat.from_json the state is float64 (np.asarray of Python floats, running_stats.py:121-125) and the
+    reference keeps updating in float64.  device_stats.increment / merge must do the same -- bit for bit what the host class
+    computes -- instead of reinterpreting the doubles as floats (the resume corruption the round-1 advisor found)."""
+    from rlgym_ppo_amd.util import WelfordRunningStat, device_stats
+    rs = np.random.RandomState(1)
+    for d in (107, 1):
+        src = WelfordRunningStat(d)
+        src.increment((rs.randn(41, d) * 2 + 1).astype(np.float32), 41)
+        x = (rs.randn(300, d) * 3 - 0.5).astype(np.float32)
+        other = WelfordRunningStat(d)
+        other.increment((rs.randn(29, d) + 4).astype(np.float32), 29)
+        for f64 in (False, True):
+            a, b = WelfordRunningStat(d), WelfordRunningStat(d)
+            for w in (a, b):
+                if f64:
+                    w.from_json(json.loads(json.dumps(src.to_json())))
+                    assert w.running_mean.dtype == np.float64
+                else:
+                    w.deserialize(src.serialize())
+                    w.running_mean = np.asarray(w.running_mean, np.float32)
+                    w.running_variance = np.asarray(w.running_variance, np.float32)
+            a.increment(x, 300)                                   # host class (the reference's arithmetic)
+            device_stats.increment(b, torch.from_numpy(x).cuda())
+            assert b.count == a.count and b.running_mean.dtype == a.running_mean.dtype
+            assert np.array_equal(a.running_mean, b.running_mean) and np.array_equal(a.running_variance, b.running_variance)
+            a.increment_from_serialized_other(other.serialize())
+            device_stats.merge(b, other.serialize(), "cuda:0")
+            assert b.count == a.count
+            assert np.array_equal(np.asarray(a.running_mean), b.running_mean)
+            assert np.array_equal(np.asarray(a.running_variance), b.running_variance)
+
+
+def test_vector_env_run_resumes_with_sane_observation_statistics(tmp_path, capsys):
+    """save -> load("latest") -> collect on a vector_env run: the reloaded (float64) statistics keep evolving exactly as the
+    host class would evolve them, and the standardised rows stay finite."""
+    from rlgym_ppo_amd import Learner
+    from rlgym_ppo_amd.util import WelfordRunningStat
+    kw = dict(vector_env=True, n_proc=1, exp_buffer_size=1024, ts_per_iteration=512, ppo_epochs=1, ppo_batch_size=512,
+              ppo_minibatch_size=256, policy_layer_sizes=(32, 32), critic_layer_sizes=(32, 32),
+              checkpoints_save_folder=str(tmp_path / "ck"), add_unix_timestamp=False, save_every_ts=500, random_seed=3)
+    first = Learner(synthetic_env.make_vector_env, timestep_limit=600, checkpoint_load_folder=None, **kw)
+    try:
+        first._learn()
+    finally:
+        first.agent.cleanup()
+    second = Learner(synthetic_env.make_vector_env, timestep_limit=10_000, checkpoint_load_folder="latest", **kw)
+    try:
+        st = second.agent.obs_stats
+        assert st.running_mean.dtype == np.float64 and st.count == first.agent.obs_stats.count
+        np.testing.assert_allclose(st.running_mean, first.agent.obs_stats.running_mean, rtol=1e-6)
+        shadow = WelfordRunningStat(1)
+        shadow.from_json(st.to_json())
+        seen = []
+        orig = second.agent._increment_obs_stats
+        second.agent._increment_obs_stats = lambda obs: (seen.append(obs.cpu().numpy()), orig(obs))[1]
+        exp, _, n, _ = second.agent.collect_timesteps(512)
+        assert len(seen) >= 2
+        for obs in seen:
+            shadow.increment(obs, obs.shape[0])
+        assert st.count == shadow.count and st.running_mean.dtype == np.float64
+        assert np.array_equal(st.running_mean, shadow.running_mean) and np.array_equal(st.running_variance, shadow.running_variance)
+        rows = exp[0]
+        assert torch.isfinite(rows).all() and rows.abs().max().item() < 20.0   # first rows are the raw reset observations
+        assert 0.05 < float(st.std[0]) < 50
+    finally:
+        second.agent.cleanup()
 
 
 def test_vector_rollout_gaussian_policy():

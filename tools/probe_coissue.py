@@ -4,6 +4,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import bench
 from rlgym_ppo_amd import _native as N
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import _diag as D
 
 L = N.lib()
 dev = torch.device("cuda:0")
@@ -18,7 +20,7 @@ for flags, label in ((1, "MFMA+LDS | 8 loads, no VALU"), (3, "MFMA+LDS | 8 loads
                      (64 + 1, "MFMA+LDS | 16 v_pk_add_f32"), (128 + 1, "MFMA+LDS | 16 v_fma_f32"),
                      (16, "MFMA only | 16 v_add_u32"), (32, "MFMA only | 16 v_lshl_add_u64"),
                      (16 + 4, "idle | 16 v_add_u32"), (32 + 4, "idle | 16 v_lshl_add_u64"), (64 + 4, "idle | 16 v_pk_add_f32")):
-    fn = lambda: N.check(L.rlppo_dbg_probe_coissue(st(), P(buf), flags, iters, P(cyc), P(out)))
+    fn = lambda: D.check(D.DL.rlppo_dbg_probe_coissue(st(), P(buf), flags, iters, P(cyc), P(out)))
     ms = bench.time_region(fn, 3)
     c = cyc.cpu().numpy().reshape(-1, 2).astype(np.float64)
     nb = iters // 4

@@ -4,6 +4,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import bench
 from rlgym_ppo_amd import _native as N
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import _diag as D
 
 L = N.lib()
 dev = torch.device("cuda:0")
@@ -19,7 +21,7 @@ for wg_per_cu in (2, 4, 8):
         iters = max(64, min(4096, (1 << 32) // (nwaves * 8192)))
         row = []
         for pat in range(4):
-            fn = lambda: N.check(L.rlppo_dbg_probe_ld(st(), pat, blocks, P(buf), span, iters, P(out)))
+            fn = lambda: D.check(D.DL.rlppo_dbg_probe_ld(st(), pat, blocks, P(buf), span, iters, P(out)))
             ms = bench.time_region(fn, 5)
             byts = nwaves * 8192 * iters
             row.append(f"{names[pat]}: {byts/ms/1e9:6.2f} TB/s = {byts/(ms*1e-3)/2.4e9/256:5.1f} B/clk/CU")

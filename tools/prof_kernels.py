@@ -25,16 +25,16 @@ idx = torch.randperm(M, device=dev)
 dW = torch.zeros(256 * 256, device=dev)
 db = torch.zeros(256, device=dev)
 tn_ws = torch.empty(max(int(L.rlppo_dbg_gemm_tn_workspace_bytes(o, i, M)) for o, i in ((256, 256), (256, 107), (90, 256))),
-                    dtype=torch.uint8, device=dev)  # too small a workspace silently selects the atomic form
+                    dtype=torch.uint8, device=dev)
 bits = torch.zeros(int(L.rlppo_dbg_gemm_nt_bits_bytes(M, 256)), dtype=torch.uint8, device=dev)  # ReLU bitmask: forward writes, dX reads
 reps = int(os.environ.get("REPS", 3))
 for _ in range(reps):
     N.check(L.rlppo_dbg_gemm_nt_bits(st(), P(A256), 256, P(W), 256, P(bias), P(C256), 256, M, 256, 256, 1, P(bits)))
-    N.check(L.rlppo_dbg_gemm_nt(st(), P(A256), 256, None, P(W), 256, P(bias), None, 0, P(C96), 96, M, 96, 256, 0))
+    N.check(L.rlppo_dbg_gemm_nt(st(), P(A256), 256, P(W), 256, P(bias), None, 0, P(C96), 96, M, 96, 256, 0))
     N.check(L.rlppo_dbg_gemm_nt_bits(st(), P(A256), 256, P(W), 256, None, P(C256), 256, M, 256, 256, 3, P(bits)))
-    N.check(L.rlppo_dbg_gemm_tn_ws(st(), P(A256), 256, 256, P(A256b), 256, 256, P(dW), P(db), 256, 256, M, P(tn_ws), tn_ws.numel()))
-    N.check(L.rlppo_dbg_gemm_tn_ws(st(), P(A256), 256, 256, P(A128), 128, 128, P(dW), P(db), 256, 107, M, P(tn_ws), tn_ws.numel()))
-    N.check(L.rlppo_dbg_gemm_tn_ws(st(), P(A96), 96, 96, P(A256), 256, 256, P(dW), P(db), 90, 256, M, P(tn_ws), tn_ws.numel()))
+    N.check(L.rlppo_dbg_gemm_tn(st(), P(A256), 256, 256, P(A256b), 256, 256, P(dW), P(db), 256, 256, M, P(tn_ws), tn_ws.numel()))
+    N.check(L.rlppo_dbg_gemm_tn(st(), P(A256), 256, 256, P(A128), 128, 128, P(dW), P(db), 256, 107, M, P(tn_ws), tn_ws.numel()))
+    N.check(L.rlppo_dbg_gemm_tn(st(), P(A96), 96, 96, P(A256), 256, 256, P(dW), P(db), 90, 256, M, P(tn_ws), tn_ws.numel()))
 rs = np.random.RandomState(0)
 n = 8192 * 256
 d = lambda x: torch.as_tensor(x).cuda()

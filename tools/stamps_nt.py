@@ -2,6 +2,8 @@ import ctypes, os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from rlgym_ppo_amd import _native as N
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import _diag as D
 L = N.lib(); M = 65536
 st = lambda: ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 P = lambda t: ctypes.c_void_p(t.data_ptr())
@@ -11,7 +13,7 @@ stamps = torch.zeros(nwg * 4 * 10, dtype=torch.int64, device="cuda")
 import bench
 names = ["prologue", "issue loads", "frags+MFMA", "wait vmcnt", "LDS writes", "barrier", "epilogue", "TOTAL"]
 for mode, label in ((0, "real"), (1, "A rows from L2"), (2, "no stores"), (64, "scalar-addressed kernel")):
-    fn = lambda: N.check(L.rlppo_dbg_gemm_nt_stamped(st(), P(A), 256, P(W), 256, P(b), P(C), 256, M, 256, 256, P(stamps), mode))
+    fn = lambda: D.check(D.DL.rlppo_dbg_gemm_nt_stamped(st(), P(A), 256, P(W), 256, P(b), P(C), 256, M, 256, 256, P(stamps), mode))
     ms = bench.time_region(fn, 5)
     raw = stamps.cpu().numpy()
     s = raw[:nwg * 32].reshape(nwg, 4, 8).astype(np.float64).mean(axis=(0, 1))
