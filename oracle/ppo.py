@@ -49,27 +49,40 @@ def minibatch_autograd(head, pol, val, obs, acts, old_logp, adv, targets, clip, 
 
 
 # ------------------------------------------------------------------------------ one minibatch, float64
-def _fwd64(params, x, out_tanh=False):
+def _fwd64(params, x, out_tanh=False, masks=None, detail=None):
+    """float64 forward.  `masks` (optional): one boolean [n, H_l] array per hidden layer that REPLACES the ReLU decision
+    [pre > 0] -- the decisions a float32 implementation actually took; where they differ from float64's own, |pre| is within
+    float32 rounding of 0, so the forward value changes by no more than that and the backward pass mirrors the
+    implementation's choice exactly.  `detail` (optional dict) receives the pre-activations and the float32 rounding scale
+    sum_k |x_k w_jk| + |b_j| of every hidden unit (what bounds a legitimate sign flip)."""
     acts = [x]
+    used = []
     h = x
     for i, (w, b) in enumerate(params):
-        h = h @ w.T + b
+        pre = h @ w.T + b
         if i < len(params) - 1:
-            h = np.maximum(h, 0.0)
+            m = (pre > 0.0) if masks is None else np.asarray(masks[i], bool)
+            if detail is not None:
+                detail.setdefault("pre", []).append(pre)
+                detail.setdefault("scale", []).append(np.abs(h) @ np.abs(w).T + np.abs(b))
+            h = pre * m
+            used.append(m)
+        else:
+            h = pre
         acts.append(h)
     if out_tanh:
         acts[-1] = np.tanh(acts[-1])
-    return acts
+    return acts, used
 
 
-def _bwd64(params, acts, dout):
+def _bwd64(params, acts, dout, masks):
     grads = [None] * len(params)
     g = dout
     for i in range(len(params) - 1, -1, -1):
         w, _ = params[i]
         grads[i] = (g.T @ acts[i], g.sum(0))
         if i > 0:
-            g = (g @ w) * (acts[i] > 0)
+            g = (g @ w) * masks[i - 1]
     return grads
 
 
@@ -83,7 +96,10 @@ def surrogate_weight(ratio, adv, clip):
 
 
 def minibatch_analytic(head, pol, val, obs, acts, old_logp, adv, targets, clip, ent_coef, mb_ratio,
-                       var_range=(0.1, 1.0)):
+                       var_range=(0.1, 1.0), masks_pol=None, masks_val=None, w_override=None, detail=None):
+    """float64 losses / statistics / gradients with hand-derived backprop.  Optional: `masks_pol` / `masks_val` impose the
+    ReLU decisions of a float32 implementation (see _fwd64); `w_override` ([n], NaN = keep) imposes its surrogate-branch
+    decision on rows whose ratio sits within rounding of a clip edge; `detail` (dict) receives per-row diagnostics."""
     f = lambda t: np.asarray(t, np.float64)
     pol = [(f(w), f(b)) for w, b in pol]
     val = [(f(w), f(b)) for w, b in val]
@@ -91,14 +107,26 @@ def minibatch_analytic(head, pol, val, obs, acts, old_logp, adv, targets, clip, 
     # float32-rounded clip edges: the reference compares fp32 ratios against 1.0 -/+ clip evaluated in
     # python floats and cast to fp32 by torch.clamp
     n = x.shape[0]
-    va = _fwd64(val, x)
+    dval = None if detail is None else detail.setdefault("val", {})
+    dpol = None if detail is None else detail.setdefault("pol", {})
+    va, vm = _fwd64(val, x, masks=masks_val, detail=dval)
     v = va[-1][:, 0]
     dv = (mb_ratio * 2.0 * (v - tg) / n)[:, None]
-    gv = _bwd64(val, va, dv)
+    gv = _bwd64(val, va, dv, vm)
+
+    def weight(ratio):
+        w = surrogate_weight(ratio, A, clip)
+        if detail is not None:
+            detail["ratio"], detail["w"] = ratio, w
+        if w_override is not None:
+            ov = np.asarray(w_override, np.float64)
+            w = np.where(np.isnan(ov), w, ov)
+        return w
+
     value_loss = np.mean((v - tg) ** 2)
 
     if head == "discrete":
-        pa = _fwd64(pol, x)
+        pa, pm = _fwd64(pol, x, masks=masks_pol, detail=dpol)
         z = pa[-1]
         z = z - z.max(-1, keepdims=True)
         p = np.exp(z)
@@ -110,15 +138,15 @@ def minibatch_analytic(head, pol, val, obs, acts, old_logp, adv, targets, clip, 
         logp = lp[rows, a]
         ent_i = -(lp * pc).sum(-1)
         ratio = np.exp(logp - old)
-        w = surrogate_weight(ratio, A, clip)
+        w = weight(ratio)
         g_pc = mb_ratio * (ent_coef / n) * (lp + 1.0)
         g_pc[rows, a] += mb_ratio * (-(A * w * ratio) / n) / pc[rows, a]
         g_p = g_pc * (p >= nets.PROB_MIN)
         dz = p * (g_p - (g_p * p).sum(-1, keepdims=True))
-        gp = _bwd64(pol, pa, dz)
+        gp = _bwd64(pol, pa, dz, pm)
         entropy = ent_i.mean()
     elif head == "gaussian":
-        pa = _fwd64(pol, x, out_tanh=True)
+        pa, pm = _fwd64(pol, x, out_tanh=True, masks=masks_pol, detail=dpol)
         y = pa[-1]
         k = y.shape[1] // 2
         m, b = nets.var_map(*var_range)
@@ -127,16 +155,21 @@ def minibatch_analytic(head, pol, val, obs, acts, old_logp, adv, targets, clip, 
         logp = (-(mu * mu) / (2 * sd * sd) + mu * xa / (sd * sd) - xa * xa / (2 * sd * sd)
                 + np.log(1.0 / np.sqrt(2 * np.pi * sd * sd))).sum(-1)
         ratio = np.exp(logp - old)
-        w = surrogate_weight(ratio, A, clip)
+        w = weight(ratio)
+        if detail is not None:  # conditioning of logp on the head's outputs: |d logp / d y_j| (tanh outputs: mean | sd pre-map)
+            detail["dlogp_dy"] = np.concatenate([np.abs((xa - mu) / (sd * sd)), np.abs(((xa - mu) ** 2 / sd ** 3 - 1.0 / sd) * m)], 1)
+            detail["logp_terms"] = (np.abs(mu * mu / (2 * sd * sd)) + np.abs(mu * xa / (sd * sd)) + np.abs(xa * xa / (2 * sd * sd))
+                                    + np.abs(np.log(1.0 / np.sqrt(2 * np.pi * sd * sd)))).sum(-1)
+            detail["y"] = y
         g_logp = (mb_ratio * (-(A * w * ratio) / n))[:, None]
         d_mu = g_logp * (xa - mu) / (sd * sd)
         d_sd = g_logp * ((xa - mu) ** 2 / sd ** 3 - 1.0 / sd) - mb_ratio * ent_coef / (n * k) / sd
         dy = np.concatenate([d_mu, d_sd * m], axis=1)
         dz = dy * (1.0 - y * y)
-        gp = _bwd64(pol, pa, dz)
+        gp = _bwd64(pol, pa, dz, pm)
         entropy = (0.5 + 0.5 * math.log(2 * math.pi) + np.log(sd)).mean()
     else:
-        pa = _fwd64(pol, x)
+        pa, pm = _fwd64(pol, x, masks=masks_pol, detail=dpol)
         z = pa[-1]
         a = f(acts).astype(np.int64)
         dz = np.zeros_like(z)
@@ -155,7 +188,7 @@ def minibatch_analytic(head, pol, val, obs, acts, old_logp, adv, targets, clip, 
             parts.append((s, bins, ls, ph, eh))
             s += bins
         ratio = np.exp(logp - old)
-        w = surrogate_weight(ratio, A, clip)
+        w = weight(ratio)
         g_logp = mb_ratio * (-(A * w * ratio) / n)
         for h, (s, bins, ls, ph, eh) in enumerate(parts):
             onehot = np.zeros((n, bins))
@@ -163,7 +196,7 @@ def minibatch_analytic(head, pol, val, obs, acts, old_logp, adv, targets, clip, 
             d = g_logp[:, None] * (onehot - ph)
             d += (-mb_ratio * ent_coef / n) * (-ph * (ls + eh[:, None]))
             dz[:, s:s + bins] = d
-        gp = _bwd64(pol, pa, dz)
+        gp = _bwd64(pol, pa, dz, pm)
         entropy = ent_i.mean()
 
     s1 = ratio * A
@@ -286,3 +319,59 @@ def learn(head, pol, val, buf, batch_size, mini_batch_size, n_epochs, clip, ent_
         "Value Function Update Magnitude": (before_v - nets.flatten(val)).norm().item(),
     }
     return report, adam_pol, adam_val
+
+
+# --------------------------------------------------------------------------------------- full learn, float64
+def learn64(head, pol, val, buf, batch_size, mini_batch_size, n_epochs, clip, ent_coef, policy_lr, critic_lr, rng,
+            var_range=(0.1, 1.0), on_step=None, weakest=None):
+    """The same loop as learn() evaluated in float64 end to end (minibatch_analytic gradients, clip coefficient, Adam):
+    the truth both float32 implementations -- the reference's CPU path and the HIP kernels -- are measured against in
+    tests/test_gpu_learner.py.  Returns float64 parameter lists; `on_step(i, pol, val)` after every optimiser step.
+    `weakest` (optional dict): receives, per network ("pol" / "val"), a flat array with the smallest |g_i| / max|g| every
+    parameter has seen in any optimiser step so far.  Adam's step lr * m / (sqrt(v) + 1e-8) is ill-conditioned in g where
+    that ratio is tiny: an absolute gradient error d moves the step by ~lr * d / |g_i|, whatever implementation made it."""
+    f = lambda t: np.asarray(t, np.float64).copy()
+    pol = [(f(w), f(b)) for w, b in pol]
+    val = [(f(w), f(b)) for w, b in val]
+    st = {id(p): [np.zeros_like(p), np.zeros_like(p)] for wb in pol + val for p in wb}
+    step = 0
+    total = len(buf["advantages"])
+    mb_ratio = mini_batch_size / batch_size
+    B = {k: np.asarray(v, np.float64) for k, v in buf.items()}
+    for _ in range(n_epochs):
+        idx = rng.permutation(total)
+        start = 0
+        while start + batch_size <= total:
+            bi = idx[start:start + batch_size]
+            start += batch_size
+            gp = [(np.zeros_like(w), np.zeros_like(b)) for w, b in pol]
+            gv = [(np.zeros_like(w), np.zeros_like(b)) for w, b in val]
+            for s in range(0, batch_size, mini_batch_size):
+                mi = bi[s:s + mini_batch_size]
+                acts = B["actions"][mi].reshape(len(mi), -1)
+                r = minibatch_analytic(head, pol, val, B["states"][mi], acts[:, 0] if head == "discrete" else acts, B["log_probs"][mi],
+                                       B["advantages"][mi], B["values"][mi], clip, ent_coef, mb_ratio, var_range)
+                for acc, new in ((gp, r["grad_policy"]), (gv, r["grad_value"])):
+                    for (aw, ab), (w, b) in zip(acc, new):
+                        aw += w
+                        ab += b
+            step += 1
+            bc1, bc2 = 1 - ADAM_B1 ** step, 1 - ADAM_B2 ** step
+            for key, params, grads, lr in (("val", val, gv, critic_lr), ("pol", pol, gp, policy_lr)):
+                if weakest is not None:
+                    flat = np.abs(np.concatenate([g.ravel() for wb in grads for g in wb]))
+                    rel = flat / max(flat.max(), 1e-300)
+                    weakest[key] = rel if key not in weakest else np.minimum(weakest[key], rel)
+                total_norm = math.sqrt(sum(float((g * g).sum()) for wb in grads for g in wb))
+                coef = min(MAX_GRAD_NORM / (total_norm + 1e-6), 1.0)
+                for wb, gwb in zip(params, grads):
+                    for p_, g in zip(wb, gwb):
+                        g = g * coef
+                        m, v = st[id(p_)]
+                        m += (1 - ADAM_B1) * (g - m)
+                        v *= ADAM_B2
+                        v += (1 - ADAM_B2) * g * g
+                        p_ -= (lr / bc1) * m / (np.sqrt(v) / math.sqrt(bc2) + ADAM_EPS)
+            if on_step is not None:
+                on_step(step - 1, pol, val)
+    return pol, val

@@ -12,6 +12,7 @@ pytestmark = pytest.mark.gpu
 
 from oracle import gae as ogae  # noqa: E402
 from oracle import nets, ppo  # noqa: E402
+import fp64_gate  # noqa: E402  (tests/fp64_gate.py: the parity gate against float64 truth)
 
 
 @pytest.fixture(scope="module")
@@ -421,7 +422,12 @@ def test_g9_gaussian_and_multidiscrete_act(L, golden):
     np.testing.assert_allclose(act.cpu().numpy(), g["act"], rtol=1e-5, atol=2e-6)
     clamped = np.abs(g["act"]) == 1.0
     assert np.array_equal(np.abs(act.cpu().numpy()) == 1.0, clamped)
-    np.testing.assert_allclose(logp.cpu().numpy(), g["logp"], rtol=2e-5, atol=2e-4)
+    # log-probabilities: float64 truth with the bound the 4-term formula's conditioning implies (tests/fp64_gate.py), and the
+    # reference's own float32 numbers within the sum of the two implementations' bounds
+    y = torch.empty(n, net.ld_out, device="cuda")
+    check(L, L.rlppo_mlp_forward(stream(), net.dims_c, net.nl, P(net.packed), P(rows), net.ld_in, n, 1, P(y), net.ld_out, P(w), w.numel()))
+    res = fp64_gate.gauss_logp_check(net.params, g["obs"], g["eps"], y, act, logp, label="G9")
+    assert np.abs(logp.cpu().numpy() - g["logp"]).max() <= res["hip"][2] * (res["hip"][1] + res["cpu"][1]) + 1e-7
 
     g = golden("g9_multidiscrete")
     net = Net(L, nets.params_from_state(g, "p."))
@@ -466,32 +472,18 @@ def run_minibatch(L, head, pol, val, obs_all, acts_all, old_all, tgt_all, adv_al
     return nets.unflatten(gp.cpu(), pol), nets.unflatten(gv.cpu(), val), stats.cpu().numpy()
 
 
-def compare_minibatch(gp, gv, stats, ref, tol=1e-5):
-    for name, got, want in (("entropy", stats[0], ref["entropy"]), ("kl", stats[1], ref["kl"]),
-                            ("value_loss", stats[2], ref["value_loss"]), ("clip_fraction", stats[3], ref["clip_fraction"]),
-                            ("policy_loss", stats[4], ref["policy_loss"])):
-        assert abs(got - want) <= tol * max(abs(want), 1e-3) + 1e-7, (name, got, want)
-    for (aw, ab), (rw, rb) in zip(gp + gv, ref["grad_policy"] + ref["grad_value"]):
-        assert relerr(aw, rw) < tol + 1e-7 / max(float(rw.abs().max()), 1e-30), ("W", relerr(aw, rw))
-        assert relerr(ab, rb) < tol + 1e-7 / max(float(rb.abs().max()), 1e-30), ("b", relerr(ab, rb))
-
-
 def test_g4_discrete_minibatch_against_reference(L, golden):
+    """Reference fixture G4 as it is -- 32 rows engineered onto the clip edges, 32 exact torch.min ties at ratio == 1, clamped
+    probabilities, clipped-high / clipped-low rows -- against float64 truth, every row in (tests/fp64_gate.py); and the parts of
+    the reference's own float32 output that no knife-edge row touches, directly."""
     g = golden("g4_discrete_loss")
     pol, val = nets.params_from_state(g, "p."), nets.params_from_state(g, "v.")
-    # rows engineered to sit exactly on a clip edge are decided by the last bit of exp(): move them off the edge and
-    # compare against the oracle on the same moved input; every other special region of the fixture stays (clamped
-    # probabilities, clipped-high / clipped-low rows, exact torch.min ties at ratio == 1).
-    old = g["old_logp"].copy()
-    edge = np.isclose(np.abs(g["out.ratio"] - 1.0), 0.2, rtol=0, atol=1e-4)
-    old[edge] += 0.05
     idx = np.arange(96)
-    gp, gv, stats = run_minibatch(L, "discrete", pol, val, g["obs"], g["acts"], old, g["targets"], g["adv"], idx, 0.2, 0.005, 0.25)
-    ref = ppo.minibatch_autograd("discrete", pol, val, torch.as_tensor(g["obs"]), torch.as_tensor(g["acts"]).view(-1),
-                                 torch.as_tensor(old), torch.as_tensor(g["adv"]), torch.as_tensor(g["targets"]), 0.2, 0.005, 0.25)
-    compare_minibatch(gp, gv, stats, ref, tol=2e-5)
-    # and the un-moved fixture: everything except the knife-edge rows' contribution must still match the reference
-    gp2, gv2, stats2 = run_minibatch(L, "discrete", pol, val, g["obs"], g["acts"], g["old_logp"], g["targets"], g["adv"], idx, 0.2, 0.005, 0.25)
+    got = run_minibatch(L, "discrete", pol, val, g["obs"], g["acts"], g["old_logp"], g["targets"], g["adv"], idx, 0.2, 0.005, 0.25)
+    out = fp64_gate.gate(L, "discrete", pol, val, g["obs"], g["acts"], g["old_logp"], g["adv"], g["targets"], 0.2, 0.005, 0.25, got,
+                         label="G4 (reference fixture, 32 clip-edge rows)")
+    assert out["edge_rows"] == 32
+    gp2, gv2, stats2 = got
     assert abs(stats2[0] - float(g["out.entropy"])) < 1e-5 * abs(float(g["out.entropy"]))
     assert abs(stats2[2] - float(g["out.value_loss"])) < 1e-5 * abs(float(g["out.value_loss"]))
     for i, (gw, gb) in enumerate(gv2):
@@ -504,11 +496,8 @@ def test_g9_other_heads_minibatch(L, golden, head, fixture):
     pol, val = nets.params_from_state(g, "p."), nets.params_from_state(g, "v.")
     n = g["obs"].shape[0]
     acts = g["act"].astype(np.float32)
-    gp, gv, stats = run_minibatch(L, head, pol, val, g["obs"], acts, g["old_logp"], g["targets"], g["adv"], np.arange(n),
-                                  0.2, 0.005, 0.5)
-    ref = ppo.minibatch_autograd(head, pol, val, torch.as_tensor(g["obs"]), torch.as_tensor(acts), torch.as_tensor(g["old_logp"]),
-                                 torch.as_tensor(g["adv"]), torch.as_tensor(g["targets"]), 0.2, 0.005, 0.5)
-    compare_minibatch(gp, gv, stats, ref, tol=5e-5)
+    got = run_minibatch(L, head, pol, val, g["obs"], acts, g["old_logp"], g["targets"], g["adv"], np.arange(n), 0.2, 0.005, 0.5)
+    fp64_gate.gate(L, head, pol, val, g["obs"], acts, g["old_logp"], g["adv"], g["targets"], 0.2, 0.005, 0.5, got, label="G9 " + head)
 
 
 def test_minibatch_gather_and_accumulate_cfg2_shape(L):
@@ -525,25 +514,15 @@ def test_minibatch_gather_and_accumulate_cfg2_shape(L):
     adv = rs.randn(n).astype(np.float32)
     tgt = rs.randn(n).astype(np.float32)
     perm = rs.permutation(n)
-    # A hidden unit whose pre-activation is within fp32 GEMM rounding of 0 gets its ReLU mask from the last bit of
-    # the accumulation order; one such flip moves a first-layer gradient row by ~1/sqrt(mb).  Those samples are
-    # ambiguous for ANY two fp32 implementations (CPU-MKL vs MFMA included), so they are left out of the comparison.
-    amb = np.zeros(n, bool)
-    for params in (pol, val):
-        h = obs.astype(np.float64)
-        for w, b in params[:-1]:
-            pre = h @ w.double().numpy().T + b.double().numpy()
-            amb |= (np.abs(pre) < 2e-5).any(1)
-            h = np.maximum(pre, 0)
-    assert amb.mean() < 0.2
-    perm = perm[~amb[perm]]
+    # No row is left out: a hidden unit whose pre-activation is within fp32 GEMM rounding of 0 gets its ReLU mask from the last
+    # bit of the accumulation order (CPU-MKL vs MFMA included); the gate reads the masks each implementation took, checks that
+    # every one that differs from float64's is such a unit, and compares against float64 under those masks.
+    acc_p = acc_v = None
     for s in range(2):
         idx = perm[s * 3000:(s + 1) * 3000]
-        gp, gv, stats = run_minibatch(L, "discrete", pol, val, obs, act.numpy(), old, tgt, adv, idx, 0.2, 0.005, 0.5)
-        ti = torch.as_tensor(idx)
-        ref = ppo.minibatch_autograd("discrete", pol, val, torch.as_tensor(obs)[ti], act[ti].float(), torch.as_tensor(old)[ti],
-                                     torch.as_tensor(adv)[ti], torch.as_tensor(tgt)[ti], 0.2, 0.005, 0.5)
-        compare_minibatch(gp, gv, stats, ref, tol=2e-5)
+        got = run_minibatch(L, "discrete", pol, val, obs, act.numpy(), old, tgt, adv, idx, 0.2, 0.005, 0.5)
+        fp64_gate.gate(L, "discrete", pol, val, obs[idx], act.numpy()[idx], old[idx], adv[idx], tgt[idx], 0.2, 0.005, 0.5, got,
+                       label=f"cfg2 shape, 3000 gathered rows (slice {s})")
 
 
 def test_minibatch_full_size_cfg2(L):
@@ -551,7 +530,7 @@ def test_minibatch_full_size_cfg2(L):
     (a) additivity, the size-independent property of the update: the gradient of the whole minibatch equals the sum of
         the gradients of its two halves (each scaled by mb_ratio/2) -- different row splits, tile counts and partial-tile
         reductions must agree; the report statistics are means, so they average;
-    (b) the oracle itself (float32 autograd restatement) on the rows whose ReLU masks are not decided by the last bit."""
+    (b) float64 truth next to the CPU float32 oracle on ALL 65,536 rows (tests/fp64_gate.py)."""
     torch.manual_seed(321)
     pol = nets.init_mlp(107, (256, 256, 256), 90)
     val = nets.init_mlp(107, (256, 256, 256), 1)
@@ -563,16 +542,7 @@ def test_minibatch_full_size_cfg2(L):
     old = (logp + torch.as_tensor(rs.randn(n).astype(np.float32) * 0.2)).numpy()
     adv = rs.randn(n).astype(np.float32)
     tgt = rs.randn(n).astype(np.float32)
-    amb = np.zeros(n, bool)
-    for params in (pol, val):
-        h = obs.astype(np.float64)
-        for w, b in params[:-1]:
-            pre = h @ w.double().numpy().T + b.double().numpy()
-            amb |= (np.abs(pre) < 2e-5).any(1)
-            h = np.maximum(pre, 0)
     perm = rs.permutation(n)
-    perm = perm[~amb[perm]]
-    assert len(perm) >= 65536
     idx = perm[:65536]
     gp, gv, st = run_minibatch(L, "discrete", pol, val, obs, act.numpy(), old, tgt, adv, idx, 0.2, 0.005, 1.0)
     gp1, gv1, st1 = run_minibatch(L, "discrete", pol, val, obs, act.numpy(), old, tgt, adv, idx[:32768], 0.2, 0.005, 0.5)
@@ -581,10 +551,8 @@ def test_minibatch_full_size_cfg2(L):
         for k in (0, 1):
             assert relerr(whole[k], h1[k].double() + h2[k].double()) < 1e-5
     np.testing.assert_allclose(st[:5], (st1[:5] + st2[:5]) / 2, rtol=1e-5, atol=1e-8)
-    ti = torch.as_tensor(idx)
-    ref = ppo.minibatch_autograd("discrete", pol, val, torch.as_tensor(obs)[ti], act[ti].float(), torch.as_tensor(old)[ti],
-                                 torch.as_tensor(adv)[ti], torch.as_tensor(tgt)[ti], 0.2, 0.005, 1.0)
-    compare_minibatch(gp, gv, st, ref, tol=2e-5)
+    fp64_gate.gate(L, "discrete", pol, val, obs[idx], act.numpy()[idx], old[idx], adv[idx], tgt[idx], 0.2, 0.005, 1.0, (gp, gv, st),
+                   label="cfg2 full minibatch, 65,536 rows, none excluded")
 
 
 def test_fused_pass_full_size_cfg2(L):

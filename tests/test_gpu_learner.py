@@ -47,6 +47,16 @@ def test_learn_matches_reference_fixture(golden, name):
     # permutation stream is the reference's; Adam state persists in the optimisers)
     n_steps = int(g["n_steps"])
     steps_per_epoch = cfg["n"] // cfg["B"]
+    # FLOAT64 TRUTH of the same learn() (oracle/ppo.py::learn64: float64 gradients, clip, Adam) after every optimiser step:
+    # the HIP parameters and the reference's own float32 parameters (the fixture) are both measured against it
+    head = {0: "discrete", 1: "multidiscrete", 2: "gaussian"}[cfg["policy_type"]]
+    truth, weakest = {}, {}
+    ppo.learn64(head, nets.params_from_state(g, "p0."), nets.params_from_state(g, "v0."),
+                {k: g["exp." + k] for k in ("states", "actions", "log_probs", "values", "advantages")}, cfg["B"], cfg["MB"],
+                cfg["epochs"], cfg["clip"], cfg["ent"], cfg["lr"], cfg["lr"], np.random.RandomState(cfg["seed"]), weakest=weakest,
+                on_step=lambda i, p, v: truth.__setitem__(i, (np.concatenate([t.ravel() for wb in p for t in wb]),
+                                                              np.concatenate([t.ravel() for wb in v for t in wb]),
+                                                              weakest["pol"].copy(), weakest["val"].copy())))
     learner.n_epochs = 1
     reports = []
     for e in range(cfg["epochs"]):
@@ -54,10 +64,28 @@ def test_learn_matches_reference_fixture(golden, name):
         s = (e + 1) * steps_per_epoch - 1
         pv = torch.nn.utils.parameters_to_vector(learner.policy.parameters())
         vv = torch.nn.utils.parameters_to_vector(learner.value_net.parameters())
-        # tolerance: rel 1e-5 after the first steps, documented to grow with the number of Adam steps
-        tol = 1e-4 if cfg["policy_type"] == 2 else 2e-5  # the gaussian head's (x-mu)^2/sd^3 terms amplify fp32 rounding
-        assert relerr(pv, g[f"step{s}.policy"]) < tol, (e, relerr(pv, g[f"step{s}.policy"]))
-        assert relerr(vv, g[f"step{s}.value"]) < tol, (e, relerr(vv, g[f"step{s}.value"]))
+        tp, tv, wp, wv = truth[s]
+        # Adam's step lr * m / (sqrt(v) + 1e-8) does not depend continuously on a gradient entry that is ~0: a parameter whose
+        # gradient was below 1e-4 of the largest one in some step turns a 3e-7 gradient rounding (what the minibatch gate
+        # measures) into up to lr * 3e-3 of parameter -- for the reference's float32 path exactly as for the kernels.  Those
+        # parameters (counted, a few percent) are held to the Adam-step bound, everything else to 1e-5.
+        errs = {}
+        for who, p_, v_ in (("hip", pv.detach().cpu().numpy().astype(np.float64), vv.detach().cpu().numpy().astype(np.float64)),
+                            ("ref", g[f"step{s}.policy"].astype(np.float64), g[f"step{s}.value"].astype(np.float64))):
+            worst_good = worst_ill = 0.0
+            for got, tr, weak in ((p_, tp, wp), (v_, tv, wv)):
+                d = np.abs(got - tr) / np.abs(tr).max()
+                ill = weak < 1e-4
+                worst_good = max(worst_good, float(d[~ill].max()))
+                worst_ill = max(worst_ill, float(d[ill].max()) if ill.any() else 0.0)
+            errs[who] = (worst_good, worst_ill)
+        n_ill = int((wp < 1e-4).sum() + (wv < 1e-4).sum())
+        print(f"[fp64 gate] {name} after optimiser step {s}: err(HIP, fp64)={errs['hip'][0]:.2e}  err(reference fp32 fixture, fp64)="
+              f"{errs['ref'][0]:.2e}  | {n_ill} of {wp.size + wv.size} parameters with an ill-conditioned Adam step: HIP "
+              f"{errs['hip'][1]:.1e}, reference {errs['ref'][1]:.1e}")
+        assert errs["hip"][0] <= max(1e-5, 1.5 * errs["ref"][0]), (name, s, errs)
+        assert n_ill <= 0.05 * (wp.size + wv.size)
+        assert errs["hip"][1] <= (s + 1) * cfg["lr"] * 0.05 / min(np.abs(tp).max(), np.abs(tv).max()), (name, s, errs)
     assert learner.cumulative_model_updates == n_steps
     assert sorted(reports[0].keys()) == sorted([
         "PPO Batch Consumption Time", "Cumulative Model Updates", "Policy Entropy", "Mean KL Divergence",

@@ -9,18 +9,8 @@ import torch
 pytestmark = pytest.mark.gpu
 
 from oracle import nets, ppo  # noqa: E402
-from test_gpu_kernels import L, Net, P, check, compare_minibatch, dev, relerr, run_minibatch, stream  # noqa: E402,F401
-
-
-def ambiguous(params_list, obs, thr=1e-5):
-    amb = np.zeros(len(obs), bool)
-    for params in params_list:
-        h = obs.astype(np.float64)
-        for w, b in params[:-1]:
-            pre = h @ w.double().numpy().T + b.double().numpy()
-            amb |= (np.abs(pre) < thr).any(1)
-            h = np.maximum(pre, 0)
-    return amb
+import fp64_gate  # noqa: E402
+from test_gpu_kernels import L, Net, P, check, dev, relerr, run_minibatch, stream  # noqa: E402,F401
 
 
 @pytest.mark.parametrize("d,hidden,A,n,mb", [(50, (100, 40), 300, 700, 333), (7, (33,), 5, 64, 64), (300, (130, 257, 64), 1500, 400, 129),
@@ -47,13 +37,10 @@ def test_discrete_odd_shapes(L, d, hidden, A, n, mb):
     assert (act.cpu() != oact).sum().item() <= max(1, n // 500)
     old = (ologp + torch.as_tensor(rs.randn(n).astype(np.float32) * 0.2)).numpy()
     adv, tgt = rs.randn(n).astype(np.float32), rs.randn(n).astype(np.float32)
-    idx = np.flatnonzero(~ambiguous([pol, val], obs))
-    idx = rs.permutation(idx)[:mb]
-    gp, gv, stats = run_minibatch(L, "discrete", pol, val, obs, oact.numpy(), old, tgt, adv, idx, 0.2, 0.005, 1.0)
-    ti = torch.as_tensor(idx)
-    ref = ppo.minibatch_autograd("discrete", pol, val, torch.as_tensor(obs)[ti], oact[ti].float(), torch.as_tensor(old)[ti],
-                                 torch.as_tensor(adv)[ti], torch.as_tensor(tgt)[ti], 0.2, 0.005, 1.0)
-    compare_minibatch(gp, gv, stats, ref, tol=3e-5)
+    idx = rs.permutation(n)[:mb]
+    got = run_minibatch(L, "discrete", pol, val, obs, oact.numpy(), old, tgt, adv, idx, 0.2, 0.005, 1.0)
+    fp64_gate.gate(L, "discrete", pol, val, obs[idx], oact.numpy()[idx], old[idx], adv[idx], tgt[idx], 0.2, 0.005, 1.0, got,
+                   label=f"odd shape d={d} hidden={hidden} A={A}")
 
 
 def test_single_row_and_empty_calls(L):
