@@ -323,12 +323,66 @@ def cpu_baseline(seed=123, reps=3):
 BF16_MFMA_PEAK_TF = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA peak (the 5 PF headline figure includes 2:1 sparsity)
 
 
-def cfg5_rooflines(value, bf16):
-    """BASELINE configs[4]: 10,435,584 algorithmic flop/sample; 968 algorithmic B/sample read by the update."""
+def cfg5_rooflines(value, bf16, learner):
+    """BASELINE configs[4]: 10,435,584 algorithmic flop/sample; 968 algorithmic B/sample read by the update.
+    Times the three hidden-layer launch shapes of a pass (512 -> 512 at the rows the update launches) through the diagnostic
+    entry points and prices each against BOTH rooflines -- the MFMA peak of its arithmetic type and 8 TB/s of HBM over its
+    algorithmic bytes -- and says which one binds."""
+    from rlgym_ppo_amd import _native as N
+    L = N.lib()
+    dev = learner._dev
+    M = int(getattr(learner, "_fused_rows", MINIBATCH))
+    H = 512
+    st = lambda: ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    P = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
+    A = torch.randn(M, H, device=dev)
+    A2 = torch.randn(M, H, device=dev)
+    W = torch.randn(H, H, device=dev) * 0.05
+    bias = torch.zeros(H, device=dev)
+    C = torch.empty(M, H, device=dev)
+    bits = torch.zeros(max(int(L.rlppo_dbg_gemm_nt_bits_bytes(M, H)), 8), dtype=torch.uint8, device=dev)
+    dW, db = torch.zeros(H * H, device=dev), torch.zeros(H, device=dev)
+    tn_ws = torch.empty(int(L.rlppo_dbg_gemm_tn_workspace_bytes(H, H, M)), dtype=torch.uint8, device=dev)
+    Ab, Wb, Cb = A.bfloat16(), W.bfloat16(), torch.empty(M, H, dtype=torch.bfloat16, device=dev)
+    flop = 2 * M * H * H
+    shapes = [
+        ("gemm_nt fwd hidden 512->512 +bitmask, fp32 MFMA", lambda: N.check(L.rlppo_dbg_gemm_nt_bits(st(), P(A), H, P(W), H, P(bias), P(C), H, M, H, H, 1, P(bits))),
+         "f32", 4 * (2 * M * H + H * H) + M * H // 8),
+        ("gemm_nt_b16 fwd hidden 512->512: bf16 operands in memory, bf16 MFMA, fp32 accumulate; writes bf16 + fp32 + bitmask",
+         lambda: N.check(L.rlppo_dbg_gemm_nt_b16(st(), P(Ab), H, P(Wb), H, P(bias), P(C), H, P(Cb), H, M, H, H, 1, 1, P(bits))),
+         "bf16", 2 * (M * H + H * H) + 6 * M * H + M * H // 8),
+        ("gemm_nt dX hidden 512->512 bitmask, fp32 MFMA", lambda: N.check(L.rlppo_dbg_gemm_nt_bits(st(), P(A), H, P(W), H, None, P(C), H, M, H, H, 3, P(bits))),
+         "f32", 4 * (2 * M * H + H * H) + M * H // 8),
+        ("gemm_tn dW hidden 512x512 (+ reduction), fp32 MFMA", lambda: N.check(L.rlppo_dbg_gemm_tn(st(), P(A), H, H, P(A2), H, H, P(dW), P(db), H, H, M, P(tn_ws), tn_ws.numel())),
+         "f32", 4 * (2 * M * H + H * H)),
+    ]
+    rows = []
+    for name, fn, kind, nbytes in shapes:
+        ms = time_region(fn, 10, warm_s=0.3)
+        peak = BF16_MFMA_PEAK_TF if kind == "bf16" else MFMA_F32_PEAK_TF
+        f_mfma, f_hbm = flop / ms / 1e9 / peak, nbytes / ms / 1e6 / HBM_PEAK_GBS
+        rows.append(dict(kernel=name, rows_per_launch=M, ms_per_launch=round(ms, 4), tflops=round(flop / ms / 1e9, 1), mfma_peak=peak,
+                         frac_mfma=round(f_mfma, 4), algorithmic_mb=round(nbytes / 1e6, 1), gb_per_s=round(nbytes / ms / 1e6, 1),
+                         frac_hbm=round(f_hbm, 4), binds="hbm" if f_hbm > f_mfma else "mfma"))
+        log("  %-110s %8.4f ms  %7.1f TFLOP/s (%.2f of %s peak)  %7.1f GB/s (%.2f of HBM)" %
+            (name[:110], ms, flop / ms / 1e9, f_mfma, kind, nbytes / ms / 1e6, f_hbm))
     fps = CFG5["flop_per_sample"]
     tf = fps * value / 1e12
-    out = {"update_flop_efficiency": dict(achieved=round(tf, 2), peak=MFMA_F32_PEAK_TF, unit="TFLOP/s", frac=round(tf / MFMA_F32_PEAK_TF, 4),
-                                          note="10,435,584 algorithmic flop/sample (SURVEY 8(d)) x measured samples/s, against the fp32 MFMA peak")}
+    out = {"kernel_breakdown": rows,
+           "update_flop_efficiency": dict(achieved=round(tf, 2), peak=MFMA_F32_PEAK_TF, unit="TFLOP/s", frac=round(tf / MFMA_F32_PEAK_TF, 4),
+                                          note="10,435,584 algorithmic flop/sample (SURVEY 8(d)) x measured samples/s, against the fp32 MFMA "
+                                               "peak" + (" (mixed precision: the forward third of the flops runs on the bf16 pipe, so this is "
+                                                         "an equivalent-fp32 rate, not a utilisation)" if bf16 else ""))}
+    dom = rows[1] if bf16 else rows[0]
+    bound = dom["binds"]
+    out["roofline"] = dict(bound=bound, achieved=dom["gb_per_s"] if bound == "hbm" else dom["tflops"],
+                           peak=HBM_PEAK_GBS if bound == "hbm" else dom["mfma_peak"], unit="GB/s" if bound == "hbm" else "TFLOP/s",
+                           frac=dom["frac_hbm"] if bound == "hbm" else dom["frac_mfma"], traffic=None, kernel=dom["kernel"],
+                           other_bound=dict(bound="mfma" if bound == "hbm" else "hbm", frac=dom["frac_mfma"] if bound == "hbm" else dom["frac_hbm"]),
+                           ms_per_launch=dom["ms_per_launch"],
+                           note="the hidden-layer forward of the selected update precision at the update's launch shape, priced against both "
+                                "rooflines (algorithmic bytes: operands once, outputs once); `bound` = the larger fraction.  HIP events on the "
+                                "launch stream, 10 launches after a 0.3 s clock ramp")
     return out
 
 
@@ -523,7 +577,7 @@ def main():
             frac=round(FLOP_PER_SAMPLE * value / 1e12 / (MFMA_F32_PEAK_TF * world), 4),
             note="1,931,776 algorithmic flop/sample x measured whole-job samples/s against %d x the fp32 MFMA peak" % world)
     if args.config == "cfg5":
-        out.update(cfg5_rooflines(value, bf16))
+        pass  # kernel lines are added below (rank 0, one GPU)
 
     emitted = []
 
@@ -546,6 +600,8 @@ def main():
         threading.Thread(target=bail, daemon=True).start()
         out["allreduce"] = allreduce_ab(learner, buf, max(1, min(args.steps, 5)), world, device, dist)
         done.set()
+    if rank == 0 and world == 1 and not args.no_extras and args.config == "cfg5":
+        out.update(cfg5_rooflines(value, bf16, learner))
     if rank == 0 and world == 1 and not args.no_extras and args.config == "cfg2":
         rows, dom = kernel_breakdown(learner)
         for r in rows:

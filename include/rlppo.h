@@ -142,6 +142,10 @@ typedef struct rlppo_minibatch_args {
     const int32_t *val_dims;      /* HOST */
     const float *pol_packed;
     const float *val_packed;
+    const float *pol_packed_r;    /* bf16 update precision only (else NULL): rlppo_net_pack_bf16's images of both networks */
+    const float *val_packed_r;
+    const void *pol_wb16;
+    const void *val_wb16;
     float *pol_grad;              /* flat arena, accumulated (+=) */
     float *val_grad;
     /* device-resident experience (ExperienceBuffer, experience_buffer.py:42-50), gathered by `idx` */
@@ -268,9 +272,24 @@ int rlppo_welford_merge(void *stream, int32_t d, void *mean, void *m2, int64_t c
 
 /* Precision of the ROLLOUT forward passes (rlppo_mlp_forward, rlppo_*_act): 0 = fp32 (default; the parity mode),
  * 1 = activations and master weights rounded to bf16 as MFMA operands, fp32 accumulation / bias / activation
- * (BASELINE configs[4] "bf16 fwd / fp32 master weights").  rlppo_ppo_minibatch always computes in fp32.  The reference
+ * (BASELINE configs[4] "bf16 fwd / fp32 master weights").  The update has its own switch (rlppo_set_update_precision).  The reference
  * has no such mode (it is fp32 throughout): outputs then agree with an fp32 forward to ~1e-2, not 1e-5. */
 int rlppo_set_inference_precision(int32_t mode);
+
+/* Precision of the PPO UPDATE (rlppo_ppo_minibatch): 0 = fp32 (default; the parity mode: fp32 losses/grads within 1e-5 of the
+ * reference), 1 = BASELINE configs[4] "bf16 fwd / fp32 master weights": every forward product of both networks multiplies
+ * bf16-rounded operands (activations and weights, round-to-nearest-even) on the bf16 MFMA pipe and accumulates in fp32; bias,
+ * activations, losses, the whole backward pass, gradient accumulation, clip and Adam stay fp32, and the master weights are the
+ * fp32 arena.  The backward is the exact fp32 backward OF THAT FORWARD (torch.autograd of F.linear(r(h), r(W), b) with r =
+ * rounding to bf16 and a straight-through gradient): dX multiplies dY with the rounded weights, dW with the rounded inputs,
+ * no gradient is rounded.  The reference has no such mode; oracle/nets.py::mlp_bf16_operands + oracle/ppo.py::minibatch_autograd(bf16=True)
+ * restate it.  Changing the mode changes rlppo_minibatch_workspace_bytes.
+ * rlppo_net_pack_bf16: the rounded images the mode needs, rebuilt after every optimiser step -- packed_r: the packed layout
+ * (rlppo_packed_floats) holding the rounded weights as fp32; wb16: rlppo_wb16_elems bf16 values, the W[Pout][Pin] blocks. */
+int rlppo_set_update_precision(int32_t mode);
+int rlppo_get_update_precision(void);
+int64_t rlppo_wb16_elems(const int32_t *dims, int32_t n_layers);
+int rlppo_net_pack_bf16(void *stream, const int32_t *dims, int32_t n_layers, const float *flat, float *packed_r, void *wb16);
 
 /* ------------------------------------------------------------------------------------------ diagnostics */
 /* A/B switches for measurements and tests (also RLPPO_TUNE="key=value,..." in the Python host).  Defaults in brackets.
@@ -291,6 +310,12 @@ int rlppo_dbg_gemm_nt(void *stream, const float *A, int64_t lda, const float *B,
 size_t rlppo_dbg_gemm_nt_bits_bytes(int64_t M, int32_t N);
 int rlppo_dbg_gemm_nt_bits(void *stream, const float *A, int64_t lda, const float *B, int64_t ldb, const float *bias, float *C,
                            int64_t ldc, int64_t M, int32_t N, int32_t K, int32_t epilogue, void *bits);
+/* The forward product of the bf16 update precision: A[M][K] and W[N][K] bf16 in memory, fp32 accumulate.  hidden != 0:
+ * C (fp32, may be NULL) and Cb (bf16, may be NULL) receive relu(A.W^T + bias) rounded to bf16, bits (may be NULL) the ReLU
+ * bitmask; N % 128 == 0.  hidden == 0: C = A.W^T + bias (epilogue 0) or tanh of it (epilogue 2), fp32.  K % 64 == 0. */
+int rlppo_dbg_gemm_nt_b16(void *stream, const void *A, int64_t lda, const void *W, int64_t ldw, const float *bias, float *C,
+                          int64_t ldc, void *Cb, int64_t ldcb, int64_t M, int32_t N, int32_t K, int32_t epilogue, int32_t hidden,
+                          void *bits);
 /* dW[out][in] += dY^T . X, db[out] += colsum(dY) through partial tiles in `ws` (rlppo_dbg_gemm_tn_workspace_bytes) and a
  * fixed-order reduction: the form rlppo_ppo_minibatch uses. */
 size_t rlppo_dbg_gemm_tn_workspace_bytes(int32_t out, int32_t in, int64_t M);

@@ -65,7 +65,28 @@ def as_obs(obs):
     return obs
 
 
+_BF16_OPERANDS = [False]
+
+
+class bf16_operands:
+    """Context manager: inside it every forward product of mlp() rounds both operands to bf16 (the build's optional bf16
+    update / rollout precision, BASELINE configs[4]); autograd through it is the fp32 backward of that forward: dX multiplies
+    dY with the rounded weights, dW with the rounded inputs, nothing in the backward pass is rounded (_RoundBF16)."""
+
+    def __init__(self, on=True):
+        self.on = on
+
+    def __enter__(self):
+        self.prev = _BF16_OPERANDS[0]
+        _BF16_OPERANDS[0] = self.on
+
+    def __exit__(self, *exc):
+        _BF16_OPERANDS[0] = self.prev
+
+
 def mlp(params, x, out_act=None):
+    if _BF16_OPERANDS[0]:
+        return mlp_bf16_operands(params, x, out_act)
     h = as_obs(x)
     for i, (w, b) in enumerate(params):
         h = torch.nn.functional.linear(h, w, b)
@@ -76,6 +97,50 @@ def mlp(params, x, out_act=None):
     return h
 
 
+class _RoundBF16(torch.autograd.Function):
+    """x -> the nearest bf16 value (round-to-nearest-even), as fp32, with an IDENTITY backward.  (Plain `.bfloat16().float()`
+    would also round the GRADIENT to bf16 on the way back -- autograd's cast backward is a cast -- and the mode keeps the
+    backward pass in fp32.)"""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.bfloat16().float()
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
+
+
+class _LinearSum64(torch.autograd.Function):
+    """F.linear whose three products are summed in float64 and rounded ONCE to fp32: the same fp32 function evaluated with a
+    different (equally valid) summation.  Used to measure how much of a bf16-forward result is decided by fp32 summation order
+    alone (an activation within that noise of a bf16 rounding boundary rounds the other way, and the flip cascades through
+    the layers): the floor below which no two implementations of the mode can agree (tests/test_gpu_cfg5.py)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        ctx.save_for_backward(x, w)
+        return (x.double() @ w.double().T + b.double()).float()
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        return (g.double() @ w.double()).float(), (g.double().T @ x.double()).float(), g.double().sum(0).float()
+
+
+_SUM64 = [False]
+
+
+class sum64:
+    """Context manager: mlp_bf16_operands sums its products in float64 (see _LinearSum64)."""
+
+    def __enter__(self):
+        _SUM64[0] = True
+
+    def __exit__(self, *exc):
+        _SUM64[0] = False
+
+
 def mlp_bf16_operands(params, x, out_act=None):
     """The build's optional rollout precision (BASELINE configs[4] "bf16 fwd / fp32 master weights"; the reference has no
     such mode): activations and weights rounded to bf16 (round-to-nearest-even) as they enter each product, fp32
@@ -83,7 +148,8 @@ def mlp_bf16_operands(params, x, out_act=None):
     separates this restatement from the MFMA kernel."""
     h = as_obs(x)
     for i, (w, b) in enumerate(params):
-        h = torch.nn.functional.linear(h.bfloat16().float(), w.bfloat16().float(), b)
+        lin = _LinearSum64.apply if _SUM64[0] else torch.nn.functional.linear
+        h = lin(_RoundBF16.apply(h), _RoundBF16.apply(w), b)
         if i < len(params) - 1:
             h = torch.relu(h)
     if out_act == "tanh":

@@ -41,7 +41,8 @@ class MinibatchArgs(ctypes.Structure):
     _fields_ = [
         ("head", c_int32), ("pol_layers", c_int32), ("val_layers", c_int32), ("act_dim", c_int32), ("slot", c_int32),
         ("pol_dims", POINTER(c_int32)), ("val_dims", POINTER(c_int32)),
-        ("pol_packed", c_void_p), ("val_packed", c_void_p), ("pol_grad", c_void_p), ("val_grad", c_void_p),
+        ("pol_packed", c_void_p), ("val_packed", c_void_p),
+        ("pol_packed_r", c_void_p), ("val_packed_r", c_void_p), ("pol_wb16", c_void_p), ("val_wb16", c_void_p), ("pol_grad", c_void_p), ("val_grad", c_void_p),
         ("states", c_void_p), ("ld_states", c_int64), ("actions", c_void_p), ("old_logp", c_void_p),
         ("targets", c_void_p), ("advantages", c_void_p), ("idx", c_void_p), ("mb", c_int64),
         ("ring_base", c_int64), ("ring_cap", c_int64),
@@ -96,6 +97,10 @@ SIGNATURES = {
     "rlppo_welford_increment": (c_int32, [c_void_p, c_void_p, c_int64, c_int64, c_int32, c_void_p, c_void_p, c_int64, c_int32]),
     "rlppo_welford_merge": (c_int32, [c_void_p, c_int32, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int32]),
     "rlppo_set_inference_precision": (c_int32, [c_int32]),
+    "rlppo_set_update_precision": (c_int32, [c_int32]),
+    "rlppo_get_update_precision": (c_int32, []),
+    "rlppo_wb16_elems": (c_int64, [_P32, c_int32]),
+    "rlppo_net_pack_bf16": (c_int32, [c_void_p, _P32, c_int32, c_void_p, c_void_p, c_void_p]),
     "rlppo_dbg_set": (c_int32, [c_int32, c_int32]),
     "rlppo_selection_epoch": (c_int64, []),
     "rlppo_dbg_gemm_nt": (c_int32, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_int64,
@@ -103,6 +108,8 @@ SIGNATURES = {
     "rlppo_dbg_gemm_nt_bits_bytes": (c_size_t, [c_int64, c_int32]),
     "rlppo_dbg_gemm_nt_bits": (c_int32, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int64,
                                          c_int32, c_int32, c_int32, c_void_p]),
+    "rlppo_dbg_gemm_nt_b16": (c_int32, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_int64,
+                                        c_int64, c_int32, c_int32, c_int32, c_int32, c_void_p]),
     "rlppo_dbg_gemm_tn_workspace_bytes": (c_size_t, [c_int32, c_int32, c_int64]),
     "rlppo_dbg_gemm_tn": (c_int32, [c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_int64, c_int32, c_void_p, c_void_p,
                                     c_int32, c_int32, c_int64, c_void_p, c_size_t]),

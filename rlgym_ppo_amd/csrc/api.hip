@@ -98,6 +98,55 @@ static int forward(hipStream_t st, const NetLayout &net, const float *packed, co
     return 0;
 }
 
+// Forward pass of the bf16 UPDATE precision (rlppo_set_update_precision(1)): every product multiplies bf16-rounded operands
+// and accumulates in fp32.  x / xb: the layer input as rounded fp32 and as bf16 (same values); acts[l] receives the hidden
+// output ROUNDED (fp32), actsb[l] its bf16 copy, bits[l] the ReLU bitmask; the output layer is stored unrounded in fp32.
+// Layers whose shape gemm_nt_b16_kernel does not cover run the fp32 kernels on the rounded copies (identical products) and
+// are rounded by a separate pass.
+static int forward_b16(hipStream_t st, const NetLayout &net, const float *packed_r, const unsigned short *wb16, const float *x,
+                       const unsigned short *xb, int64_t ldx, int64_t n, int out_tanh, float *const *acts,
+                       unsigned short *const *actsb, unsigned long long *const *bits, bool *have_bits) {
+    for (int l = 0; l < net.n_layers; ++l) have_bits[l] = false;
+    int64_t off16 = 0;
+    for (int l = 0; l < net.n_layers; ++l) {
+        const LayerLayout &L = net.L[l];
+        const bool last = l == net.n_layers - 1;
+        int rc;
+        if (last) {
+            const int epi = out_tanh ? EPI_BIAS_TANH : EPI_BIAS;
+            if (!out_tanh && gemv_head_ok(L.out, L.pin))
+                rc = launch_gemv_fwd(st, x, ldx, packed_r + L.off_w, packed_r + L.off_b, acts[l], L.pout, n, L.pin, L.pout);
+            else if (nt_b16_ok(L.pout, L.pin, false))
+                rc = launch_gemm_nt_b16(st, xb, ldx, wb16 + off16, L.pin, packed_r + L.off_b, acts[l], L.pout, nullptr, 0, n, L.pout,
+                                        L.pin, epi, false, nullptr);
+            else
+                rc = launch_gemm_nt(st, x, ldx, packed_r + L.off_w, L.pin, packed_r + L.off_b, nullptr, 0, acts[l], L.pout, n, L.pout,
+                                    L.pin, epi);
+        } else if (nt_b16_ok(L.pout, L.pin, true)) {
+            rc = launch_gemm_nt_b16(st, xb, ldx, wb16 + off16, L.pin, packed_r + L.off_b, acts[l], L.pout, actsb[l], L.pout, n, L.pout,
+                                    L.pin, EPI_BIAS_RELU, true, bits[l]);
+            have_bits[l] = rc == 0 && bits[l] != nullptr;
+        } else {
+            rc = -1;
+            if (bits[l]) {
+                rc = launch_gemm_nt_bits(st, x, ldx, packed_r + L.off_w, L.pin, packed_r + L.off_b, acts[l], L.pout, n, L.pout, L.pin,
+                                         EPI_BIAS_RELU, bits[l]);
+                have_bits[l] = rc == 0;
+            }
+            if (rc == -1)
+                rc = launch_gemm_nt(st, x, ldx, packed_r + L.off_w, L.pin, packed_r + L.off_b, nullptr, 0, acts[l], L.pout, n, L.pout,
+                                    L.pin, EPI_BIAS_RELU);
+            if (rc == 0) rc = launch_round_rows(st, acts[l], actsb[l], n * (int64_t)L.pout);
+        }
+        if (rc) return rc;
+        off16 += (int64_t)L.pout * L.pin;
+        x = acts[l];
+        xb = actsb[l];
+        ldx = L.pout;
+    }
+    return 0;
+}
+
 static size_t forward_ws_floats(const NetLayout &net, int64_t n) { return (size_t)2 * (size_t)n * (size_t)max_pout(net); }
 
 // runs the net with ping-pong buffers from the workspace and returns the pointer/ld of the last layer's output
@@ -258,6 +307,7 @@ int rlppo_gae(void *stream, const float *rews, const float *dones, const float *
 
 // ------------------------------------------------------------------------------------------- PPO minibatch
 static int g_two_streams = 1;  // tuning: rlppo_dbg_set(4, 0/1)
+static int g_update_bf16 = 0;   // rlppo_set_update_precision
 // Library-owned streams: slot s > 0 runs its policy chain on g_main[s]; every slot runs its critic chain on g_side[s].
 static hipStream_t g_main[RLPPO_MAX_SLOTS] = {}, g_side[RLPPO_MAX_SLOTS] = {};
 static hipEvent_t g_ev_fork[RLPPO_MAX_SLOTS] = {}, g_ev_join[RLPPO_MAX_SLOTS] = {}, g_ev_slot[RLPPO_MAX_SLOTS] = {};
@@ -304,7 +354,14 @@ static size_t train_ws_floats(const NetLayout &pol, const NetLayout &val, int64_
     size_t bits = 0;                                                         // ReLU bitmasks of the hidden layers (1/32 of h)
     for (int l = 0; l + 1 < pol.n_layers; ++l) bits += nt_bits_floats(mb, pol.L[l].pout);
     for (int l = 0; l + 1 < val.n_layers; ++l) bits += nt_bits_floats(mb, val.L[l].pout);
-    return per_row * (size_t)mb + tn_ws_floats(pol, mb) + tn_ws_floats(val, mb) + bits + 2;  // + one partial-tile buffer per chain
+    size_t b16 = 0;  // bf16 update precision: bf16 copies of the gathered states and of every hidden activation (2 B/element)
+    if (g_update_bf16) {
+        size_t el = pol.L[0].pin;
+        for (int l = 0; l + 1 < pol.n_layers; ++l) el += pol.L[l].pout;
+        for (int l = 0; l + 1 < val.n_layers; ++l) el += val.L[l].pout;
+        b16 = (el * (size_t)mb + 1) / 2 + 4;
+    }
+    return per_row * (size_t)mb + tn_ws_floats(pol, mb) + tn_ws_floats(val, mb) + bits + b16 + 2;  // + one partial-tile buffer per chain
 }
 
 size_t rlppo_minibatch_workspace_bytes(const int32_t *pol_dims, int32_t pol_layers, const int32_t *val_dims,
@@ -439,8 +496,30 @@ int rlppo_ppo_minibatch(void *stream, const rlppo_minibatch_args *a) {
     float *const states = w;
     const int64_t ld_states = pol.L[0].pin;
     w += (size_t)mb * pol.L[0].pin;
-    rc = launch_gather_rows(st, a->states, a->ld_states, a->idx, states, pol.L[0].pin, mb, ring_base, ring_cap);
+    // bf16 update precision: bf16 copies of the gathered rows and of the hidden activations, and the rounded weight images
+    const bool b16 = g_update_bf16 != 0;
+    unsigned short *states_b = nullptr, *pactb[RLPPO_MAX_LAYERS] = {}, *vactb[RLPPO_MAX_LAYERS] = {};
+    if (b16) {
+        RLPPO_CHECK_ARG(a->pol_packed_r && a->val_packed_r && a->pol_wb16 && a->val_wb16,
+                        "ppo_minibatch: the bf16 update precision needs the rlppo_net_pack_bf16 images of both networks");
+        if ((reinterpret_cast<uintptr_t>(w) & 15) != 0) w += 4 - ((reinterpret_cast<uintptr_t>(w) >> 2) & 3);
+        unsigned short *hb = reinterpret_cast<unsigned short *>(w);
+        states_b = hb;
+        hb += (size_t)mb * pol.L[0].pin;
+        for (int l = 0; l + 1 < pol.n_layers; ++l) {
+            pactb[l] = hb;
+            hb += (size_t)mb * pol.L[l].pout;
+        }
+        for (int l = 0; l + 1 < val.n_layers; ++l) {
+            vactb[l] = hb;
+            hb += (size_t)mb * val.L[l].pout;
+        }
+        rc = launch_gather_rows_round(st, a->states, a->ld_states, a->idx, states, states_b, pol.L[0].pin, mb, ring_base, ring_cap);
+    } else {
+        rc = launch_gather_rows(st, a->states, a->ld_states, a->idx, states, pol.L[0].pin, mb, ring_base, ring_cap);
+    }
     if (rc) return rc;
+    const float *pol_w = b16 ? a->pol_packed_r : a->pol_packed, *val_w = b16 ? a->val_packed_r : a->val_packed;
     // forward of both nets
     // The two networks are independent until the loss epilogue and again after it, so their launch chains run on
     // two streams (the caller's + one library-owned side stream, forked/joined with events: capturable).  Each
@@ -452,9 +531,17 @@ int rlppo_ppo_minibatch(void *stream, const rlppo_minibatch_args *a) {
         rc = order_after(side, st, g_ev_fork[slot]);
         if (rc) return rc;
     }
-    rc = forward(side, val, a->val_packed, states, ld_states, mb, 0, vact, 0, vbits, vhave);
-    if (rc) return rc;
-    rc = forward(st, pol, a->pol_packed, states, ld_states, mb, a->head == RLPPO_HEAD_GAUSSIAN, pact, 0, pbits, phave);
+    if (b16) {
+        rc = forward_b16(side, val, val_w, reinterpret_cast<const unsigned short *>(a->val_wb16), states, states_b, ld_states, mb, 0,
+                         vact, vactb, vbits, vhave);
+        if (rc) return rc;
+        rc = forward_b16(st, pol, pol_w, reinterpret_cast<const unsigned short *>(a->pol_wb16), states, states_b, ld_states, mb,
+                         a->head == RLPPO_HEAD_GAUSSIAN, pact, pactb, pbits, phave);
+    } else {
+        rc = forward(side, val, val_w, states, ld_states, mb, 0, vact, 0, vbits, vhave);
+        if (rc) return rc;
+        rc = forward(st, pol, pol_w, states, ld_states, mb, a->head == RLPPO_HEAD_GAUSSIAN, pact, 0, pbits, phave);
+    }
     if (rc) return rc;
     // loss epilogue: outputs -> output gradients in place, report statistics accumulated on device.  The value loss only
     // needs the critic's output and the policy loss only the policy's, so each chain runs its own loss kernel and the chains
@@ -490,9 +577,11 @@ int rlppo_ppo_minibatch(void *stream, const rlppo_minibatch_args *a) {
     }
     if (rc) return rc;
 
-    rc = backward(side, val, a->val_packed, states, ld_states, mb, vact, vdx, a->val_grad, val_tn_ws, tn_ws_floats(val, mb), vbits, vhave);
+    // (bf16 precision: the backward is the fp32 backward of the rounded-operand forward -- dX against the rounded weights, dW
+    // against the rounded inputs the forward saved -- which is what autograd computes for that forward)
+    rc = backward(side, val, val_w, states, ld_states, mb, vact, vdx, a->val_grad, val_tn_ws, tn_ws_floats(val, mb), vbits, vhave);
     if (rc) return rc;
-    rc = backward(st, pol, a->pol_packed, states, ld_states, mb, pact, pdx, a->pol_grad, pol_tn_ws, tn_ws_floats(pol, mb), pbits, phave);
+    rc = backward(st, pol, pol_w, states, ld_states, mb, pact, pdx, a->pol_grad, pol_tn_ws, tn_ws_floats(pol, mb), pbits, phave);
     if (rc) return rc;
     if (side != st) rc = order_after(st, side, g_ev_join[slot]);
     return rc;
@@ -571,7 +660,28 @@ int rlppo_welford_merge(void *stream, int32_t d, void *mean, void *m2, int64_t c
     return launch_welford_merge((hipStream_t)stream, d, mean, m2, (long long)count, other_mean, other_m2, (long long)other_count,
                                 state_is_f64 != 0);
 }
+int64_t rlppo_wb16_elems(const int32_t *dims, int32_t n_layers) {
+    NetLayout net;
+    if (make_layout(dims, n_layers, &net)) return -1;
+    int64_t n = 0;
+    for (int l = 0; l < net.n_layers; ++l) n += (int64_t)net.L[l].pout * net.L[l].pin;
+    return n;
+}
+int rlppo_net_pack_bf16(void *stream, const int32_t *dims, int32_t n_layers, const float *flat, float *packed_r, void *wb16) {
+    NetLayout net;
+    int rc = make_layout(dims, n_layers, &net);
+    if (rc) return rc;
+    RLPPO_CHECK_ARG(flat && packed_r && wb16, "net_pack_bf16: null pointer");
+    return launch_pack_bf16((hipStream_t)stream, net, flat, packed_r, reinterpret_cast<unsigned short *>(wb16));
+}
 static int64_t g_selection_epoch = 0;  // bumped by every call that changes which kernels later launches select
+int rlppo_set_update_precision(int32_t mode) {
+    RLPPO_CHECK_ARG(mode == 0 || mode == 1, "set_update_precision: mode %d (0 = fp32, 1 = bf16-operand forward)", mode);
+    g_update_bf16 = mode;
+    ++g_selection_epoch;
+    return 0;
+}
+int rlppo_get_update_precision(void) { return g_update_bf16; }
 int rlppo_set_inference_precision(int32_t mode) {
     RLPPO_CHECK_ARG(mode == 0 || mode == 1, "set_inference_precision: mode %d (0 = fp32, 1 = bf16 operands)", mode);
     set_infer_bf16(mode);
@@ -605,6 +715,13 @@ int rlppo_dbg_gemm_nt(void *stream, const float *A, int64_t lda, const float *B,
                       const float *mask_src, int64_t ld_mask, float *C, int64_t ldc, int64_t M, int32_t N, int32_t K,
                       int32_t epilogue) {
     return launch_gemm_nt((hipStream_t)stream, A, lda, B, ldb, bias, mask_src, ld_mask, C, ldc, M, N, K, epilogue);
+}
+int rlppo_dbg_gemm_nt_b16(void *stream, const void *A, int64_t lda, const void *W, int64_t ldw, const float *bias, float *C,
+                          int64_t ldc, void *Cb, int64_t ldcb, int64_t M, int32_t N, int32_t K, int32_t epilogue, int32_t hidden,
+                          void *bits) {
+    return launch_gemm_nt_b16((hipStream_t)stream, reinterpret_cast<const unsigned short *>(A), lda,
+                              reinterpret_cast<const unsigned short *>(W), ldw, bias, C, ldc, reinterpret_cast<unsigned short *>(Cb),
+                              ldcb, M, N, K, epilogue, hidden != 0, reinterpret_cast<unsigned long long *>(bits));
 }
 size_t rlppo_dbg_gemm_tn_workspace_bytes(int32_t out, int32_t in, int64_t M) { return tn_partial_floats(out, in, M) * sizeof(float); }
 int rlppo_dbg_gemm_tn(void *stream, const float *dY, int64_t ldy, int32_t ny_valid, const float *X, int64_t ldx,

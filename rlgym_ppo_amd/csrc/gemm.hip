@@ -440,6 +440,193 @@ int launch_gemm_nt_bf16(hipStream_t st, const float *A, int64_t lda, const float
     }
 }
 
+// ------------------------------------------------------------------------------------------------ gemm_nt, bf16 in memory
+// Forward product of the bf16 UPDATE precision (rlppo_set_update_precision(1); BASELINE configs[4] "bf16 fwd / fp32 master
+// weights"): both operands are bf16 IN MEMORY -- the activations as the previous layer's epilogue (or the minibatch gather)
+// left them, the weights as rlppo_net_pack_bf16 rounded the fp32 master copy after the optimiser step -- so a tile row of
+// 64 k-values is the same 128 bytes as 32 fp32 values: staging, LDS image and swizzle are those of gemm_nt_dma_kernel<.., 32>,
+// the K loop runs half as many tiles, a ds_read_b128 fragment feeds ONE v_mfma_f32_16x16x32_bf16 (no conversion in the loop),
+// accumulation, bias and activation stay fp32.
+// HIDDEN layers: h = relu(acc) is rounded to bf16 once (v_cvt_pk_bf16_f32, round-to-nearest-even) and written three ways:
+// as bf16 (the next layer's A operand, 2 B/element), as the same value in fp32 (the X operand of the fp32 weight-gradient
+// product: autograd of a forward with bf16-rounded operands multiplies dY with the ROUNDED input), and as the ReLU bitmask
+// of the dX product.  The output layer stores plain fp32 (bias or bias + tanh) for the loss kernel.
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+template <int NB, int EPI, bool HIDDEN>
+__global__ __launch_bounds__(256, 2) void gemm_nt_b16_kernel(const unsigned short *__restrict__ A, unsigned lda_b,
+                                                             const unsigned short *__restrict__ B, unsigned ldb_b,
+                                                             const float *__restrict__ bias, float *__restrict__ C,
+                                                             unsigned ldc_b, unsigned short *__restrict__ Cb, unsigned ldcb_b,
+                                                             int64_t M, int K, unsigned long long *__restrict__ bits) {
+    constexpr int BN = NB * 16;
+    constexpr int BKT = 32;          // tile row = 128 bytes = 64 bf16 (the fp32 kernel's 32 floats)
+    constexpr int CPR = BKT / 4, RPW = 64 / CPR, RPP = 4 * RPW;
+    constexpr int A_IT = SBM / RPP, B_IT = BN / RPP;
+    static_assert(BN % RPP == 0, "column tile must be a whole number of staging passes");
+    static_assert(!HIDDEN || EPI == EPI_BIAS_RELU, "hidden layers are bias + ReLU");
+    __shared__ __attribute__((aligned(16))) float lds[2 * SBM * BKT + 2 * BN * BKT];
+    float *As = lds;
+    float *Bs = lds + 2 * SBM * BKT;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const int r16 = lane & 15, q = lane >> 4;
+    int row_tile, col_tile;
+    xcd_tile(row_tile, col_tile);
+    const int64_t m0 = (int64_t)row_tile * SBM;
+    const int n0 = col_tile * BN;
+    const int rows_here = (int)((M - m0) < SBM ? (M - m0) : SBM);
+
+    const __amdgpu_buffer_rsrc_t a_rs = make_rsrc(reinterpret_cast<const char *>(A) + m0 * lda_b,
+                                                  (unsigned)(rows_here - 1) * lda_b + (unsigned)K * 2);
+    const __amdgpu_buffer_rsrc_t b_rs = make_rsrc(reinterpret_cast<const char *>(B) + (int64_t)n0 * ldb_b,
+                                                  (unsigned)(BN - 1) * ldb_b + (unsigned)K * 2);
+    const int row_p = wave * RPW + lane / CPR, pch = lane % CPR;
+    const int lch = pch ^ (row_p & 7);
+    const unsigned a_off = (unsigned)row_p * lda_b + lch * 16;
+    const unsigned b_off = (unsigned)row_p * ldb_b + lch * 16;
+    const unsigned a_step = (unsigned)RPP * lda_b, b_step = (unsigned)RPP * ldb_b;
+
+    f32x4 acc[2][NB];
+    {
+        const __amdgpu_buffer_rsrc_t bias_rs = make_rsrc(bias + n0, BN * 4);
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            acc[0][j] = ldb(bias_rs, (unsigned)(q * 16), j * 64);
+            acc[1][j] = acc[0][j];
+        }
+    }
+    auto issue_tile = [&](int buf, unsigned kb) {
+        float *Ad = As + buf * SBM * BKT + wave_u * RPW * BKT;
+        float *Bd = Bs + buf * BN * BKT + wave_u * RPW * BKT;
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rs, Ad + i * RPP * BKT, 16, a_off, kb + i * a_step, 0, 0);
+#pragma unroll
+        for (int i = 0; i < B_IT; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(b_rs, Bd + i * RPP * BKT, 16, b_off, kb + i * b_step, 0, 0);
+    };
+
+    const int nk = K / 64;
+    issue_tile(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if ((kt + 1) < nk) issue_tile(cur ^ 1, (unsigned)(kt + 1) * 128u);
+        const float *Ac = As + cur * SBM * BKT + (wave * 32) * BKT;
+        const float *Bc = Bs + cur * BN * BKT;
+#pragma unroll
+        for (int kc = 0; kc < 2; ++kc) {  // 32 k-values per MFMA: chunk kc * 4 + q holds k = 32 kc + 8 q .. + 7 of the row
+            bf16x8 fa[2], fb[NB];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                fa[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4 *>(&Ac[dswz<32>(i * 16 + r16, kc * 4 + q)]));
+#pragma unroll
+            for (int j = 0; j < NB; ++j)
+                fb[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4 *>(&Bc[dswz<32>(j * 16 + r16, kc * 4 + q)]));
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < NB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    if (!HIDDEN) {
+        nt_epilogue<NB, EPI>(acc, nullptr, 0, C, ldc_b, m0, n0, rows_here, wave, r16, q);
+        return;
+    }
+    // relu, bitmask, one rounding to bf16; the stores come last, from registers nothing writes again (section 5 hazard rule)
+    u32x2 pk[2][NB];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[i][j][e] = relu1(acc[i][j][e]);
+    const unsigned long long word = relu_bits<NB>(acc);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            unsigned short h[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float x = acc[i][j][e];
+                h[e] = __builtin_bit_cast(unsigned short, (__bf16)x);
+                acc[i][j][e] = __uint_as_float((unsigned)h[e] << 16);  // the rounded value, exactly, as fp32
+            }
+            pk[i][j] = u32x2{(unsigned)h[0] | ((unsigned)h[1] << 16), (unsigned)h[2] | ((unsigned)h[3] << 16)};
+        }
+    if (bits) bits[((size_t)row_tile * gridDim.y + col_tile) * 256 + tid] = word;
+    __builtin_amdgcn_sched_barrier(0);
+    const int row_l = wave * 32 + r16;
+    if (Cb) {
+        const __amdgpu_buffer_rsrc_t cb_rs = make_rsrc(reinterpret_cast<char *>(Cb) + m0 * ldcb_b + (int64_t)n0 * 2,
+                                                       (unsigned)(rows_here - 1) * ldcb_b + BN * 2);
+        const unsigned cb_off = (unsigned)row_l * ldcb_b + q * 8;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < NB; ++j) __builtin_amdgcn_raw_buffer_store_b64(pk[i][j], cb_rs, cb_off, 16 * i * ldcb_b + j * 32, 0);
+    }
+    if (C) {
+        const __amdgpu_buffer_rsrc_t c_rs = make_rsrc(reinterpret_cast<char *>(C) + m0 * ldc_b + (int64_t)n0 * 4,
+                                                      (unsigned)(rows_here - 1) * ldc_b + BN * 4);
+        const unsigned c_off = (unsigned)row_l * ldc_b + q * 16;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < NB; ++j) stb(c_rs, c_off, 16 * i * ldc_b + j * 64, acc[i][j]);
+    }
+}
+
+// Applicability of the bf16-in-memory forward: K a multiple of 64 (one LDS tile row = 64 k-values), hidden widths a multiple
+// of 128 (the bitmask tile geometry).  Everything else takes the fp32 kernels on the ROUNDED fp32 copies -- the same products
+// (a product of two bf16 values is exact in fp32), only slower -- followed by round_rows (optim.hip).
+bool nt_b16_ok(int N, int K, bool hidden) {
+    if (K % 64 != 0) return false;
+    return hidden ? N % 128 == 0 : (N % 128 == 0 || N == 96 || N == 64 || N == 32);
+}
+
+int launch_gemm_nt_b16(hipStream_t st, const unsigned short *A, int64_t lda, const unsigned short *B, int64_t ldb, const float *bias,
+                       float *C, int64_t ldc, unsigned short *Cb, int64_t ldcb, int64_t M, int N, int K, int epi, bool hidden,
+                       unsigned long long *bits) {
+    if (M <= 0) return 0;
+    RLPPO_CHECK_ARG(nt_b16_ok(N, K, hidden) && A && B && bias, "gemm_nt (bf16 in memory): N=%d K=%d not supported", N, K);
+    RLPPO_CHECK_ARG(lda % 8 == 0 && ldb % 8 == 0 && lda >= K && ldb >= K && (!C || (ldc % 4 == 0 && ldc >= N)) &&
+                        (!Cb || (ldcb % 4 == 0 && ldcb >= N)) && (C || Cb),
+                    "gemm_nt (bf16 in memory): leading dimensions lda=%ld ldb=%ld ldc=%ld ldcb=%ld", (long)lda, (long)ldb, (long)ldc,
+                    (long)ldcb);
+    const int64_t lim = (int64_t)1 << 31;
+    RLPPO_CHECK_ARG(129 * lda * 2 < lim && 129 * ldb * 2 < lim && 129 * ldc * 4 < lim && 129 * ldcb * 2 < lim,
+                    "gemm_nt (bf16 in memory): a leading dimension is too wide for 32-bit tile offsets");
+    const unsigned la = (unsigned)(lda * 2), lb = (unsigned)(ldb * 2), lc = (unsigned)(ldc * 4), lcb = (unsigned)(ldcb * 2);
+    const int nb = N % 128 == 0 ? 8 : N / 16;
+    dim3 grid((unsigned)cdiv(M, SBM), (unsigned)(N / (nb * 16)));
+#define B16(NBV, E, H)                                                                                                      \
+    hipLaunchKernelGGL((gemm_nt_b16_kernel<NBV, E, H>), grid, dim3(256), 0, st, A, la, B, lb, bias, C, lc, Cb, lcb, M, K, bits)
+    if (hidden) {
+        RLPPO_CHECK_ARG(epi == EPI_BIAS_RELU, "gemm_nt (bf16 in memory): hidden layers are bias + ReLU");
+        B16(8, EPI_BIAS_RELU, true);
+    } else {
+        RLPPO_CHECK_ARG((epi == EPI_BIAS || epi == EPI_BIAS_TANH) && C, "gemm_nt (bf16 in memory): output layer epilogue %d", epi);
+        const bool th = epi == EPI_BIAS_TANH;
+        switch (nb) {
+            case 8: if (th) B16(8, EPI_BIAS_TANH, false); else B16(8, EPI_BIAS, false); break;
+            case 6: if (th) B16(6, EPI_BIAS_TANH, false); else B16(6, EPI_BIAS, false); break;
+            case 4: if (th) B16(4, EPI_BIAS_TANH, false); else B16(4, EPI_BIAS, false); break;
+            default: if (th) B16(2, EPI_BIAS_TANH, false); else B16(2, EPI_BIAS, false); break;
+        }
+    }
+#undef B16
+    RLPPO_LAUNCH_CHECK();
+    return 0;
+}
+
 // floats of workspace one hidden layer's ReLU bitmask needs (8 bytes per lane and 128 x 128 tile); 0 = width not supported
 size_t nt_bits_floats(int64_t M, int N) {
     if (N % 128 != 0 || M <= 0) return 0;

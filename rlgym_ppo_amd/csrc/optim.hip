@@ -47,6 +47,74 @@ int launch_pack(hipStream_t st, const NetLayout &net, const float *flat, float *
     return 0;
 }
 
+// bf16 update precision: the fp32 master copy rounded to bf16 (round-to-nearest-even), once per optimiser step:
+//   packed_r -- the packed image (W | W^T | b per layer) holding the ROUNDED weights as fp32 (the fp32 dX product and the
+//               critic's matrix-vector head then multiply exactly what the bf16 forward multiplied); biases stay fp32;
+//   wb16     -- the W[Pout][Pin] blocks alone as bf16, layer after layer (the B operand of gemm_nt_b16_kernel).
+__device__ __forceinline__ unsigned short bf16_bits(float x) { return __builtin_bit_cast(unsigned short, (__bf16)x); }
+__global__ __launch_bounds__(256) void pack_bf16_kernel(const float *__restrict__ flat, float *__restrict__ packed_r,
+                                                        unsigned short *__restrict__ wb16, PackJobs jobs) {
+    for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < jobs.total; g += (int64_t)gridDim.x * blockDim.x) {
+        int l = 0;
+        while (l + 1 < jobs.n && g >= jobs.j[l + 1].first) ++l;
+        const PackJob &J = jobs.j[l];
+        const int64_t e = g - J.first;
+        const int o = (int)(e / J.pin), i = (int)(e % J.pin);
+        const float w = (o < J.out && i < J.in) ? flat[J.off_flat_w + (int64_t)o * J.in + i] : 0.f;
+        const unsigned short h = bf16_bits(w);
+        const float wr = __uint_as_float((unsigned)h << 16);
+        packed_r[J.off_w + (int64_t)o * J.pin + i] = wr;
+        packed_r[J.off_wt + (int64_t)i * J.pout + o] = wr;
+        wb16[J.first + e] = h;  // J.first = sum of the previous layers' Pout * Pin
+        if (i == 0) packed_r[J.off_b + o] = o < J.out ? flat[J.off_flat_b + o] : 0.f;
+    }
+}
+
+int launch_pack_bf16(hipStream_t st, const NetLayout &net, const float *flat, float *packed_r, unsigned short *wb16) {
+    PackJobs jobs;
+    jobs.n = net.n_layers;
+    int64_t tot = 0;
+    for (int l = 0; l < net.n_layers; ++l) {
+        const LayerLayout &L = net.L[l];
+        jobs.j[l] = PackJob{L.in, L.out, L.pin, L.pout, L.off_w, L.off_wt, L.off_b, L.off_flat_w, L.off_flat_b, tot};
+        tot += (int64_t)L.pin * L.pout;
+    }
+    jobs.total = tot;
+    const int blocks = (int)(cdiv(tot, 256) < 2048 ? cdiv(tot, 256) : 2048);
+    hipLaunchKernelGGL(pack_bf16_kernel, dim3(blocks), dim3(256), 0, st, flat, packed_r, wb16, jobs);
+    RLPPO_LAUNCH_CHECK();
+    return 0;
+}
+
+// x[r][0..width) -> rounded to bf16 in place (as fp32) + the bf16 copy xb[r][0..width): the hand-over of a layer that took the
+// fp32 kernels in the bf16 update precision (shapes gemm_nt_b16_kernel does not cover).  4 elements per thread.
+__global__ __launch_bounds__(256) void round_rows_kernel(float *__restrict__ x, unsigned short *__restrict__ xb, int64_t n4) {
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
+    for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < n4; g += (int64_t)gridDim.x * blockDim.x) {
+        f32x4 v = reinterpret_cast<f32x4 *>(x)[g];
+        u16x4 h;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float f = v[e];
+            h[e] = bf16_bits(f);
+            v[e] = __uint_as_float((unsigned)h[e] << 16);
+        }
+        reinterpret_cast<f32x4 *>(x)[g] = v;
+        reinterpret_cast<u16x4 *>(xb)[g] = h;
+    }
+}
+
+int launch_round_rows(hipStream_t st, float *x, unsigned short *xb, int64_t n_elems) {
+    if (n_elems <= 0) return 0;
+    RLPPO_CHECK_ARG(n_elems % 4 == 0, "round_rows: element count %ld is not a multiple of 4", (long)n_elems);
+    const int64_t n4 = n_elems / 4;
+    const int blocks = (int)(cdiv(n4, 256) < 8192 ? cdiv(n4, 256) : 8192);
+    hipLaunchKernelGGL(round_rows_kernel, dim3(blocks), dim3(256), 0, st, x, xb, n4);
+    RLPPO_LAUNCH_CHECK();
+    return 0;
+}
+
 // --------------------------------------------------------------------------------------------- pad rows
 template <typename T>
 __global__ __launch_bounds__(256) void pad_rows_kernel(const T *__restrict__ src, int64_t n, int64_t d, int64_t ld_src,
@@ -93,6 +161,42 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const float *__restric
     if (row >= n) return;
     const f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(src + ring_row(idx[row], ring_base, ring_cap) * ld_src) + c);
     reinterpret_cast<f32x4 *>(dst)[t] = v;
+}
+
+// The same gather for the bf16 update precision: the gathered observation rows are rounded to bf16 on the way -- written as
+// fp32 (X operand of the first layer's fp32 weight gradient) and as bf16 (A operand of the first layer's bf16 forward).
+__global__ __launch_bounds__(256) void gather_rows_round_kernel(const float *__restrict__ src, int64_t ld_src,
+                                                                const int64_t *__restrict__ idx, float *__restrict__ dst,
+                                                                unsigned short *__restrict__ dstb, int chunks_per_row, int64_t n,
+                                                                int64_t ring_base, int64_t ring_cap) {
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t row = t / chunks_per_row;
+    const int c = (int)(t - row * chunks_per_row);
+    if (row >= n) return;
+    f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(src + ring_row(idx[row], ring_base, ring_cap) * ld_src) + c);
+    u16x4 h;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float f = v[e];
+        h[e] = bf16_bits(f);
+        v[e] = __uint_as_float((unsigned)h[e] << 16);
+    }
+    reinterpret_cast<f32x4 *>(dst)[t] = v;
+    reinterpret_cast<u16x4 *>(dstb)[t] = h;
+}
+
+int launch_gather_rows_round(hipStream_t st, const float *src, int64_t ld_src, const int64_t *idx, float *dst, unsigned short *dstb,
+                             int width, int64_t n, int64_t ring_base, int64_t ring_cap) {
+    if (n <= 0) return 0;
+    RLPPO_CHECK_ARG(width > 0 && width % 4 == 0 && ld_src >= width && ld_src % 4 == 0, "gather_rows: width=%d ld=%ld", width,
+                    (long)ld_src);
+    const int cpr = width / 4;
+    hipLaunchKernelGGL(gather_rows_round_kernel, dim3((unsigned)cdiv(n * cpr, 256)), dim3(256), 0, st, src, ld_src, idx, dst, dstb,
+                       cpr, n, ring_base, ring_cap);
+    RLPPO_LAUNCH_CHECK();
+    return 0;
 }
 
 int launch_gather_rows(hipStream_t st, const float *src, int64_t ld_src, const int64_t *idx, float *dst, int width,

@@ -70,6 +70,8 @@ class NetArena:
         self.grad = torch.zeros(self.n_flat, dtype=torch.float32, device=device)
         self.packed = torch.zeros(self.n_packed, dtype=torch.float32, device=device)
         self.ws = Workspace(device)
+        self.packed_r = self.wb16 = None  # bf16 update precision: rounded images (rlppo_net_pack_bf16), built on first use
+        self._packed_bf16_key = None
         self._packed_key = None
         self.native_epoch = 0  # bumped whenever a kernel rewrites `flat` behind torch's back (Adam)
         self.bind()
@@ -108,6 +110,21 @@ class NetArena:
         if key != self._packed_key:
             N.check(N.lib().rlppo_net_pack(stream_ptr(), self.dims_c, self.n_layers, ptr(self.flat), ptr(self.packed)))
             self._packed_key = key
+
+    def ensure_packed_bf16(self):
+        """The rounded weight images of the bf16 update precision (packed layout with bf16-rounded values as fp32 + the W
+        blocks as bf16), rebuilt whenever the master weights changed.  Returns (packed_r, wb16)."""
+        if not self.is_bound():
+            self.bind()
+        if self.packed_r is None:
+            self.packed_r = torch.zeros(self.n_packed, dtype=torch.float32, device=self.device)
+            self.wb16 = torch.zeros(int(N.lib().rlppo_wb16_elems(self.dims_c, self.n_layers)), dtype=torch.bfloat16, device=self.device)
+        key = self._pack_key()
+        if key != self._packed_bf16_key:
+            N.check(N.lib().rlppo_net_pack_bf16(stream_ptr(), self.dims_c, self.n_layers, ptr(self.flat), ptr(self.packed_r),
+                                                ptr(self.wb16)))
+            self._packed_bf16_key = key
+        return self.packed_r, self.wb16
 
     def _pack_key(self):
         # bind() re-points every Parameter with `p.data = view`, which gives it a version counter of its own: in-place updates
@@ -374,6 +391,17 @@ def selection_epoch():
     """Counter the library bumps whenever a call changes which kernels later launches select (precision setters, A/B
     switches): captured graphs of library calls are keyed on it (ppo/_mlp.py::ActGraph)."""
     return int(N.lib().rlppo_selection_epoch())
+
+
+def set_update_precision(mode):
+    """Precision of the PPO update (PPOLearner.learn): "fp32" (default: the reference's arithmetic, 1e-5 parity) or "bf16" =
+    BASELINE configs[4] "bf16 fwd / fp32 master weights": forward products on bf16-rounded operands (bf16 MFMA, fp32
+    accumulate), fp32 losses / backward / gradient accumulation / clip / Adam on the fp32 master arena (include/rlppo.h)."""
+    N.check(N.lib().rlppo_set_update_precision({"fp32": 0, "bf16": 1}[mode]))
+
+
+def update_precision():
+    return "bf16" if N.lib().rlppo_get_update_precision() else "fp32"
 
 
 def set_inference_precision(mode):

@@ -185,6 +185,10 @@ class PPOLearner(object):
         a.pol_dims = ctypes.cast(pa.dims_c, ctypes.POINTER(ctypes.c_int32))
         a.val_dims = ctypes.cast(va.dims_c, ctypes.POINTER(ctypes.c_int32))
         a.pol_packed, a.val_packed = pa.packed.data_ptr(), va.packed.data_ptr()
+        self._bf16 = bool(N.lib().rlppo_get_update_precision())  # bf16-operand forward: the rounded weight images travel too
+        if self._bf16:
+            (pr, pw), (vr, vw) = pa.ensure_packed_bf16(), va.ensure_packed_bf16()
+            a.pol_packed_r, a.val_packed_r, a.pol_wb16, a.val_wb16 = pr.data_ptr(), vr.data_ptr(), pw.data_ptr(), vw.data_ptr()
         a.pol_grad, a.val_grad = pa.grad.data_ptr(), va.grad.data_ptr()
         st, a.ring_base, a.ring_cap = exp.ring()  # physical rows; the kernels map the permutation's logical rows onto them
         a.states, a.ld_states = st["states"].data_ptr(), st["states"].shape[1]
@@ -245,6 +249,9 @@ class PPOLearner(object):
                     grads_zero = False
                     pa.ensure_packed()
                     va.ensure_packed()
+                    if self._bf16:  # re-round the master weights the optimiser step just moved (one small launch per net)
+                        pa.ensure_packed_bf16()
+                        va.ensure_packed_bf16()
                     for k, (j, cnt) in enumerate(fuse_runs(slices_for_rank(n_slices, rank, world), self.max_fused_minibatches)):
                         args.slot = k % self.n_slots
                         args.workspace = self._slot_ws[args.slot]

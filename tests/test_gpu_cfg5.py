@@ -32,6 +32,67 @@ def test_cfg5_shape_minibatch_and_sampling(L):
                    label="cfg5 shape (obs 231, 512x4, Gaussian head), 3072 rows")
 
 
+@pytest.mark.parametrize("shape", ["cfg5", "cfg2", "odd"])
+def test_bf16_update_precision_against_its_restatement(L, shape):
+    """BASELINE configs[4] "bf16 fwd / fp32 master weights" inside the UPDATE (rlppo_set_update_precision(1)): every forward
+    product on bf16-rounded operands (bf16 MFMA, fp32 accumulate), fp32 loss / backward / accumulation.  Checked against
+    oracle/ppo.py::minibatch_autograd under oracle/nets.py::bf16_operands -- torch autograd of F.linear(r(h), r(W), b), r =
+    rounding to bf16 with a straight-through gradient, i.e. the fp32 backward of that forward.
+    Two correct evaluations of that function agree up to fp32 summation order EXCEPT where an activation sits within that noise
+    of a bf16 rounding boundary and is rounded the other way (one bf16 ulp = 0.4 %), which shifts the next layer's sums and
+    cascades.  The test MEASURES that floor -- the restatement against itself with its sums taken in float64
+    (oracle/nets.py::sum64): ~2e-4 at 256x3, up to 4e-2 at 512x4 with the ill-conditioned Gaussian head -- and holds the kernels
+    to 3x it.  Also printed: the distance of the mode from float64 truth of the unrounded function (10-15 % of the gradient: a
+    different arithmetic), and the fp32 parity mode is checked to be untouched afterwards.  "odd" = widths the bf16 kernel does
+    not cover (fp32 kernels on the rounded copies + a rounding pass: same products)."""
+    torch.manual_seed(11)
+    rs = np.random.RandomState(11)
+    if shape == "cfg5":
+        d, hid, head, n, mb = 231, (512, 512, 512, 512), "gaussian", 5000, 3072
+    elif shape == "cfg2":
+        d, hid, head, n, mb = 107, (256, 256, 256), "discrete", 5000, 3000
+    else:
+        d, hid, head, n, mb = 50, (96, 128, 40), "discrete", 900, 700
+    n_out = 16 if head == "gaussian" else 90
+    pol, val = nets.init_mlp(d, hid, n_out), nets.init_mlp(d, hid, 1)
+    obs = np.clip(rs.randn(n, d), -5, 5).astype(np.float32)
+    if head == "gaussian":
+        mean, std = nets.gauss_out(pol, obs)
+        act, logp = nets.gauss_sample(mean, std, torch.as_tensor(rs.randn(n, 8).astype(np.float32)))
+    else:
+        act, logp = nets.discrete_sample(nets.discrete_probs(pol, obs), nets.draw_exp_noise(n, n_out))
+        act = act.float()
+    old = (logp + torch.as_tensor(rs.randn(n).astype(np.float32) * 0.1)).numpy()
+    adv, tgt = rs.randn(n).astype(np.float32), rs.randn(n).astype(np.float32)
+    idx = rs.permutation(n)[:mb]
+    ti = torch.as_tensor(idx)
+    gp, gv, st = run_minibatch(L, head, pol, val, obs, act.numpy(), old, tgt, adv, idx, 0.2, 0.005, 0.5, precision="bf16")
+    with nets.bf16_operands():
+        ref = ppo.minibatch_autograd(head, pol, val, torch.as_tensor(obs)[ti], act[ti], torch.as_tensor(old)[ti], torch.as_tensor(adv)[ti],
+                                     torch.as_tensor(tgt)[ti], 0.2, 0.005, 0.5)
+    with nets.bf16_operands(), nets.sum64():
+        ref2 = ppo.minibatch_autograd(head, pol, val, torch.as_tensor(obs)[ti], act[ti], torch.as_tensor(old)[ti], torch.as_tensor(adv)[ti],
+                                      torch.as_tensor(tgt)[ti], 0.2, 0.005, 0.5)
+    floor = fp64_gate.grads_err(ref2["grad_policy"] + ref2["grad_value"], ref["grad_policy"] + ref["grad_value"])
+    truth = ppo.minibatch_analytic(head, pol, val, obs[idx], act.numpy()[idx], old[idx], adv[idx], tgt[idx], 0.2, 0.005, 0.5)
+    e_ref = fp64_gate.grads_err(gp + gv, ref["grad_policy"] + ref["grad_value"])
+    e_true = fp64_gate.grads_err(gp + gv, truth["grad_policy"] + truth["grad_value"])
+    e_ref_true = fp64_gate.grads_err(ref["grad_policy"] + ref["grad_value"], truth["grad_policy"] + truth["grad_value"])
+    print(f"[bf16 update] {shape}: err(HIP bf16, CPU bf16 restatement)={e_ref:.2e}   summation-order floor of the restatement itself="
+          f"{floor:.2e}   distance from float64 truth of the fp32 function: HIP {e_true:.2e}, restatement {e_ref_true:.2e}")
+    per = [max(fp64_gate._rel(gw, ww), fp64_gate._rel(gb, wb)) for (gw, gb), (ww, wb) in zip(gp + gv, ref["grad_policy"] + ref["grad_value"])]
+    print("   per-layer err vs restatement (policy layers, then critic):", " ".join(f"{e:.1e}" for e in per),
+          " stats HIP", [float(f"{x:.6g}") for x in st[:5]], "ref", [float(f"{ref[k]:.6g}") for k in ("entropy", "kl", "value_loss", "clip_fraction", "policy_loss")])
+    assert e_ref <= max(1e-3, 3.0 * floor), (e_ref, floor)
+    assert 1e-4 < e_true < 0.5 and abs(e_true - e_ref_true) < 0.1 * e_ref_true + 3.0 * floor + 2e-3
+    for name, k in (("entropy", 0), ("kl", 1), ("value_loss", 2), ("policy_loss", 4)):
+        tol = max(2e-4, 3.0 * abs(ref2[name] - ref[name]) / max(abs(ref[name]), 1e-2))
+        assert abs(st[k] - ref[name]) <= tol * max(abs(ref[name]), 1e-2), (name, st[k], ref[name], ref2[name])
+    # the parity mode is back
+    got = run_minibatch(L, head, pol, val, obs, act.numpy(), old, tgt, adv, idx, 0.2, 0.005, 0.5)
+    fp64_gate.gate(L, head, pol, val, obs[idx], act.numpy()[idx], old[idx], adv[idx], tgt[idx], 0.2, 0.005, 0.5, got, label=f"fp32 after bf16 ({shape})")
+
+
 def test_cfg5_policy_classes_round_trip():
     from rlgym_ppo_amd.ppo import ContinuousPolicy, ValueEstimator
     torch.manual_seed(9)
@@ -97,3 +158,43 @@ def test_cfg5_bf16_forward_mode():
     assert 1e-5 < d_a < 0.1 and 1e-5 < d_v < 0.1, (d_a, d_v)  # a different arithmetic, not a different function
     a_back, _ = pol.get_action(obs, noise=eps)
     assert torch.equal(a_back, a32)  # switching back restores the parity mode
+
+
+def test_learner_runs_in_the_bf16_update_precision():
+    """PPOLearner.learn under engine.set_update_precision("bf16"): the rounded weight images follow every optimiser step, the
+    parameters stay finite and close to the fp32 run's (same data, same shuffle), and switching back restores the fp32 path."""
+    from rlgym_ppo_amd.engine import set_update_precision, update_precision
+    from rlgym_ppo_amd.ppo import ExperienceBuffer, PPOLearner
+
+    def run(mode):
+        torch.manual_seed(3)
+        learner = PPOLearner(231, 8, 2, (512, 512), (512, 512), (0.1, 1.0), 2048, 2, 3e-4, 3e-4, 0.2, 0.005, 1024, "cuda:0")
+        rs = np.random.RandomState(3)
+        n = 4096
+        obs = np.clip(rs.randn(n, 231), -5, 5).astype(np.float32)
+        act, logp = learner.policy.get_action(obs, noise=torch.as_tensor(rs.randn(n, 8).astype(np.float32)))
+        buf = ExperienceBuffer(n, 3, "cpu")
+        z = np.zeros(n, np.float32)
+        buf.submit_experience(obs, act.numpy(), logp.numpy() + 0.05 * rs.randn(n).astype(np.float32), z, obs, z, z,
+                              rs.randn(n).astype(np.float32), rs.randn(n).astype(np.float32))
+        set_update_precision(mode)
+        try:
+            report = learner.learn(buf)
+        finally:
+            set_update_precision("fp32")
+        return learner.policy.arena.flat.clone(), learner.value_net.arena.flat.clone(), report
+
+    p32, v32, r32 = run("fp32")
+    p16, v16, r16 = run("bf16")
+    assert update_precision() == "fp32"
+    assert torch.isfinite(p16).all() and torch.isfinite(v16).all()
+    assert r16["Cumulative Model Updates"] == r32["Cumulative Model Updates"] == 4
+    # a different arithmetic (bf16 forward), not a different algorithm: 4 Adam steps move a parameter by at most ~4 lr, so the
+    # two runs can be at most ~8 lr apart (a near-zero gradient entry whose sign the rounding flips), and are not identical
+    moved = (p32 - p16).abs().max().item()
+    assert 0 < moved < 8 * 3e-4 * 1.2
+    assert (p32 - p16).abs().mean().item() < 0.25 * 3e-4
+    for k in ("Policy Entropy", "Value Function Loss"):
+        assert abs(r16[k] - r32[k]) <= 2e-2 * abs(r32[k]), (k, r16[k], r32[k])
+    p32b, v32b, _ = run("fp32")
+    assert torch.equal(p32, p32b) and torch.equal(v32, v32b)   # the fp32 path is bit-reproducible and untouched by the switch

@@ -71,6 +71,45 @@ def test_gemm_nt(L, M, N, K, epi):
     assert relerr(C, ref) < (5e-6 if epi == 2 else 2e-6)
 
 
+@pytest.mark.parametrize("M,N,K,hidden,epi", [(3072, 512, 512, 1, 1), (1000, 256, 256, 1, 1), (4096 + 77, 512, 256, 1, 1), (700, 128, 64, 1, 1),
+                                              (3000, 32, 512, 0, 2), (2500, 96, 256, 0, 0), (513, 256, 128, 0, 0)])
+def test_gemm_nt_b16(L, M, N, K, hidden, epi):
+    """The bf16-in-memory forward product (bf16 update precision): exact bf16 products, fp32 accumulation.  Hidden form: the
+    three outputs (bf16, the same values as fp32, ReLU bitmask) are mutually consistent and equal the float64 product rounded to
+    bf16 except where fp32 summation noise crosses a rounding boundary; the bitmask is the one the fp32 dX kernel expects."""
+    g = torch.Generator().manual_seed(M + N + K)
+    A = (torch.randn(M, K, generator=g)).bfloat16()
+    W = (torch.randn(N, K, generator=g) * (0.05 if epi == 2 else 0.1)).bfloat16()
+    bias = torch.randn(N, generator=g) * 0.1
+    Ad, Wd, bd = A.cuda(), W.cuda(), bias.cuda()
+    C = torch.full((M, N), float("nan"), device="cuda")
+    ref = A.double() @ W.double().T + bias.double()
+    if not hidden:
+        check(L, L.rlppo_dbg_gemm_nt_b16(stream(), P(Ad), K, P(Wd), K, P(bd), P(C), N, None, 0, M, N, K, epi, 0, None))
+        ref = torch.tanh(ref) if epi == 2 else ref
+        assert relerr(C, ref) < 5e-6
+        return
+    Cb = torch.zeros(M, N, dtype=torch.bfloat16, device="cuda")
+    bits = torch.zeros(int(L.rlppo_dbg_gemm_nt_bits_bytes(M, N)), dtype=torch.uint8, device="cuda")
+    check(L, L.rlppo_dbg_gemm_nt_b16(stream(), P(Ad), K, P(Wd), K, P(bd), P(C), N, P(Cb), N, M, N, K, 1, 1, P(bits)))
+    torch.cuda.synchronize()
+    assert torch.equal(C.cpu(), Cb.float().cpu())                       # the fp32 copy IS the bf16 value
+    want = ref.clamp(min=0).float().bfloat16().float()
+    diff = (C.cpu() - want).abs()
+    # at most one bf16 ulp (+ the fp32 summation noise of a K-term sum, which dominates where the sum nearly cancels), and
+    # only where that noise crosses a rounding boundary
+    ulp = want.abs() * 2.0 ** -7 + 2.0 ** -24 * K * (A.float().abs() @ W.float().abs().T + bias.abs()).double()
+    assert (diff <= ulp).all() and (diff > 0).float().mean().item() < 2e-3
+    # the bitmask drives the fp32 masked-dX kernel: dX = (dY . Wt^T) masked by it must equal masking by C > 0
+    dY = torch.randn(M, 128, device="cuda")
+    Wt = torch.randn(N, 128, device="cuda") * 0.05
+    D0, D1 = torch.empty(M, N, device="cuda"), torch.full((M, N), -7.0, device="cuda")
+    check(L, L.rlppo_dbg_gemm_nt(stream(), P(dY), 128, P(Wt), 128, None, P(C), N, P(D0), N, M, N, 128, 3))
+    check(L, L.rlppo_dbg_gemm_nt_bits(stream(), P(dY), 128, P(Wt), 128, None, P(D1), N, M, N, 128, 3, P(bits)))
+    torch.cuda.synchronize()
+    assert torch.equal(D0, D1)
+
+
 def test_relu_bitmask_forms_are_bitwise_equal(L):
     """The hidden-layer forward that also writes the ReLU bitmask gives the same activations as the plain
     forward, and the dX product masked by that bitmask gives the same result as the one masked by re-reading the activation
@@ -444,8 +483,15 @@ def test_g9_gaussian_and_multidiscrete_act(L, golden):
 
 
 # ---------------------------------------------------------------------------------------- PPO minibatch
-def run_minibatch(L, head, pol, val, obs_all, acts_all, old_all, tgt_all, adv_all, idx, clip, ent, mb_ratio, var=(0.1, 1.0)):
+def run_minibatch(L, head, pol, val, obs_all, acts_all, old_all, tgt_all, adv_all, idx, clip, ent, mb_ratio, var=(0.1, 1.0),
+                  precision="fp32"):
     from rlgym_ppo_amd import _native as N
+    if precision == "bf16":  # the bf16-operand forward (rlppo_set_update_precision): same call with the rounded weight images
+        check(L, L.rlppo_set_update_precision(1))
+        try:
+            return run_minibatch(L, head, pol, val, obs_all, acts_all, old_all, tgt_all, adv_all, idx, clip, ent, mb_ratio, var, "bf16*")
+        finally:
+            check(L, L.rlppo_set_update_precision(0))
     P_, V_ = Net(L, pol), Net(L, val)
     states = P_.pad(obs_all)
     acts = dev(np.asarray(acts_all, np.float32).reshape(len(obs_all), -1))
@@ -462,6 +508,14 @@ def run_minibatch(L, head, pol, val, obs_all, acts_all, old_all, tgt_all, adv_al
     mb = len(idx)
     ws = torch.empty(int(L.rlppo_minibatch_workspace_bytes(P_.dims_c, P_.nl, V_.dims_c, V_.nl, mb)), dtype=torch.uint8, device="cuda")
     a.pol_packed, a.val_packed, a.pol_grad, a.val_grad = P_.packed.data_ptr(), V_.packed.data_ptr(), gp.data_ptr(), gv.data_ptr()
+    if precision == "bf16*":
+        imgs = []
+        for net in (P_, V_):
+            pr = torch.zeros_like(net.packed)
+            wb = torch.zeros(int(L.rlppo_wb16_elems(net.dims_c, net.nl)), dtype=torch.bfloat16, device="cuda")
+            check(L, L.rlppo_net_pack_bf16(stream(), net.dims_c, net.nl, P(net.flat), P(pr), P(wb)))
+            imgs += [pr, wb]
+        a.pol_packed_r, a.pol_wb16, a.val_packed_r, a.val_wb16 = (t.data_ptr() for t in imgs)
     a.states, a.ld_states, a.actions = states.data_ptr(), states.shape[1], acts.data_ptr()
     a.old_logp, a.targets, a.advantages, a.idx, a.mb = old.data_ptr(), tgt.data_ptr(), adv.data_ptr(), idxd.data_ptr(), mb
     a.clip_range, a.ent_coef, a.mb_ratio = clip, ent, mb_ratio
