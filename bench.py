@@ -276,7 +276,9 @@ def rollout_bench(learner):
     return dict(workload="4096 x 107 obs per step, 256x3 policy, 90 actions",
                 obs_per_s_host_noise=round(N_AGENTS / t_parity), ms_per_step_host_noise=round(t_parity * 1e3, 3),
                 obs_per_s_resident_noise=round(N_AGENTS / t_given), ms_per_step_resident_noise=round(t_given * 1e3, 3),
-                note="host_noise = torch CPU exponential_ draw (bit-exact action parity mode) + H2D/D2H included")
+                note="host_noise = the bit-exact action parity mode: Exp(1) noise of torch's CPU generator stream (librlppo's host "
+                     "implementation of torch's exponential_, drawn one step ahead on a helper thread; round 1: torch's serial kernel "
+                     "on the learner thread, 4.7 ms/step) + H2D/D2H included; resident_noise = noise already in HBM")
 
 
 def cpu_baseline(seed=123, reps=3):

@@ -251,6 +251,14 @@ int rlppo_mt19937_permutation(uint32_t *state625, int64_t n, int64_t *out);
 int rlppo_mt19937_draw_targets(uint32_t *state625, int64_t n, uint32_t *targets);
 int rlppo_apply_swap_targets(int64_t n, const uint32_t *targets, int64_t *out);
 
+/* torch.empty(n).exponential_(lambda) of PyTorch's CPU generator, bit for bit: the Exp(1) noise torch.multinomial(probs, 1,
+ * True) / Categorical.sample() consume in the reference's rollout (discrete_policy.py:59), i.e. the stream
+ * that makes a seeded run pick the reference's action indices.  HOST code, HOST pointers.  `state`: the generator's serialised
+ * state as torch.get_rng_state() returns it (5056 bytes), advanced in place exactly as torch advances it (2 n MT19937 words).
+ * The serial MT19937 phase is vectorised and the double-precision log1p transform runs on `threads` threads: 4096 x 90 values
+ * in ~0.5 ms instead of the ~4.7 ms of torch's serial kernel. */
+int rlppo_torch_cpu_exponential(void *state, int64_t state_bytes, int64_t n, double lambda, float *out, int32_t threads);
+
 /* dst[r][0..width) = src[idx[r]][0..width), fp32 rows, 16 bytes per thread (width, ld_src multiples of 4; dst rows are
  * `width` floats apart).  The minibatch gather of experience_buffer.py:82-87 (used inside rlppo_ppo_minibatch) and the
  * step-major -> trajectory-major flatten of a device-resident rollout (batched_agent_manager.py:154-172 builds the same

@@ -93,6 +93,7 @@ SIGNATURES = {
     "rlppo_mt19937_permutation": (c_int32, [POINTER(c_uint32), c_int64, c_void_p]),
     "rlppo_mt19937_draw_targets": (c_int32, [POINTER(c_uint32), c_int64, c_void_p]),
     "rlppo_apply_swap_targets": (c_int32, [c_int64, c_void_p, c_void_p]),
+    "rlppo_torch_cpu_exponential": (c_int32, [c_void_p, c_int64, c_int64, c_double, c_void_p, c_int32]),
     "rlppo_gather_rows": (c_int32, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int32, c_int64]),
     "rlppo_welford_increment": (c_int32, [c_void_p, c_void_p, c_int64, c_int64, c_int32, c_void_p, c_void_p, c_int64, c_int32]),
     "rlppo_welford_merge": (c_int32, [c_void_p, c_int32, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int32]),

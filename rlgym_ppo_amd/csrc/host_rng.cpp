@@ -237,3 +237,187 @@ int rlppo_apply_swap_targets(int64_t n, const uint32_t *targets, int64_t *out) {
     return 0;
 }
 }
+
+// ------------------------------------------------------------------------------------------------------------------------
+// torch.empty(n).exponential_(lambda) of PyTorch's CPU generator, bit for bit -- the noise torch.multinomial(probs, 1, True)
+// and Categorical.sample() draw in the reference's rollout (rlgym_ppo/ppo/discrete_policy.py:59, util/torch_functions.py:115;
+// SURVEY.md section 8(a1)).  PyTorch is a third-party dependency of the reference (requirements.txt, unpinned `torch>1.13`);
+// the algorithm restated here is the published one of its CPU path (ATen/native/cpu/DistributionTemplates.h
+// exponential_kernel_default -> ATen/core/DistributionsHelper.h + TransformationHelper.h, c10 MT19937RNGEngine.h), pinned by
+// tests/test_abi_and_layout.py against torch itself on every box:
+//   per element: r64 = (engine() << 32) | engine()            two tempered MT19937 words, high word first (random64)
+//                u   = (r64 & (2^53 - 1)) * 2^-53              uniform_real_distribution<double>
+//                q   = (float)(-1/lambda * log1p(-u))          transformation::exponential, CPU branch, double math
+// The stream phase (MT19937 regeneration + tempering) is serial and vectorised; the transform is embarrassingly parallel
+// and runs on `threads` std::threads.  torch's own kernel is serial at ~12-26 ns per element (4.7 ms for the 4096 x 90
+// draw of one rollout step, the whole cost of the bit-exact rollout mode in round 1).
+//
+// `state` is the generator's serialised state as torch.get_rng_state() returns it (CPUGeneratorImpl.cpp,
+// CPUGeneratorImplState: 5056 bytes): { u64 seed; i32 left; i32 seeded; u64 next; u64 mt[624]; double normal_x, normal_y,
+// normal_rho; i32 normal_is_valid; float next_float_normal_sample; bool valid }.  It is advanced in place exactly as the
+// generator would advance (left/next follow c10::mt19937: `if (--left == 0) next_state(); y = state[next++]`).
+#include <math.h>
+
+#include <thread>
+
+namespace {
+struct TorchState {
+    uint64_t seed;
+    int32_t left, seeded;
+    uint64_t next;
+    uint64_t mt[N];
+};
+static_assert(sizeof(TorchState) == 8 + 8 + 8 + 8 * N, "layout of the legacy generator state header");
+
+inline void temper8(const uint32_t *src, uint32_t *dst) {
+    __m256i y = _mm256_loadu_si256((const __m256i *)src);
+    y = _mm256_xor_si256(y, _mm256_srli_epi32(y, 11));
+    y = _mm256_xor_si256(y, _mm256_and_si256(_mm256_slli_epi32(y, 7), _mm256_set1_epi32((int)0x9d2c5680u)));
+    y = _mm256_xor_si256(y, _mm256_and_si256(_mm256_slli_epi32(y, 15), _mm256_set1_epi32((int)0xefc60000u)));
+    y = _mm256_xor_si256(y, _mm256_srli_epi32(y, 18));
+    _mm256_storeu_si256((__m256i *)dst, y);
+}
+}  // namespace
+
+#include <atomic>
+#include <condition_variable>
+#include <mutex>
+
+namespace {
+struct ExpJob {
+    static constexpr int64_t SLICE = 2048;
+    const uint32_t *w = nullptr;
+    float *out = nullptr;
+    int64_t n = 0;
+    double scale = -1.0;
+    std::atomic<int64_t> published{0};  // elements whose two words are in `w`
+    std::atomic<int64_t> claimed{0};    // next element nobody has taken yet
+    std::atomic<int> busy{0};           // helper threads still inside work()
+    void work() {
+        for (;;) {
+            const int64_t lo = claimed.fetch_add(SLICE, std::memory_order_relaxed);
+            if (lo >= n) return;
+            const int64_t hi = lo + SLICE < n ? lo + SLICE : n;
+            while (published.load(std::memory_order_acquire) < hi) _mm_pause();  // the stream phase is ~3x faster than one transformer
+            for (int64_t i = lo; i < hi; i++) {
+                const uint64_t r64 = ((uint64_t)w[2 * i] << 32) | (uint64_t)w[2 * i + 1];
+                const double u = (double)(r64 & ((1ULL << 53) - 1)) * (1.0 / 9007199254740992.0);
+                out[i] = (float)(scale * log1p(-u));
+            }
+        }
+    }
+};
+
+// Persistent helper threads (created on first use, detached: they sleep on a condition variable between draws and die with
+// the process).  One job at a time; callers from different threads serialise on `gate`.
+struct ExpPool {
+    std::mutex m, gate;
+    std::condition_variable cv;
+    ExpJob *job = nullptr;
+    uint64_t generation = 0;
+    int wanted = 0, spawned = 0;
+    static ExpPool &get() {
+        static ExpPool *p = new ExpPool();  // intentionally leaked: no destructor races at exit
+        return *p;
+    }
+    void start(ExpJob *j, int helpers) {
+        gate.lock();
+        std::unique_lock<std::mutex> lk(m);
+        for (; spawned < helpers; ++spawned) {
+            const int id = spawned;
+            std::thread([this, id] { loop(id); }).detach();
+        }
+        j->busy.store(helpers, std::memory_order_relaxed);
+        job = j;
+        wanted = helpers;
+        ++generation;
+        lk.unlock();
+        cv.notify_all();
+    }
+    void finish(ExpJob *j) {
+        while (j->busy.load(std::memory_order_acquire) > 0) std::this_thread::yield();
+        {
+            std::lock_guard<std::mutex> lk(m);
+            job = nullptr;
+        }
+        gate.unlock();
+    }
+    void loop(int id) {
+        uint64_t seen = 0;
+        for (;;) {
+            ExpJob *j;
+            {
+                std::unique_lock<std::mutex> lk(m);
+                cv.wait(lk, [&] { return generation != seen; });
+                seen = generation;
+                j = id < wanted ? job : nullptr;
+            }
+            if (j) {
+                j->work();
+                j->busy.fetch_sub(1, std::memory_order_release);
+            }
+        }
+    }
+};
+}  // namespace
+
+extern "C" int rlppo_torch_cpu_exponential(void *state, int64_t state_bytes, int64_t n, double lambda, float *out, int32_t threads) {
+    if (!state || state_bytes < (int64_t)sizeof(TorchState) || n < 0 || (n > 0 && !out) || !(lambda > 0.0)) return RLPPO_ERR_ARG;
+    if (n == 0) return 0;
+    TorchState *ts = reinterpret_cast<TorchState *>(state);
+    if (ts->left < 1 || ts->left > N || ts->next > (uint64_t)N) return RLPPO_ERR_ARG;
+    uint32_t mt[N + 8];
+    for (int i = 0; i < N; i++) mt[i] = (uint32_t)ts->mt[i];
+    int left = ts->left;
+    uint32_t next = (uint32_t)ts->next;
+
+    // The stream phase (serial: MT19937 regeneration + tempering, ~0.9 ns per word) publishes the tempered words chunk by
+    // chunk; the transform phase (double-precision log1p, ~7 ns per element) runs on persistent helper threads that claim
+    // slices of 2048 elements as soon as their words are published -- the two phases overlap instead of adding up.
+    static thread_local std::vector<uint32_t> words;
+    words.resize((size_t)(2 * n) + 8);
+    uint32_t *w = words.data();
+    const double scale = -1.0 / lambda;
+    ExpJob job;
+    job.w = w;
+    job.out = out;
+    job.n = n;
+    job.scale = scale;
+    int t = threads < 1 ? 1 : (threads > 32 ? 32 : threads);
+    if ((int64_t)(t - 1) * ExpJob::SLICE > n) t = (int)(n / ExpJob::SLICE) + 1;
+    ExpPool &pool = ExpPool::get();
+    if (t > 1) pool.start(&job, t - 1);
+
+    int64_t need = 2 * n, got = 0;
+    while (got < need) {
+        // words still unread in the current block: state[next .. 623] are readable while left - 1 > 0 reads remain
+        int avail = left - 1;
+        if (avail == 0) {  // `--left == 0` -> next_state(): left = 624, next = 0, and this call reads state[0]
+            regen(mt);
+            left = N + 1;  // bookkeeping: after the read below left == 624, as in c10::mt19937
+            next = 0;
+            avail = N;
+        }
+        int take = (int64_t)avail < need - got ? avail : (int)(need - got);
+        int k = 0;
+        for (; k + 8 <= take; k += 8) temper8(mt + next + k, w + got + k);
+        for (; k < take; k++) {
+            uint32_t y = mt[next + k];
+            y ^= (y >> 11);
+            y ^= (y << 7) & 0x9d2c5680u;
+            y ^= (y << 15) & 0xefc60000u;
+            y ^= (y >> 18);
+            w[got + k] = y;
+        }
+        got += take;
+        next += (uint32_t)take;
+        left -= take;
+        job.published.store(got / 2, std::memory_order_release);
+    }
+    for (int i = 0; i < N; i++) ts->mt[i] = mt[i];
+    ts->left = left;
+    ts->next = next;
+    job.work();                  // the calling thread helps with what is left
+    if (t > 1) pool.finish(&job);
+    return 0;
+}

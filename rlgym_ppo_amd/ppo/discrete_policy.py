@@ -9,7 +9,7 @@ import torch
 import torch.nn as nn
 
 from .. import _native as N
-from ..engine import ptr, stream_ptr
+from ..engine import host_exponential, ptr, stream_ptr
 from ._mlp import ArenaModule, build_body
 
 
@@ -52,7 +52,7 @@ class DiscreteFF(ArenaModule):
         return (n, self.n_actions)
 
     def _draw_noise(self, n):
-        return torch.empty(n, self.n_actions).exponential_(1)
+        return host_exponential((n, self.n_actions))  # == torch.empty(n, A).exponential_(1), drawn ahead (engine.py)
 
     def _action_buffer(self, cap):
         return torch.zeros(cap, dtype=torch.int64)
@@ -70,7 +70,7 @@ class DiscreteFF(ArenaModule):
         if noise is None and self.noise_mode == "device":
             noise = torch.empty(n, self.n_actions, device=a.device).exponential_(1)  # fast mode: torch's HIP generator, not the reference's CPU stream
         elif noise is None:
-            noise = torch.empty(n, self.n_actions).exponential_(1)
+            noise = host_exponential((n, self.n_actions))
         q = torch.as_tensor(noise, dtype=torch.float32).to(a.device, non_blocking=True).contiguous()
         a.ensure_packed()
         actions = torch.empty(n, dtype=torch.int64, device=a.device)

@@ -4,7 +4,7 @@ import numpy as np
 import torch
 
 from .. import _native as N
-from ..engine import ptr, stream_ptr
+from ..engine import host_exponential, ptr, stream_ptr
 from ..util import torch_functions
 from ._mlp import ArenaModule, build_body
 
@@ -45,7 +45,7 @@ class MultiDiscreteFF(ArenaModule):
         return (n * 8, 3)
 
     def _draw_noise(self, n):
-        return torch.empty(n * 8, 3).exponential_(1)  # Categorical.sample -> multinomial on [n*8, 3]
+        return host_exponential((n * 8, 3))  # Categorical.sample -> multinomial on [n*8, 3]: torch.empty(n*8, 3).exponential_(1)
 
     def _action_buffer(self, cap):
         return torch.zeros((cap, 8), dtype=torch.int64)
@@ -62,7 +62,7 @@ class MultiDiscreteFF(ArenaModule):
         if noise is None and self.noise_mode == "device":
             noise = torch.empty(n * 8, 3, device=a.device).exponential_(1)  # fast mode: torch's HIP generator, not the reference's CPU stream
         elif noise is None:
-            noise = torch.empty(n * 8, 3).exponential_(1)  # Categorical.sample -> multinomial on [n*8, 3]
+            noise = host_exponential((n * 8, 3))  # Categorical.sample -> multinomial on [n*8, 3]
         q = torch.as_tensor(noise, dtype=torch.float32).to(a.device, non_blocking=True).contiguous()
         a.ensure_packed()
         actions = torch.empty((n, 8), dtype=torch.int64, device=a.device)

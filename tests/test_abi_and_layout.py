@@ -184,3 +184,52 @@ def test_welford_matches_reference(golden):
     c = WelfordRunningStat(1)
     c.from_json(js)
     assert c.count == st.count and np.allclose(c.std, st.std)
+
+
+def test_host_exponential_is_torch_exponential_bit_for_bit():
+    """rlppo_torch_cpu_exponential == torch.empty(n).exponential_(1) on the global CPU generator: same values, same generator
+    advance (block boundaries of the MT19937 stream included), interleaved with other consumers of the generator; and the
+    speculative look-ahead pipeline on top of it (engine.HostExponential) never changes the observable stream."""
+    import ctypes
+    import torch
+    from rlgym_ppo_amd import _native as N
+    from rlgym_ppo_amd import engine
+    L = N.lib()
+
+    def draw(n, threads):
+        a = torch.get_rng_state().numpy().copy()
+        out = np.empty(n, np.float32)
+        N.check(L.rlppo_torch_cpu_exponential(ctypes.c_void_p(a.ctypes.data), a.size, n, 1.0, ctypes.c_void_p(out.ctypes.data), threads))
+        torch.set_rng_state(torch.from_numpy(a))
+        return torch.from_numpy(out)
+
+    for seed, sizes in ((0, [1, 7, 90 * 4096, 3, 624, 625, 311, 90 * 64]), (123, [312, 312, 1, 4096 * 90, 10]), (5, [2 * 624 * 3, 5])):
+        torch.manual_seed(seed)
+        ref = [torch.empty(n).exponential_(1) for n in sizes]
+        s_ref = torch.get_rng_state()
+        torch.manual_seed(seed)
+        got = [draw(n, 1 + i % 5) for i, n in enumerate(sizes)]
+        assert all(torch.equal(a, b) for a, b in zip(ref, got)) and torch.equal(s_ref, torch.get_rng_state())
+    torch.manual_seed(9)
+    r = [torch.empty(1000).exponential_(1), torch.randn(33), torch.empty(5000).exponential_(1), torch.rand(7), torch.randint(0, 9, (5,))]
+    torch.manual_seed(9)
+    g = [draw(1000, 3), torch.randn(33), draw(5000, 2), torch.rand(7), torch.randint(0, 9, (5,))]
+    assert all(torch.equal(a, b) for a, b in zip(r, g))
+    assert L.rlppo_torch_cpu_exponential(None, 0, 4, 1.0, None, 1) != 0
+
+    # the look-ahead pipeline: a rollout-like sequence with a foreign draw, a shape change and a re-seed in between
+    def sequence(draw_):
+        fn = lambda shape: draw_(shape).clone()         # the pipeline hands out views of recycled pinned buffers
+        torch.manual_seed(3)
+        out = [fn((64, 90)), fn((64, 90)), fn((64, 90))]
+        out.append(torch.randn(5))                      # somebody else uses the generator: the speculation must be dropped
+        out += [fn((64, 90)), fn((8 * 8, 3)), fn((64, 90)), fn((64, 90))]
+        torch.manual_seed(4)                            # re-seeded
+        out += [fn((64, 90)), fn((64, 90))]
+        return out, torch.get_rng_state()
+
+    ref, s_ref = sequence(lambda shape: torch.empty(shape).exponential_(1))
+    engine._HOST_EXP = None
+    got, s_got = sequence(engine.host_exponential)
+    assert all(torch.equal(a, b) for a, b in zip(ref, got)) and torch.equal(s_ref, s_got)
+    assert engine._HOST_EXP.hits >= 3 and engine._HOST_EXP.misses >= 4   # both paths were exercised

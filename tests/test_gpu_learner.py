@@ -378,6 +378,45 @@ def test_get_action_graph_replay_equals_eager_path():
     assert set(pol._graphs) == {16, 32, 80, 256, 1024, 48}
 
 
+def test_seeded_rollout_draws_the_reference_noise_stream():
+    """128 rollout steps of 64 agents from one seed: DiscreteFF.get_action's default noise (librlppo's host implementation of
+    torch's CPU exponential_, drawn one step ahead on a helper thread -- engine.HostExponential) is the stream the reference's
+    torch.multinomial consumes, so the action indices are the oracle's (identical noise; an index may only differ on a
+    near-tie of p/q caused by the ulp-level difference of the probabilities: none expected, margin stated) and the generator
+    ends in the reference's state."""
+    from rlgym_ppo_amd import engine
+    from rlgym_ppo_amd.ppo import DiscreteFF
+    torch.manual_seed(77)
+    pol = DiscreteFF(107, 90, (64, 64), "cuda:0")
+    params = [(l.weight.detach().cpu(), l.bias.detach().cpu()) for l in pol.arena.linears]
+    rs = np.random.RandomState(5)
+    obs = [np.clip(rs.randn(64, 107), -5, 5).astype(np.float32) for _ in range(128)]
+    torch.manual_seed(1234)
+    want = []
+    for o in obs:
+        q = nets.draw_exp_noise(64, 90)
+        p = nets.discrete_probs(params, o)
+        want.append((nets.discrete_sample(p, q), p, q))
+    s_ref = torch.get_rng_state()
+    for graphs in (True, False):
+        pol.act_graphs = graphs
+        torch.manual_seed(1234)
+        engine._HOST_EXP = None
+        mismatches = 0
+        for o, ((a_ref, lp_ref), p, q) in zip(obs, want):
+            a, lp = pol.get_action(o)
+            bad = (a != a_ref).nonzero().flatten().tolist()
+            for i in bad:
+                s = p[i] / q[i]
+                assert abs(s[a[i]] - s[a_ref[i]]) <= 1e-5 * s[a_ref[i]], "index mismatch that is not a near-tie"
+            mismatches += len(bad)
+            same = a == a_ref
+            assert (lp[same] - lp_ref[same]).abs().max().item() < 1e-5
+        assert mismatches <= 1
+        assert torch.equal(torch.get_rng_state(), s_ref)
+        assert engine._HOST_EXP.hits >= 126                     # every step but the first was served from the look-ahead
+
+
 def test_captured_act_graphs_follow_the_inference_precision():
     """A captured graph replays the kernels selected at capture time; the graph cache is keyed on the library's selection
     epoch, so set_inference_precision takes effect for small (graph-served, n <= 1024) batches too, both ways."""
