@@ -186,8 +186,8 @@ def pmc_traffic_for(kernel_label):
 
 
 def gae_traffic():
-    try:
-        return round(json.load(open(os.path.join(ROOT, "profiles", TRAFFIC_JSON)))["rlppo::gae_lookback_kernel"]["hbm_bytes"])
+    try:  # tools/prof_gae.py under rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, summarised by tools/pmc_traffic.py
+        return round(json.load(open(os.path.join(ROOT, "profiles", "r02_gae_traffic.json")))["rlppo::gae_lookback_kernel<false>"]["hbm_bytes"])
     except Exception:
         return None
 
@@ -234,7 +234,7 @@ def gae_bench():
     ms_two = float(np.median(times[0]))
     alg_bytes = 28 * n
     out = dict(workload="8192 trajectories x 256 steps fp32 (BASELINE configs[2])", steps=n, ms_per_scan=round(ms, 5),
-               steps_per_s=round(n / ms * 1e3), algorithm="single launch: chunk scan + raw look-ahead fast path, decoupled look-back with epoch tags otherwise (no memset)",
+               steps_per_s=round(n / ms * 1e3), algorithm="single launch: chunk scan + raw look-ahead fast path, decoupled look-back with per-launch tags otherwise (no memset)",
                ms_per_scan_two_launch=round(ms_two, 5),
                roofline=dict(bound="hbm", achieved=round(alg_bytes / ms / 1e6, 1), peak=HBM_PEAK_GBS, unit="GB/s",
                              frac=round(alg_bytes / ms / 1e6 / HBM_PEAK_GBS, 4), traffic=gae_traffic(), algorithmic_bytes=alg_bytes,

@@ -121,7 +121,11 @@ size_t rlppo_gae_workspace_bytes(int64_t n);
  * learner.py:347-352).  return_std: the running return std (learner.py:356); pass NaN for `None`
  * (no reward scaling).  Outputs float[n]: value_targets = V + adv, advantages, returns.
  * Arithmetic: reward scaling in float32 (as the reference's float32/float32 division), recurrences in
- * float64, outputs rounded once to float32 -- the reference's behaviour under its pinned NumPy < 2. */
+ * float64, outputs rounded once to float32 -- the reference's behaviour under its pinned NumPy < 2.
+ * One launch (chunk scans + decoupled look-back; per-launch record tags, so launches on one workspace never interfere); inside
+ * a stream capture the stateless two-launch form is used instead.  A look-back wait is bounded: if it ever times out (not
+ * expected: a chunk only waits on workgroups dispatched before it) the affected outputs are NaN and word 1 of the workspace
+ * (uint32) counts the event -- never a silent wrong result, never a hang. */
 int rlppo_gae(void *stream, const float *rews, const float *dones, const float *truncated, const float *values,
               int64_t n, double gamma, double lmbda, float return_std,
               float *value_targets, float *advantages, float *returns, void *workspace, size_t ws_bytes);
@@ -303,7 +307,8 @@ int rlppo_net_pack_bf16(void *stream, const int32_t *dims, int32_t n_layers, con
 /* A/B switches for measurements and tests (also RLPPO_TUNE="key=value,..." in the Python host).  Defaults in brackets.
  *   1 GAE algorithm [1 single-pass look-back | 0 two launches]
  *   4 policy / critic chains of rlppo_ppo_minibatch on two streams [1]
- *  21 GAE look-back spin limit before the raw-step slow path [-1 = default 2^18 | 0 = always the slow path (tests)] */
+ *  21 GAE look-back spin limit [-1 = default 2^20 | 0 = every wait times out at once (tests)]
+ *  22 GAE grid [0 = at most the resident capacity, workgroups loop over chunks beyond it | 1 = one workgroup per chunk always] */
 int rlppo_dbg_set(int32_t key, int32_t value);
 /* Counter bumped by every call that changes which kernels later launches select (rlppo_dbg_set, rlppo_set_*_precision): a
  * host that caches captured graphs of library calls keys them on it (rlgym_ppo_amd/ppo/_mlp.py::ActGraph). */

@@ -694,6 +694,7 @@ int rlppo_dbg_set(int32_t key, int32_t value) {
         case 1: set_gae_algo(value); return 0;
         case 4: g_two_streams = value; return 0;
         case 21: set_gae_spin_limit(value); return 0;
+        case 22: set_gae_oversubscribe(value); return 0;
         default: break;
     }
     set_error("dbg_set: unknown key %d", key);

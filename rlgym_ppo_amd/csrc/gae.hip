@@ -24,7 +24,10 @@
 namespace rlppo {
 
 constexpr int GAE_THREADS = 256;
-constexpr int GAE_EPT = 8;                           // steps per thread (two float4 per input array)
+#ifndef GAE_EPT_V
+#define GAE_EPT_V 8
+#endif
+constexpr int GAE_EPT = GAE_EPT_V;                   // steps per thread (GAE_EPT / 4 float4 per input array)
 constexpr int GAE_BLOCK = GAE_THREADS * GAE_EPT;     // 2048 steps per workgroup
 
 struct Aff2 {  // the two composites carried together: advantage (a,b) and return (c,d)
@@ -84,7 +87,12 @@ struct GaeParams {
 // Loads the GAE_EPT steps of this thread and turns them into per-step coefficients.
 struct Steps {
     double b_adv[GAE_EPT];
-    float m[GAE_EPT];  // nd * nt (exact for 0/1 flags); a_adv = gamma*lambda*m, a_ret = gamma*m are formed on use
+    // nd * nt of every step is 0 or 1 for 0/1 flags: one bit each (bit e), plus a "past the end of the data" marker (bit 16 + e:
+    // identity step, a_adv = a_ret = 1); a_adv = gamma*lambda*m and a_ret = gamma*m are formed on use.  (Eight floats here
+    // were what pushed the single-pass kernel 3 registers over its 128-VGPR budget: 12 bytes of scratch per lane = 3.1 MB of
+    // extra HBM writes per 8192 x 256 scan.)  The reference's flags are exactly 0.0 / 1.0 (batched_agent_manager.py:145,
+    // experience_buffer.py:47-48); launch_gae's contract says so.
+    unsigned mbits;
     float r[GAE_EPT], v[GAE_EPT];
 };
 
@@ -132,6 +140,7 @@ __device__ __forceinline__ void load_raw(const float *__restrict__ rews, const f
 
 __device__ __forceinline__ void make_steps(const RawSteps &w, int64_t t0, int64_t n, const GaeParams &p, Steps &s) {
     const float *r = w.r, *d = w.d, *tr = w.tr, *v = w.v;
+    s.mbits = 0;
 #pragma unroll
     for (int e = 0; e < GAE_EPT; ++e) {
         if (t0 + e < n) {
@@ -140,11 +149,11 @@ __device__ __forceinline__ void make_steps(const RawSteps &w, int64_t t0, int64_
             float rn = r[e];
             if (p.use_std) rn = fminf(fmaxf(r[e] / p.ret_std, -10.f), 10.f);
             s.b_adv[e] = ((double)rn + p.gamma * (double)v[e + 1] * nd) - (double)v[e];
-            s.m[e] = (float)(nd * nt);
+            s.mbits |= ((float)(nd * nt) != 0.f ? 1u : 0u) << e;
             s.r[e] = r[e];
         } else {  // past the end: identity, so partial blocks need no special casing downstream
             s.b_adv[e] = 0.0;
-            s.m[e] = -1.f;  // marker: a_adv = a_ret = 1
+            s.mbits |= 0x10000u << e;  // marker: a_adv = a_ret = 1
             s.r[e] = 0.f;
         }
         s.v[e] = v[e];
@@ -160,10 +169,10 @@ __device__ __forceinline__ void load_steps(const float *__restrict__ rews, const
 }
 
 __device__ __forceinline__ double coef_adv(const Steps &s, int e, const GaeParams &p) {
-    return s.m[e] < 0.f ? 1.0 : p.gl * (double)s.m[e];
+    return (s.mbits >> (16 + e)) & 1u ? 1.0 : ((s.mbits >> e) & 1u ? p.gl : 0.0);
 }
 __device__ __forceinline__ double coef_ret(const Steps &s, int e, const GaeParams &p) {
-    return s.m[e] < 0.f ? 1.0 : p.gamma * (double)s.m[e];
+    return (s.mbits >> (16 + e)) & 1u ? 1.0 : ((s.mbits >> e) & 1u ? p.gamma : 0.0);
 }
 
 __device__ __forceinline__ Aff2 thread_composite(const Steps &s, const GaeParams &p) {
@@ -300,7 +309,7 @@ constexpr int LB_AGG = 8;                       // granules of the aggregate rec
 constexpr int LB_INC = 4;                       // granules of the inclusive record: 2 doubles
 constexpr int LB_STRIDE = 16;                   // granules per chunk (128 B: one line per chunk)
 constexpr int LOOKAHEAD = 256;                  // raw steps of the next chunk inspected by wave 0 (4 per lane)
-constexpr unsigned LB_SPIN_LIMIT = 1u << 18;    // bounded spin (~0.1-0.3 s), then the slow path: never a hang, never a wrong carry
+constexpr unsigned LB_SPIN_LIMIT = 1u << 20;    // bounded spin (~1 s): never a hang; a timeout poisons the outputs with NaN
 
 __device__ __forceinline__ void put_granule(u64 *p, unsigned tag, unsigned v) {
     __hip_atomic_store(p, ((u64)tag << 32) | v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -311,6 +320,9 @@ __device__ __forceinline__ void put_double(u64 *p, unsigned tag, double d) {
     put_granule(p + 1, tag, (unsigned)(bits >> 32));
 }
 
+// LOOP = false: one chunk per workgroup (the grid covers every chunk; the usual case) -- without the loop-carried state the
+// kernel fits its 128-VGPR budget with no scratch at all.
+template <bool LOOP>
 __global__ __launch_bounds__(GAE_THREADS, 4) void gae_lookback_kernel(const float *__restrict__ rews,
                                                                     const float *__restrict__ dones,
                                                                     const float *__restrict__ trunc,
@@ -335,7 +347,7 @@ __global__ __launch_bounds__(GAE_THREADS, 4) void gae_lookback_kernel(const floa
     // Chunks are taken right-to-left, grid-strided.  A chunk waits only on chunks to its right, i.e. on work of this
     // same round owned by lower block ids or on earlier rounds; the launcher sizes the grid to the number of
     // co-resident workgroups, so every awaited chunk belongs to a running workgroup whatever the dispatch order.
-    for (int chunk = n_blocks - 1 - (int)blockIdx.x; chunk >= 0; chunk -= (int)gridDim.x) {
+    for (int chunk = n_blocks - 1 - (int)blockIdx.x; chunk >= 0; chunk = LOOP ? chunk - (int)gridDim.x : -1) {
     const int64_t t0 = ((int64_t)chunk * GAE_THREADS + threadIdx.x) * GAE_EPT;
 
     // Look-ahead window = the first LOOKAHEAD (= 256) raw steps of the next chunk, ONE per thread, requested together
@@ -363,6 +375,10 @@ __global__ __launch_bounds__(GAE_THREADS, 4) void gae_lookback_kernel(const floa
     Steps s;
     make_steps(raw, t0, n, p, s);
     const Aff2 mine = thread_composite(s, p);
+    // Who will ever read this chunk's records?  Only the chunk to the left, and only if its look-ahead over OUR first
+    // LOOKAHEAD steps finds no trajectory end (a chunk whose own carry came from the fast path publishes its inclusive value
+    // alone, so nobody walks past it).  Threads 0 .. LOOKAHEAD / GAE_EPT - 1 of wave 0 hold those steps.
+    const bool prefix_open = wave != 0 || (__ballot(lane < LOOKAHEAD / GAE_EPT && mine.a == 0.0 && mine.c == 0.0) == 0ull);
     // one shuffle scan serves both purposes: lane l gets the composite of lanes l..63 (needed for the outputs) and
     // lane 0's value is the wave total (needed for the chunk aggregate)
     const Aff2 inc = wave_suffix_scan(mine, lane);
@@ -374,12 +390,6 @@ __global__ __launch_bounds__(GAE_THREADS, 4) void gae_lookback_kernel(const floa
     if (wave == 0) {
         double carry_adv = 0.0, carry_ret = 0.0;
         if (chunk + 1 < n_blocks) {
-            if (lane == 0) {  // publish the aggregate first so that chunks to the left can pass through this one
-                put_double(rec + 0, TAG_AGG, agg.a);
-                put_double(rec + 2, TAG_AGG, agg.b);
-                put_double(rec + 4, TAG_AGG, agg.c);
-                put_double(rec + 6, TAG_AGG, agg.d);
-            }
             // Fast path: compose the first LOOKAHEAD raw steps of the next chunk.  A trajectory end inside them
             // (a == 0) fixes the carry with no dependence on any other workgroup -- the normal case for rollout data.
             Aff2 acc = aff_identity();
@@ -392,6 +402,14 @@ __global__ __launch_bounds__(GAE_THREADS, 4) void gae_lookback_kernel(const floa
                     carry_ret = la.d;
                     done = true;
                 }
+            }
+            // general path ahead: publish the aggregate first so that the chunk to the left can pass through this one
+            // while we wait (only it can ask, and only if our prefix holds no trajectory end)
+            if (!done && prefix_open && lane == 0) {
+                put_double(rec + 0, TAG_AGG, agg.a);
+                put_double(rec + 2, TAG_AGG, agg.b);
+                put_double(rec + 4, TAG_AGG, agg.c);
+                put_double(rec + 6, TAG_AGG, agg.d);
             }
             int j = chunk + 1;
             unsigned spins = 0;
@@ -420,35 +438,33 @@ __global__ __launch_bounds__(GAE_THREADS, 4) void gae_lookback_kernel(const floa
                         carry_ret = acc.d;
                         done = true;
                     } else {
-                        ++j;  // chunk n_blocks-1 always publishes an inclusive record, so j never runs off the end
+                        // an aggregate-only record means chunk j's own look-ahead failed, i.e. chunk j + 1's prefix holds no
+                        // trajectory end, i.e. chunk j + 1 publishes too: the walk only ever visits publishers, and the
+                        // rightmost chunk's carry is known (0), so it never publishes an aggregate and j never runs off the end
+                        ++j;
                         spins = 0;
                     }
                 } else {
                     __builtin_amdgcn_s_sleep(2);
                     if (++spins > spin_limit) {
-                        // Slow path: the awaited record did not appear.  Nothing is given up: the carry is recomputed
-                        // from the RAW steps to the right of what has been composed so far (64 per iteration, one per
-                        // lane) up to the first trajectory end or the end of the data -- correct whatever the other
-                        // workgroups do, merely slow; slow_word counts how often it happened (expected: never).
+                        // The awaited record did not appear within the bound.  With per-launch tags and chunks taken in
+                        // dispatch order (a chunk only ever waits on a workgroup dispatched before it) this cannot happen
+                        // short of a defect, and then it must not pass silently: the carry is poisoned, so this chunk's
+                        // outputs (and those of the chunks that chain through it) come out as NaN, and the workspace
+                        // header counts the event.  (Recomputing the carry here from raw steps was tried: its registers
+                        // pushed the common path into 152 bytes of scratch per lane, +29 % write traffic, +8 % time.)
                         if (lane == 0) atomicAdd(slow_word, 1u);
-                        for (int64_t pos = (int64_t)j * GAE_BLOCK; pos < n; pos += 64) {
-                            const int64_t t = pos + lane;
-                            Aff2 f = aff_identity();
-                            if (t < n) f = step_affine(rews[t], dones[t], trunc[t], values[t], values[t + 1], p);
-                            const Aff2 sc = wave_suffix_scan(f, lane);
-                            acc = compose(acc, readlane_aff(sc, 0));
-                            if (acc.a == 0.0 && acc.c == 0.0) break;
-                        }
-                        carry_adv = acc.b;  // x = 0 beyond the last step
-                        carry_ret = acc.d;
+                        carry_adv = carry_ret = __longlong_as_double(0x7ff8000000000000ll);
                         done = true;
                     }
                 }
             }
         }
         if (lane == 0) {
-            put_double(rec + 8, TAG_INC, agg.b + agg.a * carry_adv);   // x at the first step of this chunk
-            put_double(rec + 10, TAG_INC, agg.d + agg.c * carry_ret);
+            if (prefix_open) {  // (a prefix with a trajectory end: the left neighbour's look-ahead never needs our records)
+                put_double(rec + 8, TAG_INC, agg.b + agg.a * carry_adv);   // x at the first step of this chunk
+                put_double(rec + 10, TAG_INC, agg.d + agg.c * carry_ret);
+            }
             s_carry[0] = carry_adv;
             s_carry[1] = carry_ret;
         }
@@ -493,15 +509,15 @@ __global__ __launch_bounds__(GAE_THREADS, 4) void gae_lookback_kernel(const floa
     }
 }
 
-static int g_gae_grid_div = 1;  // tuning: rlppo_dbg_set(18, k): k chunks per workgroup (measured slower: the chunk is latency-bound)
-void set_gae_grid_div(int v) { g_gae_grid_div = v; }
+static int g_gae_oversubscribe = 0;  // rlppo_dbg_set(22, 0/1)
+void set_gae_oversubscribe(int v) { g_gae_oversubscribe = v; }
 static int g_gae_algo = 1;  // 1 = single-pass look-back (default), 0 = two launches (summary + apply)
 void set_gae_algo(int a) { g_gae_algo = a; }
-static unsigned g_gae_spin_limit = LB_SPIN_LIMIT;  // rlppo_dbg_set(21, v): tests set 0 to force the slow path
+static unsigned g_gae_spin_limit = LB_SPIN_LIMIT;  // rlppo_dbg_set(21, v): tests set 0 to force the timeout path
 void set_gae_spin_limit(int v) { g_gae_spin_limit = v < 0 ? LB_SPIN_LIMIT : (unsigned)v; }
 
-// workspace: [0,16) header: word 1 = number of look-back waits that ended in the slow path (diagnostic, never reset by the
-// library) | look-back state (128 B per chunk) ; the two-launch path uses the same
+// workspace: [0,16) header: word 1 = number of look-back waits that timed out (their chunks' outputs are NaN; never reset by
+// the library) | look-back state (128 B per chunk) ; the two-launch path uses the same
 // region for its per-chunk composites (32 B per chunk)
 size_t gae_workspace_bytes(int64_t n) { return 16 + (size_t)(cdiv(n > 0 ? n : 1, GAE_BLOCK)) * LB_STRIDE * sizeof(u64); }
 
@@ -533,14 +549,17 @@ int launch_gae(hipStream_t st, const float *rews, const float *dones, const floa
             hipDeviceProp_t prop;
             RLPPO_HIP(hipGetDevice(&dev));
             RLPPO_HIP(hipGetDeviceProperties(&prop, dev));
-            RLPPO_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gae_lookback_kernel, GAE_THREADS, 0));
+            RLPPO_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gae_lookback_kernel<true>, GAE_THREADS, 0));
             // the occupancy API over-reports by one block per CU only in the SGPR-limited 7-8 blocks/CU regime
             // (MI355X_MICROARCH.md "Residency and cooperative launch"); this kernel is VGPR-limited far below that
             per_cu = per_cu > 6 ? 6 : (per_cu < 1 ? 1 : per_cu);
             resident = per_cu * prop.multiProcessorCount;
         }
-        int grid = nb < resident ? nb : resident;
-        if (g_gae_grid_div > 1 && grid / g_gae_grid_div >= 256) grid = (int)cdiv(nb, cdiv(nb, grid / g_gae_grid_div));  // whole rounds
+        // g_gae_oversubscribe: one workgroup per chunk even beyond the resident capacity.  Chunks are taken right to left in
+        // workgroup-id order and every XCD dispatches its workgroups in id order, so the smallest unfinished chunk always holds
+        // (or is next in line for) a slot and waits on nothing unfinished: no deadlock without co-residency, and the loads of a
+        // later wave of workgroups overlap the stores of an earlier one instead of all workgroups moving in lockstep.
+        int grid = (nb < resident || g_gae_oversubscribe) ? nb : resident;
         // per-launch tag: process-wide counter seeded from the clock (a recycled workspace may hold records of another
         // process's launches), never 0 (zero-filled memory)
         static std::atomic<unsigned> g_tag{0};
@@ -551,8 +570,12 @@ int launch_gae(hipStream_t st, const float *rews, const float *dones, const floa
         }
         unsigned tag = g_tag.fetch_add(1, std::memory_order_relaxed) + 1;
         if (tag == 0) tag = g_tag.fetch_add(1, std::memory_order_relaxed) + 1;
-        hipLaunchKernelGGL(gae_lookback_kernel, dim3(grid), dim3(GAE_THREADS), 0, st, rews, dones, trunc, values, n, p, state,
-                           tag, g_gae_spin_limit, hdr + 1, nb, vt, adv, ret);
+        if (grid == nb)
+            hipLaunchKernelGGL(gae_lookback_kernel<false>, dim3(grid), dim3(GAE_THREADS), 0, st, rews, dones, trunc, values, n, p,
+                               state, tag, g_gae_spin_limit, hdr + 1, nb, vt, adv, ret);
+        else
+            hipLaunchKernelGGL(gae_lookback_kernel<true>, dim3(grid), dim3(GAE_THREADS), 0, st, rews, dones, trunc, values, n, p,
+                               state, tag, g_gae_spin_limit, hdr + 1, nb, vt, adv, ret);
         RLPPO_LAUNCH_CHECK();
         return 0;
     }

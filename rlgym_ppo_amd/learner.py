@@ -220,7 +220,10 @@ class Learner(object):
 
         if self.standardize_returns:
             n_to_increment = min(self.max_returns_per_stats_increment, n)
-            self.return_stats.increment(returns[:n_to_increment].cpu().numpy(), n_to_increment)
+            head = returns[:n_to_increment].cpu().numpy()
+            if np.isnan(head).any():  # rlppo_gae poisons what a timed-out look-back wait would have got wrong (include/rlppo.h)
+                raise RuntimeError("GAE produced NaN returns (look-back timeout or NaN inputs): refusing to train on them")
+            self.return_stats.increment(head, n_to_increment)
 
         self.experience_buffer._d = d_logical  # logical width of the padded rows
         self.experience_buffer.submit_experience(rows[:n], actions, log_probs, rews_d, next_states, dones_d, trunc_d,
