@@ -2,12 +2,18 @@
 
 On the accelerated path: `_send_actions` stacks the ready observations into one [n, d] matrix and makes ONE call to
 `policy.get_action` (librlppo's fused forward + sampling), and observations are standardised with the reference's
-scalar statistics (quirk Q5).  Everything else here is CPU control plane kept interface-compatible: env workers are
-separate processes (or, with n_processes=0, one in-process environment) talking over multiprocessing pipes.
+scalar statistics (quirk Q5).  Everything else here is CPU control plane kept interface- AND wire-compatible: env workers are
+separate processes that speak the reference's protocol -- UDP datagrams with three-float magic headers plus one slab per
+worker of a shared RawArray('f') for the step data (comm_consts.py; reference batched_agent_manager.py:254-299,436-476) -- so a
+worker process built for the reference can serve this manager and vice versa.  With n_processes=0 one environment runs inside
+the learner process (no IPC), and VectorAgentManager keeps a vectorised environment's rollout on the GPU.
 """
 import multiprocessing as mp
+import multiprocessing.sharedctypes
+import pickle
+import selectors
+import socket
 import time
-from multiprocessing.connection import wait
 
 import numpy as np
 import torch
@@ -17,9 +23,91 @@ from . import comm_consts as C
 from .batched_agent import _as_f32, batched_agent_process, describe_action_space
 from .batched_trajectory import BatchedTrajectory
 
+# messages as the manager's logic sees them, whatever carried them
+RESET_STATE, STEP_DATA, ENV_SHAPES = "env_reset_state", "env_step_data", "env_shapes"
+
+
+def parse_step_slab(shm_view):
+    """One step out of a worker's slab (layout: comm_consts.py; reference batched_agent_manager.py:254-299) ->
+    (prev_n_agents, done, truncated, rewards list, metrics array, observation [n_agents, d] float32 copy)."""
+    prev_n = int(shm_view[0])
+    done, truncated = float(shm_view[1]), float(shm_view[2])
+    state_rank, metrics_rank = int(shm_view[3]), int(shm_view[4])
+    o = 5
+    metrics_shape = [int(d) for d in shm_view[o:o + metrics_rank]]
+    o += metrics_rank
+    state_shape = [int(d) for d in shm_view[o:o + state_rank]]
+    o += state_rank
+    if state_rank == 1:
+        state_shape = [1, state_shape[0]]
+    rews = [float(r) for r in shm_view[o:o + prev_n]]
+    o += prev_n
+    n_metrics = int(np.prod(metrics_shape)) if metrics_rank else 0
+    metrics = np.array(shm_view[o:o + n_metrics], dtype=np.float32).reshape(metrics_shape if metrics_rank else (0,))
+    o += n_metrics
+    n_obs = int(np.prod(state_shape))
+    obs = np.array(shm_view[o:o + n_obs], dtype=np.float32).reshape(state_shape)
+    return prev_n, done, truncated, rews, metrics, obs
+
+
+class _ProcessWorker:
+    """Learner-side end of one worker process: a UDP socket bound to 127.0.0.1 and the worker's slab of the shared array."""
+
+    def __init__(self, proc_id, ctx, shm_buffer, shm_size, seed, render, render_delay, target):
+        self.sock = socket.socket(socket.AF_INET, socket.SOCK_DGRAM)
+        self.sock.bind(("127.0.0.1", 0))
+        offset = proc_id * shm_size * 4
+        self.proc = ctx.Process(target=target, args=(proc_id, self.sock.getsockname(), shm_buffer, offset, shm_size, seed, render,
+                                                      render_delay), daemon=True)
+        self.proc.start()
+        self.shm_view = np.frombuffer(shm_buffer, dtype=np.float32, offset=offset, count=shm_size)
+        self.child = None
+        self._actions_header = C.pack_message(C.POLICY_ACTIONS_HEADER)
+
+    def handshake(self, build_env_fn, metrics_fn):
+        _, self.child = self.sock.recvfrom(1)  # the worker's hello datagram: its source address is its endpoint
+        self.sock.sendto(pickle.dumps((C.INIT_TAG, build_env_fn, metrics_fn)), self.child)
+
+    def send_actions(self, actions):
+        self.sock.sendto(self._actions_header + np.ascontiguousarray(actions, dtype=np.float32).tobytes(), self.child)
+
+    def request_shapes(self):
+        self.sock.sendto(C.pack_message(C.ENV_SHAPES_HEADER), self.child)
+
+    def recv(self):
+        """Next message from the worker as a tuple, or None for a datagram that is not one of the protocol's."""
+        data = self.sock.recv(C.PACKET_MAX_SIZE)
+        header = C.header_of(data)
+        if header is None:
+            return None
+        if header[0] == C.ENV_STEP_DATA_HEADER[0]:
+            return (STEP_DATA,) + parse_step_slab(self.shm_view)
+        floats = np.frombuffer(data, dtype=np.float32)
+        if header == C.ENV_RESET_STATE_HEADER:
+            rank = int(floats[C.HEADER_LEN])
+            shape = [int(d) for d in floats[C.HEADER_LEN + 1:C.HEADER_LEN + 1 + rank]]
+            if rank == 1:
+                shape = [1, shape[0]]
+            return (RESET_STATE, np.array(floats[C.HEADER_LEN + 1 + rank:], dtype=np.float32).reshape(shape))
+        if header == C.ENV_SHAPES_HEADER:
+            return (ENV_SHAPES,) + tuple(float(x) for x in floats[C.HEADER_LEN:C.HEADER_LEN + 3])
+        return None
+
+    def fileno(self):
+        return self.sock.fileno()
+
+    def stop(self):
+        try:
+            if self.child is not None:
+                self.sock.sendto(C.pack_message(C.STOP_MESSAGE_HEADER), self.child)
+            self.proc.join(timeout=5)
+        finally:
+            self.sock.close()
+
 
 class _LocalWorker:
-    """n_processes=0: the environment lives in the learner process (useful for vectorised / synthetic envs)."""
+    """n_processes=0: the environment lives in the learner process (useful for vectorised / synthetic envs); same messages,
+    no transport."""
 
     def __init__(self, build_env_fn, metrics_fn, seed):
         self.env = build_env_fn()
@@ -27,22 +115,22 @@ class _LocalWorker:
         if hasattr(self.env.action_space, "seed"):
             self.env.action_space.seed(seed)
         self.obs = _as_f32(self.env.reset())
-        self.inbox = [(C.RESET_STATE, self.obs)]
+        self.inbox = [(RESET_STATE, self.obs)]
 
-    def send(self, msg):
-        if msg[0] == C.POLICY_ACTIONS:
-            prev_n = self.obs.shape[0]
-            step = self.env.step(np.asarray(msg[1]).reshape(prev_n, -1))
-            nxt, rew, done, truncated, info = step if len(step) == 5 else (step[0], step[1], step[2], False, step[3])
-            rew = [float(rew)] if np.ndim(rew) == 0 else [float(r) for r in rew]
-            if done or truncated:
-                nxt = self.env.reset()
-            self.obs = _as_f32(nxt)
-            metrics = self.metrics_fn(info["state"]) if self.metrics_fn is not None else np.empty((0,), np.float32)
-            self.inbox.append((C.STEP_DATA, prev_n, 1.0 if done else 0.0, 1.0 if truncated else 0.0, rew, metrics, self.obs))
-        elif msg[0] == C.ENV_SHAPES:
-            n_acts, code = describe_action_space(self.env.action_space)
-            self.inbox.append((C.ENV_SHAPES, float(np.prod(self.env.observation_space.shape)), n_acts, code))
+    def send_actions(self, actions):
+        prev_n = self.obs.shape[0]
+        step = self.env.step(np.asarray(actions).reshape(prev_n, -1))
+        nxt, rew, done, truncated, info = step if len(step) == 5 else (step[0], step[1], step[2], False, step[3])
+        rew = [float(rew)] if np.ndim(rew) == 0 else [float(r) for r in rew]
+        if done or truncated:
+            nxt = self.env.reset()
+        self.obs = _as_f32(nxt)
+        metrics = self.metrics_fn(info["state"]) if self.metrics_fn is not None else np.empty((0,), np.float32)
+        self.inbox.append((STEP_DATA, prev_n, 1.0 if done else 0.0, 1.0 if truncated else 0.0, rew, metrics, self.obs))
+
+    def request_shapes(self):
+        n_acts, code = describe_action_space(self.env.action_space)
+        self.inbox.append((ENV_SHAPES, float(np.prod(self.env.observation_space.shape)), n_acts, code))
 
     def recv(self):
         return self.inbox.pop(0)
@@ -50,7 +138,7 @@ class _LocalWorker:
     def poll(self):
         return bool(self.inbox)
 
-    def close(self):
+    def stop(self):
         if hasattr(self.env, "close"):
             self.env.close()
 
@@ -76,37 +164,45 @@ class BatchedAgentManager(object):
 
     # --------------------------------------------------------------------------------------------- set-up
     def init_processes(self, n_processes, build_env_fn, collect_metrics_fn=None, spawn_delay=None, render=False,
-                       render_delay=None, shm_buffer_size=8192):
+                       render_delay=None, shm_buffer_size=8192, worker_target=None):
+        """Spawns the env workers (reference signature, batched_agent_manager.py:398-406) and returns (obs size, n actions,
+        action space type).  `shm_buffer_size`: BYTES of shared memory per worker for one step's data.  `worker_target`
+        (not in the reference): the process entry point -- any function with the reference worker's signature and wire
+        behaviour, e.g. the reference's own batched_agent_process."""
         self.n_procs = max(1, n_processes)
         n = self.n_procs
         self.ep_rews = [[0] for _ in range(n)]
         self.trajectory_map = [BatchedTrajectory() for _ in range(n)]
         self.current_obs = [None] * n
         self.next_obs = [None] * n
+        self.selector = selectors.DefaultSelector()
         if n_processes <= 0:
-            self.processes = [(None, _LocalWorker(build_env_fn, collect_metrics_fn, self.seed))]
+            self.processes = [_LocalWorker(build_env_fn, collect_metrics_fn, self.seed)]
         else:
             methods = mp.get_all_start_methods()
             ctx = mp.get_context("forkserver" if "forkserver" in methods else "spawn")
+            self.shm_size = shm_buffer_size // 4
+            self.shm_buffer = multiprocessing.sharedctypes.RawArray("f", n * self.shm_size)
+            target = worker_target or batched_agent_process
             self.processes = []
             for pid in range(n):
-                parent, child = ctx.Pipe()
-                proc = ctx.Process(target=batched_agent_process,
-                                   args=(pid, child, self.seed + pid, pid == 0 and render, render_delay), daemon=True)
-                proc.start()
-                child.close()
+                w = _ProcessWorker(pid, ctx, self.shm_buffer, self.shm_size, self.seed + pid, pid == 0 and render, render_delay, target)
+                self.selector.register(w.sock, selectors.EVENT_READ, pid)
+                self.processes.append(w)
+            for w in self.processes:
+                w.handshake(build_env_fn, collect_metrics_fn)
                 if spawn_delay is not None:
                     time.sleep(spawn_delay)
-                parent.send((C.INIT, build_env_fn, collect_metrics_fn))
-                self.processes.append((proc, parent))
         self._get_initial_states()
         return self._get_env_shapes()
 
     def _get_initial_states(self):
         self.current_pids = []
-        for pid, (_, conn) in enumerate(self.processes):
-            tag, obs = conn.recv()
-            assert tag == C.RESET_STATE
+        for pid, w in enumerate(self.processes):
+            msg = w.recv()
+            while msg is None or msg[0] != RESET_STATE:
+                msg = w.recv()
+            obs = msg[1]
             if self.standardize_obs:
                 if self.obs_stats is None:
                     self.obs_stats = WelfordRunningStat(shape=obs.shape[-1])
@@ -115,11 +211,11 @@ class BatchedAgentManager(object):
             self.current_pids.append(pid)
 
     def _get_env_shapes(self):
-        _, conn = self.processes[0]
-        conn.send((C.ENV_SHAPES,))
+        w = self.processes[0]
+        w.request_shapes()
         while True:
-            msg = conn.recv()
-            if msg[0] == C.ENV_SHAPES:
+            msg = w.recv()
+            if msg is not None and msg[0] == ENV_SHAPES:
                 return int(msg[1]), int(msg[2]), int(msg[3])
 
     # ------------------------------------------------------------------------------------------- rollout
@@ -137,7 +233,7 @@ class BatchedAgentManager(object):
             stop = step + o.shape[0]
             traj = self.trajectory_map[pid]
             traj.state, traj.action, traj.log_prob = inference_batch[step:stop], actions[step:stop], log_probs[step:stop]
-            self.processes[pid][1].send((C.POLICY_ACTIONS, actions[step:stop]))
+            self.processes[pid].send_actions(actions[step:stop])
             step = stop
         self.current_pids = []
 
@@ -150,19 +246,21 @@ class BatchedAgentManager(object):
             mean0, std0 = self.obs_stats.mean[0], self.obs_stats.std[0]   # scalars of feature 0 (quirk Q5)
             if self.per_feature_obs_standardization:
                 mean0, std0 = self.obs_stats.mean.reshape(-1), self.obs_stats.std.reshape(-1)  # broadcast over the rows
-        conns = {conn: pid for pid, (_, conn) in enumerate(self.processes)}
-        local = isinstance(self.processes[0][1], _LocalWorker)
+        local = isinstance(self.processes[0], _LocalWorker)
         while n_collected < n_obs_per_inference:
-            ready = [c for c in conns if c.poll()] if local else wait(list(conns))
-            if local and not ready:
-                break
-            for conn in ready:
-                n_collected += self._collect_response(conns[conn], conn, collected_metrics, mean0, std0)
+            if local:
+                if not self.processes[0].poll():
+                    break
+                ready = [0]
+            else:
+                ready = [key.data for key, event in self.selector.select() if event & selectors.EVENT_READ]
+            for pid in ready:
+                n_collected += self._collect_response(pid, self.processes[pid], collected_metrics, mean0, std0)
         return collected_metrics, n_collected
 
-    def _collect_response(self, pid, conn, collected_metrics, mean0, std0):
-        msg = conn.recv()
-        if msg[0] != C.STEP_DATA:
+    def _collect_response(self, pid, worker, collected_metrics, mean0, std0):
+        msg = worker.recv()
+        if msg is None or msg[0] != STEP_DATA:
             return 0
         _, prev_n, done, truncated, rews, metrics, nxt = msg
         collected_metrics.append(metrics)
@@ -239,14 +337,14 @@ class BatchedAgentManager(object):
         return tuple(np.asarray(c) for c in cols), metrics, n_collected, time.perf_counter() - t1
 
     def cleanup(self):
-        for proc, conn in self.processes:
+        for w in self.processes:
             try:
-                if proc is not None:
-                    conn.send((C.STOP,))
-                    proc.join(timeout=5)
-                conn.close()
+                w.stop()
             except Exception:
                 import traceback
                 print("Unable to join process")
                 traceback.print_exc()
         self.processes = []
+        if getattr(self, "selector", None) is not None:
+            self.selector.close()
+            self.selector = None

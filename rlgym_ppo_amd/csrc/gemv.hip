@@ -185,8 +185,6 @@ __global__ __launch_bounds__(256) void gemv_dw_reduce_kernel(const float *__rest
     }
 }
 
-static int g_gemv = 1;  // tuning: rlppo_dbg_set(15, 0/1)
-void set_gemv(int v) { g_gemv = v; }
 // the shapes the three kernels take: padded input width a power of two in [32, 1024] (one 16-byte chunk per thread column)
 bool gemv_head_ok(int out, int kp) { return out == 1 && kp >= 32 && kp <= 1024 && (kp & (kp - 1)) == 0; }
 

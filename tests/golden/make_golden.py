@@ -414,6 +414,33 @@ def g10_checkpoint(R):
     save("g10_checkpoint", meta=np.array(json.dumps(meta)))
 
 
+def g11_wire(R):
+    """G11: what the reference's env worker (batched_agents/batched_agent.py:4-222) puts on the wire -- every datagram and,
+    after every step, its slab of the shared array -- for scripted action sequences (oracle/host.py::drive_worker is the
+    scripted learner side).  Two cases: a 2-agent environment without a metrics function, and a one-agent environment with
+    rank-1 observations, a scalar reward and a metrics function; both cross episode ends (reset) and a truncation."""
+    sys.path.insert(0, os.path.join(os.path.dirname(HERE)))
+    import synthetic_env
+    from oracle import host
+    gym = sys.modules["gym"]  # the worker imports gym for its action-space type checks: give the stub the names it reads
+    gym.spaces = types.SimpleNamespace(multi_discrete=types.SimpleNamespace(MultiDiscrete=synthetic_env.MultiDiscrete),
+                                       box=types.SimpleNamespace(Box=synthetic_env.Box))
+    from rlgym_ppo.batched_agents.batched_agent import batched_agent_process
+    out = {}
+    rs = np.random.RandomState(11)
+    cases = (("multi", synthetic_env.make_wire_env, None, [rs.randint(0, 7, (2, 1)).astype(np.float32) for _ in range(14)]),
+             ("single", synthetic_env.make_single_env, synthetic_env.step_count_metrics,
+              [rs.randint(0, 5, (1, 1)).astype(np.float32) for _ in range(9)]))
+    for tag, env_fn, metrics_fn, actions in cases:
+        rec = host.drive_worker(batched_agent_process, env_fn, metrics_fn, actions)
+        out[tag + ".reset"], out[tag + ".shapes"] = rec["reset"], rec["shapes"]
+        out[tag + ".n_steps"] = len(actions)
+        out[tag + ".actions"] = np.stack(actions)
+        for i, (h, sl) in enumerate(zip(rec["step_headers"], rec["slabs"])):
+            out[f"{tag}.hdr{i}"], out[f"{tag}.slab{i}"] = h, sl
+    save("g11_wire", **out)
+
+
 def main():
     if not os.path.isdir(REF):
         raise SystemExit("reference tree not present: fixtures can only be regenerated in the build container")
@@ -428,6 +455,7 @@ def main():
     g8_fifo(R)
     g9_other_heads(R)
     g10_checkpoint(R)
+    g11_wire(R)
 
 
 if __name__ == "__main__":

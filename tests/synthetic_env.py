@@ -108,3 +108,45 @@ class SyntheticVectorEnv:
 
 def make_vector_env():
     return SyntheticVectorEnv()
+
+
+class SyntheticSingleEnv:
+    """ONE agent, rank-1 observations and a scalar reward (the shape a plain gym environment has): exercises the rank-1
+    branches of the worker <-> learner wire format; `info["state"]` carries the step count for a metrics function."""
+
+    def __init__(self, obs_dim=11, n_actions=5, ep_len=6, seed=0):
+        self.obs_dim, self.ep_len = obs_dim, ep_len
+        self.rs = np.random.RandomState(seed)
+        self.observation_space = _Space(shape=(obs_dim,))
+        self.action_space = Discrete(n=n_actions)
+        self.t = 0
+
+    def _obs(self):
+        return (self.rs.randn(self.obs_dim) * 2 + 0.5).astype(np.float32)
+
+    def reset(self):
+        self.t = 0
+        return self._obs()
+
+    def step(self, actions):
+        self.t += 1
+        rew = float(np.tanh(float(np.sum(actions)) * 0.1) + self.rs.randn() * 0.1)
+        done = self.t >= self.ep_len
+        truncated = (not done) and self.t == 4
+        return self._obs(), rew, done, truncated, {"state": self.t}
+
+    def close(self):
+        pass
+
+
+def make_single_env():
+    return SyntheticSingleEnv()
+
+
+def make_wire_env():
+    return SyntheticEnv(obs_dim=13, n_actions=7, n_agents=2, ep_len=5, seed=2)
+
+
+def step_count_metrics(state):
+    """A metrics function (what Learner passes as collect_metrics_fn): float32 vector of length 3."""
+    return np.asarray([state, 2.0 * state, -1.0], dtype=np.float32)
