@@ -351,6 +351,8 @@ static size_t train_ws_floats(const NetLayout &pol, const NetLayout &val, int64_
     int m = max_pout(pol) > max_pout(val) ? max_pout(pol) : max_pout(val);
     per_row += (size_t)(pol.n_layers - 1 + val.n_layers - 1) * (size_t)m;  // one dX buffer per layer and net
     per_row += (size_t)pol.L[0].pin;                                         // the gathered minibatch states
+    per_row += 3 + (size_t)pol.L[pol.n_layers - 1].pout;                      // gathered old log-prob, advantage, target, actions
+                                                                             // (act_dim <= the policy's output width)
     size_t bits = 0;                                                         // ReLU bitmasks of the hidden layers (1/32 of h)
     for (int l = 0; l + 1 < pol.n_layers; ++l) bits += nt_bits_floats(mb, pol.L[l].pout);
     for (int l = 0; l + 1 < val.n_layers; ++l) bits += nt_bits_floats(mb, val.L[l].pout);
@@ -496,6 +498,8 @@ int rlppo_ppo_minibatch(void *stream, const rlppo_minibatch_args *a) {
     float *const states = w;
     const int64_t ld_states = pol.L[0].pin;
     w += (size_t)mb * pol.L[0].pin;
+    float *const wmeta = w;
+    w += (size_t)mb * (3 + (size_t)pol.L[pol.n_layers - 1].pout);
     // bf16 update precision: bf16 copies of the gathered rows and of the hidden activations, and the rounded weight images
     const bool b16 = g_update_bf16 != 0;
     unsigned short *states_b = nullptr, *pactb[RLPPO_MAX_LAYERS] = {}, *vactb[RLPPO_MAX_LAYERS] = {};
@@ -520,6 +524,12 @@ int rlppo_ppo_minibatch(void *stream, const rlppo_minibatch_args *a) {
     }
     if (rc) return rc;
     const float *pol_w = b16 ? a->pol_packed_r : a->pol_packed, *val_w = b16 ? a->val_packed_r : a->val_packed;
+    // the minibatch's per-row scalars, gathered once (the loss kernels stream them)
+    RLPPO_CHECK_ARG(a->act_dim >= 1 && a->act_dim <= pol.L[pol.n_layers - 1].pout, "ppo_minibatch: act_dim=%d", a->act_dim);
+    float *g_old = wmeta, *g_adv = wmeta + mb, *g_tgt = wmeta + 2 * (size_t)mb, *g_act = wmeta + 3 * (size_t)mb;
+    rc = launch_gather_meta(st, a->idx, a->actions, a->act_dim, a->old_logp, a->advantages, a->targets, g_act, g_old, g_adv, g_tgt, mb,
+                            ring_base, ring_cap);
+    if (rc) return rc;
     // forward of both nets
     // The two networks are independent until the loss epilogue and again after it, so their launch chains run on
     // two streams (the caller's + one library-owned side stream, forked/joined with events: capturable).  Each
@@ -559,18 +569,15 @@ int rlppo_ppo_minibatch(void *stream, const rlppo_minibatch_args *a) {
     cfg.ring_cap = ring_cap;
     float *pout = pact[pol.n_layers - 1], *vout = vact[val.n_layers - 1];
     const int64_t ldp = pol.L[pol.n_layers - 1].pout, ldv = val.L[val.n_layers - 1].pout;
-    rc = launch_value_loss(side, vout, ldv, a->idx, a->targets, mb, cfg, a->stats);
+    rc = launch_value_loss(side, vout, ldv, nullptr, g_tgt, mb, cfg, a->stats);
     if (rc) return rc;
     float *vjoint = nullptr;  // the loss kernels' joint form (policy + value in one launch) is not used by this entry point
     if (a->head == RLPPO_HEAD_DISCRETE)
-        rc = launch_discrete_loss(st, pout, ldp, n_out, vjoint, ldv, a->idx, a->actions, a->old_logp, a->targets,
-                                  a->advantages, mb, cfg, a->stats);
+        rc = launch_discrete_loss(st, pout, ldp, n_out, vjoint, ldv, nullptr, g_act, g_old, g_tgt, g_adv, mb, cfg, a->stats);
     else if (a->head == RLPPO_HEAD_GAUSSIAN)
-        rc = launch_gaussian_loss(st, pout, ldp, n_out / 2, vjoint, ldv, a->idx, a->actions, a->old_logp, a->targets,
-                                  a->advantages, mb, cfg, a->stats);
+        rc = launch_gaussian_loss(st, pout, ldp, n_out / 2, vjoint, ldv, nullptr, g_act, g_old, g_tgt, g_adv, mb, cfg, a->stats);
     else if (a->head == RLPPO_HEAD_MULTIDISCRETE)
-        rc = launch_multidiscrete_loss(st, pout, ldp, vjoint, ldv, a->idx, a->actions, a->old_logp, a->targets, a->advantages,
-                                       mb, cfg, a->stats);
+        rc = launch_multidiscrete_loss(st, pout, ldp, vjoint, ldv, nullptr, g_act, g_old, g_tgt, g_adv, mb, cfg, a->stats);
     else {
         set_error("ppo_minibatch: unknown head %d", a->head);
         rc = RLPPO_ERR_ARG;

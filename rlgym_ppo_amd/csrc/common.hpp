@@ -150,6 +150,9 @@ int launch_welford_merge(hipStream_t st, int d, void *mean, void *m2, long long 
                          long long ocount, int state_f64);
 int launch_gather_rows(hipStream_t st, const float *src, int64_t ld_src, const int64_t *idx, float *dst, int width, int64_t n,
                        int64_t ring_base = 0, int64_t ring_cap = INT64_MAX);
+int launch_gather_meta(hipStream_t st, const int64_t *idx, const float *actions, int act_dim, const float *old_logp,
+                       const float *adv, const float *targets, float *g_act, float *g_old, float *g_adv, float *g_tgt, int64_t n,
+                       int64_t ring_base, int64_t ring_cap);
 int launch_pad_rows(hipStream_t, const void *, int, int64_t, int64_t, int64_t, float *, int64_t, int, float, float);
 int launch_pad_rows_vec(hipStream_t, const void *, int, int64_t, int64_t, int64_t, float *, int64_t, const float *, const float *);
 

@@ -172,7 +172,11 @@ __global__ __launch_bounds__(256, BKT == 16 ? 4 : 2) void gemm_nt_dma_kernel(con
     constexpr int RPW = 64 / CPR;    // tile rows one wave instruction fills
     constexpr int RPP = 4 * RPW;     // rows per pass of the 4 waves
     constexpr int A_IT = SBM / RPP, B_IT = BN / RPP;
-    static_assert(BN % RPP == 0, "column tile must be a whole number of staging passes");
+    // a column tile that is not a whole number of staging passes (BN = 96 at BKT = 16: 1.5 passes of 64 rows) gets one more
+    // pass issued only by the waves whose rows exist (wave-uniform branch): the 96-wide policy head then runs the BK = 16 /
+    // four-workgroups-per-CU form like the 128-multiples instead of BK = 32 at two per CU
+    constexpr int B_REM = BN % RPP;
+    static_assert(B_REM % RPW == 0, "the ragged staging pass must be whole wave instructions");
     __shared__ __attribute__((aligned(16))) float lds[2 * SBM * BKT + 2 * BN * BKT];
     float *As = lds;
     float *Bs = lds + 2 * SBM * BKT;
@@ -226,6 +230,8 @@ __global__ __launch_bounds__(256, BKT == 16 ? 4 : 2) void gemm_nt_dma_kernel(con
 #pragma unroll
         for (int i = 0; i < B_IT; ++i)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(b_rs, Bd + i * RPP * BKT, 16, b_off, kb + i * b_step, 0, 0);
+        if (B_REM != 0 && wave_u * RPW < B_REM)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(b_rs, Bd + B_IT * RPP * BKT, 16, b_off, kb + B_IT * b_step, 0, 0);
     };
 
     const int nk = K / BKT;
@@ -386,8 +392,9 @@ template <int NB>
 static int launch_nt_1(hipStream_t st, dim3 grid, int epi, const float *A, unsigned lda_b, const float *B, unsigned ldb_b,
                        const float *bias, const float *mask_src, unsigned ldm_b, float *C, unsigned ldc_b, int64_t M,
                        int K) {
-    // BK = 16 (32 KiB of LDS, four workgroups per CU) fills 64 tile rows per staging pass: column tiles of 32 / 96 take BK = 32
-    constexpr int BKT = (NB * 16) % 64 == 0 ? 16 : 32;
+    // BK = 16 (<= 32 KiB of LDS, four workgroups per CU) fills 64 tile rows per staging pass (+ a ragged pass of 32 for the
+    // 96-wide tile); the 32-wide tile (half a pass) stays at BK = 32
+    constexpr int BKT = (NB * 16) % 32 == 0 && NB * 16 >= 64 ? 16 : 32;
 #define NT(E)                                                                                                          \
     case E:                                                                                                            \
         hipLaunchKernelGGL((gemm_nt_dma_kernel<NB, E, BKT>), grid, dim3(256), 0, st, A, lda_b, B, ldb_b, bias, mask_src, \

@@ -183,7 +183,7 @@ __global__ __launch_bounds__(256) void discrete_loss_kernel(float *__restrict__ 
     float st[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
     // grid-stride over rows: statistics stay in registers, so a launch issues 5 atomics per BLOCK, not per 4 rows
     for (int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); row < mb; row += (int64_t)gridDim.x * 4) {
-        const int64_t src = ring_row(idx[row], cfg.ring_base, cfg.ring_cap);
+        const int64_t src = idx ? ring_row(idx[row], cfg.ring_base, cfg.ring_cap) : row;  // idx == null: per-row data already gathered
         float *z = logits + row * ld;
         float p[EPL], pc[EPL], lp[EPL];
         row_softmax<EPL>(z, A, lane, p, pc);
@@ -280,7 +280,7 @@ __global__ __launch_bounds__(256) void discrete_loss16_kernel(float *__restrict_
     for (int64_t base = (int64_t)blockIdx.x * 16; base < mb; base += (int64_t)gridDim.x * 16) {
         const bool live = base + grp < mb;
         const int64_t row = live ? base + grp : mb - 1;  // idle groups of the last pass shadow the last row (no stores)
-        const int64_t src = ring_row(idx[row], cfg.ring_base, cfg.ring_cap);
+        const int64_t src = idx ? ring_row(idx[row], cfg.ring_base, cfg.ring_cap) : row;  // idx == null: per-row data already gathered
         float *z = logits + row * ld + c0;
         float p[8], pc[8], lp[8];
         if (in_row) {
@@ -373,7 +373,7 @@ __global__ __launch_bounds__(256) void value_loss_kernel(float *__restrict__ vou
                                                          double *__restrict__ stats) {
     float st[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
     for (int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x; row < mb; row += (int64_t)gridDim.x * 256)
-        st[RLPPO_STAT_VLOSS] += value_row(vout + row * ldv, targets[ring_row(idx[row], cfg.ring_base, cfg.ring_cap)], cfg) * cfg.inv_mb;
+        st[RLPPO_STAT_VLOSS] += value_row(vout + row * ldv, targets[idx ? ring_row(idx[row], cfg.ring_base, cfg.ring_cap) : row], cfg) * cfg.inv_mb;
     block_stats_add(stats, st, true);
 }
 
@@ -457,7 +457,7 @@ __global__ __launch_bounds__(256) void gaussian_loss_kernel(float *__restrict__ 
     const bool active = row < mb;
     float st[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
     if (active) {
-        const int64_t src = ring_row(idx[row], cfg.ring_base, cfg.ring_cap);
+        const int64_t src = idx ? ring_row(idx[row], cfg.ring_base, cfg.ring_cap) : row;  // idx == null: per-row data already gathered
         float *yr = y + row * ld;
         float mean[MAX_K], sd[MAX_K], x[MAX_K];
         float lp = 0.f, ent = 0.f;
@@ -568,7 +568,7 @@ __global__ __launch_bounds__(256) void multidiscrete_loss_kernel(float *__restri
     const bool active = row < mb;
     float st[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
     if (active) {
-        const int64_t src = ring_row(idx[row], cfg.ring_base, cfg.ring_cap);
+        const int64_t src = idx ? ring_row(idx[row], cfg.ring_base, cfg.ring_cap) : row;  // idx == null: per-row data already gathered
         float *z = logits + row * ld;
         float ls[21], ph[21], eh[8];
         int act[8];
