@@ -164,18 +164,20 @@ def kernel_breakdown(learner):
     return rows, dominant
 
 
-TRAFFIC_JSON = "r01_traffic_v9.json"  # tools/pmc_traffic.py output of the committed PMC passes
+TRAFFIC_JSON = "r02_traffic.json"  # tools/pmc_traffic.py output of the committed PMC passes (tools/round_profile.sh)
 
 
 def pmc_traffic_for(kernel_label):
     """HBM bytes per launch of the dominant kernel, from the committed PMC passes (bench.py cannot run rocprofv3 on itself)."""
     path = os.path.join(ROOT, "profiles", TRAFFIC_JSON)
-    key = {"gemm_tn dW hidden 256x256 (x4)": "rlppo::gemm_tn_dma_kernel<32, true> {dW hidden 256x256}",
-           "gemm_tn dW L0 256x107 (x2)": "rlppo::gemm_tn_dma_kernel<32, true> {dW L0 256x107}",
-           "gemm_tn dW head 90x256": "rlppo::gemm_tn_dma_kernel<32, true> {dW head 90x256}",
-           "gemm_nt fwd hidden 256->256 +bitmask (x4)": "rlppo::gemm_nt_dma_kernel<8, 1, 16, true>",
-           "gemm_nt fwd head 256->96": "rlppo::gemm_nt_dma_kernel<6, 0, 32, false>",
-           "gemm_nt dX hidden 256->256 bitmask (x4)": "rlppo::gemm_nt_dma_kernel<8, 3, 16, true>"}.get(kernel_label)
+    key = {"gemm_tn dW hidden 256x256 (x4)": "rlppo::gemm_tn_dma_kernel<32> {dW hidden 256x256}",
+           "gemm_tn dW L0 256x107 (x2)": "rlppo::gemm_tn_dma_kernel<32> {dW L0 256x107}",
+           "gemm_tn dW head 90x256": "rlppo::gemm_tn_dma_kernel<32> {dW head 90x256}",
+           "gemm_nt fwd hidden 256->256 +bitmask (x4)": "rlppo::gemm_nt_dma_kernel<8, 1, 16, true> {fwd hidden 256->256}",
+           "gemm_nt fwd L0 128->256 +bitmask (x2 nets)": "rlppo::gemm_nt_dma_kernel<8, 1, 16, true> {fwd L0 128->256}",
+           "gemm_nt fwd head 256->96": "rlppo::gemm_nt_dma_kernel<6, 0, 16, false>",
+           "gemm_nt dX hidden 256->256 bitmask (x4)": "rlppo::gemm_nt_dma_kernel<8, 3, 16, true> {dX hidden 256->256}",
+           "gemm_nt dX head 96->256 bitmask": "rlppo::gemm_nt_dma_kernel<8, 3, 16, true> {dX head 96->256}"}.get(kernel_label)
     try:
         # tools/prof_kernels.py launches the same shapes as kernel_breakdown (M = 524,288 rows); tools/pmc_summary.py tells the
         # three dW shapes (same kernel, same grid) apart by their position in the launch cycle

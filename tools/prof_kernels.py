@@ -30,8 +30,10 @@ bits = torch.zeros(int(L.rlppo_dbg_gemm_nt_bits_bytes(M, 256)), dtype=torch.uint
 reps = int(os.environ.get("REPS", 3))
 for _ in range(reps):
     N.check(L.rlppo_dbg_gemm_nt_bits(st(), P(A256), 256, P(W), 256, P(bias), P(C256), 256, M, 256, 256, 1, P(bits)))
+    N.check(L.rlppo_dbg_gemm_nt_bits(st(), P(A128), 128, P(W), 128, P(bias), P(C256), 256, M, 256, 128, 1, P(bits)))
     N.check(L.rlppo_dbg_gemm_nt(st(), P(A256), 256, P(W), 256, P(bias), None, 0, P(C96), 96, M, 96, 256, 0))
     N.check(L.rlppo_dbg_gemm_nt_bits(st(), P(A256), 256, P(W), 256, None, P(C256), 256, M, 256, 256, 3, P(bits)))
+    N.check(L.rlppo_dbg_gemm_nt_bits(st(), P(A96), 96, P(W), 96, None, P(C256), 256, M, 256, 96, 3, P(bits)))
     N.check(L.rlppo_dbg_gemm_tn(st(), P(A256), 256, 256, P(A256b), 256, 256, P(dW), P(db), 256, 256, M, P(tn_ws), tn_ws.numel()))
     N.check(L.rlppo_dbg_gemm_tn(st(), P(A256), 256, 256, P(A128), 128, 128, P(dW), P(db), 256, 107, M, P(tn_ws), tn_ws.numel()))
     N.check(L.rlppo_dbg_gemm_tn(st(), P(A96), 96, 96, P(A256), 256, 256, P(dW), P(db), 90, 256, M, P(tn_ws), tn_ws.numel()))
@@ -42,6 +44,4 @@ R, V = d(rs.randn(n).astype(np.float32)), d(rs.randn(n + 1).astype(np.float32))
 D = d((rs.rand(n) < 0.005).astype(np.float32))
 T = torch.zeros(n, device="cuda")
 T[255::256] = 1
-for _ in range(reps * 3):
-    torch_functions.gae_device(R, D, T, V, 0.99, 0.95, 1.7)
-torch.cuda.synchronize()
+torch.cuda.synchronize()  # (the GAE scan has its own script: tools/prof_gae.py)
