@@ -93,6 +93,15 @@ int rlppo_discrete_act(void *stream, const int32_t *dims, int32_t n_layers, cons
                        const float *obs, int64_t ld_obs, int64_t n, const float *noise_q,
                        int64_t *actions, float *logp, float *probs_out, void *workspace, size_t ws_bytes);
 
+/* DiscreteFF.get_output (discrete_policy.py:34-42) and the deterministic branch of get_action (:52-57).
+ * probs_out (optional): float[n][ld_probs] = softmax of the head (clamp_probs = 0, get_output) or clamp(softmax, 1e-11, 1)
+ * (clamp_probs = 1, what get_action works on).  flat_argmax (optional): int64[1] = numpy's argmax over the FLATTENED clamped
+ * [n, n_actions] array -- the reference's deterministic action (one index for the whole batch, first occurrence of the maximum;
+ * n * n_actions < 2^32).  At least one of the two outputs must be given.  Workspace: rlppo_forward_workspace_bytes. */
+int rlppo_discrete_probs(void *stream, const int32_t *dims, int32_t n_layers, const float *packed,
+                         const float *obs, int64_t ld_obs, int64_t n, int32_t clamp_probs, float *probs_out,
+                         int64_t ld_probs, int64_t *flat_argmax, void *workspace, size_t ws_bytes);
+
 /* The selection step alone on caller-supplied probabilities p[n][ld_p] (used by tests to show index equality
  * is exact given identical probs, and by the multi-discrete head with n*8 rows of 3). */
 int rlppo_categorical_select(void *stream, const float *probs, int64_t ld_p, int64_t n, int32_t n_cat,

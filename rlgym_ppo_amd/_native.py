@@ -70,6 +70,8 @@ SIGNATURES = {
                                     c_int64, c_void_p, c_size_t]),
     "rlppo_discrete_act": (c_int32, [c_void_p, _P32, c_int32, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p,
                                      c_void_p, c_void_p, c_void_p, c_size_t]),
+    "rlppo_discrete_probs": (c_int32, [c_void_p, _P32, c_int32, c_void_p, c_void_p, c_int64, c_int64, c_int32, c_void_p,
+                                       c_int64, c_void_p, c_void_p, c_size_t]),
     "rlppo_categorical_select": (c_int32, [c_void_p, c_void_p, c_int64, c_int64, c_int32, c_void_p, c_void_p, c_void_p]),
     "rlppo_gaussian_act": (c_int32, [c_void_p, _P32, c_int32, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_float,
                                      c_float, c_void_p, c_void_p, c_void_p, c_size_t]),

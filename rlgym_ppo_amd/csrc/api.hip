@@ -254,6 +254,23 @@ int rlppo_discrete_act(void *stream, const int32_t *dims, int32_t n_layers, cons
     return launch_discrete_sample_logits((hipStream_t)stream, o, ldo, n, dims[n_layers], noise_q, actions, logp, probs_out);
 }
 
+int rlppo_discrete_probs(void *stream, const int32_t *dims, int32_t n_layers, const float *packed, const float *obs,
+                         int64_t ld_obs, int64_t n, int32_t clamp_probs, float *probs_out, int64_t ld_probs,
+                         int64_t *flat_argmax, void *workspace, size_t ws_bytes) {
+    NetLayout net;
+    int rc = make_layout(dims, n_layers, &net);
+    if (rc) return rc;
+    if (n == 0) return 0;
+    RLPPO_CHECK_ARG(n > 0 && packed && obs && workspace && (probs_out || flat_argmax), "discrete_probs: bad argument");
+    RLPPO_CHECK_ARG(!probs_out || ld_probs >= dims[n_layers], "discrete_probs: ld_probs %lld < n_actions %d", (long long)ld_probs,
+                    dims[n_layers]);
+    const float *o;
+    int64_t ldo;
+    rc = forward_pingpong((hipStream_t)stream, net, packed, obs, ld_obs, n, 0, workspace, ws_bytes, nullptr, &o, &ldo);
+    if (rc) return rc;
+    return launch_discrete_probs((hipStream_t)stream, o, ldo, n, dims[n_layers], clamp_probs != 0, probs_out, ld_probs, flat_argmax);
+}
+
 int rlppo_categorical_select(void *stream, const float *probs, int64_t ld_p, int64_t n, int32_t n_cat,
                              const float *noise_q, int64_t *actions, float *logp) {
     if (n == 0) return 0;

@@ -113,6 +113,8 @@ __host__ __device__ __forceinline__ int64_t ring_row(int64_t i, int64_t base, in
     return r >= cap ? r - cap : r;
 }
 int launch_discrete_sample_logits(hipStream_t, const float *, int64_t, int64_t, int, const float *, int64_t *, float *, float *);
+int launch_discrete_probs(hipStream_t st, const float *logits, int64_t ld, int64_t n, int A, int clamp, float *probs,
+                          int64_t ld_p, int64_t *flat_argmax);
 int launch_categorical_select(hipStream_t, const float *, int64_t, int64_t, int, const float *, int64_t *, float *);
 int launch_gaussian_sample(hipStream_t, const float *, int64_t, int64_t, int, const float *, float, float, float *, float *);
 int launch_multidiscrete_sample(hipStream_t, const float *, int64_t, int64_t, const float *, int64_t *, float *);

@@ -132,6 +132,80 @@ int launch_categorical_select(hipStream_t st, const float *probs, int64_t ld, in
     return launch_discrete_sample<true>(st, probs, ld, n, A, noise, actions, logp, nullptr);
 }
 
+// ---------------------------------------------------------------- discrete: probabilities / deterministic choice
+// DiscreteFF.get_output (discrete_policy.py:34-42: softmax) and the deterministic branch of get_action (:52-57: clamp, then
+// numpy's argmax over the FLATTENED [n, A] array -- quirk Q11: one index for the whole batch, first occurrence of the maximum).
+// The flat arg-max is one 64-bit atomic max per row on key = (float bits of the row maximum << 32) | ~flat index: clamped
+// probabilities are positive, so their bit patterns order like the values, and of equal values the smaller flat index wins.
+template <int EPL>
+__global__ __launch_bounds__(256) void discrete_probs_kernel(const float *__restrict__ logits, int64_t ld, int64_t n, int A,
+                                                              int clamp, float *__restrict__ probs, int64_t ld_p,
+                                                              unsigned long long *__restrict__ key) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n) return;
+    float p[EPL], pc[EPL];
+    row_softmax<EPL>(logits + row * ld, A, lane, p, pc);
+    float best = -1.f;
+    int besti = 0x7fffffff;
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) {
+        const int c = lane + 64 * e;
+        if (c < A) {
+            if (probs) probs[row * ld_p + c] = clamp ? pc[e] : p[e];
+            if (pc[e] > best) {
+                best = pc[e];
+                besti = c;
+            }
+        }
+    }
+    if (!key) return;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(best, o);
+        const int oi = __shfl_xor(besti, o);
+        if (ov > best || (ov == best && oi < besti)) {
+            best = ov;
+            besti = oi;
+        }
+    }
+    if (lane == 0) {
+        const unsigned long long flat = (unsigned long long)(row * A + besti);
+        atomicMax(key, ((unsigned long long)__float_as_uint(best) << 32) | (0xffffffffull - flat));
+    }
+}
+__global__ void decode_flat_argmax_kernel(unsigned long long *key) {
+    *(long long *)key = (long long)(0xffffffffull - (*key & 0xffffffffull));
+}
+
+int launch_discrete_probs(hipStream_t st, const float *logits, int64_t ld, int64_t n, int A, int clamp, float *probs,
+                          int64_t ld_p, int64_t *flat_argmax) {
+    if (n <= 0) return 0;
+    if (flat_argmax && (unsigned long long)n * (unsigned long long)A > 0xffffffffull) {
+        set_error("discrete_probs: n * n_actions exceeds the 32-bit flat index of the arg-max key");
+        return RLPPO_ERR_ARG;
+    }
+    unsigned long long *key = (unsigned long long *)flat_argmax;
+    if (key) RLPPO_HIP(hipMemsetAsync(key, 0, sizeof(*key), st));
+    dim3 grid((unsigned)cdiv(n, 4)), block(256);
+    if (A <= 128)
+        hipLaunchKernelGGL((discrete_probs_kernel<2>), grid, block, 0, st, logits, ld, n, A, clamp, probs, ld_p, key);
+    else if (A <= 512)
+        hipLaunchKernelGGL((discrete_probs_kernel<8>), grid, block, 0, st, logits, ld, n, A, clamp, probs, ld_p, key);
+    else if (A <= 2048)
+        hipLaunchKernelGGL((discrete_probs_kernel<32>), grid, block, 0, st, logits, ld, n, A, clamp, probs, ld_p, key);
+    else {
+        set_error("discrete head: n_actions=%d > 2048 unsupported", A);
+        return RLPPO_ERR_ARG;
+    }
+    RLPPO_LAUNCH_CHECK();
+    if (key) {
+        hipLaunchKernelGGL(decode_flat_argmax_kernel, dim3(1), dim3(1), 0, st, key);
+        RLPPO_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
 // ------------------------------------------------------------------------------------ shared loss pieces
 // d/d(ratio) of min(ratio*A, clamp(ratio)*A), divided by A
 __device__ __forceinline__ float surrogate_weight(float ratio, float adv, const LossCfg &c, float &s_min) {

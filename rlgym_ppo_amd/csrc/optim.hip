@@ -480,8 +480,12 @@ int launch_clip_adam_pack2(hipStream_t st, const NetLayout *nets, float *const *
         N.max_norm = max_norm[k]; N.step_size = step_size[k]; N.bc2_sqrt = bc2_sqrt[k]; N.omb1 = omb1[k]; N.beta2 = beta2[k];
         N.omb2 = omb2[k]; N.eps = eps[k];
         fill_jobs(nets[k], &N.jobs);
-        RLPPO_HIP(hipMemsetAsync(gnorm2[k], 0, sizeof(double), st));
         nmax = n[k] > nmax ? n[k] : nmax;
+    }
+    if (gnorm2[1] == gnorm2[0] + 1 || gnorm2[0] == gnorm2[1] + 1) {  // adjacent accumulators (PPOLearner's): one fill
+        RLPPO_HIP(hipMemsetAsync(gnorm2[0] < gnorm2[1] ? gnorm2[0] : gnorm2[1], 0, 2 * sizeof(double), st));
+    } else {
+        for (int k = 0; k < 2; ++k) RLPPO_HIP(hipMemsetAsync(gnorm2[k], 0, sizeof(double), st));
     }
     const int blocks = (int)(cdiv(nmax, 256) < 1024 ? cdiv(nmax, 256) : 1024);
     hipLaunchKernelGGL(sqnorm2_kernel, dim3(blocks, 2), dim3(256), 0, st, o);

@@ -20,14 +20,23 @@ class DiscreteFF(ArenaModule):
         self.n_actions = int(n_actions)
         self._finish(device)
 
+    def _probs(self, rows, clamp, want_probs=True, want_argmax=False):
+        """rlppo_discrete_probs on padded device rows: softmax (or clamp(softmax)) [n, n_actions] and/or the flat arg-max."""
+        a = self.arena
+        n = rows.shape[0]
+        a.ensure_packed()
+        probs = torch.empty(n, self.n_actions, dtype=torch.float32, device=a.device) if want_probs else None
+        best = torch.empty(1, dtype=torch.int64, device=a.device) if want_argmax else None
+        ws = a.forward_ws(n)
+        N.check(N.lib().rlppo_discrete_probs(stream_ptr(), a.dims_c, a.n_layers, ptr(a.packed), ptr(rows), rows.shape[1], n, int(clamp),
+                                             ptr(probs) if want_probs else None, self.n_actions, ptr(best) if want_argmax else None,
+                                             ptr(ws), ws.numel()))
+        return probs, best
+
     @torch.no_grad()
     def get_output(self, obs):
         """Softmax probabilities [n, n_actions] on the device (discrete_policy.py:34-42)."""
-        rows = self.arena.stage_obs(obs)
-        logits = self.arena.forward(rows)[:, :self.n_actions]
-        # softmax of 90 numbers per row is not worth a kernel of its own for this compatibility accessor;
-        # get_action() below uses the fused kernel.
-        return torch.softmax(logits, dim=-1)
+        return self._probs(self.arena.stage_obs(obs), clamp=False)[0]
 
     @torch.no_grad()
     def get_action(self, obs, deterministic=False, noise=None, standardize=None):
@@ -41,9 +50,8 @@ class DiscreteFF(ArenaModule):
                 return out
         rows = a.stage_obs(obs, standardize)
         n = rows.shape[0]
-        if deterministic:
-            probs = torch.clamp(torch.softmax(a.forward(rows)[:, :self.n_actions], dim=-1), min=1e-11, max=1)
-            return probs.cpu().numpy().argmax(), 0  # quirk Q11: flat argmax over the whole batch
+        if deterministic:  # quirk Q11: numpy's argmax over the flattened clamped [n, A] array -- one index for the whole batch
+            return np.int64(self._probs(rows, clamp=True, want_probs=False, want_argmax=True)[1].item()), 0
         actions, logp = self.act_padded(rows, noise)
         return actions.cpu(), logp.cpu()
 

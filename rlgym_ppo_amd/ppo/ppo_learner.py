@@ -137,6 +137,9 @@ class PPOLearner(object):
 
         self.policy_optimizer = FusedAdam(self.policy, lr=policy_lr)
         self.value_optimizer = FusedAdam(self.value_net, lr=critic_lr)
+        # both squared-norm accumulators side by side: rlppo_clip_adam_pack2 then clears them with one fill
+        self._gnorm2 = torch.zeros(2, dtype=torch.float64, device=self._dev)
+        self.policy_optimizer.gnorm2, self.value_optimizer.gnorm2 = self._gnorm2[0:1], self._gnorm2[1:2]
 
         n_pol = sum(p.numel() for p in self.policy.parameters() if p.requires_grad)
         n_val = sum(p.numel() for p in self.value_net.parameters() if p.requires_grad)
@@ -230,6 +233,7 @@ class PPOLearner(object):
         n_batches = total // B if B > 0 else 0
 
         t1 = time.time()
+        grads_zero = False
         if n_batches > 0 and total > 0:
             if exp.ring()[0]["actions"][:1].reshape(1, -1).shape[1] != self._act_dim:
                 raise ValueError("experience buffer action width does not match the policy head")
@@ -240,7 +244,6 @@ class PPOLearner(object):
             # stream (engine.LegacyPermutation / DeviceIndexRing): here an epoch only orders the stream after that copy.
             # With 8 ranks the GPU share of an epoch is ~1.1 ms; the serial stream phase (~0.8 ms per 512k indices) is
             # the only part of the shuffle that cannot be spread over threads.
-            grads_zero = False
             for epoch in range(self.n_epochs):
                 idx_dev = exp.epoch_indices_device()
                 for b in range(n_batches):
@@ -286,12 +289,13 @@ class PPOLearner(object):
         # mean over the passes of ALL ranks even when the slices do not divide evenly over them (3 slices on 2 ranks)
         self._stats[N.STAT_PASSES] += float(n_passes)
         all_reduce_sum(self._stats, dist)
-        stats = self._stats.cpu().numpy()  # the only device->host sync of learn()
+        # update magnitudes (ppo_learner.py:214-222: fp32 norms) travel with the statistics: ONE device->host sync per learn()
+        mags = torch.stack(((policy_before - pa.flat).norm(), (critic_before - va.flat).norm()))
+        stats = torch.cat((self._stats, mags.double())).cpu().numpy()
         elapsed = time.time() - t1
         n_iter_r = max(n_iterations, 1)
         n_mb_r = max(float(stats[N.STAT_PASSES]), 1.0)
-        policy_update_magnitude = (policy_before - pa.flat).norm().item()
-        critic_update_magnitude = (critic_before - va.flat).norm().item()
+        policy_update_magnitude, critic_update_magnitude = float(stats[N.N_STATS]), float(stats[N.N_STATS + 1])
         self.cumulative_model_updates += n_iter_r
 
         report = {
@@ -304,8 +308,8 @@ class PPOLearner(object):
             "Policy Update Magnitude": policy_update_magnitude,
             "Value Function Update Magnitude": critic_update_magnitude,
         }
-        self.policy_optimizer.zero_grad()
-        self.value_optimizer.zero_grad()
+        if not grads_zero:  # the fused optimiser step leaves the arena zeroed
+            self._grad_all.zero_()
         return report
 
     # ---------------------------------------------------------------------------------------- checkpoints

@@ -399,6 +399,44 @@ def test_g1_discrete_act(L, golden):
     np.testing.assert_allclose(lp2.cpu().numpy(), g["logp"], rtol=1e-6, atol=1e-6)
 
 
+@pytest.mark.parametrize("A", [90, 300, 1000])
+def test_discrete_probs_and_deterministic_choice(L, golden, A):
+    """rlppo_discrete_probs = DiscreteFF.get_output (softmax) and the deterministic branch of get_action: clamp(1e-11, 1), then
+    numpy's argmax over the FLATTENED [n, A] array (discrete_policy.py:52-57, quirk Q11) -- first occurrence of the maximum."""
+    g = golden("g1_discrete_forward")
+    if A == 90:  # the reference's own numbers
+        net = Net(L, nets.params_from_state(g, "p."))
+        rows = net.pad(g["obs"])
+        probs, best, w = torch.full((64, 96), float("nan"), device="cuda"), torch.full((1,), -7, dtype=torch.int64, device="cuda"), net.ws(64)
+        check(L, L.rlppo_discrete_probs(stream(), net.dims_c, net.nl, P(net.packed), P(rows), net.ld_in, 64, 1, P(probs), 96, P(best),
+                                        P(w), w.numel()))
+        assert relerr(probs[:, :90], g["probs"]) < 1e-5 and torch.isnan(probs[:, 90:]).all()  # ld_probs respected
+        assert int(best) == int(g["det_action"]) == int(probs[:, :90].cpu().numpy().argmax())
+    rs = np.random.RandomState(A)
+    n, d = 777, 40
+    params = [(torch.as_tensor(rs.randn(A, d).astype(np.float32)), torch.as_tensor(rs.randn(A).astype(np.float32) * 3))]
+    params[0][1][5] = 60.0  # softmax underflows below 1e-11 elsewhere in those rows -> the clamp is visible
+    net = Net(L, params)
+    obs = rs.randn(n, d).astype(np.float32)
+    rows, w = net.pad(obs), net.ws(n)
+    soft, clamped = torch.empty(n, A, device="cuda"), torch.empty(n, A, device="cuda")
+    best = torch.empty(1, dtype=torch.int64, device="cuda")
+    check(L, L.rlppo_discrete_probs(stream(), net.dims_c, net.nl, P(net.packed), P(rows), net.ld_in, n, 0, P(soft), A, None, P(w), w.numel()))
+    check(L, L.rlppo_discrete_probs(stream(), net.dims_c, net.nl, P(net.packed), P(rows), net.ld_in, n, 1, P(clamped), A, P(best), P(w), w.numel()))
+    ref = torch.softmax(nets.mlp(params, torch.as_tensor(obs)).double(), -1)
+    assert relerr(soft, ref) < 2e-6 and float(soft.min()) < 1e-11
+    assert torch.equal(clamped, soft.clamp(min=1e-11, max=1))
+    assert int(best) == int(clamped.cpu().numpy().argmax())  # exact given the library's own probabilities
+    # ties: a bias-only head gives every row the same probabilities with the maximum at two columns -> the first column of row 0
+    bias = torch.zeros(A)
+    bias[[A - 3, 17]] = 4.0
+    tie = Net(L, [(torch.zeros(A, d), bias)])
+    only = torch.empty(1, dtype=torch.int64, device="cuda")
+    check(L, L.rlppo_discrete_probs(stream(), tie.dims_c, tie.nl, P(tie.packed), P(rows), tie.ld_in, n, 1, None, 0, P(only), P(w), w.numel()))
+    assert int(only) == 17
+    assert L.rlppo_discrete_probs(stream(), tie.dims_c, tie.nl, P(tie.packed), P(rows), tie.ld_in, n, 1, None, 0, None, P(w), w.numel()) != 0
+
+
 def test_categorical_select_exact_at_scale(L):
     # 4096 x 90 (the rollout shape of BASELINE configs[1]): identical probs + identical noise => identical indices
     torch.manual_seed(3)
