@@ -591,19 +591,29 @@ def main():
             print(json.dumps(out), flush=True)
 
     if world > 1 and args.allreduce == "ab" and not dryrun:
-        # watchdog: the direct communicator has its first multi-rank run here; if the A/B wedges, every rank still leaves with
-        # the headline line printed
-        import threading
-        done = threading.Event()
+        # The direct communicator has its first multi-rank run here.  Whatever happens to the A/B, every rank leaves and rank 0
+        # has printed the headline line: a watchdog thread prints it and exits the process if the A/B has not finished within
+        # 120 s, or as soon as SIGTERM arrives (the launcher tearing the job down because another rank died) -- the signal
+        # reaches the thread through a wake-up descriptor, so it is seen even while the main thread is blocked in a collective.
+        import select, signal, socket, threading
+        rd, wr = socket.socketpair()
+        wr.setblocking(False)
+        signal.signal(signal.SIGTERM, lambda *_: None)
+        signal.set_wakeup_fd(wr.fileno())
 
         def bail():
-            if not done.wait(120.0):
-                out["allreduce"] = {"error": "A/B did not finish within 120 s; skipped"}
-                emit()
-                os._exit(0)
+            ready, _, _ = select.select([rd], [], [], 120.0)
+            got = rd.recv(16) if ready else b""
+            if got[:1] == b"\0":  # the A/B finished
+                return
+            out["allreduce"] = {"error": "A/B skipped: " + ("terminated by signal %d" % got[0] if got else "not finished within 120 s")}
+            emit()
+            os._exit(0)
         threading.Thread(target=bail, daemon=True).start()
         out["allreduce"] = allreduce_ab(learner, buf, max(1, min(args.steps, 5)), world, device, dist)
-        done.set()
+        wr.send(b"\0")
+        signal.set_wakeup_fd(-1)
+        signal.signal(signal.SIGTERM, signal.SIG_DFL)
     if rank == 0 and world == 1 and not args.no_extras and args.config == "cfg5":
         out.update(cfg5_rooflines(value, bf16, learner))
     if rank == 0 and world == 1 and not args.no_extras and args.config == "cfg2":

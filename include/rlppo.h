@@ -338,6 +338,12 @@ int rlppo_dbg_gemm_nt_bits(void *stream, const float *A, int64_t lda, const floa
 int rlppo_dbg_gemm_nt_b16(void *stream, const void *A, int64_t lda, const void *W, int64_t ldw, const float *bias, float *C,
                           int64_t ldc, void *Cb, int64_t ldcb, int64_t M, int32_t N, int32_t K, int32_t epilogue, int32_t hidden,
                           void *bits);
+/* hidden == 2 is the backward product of that precision: Cb[M][N] (bf16) = round_bf16(A . W^T) masked by the ReLU bitmask `bits`
+ * the hidden forward of the same M x N geometry wrote (epilogue 3, bias and C NULL; N % 128 == 0, K % 64 == 0).
+ * rlppo_dbg_gemm_tn_b16: the weight-gradient product of that precision, dW[out][in] += dY^T . X, db[out] += colsum(dY), both
+ * operands bf16 [M][ld] with pout / pin (multiples of 128) columns of which out / in are meaningful; workspace as rlppo_dbg_gemm_tn. */
+int rlppo_dbg_gemm_tn_b16(void *stream, const void *dY, int64_t ldy, const void *X, int64_t ldx, float *dW, float *db, int32_t pout,
+                          int32_t pin, int32_t out, int32_t in, int64_t M, void *ws, size_t ws_bytes);
 /* dW[out][in] += dY^T . X, db[out] += colsum(dY) through partial tiles in `ws` (rlppo_dbg_gemm_tn_workspace_bytes) and a
  * fixed-order reduction: the form rlppo_ppo_minibatch uses. */
 size_t rlppo_dbg_gemm_tn_workspace_bytes(int32_t out, int32_t in, int64_t M);

@@ -70,8 +70,11 @@ _BF16_OPERANDS = [False]
 
 class bf16_operands:
     """Context manager: inside it every forward product of mlp() rounds both operands to bf16 (the build's optional bf16
-    update / rollout precision, BASELINE configs[4]); autograd through it is the fp32 backward of that forward: dX multiplies
-    dY with the rounded weights, dW with the rounded inputs, nothing in the backward pass is rounded (_RoundBF16)."""
+    update / rollout precision, BASELINE configs[4]); autograd through it is mixed-precision training as torch writes it: the
+    hidden activations are bf16 tensors (`h.bfloat16().float()`), so the gradient with respect to each of them is rounded to bf16
+    as well (autograd's cast backward is a cast) and EVERY product of the backward pass -- dX = dY . r(W), dW = dY^T . r(X) --
+    multiplies bf16 values with fp32 accumulation; the weights are fp32 master copies whose gradient stays fp32 (_RoundBF16:
+    the rounding of a weight has an identity backward, dW and db are never rounded)."""
 
     def __init__(self, on=True):
         self.on = on
@@ -98,9 +101,9 @@ def mlp(params, x, out_act=None):
 
 
 class _RoundBF16(torch.autograd.Function):
-    """x -> the nearest bf16 value (round-to-nearest-even), as fp32, with an IDENTITY backward.  (Plain `.bfloat16().float()`
-    would also round the GRADIENT to bf16 on the way back -- autograd's cast backward is a cast -- and the mode keeps the
-    backward pass in fp32.)"""
+    """x -> the nearest bf16 value (round-to-nearest-even), as fp32, with an IDENTITY backward: the rounding of an fp32 MASTER
+    WEIGHT (its gradient is accumulated in fp32, unrounded).  Activations use plain `.bfloat16().float()`, whose backward rounds
+    the gradient to bf16 -- the gradient of a bf16 tensor."""
 
     @staticmethod
     def forward(ctx, x):
@@ -145,11 +148,12 @@ def mlp_bf16_operands(params, x, out_act=None):
     """The build's optional rollout precision (BASELINE configs[4] "bf16 fwd / fp32 master weights"; the reference has no
     such mode): activations and weights rounded to bf16 (round-to-nearest-even) as they enter each product, fp32
     accumulation, fp32 bias and activation.  Products of two bf16 values are exact in fp32, so only the summation order
-    separates this restatement from the MFMA kernel."""
+    separates this restatement from the MFMA kernel.  Under autograd the activation casts round the gradients that flow back
+    through them (see bf16_operands)."""
     h = as_obs(x)
     for i, (w, b) in enumerate(params):
         lin = _LinearSum64.apply if _SUM64[0] else torch.nn.functional.linear
-        h = lin(_RoundBF16.apply(h), _RoundBF16.apply(w), b)
+        h = lin(h.bfloat16().float(), _RoundBF16.apply(w), b)
         if i < len(params) - 1:
             h = torch.relu(h)
     if out_act == "tanh":

@@ -373,11 +373,11 @@ static size_t train_ws_floats(const NetLayout &pol, const NetLayout &val, int64_
     size_t bits = 0;                                                         // ReLU bitmasks of the hidden layers (1/32 of h)
     for (int l = 0; l + 1 < pol.n_layers; ++l) bits += nt_bits_floats(mb, pol.L[l].pout);
     for (int l = 0; l + 1 < val.n_layers; ++l) bits += nt_bits_floats(mb, val.L[l].pout);
-    size_t b16 = 0;  // bf16 update precision: bf16 copies of the gathered states and of every hidden activation (2 B/element)
+    size_t b16 = 0;  // bf16 update precision: the gathered states, every hidden activation and its gradient as bf16 (2 B/element)
     if (g_update_bf16) {
-        size_t el = pol.L[0].pin;
-        for (int l = 0; l + 1 < pol.n_layers; ++l) el += pol.L[l].pout;
-        for (int l = 0; l + 1 < val.n_layers; ++l) el += val.L[l].pout;
+        size_t el = pol.L[0].pin;  // + per hidden layer: the activation and its gradient
+        for (int l = 0; l + 1 < pol.n_layers; ++l) el += 2 * (size_t)pol.L[l].pout;
+        for (int l = 0; l + 1 < val.n_layers; ++l) el += 2 * (size_t)val.L[l].pout;
         b16 = (el * (size_t)mb + 1) / 2 + 4;
     }
     return per_row * (size_t)mb + tn_ws_floats(pol, mb) + tn_ws_floats(val, mb) + bits + b16 + 2;  // + one partial-tile buffer per chain
@@ -425,6 +425,88 @@ static int backward(hipStream_t st, const NetLayout &net, const float *packed, c
                                     L.pin, L.pout, EPI_MASK);
         }
         if (rc) return rc;
+    }
+    return rc;
+}
+
+// Backward of one net in the bf16 update precision: the hidden activations are bf16 tensors,
+// so the gradient with respect to each of them is rounded to bf16 (dxb[l], already masked by relu'), and every product
+// multiplies bf16 values with fp32 accumulation: dW_l = dxb[l]^T . actsb[l-1] (gemm_tn_b16_kernel), dX = dxb[l] . r(W_l)
+// (gemm_nt_b16_kernel, B16_DX).  dW / db accumulate unrounded into the fp32 gradient arena.  The output layer's gradient comes
+// from the loss kernel in fp32 and its (narrow) products stay on the fp32 kernels, as do layers whose shapes the bf16 kernels
+// do not cover -- on fp32 copies of the same bf16 values, followed by the same rounding: identical mathematics.
+static int backward_b16(hipStream_t st, const NetLayout &net, const float *packed_r, const unsigned short *wb16, const float *states,
+                        const unsigned short *states_b, int64_t ld_states, int64_t mb, float *const *acts,
+                        unsigned short *const *actsb, float *const *dx, unsigned short *const *dxb, float *grad, float *tn_ws,
+                        size_t tn_floats, unsigned long long *const *bits, const bool *have_bits) {
+    const int last = net.n_layers - 1;
+    int64_t first[RLPPO_MAX_LAYERS], total = 0;  // element offsets of the layers' blocks inside the bf16 weight images
+    for (int l = 0; l < net.n_layers; ++l) {
+        first[l] = total;
+        total += (int64_t)net.L[l].pout * net.L[l].pin;
+    }
+    bool dx_f32[RLPPO_MAX_LAYERS] = {};  // dx[l] holds the fp32 copy of dxb[l]
+    int rc = 0;
+    for (int l = last; l >= 0; --l) {
+        const LayerLayout &L = net.L[l];
+        const float *X = l > 0 ? acts[l - 1] : states;
+        const unsigned short *Xb = l > 0 ? actsb[l - 1] : states_b;
+        const int64_t ldx = l > 0 ? net.L[l - 1].pout : ld_states;
+        const bool gemv = l == last && l > 0 && gemv_head_ok(L.out, L.pin);
+        // ---- dW, db
+        if (l == last) {
+            if (gemv)
+                rc = launch_gemv_dw(st, acts[last], L.pout, X, ldx, grad + L.off_flat_w, grad + L.off_flat_b, L.in, L.pin, mb, tn_ws,
+                                    tn_floats);
+            else
+                rc = launch_gemm_tn(st, acts[last], L.pout, L.pout, X, ldx, L.pin, grad + L.off_flat_w, grad + L.off_flat_b, L.out,
+                                    L.in, mb, tn_ws, tn_floats);
+        } else if (tn_b16_ok(L.pout, L.pin) && ldx % 8 == 0) {
+            rc = launch_gemm_tn_b16(st, dxb[l], L.pout, Xb, ldx, grad + L.off_flat_w, grad + L.off_flat_b, L.pout, L.pin, L.out, L.in,
+                                    mb, tn_ws, tn_floats);
+        } else {
+            if (!dx_f32[l]) {
+                rc = launch_expand_rows(st, dxb[l], dx[l], mb * (int64_t)L.pout);
+                if (rc) return rc;
+                dx_f32[l] = true;
+            }
+            rc = launch_gemm_tn(st, dx[l], L.pout, L.pout, X, ldx, L.pin, grad + L.off_flat_w, grad + L.off_flat_b, L.out, L.in, mb,
+                                tn_ws, tn_floats);
+        }
+        if (rc) return rc;
+        if (l == 0) break;
+        // ---- dX of layer l = the (rounded, masked) gradient of hidden activation l - 1
+        if (l < last && have_bits[l - 1] && nt_b16_ok(L.pin, L.pout, true)) {
+            rc = launch_gemm_nt_b16(st, dxb[l], L.pout, wb16 + total + first[l], L.pout, nullptr, nullptr, 0, dxb[l - 1], L.pin, mb,
+                                    L.pin, L.pout, EPI_MASK, 2, bits[l - 1]);
+            if (rc) return rc;
+            continue;
+        }
+        const float *dY = acts[last];
+        if (l < last) {
+            if (!dx_f32[l]) {
+                rc = launch_expand_rows(st, dxb[l], dx[l], mb * (int64_t)L.pout);
+                if (rc) return rc;
+                dx_f32[l] = true;
+            }
+            dY = dx[l];
+        }
+        rc = -1;
+        if (gemv) {
+            if (have_bits[l - 1]) rc = launch_gemv_dx_bits(st, dY, L.pout, packed_r + L.off_w, bits[l - 1], dx[l - 1], L.pin, L.pin, mb);
+            if (rc == -1) rc = launch_gemv_dx(st, dY, L.pout, packed_r + L.off_w, acts[l - 1], L.pin, dx[l - 1], L.pin, L.pin, mb);
+        } else {
+            if (have_bits[l - 1])
+                rc = launch_gemm_nt_bits(st, dY, L.pout, packed_r + L.off_wt, L.pout, nullptr, dx[l - 1], L.pin, mb, L.pin, L.pout,
+                                         EPI_MASK, bits[l - 1]);
+            if (rc == -1)
+                rc = launch_gemm_nt(st, dY, L.pout, packed_r + L.off_wt, L.pout, nullptr, acts[l - 1], L.pin, dx[l - 1], L.pin, mb,
+                                    L.pin, L.pout, EPI_MASK);
+        }
+        if (rc) return rc;
+        rc = launch_round_rows(st, dx[l - 1], dxb[l - 1], mb * (int64_t)L.pin);  // the gradient of a bf16 activation is bf16
+        if (rc) return rc;
+        dx_f32[l - 1] = true;
     }
     return rc;
 }
@@ -520,6 +602,7 @@ int rlppo_ppo_minibatch(void *stream, const rlppo_minibatch_args *a) {
     // bf16 update precision: bf16 copies of the gathered rows and of the hidden activations, and the rounded weight images
     const bool b16 = g_update_bf16 != 0;
     unsigned short *states_b = nullptr, *pactb[RLPPO_MAX_LAYERS] = {}, *vactb[RLPPO_MAX_LAYERS] = {};
+    unsigned short *pdxb[RLPPO_MAX_LAYERS] = {}, *vdxb[RLPPO_MAX_LAYERS] = {};
     if (b16) {
         RLPPO_CHECK_ARG(a->pol_packed_r && a->val_packed_r && a->pol_wb16 && a->val_wb16,
                         "ppo_minibatch: the bf16 update precision needs the rlppo_net_pack_bf16 images of both networks");
@@ -533,6 +616,14 @@ int rlppo_ppo_minibatch(void *stream, const rlppo_minibatch_args *a) {
         }
         for (int l = 0; l + 1 < val.n_layers; ++l) {
             vactb[l] = hb;
+            hb += (size_t)mb * val.L[l].pout;
+        }
+        for (int l = 0; l + 1 < pol.n_layers; ++l) {
+            pdxb[l] = hb;
+            hb += (size_t)mb * pol.L[l].pout;
+        }
+        for (int l = 0; l + 1 < val.n_layers; ++l) {
+            vdxb[l] = hb;
             hb += (size_t)mb * val.L[l].pout;
         }
         rc = launch_gather_rows_round(st, a->states, a->ld_states, a->idx, states, states_b, pol.L[0].pin, mb, ring_base, ring_cap);
@@ -601,11 +692,17 @@ int rlppo_ppo_minibatch(void *stream, const rlppo_minibatch_args *a) {
     }
     if (rc) return rc;
 
-    // (bf16 precision: the backward is the fp32 backward of the rounded-operand forward -- dX against the rounded weights, dW
-    // against the rounded inputs the forward saved -- which is what autograd computes for that forward)
-    rc = backward(side, val, val_w, states, ld_states, mb, vact, vdx, a->val_grad, val_tn_ws, tn_ws_floats(val, mb), vbits, vhave);
-    if (rc) return rc;
-    rc = backward(st, pol, pol_w, states, ld_states, mb, pact, pdx, a->pol_grad, pol_tn_ws, tn_ws_floats(pol, mb), pbits, phave);
+    if (b16) {
+        rc = backward_b16(side, val, val_w, reinterpret_cast<const unsigned short *>(a->val_wb16), states, states_b, ld_states, mb, vact,
+                          vactb, vdx, vdxb, a->val_grad, val_tn_ws, tn_ws_floats(val, mb), vbits, vhave);
+        if (rc) return rc;
+        rc = backward_b16(st, pol, pol_w, reinterpret_cast<const unsigned short *>(a->pol_wb16), states, states_b, ld_states, mb, pact,
+                          pactb, pdx, pdxb, a->pol_grad, pol_tn_ws, tn_ws_floats(pol, mb), pbits, phave);
+    } else {
+        rc = backward(side, val, val_w, states, ld_states, mb, vact, vdx, a->val_grad, val_tn_ws, tn_ws_floats(val, mb), vbits, vhave);
+        if (rc) return rc;
+        rc = backward(st, pol, pol_w, states, ld_states, mb, pact, pdx, a->pol_grad, pol_tn_ws, tn_ws_floats(pol, mb), pbits, phave);
+    }
     if (rc) return rc;
     if (side != st) rc = order_after(st, side, g_ev_join[slot]);
     return rc;
@@ -689,7 +786,7 @@ int64_t rlppo_wb16_elems(const int32_t *dims, int32_t n_layers) {
     if (make_layout(dims, n_layers, &net)) return -1;
     int64_t n = 0;
     for (int l = 0; l < net.n_layers; ++l) n += (int64_t)net.L[l].pout * net.L[l].pin;
-    return n;
+    return 2 * n;  // the W blocks, then the W^T blocks
 }
 int rlppo_net_pack_bf16(void *stream, const int32_t *dims, int32_t n_layers, const float *flat, float *packed_r, void *wb16) {
     NetLayout net;
@@ -746,7 +843,13 @@ int rlppo_dbg_gemm_nt_b16(void *stream, const void *A, int64_t lda, const void *
                           void *bits) {
     return launch_gemm_nt_b16((hipStream_t)stream, reinterpret_cast<const unsigned short *>(A), lda,
                               reinterpret_cast<const unsigned short *>(W), ldw, bias, C, ldc, reinterpret_cast<unsigned short *>(Cb),
-                              ldcb, M, N, K, epilogue, hidden != 0, reinterpret_cast<unsigned long long *>(bits));
+                              ldcb, M, N, K, epilogue, hidden, reinterpret_cast<unsigned long long *>(bits));
+}
+int rlppo_dbg_gemm_tn_b16(void *stream, const void *dY, int64_t ldy, const void *X, int64_t ldx, float *dW, float *db, int32_t pout,
+                          int32_t pin, int32_t out, int32_t in, int64_t M, void *ws, size_t ws_bytes) {
+    return launch_gemm_tn_b16((hipStream_t)stream, reinterpret_cast<const unsigned short *>(dY), ldy,
+                              reinterpret_cast<const unsigned short *>(X), ldx, dW, db, pout, pin, out, in, M, (float *)ws,
+                              ws_bytes / sizeof(float));
 }
 size_t rlppo_dbg_gemm_tn_workspace_bytes(int32_t out, int32_t in, int64_t M) { return tn_partial_floats(out, in, M) * sizeof(float); }
 int rlppo_dbg_gemm_tn(void *stream, const float *dY, int64_t ldy, int32_t ny_valid, const float *X, int64_t ldx,

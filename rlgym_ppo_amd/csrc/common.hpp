@@ -84,8 +84,11 @@ int get_infer_bf16();
 // hidden: relu, rounded output as bf16 (Cb) + fp32 (C) + ReLU bitmask; output layer (!hidden): fp32 C, epi bias / bias+tanh
 bool nt_b16_ok(int N, int K, bool hidden);
 int launch_gemm_nt_b16(hipStream_t st, const unsigned short *A, int64_t lda, const unsigned short *B, int64_t ldb, const float *bias,
-                       float *C, int64_t ldc, unsigned short *Cb, int64_t ldcb, int64_t M, int N, int K, int epi, bool hidden,
-                       unsigned long long *bits);
+                       float *C, int64_t ldc, unsigned short *Cb, int64_t ldcb, int64_t M, int N, int K, int epi, int mode,
+                       unsigned long long *bits);  // mode: 0 output layer, 1 hidden layer, 2 rounded + masked dX
+bool tn_b16_ok(int pout, int pin);
+int launch_gemm_tn_b16(hipStream_t st, const unsigned short *dY, int64_t ldy, const unsigned short *X, int64_t ldx, float *dW,
+                       float *db, int pout, int pin, int out, int in, int64_t M, float *ws, size_t ws_floats);
 // dW[n][k] += sum_m dY[m][n] X[m][k] ; db[n] += sum_m dY[m][n]: partial tiles in `ws` (>= tn_partial_floats(out, in, M)
 // floats) + a fixed-order reduction into the flat arena
 size_t tn_partial_floats(int out, int in, int64_t M);
@@ -139,6 +142,7 @@ int launch_gae(hipStream_t, const float *, const float *, const float *, const f
 int launch_pack(hipStream_t, const NetLayout &, const float *, float *);
 int launch_pack_bf16(hipStream_t st, const NetLayout &net, const float *flat, float *packed_r, unsigned short *wb16);
 int launch_round_rows(hipStream_t st, float *x, unsigned short *xb, int64_t n_elems);
+int launch_expand_rows(hipStream_t st, const unsigned short *xb, float *x, int64_t n_elems);
 int launch_gather_rows_round(hipStream_t st, const float *src, int64_t ld_src, const int64_t *idx, float *dst, unsigned short *dstb,
                              int width, int64_t n, int64_t ring_base, int64_t ring_cap);
 int launch_clip_adam(hipStream_t, float *p, float *g, float *m, float *v, int64_t n, float max_norm, float step_size,

@@ -458,8 +458,13 @@ int launch_gemm_nt_bf16(hipStream_t st, const float *A, int64_t lda, const float
 // as bf16 (the next layer's A operand, 2 B/element), as the same value in fp32 (the X operand of the fp32 weight-gradient
 // product: autograd of a forward with bf16-rounded operands multiplies dY with the ROUNDED input), and as the ReLU bitmask
 // of the dX product.  The output layer stores plain fp32 (bias or bias + tanh) for the loss kernel.
+// B16_DX is the backward product of the same precision, dX = (dY . W) rounded to bf16 and masked by relu'(h): in mixed-precision
+// training the hidden activations are bf16 tensors, so the gradient with respect to each of them is a bf16 tensor too
+//  -- A = dY[M][pout] bf16, B = W^T[pin][pout] bf16, no bias, the mask is the ReLU bitmask the
+// forward left for this tile geometry (one 8-byte word per lane, read before the K loop), the output is bf16 only.
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-template <int NB, int EPI, bool HIDDEN>
+enum { B16_OUT = 0, B16_HIDDEN = 1, B16_DX = 2 };
+template <int NB, int EPI, int MODE>
 __global__ __launch_bounds__(256, 2) void gemm_nt_b16_kernel(const unsigned short *__restrict__ A, unsigned lda_b,
                                                              const unsigned short *__restrict__ B, unsigned ldb_b,
                                                              const float *__restrict__ bias, float *__restrict__ C,
@@ -470,7 +475,9 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_b16_kernel(const unsigned shor
     constexpr int CPR = BKT / 4, RPW = 64 / CPR, RPP = 4 * RPW;
     constexpr int A_IT = SBM / RPP, B_IT = BN / RPP;
     static_assert(BN % RPP == 0, "column tile must be a whole number of staging passes");
+    constexpr bool HIDDEN = MODE == B16_HIDDEN, DX = MODE == B16_DX;
     static_assert(!HIDDEN || EPI == EPI_BIAS_RELU, "hidden layers are bias + ReLU");
+    static_assert(!DX || (EPI == EPI_MASK && NB == 8), "the dX form masks whole 128 x 128 tiles");
     __shared__ __attribute__((aligned(16))) float lds[2 * SBM * BKT + 2 * BN * BKT];
     float *As = lds;
     float *Bs = lds + 2 * SBM * BKT;
@@ -496,7 +503,12 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_b16_kernel(const unsigned shor
     const unsigned a_step = (unsigned)RPP * lda_b, b_step = (unsigned)RPP * ldb_b;
 
     f32x4 acc[2][NB];
-    {
+    unsigned long long mask_word = 0;
+    if (DX) {
+        mask_word = bits[((size_t)row_tile * gridDim.y + col_tile) * 256 + tid];
+#pragma unroll
+        for (int j = 0; j < NB; ++j) acc[0][j] = acc[1][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    } else {
         const __amdgpu_buffer_rsrc_t bias_rs = make_rsrc(bias + n0, BN * 4);
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
@@ -542,12 +554,38 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_b16_kernel(const unsigned shor
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
-    if (!HIDDEN) {
+    if (MODE == B16_OUT) {
         nt_epilogue<NB, EPI>(acc, nullptr, 0, C, ldc_b, m0, n0, rows_here, wave, r16, q);
         return;
     }
-    // relu, bitmask, one rounding to bf16; the stores come last, from registers nothing writes again (section 5 hazard rule)
     u32x2 pk[2][NB];
+    if (DX) {  // one rounding to bf16 (the gradient of a bf16 activation), then relu'(h) from the forward's bitmask
+        const unsigned lo = (unsigned)mask_word, hi = (unsigned)(mask_word >> 32);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                unsigned h[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int b = (i * NB + j) * 4 + e;
+                    const unsigned m = 0u - (((b < 32 ? lo : hi) >> (b & 31)) & 1u);  // 0 or ~0
+                    const float x = acc[i][j][e];
+                    h[e] = (unsigned)__builtin_bit_cast(unsigned short, (__bf16)x) & m;
+                }
+                pk[i][j] = u32x2{h[0] | (h[1] << 16), h[2] | (h[3] << 16)};
+            }
+        __builtin_amdgcn_sched_barrier(0);
+        const __amdgpu_buffer_rsrc_t cb_rs = make_rsrc(reinterpret_cast<char *>(Cb) + m0 * ldcb_b + (int64_t)n0 * 2,
+                                                       (unsigned)(rows_here - 1) * ldcb_b + BN * 2);
+        const unsigned cb_off = (unsigned)(wave * 32 + r16) * ldcb_b + q * 8;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < NB; ++j) __builtin_amdgcn_raw_buffer_store_b64(pk[i][j], cb_rs, cb_off, 16 * i * ldcb_b + j * 32, 0);
+        return;
+    }
+    // relu, bitmask, one rounding to bf16; the stores come last, from registers nothing writes again (section 5 hazard rule)
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -599,11 +637,18 @@ bool nt_b16_ok(int N, int K, bool hidden) {
     return hidden ? N % 128 == 0 : (N % 128 == 0 || N == 96 || N == 64 || N == 32);
 }
 
+// mode: 0 = output layer, 1 = hidden layer, 2 = masked + rounded dX (bias unused, bits read, Cb only)
 int launch_gemm_nt_b16(hipStream_t st, const unsigned short *A, int64_t lda, const unsigned short *B, int64_t ldb, const float *bias,
-                       float *C, int64_t ldc, unsigned short *Cb, int64_t ldcb, int64_t M, int N, int K, int epi, bool hidden,
+                       float *C, int64_t ldc, unsigned short *Cb, int64_t ldcb, int64_t M, int N, int K, int epi, int mode,
                        unsigned long long *bits) {
     if (M <= 0) return 0;
-    RLPPO_CHECK_ARG(nt_b16_ok(N, K, hidden) && A && B && bias, "gemm_nt (bf16 in memory): N=%d K=%d not supported", N, K);
+    const bool hidden = mode != B16_OUT;
+    RLPPO_CHECK_ARG(mode >= B16_OUT && mode <= B16_DX && nt_b16_ok(N, K, hidden) && A && B && (bias || mode == B16_DX),
+                    "gemm_nt (bf16 in memory): N=%d K=%d mode=%d not supported", N, K, mode);
+    if (mode == B16_DX) {
+        RLPPO_CHECK_ARG(epi == EPI_MASK && bits && Cb && !C, "gemm_nt (bf16 in memory): the dX form needs the bitmask and a bf16 output");
+        ldc = 0;
+    }
     RLPPO_CHECK_ARG(lda % 8 == 0 && ldb % 8 == 0 && lda >= K && ldb >= K && (!C || (ldc % 4 == 0 && ldc >= N)) &&
                         (!Cb || (ldcb % 4 == 0 && ldcb >= N)) && (C || Cb),
                     "gemm_nt (bf16 in memory): leading dimensions lda=%ld ldb=%ld ldc=%ld ldcb=%ld", (long)lda, (long)ldb, (long)ldc,
@@ -616,17 +661,19 @@ int launch_gemm_nt_b16(hipStream_t st, const unsigned short *A, int64_t lda, con
     dim3 grid((unsigned)cdiv(M, SBM), (unsigned)(N / (nb * 16)));
 #define B16(NBV, E, H)                                                                                                      \
     hipLaunchKernelGGL((gemm_nt_b16_kernel<NBV, E, H>), grid, dim3(256), 0, st, A, la, B, lb, bias, C, lc, Cb, lcb, M, K, bits)
-    if (hidden) {
+    if (mode == B16_DX) {
+        B16(8, EPI_MASK, B16_DX);
+    } else if (hidden) {
         RLPPO_CHECK_ARG(epi == EPI_BIAS_RELU, "gemm_nt (bf16 in memory): hidden layers are bias + ReLU");
-        B16(8, EPI_BIAS_RELU, true);
+        B16(8, EPI_BIAS_RELU, B16_HIDDEN);
     } else {
         RLPPO_CHECK_ARG((epi == EPI_BIAS || epi == EPI_BIAS_TANH) && C, "gemm_nt (bf16 in memory): output layer epilogue %d", epi);
         const bool th = epi == EPI_BIAS_TANH;
         switch (nb) {
-            case 8: if (th) B16(8, EPI_BIAS_TANH, false); else B16(8, EPI_BIAS, false); break;
-            case 6: if (th) B16(6, EPI_BIAS_TANH, false); else B16(6, EPI_BIAS, false); break;
-            case 4: if (th) B16(4, EPI_BIAS_TANH, false); else B16(4, EPI_BIAS, false); break;
-            default: if (th) B16(2, EPI_BIAS_TANH, false); else B16(2, EPI_BIAS, false); break;
+            case 8: if (th) B16(8, EPI_BIAS_TANH, B16_OUT); else B16(8, EPI_BIAS, B16_OUT); break;
+            case 6: if (th) B16(6, EPI_BIAS_TANH, B16_OUT); else B16(6, EPI_BIAS, B16_OUT); break;
+            case 4: if (th) B16(4, EPI_BIAS_TANH, B16_OUT); else B16(4, EPI_BIAS, B16_OUT); break;
+            default: if (th) B16(2, EPI_BIAS_TANH, B16_OUT); else B16(2, EPI_BIAS, B16_OUT); break;
         }
     }
 #undef B16
@@ -854,6 +901,165 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_dma_kernel(const float *__rest
     }
 }
 
+// ------------------------------------------------------------------------------------------------ gemm_tn, bf16 in memory
+// Weight-gradient product of the bf16 update precision: dW[n][k] = sum_m dY[m][n] X[m][k] with BOTH operands bf16 in memory
+// (dY: the rounded, masked gradient the dX kernel left; X: the rounded activation the forward left) on
+// v_mfma_f32_16x16x32_bf16, fp32 accumulation, the same partial-tile output as gemm_tn_dma_kernel (so tn_reduce_kernel, the
+// fixed summation order and the bias column sums are shared).
+// The contraction runs over ROWS of both operands, so an MFMA operand -- 8 consecutive m for one column -- is strided in
+// memory.  The stage (64 rows x 128 columns of each operand, 256-byte rows) goes global -> LDS by LDS-DMA exactly as it lies
+// in memory and is read with ds_read_b64_tr_b16, gfx950's transposing LDS read: per 16-lane group it takes a 4-row x
+// 16-column block and hands lane i column i (cdna_hip_programming.md T10).  Two reads (rows 8q..8q+3, 8q+4..8q+7) make one
+// operand.  LDS image: 16-byte chunk c of row r sits at chunk c ^ (((r & 3) << 2) | ((r >> 2) & 3)) of the row (T10 image
+// (b): the 4 rows of a block land 16 banks apart, the two blocks of a 32-lane half 8 banks apart -- conflict-free), applied
+// on the DMA's SOURCE address.  The bias gradient is one more MFMA per n block against a constant operand of ones.
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ s16x4 lds_tr16(const char *lds_base, int byte_off) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+        (s16x4 __attribute__((address_space(3))) *)(const __attribute__((address_space(3))) char *)(lds_base + byte_off));
+}
+constexpr int TNB_ROWS = 64;  // rows per stage
+__global__ __launch_bounds__(256, 2) void gemm_tn_b16_kernel(const unsigned short *__restrict__ dY, unsigned ldy_b,
+                                                             const unsigned short *__restrict__ X, unsigned ldx_b, bool with_db,
+                                                             int out, int64_t M, int rows_per_wg, float *__restrict__ partial) {
+    constexpr int TMT = TNB_ROWS, TILE_B = TMT * 256;  // bytes of one operand's stage
+    __shared__ __attribute__((aligned(16))) char lds[4 * TILE_B];  // [2 buffers][Y | X]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const int r16 = lane & 15, q = lane >> 4;
+    const int wn = wave >> 1, wk = wave & 1;
+    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;  // XCD-aware order: see gemm_tn_dma_kernel
+    {
+        const int T = gridDim.x * gridDim.y;
+        if ((gridDim.z & 7) == 0 && T > 1) {
+            const int id = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x, g = id % (8 * T);
+            const int tile = g >> 3;
+            bz = (id / (8 * T)) * 8 + (g & 7);
+            bx = tile % gridDim.x;
+            by = tile / gridDim.x;
+        }
+    }
+    const int n0 = bx * 128, k0 = by * 128;
+    const int64_t mbeg = (int64_t)bz * rows_per_wg;
+    const int rows = (int)((M - mbeg) < rows_per_wg ? (M - mbeg) : rows_per_wg);  // >= 1
+    const int steps = (rows + TMT - 1) / TMT;
+    const int rem = rows - (steps - 1) * TMT;  // rows of the last stage, 1..TMT
+
+    // DMA: waves 0,1 stage dY (rows 0..31 / 32..63 of the stage), waves 2,3 stage X; one instruction = 4 rows of 256 bytes
+    const bool is_x = wave_u >= 2;
+    const unsigned ld_b = is_x ? ldx_b : ldy_b;
+    const char *src = is_x ? reinterpret_cast<const char *>(X) + mbeg * ldx_b + (int64_t)k0 * 2
+                           : reinterpret_cast<const char *>(dY) + mbeg * ldy_b + (int64_t)n0 * 2;
+    const __amdgpu_buffer_rsrc_t rs = make_rsrc(src, (unsigned)(rows - 1) * ld_b + 256u);
+    const int half = wave_u & 1;
+    unsigned goff[4];  // per-lane source offset of row group g & 3 (the swizzle depends on (row >> 2) & 3)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int row = 32 * half + 4 * g + (lane >> 4);
+        const int lch = (lane & 15) ^ ((((lane >> 4) & 3) << 2) | (g & 3));  // (row & 3) == lane >> 4, ((row >> 2) & 3) == g & 3
+        goff[g] = (unsigned)row * ld_b + lch * 16;
+    }
+    auto issue_stage = [&](int buf, int stage) {
+        char *dst = lds + (2 * buf + (is_x ? 1 : 0)) * TILE_B + half * 32 * 256;
+        const unsigned sbase = (unsigned)stage * TMT * ld_b;
+#pragma unroll
+        for (int g = 0; g < 8; ++g)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, reinterpret_cast<float *>(dst + g * 1024), 16, goff[g & 3],
+                                                     sbase + (g >> 2) * 16 * ld_b, 0, 0);
+    };
+    // a ragged last stage: the DMA drops the rows past the split, so their (stale) LDS rows are cleared by hand
+    auto clear_tail = [&](int buf) {
+        const f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int r = rem + (tid >> 4); r < TMT; r += 16) {
+            *reinterpret_cast<f32x4 *>(lds + (2 * buf) * TILE_B + r * 256 + (tid & 15) * 16) = z;
+            *reinterpret_cast<f32x4 *>(lds + (2 * buf + 1) * TILE_B + r * 256 + (tid & 15) * 16) = z;
+        }
+    };
+
+    f32x4 acc[4][4], accb[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        accb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const bool want_db = with_db && by == 0 && (wave_u & 1) == 0;  // scalar condition: waves with wk == 0
+
+    // transposed-read addresses (bytes inside an operand's stage) of column block cb, half-octet h, for the 8-row octet q of
+    // MFMA step 0; MFMA step s adds 32 rows (the swizzle only looks at row bits 0..3, which 32 s leaves alone)
+    int ay[4][2], ax[4][2];
+    {
+        const int qq = r16 >> 2, p = r16 & 3;
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int row = 8 * q + 4 * h + qq;
+                const int sw = (qq << 2) | ((2 * q + h) & 3);
+                ay[c][h] = row * 256 + (((2 * (wn * 4 + c) + (p >> 1)) ^ sw) << 4) + 8 * (p & 1);
+                ax[c][h] = row * 256 + (((2 * (wk * 4 + c) + (p >> 1)) ^ sw) << 4) + 8 * (p & 1);
+            }
+    }
+    bf16x8 ones;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
+
+    issue_stage(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (steps == 1 && rem < TMT) clear_tail(0);
+    __syncthreads();
+    for (int st = 0; st < steps; ++st) {
+        const int cur = st & 1;
+        const bool more = (st + 1) < steps;
+        if (more) issue_stage(cur ^ 1, st + 1);
+        const char *Yc = lds + (2 * cur) * TILE_B;
+        const char *Xc = lds + (2 * cur + 1) * TILE_B;
+#pragma unroll
+        for (int s = 0; s < TMT / 32; ++s) {
+            bf16x8 fa[4], fb[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const s16x4 a0 = lds_tr16(Yc, ay[c][0] + s * 32 * 256), a1 = lds_tr16(Yc, ay[c][1] + s * 32 * 256);
+                const s16x4 b0 = lds_tr16(Xc, ax[c][0] + s * 32 * 256), b1 = lds_tr16(Xc, ax[c][1] + s * 32 * 256);
+                fa[c] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7));
+                fb[c] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7));
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+            if (want_db) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], ones, accb[i], 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);  // keep the MFMAs above the wait: they are what hides the DMA latency
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (more && (st + 2) == steps && rem < TMT) clear_tail(cur ^ 1);
+        __syncthreads();
+    }
+
+    if (want_db && r16 == 0) {  // every column of the ones product holds the same sum: lanes with k = 0 write it
+        float *pdb = partial + (size_t)gridDim.z * gridDim.y * gridDim.x * (128 * 128) + ((size_t)bz * gridDim.x + bx) * 128;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int nl = wn * 64 + i * 16 + 4 * q + e;
+                if (n0 + nl < out) pdb[nl] = accb[i][e];
+            }
+    }
+    {  // partial tile, the layout tn_reduce_kernel reads; last instructions of the wave (store-data hazard rule)
+        const size_t tile_id = (size_t)bz * (gridDim.x * gridDim.y) + (size_t)by * gridDim.x + bx;
+        const __amdgpu_buffer_rsrc_t p_rs = make_rsrc(partial + tile_id * (128 * 128), 128 * 128 * 4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) stb(p_rs, (unsigned)tid * 16, (unsigned)(i * 4 + j) * 4096, acc[i][j]);
+    }
+}
+
 // Sums the partial tiles of gemm_tn_dma_kernel over the splits and adds the result into dW[out][in].
 // Block = 64 consecutive 16-byte elements of one tile x 4 split lanes (one wave each: 1 KiB coalesced per load, 8 loads
 // in flight); the four partial sums meet in LDS.  The final add is an atomic only so that launches of different
@@ -956,6 +1162,34 @@ int launch_gemm_tn(hipStream_t st, const float *dY, int64_t ldy, int ny_valid, c
     dim3 grid((unsigned)tiles_x, (unsigned)tiles_y, (unsigned)splits);
     hipLaunchKernelGGL((gemm_tn_dma_kernel<TM>), grid, dim3(256), 0, st, dY, (unsigned)(ldy * 4), ny_valid, X,
                        (unsigned)(ldx * 4), kx_valid, db != nullptr, out, in, M, rows_per_wg, ws);
+    RLPPO_LAUNCH_CHECK();
+    hipLaunchKernelGGL(tn_reduce_kernel, dim3(64, (unsigned)(tiles_x * tiles_y)), dim3(256), 0, st, ws, splits, tiles_x,
+                       tiles_x * tiles_y, dW, db, out, in);
+    RLPPO_LAUNCH_CHECK();
+    return 0;
+}
+// The bf16-in-memory form of launch_gemm_tn: padded widths pout / pin multiples of 128 (whole tiles; the operands' columns
+// beyond out / in are zero padding), leading dimensions in elements; dW[out][in], db[out] are the unpadded gradient arrays.
+bool tn_b16_ok(int pout, int pin) { return pout > 0 && pin > 0 && pout % 128 == 0 && pin % 128 == 0; }
+int launch_gemm_tn_b16(hipStream_t st, const unsigned short *dY, int64_t ldy, const unsigned short *X, int64_t ldx, float *dW,
+                       float *db, int pout, int pin, int out, int in, int64_t M, float *ws, size_t ws_floats) {
+    if (M <= 0) return 0;
+    RLPPO_CHECK_ARG(tn_b16_ok(pout, pin) && ldy % 8 == 0 && ldx % 8 == 0 && pout <= ldy && pin <= ldx && out <= pout && in <= pin &&
+                        out > pout - 128 && in > pin - 128 && dY && X && dW,
+                    "gemm_tn (bf16 in memory): bad shapes pout=%d pin=%d out=%d in=%d ldy=%ld ldx=%ld", pout, pin, out, in, (long)ldy,
+                    (long)ldx);
+    if (!ws || ws_floats < tn_partial_floats(out, in, M)) {
+        set_error("gemm_tn (bf16 in memory): workspace %zu < %zu floats", ws ? ws_floats : (size_t)0, tn_partial_floats(out, in, M));
+        return RLPPO_ERR_WORKSPACE;
+    }
+    const int rows_per_wg = (int)round_up(tn_partial_rows(out, in, M), TNB_ROWS);
+    const int64_t lim = (int64_t)1 << 30;
+    RLPPO_CHECK_ARG((rows_per_wg + TNB_ROWS) * ldy * 2 < lim && (rows_per_wg + TNB_ROWS) * ldx * 2 < lim,
+                    "gemm_tn (bf16 in memory): a leading dimension is too wide for 32-bit tile offsets");
+    const int tiles_x = pout / 128, tiles_y = pin / 128, splits = (int)cdiv(M, rows_per_wg);
+    dim3 grid((unsigned)tiles_x, (unsigned)tiles_y, (unsigned)splits);
+    hipLaunchKernelGGL(gemm_tn_b16_kernel, grid, dim3(256), 0, st, dY, (unsigned)(ldy * 2), X, (unsigned)(ldx * 2), db != nullptr,
+                       out, M, rows_per_wg, ws);
     RLPPO_LAUNCH_CHECK();
     hipLaunchKernelGGL(tn_reduce_kernel, dim3(64, (unsigned)(tiles_x * tiles_y)), dim3(256), 0, st, ws, splits, tiles_x,
                        tiles_x * tiles_y, dW, db, out, in);

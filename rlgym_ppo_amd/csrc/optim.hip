@@ -50,7 +50,8 @@ int launch_pack(hipStream_t st, const NetLayout &net, const float *flat, float *
 // bf16 update precision: the fp32 master copy rounded to bf16 (round-to-nearest-even), once per optimiser step:
 //   packed_r -- the packed image (W | W^T | b per layer) holding the ROUNDED weights as fp32 (the fp32 dX product and the
 //               critic's matrix-vector head then multiply exactly what the bf16 forward multiplied); biases stay fp32;
-//   wb16     -- the W[Pout][Pin] blocks alone as bf16, layer after layer (the B operand of gemm_nt_b16_kernel).
+//   wb16     -- the W[Pout][Pin] blocks alone as bf16, layer after layer (the B operand of the forward gemm_nt_b16_kernel),
+//               followed by the W^T[Pin][Pout] blocks in the same order (the B operand of its dX form).
 __device__ __forceinline__ unsigned short bf16_bits(float x) { return __builtin_bit_cast(unsigned short, (__bf16)x); }
 __global__ __launch_bounds__(256) void pack_bf16_kernel(const float *__restrict__ flat, float *__restrict__ packed_r,
                                                         unsigned short *__restrict__ wb16, PackJobs jobs) {
@@ -66,6 +67,7 @@ __global__ __launch_bounds__(256) void pack_bf16_kernel(const float *__restrict_
         packed_r[J.off_w + (int64_t)o * J.pin + i] = wr;
         packed_r[J.off_wt + (int64_t)i * J.pout + o] = wr;
         wb16[J.first + e] = h;  // J.first = sum of the previous layers' Pout * Pin
+        wb16[jobs.total + J.first + (int64_t)i * J.pout + o] = h;
         if (i == 0) packed_r[J.off_b + o] = o < J.out ? flat[J.off_flat_b + o] : 0.f;
     }
 }
@@ -111,6 +113,29 @@ int launch_round_rows(hipStream_t st, float *x, unsigned short *xb, int64_t n_el
     const int64_t n4 = n_elems / 4;
     const int blocks = (int)(cdiv(n4, 256) < 8192 ? cdiv(n4, 256) : 8192);
     hipLaunchKernelGGL(round_rows_kernel, dim3(blocks), dim3(256), 0, st, x, xb, n4);
+    RLPPO_LAUNCH_CHECK();
+    return 0;
+}
+
+// xb (bf16) -> x (the same values as fp32): the hand-over from a bf16-in-memory kernel to a layer that takes the fp32 kernels.
+__global__ __launch_bounds__(256) void expand_rows_kernel(const unsigned short *__restrict__ xb, float *__restrict__ x, int64_t n4) {
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
+    for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < n4; g += (int64_t)gridDim.x * blockDim.x) {
+        const u16x4 h = reinterpret_cast<const u16x4 *>(xb)[g];
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = __uint_as_float((unsigned)h[e] << 16);
+        reinterpret_cast<f32x4 *>(x)[g] = v;
+    }
+}
+
+int launch_expand_rows(hipStream_t st, const unsigned short *xb, float *x, int64_t n_elems) {
+    if (n_elems <= 0) return 0;
+    RLPPO_CHECK_ARG(n_elems % 4 == 0, "expand_rows: element count %ld is not a multiple of 4", (long)n_elems);
+    const int64_t n4 = n_elems / 4;
+    const int blocks = (int)(cdiv(n4, 256) < 8192 ? cdiv(n4, 256) : 8192);
+    hipLaunchKernelGGL(expand_rows_kernel, dim3(blocks), dim3(256), 0, st, xb, x, n4);
     RLPPO_LAUNCH_CHECK();
     return 0;
 }

@@ -34,17 +34,19 @@ def test_cfg5_shape_minibatch_and_sampling(L):
 
 @pytest.mark.parametrize("shape", ["cfg5", "cfg2", "odd"])
 def test_bf16_update_precision_against_its_restatement(L, shape):
-    """BASELINE configs[4] "bf16 fwd / fp32 master weights" inside the UPDATE (rlppo_set_update_precision(1)): every forward
-    product on bf16-rounded operands (bf16 MFMA, fp32 accumulate), fp32 loss / backward / accumulation.  Checked against
-    oracle/ppo.py::minibatch_autograd under oracle/nets.py::bf16_operands -- torch autograd of F.linear(r(h), r(W), b), r =
-    rounding to bf16 with a straight-through gradient, i.e. the fp32 backward of that forward.
-    Two correct evaluations of that function agree up to fp32 summation order EXCEPT where an activation sits within that noise
-    of a bf16 rounding boundary and is rounded the other way (one bf16 ulp = 0.4 %), which shifts the next layer's sums and
-    cascades.  The test MEASURES that floor -- the restatement against itself with its sums taken in float64
-    (oracle/nets.py::sum64): ~2e-4 at 256x3, up to 4e-2 at 512x4 with the ill-conditioned Gaussian head -- and holds the kernels
+    """BASELINE configs[4] "bf16 fwd / fp32 master weights" inside the UPDATE (rlppo_set_update_precision(1)): mixed-precision
+    training as torch writes it.  Every forward product multiplies bf16-rounded operands (bf16 MFMA, fp32 accumulate); the hidden
+    activations are bf16 tensors, so the gradient with respect to each of them is rounded to bf16 too and every backward product
+    (dX, dW) multiplies bf16 values on the bf16 MFMA with fp32 accumulation; loss, dW / db accumulation, clip and Adam stay fp32
+    on the fp32 master weights.  Checked against oracle/ppo.py::minibatch_autograd under oracle/nets.py::bf16_operands -- torch
+    autograd of F.linear(h.bfloat16().float(), r(W), b), r = rounding of a master weight with an identity backward.
+    Two correct evaluations of that function agree up to fp32 summation order EXCEPT where an activation (or a gradient) sits within
+    that noise of a bf16 rounding boundary and is rounded the other way (one bf16 ulp = 0.4 %), which shifts the next layer's sums
+    and cascades.  The test MEASURES that floor -- the restatement against itself with its sums taken in float64
+    (oracle/nets.py::sum64): ~4e-4 at 256x3, ~2e-2 at 512x4 with the ill-conditioned Gaussian head -- and holds the kernels
     to 3x it.  Also printed: the distance of the mode from float64 truth of the unrounded function (10-15 % of the gradient: a
-    different arithmetic), and the fp32 parity mode is checked to be untouched afterwards.  "odd" = widths the bf16 kernel does
-    not cover (fp32 kernels on the rounded copies + a rounding pass: same products)."""
+    different arithmetic), and the fp32 parity mode is checked to be untouched afterwards.  "odd" = widths the bf16 kernels do
+    not cover (fp32 kernels on fp32 copies of the same bf16 values + the same rounding passes: identical mathematics)."""
     torch.manual_seed(11)
     rs = np.random.RandomState(11)
     if shape == "cfg5":

@@ -110,6 +110,64 @@ def test_gemm_nt_b16(L, M, N, K, hidden, epi):
     assert torch.equal(D0, D1)
 
 
+@pytest.mark.parametrize("M,N,K", [(3072, 512, 512), (4096 + 77, 256, 512), (700, 128, 64), (65536, 512, 512)])
+def test_gemm_nt_b16_dx(L, M, N, K):
+    """The backward product of the bf16 update precision: dX = round_bf16(dY . W^T-operand) masked by the ReLU bitmask the hidden
+    forward of the same M x N geometry wrote.  bf16 in, bf16 out; ragged last row tile; the mask is exact."""
+    g = torch.Generator().manual_seed(M + N + K + 1)
+    # a hidden forward of width N produces the bitmask (and the activation it describes)
+    A0 = torch.randn(M, 64, generator=g).bfloat16().cuda()
+    W0 = (torch.randn(N, 64, generator=g) * 0.1).bfloat16().cuda()
+    b0 = (torch.randn(N, generator=g) * 0.1).cuda()
+    H = torch.zeros(M, N, dtype=torch.bfloat16, device="cuda")
+    bits = torch.zeros(int(L.rlppo_dbg_gemm_nt_bits_bytes(M, N)), dtype=torch.uint8, device="cuda")
+    check(L, L.rlppo_dbg_gemm_nt_b16(stream(), P(A0), 64, P(W0), 64, P(b0), None, 0, P(H), N, M, N, 64, 1, 1, P(bits)))
+    dY = torch.randn(M, K, generator=g).bfloat16()
+    Wt = (torch.randn(N, K, generator=g) * 0.05).bfloat16()       # W^T[pin = N][pout = K]
+    dYd, Wtd = dY.cuda(), Wt.cuda()
+    out = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device="cuda")
+    check(L, L.rlppo_dbg_gemm_nt_b16(stream(), P(dYd), K, P(Wtd), K, None, None, 0, P(out), N, M, N, K, 3, 2, P(bits)))
+    torch.cuda.synchronize()
+    on = (H > 0).cpu()
+    assert 0.3 < on.float().mean().item() < 0.7
+    got = out.float().cpu()
+    assert (got[~on] == 0).all() and not torch.isnan(got).any()
+    prod = dY.double() @ Wt.double().T
+    want = prod.float().bfloat16().float() * on
+    diff = (got - want).abs()
+    ulp = want.abs() * 2.0 ** -7 + 2.0 ** -24 * K * (dY.float().abs() @ Wt.float().abs().T).double()
+    assert (diff <= ulp).all() and (diff > 0).float().mean().item() < 2e-3
+    assert L.rlppo_dbg_gemm_nt_b16(stream(), P(dYd), K, P(Wtd), K, None, None, 0, P(out), N, M, N, K, 3, 2, None) != 0  # no bitmask
+
+
+@pytest.mark.parametrize("M,pout,pin,out,in_", [(4096, 128, 128, 128, 128), (1000, 256, 128, 256, 107), (70000, 512, 512, 512, 512),
+                                               (33, 128, 256, 100, 231), (65536, 512, 256, 512, 231), (5000 + 13, 256, 384, 256, 384)])
+def test_gemm_tn_b16(L, M, pout, pin, out, in_):
+    """The weight-gradient product of the bf16 update precision: dW += dY^T . X, db += colsum(dY), both operands bf16 in memory,
+    contraction over rows through the transposing LDS read; partial tiles + the fixed-order reduction of the fp32 form: ragged last
+    stage, padded columns, accumulation on top of existing gradients, bit-identical from run to run."""
+    g = torch.Generator().manual_seed(M + pout + in_)
+    dY = torch.zeros(M, pout)
+    dY[:, :out] = torch.randn(M, out, generator=g)
+    X = torch.zeros(M, pin + 8)                      # ldx > pin
+    X[:, :in_] = torch.randn(M, in_, generator=g)
+    dYb, Xb = dY.bfloat16(), X.bfloat16()
+    dW0, db0 = torch.randn(out, in_, generator=g), torch.randn(out, generator=g)
+    dYd, Xd = dYb.cuda(), Xb.cuda()
+    ws = torch.empty(int(L.rlppo_dbg_gemm_tn_workspace_bytes(out, in_, M)), dtype=torch.uint8, device="cuda")
+    ws.fill_(0xFF)
+    results = []
+    for _ in range(3):
+        dW, db = dev(dW0), dev(db0)
+        check(L, L.rlppo_dbg_gemm_tn_b16(stream(), P(dYd), pout, P(Xd), pin + 8, P(dW), P(db), pout, pin, out, in_, M, P(ws), ws.numel()))
+        results.append(dW.clone())
+    refW = dW0.double() + dYb[:, :out].double().T @ Xb[:, :in_].double()
+    refb = db0.double() + dYb[:, :out].double().sum(0)
+    assert relerr(results[0], refW) < 2e-6 and relerr(db, refb) < 2e-6
+    assert torch.equal(results[0], results[1]) and torch.equal(results[0], results[2])
+    assert L.rlppo_dbg_gemm_tn_b16(stream(), P(dYd), pout, P(Xd), pin + 8, P(dW), P(db), pout, pin + 32, out, in_, M, P(ws), ws.numel()) != 0
+
+
 def test_relu_bitmask_forms_are_bitwise_equal(L):
     """The hidden-layer forward that also writes the ReLU bitmask gives the same activations as the plain
     forward, and the dX product masked by that bitmask gives the same result as the one masked by re-reading the activation
