@@ -344,6 +344,14 @@ int rlppo_dbg_gemm_nt_b16(void *stream, const void *A, int64_t lda, const void *
  * operands bf16 [M][ld] with pout / pin (multiples of 128) columns of which out / in are meaningful; workspace as rlppo_dbg_gemm_tn. */
 int rlppo_dbg_gemm_tn_b16(void *stream, const void *dY, int64_t ldy, const void *X, int64_t ldx, float *dW, float *db, int32_t pout,
                           int32_t pin, int32_t out, int32_t in, int64_t M, void *ws, size_t ws_bytes);
+/* The output layer's two backward products in the bf16 update precision for a head of out <= 32 outputs (gemv.hip): dY[M][ldy]
+ * fp32 (the loss gradient), W[out][ldw] fp32 (bf16-rounded values), hb[M][ldh] the last hidden activation as bf16, bits its ReLU
+ * bitmask (rlppo_dbg_gemm_nt_bits_bytes(M, kp)): dxb[M][kp] (bf16) = round_bf16(dY . W) masked; dW[out][in] += dY^T . hb,
+ * db[out] += colsum(dY) with a fixed summation order.  kp: padded hidden width, a power of two and a multiple of 128. */
+size_t rlppo_dbg_thin_head_workspace_bytes(int32_t out, int32_t kp, int64_t M);
+int rlppo_dbg_thin_head_b16(void *stream, const float *dY, int64_t ldy, int32_t out, const float *W, int64_t ldw, const void *bits,
+                            const void *hb, int64_t ldh, void *dxb, float *dW, float *db, int32_t in, int32_t kp, int64_t M, void *ws,
+                            size_t ws_bytes);
 /* dW[out][in] += dY^T . X, db[out] += colsum(dY) through partial tiles in `ws` (rlppo_dbg_gemm_tn_workspace_bytes) and a
  * fixed-order reduction: the form rlppo_ppo_minibatch uses. */
 size_t rlppo_dbg_gemm_tn_workspace_bytes(int32_t out, int32_t in, int64_t M);

@@ -115,6 +115,9 @@ SIGNATURES = {
                                         c_int64, c_int32, c_int32, c_int32, c_int32, c_void_p]),
     "rlppo_dbg_gemm_tn_b16": (c_int32, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int32, c_int32, c_int32,
                                         c_int32, c_int64, c_void_p, c_size_t]),
+    "rlppo_dbg_thin_head_workspace_bytes": (c_size_t, [c_int32, c_int32, c_int64]),
+    "rlppo_dbg_thin_head_b16": (c_int32, [c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p,
+                                          c_void_p, c_void_p, c_int32, c_int32, c_int64, c_void_p, c_size_t]),
     "rlppo_dbg_gemm_tn_workspace_bytes": (c_size_t, [c_int32, c_int32, c_int64]),
     "rlppo_dbg_gemm_tn": (c_int32, [c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_int64, c_int32, c_void_p, c_void_p,
                                     c_int32, c_int32, c_int64, c_void_p, c_size_t]),

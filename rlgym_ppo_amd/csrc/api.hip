@@ -99,34 +99,58 @@ static int forward(hipStream_t st, const NetLayout &net, const float *packed, co
 }
 
 // Forward pass of the bf16 UPDATE precision (rlppo_set_update_precision(1)): every product multiplies bf16-rounded operands
-// and accumulates in fp32.  x / xb: the layer input as rounded fp32 and as bf16 (same values); acts[l] receives the hidden
-// output ROUNDED (fp32), actsb[l] its bf16 copy, bits[l] the ReLU bitmask; the output layer is stored unrounded in fp32.
-// Layers whose shape gemm_nt_b16_kernel does not cover run the fp32 kernels on the rounded copies (identical products) and
-// are rounded by a separate pass.
+// and accumulates in fp32.  x / xb: the layer input as rounded fp32 and as bf16 (same values); actsb[l] receives the hidden
+// output rounded to bf16, bits[l] its ReLU bitmask; acts[l] receives the same values as fp32 only where somebody will read them
+// (want_f32[l]: the next layer or its weight gradient takes an fp32 kernel) -- f32_valid[l] reports it; the output layer is
+// stored unrounded in fp32.  Layers whose shape gemm_nt_b16_kernel does not cover run the fp32 kernels on the fp32 copies
+// (identical products) and are rounded by a separate pass.
+static bool b16_next_wants_f32(const NetLayout &net, int l) {  // does the consumer of hidden activation l read it as fp32?
+    const int nx = l + 1, last = net.n_layers - 1;
+    const LayerLayout &N = net.L[nx];
+    if (nx == last) {
+        const bool fwd_b16 = gemv_head_ok(N.out, N.pin) || nt_b16_ok(N.pout, N.pin, false);
+        return !(fwd_b16 && thin_head_ok(N.out, N.pin));
+    }
+    return !(nt_b16_ok(N.pout, N.pin, true) && tn_b16_ok(N.pout, N.pin));
+}
 static int forward_b16(hipStream_t st, const NetLayout &net, const float *packed_r, const unsigned short *wb16, const float *x,
                        const unsigned short *xb, int64_t ldx, int64_t n, int out_tanh, float *const *acts,
-                       unsigned short *const *actsb, unsigned long long *const *bits, bool *have_bits) {
-    for (int l = 0; l < net.n_layers; ++l) have_bits[l] = false;
+                       unsigned short *const *actsb, unsigned long long *const *bits, bool *have_bits, bool *f32_valid) {
+    for (int l = 0; l < net.n_layers; ++l) have_bits[l] = f32_valid[l] = false;
     int64_t off16 = 0;
+    bool x_f32 = true;  // the gathered states exist in both forms
     for (int l = 0; l < net.n_layers; ++l) {
         const LayerLayout &L = net.L[l];
         const bool last = l == net.n_layers - 1;
-        int rc;
+        int rc = 0;
+        auto need_x_f32 = [&]() -> int {  // an fp32 kernel is about to read this layer's input
+            if (x_f32) return 0;
+            x_f32 = f32_valid[l - 1] = true;
+            return launch_expand_rows(st, actsb[l - 1], acts[l - 1], n * (int64_t)net.L[l - 1].pout);
+        };
         if (last) {
             const int epi = out_tanh ? EPI_BIAS_TANH : EPI_BIAS;
             if (!out_tanh && gemv_head_ok(L.out, L.pin))
-                rc = launch_gemv_fwd(st, x, ldx, packed_r + L.off_w, packed_r + L.off_b, acts[l], L.pout, n, L.pin, L.pout);
+                rc = launch_gemv_fwd_b16(st, xb, ldx, packed_r + L.off_w, packed_r + L.off_b, acts[l], L.pout, n, L.pin, L.pout);
             else if (nt_b16_ok(L.pout, L.pin, false))
                 rc = launch_gemm_nt_b16(st, xb, ldx, wb16 + off16, L.pin, packed_r + L.off_b, acts[l], L.pout, nullptr, 0, n, L.pout,
-                                        L.pin, epi, false, nullptr);
-            else
-                rc = launch_gemm_nt(st, x, ldx, packed_r + L.off_w, L.pin, packed_r + L.off_b, nullptr, 0, acts[l], L.pout, n, L.pout,
-                                    L.pin, epi);
-        } else if (nt_b16_ok(L.pout, L.pin, true)) {
-            rc = launch_gemm_nt_b16(st, xb, ldx, wb16 + off16, L.pin, packed_r + L.off_b, acts[l], L.pout, actsb[l], L.pout, n, L.pout,
-                                    L.pin, EPI_BIAS_RELU, true, bits[l]);
-            have_bits[l] = rc == 0 && bits[l] != nullptr;
+                                        L.pin, epi, 0, nullptr);
+            else {
+                rc = need_x_f32();
+                if (rc == 0)
+                    rc = launch_gemm_nt(st, x, ldx, packed_r + L.off_w, L.pin, packed_r + L.off_b, nullptr, 0, acts[l], L.pout, n,
+                                        L.pout, L.pin, epi);
+            }
+            f32_valid[l] = true;
+        } else if (nt_b16_ok(L.pout, L.pin, true) && bits[l]) {
+            const bool want = b16_next_wants_f32(net, l);
+            rc = launch_gemm_nt_b16(st, xb, ldx, wb16 + off16, L.pin, packed_r + L.off_b, want ? acts[l] : nullptr, L.pout, actsb[l],
+                                    L.pout, n, L.pout, L.pin, EPI_BIAS_RELU, 1, bits[l]);
+            have_bits[l] = rc == 0;
+            f32_valid[l] = want;
         } else {
+            rc = need_x_f32();
+            if (rc) return rc;
             rc = -1;
             if (bits[l]) {
                 rc = launch_gemm_nt_bits(st, x, ldx, packed_r + L.off_w, L.pin, packed_r + L.off_b, acts[l], L.pout, n, L.pout, L.pin,
@@ -137,11 +161,13 @@ static int forward_b16(hipStream_t st, const NetLayout &net, const float *packed
                 rc = launch_gemm_nt(st, x, ldx, packed_r + L.off_w, L.pin, packed_r + L.off_b, nullptr, 0, acts[l], L.pout, n, L.pout,
                                     L.pin, EPI_BIAS_RELU);
             if (rc == 0) rc = launch_round_rows(st, acts[l], actsb[l], n * (int64_t)L.pout);
+            f32_valid[l] = true;
         }
         if (rc) return rc;
         off16 += (int64_t)L.pout * L.pin;
         x = acts[l];
         xb = actsb[l];
+        x_f32 = f32_valid[l];
         ldx = L.pout;
     }
     return 0;
@@ -356,6 +382,10 @@ static size_t tn_ws_floats(const NetLayout &net, int64_t mb) {
             const size_t g = (size_t)cdiv(mb, 64) * (size_t)(net.L[l].pin + 4);  // upper bound: at least 64 rows per block
             if (g > f) f = g;
         }
+        if (g_update_bf16 && l == net.n_layers - 1) {  // narrow head of the bf16 precision: per-lane partials of thin_dw_b16
+            const size_t g = thin_dw_ws_floats(net.L[l].out, net.L[l].pin, mb);
+            if (g > f) f = g;
+        }
         if (f > m) m = f;
     }
     return m;
@@ -433,12 +463,13 @@ static int backward(hipStream_t st, const NetLayout &net, const float *packed, c
 // so the gradient with respect to each of them is rounded to bf16 (dxb[l], already masked by relu'), and every product
 // multiplies bf16 values with fp32 accumulation: dW_l = dxb[l]^T . actsb[l-1] (gemm_tn_b16_kernel), dX = dxb[l] . r(W_l)
 // (gemm_nt_b16_kernel, B16_DX).  dW / db accumulate unrounded into the fp32 gradient arena.  The output layer's gradient comes
-// from the loss kernel in fp32 and its (narrow) products stay on the fp32 kernels, as do layers whose shapes the bf16 kernels
-// do not cover -- on fp32 copies of the same bf16 values, followed by the same rounding: identical mathematics.
+// from the loss kernel in fp32: narrow heads stream it through thin_dw_b16 / thin_dx_b16 (gemv.hip).  Shapes those kernels do
+// not cover take the fp32 kernels on fp32 copies of the same bf16 values (expanded on demand), followed by the same rounding:
+// identical mathematics.
 static int backward_b16(hipStream_t st, const NetLayout &net, const float *packed_r, const unsigned short *wb16, const float *states,
                         const unsigned short *states_b, int64_t ld_states, int64_t mb, float *const *acts,
                         unsigned short *const *actsb, float *const *dx, unsigned short *const *dxb, float *grad, float *tn_ws,
-                        size_t tn_floats, unsigned long long *const *bits, const bool *have_bits) {
+                        size_t tn_floats, unsigned long long *const *bits, const bool *have_bits, bool *f32_valid) {
     const int last = net.n_layers - 1;
     int64_t first[RLPPO_MAX_LAYERS], total = 0;  // element offsets of the layers' blocks inside the bf16 weight images
     for (int l = 0; l < net.n_layers; ++l) {
@@ -447,6 +478,16 @@ static int backward_b16(hipStream_t st, const NetLayout &net, const float *packe
     }
     bool dx_f32[RLPPO_MAX_LAYERS] = {};  // dx[l] holds the fp32 copy of dxb[l]
     int rc = 0;
+    auto act_f32 = [&](int l) -> int {  // an fp32 kernel is about to read hidden activation l
+        if (l < 0 || f32_valid[l]) return 0;
+        f32_valid[l] = true;
+        return launch_expand_rows(st, actsb[l], acts[l], mb * (int64_t)net.L[l].pout);
+    };
+    auto grad_f32 = [&](int l) -> int {  // ... or the gradient of hidden activation l
+        if (dx_f32[l]) return 0;
+        dx_f32[l] = true;
+        return launch_expand_rows(st, dxb[l], dx[l], mb * (int64_t)net.L[l].pout);
+    };
     for (int l = last; l >= 0; --l) {
         const LayerLayout &L = net.L[l];
         const float *X = l > 0 ? acts[l - 1] : states;
@@ -455,21 +496,26 @@ static int backward_b16(hipStream_t st, const NetLayout &net, const float *packe
         const bool gemv = l == last && l > 0 && gemv_head_ok(L.out, L.pin);
         // ---- dW, db
         if (l == last) {
-            if (gemv)
-                rc = launch_gemv_dw(st, acts[last], L.pout, X, ldx, grad + L.off_flat_w, grad + L.off_flat_b, L.in, L.pin, mb, tn_ws,
-                                    tn_floats);
-            else
-                rc = launch_gemm_tn(st, acts[last], L.pout, L.pout, X, ldx, L.pin, grad + L.off_flat_w, grad + L.off_flat_b, L.out,
-                                    L.in, mb, tn_ws, tn_floats);
+            rc = l > 0 ? launch_thin_dw_b16(st, acts[last], L.pout, Xb, ldx, grad + L.off_flat_w, grad + L.off_flat_b, L.out, L.in,
+                                            L.pin, mb, tn_ws, tn_floats)
+                       : -1;
+            if (rc == -1) {
+                rc = act_f32(l - 1);
+                if (rc) return rc;
+                if (gemv)
+                    rc = launch_gemv_dw(st, acts[last], L.pout, X, ldx, grad + L.off_flat_w, grad + L.off_flat_b, L.in, L.pin, mb,
+                                        tn_ws, tn_floats);
+                else
+                    rc = launch_gemm_tn(st, acts[last], L.pout, L.pout, X, ldx, L.pin, grad + L.off_flat_w, grad + L.off_flat_b,
+                                        L.out, L.in, mb, tn_ws, tn_floats);
+            }
         } else if (tn_b16_ok(L.pout, L.pin) && ldx % 8 == 0) {
             rc = launch_gemm_tn_b16(st, dxb[l], L.pout, Xb, ldx, grad + L.off_flat_w, grad + L.off_flat_b, L.pout, L.pin, L.out, L.in,
                                     mb, tn_ws, tn_floats);
         } else {
-            if (!dx_f32[l]) {
-                rc = launch_expand_rows(st, dxb[l], dx[l], mb * (int64_t)L.pout);
-                if (rc) return rc;
-                dx_f32[l] = true;
-            }
+            rc = grad_f32(l);
+            if (rc == 0) rc = act_f32(l - 1);
+            if (rc) return rc;
             rc = launch_gemm_tn(st, dx[l], L.pout, L.pout, X, ldx, L.pin, grad + L.off_flat_w, grad + L.off_flat_b, L.out, L.in, mb,
                                 tn_ws, tn_floats);
         }
@@ -482,26 +528,35 @@ static int backward_b16(hipStream_t st, const NetLayout &net, const float *packe
             if (rc) return rc;
             continue;
         }
+        if (l == last && have_bits[l - 1]) {
+            rc = launch_thin_dx_b16(st, acts[last], L.pout, L.out, packed_r + L.off_w, L.pin, bits[l - 1], dxb[l - 1], L.pin, L.pin, mb);
+            if (rc == 0) continue;
+            if (rc != -1) return rc;
+        }
         const float *dY = acts[last];
         if (l < last) {
-            if (!dx_f32[l]) {
-                rc = launch_expand_rows(st, dxb[l], dx[l], mb * (int64_t)L.pout);
-                if (rc) return rc;
-                dx_f32[l] = true;
-            }
+            rc = grad_f32(l);
+            if (rc) return rc;
             dY = dx[l];
         }
         rc = -1;
         if (gemv) {
             if (have_bits[l - 1]) rc = launch_gemv_dx_bits(st, dY, L.pout, packed_r + L.off_w, bits[l - 1], dx[l - 1], L.pin, L.pin, mb);
-            if (rc == -1) rc = launch_gemv_dx(st, dY, L.pout, packed_r + L.off_w, acts[l - 1], L.pin, dx[l - 1], L.pin, L.pin, mb);
+            if (rc == -1) {
+                rc = act_f32(l - 1);
+                if (rc) return rc;
+                rc = launch_gemv_dx(st, dY, L.pout, packed_r + L.off_w, acts[l - 1], L.pin, dx[l - 1], L.pin, L.pin, mb);
+            }
         } else {
             if (have_bits[l - 1])
                 rc = launch_gemm_nt_bits(st, dY, L.pout, packed_r + L.off_wt, L.pout, nullptr, dx[l - 1], L.pin, mb, L.pin, L.pout,
                                          EPI_MASK, bits[l - 1]);
-            if (rc == -1)
+            if (rc == -1) {
+                rc = act_f32(l - 1);
+                if (rc) return rc;
                 rc = launch_gemm_nt(st, dY, L.pout, packed_r + L.off_wt, L.pout, nullptr, acts[l - 1], L.pin, dx[l - 1], L.pin, mb,
                                     L.pin, L.pout, EPI_MASK);
+            }
         }
         if (rc) return rc;
         rc = launch_round_rows(st, dx[l - 1], dxb[l - 1], mb * (int64_t)L.pin);  // the gradient of a bf16 activation is bf16
@@ -583,6 +638,7 @@ int rlppo_ppo_minibatch(void *stream, const rlppo_minibatch_args *a) {
     if ((reinterpret_cast<uintptr_t>(w) & 7) != 0) ++w;
     unsigned long long *pbits[RLPPO_MAX_LAYERS] = {}, *vbits[RLPPO_MAX_LAYERS] = {};
     bool phave[RLPPO_MAX_LAYERS] = {}, vhave[RLPPO_MAX_LAYERS] = {};
+    bool pf32[RLPPO_MAX_LAYERS] = {}, vf32[RLPPO_MAX_LAYERS] = {};  // bf16 precision: which activations also exist as fp32
     for (int l = 0; l + 1 < pol.n_layers; ++l) {
         const size_t f = nt_bits_floats(mb, pol.L[l].pout);
         pbits[l] = f ? reinterpret_cast<unsigned long long *>(w) : nullptr;
@@ -651,10 +707,10 @@ int rlppo_ppo_minibatch(void *stream, const rlppo_minibatch_args *a) {
     }
     if (b16) {
         rc = forward_b16(side, val, val_w, reinterpret_cast<const unsigned short *>(a->val_wb16), states, states_b, ld_states, mb, 0,
-                         vact, vactb, vbits, vhave);
+                         vact, vactb, vbits, vhave, vf32);
         if (rc) return rc;
         rc = forward_b16(st, pol, pol_w, reinterpret_cast<const unsigned short *>(a->pol_wb16), states, states_b, ld_states, mb,
-                         a->head == RLPPO_HEAD_GAUSSIAN, pact, pactb, pbits, phave);
+                         a->head == RLPPO_HEAD_GAUSSIAN, pact, pactb, pbits, phave, pf32);
     } else {
         rc = forward(side, val, val_w, states, ld_states, mb, 0, vact, 0, vbits, vhave);
         if (rc) return rc;
@@ -694,10 +750,10 @@ int rlppo_ppo_minibatch(void *stream, const rlppo_minibatch_args *a) {
 
     if (b16) {
         rc = backward_b16(side, val, val_w, reinterpret_cast<const unsigned short *>(a->val_wb16), states, states_b, ld_states, mb, vact,
-                          vactb, vdx, vdxb, a->val_grad, val_tn_ws, tn_ws_floats(val, mb), vbits, vhave);
+                          vactb, vdx, vdxb, a->val_grad, val_tn_ws, tn_ws_floats(val, mb), vbits, vhave, vf32);
         if (rc) return rc;
         rc = backward_b16(st, pol, pol_w, reinterpret_cast<const unsigned short *>(a->pol_wb16), states, states_b, ld_states, mb, pact,
-                          pactb, pdx, pdxb, a->pol_grad, pol_tn_ws, tn_ws_floats(pol, mb), pbits, phave);
+                          pactb, pdx, pdxb, a->pol_grad, pol_tn_ws, tn_ws_floats(pol, mb), pbits, phave, pf32);
     } else {
         rc = backward(side, val, val_w, states, ld_states, mb, vact, vdx, a->val_grad, val_tn_ws, tn_ws_floats(val, mb), vbits, vhave);
         if (rc) return rc;
@@ -850,6 +906,17 @@ int rlppo_dbg_gemm_tn_b16(void *stream, const void *dY, int64_t ldy, const void 
     return launch_gemm_tn_b16((hipStream_t)stream, reinterpret_cast<const unsigned short *>(dY), ldy,
                               reinterpret_cast<const unsigned short *>(X), ldx, dW, db, pout, pin, out, in, M, (float *)ws,
                               ws_bytes / sizeof(float));
+}
+size_t rlppo_dbg_thin_head_workspace_bytes(int32_t out, int32_t kp, int64_t M) { return thin_dw_ws_floats(out, kp, M) * sizeof(float); }
+int rlppo_dbg_thin_head_b16(void *stream, const float *dY, int64_t ldy, int32_t out, const float *W, int64_t ldw, const void *bits,
+                            const void *hb, int64_t ldh, void *dxb, float *dW, float *db, int32_t in, int32_t kp, int64_t M, void *ws,
+                            size_t ws_bytes) {
+    int rc = launch_thin_dx_b16((hipStream_t)stream, dY, ldy, out, W, ldw, reinterpret_cast<const unsigned long long *>(bits),
+                                reinterpret_cast<unsigned short *>(dxb), kp, kp, M);
+    if (rc) return rc == -1 ? RLPPO_ERR_ARG : rc;
+    rc = launch_thin_dw_b16((hipStream_t)stream, dY, ldy, reinterpret_cast<const unsigned short *>(hb), ldh, dW, db, out, in, kp, M,
+                            (float *)ws, ws_bytes / sizeof(float));
+    return rc == -1 ? RLPPO_ERR_ARG : rc;
 }
 size_t rlppo_dbg_gemm_tn_workspace_bytes(int32_t out, int32_t in, int64_t M) { return tn_partial_floats(out, in, M) * sizeof(float); }
 int rlppo_dbg_gemm_tn(void *stream, const float *dY, int64_t ldy, int32_t ny_valid, const float *X, int64_t ldx,

@@ -98,6 +98,15 @@ int launch_gemm_tn(hipStream_t st, const float *dY, int64_t ldy, int ny_valid, c
 // gemv.hip: the critic's one-output head ---------------------------------------------------------------
 bool gemv_head_ok(int out, int kp);
 int launch_gemv_fwd(hipStream_t st, const float *x, int64_t ldx, const float *w, const float *b, float *y, int64_t ldy, int64_t n, int kp, int pout);
+int launch_gemv_fwd_b16(hipStream_t st, const unsigned short *x, int64_t ldx, const float *w, const float *b, float *y, int64_t ldy,
+                        int64_t n, int kp, int pout);
+// narrow heads (<= 32 outputs) of the bf16 update precision: bf16 activation in, bf16 gradient out (gemv.hip)
+bool thin_head_ok(int out, int kp);
+size_t thin_dw_ws_floats(int out, int kp, int64_t n);
+int launch_thin_dx_b16(hipStream_t st, const float *dy, int64_t ldy, int out, const float *w, int64_t ldw,
+                       const unsigned long long *bits, unsigned short *dxb, int64_t ldc, int kp, int64_t n);
+int launch_thin_dw_b16(hipStream_t st, const float *dy, int64_t ldy, const unsigned short *xb, int64_t ldx, float *dw, float *db,
+                       int out, int in, int kp, int64_t n, float *ws, size_t ws_floats);
 int launch_gemv_dx(hipStream_t st, const float *dy, int64_t ldy, const float *w, const float *mask, int64_t ldm, float *dx, int64_t ldc, int kp, int64_t n);
 int launch_gemv_dx_bits(hipStream_t st, const float *dy, int64_t ldy, const float *w, const unsigned long long *bits, float *dx,
                         int64_t ldc, int kp, int64_t n);

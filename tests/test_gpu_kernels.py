@@ -168,6 +168,49 @@ def test_gemm_tn_b16(L, M, pout, pin, out, in_):
     assert L.rlppo_dbg_gemm_tn_b16(stream(), P(dYd), pout, P(Xd), pin + 8, P(dW), P(db), pout, pin + 32, out, in_, M, P(ws), ws.numel()) != 0
 
 
+@pytest.mark.parametrize("M,out,kp,in_", [(3000, 1, 512, 512), (4096 + 50, 16, 512, 512), (777, 21, 128, 100), (70000, 8, 256, 256),
+                                         (600, 32, 1024, 1024)])
+def test_thin_head_b16(L, M, out, kp, in_):
+    """Narrow output layers (<= 32 outputs) in the bf16 update precision: dX = round_bf16(dY . W) masked by the hidden layer's ReLU
+    bitmask (bf16 out), dW += dY^T . hb, db += colsum(dY) with hb the bf16 activation; ragged row tiles, accumulation on top of
+    existing gradients, bit-identical from run to run."""
+    g = torch.Generator().manual_seed(M + out + kp)
+    A0 = torch.randn(M, 64, generator=g).bfloat16().cuda()
+    W0 = (torch.randn(kp, 64, generator=g) * 0.1).bfloat16().cuda()
+    b0 = (torch.randn(kp, generator=g) * 0.1).cuda()
+    hb = torch.zeros(M, kp, dtype=torch.bfloat16, device="cuda")                 # the hidden activation and its bitmask
+    bits = torch.zeros(int(L.rlppo_dbg_gemm_nt_bits_bytes(M, kp)), dtype=torch.uint8, device="cuda")
+    check(L, L.rlppo_dbg_gemm_nt_b16(stream(), P(A0), 64, P(W0), 64, P(b0), None, 0, P(hb), kp, M, kp, 64, 1, 1, P(bits)))
+    dY = torch.zeros(M, 32)
+    dY[:, :out] = torch.randn(M, out, generator=g)
+    W = torch.zeros(32, kp)
+    W[:out] = (torch.randn(out, kp, generator=g) * 0.05).bfloat16().float()
+    dW0, db0 = torch.randn(out, in_, generator=g), torch.randn(out, generator=g)
+    dYd, Wd = dev(dY), dev(W)
+    ws = torch.empty(int(L.rlppo_dbg_thin_head_workspace_bytes(out, kp, M)), dtype=torch.uint8, device="cuda")
+    ws.fill_(0xFF)
+    res = []
+    for _ in range(2):
+        dxb = torch.full((M, kp), float("nan"), dtype=torch.bfloat16, device="cuda")
+        dW, db = dev(dW0), dev(db0)
+        check(L, L.rlppo_dbg_thin_head_b16(stream(), P(dYd), 32, out, P(Wd), kp, P(bits), P(hb), kp, P(dxb), P(dW), P(db), in_, kp, M,
+                                           P(ws), ws.numel()))
+        res.append((dxb.clone(), dW.clone(), db.clone()))
+    torch.cuda.synchronize()
+    on = (hb > 0).cpu()
+    h = hb.float().cpu()
+    got = res[0][0].float().cpu()
+    prod = dY[:, :out].double() @ W[:out].double()
+    want = prod.float().bfloat16().float() * on
+    diff = (got - want).abs()
+    ulp = want.abs() * 2.0 ** -7 + 2.0 ** -22 * (dY[:, :out].abs() @ W[:out].abs()).double()
+    assert (got[~on] == 0).all() and (diff <= ulp).all() and (diff > 0).float().mean().item() < 2e-3
+    refW = dW0.double() + dY[:, :out].double().T @ h[:, :in_].double()
+    refb = db0.double() + dY[:, :out].double().sum(0)
+    assert relerr(res[0][1], refW) < 2e-6 and relerr(res[0][2], refb) < 2e-6
+    assert all(torch.equal(a, b) for a, b in zip(res[0], res[1]))
+
+
 def test_relu_bitmask_forms_are_bitwise_equal(L):
     """The hidden-layer forward that also writes the ReLU bitmask gives the same activations as the plain
     forward, and the dX product masked by that bitmask gives the same result as the one masked by re-reading the activation
