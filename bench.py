@@ -349,17 +349,29 @@ def cfg5_rooflines(value, bf16, learner):
     tn_ws = torch.empty(int(L.rlppo_dbg_gemm_tn_workspace_bytes(H, H, M)), dtype=torch.uint8, device=dev)
     Ab, Wb, Cb = A.bfloat16(), W.bfloat16(), torch.empty(M, H, dtype=torch.bfloat16, device=dev)
     flop = 2 * M * H * H
-    shapes = [
+    dYb = torch.randn(M, H, device=dev).bfloat16()
+    dXb = torch.empty(M, H, dtype=torch.bfloat16, device=dev)
+    f32_shapes = [
         ("gemm_nt fwd hidden 512->512 +bitmask, fp32 MFMA", lambda: N.check(L.rlppo_dbg_gemm_nt_bits(st(), P(A), H, P(W), H, P(bias), P(C), H, M, H, H, 1, P(bits))),
          "f32", 4 * (2 * M * H + H * H) + M * H // 8),
-        ("gemm_nt_b16 fwd hidden 512->512: bf16 operands in memory, bf16 MFMA, fp32 accumulate; writes bf16 + fp32 + bitmask",
-         lambda: N.check(L.rlppo_dbg_gemm_nt_b16(st(), P(Ab), H, P(Wb), H, P(bias), P(C), H, P(Cb), H, M, H, H, 1, 1, P(bits))),
-         "bf16", 2 * (M * H + H * H) + 6 * M * H + M * H // 8),
         ("gemm_nt dX hidden 512->512 bitmask, fp32 MFMA", lambda: N.check(L.rlppo_dbg_gemm_nt_bits(st(), P(A), H, P(W), H, None, P(C), H, M, H, H, 3, P(bits))),
          "f32", 4 * (2 * M * H + H * H) + M * H // 8),
         ("gemm_tn dW hidden 512x512 (+ reduction), fp32 MFMA", lambda: N.check(L.rlppo_dbg_gemm_tn(st(), P(A), H, H, P(A2), H, H, P(dW), P(db), H, H, M, P(tn_ws), tn_ws.numel())),
          "f32", 4 * (2 * M * H + H * H)),
     ]
+    b16_shapes = [
+        ("gemm_nt_b16w fwd hidden 512->512: bf16 operands in memory, bf16 MFMA, fp32 accumulate; writes bf16 + ReLU bitmask",
+         lambda: N.check(L.rlppo_dbg_gemm_nt_b16(st(), P(Ab), H, P(Wb), H, P(bias), None, 0, P(Cb), H, M, H, H, 1, 1, P(bits))),
+         "bf16", 2 * (M * H + H * H) + 2 * M * H + M * H // 8),
+        ("gemm_nt_b16w dX hidden 512->512: bf16 dY x bf16 W^T, rounded to bf16, masked by the bitmask",
+         lambda: N.check(L.rlppo_dbg_gemm_nt_b16(st(), P(dYb), H, P(Wb), H, None, None, 0, P(dXb), H, M, H, H, 3, 2, P(bits))),
+         "bf16", 2 * (M * H + H * H) + 2 * M * H + M * H // 8),
+        ("gemm_tn_b16 dW hidden 512x512 (+ reduction): bf16 dY^T x bf16 X through transposing LDS reads",
+         lambda: N.check(L.rlppo_dbg_gemm_tn_b16(st(), P(dYb), H, P(Ab), H, P(dW), P(db), H, H, H, H, M, P(tn_ws), tn_ws.numel())),
+         "bf16", 2 * (2 * M * H) + 4 * H * H),
+    ]
+    # the selected precision's kernels first (the first line is the roofline kernel), the other precision's for comparison
+    shapes = (b16_shapes + f32_shapes) if bf16 else (f32_shapes + b16_shapes)
     rows = []
     for name, fn, kind, nbytes in shapes:
         ms = time_region(fn, 10, warm_s=0.3)
@@ -375,9 +387,10 @@ def cfg5_rooflines(value, bf16, learner):
     out = {"kernel_breakdown": rows,
            "update_flop_efficiency": dict(achieved=round(tf, 2), peak=MFMA_F32_PEAK_TF, unit="TFLOP/s", frac=round(tf / MFMA_F32_PEAK_TF, 4),
                                           note="10,435,584 algorithmic flop/sample (SURVEY 8(d)) x measured samples/s, against the fp32 MFMA "
-                                               "peak" + (" (mixed precision: the forward third of the flops runs on the bf16 pipe, so this is "
-                                                         "an equivalent-fp32 rate, not a utilisation)" if bf16 else ""))}
-    dom = rows[1] if bf16 else rows[0]
+                                               "peak" + (" (bf16 update precision: all hidden-layer products run on the bf16 pipe, so this is an "
+                                                         "equivalent-fp32 rate, not a utilisation; the kernels are HBM-side bound, see "
+                                                         "kernel_breakdown)" if bf16 else ""))}
+    dom = rows[0]
     bound = dom["binds"]
     out["roofline"] = dict(bound=bound, achieved=dom["gb_per_s"] if bound == "hbm" else dom["tflops"],
                            peak=HBM_PEAK_GBS if bound == "hbm" else dom["mfma_peak"], unit="GB/s" if bound == "hbm" else "TFLOP/s",
@@ -562,7 +575,7 @@ def main():
                     "256x3 policy + 256x3 critic; ppo_batch 524,288, minibatch 65,536")
     else:
         workload = ("BASELINE configs[4]: 524,288-sample buffer, obs 231 f32, Gaussian policy with 8 actions, 512x4 policy + 512x4 "
-                    "critic, " + ("bf16-operand forward / fp32 master weights, accumulation and backward" if bf16 else "fp32 update") +
+                    "critic, " + ("bf16 update precision: bf16-operand products forward and backward (bf16 activations and activation gradients), fp32 accumulation, loss, dW/db, clip, Adam and master weights" if bf16 else "fp32 update") +
                     "; ppo_batch 524,288, minibatch 65,536")
     per_rank = 8 // world if 8 % world == 0 else 1
     out = {

@@ -682,7 +682,12 @@ int rlppo_ppo_minibatch(void *stream, const rlppo_minibatch_args *a) {
             vdxb[l] = hb;
             hb += (size_t)mb * val.L[l].pout;
         }
-        rc = launch_gather_rows_round(st, a->states, a->ld_states, a->idx, states, states_b, pol.L[0].pin, mb, ring_base, ring_cap);
+        // the fp32 form of the gathered rows only if a first layer takes the fp32 kernels (the predicates of forward_b16 / backward_b16)
+        auto lean0 = [](const NetLayout &n) {
+            return n.n_layers > 1 && nt_b16_ok(n.L[0].pout, n.L[0].pin, true) && tn_b16_ok(n.L[0].pout, n.L[0].pin);
+        };
+        rc = launch_gather_rows_round(st, a->states, a->ld_states, a->idx, lean0(pol) && lean0(val) ? nullptr : states, states_b,
+                                      pol.L[0].pin, mb, ring_base, ring_cap);
     } else {
         rc = launch_gather_rows(st, a->states, a->ld_states, a->idx, states, pol.L[0].pin, mb, ring_base, ring_cap);
     }
@@ -872,6 +877,7 @@ int rlppo_dbg_set(int32_t key, int32_t value) {
         case 4: g_two_streams = value; return 0;
         case 21: set_gae_spin_limit(value); return 0;
         case 22: set_gae_oversubscribe(value); return 0;
+        case 23: set_b16_wide_tiles(value); return 0;
         default: break;
     }
     set_error("dbg_set: unknown key %d", key);

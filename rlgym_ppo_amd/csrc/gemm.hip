@@ -497,7 +497,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_b16_kernel(const unsigned shor
     const __amdgpu_buffer_rsrc_t b_rs = make_rsrc(reinterpret_cast<const char *>(B) + (int64_t)n0 * ldb_b,
                                                   (unsigned)(BN - 1) * ldb_b + (unsigned)K * 2);
     const int row_p = wave * RPW + lane / CPR, pch = lane % CPR;
-    const int lch = pch ^ (row_p & 7);
+    const int lch = BKT == 32 ? (pch ^ (row_p & 7)) : (pch ^ ((0 - (row_p >> 2)) & 3));  // source side of dswz<BKT>
     const unsigned a_off = (unsigned)row_p * lda_b + lch * 16;
     const unsigned b_off = (unsigned)row_p * ldb_b + lch * 16;
     const unsigned a_step = (unsigned)RPP * lda_b, b_step = (unsigned)RPP * ldb_b;
@@ -527,24 +527,24 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_b16_kernel(const unsigned shor
             __builtin_amdgcn_raw_ptr_buffer_load_lds(b_rs, Bd + i * RPP * BKT, 16, b_off, kb + i * b_step, 0, 0);
     };
 
-    const int nk = K / 64;
+    const int nk = K / (2 * BKT);
     issue_tile(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
-        if ((kt + 1) < nk) issue_tile(cur ^ 1, (unsigned)(kt + 1) * 128u);
+        if ((kt + 1) < nk) issue_tile(cur ^ 1, (unsigned)(kt + 1) * (4u * BKT));
         const float *Ac = As + cur * SBM * BKT + (wave * 32) * BKT;
         const float *Bc = Bs + cur * BN * BKT;
 #pragma unroll
-        for (int kc = 0; kc < 2; ++kc) {  // 32 k-values per MFMA: chunk kc * 4 + q holds k = 32 kc + 8 q .. + 7 of the row
+        for (int kc = 0; kc < BKT / 16; ++kc) {  // 32 k-values per MFMA: chunk kc * 4 + q holds k = 32 kc + 8 q .. + 7 of the row
             bf16x8 fa[2], fb[NB];
 #pragma unroll
             for (int i = 0; i < 2; ++i)
-                fa[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4 *>(&Ac[dswz<32>(i * 16 + r16, kc * 4 + q)]));
+                fa[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4 *>(&Ac[dswz<BKT>(i * 16 + r16, kc * 4 + q)]));
 #pragma unroll
             for (int j = 0; j < NB; ++j)
-                fb[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4 *>(&Bc[dswz<32>(j * 16 + r16, kc * 4 + q)]));
+                fb[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4 *>(&Bc[dswz<BKT>(j * 16 + r16, kc * 4 + q)]));
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -629,9 +629,193 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_b16_kernel(const unsigned shor
     }
 }
 
+// The same two products on a 256 x 256 output tile (8 waves as 4 x 2, each 64 rows x 128 columns).  The bf16 MFMA does 16x the
+// flops per cycle of the fp32 one, so with 128 x 128 tiles the kernel above is bound by the rate at which tiles can be brought
+// into LDS (the bytes in flight are capped by the LDS, ~2 us of latency each): 4.3 GB of tile traffic per 512 -> 512 launch of
+// 524,288 rows at ~9.4 TB/s.  A 256 x 256 tile needs half the bytes per flop.  Two 64 KiB stages (dynamic LDS, one workgroup per
+// CU); the ReLU bitmask keeps the 128 x 128-tile layout of relu_bits (a wave owns two of its 32-row lane slots), so every
+// consumer of the bitmask is unchanged.
+template <int MODE, int BKT, int NBUF>
+__global__ __launch_bounds__(512, 1) void gemm_nt_b16w_kernel(const unsigned short *__restrict__ A, unsigned lda_b,
+                                                              const unsigned short *__restrict__ B, unsigned ldb_b,
+                                                              const float *__restrict__ bias, float *__restrict__ C, unsigned ldc_b,
+                                                              unsigned short *__restrict__ Cb, unsigned ldcb_b, int64_t M, int K,
+                                                              unsigned long long *__restrict__ bits, int row_tiles128) {
+    // K tiles of 2 BKT values (tile rows of 4 BKT bytes) in a ring of NBUF stages: NBUF - 1 tiles are in flight while one is
+    // multiplied.  Measured at 512 -> 512, 524,288 rows: two 64 KiB stages (BKT 32) ~400 us, four 32 KiB stages (BKT 16) ~440 us; the
+    // 128 x 128 kernel above 458 us at two workgroups per CU and ~430 us with 32 KiB stages at four per CU.  In every form the MFMA pipe
+    // is ~1/3 busy and the waves wait half of their cycles (SQ_WAIT_INST_ANY): after each barrier all 8 waves read their fragments
+    // at once, and with one workgroup per CU nothing else fills that gap.
+    constexpr int TM = 256, TN = 256, STAGE = (TM + TN) * BKT;     // floats
+    constexpr int CPR = BKT / 4, RPI = 64 / CPR, PASS = 8 * RPI;  // 16-byte chunks per row, rows per wave instruction, rows per pass
+    constexpr int DIST = NBUF - 1, PER_STAGE = 2 * (TM / PASS);   // DMA instructions per wave and stage
+    constexpr bool DX = MODE == B16_DX;
+    extern __shared__ __attribute__((aligned(16))) float wlds[];  // [NBUF][A: TM x BKT | B: TN x BKT]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const int r16 = lane & 15, q = lane >> 4;
+    const int wr = wave_u >> 1, wc = wave_u & 1;
+    int row_tile, col_tile;
+    xcd_tile(row_tile, col_tile);
+    const int64_t m0 = (int64_t)row_tile * TM;
+    const int n0 = col_tile * TN;
+    const int rows_here = (int)((M - m0) < TM ? (M - m0) : TM);
+
+    const __amdgpu_buffer_rsrc_t a_rs = make_rsrc(reinterpret_cast<const char *>(A) + m0 * lda_b,
+                                                  (unsigned)(rows_here - 1) * lda_b + (unsigned)K * 2);
+    const __amdgpu_buffer_rsrc_t b_rs = make_rsrc(reinterpret_cast<const char *>(B) + (int64_t)n0 * ldb_b,
+                                                  (unsigned)(TN - 1) * ldb_b + (unsigned)K * 2);
+    // DMA lane map: one wave instruction = RPI rows of 4 BKT bytes; a pass of the 8 waves = PASS rows
+    const int row_p = wave * RPI + lane / CPR, pch = lane % CPR;
+    const int lch = BKT == 32 ? (pch ^ (row_p & 7)) : (pch ^ ((0 - (row_p >> 2)) & 3));  // the source side of dswz<BKT>
+    const unsigned a_off = (unsigned)row_p * lda_b + lch * 16;
+    const unsigned b_off = (unsigned)row_p * ldb_b + lch * 16;
+    const unsigned a_step = (unsigned)PASS * lda_b, b_step = (unsigned)PASS * ldb_b;
+
+    // bitmask words of this wave's two 32-row lane slots (128 x 128-tile layout of relu_bits)
+    size_t widx[2];
+    bool wlive[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int rt128 = row_tile * 2 + (wr >> 1), ct128 = col_tile * 2 + wc, nct128 = gridDim.y * 2;
+        widx[h] = ((size_t)rt128 * nct128 + ct128) * 256 + ((2 * wr + h) & 3) * 64 + lane;
+        wlive[h] = rt128 < row_tiles128;
+    }
+    f32x4 acc[4][8];
+    unsigned long long mask_word[2] = {0, 0};
+    if (DX) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+            if (wlive[h]) mask_word[h] = bits[widx[h]];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    } else {
+        const __amdgpu_buffer_rsrc_t bias_rs = make_rsrc(bias + n0 + wc * 128, 128 * 4);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            acc[0][j] = ldb(bias_rs, (unsigned)(q * 16), j * 64);
+            acc[1][j] = acc[2][j] = acc[3][j] = acc[0][j];
+        }
+    }
+    auto issue_tile = [&](int buf, unsigned kb) {
+        float *Ad = wlds + buf * STAGE + wave_u * RPI * BKT;
+        float *Bd = wlds + buf * STAGE + TM * BKT + wave_u * RPI * BKT;
+#pragma unroll
+        for (int i = 0; i < TM / PASS; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rs, Ad + i * PASS * BKT, 16, a_off, kb + i * a_step, 0, 0);
+#pragma unroll
+        for (int i = 0; i < TN / PASS; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(b_rs, Bd + i * PASS * BKT, 16, b_off, kb + i * b_step, 0, 0);
+    };
+
+    const int nk = K / (2 * BKT);
+#pragma unroll
+    for (int d = 0; d < DIST; ++d)
+        if (d < nk) issue_tile(d, (unsigned)d * (4u * BKT));
+    int cur = 0, nxt = DIST % NBUF;
+    for (int kt = 0; kt < nk; ++kt) {
+        // this wave's pieces of tile kt have landed when at most the later tiles' instructions are outstanding
+        const int later = (nk - 1 - kt) < (DIST - 1) ? (nk - 1 - kt) : (DIST - 1);
+        if (later >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PER_STAGE) : "memory");
+        else if (later == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_STAGE) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();  // everybody's pieces of tile kt are in LDS, and everybody is done reading tile kt - 1
+        if (kt + DIST < nk) issue_tile(nxt, (unsigned)(kt + DIST) * (4u * BKT));  // into the buffer tile kt - 1 occupied
+        const float *Ac = wlds + cur * STAGE + (wr * 64) * BKT;
+        const float *Bc = wlds + cur * STAGE + TM * BKT + (wc * 128) * BKT;
+#pragma unroll
+        for (int kc = 0; kc < BKT / 16; ++kc) {
+            bf16x8 fa[4], fb[8];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                fa[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4 *>(&Ac[dswz<BKT>(i * 16 + r16, kc * 4 + q)]));
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                fb[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4 *>(&Bc[dswz<BKT>(j * 16 + r16, kc * 4 + q)]));
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        cur = cur + 1 == NBUF ? 0 : cur + 1;
+        nxt = nxt + 1 == NBUF ? 0 : nxt + 1;
+    }
+
+    // epilogue, 32-row slot by slot (h): one rounding to bf16; forward: relu + bitmask first, dX: the forward's mask afterwards
+    const int row_l = wr * 64 + r16;
+    const __amdgpu_buffer_rsrc_t cb_rs = make_rsrc(reinterpret_cast<char *>(Cb) + m0 * ldcb_b + (int64_t)(n0 + wc * 128) * 2,
+                                                   (unsigned)(rows_here - 1) * ldcb_b + 128 * 2);
+    const unsigned cb_off = (unsigned)row_l * ldcb_b + q * 8;
+    u32x2 pk[4][8];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        unsigned lo, hi;
+        if (DX) {
+            lo = (unsigned)mask_word[h];
+            hi = (unsigned)(mask_word[h] >> 32);
+        } else {
+            lo = hi = 0;
+#pragma unroll
+            for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float x = relu1(acc[2 * h + ii][j][e]);
+                        acc[2 * h + ii][j][e] = x;
+                        const int b = (ii * 8 + j) * 4 + e;
+                        const unsigned v = x > 0.f ? 1u : 0u;
+                        if (b < 32) lo |= v << b;
+                        else hi |= v << (b - 32);
+                    }
+            if (bits && wlive[h]) bits[widx[h]] = ((unsigned long long)hi << 32) | lo;
+        }
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                unsigned hv[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float x = acc[2 * h + ii][j][e];
+                    unsigned v = (unsigned)__builtin_bit_cast(unsigned short, (__bf16)x);
+                    if (DX) {
+                        const int b = (ii * 8 + j) * 4 + e;
+                        v &= 0u - (((b < 32 ? lo : hi) >> (b & 31)) & 1u);
+                    } else {
+                        acc[2 * h + ii][j][e] = __uint_as_float(v << 16);  // the rounded value as fp32 (for the optional fp32 copy)
+                    }
+                    hv[e] = v;
+                }
+                pk[2 * h + ii][j] = u32x2{hv[0] | (hv[1] << 16), hv[2] | (hv[3] << 16)};
+            }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) __builtin_amdgcn_raw_buffer_store_b64(pk[i][j], cb_rs, cb_off, 16 * i * ldcb_b + j * 32, 0);
+    if (!DX && C) {
+        const __amdgpu_buffer_rsrc_t c_rs = make_rsrc(reinterpret_cast<char *>(C) + m0 * ldc_b + (int64_t)(n0 + wc * 128) * 4,
+                                                      (unsigned)(rows_here - 1) * ldc_b + 128 * 4);
+        const unsigned c_off = (unsigned)row_l * ldc_b + q * 16;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) stb(c_rs, c_off, 16 * i * ldc_b + j * 64, acc[i][j]);
+    }
+}
+
 // Applicability of the bf16-in-memory forward: K a multiple of 64 (one LDS tile row = 64 k-values), hidden widths a multiple
 // of 128 (the bitmask tile geometry).  Everything else takes the fp32 kernels on the ROUNDED fp32 copies -- the same products
 // (a product of two bf16 values is exact in fp32), only slower -- followed by round_rows (optim.hip).
+static int g_b16_wide = 1;  // rlppo_dbg_set(23, .): 256 x 256 tiles for the hidden / dX products of the bf16 update precision (0: 128 x 128)
+void set_b16_wide_tiles(int on) { g_b16_wide = on != 0; }
 bool nt_b16_ok(int N, int K, bool hidden) {
     if (K % 64 != 0) return false;
     return hidden ? N % 128 == 0 : (N % 128 == 0 || N == 96 || N == 64 || N == 32);
@@ -657,6 +841,27 @@ int launch_gemm_nt_b16(hipStream_t st, const unsigned short *A, int64_t lda, con
     RLPPO_CHECK_ARG(129 * lda * 2 < lim && 129 * ldb * 2 < lim && 129 * ldc * 4 < lim && 129 * ldcb * 2 < lim,
                     "gemm_nt (bf16 in memory): a leading dimension is too wide for 32-bit tile offsets");
     const unsigned la = (unsigned)(lda * 2), lb = (unsigned)(ldb * 2), lc = (unsigned)(ldc * 4), lcb = (unsigned)(ldcb * 2);
+    if (mode != B16_OUT && N % 256 == 0 && M >= 1024 && Cb && g_b16_wide && 257 * lda * 2 < lim && 257 * ldb * 2 < lim &&
+        257 * ldc * 4 < lim && 257 * ldcb * 2 < lim) {  // 256 x 256 tiles
+        static bool attr_set[2] = {false, false};
+        const int which = mode == B16_DX ? 1 : 0;
+        constexpr int BKT = 32, NBUF = 2, LDS_BYTES = NBUF * 512 * BKT * 4;
+        const void *fn = which ? (const void *)gemm_nt_b16w_kernel<B16_DX, BKT, NBUF> : (const void *)gemm_nt_b16w_kernel<B16_HIDDEN, BKT, NBUF>;
+        if (!attr_set[which]) {
+            RLPPO_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+            attr_set[which] = true;
+        }
+        dim3 wgrid((unsigned)cdiv(M, 256), (unsigned)(N / 256));
+        const int rt128 = (int)cdiv(M, 128);
+        if (which)
+            hipLaunchKernelGGL((gemm_nt_b16w_kernel<B16_DX, BKT, NBUF>), wgrid, dim3(512), LDS_BYTES, st, A, la, B, lb, bias, C, lc, Cb, lcb, M, K,
+                               bits, rt128);
+        else
+            hipLaunchKernelGGL((gemm_nt_b16w_kernel<B16_HIDDEN, BKT, NBUF>), wgrid, dim3(512), LDS_BYTES, st, A, la, B, lb, bias, C, lc, Cb, lcb, M,
+                               K, bits, rt128);
+        RLPPO_LAUNCH_CHECK();
+        return 0;
+    }
     const int nb = N % 128 == 0 ? 8 : N / 16;
     dim3 grid((unsigned)cdiv(M, SBM), (unsigned)(N / (nb * 16)));
 #define B16(NBV, E, H)                                                                                                      \

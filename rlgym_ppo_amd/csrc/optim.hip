@@ -208,7 +208,7 @@ __global__ __launch_bounds__(256) void gather_rows_round_kernel(const float *__r
         h[e] = bf16_bits(f);
         v[e] = __uint_as_float((unsigned)h[e] << 16);
     }
-    reinterpret_cast<f32x4 *>(dst)[t] = v;
+    if (dst) reinterpret_cast<f32x4 *>(dst)[t] = v;  // the fp32 form only when an fp32 kernel will read the rows
     reinterpret_cast<u16x4 *>(dstb)[t] = h;
 }
 

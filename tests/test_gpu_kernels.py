@@ -73,7 +73,7 @@ def test_gemm_nt(L, M, N, K, epi):
 
 @pytest.mark.parametrize("M,N,K,hidden,epi", [(3072, 512, 512, 1, 1), (1000, 256, 256, 1, 1), (4096 + 77, 512, 256, 1, 1), (700, 128, 64, 1, 1),
                                               (3000, 32, 512, 0, 2), (2500, 96, 256, 0, 0), (513, 256, 128, 0, 0)])
-def test_gemm_nt_b16(L, M, N, K, hidden, epi):
+def test_gemm_nt_b16(L, M, N, K, hidden, epi, b16_tiles):
     """The bf16-in-memory forward product (bf16 update precision): exact bf16 products, fp32 accumulation.  Hidden form: the
     three outputs (bf16, the same values as fp32, ReLU bitmask) are mutually consistent and equal the float64 product rounded to
     bf16 except where fp32 summation noise crosses a rounding boundary; the bitmask is the one the fp32 dX kernel expects."""
@@ -110,8 +110,16 @@ def test_gemm_nt_b16(L, M, N, K, hidden, epi):
     assert torch.equal(D0, D1)
 
 
+@pytest.fixture(params=[1, 0], ids=["tile256", "tile128"])
+def b16_tiles(L, request):
+    """Both tile shapes of the bf16 hidden / dX products (rlppo_dbg_set(23)): 256 x 256 (default where it applies) and 128 x 128."""
+    check(L, L.rlppo_dbg_set(23, request.param))
+    yield request.param
+    check(L, L.rlppo_dbg_set(23, 1))
+
+
 @pytest.mark.parametrize("M,N,K", [(3072, 512, 512), (4096 + 77, 256, 512), (700, 128, 64), (65536, 512, 512)])
-def test_gemm_nt_b16_dx(L, M, N, K):
+def test_gemm_nt_b16_dx(L, M, N, K, b16_tiles):
     """The backward product of the bf16 update precision: dX = round_bf16(dY . W^T-operand) masked by the ReLU bitmask the hidden
     forward of the same M x N geometry wrote.  bf16 in, bf16 out; ragged last row tile; the mask is exact."""
     g = torch.Generator().manual_seed(M + N + K + 1)
