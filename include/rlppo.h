@@ -298,15 +298,20 @@ int rlppo_welford_merge(void *stream, int32_t d, void *mean, void *m2, int64_t c
 int rlppo_set_inference_precision(int32_t mode);
 
 /* Precision of the PPO UPDATE (rlppo_ppo_minibatch): 0 = fp32 (default; the parity mode: fp32 losses/grads within 1e-5 of the
- * reference), 1 = BASELINE configs[4] "bf16 fwd / fp32 master weights": every forward product of both networks multiplies
- * bf16-rounded operands (activations and weights, round-to-nearest-even) on the bf16 MFMA pipe and accumulates in fp32; bias,
- * activations, losses, the whole backward pass, gradient accumulation, clip and Adam stay fp32, and the master weights are the
- * fp32 arena.  The backward is the exact fp32 backward OF THAT FORWARD (torch.autograd of F.linear(r(h), r(W), b) with r =
- * rounding to bf16 and a straight-through gradient): dX multiplies dY with the rounded weights, dW with the rounded inputs,
- * no gradient is rounded.  The reference has no such mode; oracle/nets.py::mlp_bf16_operands + oracle/ppo.py::minibatch_autograd(bf16=True)
- * restate it.  Changing the mode changes rlppo_minibatch_workspace_bytes.
+ * reference), 1 = BASELINE configs[4] "bf16 fwd / fp32 master weights" = mixed-precision training as torch writes it:
+ *   - every forward product of both networks multiplies bf16-rounded operands (activations and weights, round-to-nearest-even)
+ *     on the bf16 MFMA pipe and accumulates in fp32; bias and activation in fp32; the hidden activations are stored as bf16;
+ *   - the gradient with respect to each hidden activation is therefore a bf16 tensor too (rounded once, after the fp32
+ *     accumulation), and every backward product -- dX = dY . r(W), dW = dY^T . r(X) -- multiplies bf16 values on the bf16 MFMA
+ *     pipe with fp32 accumulation;
+ *   - the loss and its gradient with respect to the network outputs, dW / db accumulation, clip and Adam are fp32 and the master
+ *     weights are the fp32 arena (the gradient of a weight is never rounded).
+ * It is torch.autograd of F.linear(h.bfloat16().float(), r(W), b) per layer, r = rounding of a master weight with an identity
+ * backward.  The reference has no such mode; the test suite restates it on the CPU (tests/test_gpu_cfg5.py).  Changing the mode
+ * changes rlppo_minibatch_workspace_bytes.
  * rlppo_net_pack_bf16: the rounded images the mode needs, rebuilt after every optimiser step -- packed_r: the packed layout
- * (rlppo_packed_floats) holding the rounded weights as fp32; wb16: rlppo_wb16_elems bf16 values, the W[Pout][Pin] blocks. */
+ * (rlppo_packed_floats) holding the rounded weights as fp32; wb16: rlppo_wb16_elems bf16 values, the W[Pout][Pin] blocks of all
+ * layers followed by the W^T[Pin][Pout] blocks. */
 int rlppo_set_update_precision(int32_t mode);
 int rlppo_get_update_precision(void);
 int64_t rlppo_wb16_elems(const int32_t *dims, int32_t n_layers);

@@ -481,8 +481,9 @@ def selection_epoch():
 
 def set_update_precision(mode):
     """Precision of the PPO update (PPOLearner.learn): "fp32" (default: the reference's arithmetic, 1e-5 parity) or "bf16" =
-    BASELINE configs[4] "bf16 fwd / fp32 master weights": forward products on bf16-rounded operands (bf16 MFMA, fp32
-    accumulate), fp32 losses / backward / gradient accumulation / clip / Adam on the fp32 master arena (include/rlppo.h)."""
+    BASELINE configs[4] "bf16 fwd / fp32 master weights", i.e. mixed-precision training: forward AND backward products on bf16
+    operands (bf16 activations and activation gradients, bf16 MFMA, fp32 accumulate), fp32 losses / dW, db accumulation / clip /
+    Adam on the fp32 master arena (include/rlppo.h)."""
     N.check(N.lib().rlppo_set_update_precision({"fp32": 0, "bf16": 1}[mode]))
 
 

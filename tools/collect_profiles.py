@@ -18,11 +18,15 @@ copies = {
     "pmc_sq.csv": f"{tag}_pmc_sq.csv", "pmc_fetch.csv": f"{tag}_pmc_fetch.csv", "pmc_write.csv": f"{tag}_pmc_write.csv",
     "traffic.json": f"{tag}_traffic.json", "gae_pmc_fetch.csv": f"{tag}_gae_pmc_fetch.csv", "gae_pmc_write.csv": f"{tag}_gae_pmc_write.csv",
     "gae_traffic.json": f"{tag}_gae_traffic.json",
+    "cfg5_pmc_fetch.csv": f"{tag}_cfg5_bf16_pmc_fetch.csv", "cfg5_pmc_write.csv": f"{tag}_cfg5_bf16_pmc_write.csv",
+    "cfg5_pmc_sq.csv": f"{tag}_cfg5_bf16_pmc_sq.csv", "cfg5_traffic.json": f"{tag}_cfg5_bf16_traffic.json",
+    "rank_share.txt": f"{tag}_rank_share.txt", "gae_floor.txt": f"{tag}_gae_floor.txt",
 }
 for a, b in copies.items():
     shutil.copy(os.path.join(src, a), os.path.join(dst, b))
 for pattern, name in (("stats/*/*kernel_stats.csv", f"{tag}_bench_kernel_stats.csv"), ("stats_single/*/*kernel_stats.csv", f"{tag}_bench_kernel_stats_single_stream.csv"),
-                      ("iso/*/*kernel_stats.csv", f"{tag}_isolated_kernel_stats.csv"), ("gae_stats/*/*kernel_stats.csv", f"{tag}_gae_kernel_stats.csv")):
+                      ("iso/*/*kernel_stats.csv", f"{tag}_isolated_kernel_stats.csv"), ("gae_stats/*/*kernel_stats.csv", f"{tag}_gae_kernel_stats.csv"),
+                      ("cfg5_stats/*/*kernel_stats.csv", f"{tag}_cfg5_bf16_kernel_stats_single_stream.csv")):
     shutil.copy(newest(pattern), os.path.join(dst, name))
 for name in copies.values():
     if name.endswith(".json") and "bench" in name:  # one JSON line -> pretty-printed for reading

@@ -4,7 +4,7 @@
 set -eo pipefail
 TAG=${1:-r02}
 OUT=gpurun_out/$TAG
-rm -rf $OUT/stats $OUT/stats_single $OUT/iso $OUT/pmc_sq $OUT/pmc_fetch $OUT/pmc_write $OUT/gae_stats $OUT/gae_fetch $OUT/gae_write
+rm -rf $OUT/cfg5_stats $OUT/cfg5_fetch $OUT/cfg5_write $OUT/cfg5_sq $OUT/stats $OUT/stats_single $OUT/iso $OUT/pmc_sq $OUT/pmc_fetch $OUT/pmc_write $OUT/gae_stats $OUT/gae_fetch $OUT/gae_write
 mkdir -p $OUT
 export TMPDIR=/tmp
 if [ "$2" != "profiles-only" ]; then
@@ -23,6 +23,11 @@ rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write 
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/gae_stats -- python3 tools/prof_gae.py > $OUT/gae_stats.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/gae_fetch -- python3 tools/prof_gae.py > $OUT/gae_fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/gae_write -- python3 tools/prof_gae.py > $OUT/gae_write.log 2>&1
+# BASELINE configs[4] in the bf16 update precision: per-kernel time inside the update (single stream) and HBM traffic per launch
+RLPPO_TUNE=4=0 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/cfg5_stats -- python3 bench.py --config cfg5 --precision bf16 --steps 2 --warmup 1 --no-extras > $OUT/cfg5_stats.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/cfg5_fetch -- python3 bench.py --config cfg5 --precision bf16 --steps 1 --warmup 0 --no-extras > $OUT/cfg5_fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/cfg5_write -- python3 bench.py --config cfg5 --precision bf16 --steps 1 --warmup 0 --no-extras > $OUT/cfg5_write.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_LDS_BANK_CONFLICT --output-format csv -d $OUT/cfg5_sq -- python3 bench.py --config cfg5 --precision bf16 --steps 1 --warmup 0 --no-extras > $OUT/cfg5_sq.log 2>&1
 export PMC_CYCLE='rlppo::gemm_tn_dma_kernel<32>=dW hidden 256x256,dW L0 256x107,dW head 90x256;rlppo::tn_reduce_kernel=hidden,L0,head;rlppo::gemm_nt_dma_kernel<8, 1, 16, true>=fwd hidden 256->256,fwd L0 128->256;rlppo::gemm_nt_dma_kernel<8, 3, 16, true>=dX hidden 256->256,dX head 96->256'
 python tools/pmc_summary.py $OUT/pmc_sq > $OUT/pmc_sq.csv || true
 python tools/pmc_summary.py $OUT/pmc_fetch > $OUT/pmc_fetch.csv
@@ -31,6 +36,12 @@ python tools/pmc_traffic.py $OUT/pmc_fetch.csv $OUT/pmc_write.csv $OUT/traffic.j
 python tools/pmc_summary.py $OUT/gae_fetch > $OUT/gae_pmc_fetch.csv
 python tools/pmc_summary.py $OUT/gae_write > $OUT/gae_pmc_write.csv
 python tools/pmc_traffic.py $OUT/gae_pmc_fetch.csv $OUT/gae_pmc_write.csv $OUT/gae_traffic.json
+PMC_CYCLE= python tools/pmc_summary.py $OUT/cfg5_fetch > $OUT/cfg5_pmc_fetch.csv
+PMC_CYCLE= python tools/pmc_summary.py $OUT/cfg5_write > $OUT/cfg5_pmc_write.csv
+PMC_CYCLE= python tools/pmc_summary.py $OUT/cfg5_sq > $OUT/cfg5_pmc_sq.csv
+python tools/pmc_traffic.py $OUT/cfg5_pmc_fetch.csv $OUT/cfg5_pmc_write.csv $OUT/cfg5_traffic.json
+python tools/rank_share.py > $OUT/rank_share.txt 2> $OUT/rank_share.log
+python tools/gae_ab.py > $OUT/gae_floor.txt 2> $OUT/gae_floor.log
 find $OUT -name "*_kernel_trace.csv" -size +8M -delete || true
 find $OUT -name "*counter_collection.csv" -size +8M -delete || true
 echo DONE
