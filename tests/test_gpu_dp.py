@@ -22,10 +22,10 @@ def _free_port():
     return p
 
 
-def _build(seed=7, batch=2048):
+def _build(seed=7, batch=2048, hidden=(64, 64)):
     from rlgym_ppo_amd.ppo import ExperienceBuffer, PPOLearner
     torch.manual_seed(seed)
-    learner = PPOLearner(107, 90, 0, (64, 64), (64, 64), (0.1, 1.0), batch, 2, 3e-4, 3e-4, 0.2, 0.005, 512, "cuda:0")
+    learner = PPOLearner(107, 90, 0, hidden, hidden, (0.1, 1.0), batch, 2, 3e-4, 3e-4, 0.2, 0.005, 512, "cuda:0")
     rs = np.random.RandomState(seed)
     n = 4096
     obs = np.clip(rs.randn(n, 107), -5, 5).astype(np.float32)

@@ -63,19 +63,70 @@ def test_gemm_nt_repeatable_under_gpu_sharing():
         bg.wait()
 
 
-def test_update_is_bit_reproducible():
+def test_bf16_products_repeatable_under_gpu_sharing():
+    """The same regression for the kernels of the bf16 update precision (bf16 8-byte buffer stores of the forward / dX epilogues in
+    both tile shapes, the partial-tile stores of the transposing dW kernel): no atomics in any of them, so every run of the same
+    product must be bitwise the same while another process backs up the memory pipeline."""
+    from rlgym_ppo_amd import _native as N
+    L = N.lib()
+    st = lambda: ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    P = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
+    torch.manual_seed(1)
+    bg = subprocess.Popen([sys.executable, "-c", LOAD, "25"])
+    try:
+        time.sleep(4.0)
+        for (M, n, k) in [(512, 256, 128), (4096, 256, 256), (4096 + 33, 512, 512)]:  # 128 x 128 tiles, 256 x 256 tiles, ragged
+            A = torch.randn(M, k, device="cuda").bfloat16()
+            W = (torch.randn(n, k, device="cuda") * 0.1).bfloat16()
+            bias = torch.randn(n, device="cuda") * 0.1
+            H = torch.empty(M, n, dtype=torch.bfloat16, device="cuda")
+            bits = torch.zeros(int(L.rlppo_dbg_gemm_nt_bits_bytes(M, n)), dtype=torch.uint8, device="cuda")
+            dY = torch.randn(M, n, device="cuda").bfloat16()
+            Wt = (torch.randn(k, n, device="cuda") * 0.1).bfloat16()
+            dX = torch.empty(M, k, dtype=torch.bfloat16, device="cuda")
+            xbits = torch.zeros(int(L.rlppo_dbg_gemm_nt_bits_bytes(M, k)), dtype=torch.uint8, device="cuda")
+            xbits.random_(0, 256)
+            dW, db = torch.zeros(n, k, device="cuda"), torch.zeros(n, device="cuda")
+            ws = torch.empty(int(L.rlppo_dbg_gemm_tn_workspace_bytes(n, k, M)), dtype=torch.uint8, device="cuda")
+            fwd = lambda: N.check(L.rlppo_dbg_gemm_nt_b16(st(), P(A), k, P(W), k, P(bias), None, 0, P(H), n, M, n, k, 1, 1, P(bits)))
+            bwd = lambda: N.check(L.rlppo_dbg_gemm_nt_b16(st(), P(dY), n, P(Wt), n, None, None, 0, P(dX), k, M, k, n, 3, 2, P(xbits)))
+            grad = lambda: N.check(L.rlppo_dbg_gemm_tn_b16(st(), P(dY), n, P(A), k, P(dW), P(db), n, k, n, k, M, P(ws), ws.numel()))
+            for run, outs in ((fwd, (H, bits)), (bwd, (dX,)), (grad, (dW, db))):
+                for o in outs:
+                    o.zero_()
+                run()
+                refs = [o.clone() for o in outs]
+                differ = torch.zeros((), dtype=torch.int64, device="cuda")
+                for _ in range(400):
+                    for o in outs:
+                        o.zero_()
+                    run()
+                    for o, r in zip(outs, refs):
+                        differ += (o != r).any()
+                assert int(differ.item()) == 0, (M, n, k, run, int(differ.item()))
+    finally:
+        bg.wait()
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_update_is_bit_reproducible(precision):
     """Weight and bias gradients go through partial tiles / block partials summed in a fixed order (no fp32 atomics whose
     arrival order would leak into the sums), so two runs of the same update from the same state end in bit-identical
     parameters -- with the policy and critic chains racing on two streams and at a size where every launch splits."""
     import contextlib
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from test_gpu_dp import _build
+    from rlgym_ppo_amd.engine import set_update_precision
     finals = []
-    for _ in range(3):
-        with contextlib.redirect_stdout(open(os.devnull, "w")):
-            learner, buf = _build()
-        learner.learn(buf)
-        finals.append((learner.policy.arena.flat.clone(), learner.value_net.arena.flat.clone()))
+    set_update_precision(precision)  # bf16: the transposing dW kernel, the narrow-head partial sums and their fixed-order reductions
+    try:
+        for _ in range(3):
+            with contextlib.redirect_stdout(open(os.devnull, "w")):
+                learner, buf = _build(hidden=(64, 64) if precision == "fp32" else (256, 256))
+            learner.learn(buf)
+            finals.append((learner.policy.arena.flat.clone(), learner.value_net.arena.flat.clone()))
+    finally:
+        set_update_precision("fp32")
     for p, v in finals[1:]:
         assert torch.equal(p, finals[0][0]) and torch.equal(v, finals[0][1])
 
