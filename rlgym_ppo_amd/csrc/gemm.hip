@@ -1265,6 +1265,156 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_b16_kernel(const unsigned shor
     }
 }
 
+// The same product on a 256 x 256 output tile: 8 waves as 4 (n) x 2 (k), each 64 x 128.  The 128 x 128 form brings 32 KiB into LDS
+// per 64-row stage for 32 MFMAs per wave and waits for memory 62 % of its cycles (SQ_WAIT_ANY): it is bound by the tile bytes the
+// LDS can keep in flight; a 256 x 256 tile needs half the bytes per flop.  A stage is four images of the 128 x 128 form (dY columns
+// 0-127 / 128-255, X columns 0-127 / 128-255, each 64 rows x 256 bytes with the same swizzle), two stages = 128 KiB of dynamic LDS,
+// one workgroup per CU.  The partial tiles keep the 128 x 128 layout (a wave writes into two tiles), so the reduction is shared.
+__global__ __launch_bounds__(512, 1) void gemm_tn_b16w_kernel(const unsigned short *__restrict__ dY, unsigned ldy_b,
+                                                              const unsigned short *__restrict__ X, unsigned ldx_b, bool with_db,
+                                                              int out, int64_t M, int rows_per_wg, float *__restrict__ partial) {
+    constexpr int TMT = TNB_ROWS, IMG_B = TMT * 256, STAGE_B = 4 * IMG_B;  // bytes
+    extern __shared__ __attribute__((aligned(16))) float wlds[];
+    char *lds = reinterpret_cast<char *>(wlds);  // [2 stages][dY lo | dY hi | X lo | X hi]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const int r16 = lane & 15, q = lane >> 4;
+    const int wr = wave_u >> 1, wc = wave_u & 1;  // n rows 64 wr .., k columns 128 wc ..
+    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;  // XCD-aware order: see gemm_tn_dma_kernel
+    {
+        const int T = gridDim.x * gridDim.y;
+        if ((gridDim.z & 7) == 0 && T > 1) {
+            const int id = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x, g = id % (8 * T);
+            const int tile = g >> 3;
+            bz = (id / (8 * T)) * 8 + (g & 7);
+            bx = tile % gridDim.x;
+            by = tile / gridDim.x;
+        }
+    }
+    const int n0 = bx * 256, k0 = by * 256;
+    const int64_t mbeg = (int64_t)bz * rows_per_wg;
+    const int rows = (int)((M - mbeg) < rows_per_wg ? (M - mbeg) : rows_per_wg);  // >= 1
+    const int steps = (rows + TMT - 1) / TMT;
+    const int rem = rows - (steps - 1) * TMT;
+
+    // DMA: wave w stages image w >> 1 (0, 1: dY column halves; 2, 3: X column halves), rows 32 (w & 1) .. + 31 of the stage
+    const int img = wave_u >> 1, half = wave_u & 1;
+    const bool is_x = img >= 2;
+    const unsigned ld_b = is_x ? ldx_b : ldy_b;
+    const char *src = (is_x ? reinterpret_cast<const char *>(X) + mbeg * ldx_b + (int64_t)k0 * 2
+                            : reinterpret_cast<const char *>(dY) + mbeg * ldy_b + (int64_t)n0 * 2) + (img & 1) * 256;
+    const __amdgpu_buffer_rsrc_t rs = make_rsrc(src, (unsigned)(rows - 1) * ld_b + 256u);
+    unsigned goff[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int row = 32 * half + 4 * g + (lane >> 4);
+        const int lch = (lane & 15) ^ ((((lane >> 4) & 3) << 2) | (g & 3));
+        goff[g] = (unsigned)row * ld_b + lch * 16;
+    }
+    auto issue_stage = [&](int buf, int stage) {
+        char *dst = lds + buf * STAGE_B + img * IMG_B + half * 32 * 256;
+        const unsigned sbase = (unsigned)stage * TMT * ld_b;
+#pragma unroll
+        for (int g = 0; g < 8; ++g)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, reinterpret_cast<float *>(dst + g * 1024), 16, goff[g & 3],
+                                                     sbase + (g >> 2) * 16 * ld_b, 0, 0);
+    };
+    auto clear_tail = [&](int buf) {  // rows past a ragged split: the DMA dropped them, clear the stale LDS rows (all four images)
+        const f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int r = rem + (tid >> 6); r < TMT; r += 8)
+            *reinterpret_cast<f32x4 *>(lds + buf * STAGE_B + ((tid >> 4) & 3) * IMG_B + r * 256 + (tid & 15) * 16) = z;
+    };
+
+    f32x4 acc[4][8], accb[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        accb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const bool want_db = with_db && by == 0 && wc == 0;  // scalar condition
+
+    int ay[4][2], ax[8][2];  // transposed-read addresses inside an image: see gemm_tn_b16_kernel
+    {
+        const int qq = r16 >> 2, p = r16 & 3;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int row = 8 * q + 4 * h + qq;
+            const int sw = (qq << 2) | ((2 * q + h) & 3);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) ay[c][h] = row * 256 + (((2 * ((wr & 1) * 4 + c) + (p >> 1)) ^ sw) << 4) + 8 * (p & 1);
+#pragma unroll
+            for (int c = 0; c < 8; ++c) ax[c][h] = row * 256 + (((2 * c + (p >> 1)) ^ sw) << 4) + 8 * (p & 1);
+        }
+    }
+    bf16x8 ones;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
+
+    issue_stage(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (steps == 1 && rem < TMT) clear_tail(0);
+    __syncthreads();
+    for (int st = 0; st < steps; ++st) {
+        const int cur = st & 1;
+        const bool more = (st + 1) < steps;
+        if (more) issue_stage(cur ^ 1, st + 1);
+        const char *Yc = lds + cur * STAGE_B + (wr >> 1) * IMG_B;
+        const char *Xc = lds + cur * STAGE_B + (2 + wc) * IMG_B;
+#pragma unroll
+        for (int s = 0; s < TMT / 32; ++s) {
+            bf16x8 fa[4], fb[8];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const s16x4 a0 = lds_tr16(Yc, ay[c][0] + s * 32 * 256), a1 = lds_tr16(Yc, ay[c][1] + s * 32 * 256);
+                fa[c] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7));
+            }
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const s16x4 b0 = lds_tr16(Xc, ax[c][0] + s * 32 * 256), b1 = lds_tr16(Xc, ax[c][1] + s * 32 * 256);
+                fb[c] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7));
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+            if (want_db) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], ones, accb[i], 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (more && (st + 2) == steps && rem < TMT) clear_tail(cur ^ 1);
+        __syncthreads();
+    }
+
+    // the 128 x 128-tile layout tn_reduce_kernel reads: this wave's 64 n rows are quadrant row (wr & 1) of n tile 2 bx + (wr >> 1), its
+    // 128 k columns are both quadrant columns (j >> 2) of k tile 2 by + wc
+    const int tx128 = gridDim.x * 2, ty128 = gridDim.y * 2;
+    const int nt = bx * 2 + (wr >> 1), kt = by * 2 + wc, wn = wr & 1;
+    if (want_db && r16 == 0) {
+        float *pdb = partial + (size_t)gridDim.z * ty128 * tx128 * (128 * 128) + ((size_t)bz * tx128 + nt) * 128;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int nl = wn * 64 + i * 16 + 4 * q + e;
+                if (nt * 128 + nl < out) pdb[nl] = accb[i][e];
+            }
+    }
+    {
+        const size_t tile_id = (size_t)bz * (tx128 * ty128) + (size_t)kt * tx128 + nt;
+        const __amdgpu_buffer_rsrc_t p_rs = make_rsrc(partial + tile_id * (128 * 128), 128 * 128 * 4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                stb(p_rs, (unsigned)((wn * 2 + (j >> 2)) * 64 + lane) * 16, (unsigned)(i * 4 + (j & 3)) * 4096, acc[i][j]);
+    }
+}
+
 // Sums the partial tiles of gemm_tn_dma_kernel over the splits and adds the result into dW[out][in].
 // Block = 64 consecutive 16-byte elements of one tile x 4 split lanes (one wave each: 1 KiB coalesced per load, 8 loads
 // in flight); the four partial sums meet in LDS.  The final add is an atomic only so that launches of different
@@ -1392,9 +1542,20 @@ int launch_gemm_tn_b16(hipStream_t st, const unsigned short *dY, int64_t ldy, co
     RLPPO_CHECK_ARG((rows_per_wg + TNB_ROWS) * ldy * 2 < lim && (rows_per_wg + TNB_ROWS) * ldx * 2 < lim,
                     "gemm_tn (bf16 in memory): a leading dimension is too wide for 32-bit tile offsets");
     const int tiles_x = pout / 128, tiles_y = pin / 128, splits = (int)cdiv(M, rows_per_wg);
-    dim3 grid((unsigned)tiles_x, (unsigned)tiles_y, (unsigned)splits);
-    hipLaunchKernelGGL(gemm_tn_b16_kernel, grid, dim3(256), 0, st, dY, (unsigned)(ldy * 2), X, (unsigned)(ldx * 2), db != nullptr,
-                       out, M, rows_per_wg, ws);
+    if (pout % 256 == 0 && pin % 256 == 0 && g_b16_wide) {  // 256 x 256 tiles (same partial-tile layout, same split count)
+        static bool attr_set = false;
+        constexpr int LDS_BYTES = 2 * 4 * TNB_ROWS * 256;
+        if (!attr_set) {
+            RLPPO_HIP(hipFuncSetAttribute((const void *)gemm_tn_b16w_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(gemm_tn_b16w_kernel, dim3((unsigned)(pout / 256), (unsigned)(pin / 256), (unsigned)splits), dim3(512), LDS_BYTES,
+                           st, dY, (unsigned)(ldy * 2), X, (unsigned)(ldx * 2), db != nullptr, out, M, rows_per_wg, ws);
+    } else {
+        dim3 grid((unsigned)tiles_x, (unsigned)tiles_y, (unsigned)splits);
+        hipLaunchKernelGGL(gemm_tn_b16_kernel, grid, dim3(256), 0, st, dY, (unsigned)(ldy * 2), X, (unsigned)(ldx * 2), db != nullptr,
+                           out, M, rows_per_wg, ws);
+    }
     RLPPO_LAUNCH_CHECK();
     hipLaunchKernelGGL(tn_reduce_kernel, dim3(64, (unsigned)(tiles_x * tiles_y)), dim3(256), 0, st, ws, splits, tiles_x,
                        tiles_x * tiles_y, dW, db, out, in);

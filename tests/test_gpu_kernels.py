@@ -149,8 +149,9 @@ def test_gemm_nt_b16_dx(L, M, N, K, b16_tiles):
 
 
 @pytest.mark.parametrize("M,pout,pin,out,in_", [(4096, 128, 128, 128, 128), (1000, 256, 128, 256, 107), (70000, 512, 512, 512, 512),
-                                               (33, 128, 256, 100, 231), (65536, 512, 256, 512, 231), (5000 + 13, 256, 384, 256, 384)])
-def test_gemm_tn_b16(L, M, pout, pin, out, in_):
+                                               (33, 128, 256, 100, 231), (65536, 512, 256, 512, 231), (5000 + 13, 256, 384, 256, 384),
+                                               (3000 + 7, 256, 256, 200, 256), (100, 512, 256, 512, 256)])
+def test_gemm_tn_b16(L, M, pout, pin, out, in_, b16_tiles):
     """The weight-gradient product of the bf16 update precision: dW += dY^T . X, db += colsum(dY), both operands bf16 in memory,
     contraction over rows through the transposing LDS read; partial tiles + the fixed-order reduction of the fp32 form: ragged last
     stage, padded columns, accumulation on top of existing gradients, bit-identical from run to run."""
