@@ -635,8 +635,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_b16_kernel(const unsigned shor
 // 524,288 rows at ~9.4 TB/s.  A 256 x 256 tile needs half the bytes per flop.  Two 64 KiB stages (dynamic LDS, one workgroup per
 // CU); the ReLU bitmask keeps the 128 x 128-tile layout of relu_bits (a wave owns two of its 32-row lane slots), so every
 // consumer of the bitmask is unchanged.
-template <int MODE, int BKT, int NBUF>
-__global__ __launch_bounds__(512, 1) void gemm_nt_b16w_kernel(const unsigned short *__restrict__ A, unsigned lda_b,
+template <int MODE, int TM, int BKT, int NBUF>
+__global__ __launch_bounds__(TM * 2, TM == 256 ? 1 : 2) void gemm_nt_b16w_kernel(const unsigned short *__restrict__ A, unsigned lda_b,
                                                               const unsigned short *__restrict__ B, unsigned ldb_b,
                                                               const float *__restrict__ bias, float *__restrict__ C, unsigned ldc_b,
                                                               unsigned short *__restrict__ Cb, unsigned ldcb_b, int64_t M, int K,
@@ -646,9 +646,12 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_b16w_kernel(const unsigned sho
     // 128 x 128 kernel above 458 us at two workgroups per CU and ~430 us with 32 KiB stages at four per CU.  In every form the MFMA pipe
     // is ~1/3 busy and the waves wait half of their cycles (SQ_WAIT_INST_ANY): after each barrier all 8 waves read their fragments
     // at once, and with one workgroup per CU nothing else fills that gap.
-    constexpr int TM = 256, TN = 256, STAGE = (TM + TN) * BKT;     // floats
-    constexpr int CPR = BKT / 4, RPI = 64 / CPR, PASS = 8 * RPI;  // 16-byte chunks per row, rows per wave instruction, rows per pass
-    constexpr int DIST = NBUF - 1, PER_STAGE = 2 * (TM / PASS);   // DMA instructions per wave and stage
+    // TM = 256: 8 waves, one workgroup per CU.  TM = 128: 4 waves (2 x 2) on a 128 x 256 tile with half the LDS, two workgroups per
+    // CU -- 1.5x the tile bytes per flop, but the epilogue of one workgroup (half of a launch's time at K = 512: tools/b16_k_sweep.py)
+    // runs under the K loop of the other.
+    constexpr int TN = 256, NW = TM / 32, STAGE = (TM + TN) * BKT;   // waves; floats per stage
+    constexpr int CPR = BKT / 4, RPI = 64 / CPR, PASS = NW * RPI;    // 16-byte chunks per row, rows per wave instruction, rows per pass
+    constexpr int DIST = NBUF - 1, PER_STAGE = (TM + TN) / PASS;     // DMA instructions per wave and stage
     constexpr bool DX = MODE == B16_DX;
     extern __shared__ __attribute__((aligned(16))) float wlds[];  // [NBUF][A: TM x BKT | B: TN x BKT]
 
@@ -679,7 +682,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_b16w_kernel(const unsigned sho
     bool wlive[2];
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-        const int rt128 = row_tile * 2 + (wr >> 1), ct128 = col_tile * 2 + wc, nct128 = gridDim.y * 2;
+        const int rt128 = row_tile * (TM / 128) + (wr >> 1), ct128 = col_tile * 2 + wc, nct128 = gridDim.y * 2;
         widx[h] = ((size_t)rt128 * nct128 + ct128) * 256 + ((2 * wr + h) & 3) * 64 + lane;
         wlive[h] = rt128 < row_tiles128;
     }
@@ -748,9 +751,6 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_b16w_kernel(const unsigned sho
 
     // epilogue, 32-row slot by slot (h): one rounding to bf16; forward: relu + bitmask first, dX: the forward's mask afterwards
     const int row_l = wr * 64 + r16;
-    const __amdgpu_buffer_rsrc_t cb_rs = make_rsrc(reinterpret_cast<char *>(Cb) + m0 * ldcb_b + (int64_t)(n0 + wc * 128) * 2,
-                                                   (unsigned)(rows_here - 1) * ldcb_b + 128 * 2);
-    const unsigned cb_off = (unsigned)row_l * ldcb_b + q * 8;
     u32x2 pk[4][8];
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
@@ -796,10 +796,37 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_b16w_kernel(const unsigned sho
             }
     }
     __builtin_amdgcn_sched_barrier(0);
+    {
+        // The bf16 tile leaves through LDS: as it stands a wave-instruction would store 16 rows x 32 bytes (4 lanes x 8 bytes per
+        // row), a shape the memory system writes at ~2.7 TB/s (the K = 64 launch of tools/b16_k_sweep.py: 570 MB in 210 us whatever the
+        // tile shape).  Each wave parks its 64 x 128 sub-tile in its own 16 KiB of the (now idle) stage memory, 16-byte chunk c of
+        // row r at chunk c ^ (r & 15), and reads it back row by row: 16 bytes per lane, 256 contiguous bytes per row, 4 rows per
+        // wave-instruction.
+        __syncthreads();  // every wave is done with the last stage
+        char *mine = reinterpret_cast<char *>(wlds) + wave_u * (64 * 256);
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) __builtin_amdgcn_raw_buffer_store_b64(pk[i][j], cb_rs, cb_off, 16 * i * ldcb_b + j * 32, 0);
+            for (int j = 0; j < 8; ++j) {
+                const int r = 16 * i + r16, ch = (2 * j + (q >> 1)) ^ (r & 15);
+                *reinterpret_cast<u32x2 *>(mine + r * 256 + ch * 16 + 8 * (q & 1)) = pk[i][j];
+            }
+        // the wave reads only what it wrote itself: LDS operations of one wave complete in order, no barrier needed
+        const int rr = lane >> 4, c16 = lane & 15;
+        typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+        u32x4 v[16];
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const int r = 4 * t + rr;
+            v[t] = *reinterpret_cast<const u32x4 *>(mine + r * 256 + ((c16 ^ (r & 15)) * 16));
+        }
+        const __amdgpu_buffer_rsrc_t o_rs = make_rsrc(reinterpret_cast<char *>(Cb) + m0 * ldcb_b + (int64_t)(n0 + wc * 128) * 2,
+                                                      (unsigned)(rows_here - 1) * ldcb_b + 128 * 2);
+        const unsigned o_off = (unsigned)(wr * 64 + rr) * ldcb_b + c16 * 16;
+#pragma unroll
+        for (int t = 0; t < 16; ++t)
+            __builtin_amdgcn_raw_buffer_store_b128(v[t], o_rs, o_off, 4 * t * ldcb_b, 0);
+    }
     if (!DX && C) {
         const __amdgpu_buffer_rsrc_t c_rs = make_rsrc(reinterpret_cast<char *>(C) + m0 * ldc_b + (int64_t)(n0 + wc * 128) * 4,
                                                       (unsigned)(rows_here - 1) * ldc_b + 128 * 4);
@@ -815,7 +842,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_b16w_kernel(const unsigned sho
 // of 128 (the bitmask tile geometry).  Everything else takes the fp32 kernels on the ROUNDED fp32 copies -- the same products
 // (a product of two bf16 values is exact in fp32), only slower -- followed by round_rows (optim.hip).
 static int g_b16_wide = 1;  // rlppo_dbg_set(23, .): 256 x 256 tiles for the hidden / dX products of the bf16 update precision (0: 128 x 128)
-void set_b16_wide_tiles(int on) { g_b16_wide = on != 0; }
+void set_b16_wide_tiles(int on) { g_b16_wide = on; }
 bool nt_b16_ok(int N, int K, bool hidden) {
     if (K % 64 != 0) return false;
     return hidden ? N % 128 == 0 : (N % 128 == 0 || N == 96 || N == 64 || N == 32);
@@ -843,22 +870,29 @@ int launch_gemm_nt_b16(hipStream_t st, const unsigned short *A, int64_t lda, con
     const unsigned la = (unsigned)(lda * 2), lb = (unsigned)(ldb * 2), lc = (unsigned)(ldc * 4), lcb = (unsigned)(ldcb * 2);
     if (mode != B16_OUT && N % 256 == 0 && M >= 1024 && Cb && g_b16_wide && 257 * lda * 2 < lim && 257 * ldb * 2 < lim &&
         257 * ldc * 4 < lim && 257 * ldcb * 2 < lim) {  // 256 x 256 tiles
-        static bool attr_set[2] = {false, false};
-        const int which = mode == B16_DX ? 1 : 0;
-        constexpr int BKT = 32, NBUF = 2, LDS_BYTES = NBUF * 512 * BKT * 4;
-        const void *fn = which ? (const void *)gemm_nt_b16w_kernel<B16_DX, BKT, NBUF> : (const void *)gemm_nt_b16w_kernel<B16_HIDDEN, BKT, NBUF>;
-        if (!attr_set[which]) {
-            RLPPO_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-            attr_set[which] = true;
-        }
-        dim3 wgrid((unsigned)cdiv(M, 256), (unsigned)(N / 256));
+        // g_b16_wide: 1 = 256 x 256 tiles, one workgroup of 8 waves per CU; 2 = 128 x 256 tiles, two workgroups of 4 waves per CU
+        static bool attr_set[4] = {false, false, false, false};
+        const int which = (mode == B16_DX ? 1 : 0) + (g_b16_wide == 2 ? 2 : 0);
         const int rt128 = (int)cdiv(M, 128);
-        if (which)
-            hipLaunchKernelGGL((gemm_nt_b16w_kernel<B16_DX, BKT, NBUF>), wgrid, dim3(512), LDS_BYTES, st, A, la, B, lb, bias, C, lc, Cb, lcb, M, K,
-                               bits, rt128);
-        else
-            hipLaunchKernelGGL((gemm_nt_b16w_kernel<B16_HIDDEN, BKT, NBUF>), wgrid, dim3(512), LDS_BYTES, st, A, la, B, lb, bias, C, lc, Cb, lcb, M,
-                               K, bits, rt128);
+#define B16W(MODE_, TM_, BKT_)                                                                                               \
+    do {                                                                                                                     \
+        constexpr int STAGES_B = 2 * (TM_ + 256) * BKT_ * 4, PARK_B = (TM_ / 32) * 64 * 256; /* epilogue: 16 KiB per wave */  \
+        constexpr int LDS_BYTES = STAGES_B > PARK_B ? STAGES_B : PARK_B;                                                      \
+        if (!attr_set[which]) {                                                                                              \
+            RLPPO_HIP(hipFuncSetAttribute((const void *)gemm_nt_b16w_kernel<MODE_, TM_, BKT_, 2>,                             \
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));                           \
+            attr_set[which] = true;                                                                                          \
+        }                                                                                                                    \
+        hipLaunchKernelGGL((gemm_nt_b16w_kernel<MODE_, TM_, BKT_, 2>), dim3((unsigned)cdiv(M, TM_), (unsigned)(N / 256)),     \
+                           dim3(TM_ * 2), LDS_BYTES, st, A, la, B, lb, bias, C, lc, Cb, lcb, M, K, bits, rt128);            \
+    } while (0)
+        switch (which) {
+            case 0: B16W(B16_HIDDEN, 256, 32); break;
+            case 1: B16W(B16_DX, 256, 32); break;
+            case 2: B16W(B16_HIDDEN, 128, 16); break;
+            default: B16W(B16_DX, 128, 16); break;
+        }
+#undef B16W
         RLPPO_LAUNCH_CHECK();
         return 0;
     }
@@ -1491,9 +1525,20 @@ static int64_t tn_partial_rows(int out, int in, int64_t M) {
     const int64_t few = round_up(cdiv(M * tiles, 512), 32);
     return few > rows ? few : rows;
 }
+// rows per workgroup of the 256 x 256-tile bf16 form: one round of one workgroup per CU
+static int64_t tn_partial_rows_wide(int pout, int pin, int64_t M) {
+    const int64_t tiles = (int64_t)(pout / 256) * (pin / 256);
+    const int64_t rows = round_up(cdiv(M * tiles, 256), 64);
+    return rows > 256 ? rows : 256;
+}
 size_t tn_partial_floats(int out, int in, int64_t M) {
     if (M <= 0) return 0;
-    const size_t splits = (size_t)cdiv(M, tn_partial_rows(out, in, M));
+    size_t splits = (size_t)cdiv(M, tn_partial_rows(out, in, M));
+    const int pout = (int)round_up(out, 128), pin = (int)round_up(in, 128);
+    if (pout % 256 == 0 && pin % 256 == 0) {  // the wide bf16 form may split finer: size for whichever form splits more
+        const size_t w = (size_t)cdiv(M, tn_partial_rows_wide(pout, pin, M));
+        splits = w > splits ? w : splits;
+    }
     return splits * (size_t)(cdiv(out, 128) * cdiv(in, 128)) * (128 * 128) + splits * (size_t)cdiv(out, 128) * 128;  // tiles + db
 }
 
@@ -1541,8 +1586,13 @@ int launch_gemm_tn_b16(hipStream_t st, const unsigned short *dY, int64_t ldy, co
     const int64_t lim = (int64_t)1 << 30;
     RLPPO_CHECK_ARG((rows_per_wg + TNB_ROWS) * ldy * 2 < lim && (rows_per_wg + TNB_ROWS) * ldx * 2 < lim,
                     "gemm_tn (bf16 in memory): a leading dimension is too wide for 32-bit tile offsets");
-    const int tiles_x = pout / 128, tiles_y = pin / 128, splits = (int)cdiv(M, rows_per_wg);
-    if (pout % 256 == 0 && pin % 256 == 0 && g_b16_wide) {  // 256 x 256 tiles (same partial-tile layout, same split count)
+    const int tiles_x = pout / 128, tiles_y = pin / 128;
+    int splits = (int)cdiv(M, rows_per_wg);
+    if (pout % 256 == 0 && pin % 256 == 0 && g_b16_wide) {  // 256 x 256 tiles (same partial-tile layout, its own split count)
+        const int rows_w = (int)tn_partial_rows_wide(pout, pin, M);
+        RLPPO_CHECK_ARG((rows_w + TNB_ROWS) * ldy * 2 < lim && (rows_w + TNB_ROWS) * ldx * 2 < lim,
+                        "gemm_tn (bf16 in memory): a leading dimension is too wide for 32-bit tile offsets");
+        splits = (int)cdiv(M, rows_w);
         static bool attr_set = false;
         constexpr int LDS_BYTES = 2 * 4 * TNB_ROWS * 256;
         if (!attr_set) {
@@ -1550,7 +1600,7 @@ int launch_gemm_tn_b16(hipStream_t st, const unsigned short *dY, int64_t ldy, co
             attr_set = true;
         }
         hipLaunchKernelGGL(gemm_tn_b16w_kernel, dim3((unsigned)(pout / 256), (unsigned)(pin / 256), (unsigned)splits), dim3(512), LDS_BYTES,
-                           st, dY, (unsigned)(ldy * 2), X, (unsigned)(ldx * 2), db != nullptr, out, M, rows_per_wg, ws);
+                           st, dY, (unsigned)(ldy * 2), X, (unsigned)(ldx * 2), db != nullptr, out, M, rows_w, ws);
     } else {
         dim3 grid((unsigned)tiles_x, (unsigned)tiles_y, (unsigned)splits);
         hipLaunchKernelGGL(gemm_tn_b16_kernel, grid, dim3(256), 0, st, dY, (unsigned)(ldy * 2), X, (unsigned)(ldx * 2), db != nullptr,
