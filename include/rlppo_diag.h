@@ -27,10 +27,12 @@ int rlppo_dbg_probe_coissue(void *stream, const float *buf, int32_t flags, int32
  * mode: 0 real; 1 every workgroup reads the same 1024 A rows (A from L2); 2 output stores dropped; 3 both */
 int rlppo_dbg_gemm_nt_stamped(void *stream, const float *A, int64_t lda, const float *B, int64_t ldb, const float *bias,
                               float *C, int64_t ldc, int64_t M, int32_t N, int32_t K, uint64_t *stamps, int32_t mode);
-/* Streaming floor of the GAE scan: four fp32 input streams and three output streams of n steps (n % 8 == 0), 8 steps per thread,
- * an elementwise map instead of the scan: 28 B/step through the memory system and nothing else. */
+/* Streaming floor of the GAE scan: four fp32 input streams and three output streams of n steps (n % 2048 == 0), 8 steps per thread,
+ * an elementwise map instead of the scan: 28 B/step through the memory system and nothing else.  shape 0: a thread owns 8
+ * consecutive steps (two float4 at a 32-byte lane stride, the scan's own access shape); shape 1: a thread owns two float4 groups
+ * 256 lanes apart, so every wave-instruction moves 1 KiB of contiguous bytes. */
 int rlppo_dbg_stream_floor(void *stream, const float *r, const float *d, const float *t, const float *v, float *o0, float *o1,
-                           float *o2, int64_t n);
+                           float *o2, int64_t n, int32_t shape);
 #ifdef __cplusplus
 }
 #endif

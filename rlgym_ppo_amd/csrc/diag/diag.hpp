@@ -10,5 +10,5 @@ int launch_probe_coissue(hipStream_t st, const float *buf, int flags, int iters,
 int launch_probe2(hipStream_t st, int mode, int threads, int blocks, const float *W, float *out, int chunks);
 int launch_mfma_probe(hipStream_t st, float *out, int blocks, int iters, unsigned long long *clocks);
 int launch_stream_floor(hipStream_t st, const float *r, const float *d, const float *t, const float *v, float *o0, float *o1,
-                        float *o2, long long n);
+                        float *o2, long long n, int shape);
 }  // namespace rlppo

@@ -61,14 +61,18 @@ int launch_mfma_probe(hipStream_t st, float *out, int blocks, int iters, unsigne
 __global__ __launch_bounds__(256) void stream_floor_kernel(const float *__restrict__ r, const float *__restrict__ d,
                                                            const float *__restrict__ t, const float *__restrict__ v,
                                                            float *__restrict__ o0, float *__restrict__ o1, float *__restrict__ o2,
-                                                           long long n8) {
+                                                           long long n8, int shape) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= n8) return;
-    const float4 *r4 = (const float4 *)r + 2 * i, *d4 = (const float4 *)d + 2 * i, *t4 = (const float4 *)t + 2 * i,
-                 *v4 = (const float4 *)v + 2 * i;
+    // shape 0: a thread owns 8 consecutive steps (two float4 at a 32-byte lane stride: the scan's shape); shape 1: a thread owns two
+    // float4 groups 256 lanes apart, so that every wave-instruction moves 1 KiB of contiguous bytes
+    const long long base = shape ? (long long)blockIdx.x * 512 + threadIdx.x : 2 * i;
+    const long long step = shape ? 256 : 1;
+    const float4 *r4 = (const float4 *)r + base, *d4 = (const float4 *)d + base, *t4 = (const float4 *)t + base,
+                 *v4 = (const float4 *)v + base;
     float4 a[2], b[2], c[2], e[2];
 #pragma unroll
-    for (int k = 0; k < 2; ++k) { a[k] = r4[k]; b[k] = d4[k]; c[k] = t4[k]; e[k] = v4[k]; }
+    for (int k = 0; k < 2; ++k) { a[k] = r4[k * step]; b[k] = d4[k * step]; c[k] = t4[k * step]; e[k] = v4[k * step]; }
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
         float4 x, y, z;
@@ -76,13 +80,13 @@ __global__ __launch_bounds__(256) void stream_floor_kernel(const float *__restri
         x.z = a[k].z + 0.99f * e[k].z * (1.f - b[k].z); x.w = a[k].w + 0.99f * e[k].w * (1.f - b[k].w);
         y.x = x.x * (1.f - c[k].x); y.y = x.y * (1.f - c[k].y); y.z = x.z * (1.f - c[k].z); y.w = x.w * (1.f - c[k].w);
         z.x = y.x + e[k].x; z.y = y.y + e[k].y; z.z = y.z + e[k].z; z.w = y.w + e[k].w;
-        ((float4 *)o0)[2 * i + k] = x; ((float4 *)o1)[2 * i + k] = y; ((float4 *)o2)[2 * i + k] = z;
+        ((float4 *)o0)[base + k * step] = x; ((float4 *)o1)[base + k * step] = y; ((float4 *)o2)[base + k * step] = z;
     }
 }
 int launch_stream_floor(hipStream_t st, const float *r, const float *d, const float *t, const float *v, float *o0, float *o1,
-                        float *o2, long long n) {
+                        float *o2, long long n, int shape) {
     const long long n8 = n / 8;
-    hipLaunchKernelGGL(stream_floor_kernel, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, st, r, d, t, v, o0, o1, o2, n8);
+    hipLaunchKernelGGL(stream_floor_kernel, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, st, r, d, t, v, o0, o1, o2, n8, shape);
     RLPPO_LAUNCH_CHECK();
     return 0;
 }
@@ -109,8 +113,8 @@ int rlppo_dbg_mfma_probe(void *stream, float *out, int32_t blocks, int32_t iters
     return launch_mfma_probe((hipStream_t)stream, out, blocks, iters, (unsigned long long *)clocks);
 }
 int rlppo_dbg_stream_floor(void *stream, const float *r, const float *d, const float *t, const float *v, float *o0, float *o1,
-                           float *o2, int64_t n) {
-    if (n <= 0 || n % 8) return 1001;
-    return launch_stream_floor((hipStream_t)stream, r, d, t, v, o0, o1, o2, (long long)n);
+                           float *o2, int64_t n, int32_t shape) {
+    if (n <= 0 || n % 2048) return 1001;
+    return launch_stream_floor((hipStream_t)stream, r, d, t, v, o0, o1, o2, (long long)n, shape);
 }
 }

@@ -32,14 +32,17 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
         sys.path.insert(0, os.path.join(ROOT, "tools"))
         import _diag
         o = [torch.empty(n, device="cuda") for _ in range(3)]
-        floor = lambda: _diag.check(_diag.DL.rlppo_dbg_stream_floor(st, P(R), P(D), P(T), P(V), P(o[0]), P(o[1]), P(o[2]), n))
+        floor = lambda shape: (lambda: _diag.check(_diag.DL.rlppo_dbg_stream_floor(st, P(R), P(D), P(T), P(V), P(o[0]), P(o[1]), P(o[2]), n, shape)))
         src, dst = torch.empty(28 * n // 8, device="cuda"), torch.empty(28 * n // 8, device="cuda")
-        bench.time_region(floor, 1, warm_s=0.3)
-        fl = [bench.time_region(floor, 20, warm=2) for _ in range(7)]
+        bench.time_region(floor(0), 1, warm_s=0.3)
+        fl = [bench.time_region(floor(0), 20, warm=2) for _ in range(7)]
+        fl1 = [bench.time_region(floor(1), 20, warm=2) for _ in range(7)]
         cp = [bench.time_region(lambda: dst.copy_(src), 20, warm=2) for _ in range(7)]
-        for name, ts in (("streaming floor (same streams, elementwise map)", fl), ("device copy of 29.4 MB (same bytes moved)", cp)):
+        for name, ts in (("streaming floor (same streams, 8 consecutive steps per thread)", fl),
+                         ("streaming floor, lane-contiguous float4 (1 KiB per wave-instruction)", fl1),
+                         ("device copy of 29.4 MB (same bytes moved)", cp)):
             us = float(np.median(ts)) * 1e3
-            print(f"{name:>52s}: {us:6.2f} us  {28 * n / us / 1e6:6.2f} TB/s  ({28 * n / us / 8e6:.3f} of 8 TB/s)")
+            print(f"{name:>72s}: {us:6.2f} us  {28 * n / us / 1e6:6.2f} TB/s  ({28 * n / us / 8e6:.3f} of 8 TB/s)")
     for over in (0, 1):
         us = float(np.median(res[over])) * 1e3
         print(f"{os.environ.get('RLPPO_LIB', 'default build'):>40s}  oversubscribe={over}: {us:6.2f} us  {28 * n / us / 1e6:6.2f} TB/s  ({28 * n / us / 8e6:.3f} of 8 TB/s)")
