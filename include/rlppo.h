@@ -323,7 +323,8 @@ int rlppo_net_pack_bf16(void *stream, const int32_t *dims, int32_t n_layers, con
  *   4 policy / critic chains of rlppo_ppo_minibatch on two streams [1]
  *  21 GAE look-back spin limit [-1 = default 2^20 | 0 = every wait times out at once (tests)]
  *  22 GAE grid [0 = at most the resident capacity, workgroups loop over chunks beyond it | 1 = one workgroup per chunk always]
- *  23 bf16 update precision, hidden-layer forward / dX tile [1 = 256 x 256 (default) | 0 = 128 x 128] */
+ *  23 bf16 update precision, tile of the hidden-layer forward / dX / dW products [1 = 256 x 256, one workgroup per CU (default) |
+ *     2 = 128 x 256 forward / dX at two workgroups per CU | 0 = 128 x 128] */
 int rlppo_dbg_set(int32_t key, int32_t value);
 /* Counter bumped by every call that changes which kernels later launches select (rlppo_dbg_set, rlppo_set_*_precision): a
  * host that caches captured graphs of library calls keys them on it (rlgym_ppo_amd/ppo/_mlp.py::ActGraph). */
