@@ -603,7 +603,7 @@ def main():
             emitted.append(1)
             print(json.dumps(out), flush=True)
 
-    if world > 1 and args.allreduce == "ab" and not dryrun:
+    if world > 1 and args.allreduce == "ab" and dry != "2":  # (the one-GPU dry run walks through it too: both legs then go through gloo)
         # The direct communicator has its first multi-rank run here.  Whatever happens to the A/B, every rank leaves and rank 0
         # has printed the headline line: a watchdog thread prints it and exits the process if the A/B has not finished within
         # 120 s, or as soon as SIGTERM arrives (the launcher tearing the job down because another rank died) -- the signal
