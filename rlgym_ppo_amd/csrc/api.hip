@@ -878,6 +878,7 @@ int rlppo_dbg_set(int32_t key, int32_t value) {
         case 21: set_gae_spin_limit(value); return 0;
         case 22: set_gae_oversubscribe(value); return 0;
         case 23: set_b16_wide_tiles(value); return 0;
+        case 24: set_exp_fast_transform(value); return 0;
         default: break;
     }
     set_error("dbg_set: unknown key %d", key);

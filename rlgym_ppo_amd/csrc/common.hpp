@@ -86,6 +86,7 @@ bool nt_b16_ok(int N, int K, bool hidden);
 int launch_gemm_nt_b16(hipStream_t st, const unsigned short *A, int64_t lda, const unsigned short *B, int64_t ldb, const float *bias,
                        float *C, int64_t ldc, unsigned short *Cb, int64_t ldcb, int64_t M, int N, int K, int epi, int mode,
                        unsigned long long *bits);  // mode: 0 output layer, 1 hidden layer, 2 rounded + masked dX
+void set_exp_fast_transform(int on);  // rlppo_dbg_set(24): certified AVX2 transform of rlppo_torch_cpu_exponential (1, default) or libm only
 void set_b16_wide_tiles(int on);  // rlppo_dbg_set(23): 256 x 256 (default) or 128 x 128 tiles in the bf16 hidden / dX products
 bool tn_b16_ok(int pout, int pin);
 int launch_gemm_tn_b16(hipStream_t st, const unsigned short *dY, int64_t ldy, const unsigned short *X, int64_t ldx, float *dW,

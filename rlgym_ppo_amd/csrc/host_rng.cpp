@@ -269,6 +269,39 @@ struct TorchState {
 };
 static_assert(sizeof(TorchState) == 8 + 8 + 8 + 8 * N, "layout of the legacy generator state header");
 
+// The stream phase 16 words per step where the host has AVX-512 (checked at run time): one 624-word regeneration and the tempering
+// of `take` words from src to dst.  Same recurrences as regen() / temper8(); the 16-word steps stay inside the 227-word distance
+// between a word and the newest word it depends on.
+__attribute__((target("avx512f"))) static inline void twist16(uint32_t *mt, int kk, int far) {
+    const __m512i upper = _mm512_set1_epi32((int)UPPER), lower = _mm512_set1_epi32((int)LOWER);
+    const __m512i mat = _mm512_set1_epi32((int)MATRIX_A), one = _mm512_set1_epi32(1);
+    const __m512i cur = _mm512_loadu_si512((const void *)(mt + kk)), nxt = _mm512_loadu_si512((const void *)(mt + kk + 1));
+    const __m512i y = _mm512_or_si512(_mm512_and_si512(cur, upper), _mm512_and_si512(nxt, lower));
+    const __m512i odd = _mm512_sub_epi32(_mm512_setzero_si512(), _mm512_and_si512(y, one));  // 0 or ~0
+    const __m512i r = _mm512_xor_si512(_mm512_xor_si512(_mm512_loadu_si512((const void *)(mt + far)), _mm512_srli_epi32(y, 1)),
+                                       _mm512_and_si512(odd, mat));
+    _mm512_storeu_si512((void *)(mt + kk), r);
+}
+__attribute__((target("avx512f"))) static void regen512(uint32_t *mt) {
+    int kk = 0;
+    for (; kk + 16 <= N - M; kk += 16) twist16(mt, kk, kk + M);
+    for (; kk < N - M; kk++) mt[kk] = twist(mt[kk], mt[kk + 1], mt[kk + M]);
+    for (; kk + 16 <= N - 1; kk += 16) twist16(mt, kk, kk + (M - N));
+    for (; kk < N - 1; kk++) mt[kk] = twist(mt[kk], mt[kk + 1], mt[kk + (M - N)]);
+    mt[N - 1] = twist(mt[N - 1], mt[0], mt[M - 1]);
+}
+__attribute__((target("avx512f"))) static int temper512(const uint32_t *src, uint32_t *dst, int take) {
+    int k = 0;
+    for (; k + 16 <= take; k += 16) {
+        __m512i y = _mm512_loadu_si512((const void *)(src + k));
+        y = _mm512_xor_si512(y, _mm512_srli_epi32(y, 11));
+        y = _mm512_xor_si512(y, _mm512_and_si512(_mm512_slli_epi32(y, 7), _mm512_set1_epi32((int)0x9d2c5680u)));
+        y = _mm512_xor_si512(y, _mm512_and_si512(_mm512_slli_epi32(y, 15), _mm512_set1_epi32((int)0xefc60000u)));
+        y = _mm512_xor_si512(y, _mm512_srli_epi32(y, 18));
+        _mm512_storeu_si512((void *)(dst + k), y);
+    }
+    return k;
+}
 inline void temper8(const uint32_t *src, uint32_t *dst) {
     __m256i y = _mm256_loadu_si256((const __m256i *)src);
     y = _mm256_xor_si256(y, _mm256_srli_epi32(y, 11));
@@ -284,6 +317,134 @@ inline void temper8(const uint32_t *src, uint32_t *dst) {
 #include <mutex>
 
 namespace {
+// ---- the transform out = (float)(scale * log1p(-u)), u = k 2^-53, certified against libm
+// libm's log1p costs ~7 ns per element (2.6 ms for the 4096 x 90 draw of one rollout step); torch's result is what it returns,
+// rounded to float32.  A vectorised logarithm cannot be trusted to reproduce libm's last bit -- but only the FLOAT32 rounding of
+// the product is needed, and that is decided by any double within 1e-13 relative of libm's unless the value sits that close to a
+// float32 rounding boundary (3 elements per million).  So: x = 1 - u is exact in double (u is a multiple of 2^-53), log(x) comes
+// from an AVX2 evaluation -- x = 2^e m, m in [sqrt(1/2), sqrt(2)), s = (m - 1) / (m + 1), log m = 2 s (1 + s^2/3 + ... +
+// s^22/23), e ln2 added as hi + lo parts: relative error below 2e-15 -- and an element is accepted only if y (1 - 1e-13) and
+// y (1 + 1e-13) round to the SAME float32; libm's value (within 1 ulp of the truth, times one rounded product) lies between
+// them, so it rounds to that float as well.  Everything else (and u = 0, whose result is a signed zero) goes through libm.
+// The tests pin the outcome against torch itself and the two paths against each other over 2^24 values.
+static int g_exp_fast = 1;  // rlppo_dbg_set(24, .)
+inline void exp_exact(const uint32_t *w, float *out, int64_t i, double scale) {
+    const uint64_t r64 = ((uint64_t)w[2 * i] << 32) | (uint64_t)w[2 * i + 1];
+    const double u = (double)(r64 & ((1ULL << 53) - 1)) * (1.0 / 9007199254740992.0);
+    out[i] = (float)(scale * log1p(-u));
+}
+// the same evaluation 8 elements at a time where the host has AVX-512 (checked at run time; the file is built for AVX2)
+__attribute__((target("avx512f,avx512dq"))) static int64_t exp_transform_512(const uint32_t *w, float *out, int64_t i, int64_t hi,
+                                                                             double scale) {
+    const __m512d one = _mm512_set1_pd(1.0), half = _mm512_set1_pd(0.5), sqrt2 = _mm512_set1_pd(1.4142135623730951);
+    const __m512d inv53 = _mm512_set1_pd(1.0 / 9007199254740992.0);
+    const __m512d ln2_hi = _mm512_set1_pd(6.93147180369123816490e-01), ln2_lo = _mm512_set1_pd(1.90821492927058770002e-10);
+    const __m512d vscale = _mm512_set1_pd(scale), eps_lo = _mm512_set1_pd(1.0 - 1e-13), eps_hi = _mm512_set1_pd(1.0 + 1e-13);
+    const __m512i mask53 = _mm512_set1_epi64((1LL << 53) - 1), mant = _mm512_set1_epi64(0x000fffffffffffffLL);
+    const __m512i expo1 = _mm512_set1_epi64(0x3ff0000000000000LL), bias = _mm512_set1_epi64(1023), ione = _mm512_set1_epi64(1);
+    for (; i + 8 <= hi; i += 8) {
+        const __m512i r64 = _mm512_shuffle_epi32(_mm512_loadu_si512((const void *)(w + 2 * i)), (_MM_PERM_ENUM)0xB1);
+        const __m512d kd = _mm512_cvtepi64_pd(_mm512_and_si512(r64, mask53));       // exact: < 2^53
+        const __m512d x = _mm512_sub_pd(one, _mm512_mul_pd(kd, inv53));             // exact
+        const __m512i xb = _mm512_castpd_si512(x);
+        __m512i e = _mm512_sub_epi64(_mm512_srli_epi64(xb, 52), bias);
+        __m512d m = _mm512_castsi512_pd(_mm512_or_si512(_mm512_and_si512(xb, mant), expo1));
+        const __mmask8 big = _mm512_cmp_pd_mask(m, sqrt2, _CMP_GT_OQ);
+        m = _mm512_mask_mul_pd(m, big, m, half);
+        e = _mm512_mask_add_epi64(e, big, e, ione);
+        const __m512d ed = _mm512_cvtepi64_pd(e);
+        const __m512d sq = _mm512_div_pd(_mm512_sub_pd(m, one), _mm512_add_pd(m, one)), s2 = _mm512_mul_pd(sq, sq);
+        __m512d p = _mm512_set1_pd(1.0 / 23.0);
+        p = _mm512_fmadd_pd(p, s2, _mm512_set1_pd(1.0 / 21.0));
+        p = _mm512_fmadd_pd(p, s2, _mm512_set1_pd(1.0 / 19.0));
+        p = _mm512_fmadd_pd(p, s2, _mm512_set1_pd(1.0 / 17.0));
+        p = _mm512_fmadd_pd(p, s2, _mm512_set1_pd(1.0 / 15.0));
+        p = _mm512_fmadd_pd(p, s2, _mm512_set1_pd(1.0 / 13.0));
+        p = _mm512_fmadd_pd(p, s2, _mm512_set1_pd(1.0 / 11.0));
+        p = _mm512_fmadd_pd(p, s2, _mm512_set1_pd(1.0 / 9.0));
+        p = _mm512_fmadd_pd(p, s2, _mm512_set1_pd(1.0 / 7.0));
+        p = _mm512_fmadd_pd(p, s2, _mm512_set1_pd(1.0 / 5.0));
+        p = _mm512_fmadd_pd(p, s2, _mm512_set1_pd(1.0 / 3.0));
+        p = _mm512_fmadd_pd(p, s2, one);
+        const __m512d logm = _mm512_mul_pd(_mm512_add_pd(sq, sq), p);
+        const __m512d lg = _mm512_fmadd_pd(ed, ln2_hi, _mm512_fmadd_pd(ed, ln2_lo, logm));
+        const __m512d y = _mm512_mul_pd(vscale, lg);
+        const __m256 f0 = _mm512_cvtpd_ps(_mm512_mul_pd(y, eps_lo)), f1 = _mm512_cvtpd_ps(_mm512_mul_pd(y, eps_hi));
+        const int same = _mm256_movemask_ps(_mm256_cmp_ps(f0, f1, _CMP_EQ_OQ));
+        const int nonzero = (int)_mm512_cmp_pd_mask(lg, _mm512_setzero_pd(), _CMP_NEQ_OQ);
+        _mm256_storeu_ps(out + i, f0);
+        const int bad = ~(same & nonzero) & 255;
+        if (bad)
+            for (int t = 0; t < 8; ++t)
+                if ((bad >> t) & 1) exp_exact(w, out, i + t, scale);
+    }
+    return i;
+}
+inline void exp_transform(const uint32_t *w, float *out, int64_t lo, int64_t hi, double scale) {
+    auto exact = [&](int64_t i) { exp_exact(w, out, i, scale); };
+    int64_t i = lo;
+    static const bool have512 = __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512dq");
+    if (g_exp_fast && have512) i = exp_transform_512(w, out, i, hi, scale);
+    if (g_exp_fast) {
+        const __m256d one = _mm256_set1_pd(1.0), half = _mm256_set1_pd(0.5), sqrt2 = _mm256_set1_pd(1.4142135623730951);
+        const __m256d two52 = _mm256_set1_pd(4503599627370496.0);
+        const __m256d two84_52 = _mm256_set1_pd(19342813118337666422669312.0);  // 2^84 + 2^52
+        const __m256d inv53 = _mm256_set1_pd(1.0 / 9007199254740992.0);
+        const __m256d ln2_hi = _mm256_set1_pd(6.93147180369123816490e-01), ln2_lo = _mm256_set1_pd(1.90821492927058770002e-10);
+        const __m256d vscale = _mm256_set1_pd(scale), eps_lo = _mm256_set1_pd(1.0 - 1e-13), eps_hi = _mm256_set1_pd(1.0 + 1e-13);
+        const __m256i mask53 = _mm256_set1_epi64x((1LL << 53) - 1), lo32 = _mm256_set1_epi64x(0xffffffffLL);
+        const __m256i mant = _mm256_set1_epi64x(0x000fffffffffffffLL), expo1 = _mm256_set1_epi64x(0x3ff0000000000000LL);
+        const __m256i magic_lo = _mm256_set1_epi64x(0x4330000000000000LL), magic_hi = _mm256_set1_epi64x(0x4530000000000000LL);
+        const __m256i bias = _mm256_set1_epi64x(1023);
+        for (; i + 4 <= hi; i += 4) {
+            // r64 = (w[2i] << 32) | w[2i+1]: the pairs are stored high word first, i.e. as 64-bit lanes with the halves swapped
+            const __m256i raw = _mm256_loadu_si256((const __m256i *)(w + 2 * i));
+            const __m256i r64 = _mm256_shuffle_epi32(raw, 0xB1);
+            const __m256i k = _mm256_and_si256(r64, mask53);
+            // exact int64 (< 2^53) -> double: low 32 bits and high 21 bits through the 2^52 / 2^84 exponent tricks
+            const __m256d dlo = _mm256_castsi256_pd(_mm256_or_si256(_mm256_and_si256(k, lo32), magic_lo));
+            const __m256d dhi = _mm256_castsi256_pd(_mm256_or_si256(_mm256_srli_epi64(k, 32), magic_hi));
+            const __m256d kd = _mm256_add_pd(_mm256_sub_pd(dhi, two84_52), dlo);  // (hi 2^32 + 2^84 - 2^84 - 2^52) + (lo + 2^52): exact
+            const __m256d x = _mm256_sub_pd(one, _mm256_mul_pd(kd, inv53));       // exact: a multiple of 2^-53 in (0, 1]
+            const __m256i xb = _mm256_castpd_si256(x);
+            __m256i e = _mm256_sub_epi64(_mm256_srli_epi64(xb, 52), bias);        // x > 0: no sign bit
+            __m256d m = _mm256_castsi256_pd(_mm256_or_si256(_mm256_and_si256(xb, mant), expo1));  // [1, 2)
+            const __m256d big = _mm256_cmp_pd(m, sqrt2, _CMP_GT_OQ);
+            m = _mm256_blendv_pd(m, _mm256_mul_pd(m, half), big);
+            e = _mm256_sub_epi64(e, _mm256_castpd_si256(big));                    // big lanes are all-ones = -1: e += 1
+            // e in [-53, 0] -> double through the same 2^52 trick on e + 2^52's mantissa (e + 64 is a small non-negative integer)
+            const __m256d ed = _mm256_sub_pd(_mm256_castsi256_pd(_mm256_or_si256(_mm256_add_epi64(e, _mm256_set1_epi64x(64)), magic_lo)),
+                                             _mm256_add_pd(two52, _mm256_set1_pd(64.0)));
+            const __m256d sn = _mm256_sub_pd(m, one), sd = _mm256_add_pd(m, one);
+            const __m256d sq = _mm256_div_pd(sn, sd), s2 = _mm256_mul_pd(sq, sq);
+            __m256d p = _mm256_set1_pd(1.0 / 23.0);
+            p = _mm256_add_pd(_mm256_mul_pd(p, s2), _mm256_set1_pd(1.0 / 21.0));
+            p = _mm256_add_pd(_mm256_mul_pd(p, s2), _mm256_set1_pd(1.0 / 19.0));
+            p = _mm256_add_pd(_mm256_mul_pd(p, s2), _mm256_set1_pd(1.0 / 17.0));
+            p = _mm256_add_pd(_mm256_mul_pd(p, s2), _mm256_set1_pd(1.0 / 15.0));
+            p = _mm256_add_pd(_mm256_mul_pd(p, s2), _mm256_set1_pd(1.0 / 13.0));
+            p = _mm256_add_pd(_mm256_mul_pd(p, s2), _mm256_set1_pd(1.0 / 11.0));
+            p = _mm256_add_pd(_mm256_mul_pd(p, s2), _mm256_set1_pd(1.0 / 9.0));
+            p = _mm256_add_pd(_mm256_mul_pd(p, s2), _mm256_set1_pd(1.0 / 7.0));
+            p = _mm256_add_pd(_mm256_mul_pd(p, s2), _mm256_set1_pd(1.0 / 5.0));
+            p = _mm256_add_pd(_mm256_mul_pd(p, s2), _mm256_set1_pd(1.0 / 3.0));
+            p = _mm256_add_pd(_mm256_mul_pd(p, s2), one);
+            const __m256d logm = _mm256_mul_pd(_mm256_add_pd(sq, sq), p);
+            const __m256d lg = _mm256_add_pd(_mm256_mul_pd(ed, ln2_hi), _mm256_add_pd(logm, _mm256_mul_pd(ed, ln2_lo)));
+            const __m256d y = _mm256_mul_pd(vscale, lg);
+            const __m128 f0 = _mm256_cvtpd_ps(_mm256_mul_pd(y, eps_lo)), f1 = _mm256_cvtpd_ps(_mm256_mul_pd(y, eps_hi));
+            const int same = _mm_movemask_ps(_mm_cmpeq_ps(f0, f1));
+            const int nonzero = _mm256_movemask_pd(_mm256_cmp_pd(lg, _mm256_setzero_pd(), _CMP_NEQ_OQ));
+            _mm_storeu_ps(out + i, f0);
+            const int bad = ~(same & nonzero) & 15;
+            if (bad)
+                for (int t = 0; t < 4; ++t)
+                    if ((bad >> t) & 1) exact(i + t);
+        }
+    }
+    for (; i < hi; i++) exact(i);
+}
+
 struct ExpJob {
     static constexpr int64_t SLICE = 2048;
     const uint32_t *w = nullptr;
@@ -299,11 +460,7 @@ struct ExpJob {
             if (lo >= n) return;
             const int64_t hi = lo + SLICE < n ? lo + SLICE : n;
             while (published.load(std::memory_order_acquire) < hi) _mm_pause();  // the stream phase is ~3x faster than one transformer
-            for (int64_t i = lo; i < hi; i++) {
-                const uint64_t r64 = ((uint64_t)w[2 * i] << 32) | (uint64_t)w[2 * i + 1];
-                const double u = (double)(r64 & ((1ULL << 53) - 1)) * (1.0 / 9007199254740992.0);
-                out[i] = (float)(scale * log1p(-u));
-            }
+            exp_transform(w, out, lo, hi, scale);
         }
     }
 };
@@ -361,12 +518,17 @@ struct ExpPool {
 };
 }  // namespace
 
+namespace rlppo {
+void set_exp_fast_transform(int on) { g_exp_fast = on != 0; }
+}  // namespace rlppo
+
 extern "C" int rlppo_torch_cpu_exponential(void *state, int64_t state_bytes, int64_t n, double lambda, float *out, int32_t threads) {
     if (!state || state_bytes < (int64_t)sizeof(TorchState) || n < 0 || (n > 0 && !out) || !(lambda > 0.0)) return RLPPO_ERR_ARG;
     if (n == 0) return 0;
     TorchState *ts = reinterpret_cast<TorchState *>(state);
     if (ts->left < 1 || ts->left > N || ts->next > (uint64_t)N) return RLPPO_ERR_ARG;
-    uint32_t mt[N + 8];
+    static const bool have512 = __builtin_cpu_supports("avx512f") != 0;
+    uint32_t mt[N + 16];
     for (int i = 0; i < N; i++) mt[i] = (uint32_t)ts->mt[i];
     int left = ts->left;
     uint32_t next = (uint32_t)ts->next;
@@ -385,6 +547,13 @@ extern "C" int rlppo_torch_cpu_exponential(void *state, int64_t state_bytes, int
     job.scale = scale;
     int t = threads < 1 ? 1 : (threads > 32 ? 32 : threads);
     if ((int64_t)(t - 1) * ExpJob::SLICE > n) t = (int)(n / ExpJob::SLICE) + 1;
+    // With the vectorised transform (0.3-2 ns per element) the calling thread alone finishes the 4096 x 90 draw of a rollout step in
+    // 0.4 ms; helpers only add their wake-up and hand-shake latency to a draw of that size (0.6 ms with 2 threads, 1.1 ms with 8 on
+    // a busy host).  Large draws still spread over the pool.
+    if (g_exp_fast) {
+        const int by_size = 1 + (int)(n >> 20);  // one helper per 2^20 elements: none for the draw of a rollout step
+        t = t < by_size ? t : by_size;
+    }
     ExpPool &pool = ExpPool::get();
     if (t > 1) pool.start(&job, t - 1);
 
@@ -393,13 +562,14 @@ extern "C" int rlppo_torch_cpu_exponential(void *state, int64_t state_bytes, int
         // words still unread in the current block: state[next .. 623] are readable while left - 1 > 0 reads remain
         int avail = left - 1;
         if (avail == 0) {  // `--left == 0` -> next_state(): left = 624, next = 0, and this call reads state[0]
-            regen(mt);
+            if (have512) regen512(mt);
+            else regen(mt);
             left = N + 1;  // bookkeeping: after the read below left == 624, as in c10::mt19937
             next = 0;
             avail = N;
         }
         int take = (int64_t)avail < need - got ? avail : (int)(need - got);
-        int k = 0;
+        int k = have512 ? temper512(mt + next, w + got, take) : 0;
         for (; k + 8 <= take; k += 8) temper8(mt + next + k, w + got + k);
         for (; k < take; k++) {
             uint32_t y = mt[next + k];

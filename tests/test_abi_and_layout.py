@@ -186,6 +186,36 @@ def test_welford_matches_reference(golden):
     assert c.count == st.count and np.allclose(c.std, st.std)
 
 
+def test_host_exponential_certified_transform_equals_libm():
+    """The vectorised transform of rlppo_torch_cpu_exponential accepts an element only when its float32 rounding is certain and
+    sends the rest through libm (csrc/host_rng.cpp): over 2^22 values and several rates it must reproduce the libm-only path
+    (rlppo_dbg_set(24, 0)) and torch itself bit for bit, with the same generator advance; ragged lengths cover the vector tails."""
+    import ctypes
+    import torch
+    from rlgym_ppo_amd import _native as N
+    L = N.lib()
+
+    def draw(fast, seed, n, lam, threads):
+        torch.manual_seed(seed)
+        st = torch.get_rng_state().numpy().copy()
+        out = np.empty(n, np.float32)
+        assert L.rlppo_dbg_set(24, fast) == 0
+        assert L.rlppo_torch_cpu_exponential(ctypes.c_void_p(st.ctypes.data), st.size, n, lam, ctypes.c_void_p(out.ctypes.data), threads) == 0
+        return out, st
+
+    try:
+        for seed, n, lam, threads in ((1, 1 << 22, 1.0, 4), (2, 1000003, 1.0, 1), (3, 4099, 2.5, 2), (4, 7, 0.3, 1)):
+            a, sa = draw(1, seed, n, lam, threads)
+            b, sb = draw(0, seed, n, lam, threads)
+            assert np.array_equal(a.view(np.uint32), b.view(np.uint32)) and np.array_equal(sa, sb), (seed, n, lam)
+            torch.manual_seed(seed)
+            ref = torch.empty(n).exponential_(lam)
+            assert np.array_equal(a.view(np.uint32), ref.numpy().view(np.uint32)), (seed, n, lam)
+            assert np.array_equal(sa, torch.get_rng_state().numpy())
+    finally:
+        L.rlppo_dbg_set(24, 1)
+
+
 def test_host_exponential_is_torch_exponential_bit_for_bit():
     """rlppo_torch_cpu_exponential == torch.empty(n).exponential_(1) on the global CPU generator: same values, same generator
     advance (block boundaries of the MT19937 stream included), interleaved with other consumers of the generator; and the
