@@ -392,8 +392,9 @@ class HostExponential:
     """torch.empty(shape).exponential_(1) of the global CPU generator -- the stream torch.multinomial(probs, 1, True) consumes
     in the reference's CPU rollout (discrete_policy.py:59), which is what makes a seeded run pick the reference's action
     indices -- produced by librlppo's host implementation (rlppo_torch_cpu_exponential: bit-identical values and generator
-    advance, pinned by tests against torch itself; vectorised stream phase + multi-threaded log1p instead of torch's serial
-    12-26 ns per number) and drawn one request AHEAD on a helper thread.
+    advance, pinned by tests against torch itself; AVX-512 / AVX2 stream phase + a vectorised logarithm certified element by
+    element against the float32 rounding, libm where it cannot be, instead of torch's serial 12-26 ns per number) and drawn one
+    request AHEAD on a helper thread.
 
     The look-ahead is speculative and transparent, the contract of LegacyPermutation: after a draw of `shape` the helper draws
     the same shape again from the state the generator was left in, into a pinned buffer; the next request is served from it
@@ -407,7 +408,7 @@ class HostExponential:
     def __init__(self):
         import os
         self.lookahead = os.environ.get("RLPPO_NOISE_LOOKAHEAD", "1") != "0"
-        self.threads = max(1, min(8, (os.cpu_count() or 2) // 2))  # GPU-box host: 3.4 ms at 1, 0.49 ms at 8, slower again at 16+
+        self.threads = max(1, min(8, (os.cpu_count() or 2) // 2))  # an upper bound: the library uses one thread per 2^20 elements (0.35 ms per rollout-step draw)
         self._buf = {}       # numel -> list of pinned float32 vectors
         self._turn = 0
         self._pending = None  # dict(shape, state_in, future -> state_out, buf)
