@@ -324,7 +324,7 @@ int rlppo_net_pack_bf16(void *stream, const int32_t *dims, int32_t n_layers, con
  *  21 GAE look-back spin limit [-1 = default 2^20 | 0 = every wait times out at once (tests)]
  *  22 GAE grid [0 = at most the resident capacity, workgroups loop over chunks beyond it | 1 = one workgroup per chunk always]
  *  23 bf16 update precision, tile of the hidden-layer forward / dX / dW products [1 = 256 x 256, one workgroup per CU (default) |
- *     2 = 128 x 256 forward / dX at two workgroups per CU | 0 = 128 x 128]
+ *     0 = 128 x 128]
  *  24 rlppo_torch_cpu_exponential transform [1 = AVX2 logarithm certified element by element against float32 rounding, libm for the
  *     rest (default) | 0 = libm for every element] */
 int rlppo_dbg_set(int32_t key, int32_t value);

@@ -646,9 +646,8 @@ __global__ __launch_bounds__(TM * 2, TM == 256 ? 1 : 2) void gemm_nt_b16w_kernel
     // 128 x 128 kernel above 458 us at two workgroups per CU and ~430 us with 32 KiB stages at four per CU.  In every form the MFMA pipe
     // is ~1/3 busy and the waves wait half of their cycles (SQ_WAIT_INST_ANY): after each barrier all 8 waves read their fragments
     // at once, and with one workgroup per CU nothing else fills that gap.
-    // TM = 256: 8 waves, one workgroup per CU.  TM = 128: 4 waves (2 x 2) on a 128 x 256 tile with half the LDS, two workgroups per
-    // CU -- 1.5x the tile bytes per flop, but the epilogue of one workgroup (half of a launch's time at K = 512: tools/b16_k_sweep.py)
-    // runs under the K loop of the other.
+    // (TM = 128 -- 4 waves on a 128 x 256 tile with BKT = 16, two workgroups per CU so that one's epilogue runs under the other's K
+    // loop -- was measured at 426 us against 399 us and is not instantiated.)
     constexpr int TN = 256, NW = TM / 32, STAGE = (TM + TN) * BKT;   // waves; floats per stage
     constexpr int CPR = BKT / 4, RPI = 64 / CPR, PASS = NW * RPI;    // 16-byte chunks per row, rows per wave instruction, rows per pass
     constexpr int DIST = NBUF - 1, PER_STAGE = (TM + TN) / PASS;     // DMA instructions per wave and stage
@@ -842,7 +841,7 @@ __global__ __launch_bounds__(TM * 2, TM == 256 ? 1 : 2) void gemm_nt_b16w_kernel
 // of 128 (the bitmask tile geometry).  Everything else takes the fp32 kernels on the ROUNDED fp32 copies -- the same products
 // (a product of two bf16 values is exact in fp32), only slower -- followed by round_rows (optim.hip).
 static int g_b16_wide = 1;  // rlppo_dbg_set(23, .): 256 x 256 tiles for the hidden / dX products of the bf16 update precision (0: 128 x 128)
-void set_b16_wide_tiles(int on) { g_b16_wide = on; }
+void set_b16_wide_tiles(int on) { g_b16_wide = on != 0; }
 bool nt_b16_ok(int N, int K, bool hidden) {
     if (K % 64 != 0) return false;
     return hidden ? N % 128 == 0 : (N % 128 == 0 || N == 96 || N == 64 || N == 32);
@@ -870,28 +869,22 @@ int launch_gemm_nt_b16(hipStream_t st, const unsigned short *A, int64_t lda, con
     const unsigned la = (unsigned)(lda * 2), lb = (unsigned)(ldb * 2), lc = (unsigned)(ldc * 4), lcb = (unsigned)(ldcb * 2);
     if (mode != B16_OUT && N % 256 == 0 && M >= 1024 && Cb && g_b16_wide && 257 * lda * 2 < lim && 257 * ldb * 2 < lim &&
         257 * ldc * 4 < lim && 257 * ldcb * 2 < lim) {  // 256 x 256 tiles
-        // g_b16_wide: 1 = 256 x 256 tiles, one workgroup of 8 waves per CU; 2 = 128 x 256 tiles, two workgroups of 4 waves per CU
-        static bool attr_set[4] = {false, false, false, false};
-        const int which = (mode == B16_DX ? 1 : 0) + (g_b16_wide == 2 ? 2 : 0);
+        static bool attr_set[2] = {false, false};
+        const int which = mode == B16_DX ? 1 : 0;
         const int rt128 = (int)cdiv(M, 128);
-#define B16W(MODE_, TM_, BKT_)                                                                                               \
+#define B16W(MODE_)                                                                                                          \
     do {                                                                                                                     \
-        constexpr int STAGES_B = 2 * (TM_ + 256) * BKT_ * 4, PARK_B = (TM_ / 32) * 64 * 256; /* epilogue: 16 KiB per wave */  \
-        constexpr int LDS_BYTES = STAGES_B > PARK_B ? STAGES_B : PARK_B;                                                      \
+        constexpr int LDS_BYTES = 2 * (256 + 256) * 32 * 4; /* two 64 KiB stages; the epilogue parks 16 KiB per wave in them */ \
         if (!attr_set[which]) {                                                                                              \
-            RLPPO_HIP(hipFuncSetAttribute((const void *)gemm_nt_b16w_kernel<MODE_, TM_, BKT_, 2>,                             \
+            RLPPO_HIP(hipFuncSetAttribute((const void *)gemm_nt_b16w_kernel<MODE_, 256, 32, 2>,                               \
                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));                           \
             attr_set[which] = true;                                                                                          \
         }                                                                                                                    \
-        hipLaunchKernelGGL((gemm_nt_b16w_kernel<MODE_, TM_, BKT_, 2>), dim3((unsigned)cdiv(M, TM_), (unsigned)(N / 256)),     \
-                           dim3(TM_ * 2), LDS_BYTES, st, A, la, B, lb, bias, C, lc, Cb, lcb, M, K, bits, rt128);            \
+        hipLaunchKernelGGL((gemm_nt_b16w_kernel<MODE_, 256, 32, 2>), dim3((unsigned)cdiv(M, 256), (unsigned)(N / 256)),        \
+                           dim3(512), LDS_BYTES, st, A, la, B, lb, bias, C, lc, Cb, lcb, M, K, bits, rt128);                 \
     } while (0)
-        switch (which) {
-            case 0: B16W(B16_HIDDEN, 256, 32); break;
-            case 1: B16W(B16_DX, 256, 32); break;
-            case 2: B16W(B16_HIDDEN, 128, 16); break;
-            default: B16W(B16_DX, 128, 16); break;
-        }
+        if (which) B16W(B16_DX);
+        else B16W(B16_HIDDEN);
 #undef B16W
         RLPPO_LAUNCH_CHECK();
         return 0;

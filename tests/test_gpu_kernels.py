@@ -110,9 +110,9 @@ def test_gemm_nt_b16(L, M, N, K, hidden, epi, b16_tiles):
     assert torch.equal(D0, D1)
 
 
-@pytest.fixture(params=[1, 2, 0], ids=["tile256", "tile128x256", "tile128"])
+@pytest.fixture(params=[1, 0], ids=["tile256", "tile128"])
 def b16_tiles(L, request):
-    """The tile shapes of the bf16 hidden / dX / dW products (rlppo_dbg_set(23)): 256 x 256, 128 x 256 at two workgroups per CU, 128 x 128."""
+    """Both tile shapes of the bf16 hidden / dX / dW products (rlppo_dbg_set(23)): 256 x 256 (default where it applies) and 128 x 128."""
     check(L, L.rlppo_dbg_set(23, request.param))
     yield request.param
     check(L, L.rlppo_dbg_set(23, 1))
