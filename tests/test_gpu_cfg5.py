@@ -95,6 +95,39 @@ def test_bf16_update_precision_against_its_restatement(L, shape):
     fp64_gate.gate(L, head, pol, val, obs[idx], act.numpy()[idx], old[idx], adv[idx], tgt[idx], 0.2, 0.005, 0.5, got, label=f"fp32 after bf16 ({shape})")
 
 
+def test_bf16_update_precision_is_additive_at_full_size(L):
+    """configs[4] shape at the update's launch size, bf16 update precision: ONE fused pass over 524,288 rows against its eight
+    65,536-row minibatches (mb_ratio 1/8 each).  Per-row arithmetic is the same in both (the minibatch scalings are powers of two,
+    so every bf16 rounding falls the same way) and a weight gradient is never rounded, so the gradients must agree up to fp32
+    summation order -- with the 256 x 256-tile forward / dX / dW kernels, the narrow-head kernels and their reductions at the size
+    bench.py --config cfg5 --precision bf16 launches them."""
+    torch.manual_seed(41)
+    pol = nets.init_mlp(231, (512, 512, 512, 512), 16)
+    val = nets.init_mlp(231, (512, 512, 512, 512), 1)
+    rs = np.random.RandomState(41)
+    n = 524288
+    obs = np.clip(rs.randn(n, 231), -5, 5).astype(np.float32)
+    act = rs.uniform(-1, 1, size=(n, 8)).astype(np.float32)
+    old = (rs.randn(n) * 0.5 - 8.0).astype(np.float32)       # any old log-probabilities: additivity does not care
+    adv, tgt = rs.randn(n).astype(np.float32), rs.randn(n).astype(np.float32)
+    idx = rs.permutation(n)
+    gp, gv, st = run_minibatch(L, "gaussian", pol, val, obs, act, old, tgt, adv, idx, 0.2, 0.005, 1.0, precision="bf16")
+    acc = [[torch.zeros_like(w, dtype=torch.float64), torch.zeros_like(b, dtype=torch.float64)] for w, b in gp + gv]
+    st_sum = np.zeros(5)
+    for j in range(8):
+        gpj, gvj, stj = run_minibatch(L, "gaussian", pol, val, obs, act, old, tgt, adv, idx[j * 65536:(j + 1) * 65536], 0.2, 0.005, 0.125,
+                                      precision="bf16")
+        for a, g in zip(acc, gpj + gvj):
+            a[0] += g[0].double()
+            a[1] += g[1].double()
+        st_sum += stj[:5]
+    assert all(torch.isfinite(g[0]).all() and torch.isfinite(g[1]).all() for g in gp + gv) and float(gp[0][0].abs().max()) > 0
+    for whole, parts in zip(gp + gv, acc):
+        for k in (0, 1):
+            assert relerr(whole[k], parts[k]) < 1e-5
+    np.testing.assert_allclose(st[:5], st_sum / 8, rtol=1e-5, atol=1e-8)
+
+
 def test_cfg5_policy_classes_round_trip():
     from rlgym_ppo_amd.ppo import ContinuousPolicy, ValueEstimator
     torch.manual_seed(9)
