@@ -38,13 +38,16 @@ def _build(seed=7, batch=2048, hidden=(64, 64)):
     return learner, buf
 
 
-def _worker(rank, world, port, out, batch=2048):
+def _worker(rank, world, port, out, batch=2048, precision="fp32", hidden=(64, 64)):
     sys.path.insert(0, ROOT)
     import contextlib
     import torch.distributed as dist
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
     with contextlib.redirect_stdout(open(os.devnull, "w")):
-        learner, buf = _build(batch=batch)
+        learner, buf = _build(batch=batch, hidden=hidden)
+    if precision != "fp32":
+        from rlgym_ppo_amd.engine import set_update_precision
+        set_update_precision(precision)
     report = learner.learn(buf)
     out[rank] = (learner.policy.arena.flat.cpu(), learner.value_net.arena.flat.cpu(), report)
     dist.barrier()
@@ -70,6 +73,30 @@ def test_two_ranks_equal_one_rank():
             assert abs(report[k] - ref_report[k]) <= 2e-5 * max(abs(ref_report[k]), 1e-3) + 1e-7, (k, report[k], ref_report[k])
         assert report["Cumulative Model Updates"] == ref_report["Cumulative Model Updates"] == 4
     assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1])  # replicas stay bit-identical
+
+
+def test_two_ranks_equal_one_rank_in_the_bf16_update_precision():
+    """The same check in the bf16 update precision (256-wide nets: the bf16 forward / dX / dW kernels and the critic's narrow-head
+    kernels): per-row arithmetic does not depend on which rank owns a slice and weight gradients are never rounded, so two ranks
+    reproduce one rank up to the summation order of the all-reduce."""
+    from rlgym_ppo_amd.engine import set_update_precision
+    learner, buf = _build(hidden=(256, 256))
+    set_update_precision("bf16")
+    try:
+        ref_report = learner.learn(buf)
+    finally:
+        set_update_precision("fp32")
+    ref_p, ref_v = learner.policy.arena.flat.cpu(), learner.value_net.arena.flat.cpu()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(2, _free_port(), out, 2048, "bf16", (256, 256)), nprocs=2, join=True)
+    for rank in (0, 1):
+        p, v, report = out[rank]
+        assert ((p - ref_p).abs().max() / ref_p.abs().max()).item() < 5e-5
+        assert ((v - ref_v).abs().max() / ref_v.abs().max()).item() < 5e-5
+        for k in ("Policy Entropy", "Mean KL Divergence", "Value Function Loss", "SB3 Clip Fraction"):
+            assert abs(report[k] - ref_report[k]) <= 2e-5 * max(abs(ref_report[k]), 1e-3) + 1e-7, (k, report[k], ref_report[k])
+    assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1])
 
 
 def test_uneven_slices_report_the_mean_over_all_passes():
