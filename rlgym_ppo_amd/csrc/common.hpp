@@ -80,22 +80,26 @@ int launch_gemm_nt_bf16(hipStream_t st, const float *A, int64_t lda, const float
                         int64_t ldc, int64_t M, int N, int nb, int K, int epi);
 void set_infer_bf16(int v);
 int get_infer_bf16();
-// bf16 update precision: both operands bf16 in memory (A: activations, B: rlppo_net_pack_bf16's W blocks), fp32 accumulate.
-// hidden: relu, rounded output as bf16 (Cb) + fp32 (C) + ReLU bitmask; output layer (!hidden): fp32 C, epi bias / bias+tanh
-bool nt_b16_ok(int N, int K, bool hidden);
-int launch_gemm_nt_b16(hipStream_t st, const unsigned short *A, int64_t lda, const unsigned short *B, int64_t ldb, const float *bias,
-                       float *C, int64_t ldc, unsigned short *Cb, int64_t ldcb, int64_t M, int N, int K, int epi, int mode,
-                       unsigned long long *bits);  // mode: 0 output layer, 1 hidden layer, 2 rounded + masked dX
-void set_exp_fast_transform(int on);  // rlppo_dbg_set(24): certified AVX2 transform of rlppo_torch_cpu_exponential (1, default) or libm only
-void set_b16_wide_tiles(int on);  // rlppo_dbg_set(23): 256 x 256 (default) or 128 x 128 tiles in the bf16 hidden / dX products
-bool tn_b16_ok(int pout, int pin);
-int launch_gemm_tn_b16(hipStream_t st, const unsigned short *dY, int64_t ldy, const unsigned short *X, int64_t ldx, float *dW,
-                       float *db, int pout, int pin, int out, int in, int64_t M, float *ws, size_t ws_floats);
 // dW[n][k] += sum_m dY[m][n] X[m][k] ; db[n] += sum_m dY[m][n]: partial tiles in `ws` (>= tn_partial_floats(out, in, M)
 // floats) + a fixed-order reduction into the flat arena
 size_t tn_partial_floats(int out, int in, int64_t M);
 int launch_gemm_tn(hipStream_t st, const float *dY, int64_t ldy, int ny_valid, const float *X, int64_t ldx, int kx_valid,
                    float *dW, float *db, int out, int in, int64_t M, float *ws, size_t ws_floats);
+
+// gemm_b16.hip: the bf16 update precision, both operands bf16 in memory, fp32 accumulate ---------------------------------
+// (A: activations / activation gradients, B: rlppo_net_pack_bf16's W or W^T blocks)
+// hidden: relu, rounded output as bf16 (Cb) + fp32 (C) + ReLU bitmask; output layer (!hidden): fp32 C, epi bias / bias+tanh
+bool nt_b16_ok(int N, int K, bool hidden);
+int launch_gemm_nt_b16(hipStream_t st, const unsigned short *A, int64_t lda, const unsigned short *B, int64_t ldb, const float *bias,
+                       float *C, int64_t ldc, unsigned short *Cb, int64_t ldcb, int64_t M, int N, int K, int epi, int mode,
+                       unsigned long long *bits);  // mode: 0 output layer, 1 hidden layer, 2 rounded + masked dX
+void set_b16_wide_tiles(int on);  // rlppo_dbg_set(23): 256 x 256 (default) or 128 x 128 tiles in the bf16 hidden / dX products
+bool tn_b16_ok(int pout, int pin);
+int launch_gemm_tn_b16(hipStream_t st, const unsigned short *dY, int64_t ldy, const unsigned short *X, int64_t ldx, float *dW,
+                       float *db, int pout, int pin, int out, int in, int64_t M, float *ws, size_t ws_floats);
+
+// host_rng.cpp
+void set_exp_fast_transform(int on);  // rlppo_dbg_set(24): certified vector transform of rlppo_torch_cpu_exponential (1, default) or libm only
 
 // gemv.hip: the critic's one-output head ---------------------------------------------------------------
 bool gemv_head_ok(int out, int kp);

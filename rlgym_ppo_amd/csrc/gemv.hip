@@ -86,7 +86,7 @@ __global__ __launch_bounds__(256) void gemv_dx_kernel(const float *__restrict__ 
     *reinterpret_cast<f32x4 *>(dx + row * ldc + c) = o;
 }
 
-// The same product with the ReLU mask taken from the bitmask the hidden layer's forward GEMM wrote (csrc/gemm.hip,
+// The same product with the ReLU mask taken from the bitmask the hidden layer's forward GEMM wrote (csrc/gemm_detail.hpp,
 // relu_bits): no read of the activation at all.  A block is one 128 x 128 tile of dx and a thread is the lane that owned the
 // same 64 elements in the forward epilogue: wave w, lane (q, r16) -> rows m0 + 32 w + 16 i + r16, columns n0 + 16 j + 4 q + e,
 // bit (8 i + j) * 4 + e of the word at bits[tile * 256 + tid] (512 contiguous bytes per wave).
