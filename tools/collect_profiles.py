@@ -21,7 +21,7 @@ copies = {
     "cfg5_pmc_fetch.csv": f"{tag}_cfg5_bf16_pmc_fetch.csv", "cfg5_pmc_write.csv": f"{tag}_cfg5_bf16_pmc_write.csv",
     "cfg5_pmc_sq.csv": f"{tag}_cfg5_bf16_pmc_sq.csv", "cfg5_traffic.json": f"{tag}_cfg5_bf16_traffic.json",
     "rank_share.txt": f"{tag}_rank_share.txt", "gae_floor.txt": f"{tag}_gae_floor.txt",
-    "b16_k_sweep.txt": f"{tag}_b16_k_sweep.txt", "f32_k_sweep.txt": f"{tag}_f32_k_sweep.txt",
+    "b16_k_sweep.txt": f"{tag}_b16_k_sweep.txt", "f32_k_sweep.txt": f"{tag}_f32_k_sweep.txt", "ceilings.txt": f"{tag}_ceilings.txt",
 }
 for a, b in copies.items():
     shutil.copy(os.path.join(src, a), os.path.join(dst, b))

@@ -44,6 +44,7 @@ python tools/rank_share.py > $OUT/rank_share.txt 2> $OUT/rank_share.log
 python tools/gae_ab.py > $OUT/gae_floor.txt 2> $OUT/gae_floor.log
 python tools/b16_k_sweep.py > $OUT/b16_k_sweep.txt 2> $OUT/b16_k_sweep.log
 python tools/f32_k_sweep.py > $OUT/f32_k_sweep.txt 2> $OUT/f32_k_sweep.log
+python tools/ceilings.py > $OUT/ceilings.txt 2> $OUT/ceilings.log
 find $OUT -name "*_kernel_trace.csv" -size +8M -delete || true
 find $OUT -name "*counter_collection.csv" -size +8M -delete || true
 echo DONE
