@@ -29,6 +29,13 @@ w = torch.randn(256, 256, device=dev)
 ms = bench.time_region(lambda: a @ w.T, 10, warm_s=0.5)
 print(f"library GEMM fp32 524288 x 256 x 256 (no bias / ReLU / bitmask): {ms:.3f} ms = {2 * 524288 * 256 * 256 / ms / 1e9:.1f} TFLOP/s "
       f"(librlppo's forward with bias + ReLU + bitmask: see bench.py kernel_breakdown)")
+# ... and the configs[4] hidden-layer shape, bf16 in / bf16 out, no bias / ReLU / bitmask (the bf16 update precision's forward)
+ab = torch.randn(524288, 512, device=dev).bfloat16()
+wb = (torch.randn(512, 512, device=dev) * 0.05).bfloat16()
+ms = bench.time_region(lambda: ab @ wb.T, 10, warm_s=0.5)
+print(f"library GEMM bf16 524288 x 512 x 512 (bf16 out, no epilogue): {ms:.3f} ms = {2 * 524288 * 512 * 512 / ms / 1e9:.1f} TFLOP/s "
+      f"(librlppo's gemm_nt_b16w with bias + ReLU + rounding + bitmask: see bench.py --config cfg5 --precision bf16)")
+del ab, wb
 try:
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__))))
     import ctypes, _diag
