@@ -112,17 +112,16 @@ def kernel_breakdown(learner):
     M = int(getattr(learner, "_fused_rows", MINIBATCH))
     st = lambda: ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     P = lambda t: ctypes.c_void_p(t.data_ptr())
-    A128 = torch.randn(M, 128, device=dev)
+    K0 = int(L.rlppo_padded_width(OBS))          # 112: the first layer's padded contraction (was 128 until round 3)
+    A0 = torch.randn(M, K0, device=dev)
+    A0[:, OBS:] = 0
     A256 = torch.randn(M, 256, device=dev)
     A256b = torch.randn(M, 256, device=dev)  # second operand of dW / mask of dX: distinct memory, as in the update
     A96 = torch.randn(M, 96, device=dev)
-    A32 = torch.randn(M, 32, device=dev)
     W = torch.randn(256, 256, device=dev) * 0.05
     bias = torch.zeros(256, device=dev)
     C256 = torch.empty(M, 256, device=dev)
     C96 = torch.empty(M, 96, device=dev)
-    C32 = torch.empty(M, 32, device=dev)
-    idx = torch.randperm(M, device=dev)
     dW = torch.zeros(256 * 256, device=dev)
     db = torch.zeros(256, device=dev)
 
@@ -145,21 +144,26 @@ def kernel_breakdown(learner):
         return lambda: N.check(L.rlppo_dbg_gemm_tn(st(), P(dY), ny, ny, P(X), kx, kx, P(dW), P(db), out, in_, M, P(tn_ws),
                                                     tn_ws.numel()))
 
+    # (name, launches per pass, launch, EXECUTED flop = the padded tile shape the kernel multiplies, ALGORITHMIC flop = the logical
+    # layer shape: K = 107 observations, N = 90 actions).  The rates printed as `tflops` / `frac` are the algorithmic ones.
+    f = lambda n, k: 2 * M * n * k
     shapes = [
-        ("gemm_nt fwd L0 128->256 +bitmask (x2 nets)", 2, ntb(A128, 128, C256, 256, 256, 128, 1), 2 * M * 256 * 128),
-        ("gemm_nt fwd hidden 256->256 +bitmask (x4)", 4, ntb(A256, 256, C256, 256, 256, 256, 1), 2 * M * 256 * 256),
-        ("gemm_nt fwd head 256->96", 1, nt(A256, 256, 256, C96, 96, 96, 256, 0), 2 * M * 96 * 256),
-        ("gemm_nt dX hidden 256->256 bitmask (x4)", 4, ntb(A256, 256, C256, 256, 256, 256, 3), 2 * M * 256 * 256),
-        ("gemm_nt dX head 96->256 bitmask", 1, ntb(A96, 96, C256, 256, 256, 96, 3), 2 * M * 256 * 96),
-        ("gemm_tn dW hidden 256x256 (x4)", 4, tn(A256, 256, A256b, 256, 256, 256), 2 * M * 256 * 256),
-        ("gemm_tn dW L0 256x107 (x2)", 2, tn(A256, 256, A128, 128, 256, 107), 2 * M * 256 * 128),
-        ("gemm_tn dW head 90x256", 1, tn(A96, 96, A256, 256, 90, 256), 2 * M * 128 * 256),
+        ("gemm_nt fwd L0 %d->256 +bitmask (x2 nets)" % K0, 2, ntb(A0, K0, C256, 256, 256, K0, 1), f(256, K0), f(256, OBS)),
+        ("gemm_nt fwd hidden 256->256 +bitmask (x4)", 4, ntb(A256, 256, C256, 256, 256, 256, 1), f(256, 256), f(256, 256)),
+        ("gemm_nt fwd head 256->96", 1, nt(A256, 256, 256, C96, 96, 96, 256, 0), f(96, 256), f(ACT, 256)),
+        ("gemm_nt dX hidden 256->256 bitmask (x4)", 4, ntb(A256, 256, C256, 256, 256, 256, 3), f(256, 256), f(256, 256)),
+        ("gemm_nt dX head 96->256 bitmask", 1, ntb(A96, 96, C256, 256, 256, 96, 3), f(256, 96), f(256, ACT)),
+        ("gemm_tn dW hidden 256x256 (x4)", 4, tn(A256, 256, A256b, 256, 256, 256), f(256, 256), f(256, 256)),
+        ("gemm_tn dW L0 256x107 (x2), 128x112 tiles", 2, tn(A256, 256, A0, K0, 256, 107), f(256, K0), f(256, OBS)),
+        ("gemm_tn dW head 90x256, 96x128 tiles", 1, tn(A96, 96, A256, 256, 90, 256), f(96, 256), f(ACT, 256)),
     ]
     rows = []
-    for name, count, fn, flop in shapes:
+    for name, count, fn, flop_exec, flop in shapes:
         ms = time_region(fn, 20, warm_s=0.3)
         rows.append(dict(kernel=name, rows_per_launch=M, launches_per_minibatch=count, ms_per_launch=round(ms, 4),
-                         gflop_per_launch=round(flop / 1e9, 3), tflops=round(flop / ms / 1e9, 2)))
+                         gflop_per_launch=round(flop / 1e9, 3), tflops=round(flop / ms / 1e9, 2),
+                         frac=round(flop / ms / 1e9 / MFMA_F32_PEAK_TF, 4),
+                         executed_gflop_per_launch=round(flop_exec / 1e9, 3), executed_tflops=round(flop_exec / ms / 1e9, 2)))
     dominant = max(rows, key=lambda r: r["launches_per_minibatch"] * r["ms_per_launch"])
     return rows, dominant
 
@@ -171,10 +175,10 @@ def pmc_traffic_for(kernel_label):
     """HBM bytes per launch of the dominant kernel, from the committed PMC passes (bench.py cannot run rocprofv3 on itself)."""
     path = os.path.join(ROOT, "profiles", TRAFFIC_JSON)
     key = {"gemm_tn dW hidden 256x256 (x4)": "rlppo::gemm_tn_dma_kernel<32> {dW hidden 256x256}",
-           "gemm_tn dW L0 256x107 (x2)": "rlppo::gemm_tn_dma_kernel<32> {dW L0 256x107}",
-           "gemm_tn dW head 90x256": "rlppo::gemm_tn_dma_kernel<32> {dW head 90x256}",
+           "gemm_tn dW L0 256x107 (x2), 128x112 tiles": "rlppo::gemm_tn_dma_kernel<32> {dW L0 256x107}",
+           "gemm_tn dW head 90x256, 96x128 tiles": "rlppo::gemm_tn_dma_kernel<32> {dW head 90x256}",
            "gemm_nt fwd hidden 256->256 +bitmask (x4)": "rlppo::gemm_nt_dma_kernel<8, 1, 16, true> {fwd hidden 256->256}",
-           "gemm_nt fwd L0 128->256 +bitmask (x2 nets)": "rlppo::gemm_nt_dma_kernel<8, 1, 16, true> {fwd L0 128->256}",
+           "gemm_nt fwd L0 112->256 +bitmask (x2 nets)": "rlppo::gemm_nt_dma_kernel<8, 1, 16, true> {fwd L0 128->256}",
            "gemm_nt fwd head 256->96": "rlppo::gemm_nt_dma_kernel<6, 0, 16, false>",
            "gemm_nt dX hidden 256->256 bitmask (x4)": "rlppo::gemm_nt_dma_kernel<8, 3, 16, true> {dX hidden 256->256}",
            "gemm_nt dX head 96->256 bitmask": "rlppo::gemm_nt_dma_kernel<8, 3, 16, true> {dX head 96->256}"}.get(kernel_label)

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define RLPPO_ABI_VERSION 2
+#define RLPPO_ABI_VERSION 3
 #define RLPPO_MAX_LAYERS 16
 
 #define RLPPO_OK 0
@@ -164,6 +164,10 @@ typedef struct rlppo_minibatch_args {
     /* device-resident experience (ExperienceBuffer, experience_buffer.py:42-50), gathered by `idx` */
     const float *states;          /* [N][ld_states], padded rows */
     int64_t ld_states;
+    int64_t n_rows;               /* N, the rows the experience arrays hold (ring_cap when they are a ring).  With it known the
+                                     first layer's four launches fetch row idx[r] straight from `states` (the gather of
+                                     experience_buffer.py:82-87 fused into their load stage); 0 = unknown: the rows
+                                     are gathered into the workspace by a pass of their own first */
     const float *actions;         /* [N][act_dim], float-encoded (experience_buffer.py:72) */
     const float *old_logp;        /* [N] */
     const float *targets;         /* [N]  value targets ("values" in the buffer) */
@@ -214,12 +218,18 @@ int rlppo_clip_adam(void *stream, float *params, float *grads, float *exp_avg, f
                     double max_norm, double lr, double beta1, double beta2, double eps, int64_t step,
                     double *gnorm2);
 
-/* The optimiser tail of one batch for BOTH networks in two launches (ppo_learner.py:187-193: clip_grad_norm_ x2,
+/* The optimiser tail of one batch for BOTH networks in ONE launch (ppo_learner.py:187-193: clip_grad_norm_ x2,
  * value_optimizer.step(), policy_optimizer.step()) + the re-packing rlppo_net_pack would do + the zero_grad of the next batch
  * (ppo_learner.py:135-136): squared norms of both gradient arenas, then clip + Adam on both, every updated parameter written
  * straight into its W / W^T / b slots of `packed` (which must already hold a full rlppo_net_pack image: the zero padding is not
  * rewritten), gradients left ZERO.  Element for element the arithmetic of rlppo_clip_adam + rlppo_net_pack.  Used by
- * PPOLearner.learn; FusedAdam.step() (the public optimiser API, gradients scaled in place) stays on rlppo_clip_adam. */
+ * PPOLearner.learn; FusedAdam.step() (the public optimiser API, gradients scaled in place) stays on rlppo_clip_adam.
+ * sync_ws: RLPPO_OPT_SYNC_BYTES of device memory, 16-byte aligned, owned by the caller and ZEROED ONCE when it is allocated
+ * (never again: every completed call leaves it armed for the next): the accumulators, arrival counter and generation word of
+ * the grid barrier between the norm and the update, and at byte offset 24 a uint32 that counts barrier waits that gave up
+ * (then the affected network's parameters are poisoned with NaN; callers read the word back with their report).  Not
+ * shareable between concurrent calls.  sync_ws == NULL selects the three-operation form (fill, norms, update). */
+#define RLPPO_OPT_SYNC_BYTES 64
 typedef struct rlppo_opt_net {
     const int32_t *dims;  /* layer widths, n_layers + 1 entries */
     int32_t n_layers;
@@ -229,7 +239,7 @@ typedef struct rlppo_opt_net {
     double max_norm, lr, beta1, beta2, eps;
     int64_t step;         /* 1-based Adam step count of THIS update */
 } rlppo_opt_net;
-int rlppo_clip_adam_pack2(void *stream, const rlppo_opt_net *a, const rlppo_opt_net *b);
+int rlppo_clip_adam_pack2(void *stream, const rlppo_opt_net *a, const rlppo_opt_net *b, void *sync_ws);
 
 /* ------------------------------------------------------------------------------------- data-parallel exchange */
 

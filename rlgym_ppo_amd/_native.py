@@ -11,10 +11,11 @@ from ctypes import POINTER, c_char_p, c_double, c_float, c_int32, c_int64, c_siz
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("RLPPO_LIB") or os.path.join(HERE, "librlppo.so")  # RLPPO_LIB: an alternative build (A/B of compile-time variants)
-ABI_VERSION = 2
+ABI_VERSION = 3
 COMM_ID_BYTES = 128  # RLPPO_COMM_ID_BYTES
 MAX_LAYERS = 16
 N_STATS = 8
+OPT_SYNC_BYTES = 64  # RLPPO_OPT_SYNC_BYTES
 MAX_SLOTS = 8
 STAT_ENTROPY, STAT_KL, STAT_VLOSS, STAT_CLIPFRAC, STAT_PLOSS = 0, 1, 2, 3, 4
 STAT_PASSES = 7  # host-side: passes of rlppo_ppo_minibatch behind the sums above (summed over ranks with them)
@@ -43,7 +44,7 @@ class MinibatchArgs(ctypes.Structure):
         ("pol_dims", POINTER(c_int32)), ("val_dims", POINTER(c_int32)),
         ("pol_packed", c_void_p), ("val_packed", c_void_p),
         ("pol_packed_r", c_void_p), ("val_packed_r", c_void_p), ("pol_wb16", c_void_p), ("val_wb16", c_void_p), ("pol_grad", c_void_p), ("val_grad", c_void_p),
-        ("states", c_void_p), ("ld_states", c_int64), ("actions", c_void_p), ("old_logp", c_void_p),
+        ("states", c_void_p), ("ld_states", c_int64), ("n_rows", c_int64), ("actions", c_void_p), ("old_logp", c_void_p),
         ("targets", c_void_p), ("advantages", c_void_p), ("idx", c_void_p), ("mb", c_int64),
         ("ring_base", c_int64), ("ring_cap", c_int64),
         ("clip_range", c_float), ("ent_coef", c_float), ("mb_ratio", c_float), ("var_m", c_float), ("var_b", c_float),
@@ -85,7 +86,7 @@ SIGNATURES = {
     "rlppo_ppo_join": (c_int32, [c_void_p]),
     "rlppo_clip_adam": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_double, c_double,
                                   c_double, c_double, c_double, c_int64, c_void_p]),
-    "rlppo_clip_adam_pack2": (c_int32, [c_void_p, POINTER(OptNet), POINTER(OptNet)]),
+    "rlppo_clip_adam_pack2": (c_int32, [c_void_p, POINTER(OptNet), POINTER(OptNet), c_void_p]),
     "rlppo_comm_set_library": (c_int32, [ctypes.c_char_p]),
     "rlppo_comm_unique_id": (c_int32, [c_void_p]),
     "rlppo_comm_init": (c_int32, [c_int32, c_int32, c_void_p]),

@@ -18,7 +18,14 @@ void set_error(const char *fmt, ...) {
     va_end(ap);
 }
 
-static int64_t padded_width(int64_t d) { return round_up(d, 32); }
+// Width the first layer's contraction is padded to (zero columns in the packed weights, zero-padded observation rows).  The
+// fp32 kernels step K in tiles of 16 and the bf16 kernels in tiles of 64: pad to 16 when that saves at least a tenth of the
+// contraction over padding to 64 (107 -> 112 instead of 128: an eighth of the first layer's products, forward and dW, multiplied
+// zeros [r3]), else to 64 (231 -> 256: the bf16 update precision keeps its kernels on BASELINE configs[4]).
+static int64_t padded_width(int64_t d) {
+    const int64_t p16 = round_up(d, 16), p64 = round_up(d, 64);
+    return (p64 - p16) * 10 >= p64 ? p16 : p64;
+}
 static int64_t padded_out(int64_t d) {
     if (d <= 32) return 32;
     if (d <= 64) return 64;
@@ -66,9 +73,11 @@ static int max_pout(const NetLayout &net) {
 // ping-pong buffers, for training one buffer per layer (they are the saved activations of the backward pass).
 // Training only: bits[l] (may be null) receives the ReLU bitmask of hidden layer l and have_bits[l] says whether it was
 // written (csrc/gemm.hip, launch_gemm_nt_bits); backward() then masks dX with it instead of re-reading acts[l].
+// rowtab != nullptr: `obs` is the experience buffer's state matrix (src_rows rows) and row r of the batch is obs[rowtab[r]]
+// (the first layer fetches its rows through the table: nt_gather_ok must hold for it).
 static int forward(hipStream_t st, const NetLayout &net, const float *packed, const float *obs, int64_t ld_obs, int64_t n,
                    int out_tanh, float *const *acts, int bf16_operands = 0, unsigned long long *const *bits = nullptr,
-                   bool *have_bits = nullptr) {
+                   bool *have_bits = nullptr, const unsigned *rowtab = nullptr, int64_t src_rows = 0) {
     if (have_bits)
         for (int l = 0; l < net.n_layers; ++l) have_bits[l] = false;
     const float *x = obs;
@@ -84,8 +93,12 @@ static int forward(hipStream_t st, const NetLayout &net, const float *packed, co
             rc = -1;
             if (!last && bits && bits[l] && !bf16_operands) {
                 rc = launch_gemm_nt_bits(st, x, ldx, packed + L.off_w, L.pin, packed + L.off_b, acts[l], L.pout, n, L.pout, L.pin,
-                                         EPI_BIAS_RELU, bits[l]);
+                                         EPI_BIAS_RELU, bits[l], l == 0 ? rowtab : nullptr, src_rows);
                 if (rc == 0) have_bits[l] = true;
+            }
+            if (l == 0 && rowtab && rc != 0) {
+                if (rc == -1) set_error("forward: the gathered first layer needs the bitmask form");
+                return rc == -1 ? RLPPO_ERR_ARG : rc;
             }
             if (rc == -1)
                 rc = launch_gemm_nt(st, x, ldx, packed + L.off_w, L.pin, packed + L.off_b, nullptr, 0, acts[l], L.pout, n, L.pout,
@@ -350,11 +363,19 @@ int rlppo_gae(void *stream, const float *rews, const float *dones, const float *
 
 // ------------------------------------------------------------------------------------------- PPO minibatch
 static int g_two_streams = 1;  // tuning: rlppo_dbg_set(4, 0/1)
+static int g_fused_gather = 1;  // rlppo_dbg_set(26, 0/1): first-layer launches fetch their rows through the row table
 static int g_update_bf16 = 0;   // rlppo_set_update_precision
 // Library-owned streams: slot s > 0 runs its policy chain on g_main[s]; every slot runs its critic chain on g_side[s].
 static hipStream_t g_main[RLPPO_MAX_SLOTS] = {}, g_side[RLPPO_MAX_SLOTS] = {};
 static hipEvent_t g_ev_fork[RLPPO_MAX_SLOTS] = {}, g_ev_join[RLPPO_MAX_SLOTS] = {}, g_ev_slot[RLPPO_MAX_SLOTS] = {};
 static bool g_slot_pending[RLPPO_MAX_SLOTS] = {};
+// [r3] The reductions of the weight-gradient partial tiles run on a stream of their own per network (g_red[slot][net]): a
+// reduction depends on its dW launch only, and nothing in the chain depends on it before the optimiser step -- in the chain's
+// own stream it stood between dW(l) and dX(l) (37 us on average per reduction while the other chain's GEMMs hold the CUs, 7 per
+// pass: profiles/r03_rank_share_trace.txt).  g_ev_dw[slot][net][layer] orders a reduction behind its dW launch, g_ev_red joins.
+static int g_red_streams = 1;  // rlppo_dbg_set(25, 0/1)
+static hipStream_t g_red[RLPPO_MAX_SLOTS][2] = {};
+static hipEvent_t g_ev_dw[RLPPO_MAX_SLOTS][2][RLPPO_MAX_LAYERS] = {}, g_ev_red[RLPPO_MAX_SLOTS][2] = {};
 
 static int ensure_slot(int s) {
     if (!g_side[s]) {
@@ -363,6 +384,11 @@ static int ensure_slot(int s) {
         RLPPO_HIP(hipEventCreateWithFlags(&g_ev_fork[s], hipEventDisableTiming));
         RLPPO_HIP(hipEventCreateWithFlags(&g_ev_join[s], hipEventDisableTiming));
         RLPPO_HIP(hipEventCreateWithFlags(&g_ev_slot[s], hipEventDisableTiming));
+        for (int k = 0; k < 2; ++k) {
+            RLPPO_HIP(hipStreamCreateWithFlags(&g_red[s][k], hipStreamNonBlocking));
+            RLPPO_HIP(hipEventCreateWithFlags(&g_ev_red[s][k], hipEventDisableTiming));
+            for (int l = 0; l < RLPPO_MAX_LAYERS; ++l) RLPPO_HIP(hipEventCreateWithFlags(&g_ev_dw[s][k][l], hipEventDisableTiming));
+        }
     }
     return 0;
 }
@@ -373,21 +399,24 @@ static int order_after(hipStream_t to, hipStream_t from, hipEvent_t ev) {
     return 0;
 }
 
-// partial-tile workspace of a net's weight-gradient launches (they run one after the other on the net's stream)
+// partial-tile workspace of one weight-gradient launch of a net
+static size_t tn_layer_floats(const NetLayout &net, int l, int64_t mb) {
+    size_t f = tn_partial_floats(net.L[l].out, net.L[l].in, mb);
+    if (net.L[l].out == 1) {  // one-output head: block partials of gemv_dw_kernel (64 rows per block)
+        const size_t g = (size_t)cdiv(mb, 64) * (size_t)(net.L[l].pin + 4);  // upper bound: at least 64 rows per block
+        if (g > f) f = g;
+    }
+    if (g_update_bf16 && l == net.n_layers - 1) {  // narrow head of the bf16 precision: per-lane partials of thin_dw_b16
+        const size_t g = thin_dw_ws_floats(net.L[l].out, net.L[l].pin, mb);
+        if (g > f) f = g;
+    }
+    return (f + 3) / 4 * 4;
+}
+// ... of all of them: [r3] one buffer per LAYER (they were one buffer per net while the reductions ran in the chain's stream):
+// a layer's reduction may still be reading its partial tiles when the next layer's dW launch writes its own
 static size_t tn_ws_floats(const NetLayout &net, int64_t mb) {
     size_t m = 0;
-    for (int l = 0; l < net.n_layers; ++l) {
-        size_t f = tn_partial_floats(net.L[l].out, net.L[l].in, mb);
-        if (net.L[l].out == 1) {  // one-output head: block partials of gemv_dw_kernel (64 rows per block)
-            const size_t g = (size_t)cdiv(mb, 64) * (size_t)(net.L[l].pin + 4);  // upper bound: at least 64 rows per block
-            if (g > f) f = g;
-        }
-        if (g_update_bf16 && l == net.n_layers - 1) {  // narrow head of the bf16 precision: per-lane partials of thin_dw_b16
-            const size_t g = thin_dw_ws_floats(net.L[l].out, net.L[l].pin, mb);
-            if (g > f) f = g;
-        }
-        if (f > m) m = f;
-    }
+    for (int l = 0; l < net.n_layers; ++l) m += tn_layer_floats(net, l, mb);
     return m;
 }
 
@@ -398,8 +427,8 @@ static size_t train_ws_floats(const NetLayout &pol, const NetLayout &val, int64_
     int m = max_pout(pol) > max_pout(val) ? max_pout(pol) : max_pout(val);
     per_row += (size_t)(pol.n_layers - 1 + val.n_layers - 1) * (size_t)m;  // one dX buffer per layer and net
     per_row += (size_t)pol.L[0].pin;                                         // the gathered minibatch states
-    per_row += 3 + (size_t)pol.L[pol.n_layers - 1].pout;                      // gathered old log-prob, advantage, target, actions
-                                                                             // (act_dim <= the policy's output width)
+    per_row += 4 + (size_t)pol.L[pol.n_layers - 1].pout;                      // gathered old log-prob, advantage, target, actions
+                                                                             // (act_dim <= the policy's output width) + the row table
     size_t bits = 0;                                                         // ReLU bitmasks of the hidden layers (1/32 of h)
     for (int l = 0; l + 1 < pol.n_layers; ++l) bits += nt_bits_floats(mb, pol.L[l].pout);
     for (int l = 0; l + 1 < val.n_layers; ++l) bits += nt_bits_floats(mb, val.L[l].pout);
@@ -420,24 +449,44 @@ size_t rlppo_minibatch_workspace_bytes(const int32_t *pol_dims, int32_t pol_laye
     return train_ws_floats(pol, val, mb > 0 ? mb : 0) * sizeof(float) + 256;
 }
 
+// Where a chain's weight-gradient reductions go and how its first layer finds its rows [r3].
+struct ChainCtx {
+    hipStream_t red = nullptr;        // reductions run here behind ev_dw[layer] (nullptr: in the chain's own stream)
+    hipEvent_t *ev_dw = nullptr;
+    const unsigned *rowtab = nullptr;  // fused gather: row r of the pass is src[rowtab[r]] (first-layer dW)
+    const float *src = nullptr;
+    int64_t ld_src = 0, src_rows = 0;
+};
+
 // backward of one net: acts[l] = saved output of layer l, acts[last] holds dL/d(out) on entry; dx[l-1] receives
 // dL/d(acts[l-1]) = dY of layer l-1 (one buffer per layer: the dW launches read them later)
 static int backward(hipStream_t st, const NetLayout &net, const float *packed, const float *states, int64_t ld_states,
-                    int64_t mb, float *const *acts, float *const *dx, float *grad, float *tn_ws, size_t tn_floats,
-                    unsigned long long *const *bits, const bool *have_bits) {
+                    int64_t mb, float *const *acts, float *const *dx, float *grad, float *tn_ws,
+                    unsigned long long *const *bits, const bool *have_bits, const ChainCtx &cx) {
     const int last = net.n_layers - 1;
     int rc = 0;
+    float *ws_l[RLPPO_MAX_LAYERS];
+    for (int l = 0; l < net.n_layers; ++l) {
+        ws_l[l] = tn_ws;
+        tn_ws += tn_layer_floats(net, l, mb);
+    }
     for (int l = last; l >= 0; --l) {
         const LayerLayout &L = net.L[l];
         const float *dY = l == last ? acts[last] : dx[l];
         const float *X = l > 0 ? acts[l - 1] : states;
         const int64_t ldx = l > 0 ? net.L[l - 1].pout : ld_states;
         const bool gemv = l == last && l > 0 && gemv_head_ok(L.out, L.pin);  // one-output head (gemv.hip)
+        const size_t floats = tn_layer_floats(net, l, mb);
+        hipEvent_t ev = cx.red ? cx.ev_dw[l] : nullptr;
         if (gemv)
-            rc = launch_gemv_dw(st, dY, L.pout, X, ldx, grad + L.off_flat_w, grad + L.off_flat_b, L.in, L.pin, mb, tn_ws, tn_floats);
+            rc = launch_gemv_dw(st, dY, L.pout, X, ldx, grad + L.off_flat_w, grad + L.off_flat_b, L.in, L.pin, mb, ws_l[l], floats,
+                                cx.red, ev);
+        else if (l == 0 && cx.rowtab)
+            rc = launch_gemm_tn(st, dY, L.pout, L.pout, cx.src, cx.ld_src, L.pin, grad + L.off_flat_w, grad + L.off_flat_b, L.out, L.in,
+                                mb, ws_l[l], floats, cx.rowtab, cx.src_rows, cx.red, ev);
         else
             rc = launch_gemm_tn(st, dY, L.pout, L.pout, X, ldx, L.pin, grad + L.off_flat_w, grad + L.off_flat_b, L.out, L.in, mb,
-                                tn_ws, tn_floats);
+                                ws_l[l], floats, nullptr, 0, cx.red, ev);
         if (rc) return rc;
         if (l == 0) break;
         // dX[mb][pin] = (dY[mb][pout] . W[pout][pin]) masked by relu'(acts[l-1]); B operand = W^T [pin][pout].  The mask is the
@@ -655,6 +704,8 @@ int rlppo_ppo_minibatch(void *stream, const rlppo_minibatch_args *a) {
     w += (size_t)mb * pol.L[0].pin;
     float *const wmeta = w;
     w += (size_t)mb * (3 + (size_t)pol.L[pol.n_layers - 1].pout);
+    unsigned *const rowtab = reinterpret_cast<unsigned *>(w);  // physical buffer row of every row of the pass (gather_meta_kernel)
+    w += (size_t)mb;
     // bf16 update precision: bf16 copies of the gathered rows and of the hidden activations, and the rounded weight images
     const bool b16 = g_update_bf16 != 0;
     unsigned short *states_b = nullptr, *pactb[RLPPO_MAX_LAYERS] = {}, *vactb[RLPPO_MAX_LAYERS] = {};
@@ -688,16 +739,24 @@ int rlppo_ppo_minibatch(void *stream, const rlppo_minibatch_args *a) {
         };
         rc = launch_gather_rows_round(st, a->states, a->ld_states, a->idx, lean0(pol) && lean0(val) ? nullptr : states, states_b,
                                       pol.L[0].pin, mb, ring_base, ring_cap);
-    } else {
-        rc = launch_gather_rows(st, a->states, a->ld_states, a->idx, states, pol.L[0].pin, mb, ring_base, ring_cap);
     }
+    // [r3] fp32 precision: the four first-layer launches (two forwards, two dW) fetch their rows straight from the experience
+    // buffer through the row table (the gather fused into the load stage) when their shapes have that form; the
+    // separate gather pass into the workspace remains for the others.
+    const int64_t src_rows = a->ring_cap > 0 ? a->ring_cap : a->n_rows;
+    auto gather_form = [&](const NetLayout &n) {
+        return n.n_layers > 1 && nt_gather_ok(a->ld_states, src_rows, n.L[0].pout, n.L[0].pin) && tn_gather_ok(a->ld_states, src_rows) &&
+               !(n.L[0].out > 64 && n.L[0].out <= 96 && !(n.L[0].in > 96 && n.L[0].in <= 112));
+    };
+    const bool fused_gather = !b16 && g_fused_gather && src_rows > 0 && gather_form(pol) && gather_form(val);
+    if (!b16 && !fused_gather) rc = launch_gather_rows(st, a->states, a->ld_states, a->idx, states, pol.L[0].pin, mb, ring_base, ring_cap);
     if (rc) return rc;
     const float *pol_w = b16 ? a->pol_packed_r : a->pol_packed, *val_w = b16 ? a->val_packed_r : a->val_packed;
     // the minibatch's per-row scalars, gathered once (the loss kernels stream them)
     RLPPO_CHECK_ARG(a->act_dim >= 1 && a->act_dim <= pol.L[pol.n_layers - 1].pout, "ppo_minibatch: act_dim=%d", a->act_dim);
     float *g_old = wmeta, *g_adv = wmeta + mb, *g_tgt = wmeta + 2 * (size_t)mb, *g_act = wmeta + 3 * (size_t)mb;
     rc = launch_gather_meta(st, a->idx, a->actions, a->act_dim, a->old_logp, a->advantages, a->targets, g_act, g_old, g_adv, g_tgt, mb,
-                            ring_base, ring_cap);
+                            ring_base, ring_cap, fused_gather ? rowtab : nullptr);
     if (rc) return rc;
     // forward of both nets
     // The two networks are independent until the loss epilogue and again after it, so their launch chains run on
@@ -717,9 +776,12 @@ int rlppo_ppo_minibatch(void *stream, const rlppo_minibatch_args *a) {
         rc = forward_b16(st, pol, pol_w, reinterpret_cast<const unsigned short *>(a->pol_wb16), states, states_b, ld_states, mb,
                          a->head == RLPPO_HEAD_GAUSSIAN, pact, pactb, pbits, phave, pf32);
     } else {
-        rc = forward(side, val, val_w, states, ld_states, mb, 0, vact, 0, vbits, vhave);
+        const float *x0 = fused_gather ? a->states : states;
+        const int64_t ld0 = fused_gather ? a->ld_states : ld_states;
+        const unsigned *rt = fused_gather ? rowtab : nullptr;
+        rc = forward(side, val, val_w, x0, ld0, mb, 0, vact, 0, vbits, vhave, rt, src_rows);
         if (rc) return rc;
-        rc = forward(st, pol, pol_w, states, ld_states, mb, a->head == RLPPO_HEAD_GAUSSIAN, pact, 0, pbits, phave);
+        rc = forward(st, pol, pol_w, x0, ld0, mb, a->head == RLPPO_HEAD_GAUSSIAN, pact, 0, pbits, phave, rt, src_rows);
     }
     if (rc) return rc;
     // loss epilogue: outputs -> output gradients in place, report statistics accumulated on device.  The value loss only
@@ -760,9 +822,28 @@ int rlppo_ppo_minibatch(void *stream, const rlppo_minibatch_args *a) {
         rc = backward_b16(st, pol, pol_w, reinterpret_cast<const unsigned short *>(a->pol_wb16), states, states_b, ld_states, mb, pact,
                           pactb, pdx, pdxb, a->pol_grad, pol_tn_ws, tn_ws_floats(pol, mb), pbits, phave, pf32);
     } else {
-        rc = backward(side, val, val_w, states, ld_states, mb, vact, vdx, a->val_grad, val_tn_ws, tn_ws_floats(val, mb), vbits, vhave);
+        ChainCtx cp, cv;
+        if (g_red_streams) {
+            cp.red = g_red[slot][0];
+            cp.ev_dw = g_ev_dw[slot][0];
+            cv.red = g_red[slot][1];
+            cv.ev_dw = g_ev_dw[slot][1];
+        }
+        if (fused_gather) {
+            cp.rowtab = cv.rowtab = rowtab;
+            cp.src = cv.src = a->states;
+            cp.ld_src = cv.ld_src = a->ld_states;
+            cp.src_rows = cv.src_rows = src_rows;
+        }
+        rc = backward(side, val, val_w, states, ld_states, mb, vact, vdx, a->val_grad, val_tn_ws, vbits, vhave, cv);
         if (rc) return rc;
-        rc = backward(st, pol, pol_w, states, ld_states, mb, pact, pdx, a->pol_grad, pol_tn_ws, tn_ws_floats(pol, mb), pbits, phave);
+        rc = backward(st, pol, pol_w, states, ld_states, mb, pact, pdx, a->pol_grad, pol_tn_ws, pbits, phave, cp);
+        if (rc) return rc;
+        if (g_red_streams)  // the pass is complete when both networks' last reductions are
+            for (int k = 0; k < 2; ++k) {
+                rc = order_after(st, g_red[slot][k], g_ev_red[slot][k]);
+                if (rc) return rc;
+            }
     }
     if (rc) return rc;
     if (side != st) rc = order_after(st, side, g_ev_join[slot]);
@@ -792,7 +873,7 @@ int rlppo_clip_adam(void *stream, float *params, float *grads, float *exp_avg, f
                             (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps, gnorm2);
 }
 
-int rlppo_clip_adam_pack2(void *stream, const rlppo_opt_net *a, const rlppo_opt_net *b) {
+int rlppo_clip_adam_pack2(void *stream, const rlppo_opt_net *a, const rlppo_opt_net *b, void *sync_ws) {
     RLPPO_CHECK_ARG(a && b, "clip_adam_pack2: null descriptor");
     const rlppo_opt_net *d[2] = {a, b};
     NetLayout nets[2];
@@ -817,7 +898,7 @@ int rlppo_clip_adam_pack2(void *stream, const rlppo_opt_net *a, const rlppo_opt_
         eps[k] = (float)d[k]->eps;
     }
     return launch_clip_adam_pack2((hipStream_t)stream, nets, p, g, m, v, packed, gn, n, max_norm, step_size, bc2_sqrt, omb1, beta2,
-                                  omb2, eps);
+                                  omb2, eps, sync_ws);
 }
 
 }  // extern "C"
@@ -879,6 +960,8 @@ int rlppo_dbg_set(int32_t key, int32_t value) {
         case 22: set_gae_oversubscribe(value); return 0;
         case 23: set_b16_wide_tiles(value); return 0;
         case 24: set_exp_fast_transform(value); return 0;
+        case 25: g_red_streams = value; return 0;
+        case 26: g_fused_gather = value; return 0;
         default: break;
     }
     set_error("dbg_set: unknown key %d", key);

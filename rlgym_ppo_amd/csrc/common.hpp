@@ -75,7 +75,9 @@ int launch_gemm_nt(hipStream_t st, const float *A, int64_t lda, const float *B, 
 // returns -1 when that form does not apply (width not a multiple of 128)
 size_t nt_bits_floats(int64_t M, int N);
 int launch_gemm_nt_bits(hipStream_t st, const float *A, int64_t lda, const float *B, int64_t ldb, const float *bias, float *C,
-                        int64_t ldc, int64_t M, int N, int K, int epi, unsigned long long *bits);
+                        int64_t ldc, int64_t M, int N, int K, int epi, unsigned long long *bits, const unsigned *rowtab = nullptr,
+                        int64_t src_rows = 0);
+bool nt_gather_ok(int64_t lda, int64_t src_rows, int N, int K);  // can the forward fetch its rows through a row table?
 int launch_gemm_nt_bf16(hipStream_t st, const float *A, int64_t lda, const float *B, int64_t ldb, const float *bias, float *C,
                         int64_t ldc, int64_t M, int N, int nb, int K, int epi);
 void set_infer_bf16(int v);
@@ -83,8 +85,11 @@ int get_infer_bf16();
 // dW[n][k] += sum_m dY[m][n] X[m][k] ; db[n] += sum_m dY[m][n]: partial tiles in `ws` (>= tn_partial_floats(out, in, M)
 // floats) + a fixed-order reduction into the flat arena
 size_t tn_partial_floats(int out, int in, int64_t M);
+// rowtab: sample m is X[rowtab[m]] (fused minibatch gather); red_st / ev: run the reduction on red_st behind event ev
 int launch_gemm_tn(hipStream_t st, const float *dY, int64_t ldy, int ny_valid, const float *X, int64_t ldx, int kx_valid,
-                   float *dW, float *db, int out, int in, int64_t M, float *ws, size_t ws_floats);
+                   float *dW, float *db, int out, int in, int64_t M, float *ws, size_t ws_floats, const unsigned *rowtab = nullptr,
+                   int64_t src_rows = 0, hipStream_t red_st = nullptr, hipEvent_t ev = nullptr);
+bool tn_gather_ok(int64_t ldx, int64_t src_rows);
 
 // gemm_b16.hip: the bf16 update precision, both operands bf16 in memory, fp32 accumulate ---------------------------------
 // (A: activations / activation gradients, B: rlppo_net_pack_bf16's W or W^T blocks)
@@ -117,7 +122,7 @@ int launch_gemv_dx(hipStream_t st, const float *dy, int64_t ldy, const float *w,
 int launch_gemv_dx_bits(hipStream_t st, const float *dy, int64_t ldy, const float *w, const unsigned long long *bits, float *dx,
                         int64_t ldc, int kp, int64_t n);
 int launch_gemv_dw(hipStream_t st, const float *dy, int64_t ldy, const float *x, int64_t ldx, float *dw, float *db, int in, int kp, int64_t n,
-                   float *ws = nullptr, size_t ws_floats = 0);
+                   float *ws = nullptr, size_t ws_floats = 0, hipStream_t red_st = nullptr, hipEvent_t ev = nullptr);
 
 // heads.hip: sampling and loss epilogues ---------------------------------------------------------------
 struct LossCfg {
@@ -165,7 +170,7 @@ int launch_clip_adam(hipStream_t, float *p, float *g, float *m, float *v, int64_
 int launch_clip_adam_pack2(hipStream_t st, const NetLayout *nets, float *const *p, float *const *g, float *const *m, float *const *v,
                            float *const *packed, double *const *gnorm2, const int64_t *n, const float *max_norm,
                            const float *step_size, const float *bc2_sqrt, const float *omb1, const float *beta2, const float *omb2,
-                           const float *eps);
+                           const float *eps, void *sync_ws = nullptr);
 int launch_welford(hipStream_t st, const float *x, int64_t ld, int64_t n, int d, void *mean, void *m2, long long count0, int state_f64);
 int launch_welford_merge(hipStream_t st, int d, void *mean, void *m2, long long count, const float *omean, const float *om2,
                          long long ocount, int state_f64);
@@ -173,7 +178,7 @@ int launch_gather_rows(hipStream_t st, const float *src, int64_t ld_src, const i
                        int64_t ring_base = 0, int64_t ring_cap = INT64_MAX);
 int launch_gather_meta(hipStream_t st, const int64_t *idx, const float *actions, int act_dim, const float *old_logp,
                        const float *adv, const float *targets, float *g_act, float *g_old, float *g_adv, float *g_tgt, int64_t n,
-                       int64_t ring_base, int64_t ring_cap);
+                       int64_t ring_base, int64_t ring_cap, unsigned *rowtab = nullptr);
 int launch_pad_rows(hipStream_t, const void *, int, int64_t, int64_t, int64_t, float *, int64_t, int, float, float);
 int launch_pad_rows_vec(hipStream_t, const void *, int, int64_t, int64_t, int64_t, float *, int64_t, const float *, const float *);
 

@@ -418,9 +418,9 @@ __global__ __launch_bounds__(GAE_THREADS, 4) void gae_lookback_kernel(const floa
                 u64 g = 0;
                 if (lane < LB_AGG + LB_INC)
                     g = __hip_atomic_load(state + (size_t)j * LB_STRIDE + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const unsigned tag = (unsigned)(g >> 32), val = (unsigned)g;
-                const u64 inc_ok = __ballot(lane >= LB_AGG && lane < LB_AGG + LB_INC && tag == TAG_INC);
-                const u64 agg_ok = __ballot(lane < LB_AGG && tag == TAG_AGG);
+                const unsigned rtag = (unsigned)(g >> 32), val = (unsigned)g;  // (not `tag`: that is the launch's own, a kernel argument)
+                const u64 inc_ok = __ballot(lane >= LB_AGG && lane < LB_AGG + LB_INC && rtag == TAG_INC);
+                const u64 agg_ok = __ballot(lane < LB_AGG && rtag == TAG_AGG);
                 auto dbl = [&](int first) {
                     const unsigned lo = __shfl(val, first), hi = __shfl(val, first + 1);
                     return __longlong_as_double((long long)(((u64)hi << 32) | lo));
@@ -543,23 +543,36 @@ int launch_gae(hipStream_t st, const float *rews, const float *dones, const floa
     if (g_gae_algo == 1 && cap == hipStreamCaptureStatusNone) {
         unsigned *hdr = reinterpret_cast<unsigned *>(ws);
         u64 *state = reinterpret_cast<u64 *>(reinterpret_cast<char *>(ws) + 16);
-        static int resident = 0;  // co-resident workgroups of this kernel on the device (queried once)
+        // co-resident workgroups of this kernel, per device (queried once for each device id: a process may drive several).
+        // The LOOP form (more chunks than the grid) makes a workgroup of round k wait on one of round k - 1, which is only safe
+        // while the whole grid is resident -- and other streams' kernels may hold some of the slots the occupancy query counts:
+        // the grid is therefore kept one workgroup per CU BELOW the theoretical occupancy.
+        static std::atomic<int> resident_by_dev[64], cus_by_dev[64];
+        int dev = 0;
+        RLPPO_HIP(hipGetDevice(&dev));
+        RLPPO_CHECK_ARG(dev >= 0 && dev < 64, "gae: device id %d", dev);
+        int resident = resident_by_dev[dev].load(std::memory_order_acquire);
         if (resident == 0) {
-            int per_cu = 0, dev = 0;
+            int per_cu = 0;
             hipDeviceProp_t prop;
-            RLPPO_HIP(hipGetDevice(&dev));
             RLPPO_HIP(hipGetDeviceProperties(&prop, dev));
             RLPPO_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gae_lookback_kernel<true>, GAE_THREADS, 0));
             // the occupancy API over-reports by one block per CU only in the SGPR-limited 7-8 blocks/CU regime
             // (MI355X_MICROARCH.md "Residency and cooperative launch"); this kernel is VGPR-limited far below that
             per_cu = per_cu > 6 ? 6 : (per_cu < 1 ? 1 : per_cu);
             resident = per_cu * prop.multiProcessorCount;
+            cus_by_dev[dev].store(prop.multiProcessorCount, std::memory_order_relaxed);
+            resident_by_dev[dev].store(resident, std::memory_order_release);
         }
+        const int cus = cus_by_dev[dev].load(std::memory_order_relaxed);
+        const int loop_grid = resident - cus > 0 ? resident - cus : resident;  // LOOP form: one workgroup per CU of margin
         // g_gae_oversubscribe: one workgroup per chunk even beyond the resident capacity.  Chunks are taken right to left in
         // workgroup-id order and every XCD dispatches its workgroups in id order, so the smallest unfinished chunk always holds
         // (or is next in line for) a slot and waits on nothing unfinished: no deadlock without co-residency, and the loads of a
         // later wave of workgroups overlap the stores of an earlier one instead of all workgroups moving in lockstep.
-        int grid = (nb < resident || g_gae_oversubscribe) ? nb : resident;
+        // Up to the theoretical occupancy every chunk gets its own workgroup (the loop-free kernel: safe whatever is resident,
+        // by the dispatch-order argument above); beyond it the LOOP form runs on the margin-reduced grid.
+        int grid = (nb <= resident || g_gae_oversubscribe) ? nb : loop_grid;
         // per-launch tag: process-wide counter seeded from the clock (a recycled workspace may hold records of another
         // process's launches), never 0 (zero-filled memory)
         static std::atomic<unsigned> g_tag{0};

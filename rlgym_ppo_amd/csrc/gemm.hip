@@ -24,14 +24,22 @@
 
 namespace rlppo {
 
-template <int NB, int EPI, int BKT, bool BITS = false>
+// GATHER (the minibatch gather of experience_buffer.py:82-87 folded into the first layer's operand fetch): A is the
+// experience buffer's state matrix and row r of the product is A[rowtab[r]] -- the DMA's descriptor is then a STRUCTURED buffer
+// (stride = one buffer row) addressed by a per-lane row INDEX (buffer_load ... idxen offen lds): the index register is loaded once
+// per tile from the pass's row table (u32 physical rows, written by gather_meta_kernel), the K advance stays the scalar offset,
+// and the loop is instruction for instruction the contiguous one.  Rows past M read table entry "0" (the table's range check)
+// -- a valid row whose products land in output rows the C descriptor drops.
+template <int NB, int EPI, int BKT, bool BITS = false, bool GATHER = false>
 __global__ __launch_bounds__(256, BKT == 16 ? 4 : 2) void gemm_nt_dma_kernel(const float *__restrict__ A, unsigned lda_b,
                                                                               const float *__restrict__ B, unsigned ldb_b,
                                                                               const float *__restrict__ bias,
                                                                               const float *__restrict__ mask_src,
                                                                               unsigned ldm_b, float *__restrict__ C,
                                                                               unsigned ldc_b, int64_t M, int K,
-                                                                              unsigned long long *__restrict__ bits = nullptr) {
+                                                                              unsigned long long *__restrict__ bits = nullptr,
+                                                                              const unsigned *__restrict__ rowtab = nullptr,
+                                                                              unsigned src_rows = 0) {
     constexpr int BN = NB * 16;
     constexpr int CPR = BKT / 4;     // 16-byte chunks per tile row
     constexpr int RPW = 64 / CPR;    // tile rows one wave instruction fills
@@ -59,17 +67,25 @@ __global__ __launch_bounds__(256, BKT == 16 ? 4 : 2) void gemm_nt_dma_kernel(con
     unsigned long long mask_word = 0;
     if (BITS && EPI == EPI_MASK) mask_word = *bit_word;  // requested before the K loop: long arrived when the epilogue needs it
 
-    const __amdgpu_buffer_rsrc_t a_rs = make_rsrc(reinterpret_cast<const char *>(A) + m0 * lda_b,
-                                                  (unsigned)(rows_here - 1) * lda_b + (unsigned)K * 4);
+    const __amdgpu_buffer_rsrc_t a_rs = GATHER ? __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(A), (short)lda_b, src_rows, 0x00020000)
+                                               : make_rsrc(reinterpret_cast<const char *>(A) + m0 * lda_b,
+                                                           (unsigned)(rows_here - 1) * lda_b + (unsigned)K * 4);
     const __amdgpu_buffer_rsrc_t b_rs = make_rsrc(reinterpret_cast<const char *>(B) + (int64_t)n0 * ldb_b,
                                                   (unsigned)(BN - 1) * ldb_b + (unsigned)K * 4);
     // lane -> (row, physical chunk) of the 1 KiB piece its wave instruction fills; it fetches the logical chunk that the
     // swizzle maps there (rows of later passes keep the swizzle key, so one offset serves all passes)
     const int row_p = wave * RPW + lane / CPR, pch = lane % CPR;
     const int lch = BKT == 32 ? (pch ^ (row_p & 7)) : (pch ^ ((0 - (row_p >> 2)) & 3));
-    const unsigned a_off = (unsigned)row_p * lda_b + lch * 16;
+    const unsigned a_off = GATHER ? (unsigned)lch * 16 : (unsigned)row_p * lda_b + lch * 16;
     const unsigned b_off = (unsigned)row_p * ldb_b + lch * 16;
     const unsigned a_step = (unsigned)RPP * lda_b, b_step = (unsigned)RPP * ldb_b;
+    unsigned a_row[4];  // GATHER: the buffer rows of this lane's A_IT staging passes (a dependent bound loses the host-side launch stub: hipcc 7.2)
+    static_assert(A_IT <= 4, "a_row");  // GATHER: the buffer row each of this lane's A_IT staging passes fetches
+    if (GATHER) {
+        const __amdgpu_buffer_rsrc_t t_rs = make_rsrc(rowtab + m0, (unsigned)rows_here * 4);
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i) a_row[i] = __builtin_amdgcn_raw_buffer_load_b32(t_rs, (unsigned)(row_p + i * RPP) * 4, 0, 0);
+    }
 
     f32x4 acc[2][NB];
     if (EPI == EPI_MASK) {
@@ -90,8 +106,12 @@ __global__ __launch_bounds__(256, BKT == 16 ? 4 : 2) void gemm_nt_dma_kernel(con
         float *Ad = As + buf * SBM * BKT + wave_u * RPW * BKT;
         float *Bd = Bs + buf * BN * BKT + wave_u * RPW * BKT;
 #pragma unroll
-        for (int i = 0; i < A_IT; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rs, Ad + i * RPP * BKT, 16, a_off, kb + i * a_step, 0, 0);
+        for (int i = 0; i < A_IT; ++i) {
+            if (GATHER)
+                __builtin_amdgcn_struct_ptr_buffer_load_lds(a_rs, Ad + i * RPP * BKT, 16, a_row[i], a_off, kb, 0, 0);
+            else
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rs, Ad + i * RPP * BKT, 16, a_off, kb + i * a_step, 0, 0);
+        }
 #pragma unroll
         for (int i = 0; i < B_IT; ++i)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(b_rs, Bd + i * RPP * BKT, 16, b_off, kb + i * b_step, 0, 0);
@@ -100,6 +120,7 @@ __global__ __launch_bounds__(256, BKT == 16 ? 4 : 2) void gemm_nt_dma_kernel(con
     };
 
     const int nk = K / BKT;
+    if (GATHER) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the row indices are the first tile's addresses
     issue_tile(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -257,8 +278,22 @@ static int launch_nt_1(hipStream_t st, dim3 grid, int epi, const float *A, unsig
                        const float *bias, const float *mask_src, unsigned ldm_b, float *C, unsigned ldc_b, int64_t M,
                        int K) {
     // BK = 16 (<= 32 KiB of LDS, four workgroups per CU) fills 64 tile rows per staging pass (+ a ragged pass of 32 for the
-    // 96-wide tile); the 32-wide tile (half a pass) stays at BK = 32
+    // 96-wide tile); the 32-wide tile (half a pass) stays at BK = 32 unless K is only a multiple of 16 [r3: a first layer whose
+    // input is padded to 16], where it runs BK = 16 with its one ragged pass
     constexpr int BKT = (NB * 16) % 32 == 0 && NB * 16 >= 64 ? 16 : 32;
+    if (BKT == 32 && K % 32 != 0) {
+        if (epi == EPI_BIAS_RELU || epi == EPI_BIAS || epi == EPI_BIAS_TANH || epi == EPI_MASK) {
+#define NT16(E)                                                                                                         \
+    case E:                                                                                                            \
+        hipLaunchKernelGGL((gemm_nt_dma_kernel<NB, E, 16>), grid, dim3(256), 0, st, A, lda_b, B, ldb_b, bias, mask_src,  \
+                           ldm_b, C, ldc_b, M, K);                                                                     \
+        break;
+            switch (epi) { NT16(EPI_BIAS) NT16(EPI_BIAS_RELU) NT16(EPI_BIAS_TANH) NT16(EPI_MASK) }
+#undef NT16
+            RLPPO_LAUNCH_CHECK();
+            return 0;
+        }
+    }
 #define NT(E)                                                                                                          \
     case E:                                                                                                            \
         hipLaunchKernelGGL((gemm_nt_dma_kernel<NB, E, BKT>), grid, dim3(256), 0, st, A, lda_b, B, ldb_b, bias, mask_src, \
@@ -320,15 +355,24 @@ size_t nt_bits_floats(int64_t M, int N) {
 // instead of the activation) through gemm_nt_dma_kernel<8, ., 16, true>.  Returns -1 when that form does not apply
 // (width not a multiple of 128, operands too wide for 32-bit tile offsets): the caller then uses launch_gemm_nt
 // and, for the forward, must not hand the bitmask to the backward pass.
+// rowtab != nullptr (forward only): row r of A is A[rowtab[r]] of a `src_rows`-row matrix -- the fused minibatch gather.
+bool nt_gather_ok(int64_t lda, int64_t src_rows, int N, int K) {
+    return N % 128 == 0 && K % 16 == 0 && lda * 4 < 16384 && lda % 4 == 0 && src_rows > 0 && src_rows < ((int64_t)1 << 32);
+}
 int launch_gemm_nt_bits(hipStream_t st, const float *A, int64_t lda, const float *B, int64_t ldb, const float *bias, float *C,
-                        int64_t ldc, int64_t M, int N, int K, int epi, unsigned long long *bits) {
+                        int64_t ldc, int64_t M, int N, int K, int epi, unsigned long long *bits, const unsigned *rowtab,
+                        int64_t src_rows) {
     if (!bits || N % 128 != 0 || K % 16 != 0 || M <= 0) return -1;
     if (epi != EPI_BIAS_RELU && epi != EPI_MASK) return -1;
     const int64_t lim = (int64_t)1 << 31;
-    if (129 * lda * 4 >= lim || 129 * ldb * 4 >= lim || 129 * ldc * 4 >= lim) return -1;
+    if ((!rowtab && 129 * lda * 4 >= lim) || 129 * ldb * 4 >= lim || 129 * ldc * 4 >= lim) return -1;
     dim3 grid((unsigned)cdiv(M, SBM), (unsigned)(N / 128));
     const unsigned la = (unsigned)(lda * 4), lb = (unsigned)(ldb * 4), lc = (unsigned)(ldc * 4);
-    if (epi == EPI_BIAS_RELU)
+    if (rowtab) {
+        RLPPO_CHECK_ARG(epi == EPI_BIAS_RELU && nt_gather_ok(lda, src_rows, N, K), "gemm_nt (gathered rows): unsupported shape");
+        hipLaunchKernelGGL((gemm_nt_dma_kernel<8, EPI_BIAS_RELU, 16, true, true>), grid, dim3(256), 0, st, A, la, B, lb, bias, nullptr,
+                           0u, C, lc, M, K, bits, rowtab, (unsigned)src_rows);
+    } else if (epi == EPI_BIAS_RELU)
         hipLaunchKernelGGL((gemm_nt_dma_kernel<8, EPI_BIAS_RELU, 16, true>), grid, dim3(256), 0, st, A, la, B, lb, bias, nullptr,
                            0u, C, lc, M, K, bits);
     else
@@ -342,7 +386,7 @@ int launch_gemm_nt(hipStream_t st, const float *A, int64_t lda, const float *B, 
                    const float *mask_src, int64_t ld_mask, float *C, int64_t ldc, int64_t M, int N, int K, int epi,
                    int bf16_operands) {
     if (M <= 0) return 0;
-    RLPPO_CHECK_ARG(K > 0 && K % 32 == 0, "gemm_nt: K=%d must be a positive multiple of 32", K);
+    RLPPO_CHECK_ARG(K > 0 && K % 16 == 0, "gemm_nt: K=%d must be a positive multiple of 16", K);
     RLPPO_CHECK_ARG(lda % 4 == 0 && ldb % 4 == 0 && ldc % 4 == 0 && lda >= K && ldb >= K && ldc >= N,
                     "gemm_nt: leading dimensions lda=%ld ldb=%ld ldc=%ld incompatible with K=%d N=%d", (long)lda,
                     (long)ldb, (long)ldc, K, N);
@@ -361,7 +405,9 @@ int launch_gemm_nt(hipStream_t st, const float *A, int64_t lda, const float *B, 
     const int64_t lim = (int64_t)1 << 31;
     RLPPO_CHECK_ARG(129 * lda * 4 < lim && 129 * ldb * 4 < lim && 129 * ldc * 4 < lim && 129 * ld_mask * 4 < lim,
                     "gemm_nt: a leading dimension is too wide for 32-bit tile offsets");
-    if (bf16_operands && epi != EPI_MASK) return launch_gemm_nt_bf16(st, A, lda, B, ldb, bias, C, ldc, M, N, nb, K, epi);
+    // (the bf16-operand inference kernel steps K by 32: a layer whose K is only a multiple of 16 -- a first layer padded to 16 --
+    // keeps the fp32 kernel, i.e. is computed MORE precisely than the mode asks)
+    if (bf16_operands && epi != EPI_MASK && K % 32 == 0) return launch_gemm_nt_bf16(st, A, lda, B, ldb, bias, C, ldc, M, N, nb, K, epi);
     dim3 grid((unsigned)cdiv(M, SBM), (unsigned)(N / (nb * 16)));
     const unsigned la = (unsigned)(lda * 4), lb = (unsigned)(ldb * 4), lc = (unsigned)(ldc * 4), lm = (unsigned)(ld_mask * 4);
     switch (nb) {
@@ -384,15 +430,40 @@ constexpr unsigned OOR = 0x80000000u;  // per-lane offset that fails every descr
 // the staged dY tile (only by the workgroups of the first k tile).
 //
 // No atomics: 64 fp32 atomics per lane into dW cost 20-50 us of an 86 us launch (128-256 workgroups adding into the same
-// 110-256 KB serialise in the memory-side atomic units).  The workgroup stores its 128 x 128 partial tile with 16 coalesced
-// 16-byte stores per lane into partial[split][tile][(i*4+j)*256 + tid] and tn_reduce_kernel sums the splits afterwards: the
+// 110-256 KB serialise in the memory-side atomic units).  The workgroup stores its partial tile with coalesced 16-byte
+// stores per lane into partial[split][tile][(i*NJ+j)*256 + tid] and tn_reduce_kernel sums the splits afterwards: the
 // sum order is fixed, so the weight gradients are bit-reproducible from run to run.
-template <int TMT>
+//
+// Tile geometry <NI, NJ, WN> [r3]: the 4 waves form a WN x (4/WN) grid, a wave owns NI x NJ blocks of 16 x 16, so the
+// workgroup's output tile is (16 NI WN) rows of dW x (16 NJ 4/WN) columns.  <4,4,2> = 128 x 128 (hidden layers); <3,4,2> =
+// 96 x 128 for the 90-action head (was 128: a quarter of the MFMAs multiplied zero padding); <2,7,4> = 128 x 112 for the first
+// layer of a 107-wide observation (was 128).  The stage images keep 128-float rows whatever the tile.
+//
+// GATHER [r3]: X is the experience buffer's state matrix and sample m of the contraction is X[rowtab[m]]: the X
+// descriptor is a structured buffer addressed by a row index per lane and piece; the indices of stage s + 2 are fetched (no
+// vector ALU: descriptor + lane-constant offset + scalar offset) right after the DMA of stage s + 1 has been issued.
+struct TnGeom {
+    int ni, nj, wn;
+    __host__ __device__ int bnt() const { return wn * ni * 16; }
+    __host__ __device__ int bkx() const { return (4 / wn) * nj * 16; }
+    __host__ __device__ int tile_floats() const { return ni * nj * 1024; }
+};
+static TnGeom tn_geometry(int out, int in) {
+    if (in > 96 && in <= 112) return TnGeom{2, 7, 4};
+    if (out > 64 && out <= 96) return TnGeom{3, 4, 2};
+    return TnGeom{4, 4, 2};
+}
+
+template <int TMT, int NI, int NJ, int WN, bool GATHER>
 __global__ __launch_bounds__(256, 2) void gemm_tn_dma_kernel(const float *__restrict__ dY, unsigned ldy_b,
                                                                               int ny_valid, const float *__restrict__ X,
                                                                               unsigned ldx_b, int kx_valid,
                                                                               bool with_db, int out, int in, int64_t M,
-                                                                              int rows_per_wg, float *__restrict__ partial) {
+                                                                              int rows_per_wg, float *__restrict__ partial,
+                                                                              const unsigned *__restrict__ rowtab,
+                                                                              unsigned src_rows) {
+    constexpr int WK = 4 / WN;
+    constexpr int BNT = WN * NI * 16, BKX = WK * NJ * 16, TILE_F = NI * NJ * 1024;
     constexpr int PPW = TMT / 8;  // 1 KiB pieces per wave, per operand and stage
     __shared__ __attribute__((aligned(16))) float lds[2 * 2 * TMT * 128 < 8 * 128 ? 8 * 128 : 2 * 2 * TMT * 128];
     float *Ys = lds;                 // [2][TMT][128]
@@ -402,7 +473,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_dma_kernel(const float *__rest
     const int lane = tid & 63, wave = tid >> 6;
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     const int r16 = lane & 15, q = lane >> 4;
-    const int wn = wave >> 1, wk = wave & 1;
+    const int wn = wave / WK, wk = wave % WK;
     // XCD-aware order (see xcd_tile): the output tiles of one row split read the same dY / X rows, so they are given ids
     // that land on the same XCD back to back: id -> tile = (id % (8 T)) / 8, split = 8 (id / (8 T)) + id % 8
     int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
@@ -416,31 +487,50 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_dma_kernel(const float *__rest
             by = tile / gridDim.x;
         }
     }
-    const int n0 = bx * 128, k0 = by * 128;
+    const int n0 = bx * BNT, k0 = by * BKX;
     const int64_t mbeg = (int64_t)bz * rows_per_wg;
     const int rows = (int)((M - mbeg) < rows_per_wg ? (M - mbeg) : rows_per_wg);  // >= 1
     const int steps = (rows + TMT - 1) / TMT;
     const int rem = rows - (steps - 1) * TMT;  // rows of the last stage, 1..TMT
-    const int ny_here = (ny_valid - n0) < 128 ? (ny_valid - n0) : 128;
-    const int kx_here = (kx_valid - k0) < 128 ? (kx_valid - k0) : 128;
+    const int ny_here = (ny_valid - n0) < BNT ? (ny_valid - n0) : BNT;
+    const int kx_here = (kx_valid - k0) < BKX ? (kx_valid - k0) : BKX;
 
     const __amdgpu_buffer_rsrc_t y_rs = make_rsrc(reinterpret_cast<const char *>(dY) + mbeg * ldy_b + (int64_t)n0 * 4,
                                                   (unsigned)(rows - 1) * ldy_b + (unsigned)ny_here * 4);
-    const __amdgpu_buffer_rsrc_t x_rs = make_rsrc(reinterpret_cast<const char *>(X) + mbeg * ldx_b + (int64_t)k0 * 4,
-                                                  (unsigned)(rows - 1) * ldx_b + (unsigned)kx_here * 4);
+    const __amdgpu_buffer_rsrc_t x_rs =
+        GATHER ? __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(X), (short)ldx_b, src_rows, 0x00020000)
+               : make_rsrc(reinterpret_cast<const char *>(X) + mbeg * ldx_b + (int64_t)k0 * 4,
+                           (unsigned)(rows - 1) * ldx_b + (unsigned)kx_here * 4);
     // DMA lane map: piece = rows 2 (wave + 4 i) + (lane >> 5); physical chunk lane & 31 holds logical chunk ^ ((row & 3) << 2)
     const int row_l = 2 * wave + (lane >> 5);
     const int lch = (lane & 31) ^ ((row_l & 3) << 2);
+    const bool x_col = lch * 4 < kx_here;
     const unsigned y_off = (lch * 4 < ny_here) ? (unsigned)row_l * ldy_b + lch * 16 : OOR;
-    const unsigned x_off = (lch * 4 < kx_here) ? (unsigned)row_l * ldx_b + lch * 16 : OOR;
+    const unsigned x_off = GATHER ? (unsigned)(k0 * 4 + lch * 16) : (x_col ? (unsigned)row_l * ldx_b + lch * 16 : OOR);
     const unsigned y_row8 = 8u * ldy_b, x_row8 = 8u * ldx_b, y_stage = TMT * ldy_b, x_stage = TMT * ldx_b;  // uniform
+    // GATHER: buffer rows of this lane's PPW pieces of the stage about to be issued (entries past the split read as 0: a valid
+    // row whose dY partner rows the range check / clear_tail zero)
+    unsigned x_row[4];  // (a bound that depends on a template parameter, captured by the lambdas below, loses the host-side launch stub: hipcc 7.2)
+    static_assert(PPW <= 4, "x_row");
+    const __amdgpu_buffer_rsrc_t t_rs = make_rsrc(GATHER ? rowtab + mbeg : nullptr, GATHER ? (unsigned)rows * 4 : 0u);
+    auto load_rows = [&](int stage) {
+        if (GATHER) {
+#pragma unroll
+            for (int i = 0; i < PPW; ++i)
+                x_row[i] = __builtin_amdgcn_raw_buffer_load_b32(t_rs, (unsigned)row_l * 4, (unsigned)(stage * TMT + 8 * i) * 4, 0);
+        }
+    };
 
     auto issue_stage = [&](int buf, int stage) {
         float *Yd = Ys + (buf * TMT + 2 * wave_u) * 128, *Xd = Xs + (buf * TMT + 2 * wave_u) * 128;
 #pragma unroll
         for (int i = 0; i < PPW; ++i) {
             __builtin_amdgcn_raw_ptr_buffer_load_lds(y_rs, Yd + 8 * i * 128, 16, y_off, (unsigned)stage * y_stage + i * y_row8, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rs, Xd + 8 * i * 128, 16, x_off, (unsigned)stage * x_stage + i * x_row8, 0, 0);
+            if (GATHER) {
+                if (x_col) __builtin_amdgcn_struct_ptr_buffer_load_lds(x_rs, Xd + 8 * i * 128, 16, x_row[i], x_off, 0, 0, 0);
+            } else {
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rs, Xd + 8 * i * 128, 16, x_off, (unsigned)stage * x_stage + i * x_row8, 0, 0);
+            }
         }
     };
     // a ragged last stage: the DMA drops the rows past the split, so their (stale) LDS rows are cleared by hand
@@ -453,30 +543,41 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_dma_kernel(const float *__rest
         }
     };
 
-    f32x4 acc[4][4];
+    f32x4 acc[NI][NJ];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < NI; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     f32x4 bs4 = f32x4{0.f, 0.f, 0.f, 0.f};
     const bool want_db = with_db && by == 0;
 
+    load_rows(0);
+    if (GATHER) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     issue_stage(0, 0);
+    if (steps > 1) load_rows(1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (steps == 1 && rem < TMT) clear_tail(0);
     __syncthreads();
     // fragment addresses: element (m, col) lives at m*128 + (col ^ ((m & 3) << 4)); m & 3 == q for every fragment read
-    int fy[4], fx[4];
+    int fy[NI], fx[NJ];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        fy[i] = q * 128 + wn * 64 + ((i ^ q) << 4) + r16;
-        fx[i] = q * 128 + wk * 64 + ((i ^ q) << 4) + r16;
+    for (int i = 0; i < NI; ++i) {
+        const int g = wn * NI + i;
+        fy[i] = q * 128 + (((g & ~3) | ((g & 3) ^ q)) << 4) + r16;
+    }
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int g = wk * NJ + j;
+        fx[j] = q * 128 + (((g & ~3) | ((g & 3) ^ q)) << 4) + r16;
     }
     const int db_off = zr * 128 + zc;  // db partial sums: rows zr + 8 i, physical chunk tid & 31
     for (int st = 0; st < steps; ++st) {
         const int cur = st & 1;
         const bool more = (st + 1) < steps;
-        if (more) issue_stage(cur ^ 1, st + 1);
+        if (more) {
+            issue_stage(cur ^ 1, st + 1);
+            if ((st + 2) < steps) load_rows(st + 2);
+        }
         const float *Yc = Ys + cur * TMT * 128;
         const float *Xc = Xs + cur * TMT * 128;
         if (want_db) {
@@ -488,15 +589,15 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_dma_kernel(const float *__rest
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
                 const int m = c * 16 + s * 4;  // + q
-                float fa[4], fb[4];
+                float fa[NI], fb[NJ];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) fa[i] = Yc[m * 128 + fy[i]];
+                for (int i = 0; i < NI; ++i) fa[i] = Yc[m * 128 + fy[i]];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) fb[j] = Xc[m * 128 + fx[j]];
+                for (int j = 0; j < NJ; ++j) fb[j] = Xc[m * 128 + fx[j]];
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
+                for (int i = 0; i < NI; ++i)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) acc[i][j] = MFMA16(fa[i], fb[j], acc[i][j]);
+                    for (int j = 0; j < NJ; ++j) acc[i][j] = MFMA16(fa[i], fb[j], acc[i][j]);
             }
         }
         __builtin_amdgcn_sched_barrier(0);  // keep the MFMAs above the wait: they are what hides the DMA latency
@@ -510,12 +611,12 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_dma_kernel(const float *__rest
         const int lcol = ((tid & 31) ^ ((zr & 3) << 2)) * 4;  // the logical columns this thread's physical chunk holds
         *reinterpret_cast<f32x4 *>(&red[zr * 128 + lcol]) = bs4;
         __syncthreads();
-        if (tid < 128 && (n0 + tid) < out) {
+        if (tid < BNT && (n0 + tid) < out) {
             float sum = 0.f;
 #pragma unroll
             for (int r = 0; r < 8; ++r) sum += red[r * 128 + tid];
             // column sums of this split: partial_db[split][n tile][128], behind the tile partials
-            partial[(size_t)gridDim.z * gridDim.y * gridDim.x * (128 * 128) + ((size_t)bz * gridDim.x + bx) * 128 + tid] = sum;
+            partial[(size_t)gridDim.z * gridDim.y * gridDim.x * TILE_F + ((size_t)bz * gridDim.x + bx) * 128 + tid] = sum;
         }
     }
     // The partial-tile stores are the LAST instructions of the wave: 16-byte buffer stores whose data registers are written
@@ -523,25 +624,28 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_dma_kernel(const float *__rest
     // accumulators are never touched after them.
     {
         const size_t tile_id = (size_t)bz * (gridDim.x * gridDim.y) + (size_t)by * gridDim.x + bx;
-        const __amdgpu_buffer_rsrc_t p_rs = make_rsrc(partial + tile_id * (128 * 128), 128 * 128 * 4);
+        const __amdgpu_buffer_rsrc_t p_rs = make_rsrc(partial + tile_id * TILE_F, TILE_F * 4);
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < NI; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) stb(p_rs, (unsigned)tid * 16, (unsigned)(i * 4 + j) * 4096, acc[i][j]);
+            for (int j = 0; j < NJ; ++j) stb(p_rs, (unsigned)tid * 16, (unsigned)(i * NJ + j) * 4096, acc[i][j]);
     }
 }
 
 // Sums the partial tiles of gemm_tn_dma_kernel over the splits and adds the result into dW[out][in].
 // Block = 64 consecutive 16-byte elements of one tile x 4 split lanes (one wave each: 1 KiB coalesced per load, 8 loads
 // in flight); the four partial sums meet in LDS.  The final add is an atomic only so that launches of different
-// minibatches that share dW stay safe; there is exactly one per element and launch.
+// minibatches that share dW stay safe; there is exactly one per element and launch.  geo: the producing kernel's tile
+// geometry (a tile is geo.ni * geo.nj * 256 such elements: gridDim.x = geo.ni * geo.nj * 4 blocks per tile).
 __global__ __launch_bounds__(256) void tn_reduce_kernel(const float *__restrict__ partial, int splits, int tiles_x, int tiles,
-                                                        float *__restrict__ dW, float *__restrict__ db, int out, int in) {
+                                                        float *__restrict__ dW, float *__restrict__ db, int out, int in,
+                                                        TnGeom geo) {
     __shared__ __attribute__((aligned(16))) float red[3][64][4];
     const int tile = blockIdx.y, e64 = threadIdx.x & 63, sl = threadIdx.x >> 6;
-    const int elem4 = blockIdx.x * 64 + e64;  // 16-byte element of the tile: (i*4+j)*256 + tid
-    const f32x4 *base = reinterpret_cast<const f32x4 *>(partial) + (size_t)tile * 4096 + elem4;
-    const size_t stride = (size_t)tiles * 4096;
+    const int elem4 = blockIdx.x * 64 + e64;  // 16-byte element of the tile: (i*NJ+j)*256 + tid
+    const int tile4 = geo.tile_floats() / 4;
+    const f32x4 *base = reinterpret_cast<const f32x4 *>(partial) + (size_t)tile * tile4 + elem4;
+    const size_t stride = (size_t)tiles * tile4;
     f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
     int sp = sl;
     for (; sp + 28 < splits; sp += 32) {
@@ -556,39 +660,44 @@ __global__ __launch_bounds__(256) void tn_reduce_kernel(const float *__restrict_
     // bias gradient (one block per n tile): 128 columns x 2 halves of the splits, 16 loads in flight per thread, every
     // partial combined in a fixed order
     __shared__ float dbh[128];
-    const bool db_block = db && blockIdx.x == 63 && tile < tiles_x;
+    const int bnt = geo.bnt(), bkx = geo.bkx();
+    const bool db_block = db && blockIdx.x == gridDim.x - 1 && tile < tiles_x;
     float sdb = 0.f;
     if (db_block) {
         const int c = threadIdx.x & 127, half = threadIdx.x >> 7;
-        const float *pdb = partial + (size_t)splits * tiles * (128 * 128) + (size_t)tile * 128 + c;
+        const float *pdb = partial + (size_t)splits * tiles * geo.tile_floats() + (size_t)tile * 128 + c;
         const size_t dstride = (size_t)tiles_x * 128;
         const int s_lo = half ? (splits + 1) / 2 : 0, s_hi = half ? splits : (splits + 1) / 2;
         float a16[16];
 #pragma unroll
         for (int u = 0; u < 16; ++u) a16[u] = 0.f;
         int s2 = s_lo;
-        for (; s2 + 15 < s_hi; s2 += 16) {
-            float v[16];
+        if (c < bnt) {  // (columns past the tile's width were never written)
+            for (; s2 + 15 < s_hi; s2 += 16) {
+                float v[16];
 #pragma unroll
-            for (int u = 0; u < 16; ++u) v[u] = pdb[(size_t)(s2 + u) * dstride];
+                for (int u = 0; u < 16; ++u) v[u] = pdb[(size_t)(s2 + u) * dstride];
 #pragma unroll
-            for (int u = 0; u < 16; ++u) a16[u] += v[u];
+                for (int u = 0; u < 16; ++u) a16[u] += v[u];
+            }
+            for (int u = 0; s2 < s_hi; ++s2, ++u) a16[u] += pdb[(size_t)s2 * dstride];
         }
-        for (int u = 0; s2 < s_hi; ++s2, ++u) a16[u] += pdb[(size_t)s2 * dstride];
 #pragma unroll
         for (int u = 0; u < 16; ++u) sdb += a16[u];
         if (half) dbh[c] = sdb;
     }
     __syncthreads();
-    if (db_block && threadIdx.x < 128 && tile * 128 + (int)threadIdx.x < out) atomicAdd(db + tile * 128 + threadIdx.x, sdb + dbh[threadIdx.x]);
+    if (db_block && threadIdx.x < bnt && tile * bnt + (int)threadIdx.x < out)
+        atomicAdd(db + tile * bnt + threadIdx.x, sdb + dbh[threadIdx.x]);
     if (sl > 0) return;
 #pragma unroll
     for (int r = 0; r < 3; ++r) acc += *reinterpret_cast<const f32x4 *>(&red[r][e64][0]);
     const int ij = elem4 >> 8, t = elem4 & 255;
-    const int i = ij >> 2, j = ij & 3, wave = t >> 6, lane = t & 63;
-    const int n0 = (tile % tiles_x) * 128, k0 = (tile / tiles_x) * 128;
-    const int k = k0 + (wave & 1) * 64 + j * 16 + (lane & 15);
-    const int nb = n0 + (wave >> 1) * 64 + i * 16 + (lane >> 4) * 4;
+    const int i = ij / geo.nj, j = ij % geo.nj, wave = t >> 6, lane = t & 63;
+    const int wkc = 4 / geo.wn, wn = wave / wkc, wk = wave % wkc;
+    const int n0 = (tile % tiles_x) * bnt, k0 = (tile / tiles_x) * bkx;
+    const int k = k0 + (wk * geo.nj + j) * 16 + (lane & 15);
+    const int nb = n0 + (wn * geo.ni + i) * 16 + (lane >> 4) * 4;
     if (k < in) {
 #pragma unroll
         for (int e = 0; e < 4; ++e)
@@ -597,8 +706,7 @@ __global__ __launch_bounds__(256) void tn_reduce_kernel(const float *__restrict_
 }
 
 // rows per workgroup: no atomic traffic to trade against, so simply two workgroups per CU
-int64_t tn_partial_rows(int out, int in, int64_t M) {
-    const int64_t tiles = cdiv(out, 128) * cdiv(in, 128);
+static int64_t tn_rows_for(int64_t tiles, int64_t M) {
     int64_t rows = tiles >= 2 ? 512 : 256;
     if (M < 64 * rows) rows = round_up(cdiv(M, 64) > 32 ? cdiv(M, 64) : 32, 32);
     // large M (fused minibatches): one round of workgroups (2 per CU) instead of more and more splits -- fewer partial tiles
@@ -607,21 +715,36 @@ int64_t tn_partial_rows(int out, int in, int64_t M) {
     const int64_t few = round_up(cdiv(M * tiles, 512), 32);
     return few > rows ? few : rows;
 }
+int64_t tn_partial_rows(int out, int in, int64_t M) {  // the 128 x 128-tile forms (the bf16 kernel's partials are always that)
+    return tn_rows_for(cdiv(out, 128) * cdiv(in, 128), M);
+}
 
 size_t tn_partial_floats(int out, int in, int64_t M) {
     if (M <= 0) return 0;
+    // the fp32 kernel's geometry for this shape ...
+    const TnGeom g = tn_geometry(out, in);
+    const size_t tx = (size_t)cdiv(out, g.bnt()), ty = (size_t)cdiv(in, g.bkx());
+    const size_t sp = (size_t)cdiv(M, tn_rows_for((int64_t)(tx * ty), M));
+    size_t need = sp * tx * ty * (size_t)g.tile_floats() + sp * tx * 128;  // tiles + db
+    // ... and the bf16 kernels' 128 x 128 partials (the wide form may split finer): size for whichever needs more
     size_t splits = (size_t)cdiv(M, tn_partial_rows(out, in, M));
     const int pout = (int)round_up(out, 128), pin = (int)round_up(in, 128);
-    if (pout % 256 == 0 && pin % 256 == 0) {  // the wide bf16 form may split finer: size for whichever form splits more
+    if (pout % 256 == 0 && pin % 256 == 0) {
         const size_t w = (size_t)cdiv(M, tn_partial_rows_wide(pout, pin, M));
         splits = w > splits ? w : splits;
     }
-    return splits * (size_t)(cdiv(out, 128) * cdiv(in, 128)) * (128 * 128) + splits * (size_t)cdiv(out, 128) * 128;  // tiles + db
+    const size_t b16 = splits * (size_t)(cdiv(out, 128) * cdiv(in, 128)) * (128 * 128) + splits * (size_t)cdiv(out, 128) * 128;
+    return need > b16 ? need : b16;
 }
 
-// dW[out][in] += dY^T . X, db[out] += colsum(dY) through partial tiles in `ws` (>= tn_partial_floats floats) + a reduction
+// dW[out][in] += dY^T . X, db[out] += colsum(dY) through partial tiles in `ws` (>= tn_partial_floats floats) + a reduction.
+// rowtab != nullptr: sample m of the contraction is X[rowtab[m]] of a `src_rows`-row matrix (the fused minibatch gather).
+// red_st != nullptr: the reduction runs on that stream behind `ev` (recorded here on `st`), i.e. beside whatever `st` launches
+// next -- `ws` must then stay untouched until red_st has run it.
+bool tn_gather_ok(int64_t ldx, int64_t src_rows) { return ldx * 4 < 16384 && ldx % 4 == 0 && src_rows > 0 && src_rows < ((int64_t)1 << 32); }
 int launch_gemm_tn(hipStream_t st, const float *dY, int64_t ldy, int ny_valid, const float *X, int64_t ldx, int kx_valid,
-                   float *dW, float *db, int out, int in, int64_t M, float *ws, size_t ws_floats) {
+                   float *dW, float *db, int out, int in, int64_t M, float *ws, size_t ws_floats, const unsigned *rowtab,
+                   int64_t src_rows, hipStream_t red_st, hipEvent_t ev) {
     if (M <= 0) return 0;
     RLPPO_CHECK_ARG(ny_valid % 4 == 0 && kx_valid % 4 == 0 && ldy % 4 == 0 && ldx % 4 == 0 && ny_valid <= ldy &&
                         kx_valid <= ldx && out <= ny_valid && in <= kx_valid,
@@ -631,20 +754,40 @@ int launch_gemm_tn(hipStream_t st, const float *dY, int64_t ldy, int ny_valid, c
         set_error("gemm_tn: workspace %zu < %zu floats", ws ? ws_floats : (size_t)0, tn_partial_floats(out, in, M));
         return RLPPO_ERR_WORKSPACE;
     }
-    const int rows_per_wg = (int)tn_partial_rows(out, in, M);
+    const TnGeom g = tn_geometry(out, in);
+    const int tiles_x = (int)cdiv(out, g.bnt()), tiles_y = (int)cdiv(in, g.bkx());
+    const int rows_per_wg = (int)tn_rows_for((int64_t)tiles_x * tiles_y, M);
+    const int splits = (int)cdiv(M, rows_per_wg);
     const int64_t lim = (int64_t)1 << 30;
-    RLPPO_CHECK_ARG((rows_per_wg + TM) * ldy * 4 < lim && (rows_per_wg + TM) * ldx * 4 < lim,
+    RLPPO_CHECK_ARG((rows_per_wg + TM) * ldy * 4 < lim && (rowtab || (rows_per_wg + TM) * ldx * 4 < lim),
                     "gemm_tn: a leading dimension is too wide for 32-bit tile offsets");
-    const int tiles_x = (int)cdiv(out, 128), tiles_y = (int)cdiv(in, 128), splits = (int)cdiv(M, rows_per_wg);
+    RLPPO_CHECK_ARG(!rowtab || tn_gather_ok(ldx, src_rows), "gemm_tn (gathered rows): unsupported row stride %ld", (long)ldx);
     dim3 grid((unsigned)tiles_x, (unsigned)tiles_y, (unsigned)splits);
-    hipLaunchKernelGGL((gemm_tn_dma_kernel<TM>), grid, dim3(256), 0, st, dY, (unsigned)(ldy * 4), ny_valid, X,
-                       (unsigned)(ldx * 4), kx_valid, db != nullptr, out, in, M, rows_per_wg, ws);
+#define TN(NI_, NJ_, WN_, G_)                                                                                              \
+    hipLaunchKernelGGL((gemm_tn_dma_kernel<TM, NI_, NJ_, WN_, G_>), grid, dim3(256), 0, st, dY, (unsigned)(ldy * 4), ny_valid, X, \
+                       (unsigned)(ldx * 4), kx_valid, db != nullptr, out, in, M, rows_per_wg, ws, rowtab, (unsigned)src_rows)
+    if (g.nj == 7) {
+        if (rowtab) TN(2, 7, 4, true); else TN(2, 7, 4, false);
+    } else if (g.ni == 3) {
+        RLPPO_CHECK_ARG(!rowtab, "gemm_tn (gathered rows): the 96-row tile has no gathered form");
+        TN(3, 4, 2, false);
+    } else {
+        if (rowtab) TN(4, 4, 2, true); else TN(4, 4, 2, false);
+    }
+#undef TN
     RLPPO_LAUNCH_CHECK();
-    return launch_tn_reduce(st, ws, splits, tiles_x, tiles_y, dW, db, out, in);
+    if (red_st && red_st != st) {
+        RLPPO_HIP(hipEventRecord(ev, st));
+        RLPPO_HIP(hipStreamWaitEvent(red_st, ev, 0));
+    } else {
+        red_st = st;
+    }
+    return launch_tn_reduce(red_st, ws, splits, tiles_x, tiles_y, dW, db, out, in, g.ni, g.nj, g.wn);
 }
-int launch_tn_reduce(hipStream_t st, const float *partial, int splits, int tiles_x, int tiles_y, float *dW, float *db, int out, int in) {
-    hipLaunchKernelGGL(tn_reduce_kernel, dim3(64, (unsigned)(tiles_x * tiles_y)), dim3(256), 0, st, partial, splits, tiles_x,
-                       tiles_x * tiles_y, dW, db, out, in);
+int launch_tn_reduce(hipStream_t st, const float *partial, int splits, int tiles_x, int tiles_y, float *dW, float *db, int out, int in,
+                     int ni, int nj, int wn) {
+    hipLaunchKernelGGL(tn_reduce_kernel, dim3((unsigned)(ni * nj * 4), (unsigned)(tiles_x * tiles_y)), dim3(256), 0, st, partial, splits,
+                       tiles_x, tiles_x * tiles_y, dW, db, out, in, TnGeom{ni, nj, wn});
     RLPPO_LAUNCH_CHECK();
     return 0;
 }

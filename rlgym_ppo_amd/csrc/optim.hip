@@ -233,10 +233,11 @@ __global__ __launch_bounds__(256) void gather_meta_kernel(const int64_t *__restr
                                                           const float *__restrict__ adv, const float *__restrict__ targets,
                                                           float *__restrict__ g_act, float *__restrict__ g_old,
                                                           float *__restrict__ g_adv, float *__restrict__ g_tgt, int64_t n,
-                                                          int64_t ring_base, int64_t ring_cap) {
+                                                          int64_t ring_base, int64_t ring_cap, unsigned *__restrict__ rowtab) {
     const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (r >= n) return;
     const int64_t src = ring_row(idx[r], ring_base, ring_cap);
+    if (rowtab) rowtab[r] = (unsigned)src;  // [r3] the row table of the fused state gather (gemm.hip, GATHER)
     g_old[r] = old_logp[src];
     g_adv[r] = adv[src];
     g_tgt[r] = targets[src];
@@ -245,10 +246,10 @@ __global__ __launch_bounds__(256) void gather_meta_kernel(const int64_t *__restr
 
 int launch_gather_meta(hipStream_t st, const int64_t *idx, const float *actions, int act_dim, const float *old_logp,
                        const float *adv, const float *targets, float *g_act, float *g_old, float *g_adv, float *g_tgt, int64_t n,
-                       int64_t ring_base, int64_t ring_cap) {
+                       int64_t ring_base, int64_t ring_cap, unsigned *rowtab) {
     if (n <= 0) return 0;
     hipLaunchKernelGGL(gather_meta_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st, idx, actions, act_dim, old_logp, adv,
-                       targets, g_act, g_old, g_adv, g_tgt, n, ring_base, ring_cap);
+                       targets, g_act, g_old, g_adv, g_tgt, n, ring_base, ring_cap, rowtab);
     RLPPO_LAUNCH_CHECK();
     return 0;
 }
@@ -482,6 +483,99 @@ __global__ __launch_bounds__(256) void adam_pack2_kernel(OptPair o) {
     }
 }
 
+// ---- the same update in ONE launch: squared norms -> grid barrier -> clip + Adam + re-pack + zero_grad.
+// The two-launch form above costs, per optimiser step of an 8-rank job (profiles/r03_rank_share_trace.txt): a 6 us fill of the two
+// accumulators, 19 us for sqnorm2 (2048 workgroups queueing on two double-precision atomics) and 9 us for adam_pack2, each behind
+// a launch boundary with the chip idle -- ~45 us of a 1.2 ms step in which no GEMM can run.  Here 2 x FUSED_BLOCKS workgroups (all
+// co-resident: one per CU or fewer) add their partial sums to an accumulator in the caller's 64-byte sync block, meet at a
+// sense-reversal barrier (arrival counter + generation word, agent-scope atomics: cdna_hip_programming.md Guideline 16), and go
+// on to Adam.  The LAST arriver publishes both totals to the nets' gnorm2 outputs and re-arms the accumulators and the counter,
+// so the block needs no per-launch memset: it is zeroed ONCE by its owner and every completed launch leaves it armed.  The spin
+// is bounded; a wait that gives up counts itself in the block's timeout word and poisons that net's step with NaN (loud:
+// PPOLearner.learn reads the word back with its report and raises).
+struct FusedSync {
+    double acc[2];
+    unsigned count, gen, timeouts, pad;
+};
+constexpr int FUSED_BLOCKS = 128;            // per net; 2 x 128 workgroups of 256 threads are always co-resident on 256 CUs
+constexpr unsigned FUSED_SPIN_LIMIT = 1u << 24;  // x (s_sleep + one L2 round trip) ~ seconds
+
+__global__ __launch_bounds__(256) void adam_fused_kernel(OptPair o, FusedSync *__restrict__ sy) {
+    const int k = blockIdx.y;
+    const OptNet &N = o.net[k];
+    const unsigned nblocks = gridDim.x * gridDim.y;
+    // ---- phase 1: this workgroup's share of ||g||^2, in double (as sqnorm2_kernel)
+    double acc = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < N.n; i += (int64_t)gridDim.x * 256) {
+        const double v = (double)N.g[i];
+        acc += v * v;
+    }
+#pragma unroll
+    for (int s = 32; s > 0; s >>= 1) acc += __shfl_xor(acc, s);
+    __shared__ double red[4];
+    __shared__ float s_total;
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned g0 = __hip_atomic_load(&sy->gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // read BEFORE arriving
+        __hip_atomic_fetch_add(&sy->acc[k], red[0] + red[1] + red[2] + red[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // arrival: the release half orders our accumulator add before the count, the acquire half lets the last arriver see
+        // everybody's adds (all of them are agent-scope atomics executed at the memory side: no cached copies involved)
+        const unsigned old = __hip_atomic_fetch_add(&sy->count, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        bool ok = true;
+        if (old == nblocks - 1) {
+            for (int j = 0; j < 2; ++j) {
+                const double t = __hip_atomic_load(&sy->acc[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(o.net[j].gnorm2, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&sy->acc[j], 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            __hip_atomic_store(&sy->count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_add(&sy->gen, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);  // opens the barrier
+        } else {
+            unsigned spins = 0;
+            while (__hip_atomic_load(&sy->gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == g0) {
+                __builtin_amdgcn_s_sleep(2);
+                if (++spins > FUSED_SPIN_LIMIT) {
+                    __hip_atomic_fetch_add(&sy->timeouts, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    ok = false;
+                    break;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+        const double t = __hip_atomic_load(N.gnorm2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_total = ok ? (float)sqrt(t) : __builtin_nanf("");
+    }
+    __syncthreads();
+    // ---- phase 2: adam_pack2_kernel, element for element
+    const float total = s_total;
+    float coef = N.max_norm / (total + 1e-6f);
+    coef = coef > 1.f ? 1.f : coef;   // (a NaN total stays NaN: a timed-out barrier must not pass for an update)
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < N.n; i += (int64_t)gridDim.x * 256) {
+        const float gi = N.g[i] * coef;
+        float mi = N.m[i], vi = N.v[i];
+        mi = mi + N.omb1 * (gi - mi);
+        vi = vi * N.beta2 + (N.omb2 * gi) * gi;
+        const float denom = sqrtf(vi) / N.bc2_sqrt + N.eps;
+        const float pi = N.p[i] + (-N.step_size * mi) / denom;
+        N.p[i] = pi;
+        N.m[i] = mi;
+        N.v[i] = vi;
+        N.g[i] = 0.f;
+        int l = 0;
+        while (l + 1 < N.jobs.n && i >= N.jobs.j[l + 1].off_flat_w) ++l;
+        const PackJob &J = N.jobs.j[l];
+        if (i < J.off_flat_b) {
+            const int64_t e = i - J.off_flat_w;
+            const int r = (int)(e / J.in), c = (int)(e % J.in);
+            N.packed[J.off_w + (int64_t)r * J.pin + c] = pi;
+            N.packed[J.off_wt + (int64_t)c * J.pout + r] = pi;
+        } else {
+            N.packed[J.off_b + (i - J.off_flat_b)] = pi;
+        }
+    }
+}
+
 static void fill_jobs(const NetLayout &net, PackJobs *jobs) {
     jobs->n = net.n_layers;
     int64_t tot = 0;
@@ -496,7 +590,7 @@ static void fill_jobs(const NetLayout &net, PackJobs *jobs) {
 int launch_clip_adam_pack2(hipStream_t st, const NetLayout *nets, float *const *p, float *const *g, float *const *m, float *const *v,
                            float *const *packed, double *const *gnorm2, const int64_t *n, const float *max_norm,
                            const float *step_size, const float *bc2_sqrt, const float *omb1, const float *beta2, const float *omb2,
-                           const float *eps) {
+                           const float *eps, void *sync_ws) {
     OptPair o;
     int64_t nmax = 0;
     for (int k = 0; k < 2; ++k) {
@@ -506,6 +600,12 @@ int launch_clip_adam_pack2(hipStream_t st, const NetLayout *nets, float *const *
         N.omb2 = omb2[k]; N.eps = eps[k];
         fill_jobs(nets[k], &N.jobs);
         nmax = n[k] > nmax ? n[k] : nmax;
+    }
+    if (sync_ws) {  // one launch (the caller owns a zero-initialised 64-byte sync block)
+        RLPPO_CHECK_ARG(((uintptr_t)sync_ws & 15) == 0, "clip_adam_pack2: the sync block must be 16-byte aligned");
+        hipLaunchKernelGGL(adam_fused_kernel, dim3(FUSED_BLOCKS, 2), dim3(256), 0, st, o, reinterpret_cast<FusedSync *>(sync_ws));
+        RLPPO_LAUNCH_CHECK();
+        return 0;
     }
     if (gnorm2[1] == gnorm2[0] + 1 || gnorm2[0] == gnorm2[1] + 1) {  // adjacent accumulators (PPOLearner's): one fill
         RLPPO_HIP(hipMemsetAsync(gnorm2[0] < gnorm2[1] ? gnorm2[0] : gnorm2[1], 0, 2 * sizeof(double), st));

@@ -409,20 +409,32 @@ class HostExponential:
         import os
         self.lookahead = os.environ.get("RLPPO_NOISE_LOOKAHEAD", "1") != "0"
         self.threads = max(1, min(8, (os.cpu_count() or 2) // 2))  # an upper bound: the library uses one thread per 2^20 elements (0.35 ms per rollout-step draw)
-        self._buf = {}       # numel -> list of pinned float32 vectors
-        self._turn = 0
-        self._pending = None  # dict(shape, state_in, future -> state_out, buf)
+        self._buf = {}       # numel -> dict(ring=[pinned float32 vectors], uploaded=[event or None], turn)
+        self._pending = None  # dict(shape, state_in, future -> state_out, buf, slot)
         self.hits = self.misses = 0
+        self.checked = False  # the one-time self-check against torch's own exponential_ (see _self_check)
+        self.trusted = True
 
     def _buffer(self, numel):
-        ring = self._buf.get(numel)
-        if ring is None:
+        """Next pinned vector of the ring for this size, as (ring record, slot).  A slot whose last hand-out was uploaded with
+        an asynchronous copy (upload()) is reused only after that copy has run: the helper thread writes into it next."""
+        rec = self._buf.get(numel)
+        if rec is None:
             pin = torch.cuda.is_available()
-            ring = self._buf[numel] = [torch.empty(numel, dtype=torch.float32, pin_memory=pin) for _ in range(self.RING)]
-            if len(self._buf) > 8:  # shapes come and go (worker counts change): keep the cache small
-                self._buf.pop(next(iter(self._buf)))
-        self._turn = (self._turn + 1) % self.RING
-        return ring[self._turn]
+            rec = self._buf[numel] = dict(ring=[torch.empty(numel, dtype=torch.float32, pin_memory=pin) for _ in range(self.RING)],
+                                          uploaded=[None] * self.RING, turn=0)
+            if len(self._buf) > 8:  # shapes come and go (worker counts change): keep the cache small -- but never the ring a
+                busy = self._pending["numel"] if self._pending is not None else None  # pending speculation is writing into
+                for key in list(self._buf):
+                    if key != numel and key != busy:
+                        self._buf.pop(key)
+                        break
+        rec["turn"] = slot = (rec["turn"] + 1) % self.RING
+        ev = rec["uploaded"][slot]
+        if ev is not None:
+            ev.synchronize()
+            rec["uploaded"][slot] = None
+        return rec, slot
 
     def _draw_into(self, state, buf, numel):
         """state: uint8 tensor (a private copy of a generator state), advanced in place."""
@@ -430,48 +442,87 @@ class HostExponential:
                                                     ctypes.c_void_p(buf.data_ptr()), self.threads))
         return state
 
+    def _self_check(self):
+        """Once per process: 4096 values drawn both ways from the same generator state must agree bit for bit, values AND the
+        state the generator is left in.  rlppo_torch_cpu_exponential restates the CPU path of THIS torch build; on
+        another build (a changed transform, a vectorised CPU kernel) the stream could differ silently and a seeded run would no
+        longer pick the reference's actions -- then torch's own exponential_ is used (slower, always right) and a warning says so."""
+        self.checked = True
+        keep = torch.get_rng_state()
+        try:
+            want = torch.empty(4096).exponential_(1)
+            after_torch = torch.get_rng_state()
+            got = torch.empty(4096)
+            after_lib = self._draw_into(keep.clone(), got, 4096)
+            self.trusted = bool(torch.equal(want, got) and torch.equal(after_torch, after_lib))
+        except Exception:  # noqa: BLE001 -- e.g. an unexpected generator state size
+            self.trusted = False
+        finally:
+            torch.set_rng_state(keep)
+        if not self.trusted:
+            import warnings
+            warnings.warn("rlgym_ppo_amd: librlppo's host exponential_ does not reproduce this torch build's CPU stream; "
+                          "falling back to torch.empty(shape).exponential_(1) for the rollout noise (slower, same results)")
+
     def _speculate(self, shape, numel, state_in):
-        buf = self._buffer(numel)
+        rec, slot = self._buffer(numel)
+        buf = rec["ring"][slot]
         st = state_in.clone()
         fut = _pool("noise", 1).submit(self._draw_into, st, buf, numel)
-        self._pending = dict(shape=tuple(shape), state_in=state_in, future=fut, buf=buf)
+        self._pending = dict(shape=tuple(shape), numel=numel, state_in=state_in, future=fut, buf=buf, rec=rec, slot=slot)
 
-    def draw(self, shape):
+    def draw(self, shape, device=None):
+        """Exp(1) noise of `shape`: a view of a pinned ring buffer, or -- with `device` -- its asynchronous upload on the current
+        stream (the ring slot is then protected by an event until the copy has run)."""
         shape = tuple(int(x) for x in shape)
         numel = 1
         for x in shape:
             numel *= x
         if numel == 0:
-            return torch.empty(shape)
+            return torch.empty(shape, device=device)
+        if not self.checked:
+            self._self_check()
+        if not self.trusted:
+            out = torch.empty(shape).exponential_(1)
+            return out if device is None else out.to(device)
         state = torch.get_rng_state()
         p, self._pending = self._pending, None
         if p is not None and p["shape"] == shape and torch.equal(p["state_in"], state):
             after = p["future"].result()
-            buf = p["buf"]
+            buf, rec, slot = p["buf"], p["rec"], p["slot"]
             self.hits += 1
         else:
             if p is not None:
                 p["future"].result()  # let the helper finish before its buffer can be handed out again
-            buf = self._buffer(numel)
+            rec, slot = self._buffer(numel)
+            buf = rec["ring"][slot]
             after = self._draw_into(state.clone(), buf, numel)
             self.misses += 1
         torch.set_rng_state(after)
+        out = buf.view(shape)
+        if device is not None and torch.device(device).type == "cuda":
+            out = out.to(device, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(out.device))
+            rec["uploaded"][slot] = ev
         if self.lookahead:
             self._speculate(shape, numel, after)
-        return buf.view(shape)
+        return out
 
 
 _HOST_EXP = None
 
 
-def host_exponential(shape):
+def host_exponential(shape, device=None):
     """Exp(1) noise of `shape` from torch's global CPU generator (values and generator advance identical to
-    torch.empty(shape).exponential_(1)); the returned tensor is a view of a recycled pinned buffer -- upload or copy it before
-    the next-but-one call."""
+    torch.empty(shape).exponential_(1)).  device=None: a view of a recycled pinned buffer -- consume it (copy it synchronously)
+    before the next-but-one call.  device=cuda: the noise uploaded on the current stream with an asynchronous copy; the pinned
+    slot is not rewritten until that copy has run (an event per ring slot), so callers may keep the rollout on the device without a
+    host synchronisation per step."""
     global _HOST_EXP
     if _HOST_EXP is None:
         _HOST_EXP = HostExponential()
-    return _HOST_EXP.draw(shape)
+    return _HOST_EXP.draw(shape, device)
 
 
 def selection_epoch():

@@ -77,8 +77,8 @@ class DiscreteFF(ArenaModule):
         n = rows.shape[0]
         if noise is None and self.noise_mode == "device":
             noise = torch.empty(n, self.n_actions, device=a.device).exponential_(1)  # fast mode: torch's HIP generator, not the reference's CPU stream
-        elif noise is None:
-            noise = host_exponential((n, self.n_actions))
+        elif noise is None:  # the reference's CPU stream, uploaded asynchronously (the pinned ring slot is event-protected)
+            noise = host_exponential((n, self.n_actions), device=a.device)
         q = torch.as_tensor(noise, dtype=torch.float32).to(a.device, non_blocking=True).contiguous()
         a.ensure_packed()
         actions = torch.empty(n, dtype=torch.int64, device=a.device)

@@ -96,7 +96,7 @@ class ExperienceBuffer(object):
         return torch.as_tensor(np.ascontiguousarray(np.asarray(x, dtype=np.float32))).to(self._dev)
 
     def _pad_states(self, x):
-        if isinstance(x, torch.Tensor) and x.is_cuda and x.dim() == 2 and x.shape[1] % 32 == 0 and self._d is not None \
+        if isinstance(x, torch.Tensor) and x.is_cuda and x.dim() == 2 and self._d is not None \
                 and x.shape[1] == N.lib().rlppo_padded_width(self._d):
             return x  # already padded device rows (Learner.add_new_experience hands them over as such)
         t = self._to_dev(x)

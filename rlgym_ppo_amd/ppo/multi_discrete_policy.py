@@ -62,7 +62,7 @@ class MultiDiscreteFF(ArenaModule):
         if noise is None and self.noise_mode == "device":
             noise = torch.empty(n * 8, 3, device=a.device).exponential_(1)  # fast mode: torch's HIP generator, not the reference's CPU stream
         elif noise is None:
-            noise = host_exponential((n * 8, 3))  # Categorical.sample -> multinomial on [n*8, 3]
+            noise = host_exponential((n * 8, 3), device=a.device)  # Categorical.sample -> multinomial on [n*8, 3]
         q = torch.as_tensor(noise, dtype=torch.float32).to(a.device, non_blocking=True).contiguous()
         a.ensure_packed()
         actions = torch.empty((n, 8), dtype=torch.int64, device=a.device)

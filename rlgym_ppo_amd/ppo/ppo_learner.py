@@ -140,6 +140,8 @@ class PPOLearner(object):
         # both squared-norm accumulators side by side: rlppo_clip_adam_pack2 then clears them with one fill
         self._gnorm2 = torch.zeros(2, dtype=torch.float64, device=self._dev)
         self.policy_optimizer.gnorm2, self.value_optimizer.gnorm2 = self._gnorm2[0:1], self._gnorm2[1:2]
+        # grid-barrier state of the one-launch optimiser tail (include/rlppo.h, RLPPO_OPT_SYNC_BYTES): zeroed once, here
+        self._opt_sync = torch.zeros(N.OPT_SYNC_BYTES // 4, dtype=torch.int32, device=self._dev)
 
         n_pol = sum(p.numel() for p in self.policy.parameters() if p.requires_grad)
         n_val = sum(p.numel() for p in self.value_net.parameters() if p.requires_grad)
@@ -194,7 +196,7 @@ class PPOLearner(object):
             a.pol_packed_r, a.val_packed_r, a.pol_wb16, a.val_wb16 = pr.data_ptr(), vr.data_ptr(), pw.data_ptr(), vw.data_ptr()
         a.pol_grad, a.val_grad = pa.grad.data_ptr(), va.grad.data_ptr()
         st, a.ring_base, a.ring_cap = exp.ring()  # physical rows; the kernels map the permutation's logical rows onto them
-        a.states, a.ld_states = st["states"].data_ptr(), st["states"].shape[1]
+        a.states, a.ld_states, a.n_rows = st["states"].data_ptr(), st["states"].shape[1], st["states"].shape[0]
         a.actions = st["actions"].data_ptr()
         a.old_logp = st["log_probs"].data_ptr()
         a.targets = st["values"].data_ptr()
@@ -273,7 +275,7 @@ class PPOLearner(object):
                         # operations instead of 9 (csrc/optim.hip)
                         dv = self.value_optimizer.fused_descriptor(MAX_GRAD_NORM)
                         dp_ = self.policy_optimizer.fused_descriptor(MAX_GRAD_NORM)
-                        N.check(L.rlppo_clip_adam_pack2(st, ctypes.byref(dv), ctypes.byref(dp_)))
+                        N.check(L.rlppo_clip_adam_pack2(st, ctypes.byref(dv), ctypes.byref(dp_), ptr(self._opt_sync)))
                         va.mark_repacked()
                         pa.mark_repacked()
                         grads_zero = True
@@ -291,7 +293,10 @@ class PPOLearner(object):
         all_reduce_sum(self._stats, dist)
         # update magnitudes (ppo_learner.py:214-222: fp32 norms) travel with the statistics: ONE device->host sync per learn()
         mags = torch.stack(((policy_before - pa.flat).norm(), (critic_before - va.flat).norm()))
-        stats = torch.cat((self._stats, mags.double())).cpu().numpy()
+        stats = torch.cat((self._stats, mags.double(), self._opt_sync[6:7].double())).cpu().numpy()
+        if stats[N.N_STATS + 2] != 0:  # a barrier wait of the fused optimiser step gave up: that step wrote NaN parameters
+            raise RuntimeError("rlppo_clip_adam_pack2: %d grid-barrier wait(s) timed out; the parameters of the affected "
+                               "network are NaN (GPU shared with a kernel that never yields, or a defect)" % int(stats[N.N_STATS + 2]))
         elapsed = time.time() - t1
         n_iter_r = max(n_iterations, 1)
         n_mb_r = max(float(stats[N.STAT_PASSES]), 1.0)

@@ -23,9 +23,21 @@ def _workspace(device, nbytes):
     return _ws[key].get(nbytes)
 
 
-def gae_device(rews, dones, truncated, values, gamma=0.99, lmbda=0.95, return_std=1):
+class GAETimeout(RuntimeError):
+    """A look-back wait of rlppo_gae gave up: the affected advantages / value targets / returns are NaN (include/rlppo.h)."""
+
+
+def gae_device(rews, dones, truncated, values, gamma=0.99, lmbda=0.95, return_std=1, check=True):
     """All inputs fp32 device tensors (values has N+1 entries).  Returns (value_targets, advantages, returns) as
-    fp32 device tensors.  return_std=None disables reward scaling (torch_functions.py:62-65)."""
+    fp32 device tensors.  return_std=None disables reward scaling (torch_functions.py:62-65).
+
+    `check` (default on): the single-launch scan resolves a chunk's carry by waiting, with a bound, on records other
+    workgroups publish; if a wait ever gives up the kernel poisons that chunk's outputs with NaN and counts the event in the
+    workspace header.  That must never reach the buffer silently (NaN advantages -> Adam -> the weights are gone), so the
+    counter is cleared before the launch and read back after it -- one 4-byte read-back, the only synchronisation of this
+    call -- and a non-zero count raises GAETimeout for EVERY caller (compute_gae, Learner.add_new_experience, user code),
+    whatever part of the outputs the caller looks at.  check=False leaves the call asynchronous (timing loops; under stream
+    capture, where the stateless two-launch form runs and no wait exists, the check is skipped by itself)."""
     n = rews.shape[0]
     dev = rews.device
     assert values.shape[0] == n + 1 and dones.shape[0] == n and truncated.shape[0] == n
@@ -36,8 +48,17 @@ def gae_device(rews, dones, truncated, values, gamma=0.99, lmbda=0.95, return_st
         return vt, adv, ret
     std = float("nan") if return_std is None else float(np.float32(return_std))
     ws = _workspace(dev, N.lib().rlppo_gae_workspace_bytes(n))
+    check = check and not torch.cuda.is_current_stream_capturing()
+    hdr = ws[:16].view(torch.int32)
+    if check:
+        hdr.zero_()  # word 1 = look-back waits that timed out (a grown / recycled workspace holds anything)
     N.check(N.lib().rlppo_gae(stream_ptr(), ptr(rews), ptr(dones), ptr(truncated), ptr(values), n, float(gamma),
                               float(lmbda), std, ptr(vt), ptr(adv), ptr(ret), ptr(ws), ws.numel()))
+    if check:
+        timeouts = int(hdr[1].item())
+        if timeouts:
+            raise GAETimeout(f"rlppo_gae: {timeouts} look-back wait(s) timed out; the outputs of the affected chunks are NaN "
+                             f"and must not be trained on (GPU shared with a long-running kernel, or a defect)")
     return vt, adv, ret
 
 

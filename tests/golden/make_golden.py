@@ -419,7 +419,8 @@ def g11_wire(R):
     after every step, its slab of the shared array -- for scripted action sequences (oracle/host.py::drive_worker is the
     scripted learner side).  Two cases: a 2-agent environment without a metrics function, and a one-agent environment with
     rank-1 observations, a scalar reward and a metrics function; both cross episode ends (reset) and a truncation."""
-    sys.path.insert(0, os.path.join(os.path.dirname(HERE)))
+    sys.path.insert(0, os.path.dirname(HERE))                   # tests/: synthetic_env
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))  # the repository root: oracle/
     import synthetic_env
     from oracle import host
     gym = sys.modules["gym"]  # the worker imports gym for its action-space type checks: give the stub the names it reads

@@ -33,13 +33,14 @@ def test_every_declared_symbol_is_exported_and_bound():
 def test_layout_queries_host_only():
     from rlgym_ppo_amd import _native as N
     L = N.lib()
-    assert [L.rlppo_padded_width(d) for d in (1, 32, 33, 107, 231)] == [32, 32, 64, 128, 256]
+    # first-layer contraction: padded to 16 where that saves >= 10 % over 64 (107 -> 112), else to 64 (231 -> 256: bf16 kernels)
+    assert [L.rlppo_padded_width(d) for d in (1, 13, 32, 33, 64, 100, 107, 112, 113, 231, 256)] == [16, 16, 32, 48, 64, 112, 112, 112, 128, 256, 256]
     assert [L.rlppo_padded_out(d) for d in (1, 16, 21, 33, 90, 96, 97, 256, 300)] == [32, 32, 32, 64, 96, 96, 128, 256, 384]
     d = N.dims_array([107, 256, 256, 256, 90])
     assert L.rlppo_flat_floats(d, 4) == 182362                       # cfg2 policy parameter count
     assert L.rlppo_flat_floats(N.dims_array([107, 256, 256, 256, 1]), 4) == 159489
     assert L.rlppo_flat_floats(N.dims_array([231, 512, 512, 512, 512, 16]), 5) == 914960  # cfg5 policy
-    assert L.rlppo_packed_floats(d, 4) == 2 * (256 * 128 + 256 * 256 * 2 + 96 * 256) + 256 * 3 + 96
+    assert L.rlppo_packed_floats(d, 4) == 2 * (256 * 112 + 256 * 256 * 2 + 96 * 256) + 256 * 3 + 96
     assert L.rlppo_flat_floats(N.dims_array([0, 4]), 1) == -1 and b"dims" in L.rlppo_last_error()
     # argument errors come back as codes + message, never as exceptions across the ABI
     assert L.rlppo_net_pack(None, N.dims_array([4, 4]), 99, None, None) == 1001
@@ -263,3 +264,35 @@ def test_host_exponential_is_torch_exponential_bit_for_bit():
     got, s_got = sequence(engine.host_exponential)
     assert all(torch.equal(a, b) for a, b in zip(ref, got)) and torch.equal(s_ref, s_got)
     assert engine._HOST_EXP.hits >= 3 and engine._HOST_EXP.misses >= 4   # both paths were exercised
+
+
+def test_host_exponential_self_check_falls_back_to_torch(monkeypatch):
+    """HostExponential verifies ONCE per process that librlppo's host exponential_ reproduces this torch build's stream (4096
+    values and the generator state); a mismatch (another torch build) must not change the observable stream: torch's own
+    exponential_ serves the draws, with a warning, and the generator ends where torch's would."""
+    import warnings
+    import torch
+    from rlgym_ppo_amd import engine
+    h = engine.HostExponential()
+    torch.manual_seed(11)
+    before = torch.get_rng_state()
+    h._self_check()
+    assert h.trusted and torch.equal(before, torch.get_rng_state())   # the check itself leaves the generator untouched
+
+    bad = engine.HostExponential()
+    real = bad._draw_into
+
+    def skewed(state, buf, numel):   # a library whose stream differs in one value
+        out = real(state, buf, numel)
+        buf[0] += 1.0
+        return out
+    monkeypatch.setattr(bad, "_draw_into", skewed)
+    torch.manual_seed(12)
+    want = [torch.empty(64, 90).exponential_(1) for _ in range(3)]
+    s_want = torch.get_rng_state()
+    torch.manual_seed(12)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        got = [bad.draw((64, 90)).clone() for _ in range(3)]
+    assert not bad.trusted and any("falling back" in str(x.message) for x in w)
+    assert all(torch.equal(a, b) for a, b in zip(want, got)) and torch.equal(s_want, torch.get_rng_state())

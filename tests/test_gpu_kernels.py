@@ -419,6 +419,33 @@ def test_gae_recycled_workspace_and_loud_timeout(L):
         check(L, L.rlppo_dbg_set(21, -1))
 
 
+def test_gae_timeout_raises_through_every_python_caller(L):
+    """A timed-out look-back wait in a chunk k > 0 with a trajectory end to its left leaves the HEAD of the outputs clean, so a
+    caller that looks at returns[:150] alone (round 2's only guard) would train on NaN advantages.  gae_device clears the header's
+    counter before the launch and reads it back after: the failure raises for every caller, whatever it looks at."""
+    from rlgym_ppo_amd.util import torch_functions as TF
+    rews, dones, trunc, values = synth_gae(96, 256, seed=9, p_mid=0.0)
+    dones[:] = 0
+    trunc[:] = 0
+    trunc[-1] = 1
+    dones[2048 + 100] = 1     # a trajectory end at the start of chunk 1: chunk 0 resolves its carry from its own look-ahead
+    args = (dev(rews), dev(dones), dev(trunc), dev(values), 0.99, 0.95, 1.3)
+    vt, adv, ret = TF.gae_device(*args)   # normal run: no exception, outputs right
+    np.testing.assert_allclose(adv.cpu().numpy(), ogae.gae(rews, dones, trunc, values, 0.99, 0.95, 1.3, "f64")[1], rtol=2e-6, atol=2e-6)
+    check(L, L.rlppo_dbg_set(21, 0))
+    try:
+        _, _, ret = TF.gae_device(*args, check=False)
+        r = ret.cpu().numpy()
+        assert not np.isnan(r[:150]).any() and np.isnan(r).any()   # exactly the case the old guard missed
+        with pytest.raises(TF.GAETimeout):
+            TF.gae_device(*args)
+        with pytest.raises(TF.GAETimeout):
+            TF.compute_gae(rews, dones, trunc, values, 0.99, 0.95, 1.3)
+    finally:
+        check(L, L.rlppo_dbg_set(21, -1))
+    TF.gae_device(*args)  # and the next healthy call is clean again (the counter is cleared per call)
+
+
 def test_gae_under_graph_capture_replays_correctly(L):
     """A captured launch would replay a frozen per-launch tag, so rlppo_gae switches to its stateless two-launch form while
     the stream is capturing: replays on NEW inputs give the new outputs."""
@@ -667,7 +694,7 @@ def run_minibatch(L, head, pol, val, obs_all, acts_all, old_all, tgt_all, adv_al
             check(L, L.rlppo_net_pack_bf16(stream(), net.dims_c, net.nl, P(net.flat), P(pr), P(wb)))
             imgs += [pr, wb]
         a.pol_packed_r, a.pol_wb16, a.val_packed_r, a.val_wb16 = (t.data_ptr() for t in imgs)
-    a.states, a.ld_states, a.actions = states.data_ptr(), states.shape[1], acts.data_ptr()
+    a.states, a.ld_states, a.n_rows, a.actions = states.data_ptr(), states.shape[1], states.shape[0], acts.data_ptr()
     a.old_logp, a.targets, a.advantages, a.idx, a.mb = old.data_ptr(), tgt.data_ptr(), adv.data_ptr(), idxd.data_ptr(), mb
     a.clip_range, a.ent_coef, a.mb_ratio = clip, ent, mb_ratio
     a.var_m, a.var_b = nets.var_map(*var)
@@ -728,6 +755,42 @@ def test_minibatch_gather_and_accumulate_cfg2_shape(L):
         got = run_minibatch(L, "discrete", pol, val, obs, act.numpy(), old, tgt, adv, idx, 0.2, 0.005, 0.5)
         fp64_gate.gate(L, "discrete", pol, val, obs[idx], act.numpy()[idx], old[idx], adv[idx], tgt[idx], 0.2, 0.005, 0.5, got,
                        label=f"cfg2 shape, 3000 gathered rows (slice {s})")
+
+
+def test_fused_gather_and_side_stream_reductions_are_bitwise_neutral(L):
+    """[r3] The first layer's four launches fetch their rows straight from the experience arrays through the row table (the
+    minibatch gather fused into the GEMMs' load stage), and the weight-gradient reductions run on streams of their own
+    beside the chain.  Neither changes a single product or the order of a single sum: gradients and statistics must be BIT-identical
+    to the separate gather pass (rlppo_dbg_set(26, 0)) and to in-chain reductions (rlppo_dbg_set(25, 0)), on a ragged minibatch
+    (1500 rows: a partial row tile, a partial dW stage) drawn at random, with repeats, from a 5000-row buffer."""
+    rs = np.random.RandomState(21)
+    d, A, n, mb = 107, 90, 5000, 1500
+    torch.manual_seed(21)
+    pol, val = nets.init_mlp(d, (256, 256, 256), A), nets.init_mlp(d, (256, 256, 256), 1)
+    obs = np.clip(rs.randn(n, d), -5, 5).astype(np.float32)
+    acts = rs.randint(0, A, n).astype(np.float32)
+    old = (-np.log(A) + 0.1 * rs.randn(n)).astype(np.float32)
+    tgt, adv = rs.randn(n).astype(np.float32), rs.randn(n).astype(np.float32)
+    idx = rs.randint(0, n, mb)
+    idx[:3] = [n - 1, 0, n - 1]
+    runs = {}
+    for key, (k26, k25) in dict(fused=(1, 1), separate_gather=(0, 1), in_chain_reductions=(1, 0), round2=(0, 0)).items():
+        check(L, L.rlppo_dbg_set(26, k26))
+        check(L, L.rlppo_dbg_set(25, k25))
+        try:
+            runs[key] = run_minibatch(L, "discrete", pol, val, obs, acts, old, tgt, adv, idx, 0.2, 0.005, 0.25)
+        finally:
+            check(L, L.rlppo_dbg_set(26, 1))
+            check(L, L.rlppo_dbg_set(25, 1))
+    gp0, gv0, st0 = runs["fused"]
+    for key, (gp, gv, st) in runs.items():
+        for (a, b), (c, e) in zip(gp0 + gv0, gp + gv):
+            assert torch.equal(a, c) and torch.equal(b, e), key
+        assert np.array_equal(st0, st), key
+    # and the fused form is right (float64 truth), not merely self-consistent
+    sel = idx
+    fp64_gate.gate(L, "discrete", pol, val, obs[sel], acts[sel], old[sel], adv[sel], tgt[sel], 0.2, 0.005, 0.25, runs["fused"],
+                   label="fused gather, ragged 1500-row minibatch")
 
 
 def test_minibatch_full_size_cfg2(L):
@@ -813,8 +876,10 @@ def test_clip_adam_matches_oracle(L):
         assert relerr(gflat, nets.flatten([(w * coef, b * coef) for w, b in grads])) < 1e-6  # grads scaled in place
 
 
-def test_clip_adam_pack2_equals_separate_launches(L):
-    """rlppo_clip_adam_pack2 (both nets' clip + Adam + re-pack + zero_grad in two launches) against rlppo_clip_adam x2 +
+@pytest.mark.parametrize("one_launch", [True, False], ids=["one_launch_grid_barrier", "three_operations"])
+def test_clip_adam_pack2_equals_separate_launches(L, one_launch):
+    """rlppo_clip_adam_pack2 (both nets' clip + Adam + re-pack + zero_grad; ONE launch with a grid barrier between the norms and the
+    update when the caller hands over a sync block -- what PPOLearner does -- else fill + norms + update) against rlppo_clip_adam x2 +
     rlppo_net_pack x2: parameters, both Adam moments and the packed copies bit-identical over several steps (large and tiny
     gradients: clipped and unclipped), gradients left zero, squared norms equal; odd layer widths exercise the padding."""
     from rlgym_ppo_amd import _native as N
@@ -832,6 +897,7 @@ def test_clip_adam_pack2_equals_separate_launches(L):
                            packed=torch.zeros(npk, device="cuda"), gn=torch.zeros(1, dtype=torch.float64, device="cuda"))
             check(L, L.rlppo_net_pack(stream(), dc, nl, P(st[tag]["p"]), P(st[tag]["packed"])))
         state.append(st)
+    sync = torch.zeros(N.OPT_SYNC_BYTES // 4, dtype=torch.int32, device="cuda") if one_launch else None   # zeroed ONCE
     for step in range(1, 6):
         descs = []
         for st in state:
@@ -846,7 +912,7 @@ def test_clip_adam_pack2_equals_separate_launches(L):
             d.packed, d.gnorm2 = b["packed"].data_ptr(), b["gn"].data_ptr()
             d.max_norm, d.lr, d.beta1, d.beta2, d.eps, d.step = 0.5, 3e-4, 0.9, 0.999, 1e-8, step
             descs.append((d, gb))
-        check(L, L.rlppo_clip_adam_pack2(stream(), ctypes.byref(descs[0][0]), ctypes.byref(descs[1][0])))
+        check(L, L.rlppo_clip_adam_pack2(stream(), ctypes.byref(descs[0][0]), ctypes.byref(descs[1][0]), P(sync)))
         torch.cuda.synchronize()
         for st, (_, gb) in zip(state, descs):
             a, b = st["a"], st["b"]
@@ -854,5 +920,8 @@ def test_clip_adam_pack2_equals_separate_launches(L):
                 assert torch.equal(a[k], b[k]), (step, k)
             assert (gb == 0).all()
             assert abs(a["gn"].item() - b["gn"].item()) <= 1e-12 * a["gn"].item()
+    if one_launch:  # the barrier leaves its block armed (accumulators and counter back at zero) and never timed out
+        w = sync.cpu().numpy()
+        assert (w[:5] == 0).all() and w[5] == 5 and w[6] == 0, w
     bad = N.OptNet()
-    assert L.rlppo_clip_adam_pack2(stream(), ctypes.byref(bad), ctypes.byref(descs[1][0])) != 0
+    assert L.rlppo_clip_adam_pack2(stream(), ctypes.byref(bad), ctypes.byref(descs[1][0]), P(sync)) != 0
