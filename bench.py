@@ -388,23 +388,164 @@ def cfg5_rooflines(value, bf16, learner):
             (name[:110], ms, flop / ms / 1e9, f_mfma, kind, nbytes / ms / 1e6, f_hbm))
     fps = CFG5["flop_per_sample"]
     tf = fps * value / 1e12
+    # the whole update against the MFMA peak of the precision its hidden-layer products run in (never a fraction above 1: the
+    # bf16 precision is priced against 2.5 PFLOP/s, where it sits far below the MFMA roofline because its kernels are HBM-side bound)
+    peak = BF16_MFMA_PEAK_TF if bf16 else MFMA_F32_PEAK_TF
     out = {"kernel_breakdown": rows,
-           "update_flop_efficiency": dict(achieved=round(tf, 2), peak=MFMA_F32_PEAK_TF, unit="TFLOP/s", frac=round(tf / MFMA_F32_PEAK_TF, 4),
-                                          note="10,435,584 algorithmic flop/sample (SURVEY 8(d)) x measured samples/s, against the fp32 MFMA "
-                                               "peak" + (" (bf16 update precision: all hidden-layer products run on the bf16 pipe, so this is an "
-                                                         "equivalent-fp32 rate, not a utilisation; the kernels are HBM-side bound, see "
-                                                         "kernel_breakdown)" if bf16 else ""))}
+           "update_flop_efficiency": dict(achieved=round(tf, 2), peak=peak, unit="TFLOP/s", frac=round(tf / peak, 4),
+                                          note="10,435,584 algorithmic flop/sample (SURVEY 8(d)) x measured samples/s, against the dense %s "
+                                               "MFMA peak" % ("bf16" if bf16 else "fp32"))}
     dom = rows[0]
     bound = dom["binds"]
     out["roofline"] = dict(bound=bound, achieved=dom["gb_per_s"] if bound == "hbm" else dom["tflops"],
                            peak=HBM_PEAK_GBS if bound == "hbm" else dom["mfma_peak"], unit="GB/s" if bound == "hbm" else "TFLOP/s",
-                           frac=dom["frac_hbm"] if bound == "hbm" else dom["frac_mfma"], traffic=None, kernel=dom["kernel"],
+                           frac=dom["frac_hbm"] if bound == "hbm" else dom["frac_mfma"], traffic=cfg5_traffic(bf16), kernel=dom["kernel"],
+                           algorithmic_bytes=round(dom["algorithmic_mb"] * 1e6),
                            other_bound=dict(bound="mfma" if bound == "hbm" else "hbm", frac=dom["frac_mfma"] if bound == "hbm" else dom["frac_hbm"]),
                            ms_per_launch=dom["ms_per_launch"],
                            note="the hidden-layer forward of the selected update precision at the update's launch shape, priced against both "
                                 "rooflines (algorithmic bytes: operands once, outputs once); `bound` = the larger fraction.  HIP events on the "
                                 "launch stream, 10 launches after a 0.3 s clock ramp")
     return out
+
+
+def cfg5_traffic(bf16):
+    """HBM bytes per launch of the configs[4] hidden-layer forward from the committed PMC passes of `bench.py --config cfg5`
+    (tools/round_profile.sh: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), newest round first; None for the fp32 precision (its
+    kernels are the cfg2 ones at K = 512: no pass of their own)."""
+    if not bf16:
+        return None
+    for tag in ("r03", "r02"):
+        try:
+            t = json.load(open(os.path.join(ROOT, "profiles", tag + "_cfg5_bf16_traffic.json")))
+        except Exception:
+            continue
+        for k, v in t.items():
+            if "gemm_nt_b16" in k and ("<1," in k or "fwd" in k):
+                return round(v["hbm_bytes"])
+    return None
+
+
+def cfg5_leg(device, steps=2, warmup=1):
+    """BASELINE configs[4] on the default driver line: the same PPO-update metric on the Gaussian-policy workload (obs 231, 512x4
+    nets, 524,288-sample buffer, 10 epochs per step), in the fp32 update precision (the parity mode: the reference's arithmetic)
+    and in the bf16 update precision (mixed-precision training; the reference has no such mode: parity-unpinned by construction,
+    checked against the repository's own restatement, tests/test_gpu_cfg5.py), `steps` timed learn() calls each, with the
+    dominant kernel priced against BOTH rooflines."""
+    import contextlib
+    from rlgym_ppo_amd.engine import set_update_precision
+    out = {}
+    with contextlib.redirect_stdout(sys.stderr):
+        learner, buf = build_workload(device, config="cfg5")
+    for prec in ("fp32", "bf16"):
+        set_update_precision(prec)
+        try:
+            for _ in range(warmup):
+                learner.learn(buf)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                report = learner.learn(buf)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            value = steps * learner.n_epochs * BATCH / dt
+            log("cfg5 %s: %.1f M samples/s" % (prec, value / 1e6))
+            leg = dict(value=round(value, 1), unit="samples/s", steps=steps, warmup=warmup, ms_per_step=round(dt / steps * 1e3, 3),
+                       dtype="bf16" if prec == "bf16" else "f32",
+                       parity="pinned to the reference by fixtures G9 (fp32 arithmetic)" if prec == "fp32" else
+                              "parity-unpinned: the reference has no mixed-precision mode; held to the repository's own restatement",
+                       last_report={k: (round(v, 6) if isinstance(v, float) else v) for k, v in report.items()})
+            leg.update(cfg5_rooflines(value, prec == "bf16", learner))
+            out[prec] = leg
+        finally:
+            set_update_precision("fp32")
+    out["workload"] = ("BASELINE configs[4]: 524,288-sample buffer, obs 231 f32, Gaussian policy with 8 actions, 512x4 policy + 512x4 "
+                       "critic, ppo_batch 524,288, minibatch 65,536, 10 epochs per step")
+    del learner, buf
+    torch.cuda.empty_cache()
+    return out
+
+
+class BenchVectorEnv:
+    """4096 agents stepping in lockstep with auto-reset (the interface VectorAgentManager drives): pre-drawn observations -- the
+    leg measures the learner side of an iteration, not numpy's randn."""
+
+    class _Space:
+        def __init__(self, shape=None, n=None):
+            self.shape = shape
+            if n is not None:
+                self.n = n
+
+        def seed(self, s):
+            pass
+
+    def __init__(self):
+        self.n_agents = N_AGENTS
+        self.observation_space = BenchVectorEnv._Space(shape=(OBS,))
+        self.action_space = BenchVectorEnv._Space(n=ACT)
+        self._pool = (np.random.RandomState(0).randn(8, N_AGENTS, OBS) * 2 + 0.5).astype(np.float32)
+        self._i = 0
+        self.ep_len = 40 + (np.arange(N_AGENTS) * 7) % 100
+        self.t = np.zeros(N_AGENTS, np.int64)
+
+    def _obs(self):
+        self._i += 1
+        return self._pool[self._i % 8]
+
+    def reset(self):
+        self.t[:] = 0
+        return self._obs()
+
+    def step(self, actions):
+        actions = np.asarray(actions, np.float32).reshape(self.n_agents, -1)
+        self.t += 1
+        rew = np.tanh(actions[:, 0] * 0.01).astype(np.float32)
+        done = self.t >= self.ep_len
+        self.t[done] = 0
+        return self._obs(), rew, done.astype(np.float32), np.zeros(self.n_agents, np.float32), {"state": None}
+
+    def close(self):
+        pass
+
+
+def iteration_leg(iters=3):
+    """One whole iteration at the configs[1] scale through the reference's own entry points (rlgym_ppo/learner.py:257-270:
+    collect_timesteps -> add_new_experience -> ppo_learner.learn): 4096 agents x 128 steps collected by the device-resident
+    VectorAgentManager from a synthetic vectorised environment with the bit-exact host noise stream, the value pass + GAE +
+    buffer submit on the device, and the 10-epoch update.  Median of `iters` iterations after one warm-up."""
+    import contextlib
+    from rlgym_ppo_amd import Learner
+    with contextlib.redirect_stdout(sys.stderr):
+        learner = Learner(BenchVectorEnv, vector_env=True, n_proc=1, timestep_limit=10**9, exp_buffer_size=N_SAMPLES,
+                          ts_per_iteration=N_SAMPLES, ppo_epochs=10, ppo_batch_size=BATCH, ppo_minibatch_size=MINIBATCH,
+                          policy_layer_sizes=HID, critic_layer_sizes=HID, checkpoints_save_folder=None,
+                          checkpoint_load_folder=None, save_every_ts=10**12, log_to_wandb=False, random_seed=123)
+    sync = torch.cuda.synchronize
+    rows = []
+    try:
+        for it in range(iters + 1):
+            sync(); t0 = time.perf_counter()
+            exp, _, n, _ = learner.agent.collect_timesteps(N_SAMPLES)
+            sync(); t1 = time.perf_counter()
+            learner.add_new_experience(exp)
+            sync(); t2 = time.perf_counter()
+            with contextlib.redirect_stdout(sys.stderr):
+                learner.ppo_learner.learn(learner.experience_buffer)
+            sync(); t3 = time.perf_counter()
+            if it:
+                rows.append((t1 - t0, t2 - t1, t3 - t2))
+    finally:
+        learner.agent.cleanup()
+    c, a, l = (float(np.median([r[i] for r in rows])) * 1e3 for i in range(3))
+    del learner
+    torch.cuda.empty_cache()
+    return dict(workload="4096 agents x 128 steps per iteration (configs[1] scale), synthetic vectorised environment, 10-epoch update",
+                collect_ms=round(c, 2), collect_ms_per_env_step=round(c / N_STEPS, 4), add_new_experience_ms=round(a, 3), learn_ms=round(l, 3),
+                iteration_ms=round(c + a + l, 2), steps_per_s=round(N_SAMPLES / (c + a + l) * 1e3),
+                note="collect = 128 x (policy inference on 4096 observations with the reference's CPU noise stream + the environment's "
+                     "own step() + H2D of its observations); add_new_experience = value pass on 524,289 rows + GAE scan + ring-buffer "
+                     "submit, all on the device; learn = the headline metric's step.  steps_per_s = agent-steps per second of the "
+                     "whole iteration; median of %d iterations" % iters)
 
 
 # ---------------------------------------------------------------------------------------------------- main
@@ -432,30 +573,35 @@ def spawn_ranks(args):
     children of torch.distributed.run, and relays rank 0's JSON line.  It makes no GPU call of its own (a process that has
     initialised HIP must not be the parent of the ranks' exec chain on this pool), so everything below the import of torch is
     host-only here."""
-    import socket
+    import signal
     import subprocess
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    # --standalone: the launcher picks its own free rendezvous port on 127.0.0.1 (no probe-then-bind window)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1",
+           f"--nproc-per-node={args.gpus}", os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // max(args.gpus, 1))))
     log(f"bench.py: starting {args.gpus} ranks: {' '.join(cmd[1:8])} ...  (parent initialised HIP: {torch.cuda.is_initialized()})")
-    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    limit = float(os.environ.get("RLPPO_BENCH_TIMEOUT", 1500))
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True, start_new_session=True)
+    try:
+        stdout, _ = proc.communicate(timeout=limit)
+    except subprocess.TimeoutExpired:  # a rank that hangs must not hang the parent: end the whole job, report, fail
+        log(f"bench.py: the {args.gpus}-rank job did not finish within {limit:.0f} s; killing its process group")
+        os.killpg(proc.pid, signal.SIGKILL)
+        stdout, _ = proc.communicate()
+        print(stdout, file=sys.stderr)
+        return 124
     line = None
-    for out in proc.stdout:
-        out = out.rstrip("\n")
+    for out in stdout.splitlines():
         if out.startswith("{") and '"metric"' in out:
             line = out
         else:
             log(out)
-    rc = proc.wait()
+    rc = proc.returncode
     if line is not None:
         print(line, flush=True)
-    return rc if line is None or rc != 0 else 0
+    return rc if rc != 0 else (0 if line is not None else 1)
 
 
 def allreduce_ab(learner, buf, steps, world, device, dist):
@@ -625,7 +771,7 @@ def main():
                 return
             out["allreduce"] = {"error": "A/B skipped: " + ("terminated by signal %d" % got[0] if got else "not finished within 120 s")}
             emit()
-            os._exit(0)
+            os._exit(3)  # the headline line is out, but this process is stuck in (or was torn out of) a collective: not a clean exit
         threading.Thread(target=bail, daemon=True).start()
         out["allreduce"] = allreduce_ab(learner, buf, max(1, min(args.steps, 5)), world, device, dist)
         wr.send(b"\0")
@@ -652,6 +798,10 @@ def main():
         out["kernel_breakdown"] = rows
         out["gae"] = gae_bench()
         out["rollout"] = rollout_bench(learner)
+        del learner, buf  # the other legs build their own workloads
+        torch.cuda.empty_cache()
+        out["iteration"] = iteration_leg()
+        out["cfg5"] = cfg5_leg(device)
         out["cpu_baseline"] = cpu_baseline()
     emit()
     if world > 1:

@@ -225,11 +225,12 @@ int rlppo_clip_adam(void *stream, float *params, float *grads, float *exp_avg, f
  * rewritten), gradients left ZERO.  Element for element the arithmetic of rlppo_clip_adam + rlppo_net_pack.  Used by
  * PPOLearner.learn; FusedAdam.step() (the public optimiser API, gradients scaled in place) stays on rlppo_clip_adam.
  * sync_ws: RLPPO_OPT_SYNC_BYTES of device memory, 16-byte aligned, owned by the caller and ZEROED ONCE when it is allocated
- * (never again: every completed call leaves it armed for the next): the accumulators, arrival counter and generation word of
- * the grid barrier between the norm and the update, and at byte offset 24 a uint32 that counts barrier waits that gave up
+ * (never again: every completed call leaves it armed for the next): the state of
+ * the grid barrier between the norm and the update (arrival counter, generation word, one partial-sum slot per workgroup, added
+ * in a fixed order: the norm is bit-reproducible), and at byte offset 8 a uint32 that counts barrier waits that gave up
  * (then the affected network's parameters are poisoned with NaN; callers read the word back with their report).  Not
  * shareable between concurrent calls.  sync_ws == NULL selects the three-operation form (fill, norms, update). */
-#define RLPPO_OPT_SYNC_BYTES 64
+#define RLPPO_OPT_SYNC_BYTES 16384
 typedef struct rlppo_opt_net {
     const int32_t *dims;  /* layer widths, n_layers + 1 entries */
     int32_t n_layers;

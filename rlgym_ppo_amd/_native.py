@@ -15,7 +15,8 @@ ABI_VERSION = 3
 COMM_ID_BYTES = 128  # RLPPO_COMM_ID_BYTES
 MAX_LAYERS = 16
 N_STATS = 8
-OPT_SYNC_BYTES = 64  # RLPPO_OPT_SYNC_BYTES
+OPT_SYNC_BYTES = 16384  # RLPPO_OPT_SYNC_BYTES
+OPT_SYNC_TIMEOUT_WORD = 2  # uint32 index of the barrier-timeout counter in the sync block
 MAX_SLOTS = 8
 STAT_ENTROPY, STAT_KL, STAT_VLOSS, STAT_CLIPFRAC, STAT_PLOSS = 0, 1, 2, 3, 4
 STAT_PASSES = 7  # host-side: passes of rlppo_ppo_minibatch behind the sums above (summed over ranks with them)

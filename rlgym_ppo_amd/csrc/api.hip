@@ -369,14 +369,6 @@ static int g_update_bf16 = 0;   // rlppo_set_update_precision
 static hipStream_t g_main[RLPPO_MAX_SLOTS] = {}, g_side[RLPPO_MAX_SLOTS] = {};
 static hipEvent_t g_ev_fork[RLPPO_MAX_SLOTS] = {}, g_ev_join[RLPPO_MAX_SLOTS] = {}, g_ev_slot[RLPPO_MAX_SLOTS] = {};
 static bool g_slot_pending[RLPPO_MAX_SLOTS] = {};
-// [r3] The reductions of the weight-gradient partial tiles run on a stream of their own per network (g_red[slot][net]): a
-// reduction depends on its dW launch only, and nothing in the chain depends on it before the optimiser step -- in the chain's
-// own stream it stood between dW(l) and dX(l) (37 us on average per reduction while the other chain's GEMMs hold the CUs, 7 per
-// pass: profiles/r03_rank_share_trace.txt).  g_ev_dw[slot][net][layer] orders a reduction behind its dW launch, g_ev_red joins.
-static int g_red_streams = 1;  // rlppo_dbg_set(25, 0/1)
-static hipStream_t g_red[RLPPO_MAX_SLOTS][2] = {};
-static hipEvent_t g_ev_dw[RLPPO_MAX_SLOTS][2][RLPPO_MAX_LAYERS] = {}, g_ev_red[RLPPO_MAX_SLOTS][2] = {};
-
 static int ensure_slot(int s) {
     if (!g_side[s]) {
         RLPPO_HIP(hipStreamCreateWithFlags(&g_side[s], hipStreamNonBlocking));
@@ -384,11 +376,6 @@ static int ensure_slot(int s) {
         RLPPO_HIP(hipEventCreateWithFlags(&g_ev_fork[s], hipEventDisableTiming));
         RLPPO_HIP(hipEventCreateWithFlags(&g_ev_join[s], hipEventDisableTiming));
         RLPPO_HIP(hipEventCreateWithFlags(&g_ev_slot[s], hipEventDisableTiming));
-        for (int k = 0; k < 2; ++k) {
-            RLPPO_HIP(hipStreamCreateWithFlags(&g_red[s][k], hipStreamNonBlocking));
-            RLPPO_HIP(hipEventCreateWithFlags(&g_ev_red[s][k], hipEventDisableTiming));
-            for (int l = 0; l < RLPPO_MAX_LAYERS; ++l) RLPPO_HIP(hipEventCreateWithFlags(&g_ev_dw[s][k][l], hipEventDisableTiming));
-        }
     }
     return 0;
 }
@@ -412,11 +399,17 @@ static size_t tn_layer_floats(const NetLayout &net, int l, int64_t mb) {
     }
     return (f + 3) / 4 * 4;
 }
-// ... of all of them: [r3] one buffer per LAYER (they were one buffer per net while the reductions ran in the chain's stream):
-// a layer's reduction may still be reading its partial tiles when the next layer's dW launch writes its own
+// ... of a net's chain: the launches run one after the other on the net's stream, each followed by its reduction, so one buffer
+// of the largest size serves them all.  ([r3] measured: the reductions on streams of their own, one partial buffer per layer --
+// a reduction depends on its dW launch only and nothing waits for it before the optimiser step.  The GPU is throughput-bound
+// with two chains in flight, so taking them out of the chain saved nothing and their HBM / atomic traffic beside the same
+// chain's GEMMs cost 0.6 ms per 10-epoch learn() at one rank and 0.5 ms at the 8-rank share: profiles/r03_ab_update_side_streams.txt.)
 static size_t tn_ws_floats(const NetLayout &net, int64_t mb) {
     size_t m = 0;
-    for (int l = 0; l < net.n_layers; ++l) m += tn_layer_floats(net, l, mb);
+    for (int l = 0; l < net.n_layers; ++l) {
+        const size_t f = tn_layer_floats(net, l, mb);
+        m = f > m ? f : m;
+    }
     return m;
 }
 
@@ -449,10 +442,8 @@ size_t rlppo_minibatch_workspace_bytes(const int32_t *pol_dims, int32_t pol_laye
     return train_ws_floats(pol, val, mb > 0 ? mb : 0) * sizeof(float) + 256;
 }
 
-// Where a chain's weight-gradient reductions go and how its first layer finds its rows [r3].
+// How a chain's first layer finds its rows [r3].
 struct ChainCtx {
-    hipStream_t red = nullptr;        // reductions run here behind ev_dw[layer] (nullptr: in the chain's own stream)
-    hipEvent_t *ev_dw = nullptr;
     const unsigned *rowtab = nullptr;  // fused gather: row r of the pass is src[rowtab[r]] (first-layer dW)
     const float *src = nullptr;
     int64_t ld_src = 0, src_rows = 0;
@@ -465,11 +456,6 @@ static int backward(hipStream_t st, const NetLayout &net, const float *packed, c
                     unsigned long long *const *bits, const bool *have_bits, const ChainCtx &cx) {
     const int last = net.n_layers - 1;
     int rc = 0;
-    float *ws_l[RLPPO_MAX_LAYERS];
-    for (int l = 0; l < net.n_layers; ++l) {
-        ws_l[l] = tn_ws;
-        tn_ws += tn_layer_floats(net, l, mb);
-    }
     for (int l = last; l >= 0; --l) {
         const LayerLayout &L = net.L[l];
         const float *dY = l == last ? acts[last] : dx[l];
@@ -477,16 +463,14 @@ static int backward(hipStream_t st, const NetLayout &net, const float *packed, c
         const int64_t ldx = l > 0 ? net.L[l - 1].pout : ld_states;
         const bool gemv = l == last && l > 0 && gemv_head_ok(L.out, L.pin);  // one-output head (gemv.hip)
         const size_t floats = tn_layer_floats(net, l, mb);
-        hipEvent_t ev = cx.red ? cx.ev_dw[l] : nullptr;
         if (gemv)
-            rc = launch_gemv_dw(st, dY, L.pout, X, ldx, grad + L.off_flat_w, grad + L.off_flat_b, L.in, L.pin, mb, ws_l[l], floats,
-                                cx.red, ev);
+            rc = launch_gemv_dw(st, dY, L.pout, X, ldx, grad + L.off_flat_w, grad + L.off_flat_b, L.in, L.pin, mb, tn_ws, floats);
         else if (l == 0 && cx.rowtab)
             rc = launch_gemm_tn(st, dY, L.pout, L.pout, cx.src, cx.ld_src, L.pin, grad + L.off_flat_w, grad + L.off_flat_b, L.out, L.in,
-                                mb, ws_l[l], floats, cx.rowtab, cx.src_rows, cx.red, ev);
+                                mb, tn_ws, floats, cx.rowtab, cx.src_rows);
         else
             rc = launch_gemm_tn(st, dY, L.pout, L.pout, X, ldx, L.pin, grad + L.off_flat_w, grad + L.off_flat_b, L.out, L.in, mb,
-                                ws_l[l], floats, nullptr, 0, cx.red, ev);
+                                tn_ws, floats);
         if (rc) return rc;
         if (l == 0) break;
         // dX[mb][pin] = (dY[mb][pout] . W[pout][pin]) masked by relu'(acts[l-1]); B operand = W^T [pin][pout].  The mask is the
@@ -823,12 +807,6 @@ int rlppo_ppo_minibatch(void *stream, const rlppo_minibatch_args *a) {
                           pactb, pdx, pdxb, a->pol_grad, pol_tn_ws, tn_ws_floats(pol, mb), pbits, phave, pf32);
     } else {
         ChainCtx cp, cv;
-        if (g_red_streams) {
-            cp.red = g_red[slot][0];
-            cp.ev_dw = g_ev_dw[slot][0];
-            cv.red = g_red[slot][1];
-            cv.ev_dw = g_ev_dw[slot][1];
-        }
         if (fused_gather) {
             cp.rowtab = cv.rowtab = rowtab;
             cp.src = cv.src = a->states;
@@ -838,12 +816,6 @@ int rlppo_ppo_minibatch(void *stream, const rlppo_minibatch_args *a) {
         rc = backward(side, val, val_w, states, ld_states, mb, vact, vdx, a->val_grad, val_tn_ws, vbits, vhave, cv);
         if (rc) return rc;
         rc = backward(st, pol, pol_w, states, ld_states, mb, pact, pdx, a->pol_grad, pol_tn_ws, pbits, phave, cp);
-        if (rc) return rc;
-        if (g_red_streams)  // the pass is complete when both networks' last reductions are
-            for (int k = 0; k < 2; ++k) {
-                rc = order_after(st, g_red[slot][k], g_ev_red[slot][k]);
-                if (rc) return rc;
-            }
     }
     if (rc) return rc;
     if (side != st) rc = order_after(st, side, g_ev_join[slot]);
@@ -960,7 +932,6 @@ int rlppo_dbg_set(int32_t key, int32_t value) {
         case 22: set_gae_oversubscribe(value); return 0;
         case 23: set_b16_wide_tiles(value); return 0;
         case 24: set_exp_fast_transform(value); return 0;
-        case 25: g_red_streams = value; return 0;
         case 26: g_fused_gather = value; return 0;
         default: break;
     }

@@ -85,10 +85,10 @@ int get_infer_bf16();
 // dW[n][k] += sum_m dY[m][n] X[m][k] ; db[n] += sum_m dY[m][n]: partial tiles in `ws` (>= tn_partial_floats(out, in, M)
 // floats) + a fixed-order reduction into the flat arena
 size_t tn_partial_floats(int out, int in, int64_t M);
-// rowtab: sample m is X[rowtab[m]] (fused minibatch gather); red_st / ev: run the reduction on red_st behind event ev
+// rowtab: sample m is X[rowtab[m]] (fused minibatch gather)
 int launch_gemm_tn(hipStream_t st, const float *dY, int64_t ldy, int ny_valid, const float *X, int64_t ldx, int kx_valid,
                    float *dW, float *db, int out, int in, int64_t M, float *ws, size_t ws_floats, const unsigned *rowtab = nullptr,
-                   int64_t src_rows = 0, hipStream_t red_st = nullptr, hipEvent_t ev = nullptr);
+                   int64_t src_rows = 0);
 bool tn_gather_ok(int64_t ldx, int64_t src_rows);
 
 // gemm_b16.hip: the bf16 update precision, both operands bf16 in memory, fp32 accumulate ---------------------------------
@@ -122,7 +122,7 @@ int launch_gemv_dx(hipStream_t st, const float *dy, int64_t ldy, const float *w,
 int launch_gemv_dx_bits(hipStream_t st, const float *dy, int64_t ldy, const float *w, const unsigned long long *bits, float *dx,
                         int64_t ldc, int kp, int64_t n);
 int launch_gemv_dw(hipStream_t st, const float *dy, int64_t ldy, const float *x, int64_t ldx, float *dw, float *db, int in, int kp, int64_t n,
-                   float *ws = nullptr, size_t ws_floats = 0, hipStream_t red_st = nullptr, hipEvent_t ev = nullptr);
+                   float *ws = nullptr, size_t ws_floats = 0);
 
 // heads.hip: sampling and loss epilogues ---------------------------------------------------------------
 struct LossCfg {

@@ -739,12 +739,10 @@ size_t tn_partial_floats(int out, int in, int64_t M) {
 
 // dW[out][in] += dY^T . X, db[out] += colsum(dY) through partial tiles in `ws` (>= tn_partial_floats floats) + a reduction.
 // rowtab != nullptr: sample m of the contraction is X[rowtab[m]] of a `src_rows`-row matrix (the fused minibatch gather).
-// red_st != nullptr: the reduction runs on that stream behind `ev` (recorded here on `st`), i.e. beside whatever `st` launches
-// next -- `ws` must then stay untouched until red_st has run it.
 bool tn_gather_ok(int64_t ldx, int64_t src_rows) { return ldx * 4 < 16384 && ldx % 4 == 0 && src_rows > 0 && src_rows < ((int64_t)1 << 32); }
 int launch_gemm_tn(hipStream_t st, const float *dY, int64_t ldy, int ny_valid, const float *X, int64_t ldx, int kx_valid,
                    float *dW, float *db, int out, int in, int64_t M, float *ws, size_t ws_floats, const unsigned *rowtab,
-                   int64_t src_rows, hipStream_t red_st, hipEvent_t ev) {
+                   int64_t src_rows) {
     if (M <= 0) return 0;
     RLPPO_CHECK_ARG(ny_valid % 4 == 0 && kx_valid % 4 == 0 && ldy % 4 == 0 && ldx % 4 == 0 && ny_valid <= ldy &&
                         kx_valid <= ldx && out <= ny_valid && in <= kx_valid,
@@ -776,13 +774,7 @@ int launch_gemm_tn(hipStream_t st, const float *dY, int64_t ldy, int ny_valid, c
     }
 #undef TN
     RLPPO_LAUNCH_CHECK();
-    if (red_st && red_st != st) {
-        RLPPO_HIP(hipEventRecord(ev, st));
-        RLPPO_HIP(hipStreamWaitEvent(red_st, ev, 0));
-    } else {
-        red_st = st;
-    }
-    return launch_tn_reduce(red_st, ws, splits, tiles_x, tiles_y, dW, db, out, in, g.ni, g.nj, g.wn);
+    return launch_tn_reduce(st, ws, splits, tiles_x, tiles_y, dW, db, out, in, g.ni, g.nj, g.wn);
 }
 int launch_tn_reduce(hipStream_t st, const float *partial, int splits, int tiles_x, int tiles_y, float *dW, float *db, int out, int in,
                      int ni, int nj, int wn) {

@@ -404,7 +404,7 @@ int launch_gemv_dx_bits(hipStream_t st, const float *dy, int64_t ldy, const floa
 }
 
 int launch_gemv_dw(hipStream_t st, const float *dy, int64_t ldy, const float *x, int64_t ldx, float *dw, float *db, int in,
-                   int kp, int64_t n, float *ws, size_t ws_floats, hipStream_t red_st, hipEvent_t ev) {
+                   int kp, int64_t n, float *ws, size_t ws_floats) {
     if (n <= 0) return 0;
     // 1024 blocks at M = 65,536: enough loads in flight to stream h at HBM rate; larger M keeps about 2048 blocks
     const int rows_per_block = n > 131072 ? (int)round_up(cdiv(n, 2048), 64) : 64;
@@ -414,13 +414,7 @@ int launch_gemv_dw(hipStream_t st, const float *dy, int64_t ldy, const float *x,
                        rows_per_block, part);
     RLPPO_LAUNCH_CHECK();
     if (part) {
-        if (red_st && red_st != st) {  // the reduction beside the chain's next launch (api.hip, g_red)
-            RLPPO_HIP(hipEventRecord(ev, st));
-            RLPPO_HIP(hipStreamWaitEvent(red_st, ev, 0));
-        } else {
-            red_st = st;
-        }
-        hipLaunchKernelGGL(gemv_dw_reduce_kernel, dim3((unsigned)cdiv(kp + 1, 16)), dim3(256), 0, red_st, part, blocks, kp, dw, db, in);
+        hipLaunchKernelGGL(gemv_dw_reduce_kernel, dim3((unsigned)cdiv(kp + 1, 16)), dim3(256), 0, st, part, blocks, kp, dw, db, in);
         RLPPO_LAUNCH_CHECK();
     }
     return 0;

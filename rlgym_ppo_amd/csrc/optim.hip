@@ -484,57 +484,93 @@ __global__ __launch_bounds__(256) void adam_pack2_kernel(OptPair o) {
 }
 
 // ---- the same update in ONE launch: squared norms -> grid barrier -> clip + Adam + re-pack + zero_grad.
-// The two-launch form above costs, per optimiser step of an 8-rank job (profiles/r03_rank_share_trace.txt): a 6 us fill of the two
-// accumulators, 19 us for sqnorm2 (2048 workgroups queueing on two double-precision atomics) and 9 us for adam_pack2, each behind
-// a launch boundary with the chip idle -- ~45 us of a 1.2 ms step in which no GEMM can run.  Here 2 x FUSED_BLOCKS workgroups (all
-// co-resident: one per CU or fewer) add their partial sums to an accumulator in the caller's 64-byte sync block, meet at a
-// sense-reversal barrier (arrival counter + generation word, agent-scope atomics: cdna_hip_programming.md Guideline 16), and go
-// on to Adam.  The LAST arriver publishes both totals to the nets' gnorm2 outputs and re-arms the accumulators and the counter,
-// so the block needs no per-launch memset: it is zeroed ONCE by its owner and every completed launch leaves it armed.  The spin
-// is bounded; a wait that gives up counts itself in the block's timeout word and poisons that net's step with NaN (loud:
-// PPOLearner.learn reads the word back with its report and raises).
+// The three-operation form above costs, per optimiser step of an 8-rank job (profiles/r03_rank_share_step_gaps_before.txt): a
+// 6 us fill of the two accumulators, 19 us for sqnorm2 (2048 workgroups queueing on two double-precision atomics) and 9 us for
+// adam_pack2, each behind a launch boundary with the chip idle.  Here every workgroup writes its partial sum of squares into a
+// slot of its own in the caller's sync block and arrives at a counter; the LAST workgroup to arrive adds the slots of both
+// networks IN A FIXED ORDER (so the norm -- and with it every replica of a data-parallel job -- is bit-reproducible, which two
+// atomically accumulated doubles are not), publishes the totals to the nets' gnorm2 outputs, re-arms the counter and opens the
+// barrier (generation word).  While they wait the others already hold the Adam operands of their first elements in registers.
+// Agent-scope atomics only on the words that cross workgroups (cdna_hip_programming.md Guideline 16); the block needs no
+// per-launch memset: it is zeroed ONCE by its owner and every completed launch leaves it armed.  All workgroups are co-resident
+// (at most 4 of 256 threads per CU, no LDS to speak of); the spin is bounded, and a wait that gives up counts itself in the
+// block's timeout word and poisons that network's step with NaN (PPOLearner.learn reads the word back with its report and raises).
 struct FusedSync {
-    double acc[2];
-    unsigned count, gen, timeouts, pad;
+    unsigned count, gen, timeouts, pad[13];  // 64-byte header
+    double slot[2][512];                     // per network, per workgroup: partial sum of squares of this launch
 };
-constexpr int FUSED_BLOCKS = 128;            // per net; 2 x 128 workgroups of 256 threads are always co-resident on 256 CUs
-constexpr unsigned FUSED_SPIN_LIMIT = 1u << 24;  // x (s_sleep + one L2 round trip) ~ seconds
+static_assert(sizeof(FusedSync) <= RLPPO_OPT_SYNC_BYTES, "RLPPO_OPT_SYNC_BYTES");
+constexpr int FUSED_EPT = 6;                    // elements per thread whose operands are fetched before the barrier
+constexpr int FUSED_MAX_BLOCKS = 512;           // per network
+constexpr unsigned FUSED_SPIN_LIMIT = 1u << 22;  // x (s_sleep 8 + one L2 round trip) ~ seconds
+
+__device__ __forceinline__ void adam_one(const OptNet &N, int64_t i, float gi, float mi, float vi, float p0, float coef) {
+    gi *= coef;
+    mi = mi + N.omb1 * (gi - mi);
+    vi = vi * N.beta2 + (N.omb2 * gi) * gi;
+    const float denom = sqrtf(vi) / N.bc2_sqrt + N.eps;
+    const float pi = p0 + (-N.step_size * mi) / denom;
+    N.p[i] = pi;
+    N.m[i] = mi;
+    N.v[i] = vi;
+    N.g[i] = 0.f;  // zero_grad of the next batch (the clipped gradient is not observable inside learn())
+    int l = 0;     // flat order: W0[out][in], b0, W1, b1, ...
+    while (l + 1 < N.jobs.n && i >= N.jobs.j[l + 1].off_flat_w) ++l;
+    const PackJob &J = N.jobs.j[l];
+    if (i < J.off_flat_b) {
+        const int64_t e = i - J.off_flat_w;
+        const int r = (int)(e / J.in), c = (int)(e % J.in);
+        N.packed[J.off_w + (int64_t)r * J.pin + c] = pi;
+        N.packed[J.off_wt + (int64_t)c * J.pout + r] = pi;
+    } else {
+        N.packed[J.off_b + (i - J.off_flat_b)] = pi;
+    }
+}
 
 __global__ __launch_bounds__(256) void adam_fused_kernel(OptPair o, FusedSync *__restrict__ sy) {
-    const int k = blockIdx.y;
+    const int k = blockIdx.y, tid = threadIdx.x;
     const OptNet &N = o.net[k];
     const unsigned nblocks = gridDim.x * gridDim.y;
-    // ---- phase 1: this workgroup's share of ||g||^2, in double (as sqnorm2_kernel)
+    const int64_t stride = (int64_t)gridDim.x * 256, i0 = (int64_t)blockIdx.x * 256 + tid;
+    // ---- phase 1: this workgroup's share of ||g||^2, in double (as sqnorm2_kernel); the first FUSED_EPT elements stay in registers
+    float g[FUSED_EPT], m[FUSED_EPT], v[FUSED_EPT], p[FUSED_EPT];
     double acc = 0.0;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < N.n; i += (int64_t)gridDim.x * 256) {
-        const double v = (double)N.g[i];
-        acc += v * v;
+#pragma unroll
+    for (int e = 0; e < FUSED_EPT; ++e) {
+        const int64_t i = i0 + e * stride;
+        g[e] = i < N.n ? N.g[i] : 0.f;
+    }
+#pragma unroll
+    for (int e = 0; e < FUSED_EPT; ++e) {  // requested now, needed after the barrier
+        const int64_t i = i0 + e * stride;
+        m[e] = i < N.n ? N.m[i] : 0.f;
+        v[e] = i < N.n ? N.v[i] : 0.f;
+        p[e] = i < N.n ? N.p[i] : 0.f;
+    }
+#pragma unroll
+    for (int e = 0; e < FUSED_EPT; ++e) acc += (double)g[e] * (double)g[e];
+    for (int64_t i = i0 + FUSED_EPT * stride; i < N.n; i += stride) {
+        const double x = (double)N.g[i];
+        acc += x * x;
     }
 #pragma unroll
     for (int s = 32; s > 0; s >>= 1) acc += __shfl_xor(acc, s);
     __shared__ double red[4];
     __shared__ float s_total;
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __shared__ int s_last;
+    if ((tid & 63) == 0) red[tid >> 6] = acc;
     __syncthreads();
-    if (threadIdx.x == 0) {
+    bool ok = true;
+    if (tid == 0) {
         const unsigned g0 = __hip_atomic_load(&sy->gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // read BEFORE arriving
-        __hip_atomic_fetch_add(&sy->acc[k], red[0] + red[1] + red[2] + red[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        // arrival: the release half orders our accumulator add before the count, the acquire half lets the last arriver see
-        // everybody's adds (all of them are agent-scope atomics executed at the memory side: no cached copies involved)
+        __hip_atomic_store(&sy->slot[k][blockIdx.x], (red[0] + red[1]) + (red[2] + red[3]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // arrival: the release half orders our slot before the count, the acquire half lets the last arriver see everybody's
         const unsigned old = __hip_atomic_fetch_add(&sy->count, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-        bool ok = true;
-        if (old == nblocks - 1) {
-            for (int j = 0; j < 2; ++j) {
-                const double t = __hip_atomic_load(&sy->acc[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(o.net[j].gnorm2, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(&sy->acc[j], 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            __hip_atomic_store(&sy->count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_fetch_add(&sy->gen, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);  // opens the barrier
-        } else {
+        s_last = old == nblocks - 1;
+        if (!s_last) {
             unsigned spins = 0;
             while (__hip_atomic_load(&sy->gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == g0) {
-                __builtin_amdgcn_s_sleep(2);
+                __builtin_amdgcn_s_sleep(8);
                 if (++spins > FUSED_SPIN_LIMIT) {
                     __hip_atomic_fetch_add(&sy->timeouts, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     ok = false;
@@ -543,6 +579,28 @@ __global__ __launch_bounds__(256) void adam_fused_kernel(OptPair o, FusedSync *_
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         }
+    }
+    __syncthreads();
+    if (s_last) {  // the whole workgroup adds the slots: thread t takes slots t, t + 256 of each network; fixed tree afterwards
+        __shared__ double part[2][4];
+        for (int j = 0; j < 2; ++j) {
+            double a = 0.0;
+            for (int b = tid; b < (int)gridDim.x; b += 256)
+                a += __hip_atomic_load(&sy->slot[j][b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+            for (int s = 32; s > 0; s >>= 1) a += __shfl_xor(a, s);
+            if ((tid & 63) == 0) part[j][tid >> 6] = a;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            for (int j = 0; j < 2; ++j)
+                __hip_atomic_store(o.net[j].gnorm2, (part[j][0] + part[j][1]) + (part[j][2] + part[j][3]), __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&sy->count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_add(&sy->gen, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);  // opens the barrier
+        }
+    }
+    if (tid == 0) {
         const double t = __hip_atomic_load(N.gnorm2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         s_total = ok ? (float)sqrt(t) : __builtin_nanf("");
     }
@@ -551,29 +609,12 @@ __global__ __launch_bounds__(256) void adam_fused_kernel(OptPair o, FusedSync *_
     const float total = s_total;
     float coef = N.max_norm / (total + 1e-6f);
     coef = coef > 1.f ? 1.f : coef;   // (a NaN total stays NaN: a timed-out barrier must not pass for an update)
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < N.n; i += (int64_t)gridDim.x * 256) {
-        const float gi = N.g[i] * coef;
-        float mi = N.m[i], vi = N.v[i];
-        mi = mi + N.omb1 * (gi - mi);
-        vi = vi * N.beta2 + (N.omb2 * gi) * gi;
-        const float denom = sqrtf(vi) / N.bc2_sqrt + N.eps;
-        const float pi = N.p[i] + (-N.step_size * mi) / denom;
-        N.p[i] = pi;
-        N.m[i] = mi;
-        N.v[i] = vi;
-        N.g[i] = 0.f;
-        int l = 0;
-        while (l + 1 < N.jobs.n && i >= N.jobs.j[l + 1].off_flat_w) ++l;
-        const PackJob &J = N.jobs.j[l];
-        if (i < J.off_flat_b) {
-            const int64_t e = i - J.off_flat_w;
-            const int r = (int)(e / J.in), c = (int)(e % J.in);
-            N.packed[J.off_w + (int64_t)r * J.pin + c] = pi;
-            N.packed[J.off_wt + (int64_t)c * J.pout + r] = pi;
-        } else {
-            N.packed[J.off_b + (i - J.off_flat_b)] = pi;
-        }
+#pragma unroll
+    for (int e = 0; e < FUSED_EPT; ++e) {
+        const int64_t i = i0 + e * stride;
+        if (i < N.n) adam_one(N, i, g[e], m[e], v[e], p[e], coef);
     }
+    for (int64_t i = i0 + FUSED_EPT * stride; i < N.n; i += stride) adam_one(N, i, N.g[i], N.m[i], N.v[i], N.p[i], coef);
 }
 
 static void fill_jobs(const NetLayout &net, PackJobs *jobs) {
@@ -601,9 +642,11 @@ int launch_clip_adam_pack2(hipStream_t st, const NetLayout *nets, float *const *
         fill_jobs(nets[k], &N.jobs);
         nmax = n[k] > nmax ? n[k] : nmax;
     }
-    if (sync_ws) {  // one launch (the caller owns a zero-initialised 64-byte sync block)
+    if (sync_ws) {  // one launch (the caller owns a zero-initialised sync block)
         RLPPO_CHECK_ARG(((uintptr_t)sync_ws & 15) == 0, "clip_adam_pack2: the sync block must be 16-byte aligned");
-        hipLaunchKernelGGL(adam_fused_kernel, dim3(FUSED_BLOCKS, 2), dim3(256), 0, st, o, reinterpret_cast<FusedSync *>(sync_ws));
+        int64_t blocks = cdiv(nmax, 256 * FUSED_EPT);
+        blocks = blocks < 1 ? 1 : (blocks > FUSED_MAX_BLOCKS ? FUSED_MAX_BLOCKS : blocks);
+        hipLaunchKernelGGL(adam_fused_kernel, dim3((unsigned)blocks, 2), dim3(256), 0, st, o, reinterpret_cast<FusedSync *>(sync_ws));
         RLPPO_LAUNCH_CHECK();
         return 0;
     }

@@ -95,3 +95,32 @@ def all_reduce_sum(tensor, dist=None):
         else:
             dist.all_reduce(tensor, op=dist.ReduceOp.SUM)
     return tensor
+
+
+def run_virtual_ranks(learners, buffers):
+    """N data-parallel ranks in ONE process on one device: drives PPOLearner.learn_steps of N replicas (identical construction,
+    identical buffers) in lock step and performs every exchange as the sum, in rank order, of the tensors the replicas hand over
+    -- what the all-reduce computes.  Rank r evaluates exactly the minibatch slices slices_for_rank deals it, so the partition of
+    BASELINE configs[3] (8 ranks x one 65,536-row pass per optimiser step) runs literally on a one-GPU box, where the pool admits
+    neither 8 processes on the card nor two RCCL ranks on one GPU.  Returns the N report dictionaries."""
+    world = len(learners)
+    gens = [l.learn_steps(b, r, world) for r, (l, b) in enumerate(zip(learners, buffers))]
+    reports = [None] * world
+    pending = [next(g) for g in gens]
+    while True:
+        total = pending[0].clone()
+        for t in pending[1:]:
+            total += t
+        for t in pending:
+            t.copy_(total)
+        nxt = []
+        for r, g in enumerate(gens):
+            try:
+                nxt.append(g.send(None))
+            except StopIteration as done:
+                reports[r] = done.value
+        if len(nxt) == 0:
+            return reports
+        if len(nxt) != world:
+            raise RuntimeError("virtual ranks fell out of step: %d of %d reached the next exchange" % (len(nxt), world))
+        pending = nxt

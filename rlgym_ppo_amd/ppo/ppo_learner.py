@@ -179,6 +179,7 @@ class PPOLearner(object):
         # in launches that are k times larger.  RLPPO_FUSE=1 keeps one pass per minibatch.
         self.max_fused_minibatches = max(1, int(os.environ.get("RLPPO_FUSE", 8)))
         self.fused_optimizer_step = os.environ.get("RLPPO_FUSED_OPT", "1") != "0"  # rlppo_clip_adam_pack2 (False: FusedAdam.step x2)
+        self.one_launch_optimizer = os.environ.get("RLPPO_OPT_ONE_LAUNCH", "1") != "0"  # ... as ONE launch with a grid barrier
 
     # --------------------------------------------------------------------------------------------- learn
     def _minibatch_args(self, exp):
@@ -219,8 +220,23 @@ class PPOLearner(object):
     def learn(self, exp):
         """Compute PPO updates with an experience buffer; returns the reference's report dictionary
         (ppo_learner.py:225-234)."""
-        L = N.lib()
         dist, rank, world = dist_info()
+        steps = self.learn_steps(exp, rank, world)
+        try:
+            buf = next(steps)
+            while True:  # one exchange per optimiser step + one for the report statistics (dp.py)
+                all_reduce_sum(buf, dist)
+                buf = steps.send(None)
+        except StopIteration as done:
+            return done.value
+
+    def learn_steps(self, exp, rank=0, world=1):
+        """learn() as a generator that stops at every data-parallel exchange point: it yields the flat tensor whose sum over the
+        ranks it needs (the [grad_policy | grad_value] arena after a batch's last backward pass, the report statistics at the end)
+        and continues once the caller has put that sum into it; the report dictionary is the generator's return value.  learn()
+        drives it with torch.distributed's all-reduce; dp.run_virtual_ranks drives the generators of N replicas in ONE process
+        (the 8-way partition of BASELINE configs[3] on a one-GPU box).  With world == 1 it never yields."""
+        L = N.lib()
         pa, va = self.policy.arena, self.value_net.arena
         B, MB = self.batch_size, self.mini_batch_size
         n_slices = B // MB
@@ -268,14 +284,15 @@ class PPOLearner(object):
                         n_passes += 1
                     N.check(L.rlppo_ppo_join(st))
                     n_minibatch_iterations += n_slices
-                    if dist is not None:
-                        all_reduce_sum(self._grad_all, dist)  # RCCL over xGMI, before clipping
+                    if world > 1:
+                        yield self._grad_all  # summed over the ranks (RCCL over xGMI) before clipping
                     if self.fused_optimizer_step:
                         # both clip + Adam steps, the re-pack of both weight copies and the next batch's zero_grad: 3 stream
                         # operations instead of 9 (csrc/optim.hip)
                         dv = self.value_optimizer.fused_descriptor(MAX_GRAD_NORM)
                         dp_ = self.policy_optimizer.fused_descriptor(MAX_GRAD_NORM)
-                        N.check(L.rlppo_clip_adam_pack2(st, ctypes.byref(dv), ctypes.byref(dp_), ptr(self._opt_sync)))
+                        N.check(L.rlppo_clip_adam_pack2(st, ctypes.byref(dv), ctypes.byref(dp_),
+                                                        ptr(self._opt_sync) if self.one_launch_optimizer else None))
                         va.mark_repacked()
                         pa.mark_repacked()
                         grads_zero = True
@@ -290,10 +307,11 @@ class PPOLearner(object):
         # every pass added one mean to each report statistic; the number of passes travels with the sums, so the report is the
         # mean over the passes of ALL ranks even when the slices do not divide evenly over them (3 slices on 2 ranks)
         self._stats[N.STAT_PASSES] += float(n_passes)
-        all_reduce_sum(self._stats, dist)
+        if world > 1:
+            yield self._stats
         # update magnitudes (ppo_learner.py:214-222: fp32 norms) travel with the statistics: ONE device->host sync per learn()
         mags = torch.stack(((policy_before - pa.flat).norm(), (critic_before - va.flat).norm()))
-        stats = torch.cat((self._stats, mags.double(), self._opt_sync[6:7].double())).cpu().numpy()
+        stats = torch.cat((self._stats, mags.double(), self._opt_sync[N.OPT_SYNC_TIMEOUT_WORD:N.OPT_SYNC_TIMEOUT_WORD + 1].double())).cpu().numpy()
         if stats[N.N_STATS + 2] != 0:  # a barrier wait of the fused optimiser step gave up: that step wrote NaN parameters
             raise RuntimeError("rlppo_clip_adam_pack2: %d grid-barrier wait(s) timed out; the parameters of the affected "
                                "network are NaN (GPU shared with a kernel that never yields, or a defect)" % int(stats[N.N_STATS + 2]))

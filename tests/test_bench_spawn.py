@@ -33,3 +33,14 @@ def test_three_ranks_and_argument_relay():
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads(r.stdout.strip().splitlines()[-1])
     assert line["n_gpus"] == 3 and line["steps"] == 7
+
+
+def test_eight_ranks_the_drivers_top_configuration():
+    """N = 8 (BASELINE configs[3], the last point of the driver's scaling run) through the same launch path: 8 fresh children of
+    torch.distributed.run, rendezvous on 127.0.0.1, one collective spanning all 8, ONE JSON line with n_gpus = 8."""
+    r = _run(["--gpus", "8", "--steps", "2", "--warmup", "1"], {"RLPPO_BENCH_DRYRUN": "2", "OMP_NUM_THREADS": "1"})
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 8 and line["hip_initialised"] is False

@@ -83,3 +83,31 @@ def test_two_rank_update_equals_single_rank():
         for k in ("Policy Entropy", "Mean KL Divergence", "Value Function Loss", "SB3 Clip Fraction"):
             assert abs(report[k] - ref_report[k]) <= 1e-5 * max(abs(ref_report[k]), 1e-3), k
     assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1])  # replicas stay bit-identical
+
+
+def test_virtual_ranks_driver_sums_in_rank_order_and_keeps_lock_step():
+    """dp.run_virtual_ranks (N ranks in one process: how BASELINE configs[3]'s 8-way partition runs on a one-GPU box) against
+    stand-in replicas: every exchange hands each replica the rank-ordered sum, the generators' return values come back per rank,
+    and a replica that stops exchanging early is reported instead of deadlocking or being summed short."""
+    from rlgym_ppo_amd import dp
+
+    class Replica:
+        def __init__(self, rank, steps):
+            self.rank, self.steps, self.seen = rank, steps, []
+
+        def learn_steps(self, buf, rank, world):
+            assert rank == self.rank and world == 4
+            for s in range(self.steps):
+                g = torch.full((5,), float(10 ** rank + s))
+                yield g
+                self.seen.append(g.clone())
+            return {"rank": rank, "buf": buf}
+
+    reps = [Replica(r, 3) for r in range(4)]
+    out = dp.run_virtual_ranks(reps, ["b%d" % r for r in range(4)])
+    assert out == [{"rank": r, "buf": "b%d" % r} for r in range(4)]
+    for s in range(3):
+        want = torch.full((5,), float(sum(10 ** r + s for r in range(4))))
+        assert all(torch.equal(rep.seen[s], want) for rep in reps)
+    with pytest.raises(RuntimeError, match="out of step"):
+        dp.run_virtual_ranks([Replica(0, 3), Replica(1, 2), Replica(2, 3), Replica(3, 3)], [None] * 4)
