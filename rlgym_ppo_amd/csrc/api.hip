@@ -214,6 +214,8 @@ static int forward_pingpong(hipStream_t st, const NetLayout &net, const float *p
 
 using namespace rlppo;
 
+static int g_fused_act = 1;  // rlppo_dbg_set(27, 0/1): rlppo_discrete_act as one fused launch (fused_act.hip)
+
 extern "C" {
 
 int rlppo_abi_version(void) { return RLPPO_ABI_VERSION; }
@@ -286,6 +288,10 @@ int rlppo_discrete_act(void *stream, const int32_t *dims, int32_t n_layers, cons
     if (rc) return rc;
     if (n == 0) return 0;
     RLPPO_CHECK_ARG(n > 0 && packed && obs && noise_q && actions && logp && workspace, "discrete_act: bad argument");
+    // [r3] one launch for the whole step when the network has the form fused_act.hip covers (fp32 inference precision); the
+    // layer-by-layer chain below otherwise -- bit-identical results either way
+    if (g_fused_act && !get_infer_bf16() && fused_act_ok(net, ld_obs))
+        return launch_discrete_act_fused((hipStream_t)stream, net, packed, obs, ld_obs, n, noise_q, actions, logp, probs_out);
     const float *o;
     int64_t ldo;
     rc = forward_pingpong((hipStream_t)stream, net, packed, obs, ld_obs, n, 0, workspace, ws_bytes, nullptr, &o, &ldo);
@@ -933,6 +939,7 @@ int rlppo_dbg_set(int32_t key, int32_t value) {
         case 23: set_b16_wide_tiles(value); return 0;
         case 24: set_exp_fast_transform(value); return 0;
         case 26: g_fused_gather = value; return 0;
+        case 27: g_fused_act = value; return 0;
         default: break;
     }
     set_error("dbg_set: unknown key %d", key);

@@ -150,6 +150,11 @@ int launch_gaussian_loss(hipStream_t, float *, int64_t, int, float *, int64_t, c
 int launch_multidiscrete_loss(hipStream_t, float *, int64_t, float *, int64_t, const int64_t *, const float *, const float *,
                               const float *, const float *, int64_t, const LossCfg &, double *);
 
+// fused_act.hip: the whole rollout step of the discrete policy in one launch ----------------
+bool fused_act_ok(const NetLayout &net, int64_t ld_rows);
+int launch_discrete_act_fused(hipStream_t st, const NetLayout &net, const float *packed, const float *rows, int64_t ld_rows, int64_t n,
+                              const float *noise, int64_t *actions, float *logp, float *probs_out);
+
 // gae.hip ---------------------------------------------------------------------------------------------
 size_t gae_workspace_bytes(int64_t n);
 void set_gae_algo(int algo);

@@ -1,0 +1,298 @@
+// fused_act.hip -- the rollout step of the discrete policy in ONE launch (reference:
+// rlgym_ppo/ppo/discrete_policy.py:35-62: MLP -> softmax -> clamp -> multinomial (= argmax(p / q)) -> log p).
+//
+// At rollout sizes (8 ... 4096 observations per call) the layer-by-layer chain of rlppo_discrete_act is latency, not work:
+// 4 GEMM launches of 64 workgroups each + the sampling kernel take 76 us for 1.5 GFLOP at 4096 rows
+// (tools/rollout_breakdown.py).  Here a workgroup of 4 waves owns 16 observation rows and carries them through every layer:
+//   * activations never leave the CU: a layer's output is written into LDS in exactly the K-step-major, swizzled image the
+//     next layer's MFMA fragments are read from (the A-tile image of gemm_nt_dma_kernel);
+//   * a wave computes its own quarter of a layer's outputs, so the weights it needs are its own: every wave streams ITS rows of
+//     W (packed copy, 0.73 MB for the 256x3 policy: L2-resident) through a private ring of 4 LDS tiles by LDS-DMA, three K-steps
+//     ahead, ACROSS layer boundaries (weights do not depend on activations) and waits with counted vmcnt -- no workgroup barrier
+//     in the K loop, one per layer for the activations;
+//   * the head's logits go to LDS and the 4 waves sample 4 rows each with the code of discrete_sample_kernel.
+// Arithmetic is that of the chain, operation for operation (accumulators start from the bias, k in tiles of 16 through the same
+// v_mfma_f32_16x16x4_f32 sequence, relu as v_med3, the same softmax / division / arg-max order): logits, actions and
+// log-probabilities are BIT-identical to the layer-by-layer path (tests/test_gpu_kernels.py).
+#include "gemm_detail.hpp"
+
+namespace rlppo {
+
+namespace {
+constexpr int FA_ROWS = 16;      // observation rows per workgroup (the MFMA's 16 columns)
+constexpr int FA_STAGES = 4;     // weight tiles per wave in flight / being read
+constexpr int FA_MAX_LAYERS = 6;
+constexpr float FA_PROB_MIN = 1e-11f;
+}  // namespace
+
+struct FusedActArgs {
+    const float *rows;       // [n][ld_rows] zero-padded observation rows
+    unsigned ld_rows;        // floats
+    int64_t n;
+    const float *packed;     // rlppo_net_pack image
+    int n_layers;
+    int k[FA_MAX_LAYERS];          // padded contraction width of layer l
+    int nblk[FA_MAX_LAYERS];       // 16-wide output blocks of layer l (H / 16 for hidden layers, padded head width / 16 for the last)
+    int64_t off_w[FA_MAX_LAYERS], off_b[FA_MAX_LAYERS];  // float offsets into packed
+    int A;                   // actions
+    const float *noise;      // [n][A] Exp(1)
+    int64_t *actions;
+    float *logp;
+    float *probs_out;        // optional [n][A]
+};
+
+// JH: output blocks a wave owns in a hidden layer (H = 64 JH); the head's blocks are dealt JO = ceil(nblk / 4) per wave.
+template <int JH>
+__global__ __launch_bounds__(256, 1) void discrete_act_fused_kernel(FusedActArgs a) {
+    constexpr int H = 64 * JH;
+    constexpr int TILE = JH * 16 * 16;  // floats of one wave's weight tile (JH*16 rows x 16 k)
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float *act0 = lds;                        // [H/16 k-steps][16 rows][16] swizzled (also holds the staged input rows)
+    float *act1 = lds + H * FA_ROWS;
+    float *wring = lds + 2 * H * FA_ROWS;     // [4 waves][FA_STAGES][TILE]
+    float *biasl = wring + 4 * FA_STAGES * TILE;  // [FA_MAX_LAYERS][H]: the biases, so that no register-destination load sits in the weight stream's vmcnt window
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const int r16 = lane & 15, q = lane >> 4;
+    const int64_t row0 = (int64_t)blockIdx.x * FA_ROWS;
+    const int last = a.n_layers - 1;
+    float *const wr = wring + wave_u * FA_STAGES * TILE;
+
+    // ---- weight stream of this wave: step t of the whole network = (layer pl, k-tile pkt); every step that exists issues exactly
+    // JH pieces (pieces whose rows this wave does not own in that layer -- the head's surplus -- fall outside the descriptor: they
+    // move no data but keep the vmcnt arithmetic uniform)
+    const int lr = lane >> 2, pch = lane & 3;
+    const int lch = pch ^ ((0 - (lr >> 2)) & 3);
+    int pl = 0, pkt = 0, issued = 0;
+    auto layer_rsrc = [&](int l) {
+        const int own = l == last ? (a.nblk[l] + 3) / 4 : JH;            // blocks per wave in this layer
+        int rows = a.nblk[l] * 16 - wave_u * own * 16;                     // rows of W this wave streams
+        rows = rows < 0 ? 0 : (rows > own * 16 ? own * 16 : rows);
+        return make_rsrc(a.packed + a.off_w[l] + (int64_t)wave_u * own * 16 * a.k[l], (unsigned)rows * (unsigned)a.k[l] * 4u);
+    };
+    __amdgpu_buffer_rsrc_t w_rs = layer_rsrc(0);
+    unsigned w_off = (unsigned)lr * (unsigned)a.k[0] * 4u + lch * 16;
+    unsigned w_row16 = 16u * (unsigned)a.k[0] * 4u;
+    auto issue_next = [&]() {
+        if (pl > last) return;  // past the network's end (the waits below count what is really in flight)
+        float *dst = wr + (issued % FA_STAGES) * TILE;
+#pragma unroll
+        for (int i = 0; i < JH; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rs, dst + i * 256, 16, w_off, (unsigned)pkt * 64u + i * w_row16, 0, 0);
+        ++issued;
+        if (++pkt == a.k[pl] / 16) {
+            pkt = 0;
+            ++pl;
+            if (pl <= last) {
+                w_rs = layer_rsrc(pl);
+                w_off = (unsigned)lr * (unsigned)a.k[pl] * 4u + lch * 16;
+                w_row16 = 16u * (unsigned)a.k[pl] * 4u;
+            }
+        }
+    };
+#pragma unroll
+    for (int s = 0; s < FA_STAGES - 1; ++s) issue_next();
+
+    for (int l = 0; l <= last; ++l)
+        for (int c = tid; c < a.nblk[l] * 16; c += 256) biasl[l * H + c] = a.packed[a.off_b[l] + c];
+    // ---- stage the 16 observation rows into act0 (K-step-major image), zero rows past n
+    {
+        const int cpr = a.k[0] / 4;  // 16-byte chunks per row
+        for (int c = tid; c < FA_ROWS * cpr; c += 256) {
+            const int r = c / cpr, ch = c - r * cpr;
+            f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (row0 + r < a.n) v = *reinterpret_cast<const f32x4 *>(a.rows + (row0 + r) * (int64_t)a.ld_rows + ch * 4);
+            *reinterpret_cast<f32x4 *>(&act0[(ch >> 2) * 256 + dswz<16>(r, ch & 3)]) = v;
+        }
+    }
+    __syncthreads();  // (drains the stream's first tiles too: once per launch)
+
+    float *cur = act0, *nxt = act1;
+    int consumed = 0;
+    for (int l = 0; l <= last; ++l) {
+        const bool head = l == last;
+        const int own = head ? (a.nblk[l] + 3) / 4 : JH;
+        const int jb0 = wave_u * own;                    // first output block of this wave
+        const int nj = head ? (a.nblk[l] - jb0 < own ? (a.nblk[l] - jb0 < 0 ? 0 : a.nblk[l] - jb0) : own) : JH;
+        f32x4 acc[JH];
+#pragma unroll
+        for (int j = 0; j < JH; ++j) {
+            acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (j < nj) acc[j] = *reinterpret_cast<const f32x4 *>(&biasl[l * H + (jb0 + j) * 16 + q * 4]);
+        }
+        const int nk = a.k[l] / 16;
+        for (int kt = 0; kt < nk; ++kt) {
+            issue_next();  // keeps FA_STAGES - 1 tiles in flight behind the one about to be read
+            // all but the pieces of the `ahead` tiles issued behind this step's have landed: the tile of this step is in LDS
+            // (vmcnt immediates: ahead * JH; ahead < FA_STAGES - 1 only in the network's last steps)
+            const int ahead = issued - consumed - 1;
+            if (ahead >= 3) {
+                if (JH == 4) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+                else if (JH == 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+            } else if (ahead == 2) {
+                if (JH == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                else if (JH == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            } else if (ahead == 1) {
+                if (JH == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                else if (JH == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            const float *wt = wr + (consumed % FA_STAGES) * TILE;
+            ++consumed;
+            const f32x4 fa = *reinterpret_cast<const f32x4 *>(&cur[kt * 256 + dswz<16>(r16, q)]);
+            f32x4 fb[JH];
+#pragma unroll
+            for (int j = 0; j < JH; ++j) fb[j] = *reinterpret_cast<const f32x4 *>(&wt[dswz<16>(j * 16 + r16, q)]);
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int j = 0; j < JH; ++j) acc[j] = MFMA16(fb[j][s], fa[s], acc[j]);
+        }
+        if (!head) {
+            // relu, then straight into the next layer's fragment image: block jb = k-step jb, row r16, chunk q
+#pragma unroll
+            for (int j = 0; j < JH; ++j) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[j][e] = relu1(acc[j][e]);
+                *reinterpret_cast<f32x4 *>(&nxt[(jb0 + j) * 256 + dswz<16>(r16, q)]) = acc[j];
+            }
+        } else {
+            // logits, row-major [16][nblk*16] in the free activation buffer
+            const int ldz = a.nblk[l] * 16;
+#pragma unroll
+            for (int j = 0; j < JH; ++j)
+                if (j < nj) *reinterpret_cast<f32x4 *>(&nxt[r16 * ldz + (jb0 + j) * 16 + q * 4]) = acc[j];
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();  // raw: the weight tiles in flight stay in flight
+        float *t = cur;
+        cur = nxt;
+        nxt = t;
+    }
+
+    // ---- sampling: wave w takes rows 4 w .. 4 w + 3; element c = lane + 64 e (discrete_sample_kernel<2, false>, op for op)
+    const int A = a.A, ldz = a.nblk[last] * 16;
+    for (int rr = 0; rr < 4; ++rr) {
+        const int r = wave * 4 + rr;
+        const int64_t row = row0 + r;
+        if (row >= a.n) break;
+        const float *z = cur + r * ldz;
+        float p[2], pc[2];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int c = lane + 64 * e;
+            p[e] = c < A ? z[c] : -INFINITY;
+            mx = fmaxf(mx, p[e]);
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+        float s = 0.f;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int c = lane + 64 * e;
+            p[e] = c < A ? expf(p[e] - mx) : 0.f;
+            s += p[e];
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            p[e] = p[e] / s;
+            pc[e] = fminf(fmaxf(p[e], FA_PROB_MIN), 1.0f);
+        }
+        float best = -INFINITY, bestp = 1.f;
+        int besti = 0x7fffffff;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int c = lane + 64 * e;
+            if (c < A) {
+                const float v = pc[e] / a.noise[row * A + c];  // IEEE fp32 division, as at::div
+                if (v > best) {
+                    best = v;
+                    besti = c;
+                    bestp = pc[e];
+                }
+                if (a.probs_out) a.probs_out[row * A + c] = pc[e];
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(best, o);
+            const int oi = __shfl_xor(besti, o);
+            const float op = __shfl_xor(bestp, o);
+            if (ov > best || (ov == best && oi < besti)) {
+                best = ov;
+                besti = oi;
+                bestp = op;
+            }
+        }
+        if (lane == 0) {
+            a.actions[row] = besti;
+            a.logp[row] = logf(bestp);
+        }
+    }
+}
+
+// Does the network have the form the fused kernel covers?  n_layers in [2, 6]; all hidden widths equal, 64 / 128 / 256; the first
+// layer's padded input at most the hidden width; at most 128 actions.
+bool fused_act_ok(const NetLayout &net, int64_t ld_rows) {
+    if (net.n_layers < 2 || net.n_layers > FA_MAX_LAYERS) return false;
+    const int H = net.L[0].pout;
+    if (H != 64 && H != 128 && H != 256) return false;
+    for (int l = 0; l + 1 < net.n_layers; ++l)
+        if (net.L[l].pout != H || net.L[l].out != H) return false;
+    const LayerLayout &o = net.L[net.n_layers - 1];
+    if (o.out > 128 || o.pout > 128 || o.pout > H) return false;
+    if (net.L[0].pin > H || net.L[0].pin % 16 != 0 || ld_rows < net.L[0].pin || ld_rows % 4 != 0) return false;
+    return true;
+}
+
+int launch_discrete_act_fused(hipStream_t st, const NetLayout &net, const float *packed, const float *rows, int64_t ld_rows, int64_t n,
+                              const float *noise, int64_t *actions, float *logp, float *probs_out) {
+    if (n <= 0) return 0;
+    FusedActArgs a;
+    a.rows = rows;
+    a.ld_rows = (unsigned)ld_rows;
+    a.n = n;
+    a.packed = packed;
+    a.n_layers = net.n_layers;
+    for (int l = 0; l < net.n_layers; ++l) {
+        a.k[l] = net.L[l].pin;
+        a.nblk[l] = net.L[l].pout / 16;
+        a.off_w[l] = net.L[l].off_w;
+        a.off_b[l] = net.L[l].off_b;
+    }
+    a.A = net.L[net.n_layers - 1].out;
+    a.noise = noise;
+    a.actions = actions;
+    a.logp = logp;
+    a.probs_out = probs_out;
+    const int H = net.L[0].pout, JH = H / 64;
+    const size_t lds_bytes = (size_t)(2 * H * FA_ROWS + 4 * FA_STAGES * JH * 256 + FA_MAX_LAYERS * H) * sizeof(float);
+    dim3 grid((unsigned)cdiv(n, FA_ROWS));
+    static bool attr_set[3] = {};
+#define FA_LAUNCH(J, SLOT)                                                                                                       \
+    do {                                                                                                                         \
+        if (!attr_set[SLOT]) { /* up to 102 KiB of dynamic LDS (H = 256): above the default 64 KiB limit */                      \
+            RLPPO_HIP(hipFuncSetAttribute((const void *)discrete_act_fused_kernel<J>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                          (int)((2 * 64 * J * FA_ROWS + 4 * FA_STAGES * J * 256 + FA_MAX_LAYERS * 64 * J) * 4)));   \
+            attr_set[SLOT] = true;                                                                                               \
+        }                                                                                                                        \
+        hipLaunchKernelGGL((discrete_act_fused_kernel<J>), grid, dim3(256), lds_bytes, st, a);                                    \
+    } while (0)
+    switch (JH) {
+        case 4: FA_LAUNCH(4, 0); break;
+        case 2: FA_LAUNCH(2, 1); break;
+        default: FA_LAUNCH(1, 2); break;
+    }
+#undef FA_LAUNCH
+    RLPPO_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace rlppo

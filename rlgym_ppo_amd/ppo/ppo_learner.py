@@ -182,7 +182,7 @@ class PPOLearner(object):
         self.one_launch_optimizer = os.environ.get("RLPPO_OPT_ONE_LAUNCH", "1") != "0"  # ... as ONE launch with a grid barrier
 
     # --------------------------------------------------------------------------------------------- learn
-    def _minibatch_args(self, exp):
+    def _minibatch_args(self, exp, rank=0, world=1):
         pa, va = self.policy.arena, self.value_net.arena
         a = N.MinibatchArgs()
         a.head = self.policy_type
@@ -208,8 +208,10 @@ class PPOLearner(object):
             a.var_m, a.var_b = float(self.policy.affine_map.m), float(self.policy.affine_map.b)
         a.stats = self._stats.data_ptr()
         # one activation workspace per slot: minibatches in different slots overlap on the GPU (rlppo_ppo_join)
+        # rows of the largest pass THIS rank launches: its share of a batch's slices, fused (8 ranks x 8 slices: one 65,536-row pass)
         n_slices = self.batch_size // self.mini_batch_size
-        self._fused_rows = self.mini_batch_size * min(self.max_fused_minibatches, max(1, n_slices))
+        runs = fuse_runs(slices_for_rank(max(1, n_slices), rank, world), self.max_fused_minibatches)
+        self._fused_rows = self.mini_batch_size * max([cnt for _, cnt in runs] or [1])
         nbytes = int(N.lib().rlppo_minibatch_workspace_bytes(pa.dims_c, pa.n_layers, va.dims_c, va.n_layers, self._fused_rows))
         nbytes = (nbytes + 255) // 256 * 256
         ws = self._ws.get(nbytes * self.n_slots)
@@ -255,7 +257,7 @@ class PPOLearner(object):
         if n_batches > 0 and total > 0:
             if exp.ring()[0]["actions"][:1].reshape(1, -1).shape[1] != self._act_dim:
                 raise ValueError("experience buffer action width does not match the policy head")
-            args = self._minibatch_args(exp)
+            args = self._minibatch_args(exp, rank, world)
             st = stream_ptr()
             # The legacy-MT19937 permutation is inherently serial host work.  The buffer's shuffle pipeline draws it on
             # helper threads several epochs ahead (also across learn() calls) and uploads every index vector on its own

@@ -536,6 +536,49 @@ def test_g1_discrete_act(L, golden):
     np.testing.assert_allclose(lp2.cpu().numpy(), g["logp"], rtol=1e-6, atol=1e-6)
 
 
+@pytest.mark.parametrize("d,hidden,A", [(107, (256, 256, 256), 90), (107, (64, 64), 90), (20, (128, 128, 128, 128), 7), (231, (256, 256), 128),
+                                        (13, (64,), 5)])
+def test_fused_rollout_step_is_bit_identical_to_the_layer_chain(L, d, hidden, A):
+    """[r3] rlppo_discrete_act as ONE launch (csrc/fused_act.hip, SURVEY K1: MLP -> softmax -> clamp -> argmax(p/q) -> log p with the
+    activations in LDS and every wave streaming its own weight rows) against the layer-by-layer chain it replaces
+    (rlppo_dbg_set(27, 0)): clamped probabilities, actions and log-probabilities must agree BIT for bit, for one row, exactly one
+    row tile, ragged counts and the 4096-row rollout shape; several launches in a row (the weight ring's tail waits)."""
+    torch.manual_seed(d + A)
+    net = Net(L, nets.init_mlp(d, hidden, A))
+    rs = np.random.RandomState(d)
+    for n in (1, 16, 17, 250, 4096, 5000):
+        rows = net.pad(np.clip(rs.randn(n, d) * 2, -5, 5).astype(np.float32))
+        q = dev(rs.exponential(size=(n, A)).astype(np.float32))
+        outs = []
+        for fused in (1, 0, 1):
+            act = torch.full((n,), -7, dtype=torch.int64, device="cuda")
+            logp = torch.full((n,), float("nan"), device="cuda")
+            probs = torch.full((n, A), float("nan"), device="cuda")
+            w = net.ws(n)
+            check(L, L.rlppo_dbg_set(27, fused))
+            try:
+                check(L, L.rlppo_discrete_act(stream(), net.dims_c, net.nl, P(net.packed), P(rows), net.ld_in, n, P(q), P(act), P(logp),
+                                              P(probs), P(w), w.numel()))
+            finally:
+                check(L, L.rlppo_dbg_set(27, 1))
+            outs.append((act.cpu(), logp.cpu(), probs.cpu()))
+        for a, lp, pr in outs[1:]:
+            assert torch.equal(outs[0][0], a) and torch.equal(outs[0][1], lp) and torch.equal(outs[0][2], pr), (n, d, hidden, A)
+        assert (outs[0][0] >= 0).all() and (outs[0][0] < A).all() and not torch.isnan(outs[0][2]).any()
+    # and against the oracle at the rollout shape (the chain's own test bound: near-ties only)
+    n = 512
+    obs = np.clip(rs.randn(n, d), -5, 5).astype(np.float32)
+    qh = nets.draw_exp_noise(n, A)
+    act = torch.empty(n, dtype=torch.int64, device="cuda")
+    logp = torch.empty(n, device="cuda")
+    w = net.ws(n)
+    check(L, L.rlppo_discrete_act(stream(), net.dims_c, net.nl, P(net.packed), P(net.pad(obs)), net.ld_in, n, P(dev(qh)), P(act), P(logp),
+                                  None, P(w), w.numel()))
+    oact, ologp = nets.discrete_sample(nets.discrete_probs(net.params, obs), qh)
+    same = act.cpu() == oact
+    assert (~same).sum().item() <= 2 and (logp.cpu() - ologp)[same].abs().max().item() < 1e-5
+
+
 @pytest.mark.parametrize("A", [90, 300, 1000])
 def test_discrete_probs_and_deterministic_choice(L, golden, A):
     """rlppo_discrete_probs = DiscreteFF.get_output (softmax) and the deterministic branch of get_action: clamp(1e-11, 1), then
