@@ -93,6 +93,21 @@ int rlppo_discrete_act(void *stream, const int32_t *dims, int32_t n_layers, cons
                        const float *obs, int64_t ld_obs, int64_t n, const float *noise_q,
                        int64_t *actions, float *logp, float *probs_out, void *workspace, size_t ws_bytes);
 
+/* The whole rollout step of the discrete policy [r3] (discrete_policy.py:35-62 behind batched_agent_manager.py:202-204,303-315):
+ * raw observations as the environment hands them over ([n][ld_obs] fp32 or fp64, d = dims[0] features) -> standardise
+ * (0: no; 1: the reference's scalars of feature 0, clip((x - mean0) / std0, -5, 5); 2: per-feature vectors mean_v / std_v) and
+ * zero-pad -> MLP -> softmax -> clamp -> argmax(p / q) -> log p.  One launch when the network has the form csrc/fused_act.hip
+ * covers (equal hidden widths of 64 / 128 / 256, <= 128 actions, fp32 inference precision), else rlppo_pad_rows + the chain of
+ * rlppo_discrete_act: the same numbers, bit for bit.  Outputs: actions (int64; may be pinned host memory, like logp: the kernel
+ * stores straight into it), actions_f32 (optional: the index as float, the experience buffer's encoding), logp, rows_out
+ * (optional: the padded, standardised rows [n][ld_rows_out] -- the policy-input rows a device-resident rollout stores).
+ * workspace: rlppo_discrete_step_workspace_bytes(dims, n_layers, n). */
+size_t rlppo_discrete_step_workspace_bytes(const int32_t *dims, int32_t n_layers, int64_t n);
+int rlppo_discrete_step(void *stream, const int32_t *dims, int32_t n_layers, const float *packed, const void *obs, int32_t obs_is_f64,
+                        int64_t ld_obs, int64_t n, int32_t standardize, float mean0, float std0, const float *mean_v,
+                        const float *std_v, const float *noise_q, int64_t *actions, float *actions_f32, float *logp, float *rows_out,
+                        int64_t ld_rows_out, void *workspace, size_t ws_bytes);
+
 /* DiscreteFF.get_output (discrete_policy.py:34-42) and the deterministic branch of get_action (:52-57).
  * probs_out (optional): float[n][ld_probs] = softmax of the head (clamp_probs = 0, get_output) or clamp(softmax, 1e-11, 1)
  * (clamp_probs = 1, what get_action works on).  flat_argmax (optional): int64[1] = numpy's argmax over the FLATTENED clamped

@@ -72,6 +72,9 @@ SIGNATURES = {
                                     c_int64, c_void_p, c_size_t]),
     "rlppo_discrete_act": (c_int32, [c_void_p, _P32, c_int32, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p,
                                      c_void_p, c_void_p, c_void_p, c_size_t]),
+    "rlppo_discrete_step_workspace_bytes": (c_size_t, [_P32, c_int32, c_int64]),
+    "rlppo_discrete_step": (c_int32, [c_void_p, _P32, c_int32, c_void_p, c_void_p, c_int32, c_int64, c_int64, c_int32, c_float, c_float,
+                                      c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_size_t]),
     "rlppo_discrete_probs": (c_int32, [c_void_p, _P32, c_int32, c_void_p, c_void_p, c_int64, c_int64, c_int32, c_void_p,
                                        c_int64, c_void_p, c_void_p, c_size_t]),
     "rlppo_categorical_select": (c_int32, [c_void_p, c_void_p, c_int64, c_int64, c_int32, c_void_p, c_void_p, c_void_p]),

@@ -44,6 +44,7 @@ class VectorAgentManager(object):
         self.n_agents = 0
         self.value_input_rows = None  # [N + 1, ld] device rows of the last collect: states ++ the last next_state
         self._next_rows = None        # padded device rows of the observation the agents act on next
+        self._pending_obs = None      # fused collect: (raw device observations, standardisation scalars) the agents act on next
         self._ep_rews = None
 
     # same signature as BatchedAgentManager.init_processes (learner.py:140-150); n_processes is ignored
@@ -76,6 +77,69 @@ class VectorAgentManager(object):
     def collect_timesteps(self, n):
         """-> ((states, actions, log_probs, rewards, next_states, dones, truncated), metrics, n_collected, seconds):
         device tensors in trajectory-major order; `self.value_input_rows` holds states ++ last next_state contiguously."""
+        if getattr(self.policy, "fused_step", False):
+            return self._collect_fused(n)
+        return self._collect_chain(n)
+
+    def _collect_fused(self, n):
+        """[r3] The discrete policy's step is ONE launch (DiscreteFF.step -> rlppo_discrete_step): it standardises and pads the raw
+        observations of step t straight into the rollout storage, runs the policy, stores the action (as the buffer's float
+        encoding) and the log-probability into the storage and the action indices into pinned host memory for the environment.
+        The storage is TIME-major while collecting (everything a step writes is contiguous: no scatter copies) and is transposed
+        into the reference's trajectory-major order once per collect.  Same numbers as _collect_chain, bit for bit."""
+        t1 = time.perf_counter()
+        arena = self.policy.arena
+        dev, ld, na = arena.device, arena.ld_in, self.n_agents
+        T = max(1, -(-int(n) // na))
+        N_ = na * T
+        S = torch.empty((T + 1, na, ld), dtype=torch.float32, device=dev)     # S[t] = policy-input rows of step t; S[T]: the next collect's
+        acts_tm = torch.empty((T, na), dtype=torch.float32, device=dev)
+        logp_tm = torch.empty((T, na), dtype=torch.float32, device=dev)
+        rews = np.empty((na, T), np.float32)
+        dones = np.empty((na, T), np.float32)
+        trunc = np.empty((na, T), np.float32)
+        metrics = []
+        if self._pending_obs is None:  # first collect: the reset observations are acted on RAW (batched_agent_manager.py:366-384)
+            self._pending_obs = (torch.from_numpy(np.ascontiguousarray(self._initial_obs)).to(dev), None)
+        obs_dev, scalars = self._pending_obs
+        for t in range(T):
+            a_host, _ = self.policy.step(obs_dev, standardize=scalars, rows_out=S[t], actions_f32=acts_tm[t], logp_out=logp_tm[t],
+                                         to_host="actions")
+            step = self.env.step(a_host.numpy().astype(np.float32).reshape(na, -1))
+            if len(step) == 4:
+                obs, r, d, info = step
+                tr = np.zeros(na, np.float32)
+            else:
+                obs, r, d, tr, info = step
+            obs = np.asarray(obs, dtype=np.float32)
+            obs_dev = torch.from_numpy(np.ascontiguousarray(obs)).to(dev, non_blocking=True)   # raw observations: one upload per step
+            rews[:, t], dones[:, t], trunc[:, t] = r, d, tr
+            if self.collect_metrics_fn is not None:
+                metrics.append(self.collect_metrics_fn(info["state"]))
+            scalars = self._standardize_scalars()  # fetched BEFORE this step's increment (batched_agent_manager.py:230-235)
+            if self.standardize_obs:  # same cadence as one worker response per step
+                if self.steps_since_obs_stats_update > self.steps_per_obs_stats_increment:
+                    self._increment_obs_stats(obs_dev)
+                    self.steps_since_obs_stats_update = 0
+                else:
+                    self.steps_since_obs_stats_update += 1
+            self._track_rewards(rews[:, t], (dones[:, t] + trunc[:, t]) > 0)
+        arena.stage_obs(obs_dev, scalars, out=S[T])          # the rows the agents act on next = next_states of the last step
+        self._pending_obs = (obs_dev, scalars)
+        flat = torch.empty((N_ + 1, ld), dtype=torch.float32, device=dev)
+        nxt_flat = torch.empty((N_, ld), dtype=torch.float32, device=dev)
+        flat[:N_].view(na, T, ld).copy_(S[:T].transpose(0, 1))               # time-major -> trajectory-major, once
+        nxt_flat.view(na, T, ld).copy_(S[1:].transpose(0, 1))
+        flat[N_].copy_(S[T][na - 1])                         # next_states[-1]: what add_new_experience appends (learner.py:347)
+        trunc[:, T - 1] = np.where(dones[:, T - 1] == 0, 1.0, 0.0)   # flush rule (quirk Q4)
+        up = lambda x: torch.from_numpy(np.ascontiguousarray(x.reshape(-1))).to(dev)
+        self.value_input_rows = flat
+        self._next_rows = S[T]
+        self.cumulative_timesteps += N_
+        experience = (flat[:N_], acts_tm.t().reshape(N_, 1), logp_tm.t().reshape(N_), up(rews), nxt_flat, up(dones), up(trunc))
+        return experience, metrics, N_, time.perf_counter() - t1
+
+    def _collect_chain(self, n):
         t1 = time.perf_counter()
         arena = self.policy.arena
         dev, ld, na = arena.device, arena.ld_in, self.n_agents

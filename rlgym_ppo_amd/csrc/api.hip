@@ -290,13 +290,86 @@ int rlppo_discrete_act(void *stream, const int32_t *dims, int32_t n_layers, cons
     RLPPO_CHECK_ARG(n > 0 && packed && obs && noise_q && actions && logp && workspace, "discrete_act: bad argument");
     // [r3] one launch for the whole step when the network has the form fused_act.hip covers (fp32 inference precision); the
     // layer-by-layer chain below otherwise -- bit-identical results either way
-    if (g_fused_act && !get_infer_bf16() && fused_act_ok(net, ld_obs))
-        return launch_discrete_act_fused((hipStream_t)stream, net, packed, obs, ld_obs, n, noise_q, actions, logp, probs_out);
+    if (g_fused_act && !get_infer_bf16() && fused_act_ok(net) && ld_obs >= net.L[0].pin && ld_obs % 4 == 0) {
+        FusedActIO io;
+        io.rows = obs;
+        io.ld_rows = ld_obs;
+        io.noise = noise_q;
+        io.actions = actions;
+        io.logp = logp;
+        io.probs_out = probs_out;
+        return launch_discrete_act_fused((hipStream_t)stream, net, packed, io, n);
+    }
     const float *o;
     int64_t ldo;
     rc = forward_pingpong((hipStream_t)stream, net, packed, obs, ld_obs, n, 0, workspace, ws_bytes, nullptr, &o, &ldo);
     if (rc) return rc;
     return launch_discrete_sample_logits((hipStream_t)stream, o, ldo, n, dims[n_layers], noise_q, actions, logp, probs_out);
+}
+
+size_t rlppo_discrete_step_workspace_bytes(const int32_t *dims, int32_t n_layers, int64_t n) {
+    NetLayout net;
+    if (make_layout(dims, n_layers, &net)) return 0;
+    n = n > 0 ? n : 0;
+    return forward_ws_floats(net, n) * sizeof(float) + ((size_t)n * net.L[0].pin * sizeof(float) + 255) / 256 * 256 + 512;
+}
+
+int rlppo_discrete_step(void *stream, const int32_t *dims, int32_t n_layers, const float *packed, const void *obs, int32_t obs_is_f64,
+                        int64_t ld_obs, int64_t n, int32_t standardize, float mean0, float std0, const float *mean_v,
+                        const float *std_v, const float *noise_q, int64_t *actions, float *actions_f32, float *logp, float *rows_out,
+                        int64_t ld_rows_out, void *workspace, size_t ws_bytes) {
+    NetLayout net;
+    int rc = make_layout(dims, n_layers, &net);
+    if (rc) return rc;
+    if (n == 0) return 0;
+    const int d = net.L[0].in, pin = net.L[0].pin;
+    RLPPO_CHECK_ARG(n > 0 && packed && obs && noise_q && actions && logp && workspace, "discrete_step: bad argument");
+    RLPPO_CHECK_ARG(ld_obs >= d && standardize >= 0 && standardize <= 2 && (standardize != 2 || (mean_v && std_v)),
+                    "discrete_step: ld_obs=%ld standardize=%d", (long)ld_obs, standardize);
+    RLPPO_CHECK_ARG(!rows_out || ld_rows_out >= pin, "discrete_step: ld_rows_out=%ld < padded width %d", (long)ld_rows_out, pin);
+    hipStream_t st = (hipStream_t)stream;
+    if (g_fused_act && !get_infer_bf16() && fused_act_ok(net)) {
+        FusedActIO io;
+        io.raw = obs;
+        io.raw_is_f64 = obs_is_f64;
+        io.ld_raw = ld_obs;
+        io.standardize = standardize;
+        io.mean0 = mean0;
+        io.std0 = std0;
+        io.mean_v = mean_v;
+        io.std_v = std_v;
+        io.rows_out = rows_out;
+        io.ld_rows_out = ld_rows_out;
+        io.noise = noise_q;
+        io.actions = actions;
+        io.actions_f32 = actions_f32;
+        io.logp = logp;
+        return launch_discrete_act_fused(st, net, packed, io, n);
+    }
+    // the same step launch by launch: pad (+ standardise) into rows_out (or the head of the workspace), forward chain, sample
+    float *rows = rows_out;
+    int64_t ld_rows = ld_rows_out;
+    char *ws = reinterpret_cast<char *>(workspace);
+    if (!rows) {
+        const size_t need = (size_t)n * pin * sizeof(float);
+        RLPPO_CHECK_ARG(ws_bytes >= need + 256, "discrete_step: workspace %zu too small", ws_bytes);
+        rows = reinterpret_cast<float *>(ws);
+        ld_rows = pin;
+        ws += (need + 255) / 256 * 256;
+        ws_bytes -= (need + 255) / 256 * 256;
+    }
+    if (standardize == 2)
+        rc = launch_pad_rows_vec(st, obs, obs_is_f64, n, d, ld_obs, rows, ld_rows, mean_v, std_v);
+    else
+        rc = launch_pad_rows(st, obs, obs_is_f64, n, d, ld_obs, rows, ld_rows, standardize, mean0, std0);
+    if (rc) return rc;
+    const float *o;
+    int64_t ldo;
+    rc = forward_pingpong(st, net, packed, rows, ld_rows, n, 0, ws, ws_bytes, nullptr, &o, &ldo);
+    if (rc) return rc;
+    rc = launch_discrete_sample_logits(st, o, ldo, n, dims[n_layers], noise_q, actions, logp, nullptr);
+    if (rc || !actions_f32) return rc;
+    return launch_i64_to_f32(st, actions, actions_f32, n);
 }
 
 int rlppo_discrete_probs(void *stream, const int32_t *dims, int32_t n_layers, const float *packed, const float *obs,

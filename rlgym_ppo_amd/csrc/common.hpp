@@ -151,9 +151,23 @@ int launch_multidiscrete_loss(hipStream_t, float *, int64_t, float *, int64_t, c
                               const float *, const float *, int64_t, const LossCfg &, double *);
 
 // fused_act.hip: the whole rollout step of the discrete policy in one launch ----------------
-bool fused_act_ok(const NetLayout &net, int64_t ld_rows);
-int launch_discrete_act_fused(hipStream_t st, const NetLayout &net, const float *packed, const float *rows, int64_t ld_rows, int64_t n,
-                              const float *noise, int64_t *actions, float *logp, float *probs_out);
+struct FusedActIO {
+    const float *rows = nullptr;  // padded rows [n][ld_rows] ...
+    int64_t ld_rows = 0;
+    const void *raw = nullptr;    // ... or raw observations [n][ld_raw] (fp32 / fp64) + the standardisation of rlppo_pad_rows(_per_feature)
+    int raw_is_f64 = 0, standardize = 0;  // 0 none, 1 scalars (mean0, std0), 2 per-feature vectors
+    int64_t ld_raw = 0;
+    float mean0 = 0.f, std0 = 1.f;
+    const float *mean_v = nullptr, *std_v = nullptr;
+    float *rows_out = nullptr;    // optional: the padded rows, [n][ld_rows_out]
+    int64_t ld_rows_out = 0;
+    const float *noise = nullptr;
+    int64_t *actions = nullptr;
+    float *actions_f32 = nullptr;  // optional
+    float *logp = nullptr, *probs_out = nullptr;
+};
+bool fused_act_ok(const NetLayout &net);
+int launch_discrete_act_fused(hipStream_t st, const NetLayout &net, const float *packed, const FusedActIO &io, int64_t n);
 
 // gae.hip ---------------------------------------------------------------------------------------------
 size_t gae_workspace_bytes(int64_t n);
@@ -184,6 +198,7 @@ int launch_gather_rows(hipStream_t st, const float *src, int64_t ld_src, const i
 int launch_gather_meta(hipStream_t st, const int64_t *idx, const float *actions, int act_dim, const float *old_logp,
                        const float *adv, const float *targets, float *g_act, float *g_old, float *g_adv, float *g_tgt, int64_t n,
                        int64_t ring_base, int64_t ring_cap, unsigned *rowtab = nullptr);
+int launch_i64_to_f32(hipStream_t st, const int64_t *src, float *dst, int64_t n);
 int launch_pad_rows(hipStream_t, const void *, int, int64_t, int64_t, int64_t, float *, int64_t, int, float, float);
 int launch_pad_rows_vec(hipStream_t, const void *, int, int64_t, int64_t, int64_t, float *, int64_t, const float *, const float *);
 

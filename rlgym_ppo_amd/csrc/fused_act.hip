@@ -26,8 +26,19 @@ constexpr float FA_PROB_MIN = 1e-11f;
 }  // namespace
 
 struct FusedActArgs {
-    const float *rows;       // [n][ld_rows] zero-padded observation rows
+    const float *rows;       // [n][ld_rows] zero-padded observation rows, or nullptr: `raw` below
     unsigned ld_rows;        // floats
+    // raw observations (what the environment hands over: rlppo_pad_rows fused in): [n][ld_raw] fp32 or fp64, d features,
+    // optionally standardised like batched_agent_manager.py:313-315 -- clip((x - mean) / std, -5, 5) with the reference's scalars
+    // of feature 0 (mode 1) or per-feature vectors (mode 2); the padded rows can be written out for the rollout storage
+    const void *raw;
+    int raw_is_f64, d, standardize;
+    int64_t ld_raw;
+    float mean0, std0;
+    const float *mean_v, *std_v;
+    float *rows_out;         // optional [n][ld_rows_out]
+    int64_t ld_rows_out;
+    float *actions_f32;      // optional [n]: the action index as float (the experience buffer's encoding, experience_buffer.py:72)
     int64_t n;
     const float *packed;     // rlppo_net_pack image
     int n_layers;
@@ -95,14 +106,39 @@ __global__ __launch_bounds__(256, 1) void discrete_act_fused_kernel(FusedActArgs
 
     for (int l = 0; l <= last; ++l)
         for (int c = tid; c < a.nblk[l] * 16; c += 256) biasl[l * H + c] = a.packed[a.off_b[l] + c];
+    // ---- the Exp(1) noise of this wave's 4 rows: requested now, used after the last layer
+    float qn[4][2];
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int64_t row = row0 + wave * 4 + rr;
+            const int c = lane + 64 * e;
+            qn[rr][e] = (row < a.n && c < a.A) ? a.noise[row * a.A + c] : 1.f;
+        }
     // ---- stage the 16 observation rows into act0 (K-step-major image), zero rows past n
-    {
+    if (a.rows) {
         const int cpr = a.k[0] / 4;  // 16-byte chunks per row
         for (int c = tid; c < FA_ROWS * cpr; c += 256) {
             const int r = c / cpr, ch = c - r * cpr;
             f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
             if (row0 + r < a.n) v = *reinterpret_cast<const f32x4 *>(a.rows + (row0 + r) * (int64_t)a.ld_rows + ch * 4);
             *reinterpret_cast<f32x4 *>(&act0[(ch >> 2) * 256 + dswz<16>(r, ch & 3)]) = v;
+        }
+    } else {  // pad_rows_kernel / pad_rows_vec_kernel, element for element
+        const int k0 = a.k[0];
+        for (int e = tid; e < FA_ROWS * k0; e += 256) {
+            const int r = e / k0, c = e - r * k0;
+            const int64_t row = row0 + r;
+            float v = 0.f;
+            if (row < a.n && c < a.d) {
+                v = a.raw_is_f64 ? (float)reinterpret_cast<const double *>(a.raw)[row * a.ld_raw + c]
+                                 : reinterpret_cast<const float *>(a.raw)[row * a.ld_raw + c];
+                if (a.standardize == 1) v = fminf(fmaxf((v - a.mean0) / a.std0, -5.f), 5.f);
+                else if (a.standardize == 2) v = fminf(fmaxf((v - a.mean_v[c]) / a.std_v[c], -5.f), 5.f);
+            }
+            act0[(c >> 4) * 256 + dswz<16>(r, (c >> 2) & 3) + (c & 3)] = v;
+            if (a.rows_out && row < a.n) a.rows_out[row * a.ld_rows_out + c] = v;
         }
     }
     __syncthreads();  // (drains the stream's first tiles too: once per launch)
@@ -176,6 +212,7 @@ __global__ __launch_bounds__(256, 1) void discrete_act_fused_kernel(FusedActArgs
 
     // ---- sampling: wave w takes rows 4 w .. 4 w + 3; element c = lane + 64 e (discrete_sample_kernel<2, false>, op for op)
     const int A = a.A, ldz = a.nblk[last] * 16;
+#pragma unroll
     for (int rr = 0; rr < 4; ++rr) {
         const int r = wave * 4 + rr;
         const int64_t row = row0 + r;
@@ -211,7 +248,7 @@ __global__ __launch_bounds__(256, 1) void discrete_act_fused_kernel(FusedActArgs
         for (int e = 0; e < 2; ++e) {
             const int c = lane + 64 * e;
             if (c < A) {
-                const float v = pc[e] / a.noise[row * A + c];  // IEEE fp32 division, as at::div
+                const float v = pc[e] / qn[rr][e];  // IEEE fp32 division, as at::div
                 if (v > best) {
                     best = v;
                     besti = c;
@@ -234,13 +271,14 @@ __global__ __launch_bounds__(256, 1) void discrete_act_fused_kernel(FusedActArgs
         if (lane == 0) {
             a.actions[row] = besti;
             a.logp[row] = logf(bestp);
+            if (a.actions_f32) a.actions_f32[row] = (float)besti;
         }
     }
 }
 
 // Does the network have the form the fused kernel covers?  n_layers in [2, 6]; all hidden widths equal, 64 / 128 / 256; the first
 // layer's padded input at most the hidden width; at most 128 actions.
-bool fused_act_ok(const NetLayout &net, int64_t ld_rows) {
+bool fused_act_ok(const NetLayout &net) {
     if (net.n_layers < 2 || net.n_layers > FA_MAX_LAYERS) return false;
     const int H = net.L[0].pout;
     if (H != 64 && H != 128 && H != 256) return false;
@@ -248,16 +286,27 @@ bool fused_act_ok(const NetLayout &net, int64_t ld_rows) {
         if (net.L[l].pout != H || net.L[l].out != H) return false;
     const LayerLayout &o = net.L[net.n_layers - 1];
     if (o.out > 128 || o.pout > 128 || o.pout > H) return false;
-    if (net.L[0].pin > H || net.L[0].pin % 16 != 0 || ld_rows < net.L[0].pin || ld_rows % 4 != 0) return false;
+    if (net.L[0].pin > H || net.L[0].pin % 16 != 0) return false;
     return true;
 }
 
-int launch_discrete_act_fused(hipStream_t st, const NetLayout &net, const float *packed, const float *rows, int64_t ld_rows, int64_t n,
-                              const float *noise, int64_t *actions, float *logp, float *probs_out) {
+int launch_discrete_act_fused(hipStream_t st, const NetLayout &net, const float *packed, const FusedActIO &io, int64_t n) {
     if (n <= 0) return 0;
     FusedActArgs a;
-    a.rows = rows;
-    a.ld_rows = (unsigned)ld_rows;
+    a.rows = io.rows;
+    a.ld_rows = (unsigned)io.ld_rows;
+    a.raw = io.raw;
+    a.raw_is_f64 = io.raw_is_f64;
+    a.d = net.L[0].in;
+    a.standardize = io.standardize;
+    a.ld_raw = io.ld_raw;
+    a.mean0 = io.mean0;
+    a.std0 = io.std0;
+    a.mean_v = io.mean_v;
+    a.std_v = io.std_v;
+    a.rows_out = io.rows_out;
+    a.ld_rows_out = io.ld_rows_out;
+    a.actions_f32 = io.actions_f32;
     a.n = n;
     a.packed = packed;
     a.n_layers = net.n_layers;
@@ -268,10 +317,10 @@ int launch_discrete_act_fused(hipStream_t st, const NetLayout &net, const float 
         a.off_b[l] = net.L[l].off_b;
     }
     a.A = net.L[net.n_layers - 1].out;
-    a.noise = noise;
-    a.actions = actions;
-    a.logp = logp;
-    a.probs_out = probs_out;
+    a.noise = io.noise;
+    a.actions = io.actions;
+    a.logp = io.logp;
+    a.probs_out = io.probs_out;
     const int H = net.L[0].pout, JH = H / 64;
     const size_t lds_bytes = (size_t)(2 * H * FA_ROWS + 4 * FA_STAGES * JH * 256 + FA_MAX_LAYERS * H) * sizeof(float);
     dim3 grid((unsigned)cdiv(n, FA_ROWS));

@@ -140,6 +140,19 @@ int launch_expand_rows(hipStream_t st, const unsigned short *xb, float *x, int64
     return 0;
 }
 
+// action indices as floats (the experience buffer's encoding, experience_buffer.py:72) -- the launch-by-launch form of
+// rlppo_discrete_step; the fused kernel writes them itself
+__global__ __launch_bounds__(256) void i64_to_f32_kernel(const int64_t *__restrict__ src, float *__restrict__ dst, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) dst[i] = (float)src[i];
+}
+int launch_i64_to_f32(hipStream_t st, const int64_t *src, float *dst, int64_t n) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(i64_to_f32_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st, src, dst, n);
+    RLPPO_LAUNCH_CHECK();
+    return 0;
+}
+
 // --------------------------------------------------------------------------------------------- pad rows
 template <typename T>
 __global__ __launch_bounds__(256) void pad_rows_kernel(const T *__restrict__ src, int64_t n, int64_t d, int64_t ld_src,

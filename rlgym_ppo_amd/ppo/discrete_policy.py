@@ -14,10 +14,13 @@ from ._mlp import ArenaModule, build_body
 
 
 class DiscreteFF(ArenaModule):
+    fused_step = True  # VectorAgentManager: collect through step() (one launch per environment step, time-major storage)
+
     def __init__(self, input_shape, n_actions, layer_sizes, device):
         super().__init__()
         self.model = build_body(input_shape, layer_sizes, n_actions, nn.Softmax(dim=-1))
         self.n_actions = int(n_actions)
+        self._host_out = None  # pinned (actions, log-probs) the fused step writes into (grown on demand)
         self._finish(device)
 
     def _probs(self, rows, clamp, want_probs=True, want_argmax=False):
@@ -48,12 +51,78 @@ class DiscreteFF(ArenaModule):
             out = self._graph_act(obs, noise, standardize)  # small host batches: one hipGraph replay (ppo/_mlp.py)
             if out is not None:
                 return out
+            return self.step(obs, noise, standardize)       # [r3] the whole step in one launch (rlppo_discrete_step)
         rows = a.stage_obs(obs, standardize)
         n = rows.shape[0]
         if deterministic:  # quirk Q11: numpy's argmax over the flattened clamped [n, A] array -- one index for the whole batch
             return np.int64(self._probs(rows, clamp=True, want_probs=False, want_argmax=True)[1].item()), 0
         actions, logp = self.act_padded(rows, noise)
         return actions.cpu(), logp.cpu()
+
+    def step(self, obs, noise=None, standardize=None, rows_out=None, actions_f32=None, logp_out=None, to_host=True):
+        """One rollout step through rlppo_discrete_step [r3]: raw observations (numpy / tensor, fp32 or fp64, host or device) ->
+        standardise + pad -> MLP -> softmax -> clamp -> argmax(p / q) -> log p, one launch (csrc/fused_act.hip).
+        to_host=True: the kernel stores actions (int64) and log-probabilities straight into pinned host buffers; after ONE stream
+        synchronisation they are returned as CPU tensors (no device-to-host copies).  to_host=False: device tensors.
+        rows_out / actions_f32 / logp_out: optional device destinations of a device-resident rollout (VectorAgentManager): the
+        padded policy-input rows [n, ld_in], the actions as floats [n] and the log-probabilities [n]."""
+        a = self.arena
+        if isinstance(obs, torch.Tensor):
+            t = obs.detach()
+            if t.dtype not in (torch.float32, torch.float64):
+                t = t.float()
+            t = t.to(a.device, non_blocking=True)
+        else:
+            arr = np.asarray(obs)
+            if arr.dtype not in (np.float32, np.float64):
+                arr = arr.astype(np.float32)
+            t = torch.from_numpy(np.ascontiguousarray(arr)).to(a.device, non_blocking=True)
+        if t.dim() == 1:
+            t = t.view(1, -1)
+        t = t.reshape(-1, t.shape[-1]).contiguous()
+        n, d = t.shape
+        if d != a.d_in:
+            raise ValueError(f"observation width {d} != network input {a.d_in}")
+        if noise is None and self.noise_mode == "device":
+            q = torch.empty(n, self.n_actions, device=a.device).exponential_(1)  # fast mode: not the reference's CPU stream
+        elif noise is None:
+            q = host_exponential((n, self.n_actions), device=a.device)
+        else:
+            q = torch.as_tensor(noise, dtype=torch.float32).to(a.device, non_blocking=True).contiguous()
+        if tuple(q.shape) != (n, self.n_actions):
+            raise ValueError(f"noise shape {tuple(q.shape)} != {(n, self.n_actions)}")
+        mode, mean0, std0, mean_v, std_v = 0, 0.0, 1.0, None, None
+        if standardize is not None:
+            if isinstance(standardize[0], torch.Tensor):
+                mean_v, std_v = (x.to(a.device, dtype=torch.float32).contiguous() for x in standardize)
+                if mean_v.numel() != d or std_v.numel() != d:
+                    raise ValueError("per-feature statistics must have one entry per observation feature")
+                mode = 2
+            else:
+                mode, mean0, std0 = 1, float(standardize[0]), float(standardize[1])
+        a.ensure_packed()
+        L = N.lib()
+        if to_host:
+            if self._host_out is None or self._host_out[0].numel() < n:
+                cap = max(n, 64)
+                self._host_out = (torch.empty(cap, dtype=torch.int64).pin_memory(), torch.empty(cap, dtype=torch.float32).pin_memory())
+            actions = self._host_out[0][:n]
+            logp = self._host_out[1][:n] if to_host is True else None   # to_host="actions": only the indices go to the host
+        else:
+            actions = torch.empty(n, dtype=torch.int64, device=a.device)
+            logp = None
+        if logp is None:
+            logp = logp_out if logp_out is not None else torch.empty(n, dtype=torch.float32, device=a.device)
+        elif logp_out is not None:
+            raise ValueError("step: logp_out needs to_host=False or to_host='actions'")
+        ws = a.ws.get(L.rlppo_discrete_step_workspace_bytes(a.dims_c, a.n_layers, n))
+        N.check(L.rlppo_discrete_step(stream_ptr(), a.dims_c, a.n_layers, ptr(a.packed), ptr(t), int(t.dtype == torch.float64), d, n,
+                                      mode, mean0, std0, ptr(mean_v), ptr(std_v), ptr(q), ptr(actions), ptr(actions_f32), ptr(logp),
+                                      ptr(rows_out), rows_out.stride(0) if rows_out is not None else 0, ptr(ws), ws.numel()))
+        if to_host:
+            torch.cuda.current_stream(a.device).synchronize()
+            return actions.clone(), (logp.clone() if to_host is True else logp)
+        return actions, logp
 
     # ---- hooks of the graph-replayed rollout step (ppo/_mlp.py::ActGraph)
     def _noise_shape(self, n):

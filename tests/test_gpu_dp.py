@@ -146,42 +146,66 @@ def _build_cfg3(seed=123):
     return learner, buf
 
 
-def _same_update(p, v, report, ref_p, ref_v, ref_report, n_updates, ref_vsq=None, lr=3e-4):
-    """Parameters within 5e-5 of the 1-rank run's (relative to the largest parameter), report within 2e-5.  Adam's step
-    lr * m / (sqrt(v) + 1e-8) is discontinuous in a gradient entry that is ~0, so the few parameters whose gradient stayed below
-    1e-4 of the largest (read off the 1-rank run's second moments, `ref_vsq`) turn the 1e-7 relative gradient difference of another
-    summation order into up to a fraction of lr per step: they are counted (< 5 %) and held to half an Adam step per update."""
-    for got, ref, vsq in ((p, ref_p, None if ref_vsq is None else ref_vsq[0]), (v, ref_v, None if ref_vsq is None else ref_vsq[1])):
-        err = (got - ref).abs() / ref.abs().max()
-        ill = torch.zeros_like(err, dtype=torch.bool) if vsq is None else vsq.sqrt() < 1e-4 * vsq.sqrt().max()
-        assert err[~ill].max().item() < 5e-5, err[~ill].max().item()
-        assert ill.float().mean().item() < 0.05
-        if ill.any():
-            assert err[ill].max().item() <= n_updates * lr * 0.5 / ref.abs().max().item(), err[ill].max().item()
+def _same_update(p, v, report, ref_p, ref_v, ref_report, n_updates, tol=5e-5):
+    """Parameters within `tol` of the reference run's (relative to the largest parameter), report within 2e-5."""
+    for got, ref in ((p, ref_p), (v, ref_v)):
+        err = ((got - ref).abs().max() / ref.abs().max()).item()
+        assert err < tol, err
     for k in ("Policy Entropy", "Mean KL Divergence", "Value Function Loss", "SB3 Clip Fraction",
               "Policy Update Magnitude", "Value Function Update Magnitude"):
         assert abs(report[k] - ref_report[k]) <= 2e-5 * max(abs(ref_report[k]), 1e-3) + 1e-7, (k, report[k], ref_report[k])
     assert report["Cumulative Model Updates"] == ref_report["Cumulative Model Updates"] == n_updates
 
 
+def _adam_noise(p, v, ref_p, ref_v, n_updates, what, lr=3e-4):
+    """Two correct float32 evaluations of the same batch gradient that add their 524,288 per-sample terms in different orders differ
+    by ~1e-6 of sum|terms| per entry; Adam's step lr * m / (sqrt(v) + eps) is scale-free, so for an entry whose terms largely
+    cancel (|g| a few tens of that noise) the STEP differs by percents of lr whatever the entry's size.  Measured here between
+    the one-pass (524,288 rows) and the eight-pass (8 x 65,536, the reference's own minibatch structure) evaluation: reported,
+    and bounded by a tenth of an Adam step per update for every parameter, 5e-5 of the largest parameter for 99 % of them."""
+    worst = 0.0
+    for got, ref in ((p, ref_p), (v, ref_v)):
+        err = (got - ref).abs() / ref.abs().max()
+        q99 = torch.quantile(err[torch.randperm(err.numel())[:100000]], 0.99).item()
+        steps = (got - ref).abs().max().item() / (n_updates * lr)
+        print(f"[summation order through Adam] {what}: max {err.max().item():.2e} of max|p| (= {steps:.3f} Adam steps per update), 99 % of parameters within {q99:.1e}")
+        assert steps <= 0.1 and q99 < 5e-5, (what, steps, q99)
+        worst = max(worst, err.max().item())
+    return worst
+
+
+def _ref_cfg3(fuse):
+    """The 1-rank update of the configs[3] workload with `fuse` minibatches per pass (8: one 524,288-row pass per optimiser step,
+    the one-GPU default; 1: eight 65,536-row passes accumulating into .grad, the reference's own structure, ppo_learner.py:134-193)."""
+    import contextlib
+    with contextlib.redirect_stdout(open(os.devnull, "w")):
+        ref, ref_buf = _build_cfg3()
+        ref.max_fused_minibatches = fuse
+        report = ref.learn(ref_buf)
+    out = (ref.policy.arena.flat.cpu(), ref.value_net.arena.flat.cpu(), report, ref._fused_rows)
+    del ref, ref_buf
+    torch.cuda.empty_cache()
+    return out
+
+
 def test_configs3_eight_rank_partition_literal():
     """BASELINE configs[3] at its real shape: 8 data-parallel ranks, per-rank minibatch 65,536, 256x3 nets, B = 524,288, 2 epochs.
     The GPU pool admits at most 6 processes on a card (and RCCL refuses two ranks on one GPU), so the 8 ranks are 8 replicas in
     this process, driven in lock step by dp.run_virtual_ranks: every replica runs PPOLearner.learn_steps for its rank -- the
-    product's own dealing (dp.slices_for_rank: slice r of every batch), its own fused 65,536-row pass, its own clip + Adam -- and
-    each exchange is the rank-ordered sum an all-reduce computes.  Checked: every rank launched exactly one 65,536-row pass per
-    optimiser step; parameters and report equal the 1-rank run's (summation order differs: 5e-5 / 2e-5); replicas bit-identical."""
+    product's own dealing (dp.slices_for_rank: slice r of every batch), its own 65,536-row pass, its own clip + Adam -- and each
+    exchange is the rank-ordered sum an all-reduce computes.  Checked: every rank launched exactly one 65,536-row pass per
+    optimiser step; parameters and report equal those of the 1-rank run that evaluates the same eight 65,536-row minibatches one
+    after the other (5e-5 / 2e-5: only the order in which eight partial gradients are added differs); replicas bit-identical.
+    The distance to the one-pass 1-rank run is summation order seen through Adam: measured and bounded by _adam_noise."""
     import contextlib
     from rlgym_ppo_amd import dp
     world = 8
+    ref_p, ref_v, ref_report, rows = _ref_cfg3(fuse=1)
+    assert rows == 65536
+    one_p, one_v, one_report, rows = _ref_cfg3(fuse=8)
+    assert rows == 524288                                      # one GPU: the 8 slices of a batch in one pass
+    _adam_noise(one_p, one_v, ref_p, ref_v, CFG3["epochs"], "1 rank, one 524,288-row pass vs eight 65,536-row passes")
     with contextlib.redirect_stdout(open(os.devnull, "w")):
-        ref, ref_buf = _build_cfg3()
-        ref_report = ref.learn(ref_buf)
-        ref_p, ref_v = ref.policy.arena.flat.cpu(), ref.value_net.arena.flat.cpu()
-        ref_vsq = (ref.policy_optimizer.exp_avg_sq.cpu(), ref.value_optimizer.exp_avg_sq.cpu())
-        assert ref._fused_rows == 524288                      # one GPU: the 8 slices of a batch in one pass
-        del ref, ref_buf
-        torch.cuda.empty_cache()
         replicas = [_build_cfg3() for _ in range(world)]
     learners, bufs = [r[0] for r in replicas], [r[1] for r in replicas]
     assert all(torch.equal(l.policy.arena.flat, learners[0].policy.arena.flat) for l in learners)   # identical construction
@@ -189,7 +213,9 @@ def test_configs3_eight_rank_partition_literal():
     reports = dp.run_virtual_ranks(learners, bufs)
     for l, report in zip(learners, reports):
         assert l._fused_rows == 65536                          # one 65,536-row pass per rank and optimiser step
-        _same_update(l.policy.arena.flat.cpu(), l.value_net.arena.flat.cpu(), report, ref_p, ref_v, ref_report, CFG3["epochs"], ref_vsq)
+        _same_update(l.policy.arena.flat.cpu(), l.value_net.arena.flat.cpu(), report, ref_p, ref_v, ref_report, CFG3["epochs"])
+    _adam_noise(learners[0].policy.arena.flat.cpu(), learners[0].value_net.arena.flat.cpu(), one_p, one_v, CFG3["epochs"],
+                "8 ranks vs 1 rank (one pass)")
     for l in learners[1:]:
         assert torch.equal(l.policy.arena.flat, learners[0].policy.arena.flat) and torch.equal(l.value_net.arena.flat, learners[0].value_net.arena.flat)
         assert torch.equal(l.policy_optimizer.exp_avg_sq, learners[0].policy_optimizer.exp_avg_sq)
@@ -212,22 +238,19 @@ def _worker_cfg3(rank, world, port, out):
 def test_configs3_shape_four_process_ranks():
     """The same workload through real processes and torch.distributed: 4 ranks (gloo, all on cuda:0; the pool's limit is 6 processes
     per card) x 2 consecutive slices per rank and optimiser step, fused into one 131,072-row pass -- the N = 4 point of the
-    driver's scaling run, exchange included -- against the 1-rank update."""
-    import contextlib
-    with contextlib.redirect_stdout(open(os.devnull, "w")):
-        ref, ref_buf = _build_cfg3()
-        ref_report = ref.learn(ref_buf)
-    ref_p, ref_v = ref.policy.arena.flat.cpu(), ref.value_net.arena.flat.cpu()
-    ref_vsq = (ref.policy_optimizer.exp_avg_sq.cpu(), ref.value_optimizer.exp_avg_sq.cpu())
-    del ref, ref_buf
-    torch.cuda.empty_cache()
+    driver's scaling run, exchange included -- against the 1-rank update with the same pass structure (2 minibatches per pass)."""
+    ref_p, ref_v, ref_report, rows = _ref_cfg3(fuse=2)
+    assert rows == 131072
     mgr = mp.Manager()
     out = mgr.dict()
     mp.spawn(_worker_cfg3, args=(4, _free_port(), out), nprocs=4, join=True)
     for rank in range(4):
         p, v, report, rows = out[rank]
         assert rows == 131072
-        _same_update(p, v, report, ref_p, ref_v, ref_report, CFG3["epochs"], ref_vsq)
+        # the four partial gradients are the 1-rank run's own, bit for bit; gloo adds them in another order than the 1-rank run's
+        # accumulation into .grad, and Adam turns that into up to a few percent of a step for entries that cancel (_adam_noise)
+        _same_update(p, v, report, ref_p, ref_v, ref_report, CFG3["epochs"], tol=float("inf"))
+        _adam_noise(p, v, ref_p, ref_v, CFG3["epochs"], "4 process ranks (gloo) vs 1 rank, same passes" if rank == 0 else "rank %d" % rank)
     assert all(torch.equal(out[0][0], out[r][0]) and torch.equal(out[0][1], out[r][1]) for r in range(1, 4))
 
 
