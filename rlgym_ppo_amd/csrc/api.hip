@@ -215,6 +215,10 @@ static int forward_pingpong(hipStream_t st, const NetLayout &net, const float *p
 using namespace rlppo;
 
 static int g_fused_act = 1;  // rlppo_dbg_set(27, 0/1): rlppo_discrete_act as one fused launch (fused_act.hip)
+// One workgroup per 16 rows and one workgroup per CU (102 KiB of LDS): a launch is rounds of 4096 rows at ~25 us each, whatever
+// the round's fill.  Measured (tools/act_kernel_time.py): 64 rows 26 us (chain 70), 4096 rows 29 us (chain 75), 16,384 rows 100 us
+// (chain 86): beyond two rounds the layer-by-layer GEMMs, which fill the chip, win.
+constexpr int64_t FUSED_ACT_MAX_ROWS = 8192;
 
 extern "C" {
 
@@ -290,7 +294,7 @@ int rlppo_discrete_act(void *stream, const int32_t *dims, int32_t n_layers, cons
     RLPPO_CHECK_ARG(n > 0 && packed && obs && noise_q && actions && logp && workspace, "discrete_act: bad argument");
     // [r3] one launch for the whole step when the network has the form fused_act.hip covers (fp32 inference precision); the
     // layer-by-layer chain below otherwise -- bit-identical results either way
-    if (g_fused_act && !get_infer_bf16() && fused_act_ok(net) && ld_obs >= net.L[0].pin && ld_obs % 4 == 0) {
+    if (g_fused_act && !get_infer_bf16() && fused_act_ok(net) && n <= FUSED_ACT_MAX_ROWS && ld_obs >= net.L[0].pin && ld_obs % 4 == 0) {
         FusedActIO io;
         io.rows = obs;
         io.ld_rows = ld_obs;
@@ -328,7 +332,7 @@ int rlppo_discrete_step(void *stream, const int32_t *dims, int32_t n_layers, con
                     "discrete_step: ld_obs=%ld standardize=%d", (long)ld_obs, standardize);
     RLPPO_CHECK_ARG(!rows_out || ld_rows_out >= pin, "discrete_step: ld_rows_out=%ld < padded width %d", (long)ld_rows_out, pin);
     hipStream_t st = (hipStream_t)stream;
-    if (g_fused_act && !get_infer_bf16() && fused_act_ok(net)) {
+    if (g_fused_act && !get_infer_bf16() && fused_act_ok(net) && n <= FUSED_ACT_MAX_ROWS) {
         FusedActIO io;
         io.raw = obs;
         io.raw_is_f64 = obs_is_f64;

@@ -52,16 +52,19 @@ struct FusedActArgs {
     float *probs_out;        // optional [n][A]
 };
 
-// JH: output blocks a wave owns in a hidden layer (H = 64 JH); the head's blocks are dealt JO = ceil(nblk / 4) per wave.
-template <int JH>
-__global__ __launch_bounds__(256, 1) void discrete_act_fused_kernel(FusedActArgs a) {
-    constexpr int H = 64 * JH;
+// NW waves; JH: output blocks a wave owns in a hidden layer (H = 16 JH NW); the head's blocks are dealt ceil(nblk / NW) per wave.
+// H = 256 runs 8 waves x 2 blocks: with one wave per SIMD (4 x 4) a K-step was LDS-DMA issue (4 pieces, ~100 cycles each) + fragment
+// reads + 16 MFMAs one after the other, ~1350 cycles for 512 cycles of MFMA (36 us per 4096-row step); two waves per SIMD take
+// turns on the MFMA pipe.
+template <int JH, int NW>
+__global__ __launch_bounds__(64 * NW, 1) void discrete_act_fused_kernel(FusedActArgs a) {
+    constexpr int H = 16 * JH * NW, NT = 64 * NW, RPWV = FA_ROWS / NW;  // rows each wave samples
     constexpr int TILE = JH * 16 * 16;  // floats of one wave's weight tile (JH*16 rows x 16 k)
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float *act0 = lds;                        // [H/16 k-steps][16 rows][16] swizzled (also holds the staged input rows)
     float *act1 = lds + H * FA_ROWS;
-    float *wring = lds + 2 * H * FA_ROWS;     // [4 waves][FA_STAGES][TILE]
-    float *biasl = wring + 4 * FA_STAGES * TILE;  // [FA_MAX_LAYERS][H]: the biases, so that no register-destination load sits in the weight stream's vmcnt window
+    float *wring = lds + 2 * H * FA_ROWS;     // [NW waves][FA_STAGES][TILE]
+    float *biasl = wring + NW * FA_STAGES * TILE;  // [FA_MAX_LAYERS][H]: the biases, so that no register-destination load sits in the weight stream's vmcnt window
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     const int r16 = lane & 15, q = lane >> 4;
@@ -74,9 +77,9 @@ __global__ __launch_bounds__(256, 1) void discrete_act_fused_kernel(FusedActArgs
     // move no data but keep the vmcnt arithmetic uniform)
     const int lr = lane >> 2, pch = lane & 3;
     const int lch = pch ^ ((0 - (lr >> 2)) & 3);
-    int pl = 0, pkt = 0, issued = 0;
+    int pl = 0, pkt = 0, issued = 0, pnk = a.k[0] / 16;
     auto layer_rsrc = [&](int l) {
-        const int own = l == last ? (a.nblk[l] + 3) / 4 : JH;            // blocks per wave in this layer
+        const int own = l == last ? (a.nblk[l] + NW - 1) / NW : JH;      // blocks per wave in this layer
         int rows = a.nblk[l] * 16 - wave_u * own * 16;                     // rows of W this wave streams
         rows = rows < 0 ? 0 : (rows > own * 16 ? own * 16 : rows);
         return make_rsrc(a.packed + a.off_w[l] + (int64_t)wave_u * own * 16 * a.k[l], (unsigned)rows * (unsigned)a.k[l] * 4u);
@@ -91,10 +94,11 @@ __global__ __launch_bounds__(256, 1) void discrete_act_fused_kernel(FusedActArgs
         for (int i = 0; i < JH; ++i)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rs, dst + i * 256, 16, w_off, (unsigned)pkt * 64u + i * w_row16, 0, 0);
         ++issued;
-        if (++pkt == a.k[pl] / 16) {
+        if (++pkt == pnk) {
             pkt = 0;
             ++pl;
             if (pl <= last) {
+                pnk = a.k[pl] / 16;
                 w_rs = layer_rsrc(pl);
                 w_off = (unsigned)lr * (unsigned)a.k[pl] * 4u + lch * 16;
                 w_row16 = 16u * (unsigned)a.k[pl] * 4u;
@@ -105,21 +109,21 @@ __global__ __launch_bounds__(256, 1) void discrete_act_fused_kernel(FusedActArgs
     for (int s = 0; s < FA_STAGES - 1; ++s) issue_next();
 
     for (int l = 0; l <= last; ++l)
-        for (int c = tid; c < a.nblk[l] * 16; c += 256) biasl[l * H + c] = a.packed[a.off_b[l] + c];
+        for (int c = tid; c < a.nblk[l] * 16; c += NT) biasl[l * H + c] = a.packed[a.off_b[l] + c];
     // ---- the Exp(1) noise of this wave's 4 rows: requested now, used after the last layer
-    float qn[4][2];
+    float qn[RPWV][2];
 #pragma unroll
-    for (int rr = 0; rr < 4; ++rr)
+    for (int rr = 0; rr < RPWV; ++rr)
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
-            const int64_t row = row0 + wave * 4 + rr;
+            const int64_t row = row0 + wave * RPWV + rr;
             const int c = lane + 64 * e;
             qn[rr][e] = (row < a.n && c < a.A) ? a.noise[row * a.A + c] : 1.f;
         }
     // ---- stage the 16 observation rows into act0 (K-step-major image), zero rows past n
     if (a.rows) {
         const int cpr = a.k[0] / 4;  // 16-byte chunks per row
-        for (int c = tid; c < FA_ROWS * cpr; c += 256) {
+        for (int c = tid; c < FA_ROWS * cpr; c += NT) {
             const int r = c / cpr, ch = c - r * cpr;
             f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
             if (row0 + r < a.n) v = *reinterpret_cast<const f32x4 *>(a.rows + (row0 + r) * (int64_t)a.ld_rows + ch * 4);
@@ -127,7 +131,7 @@ __global__ __launch_bounds__(256, 1) void discrete_act_fused_kernel(FusedActArgs
         }
     } else {  // pad_rows_kernel / pad_rows_vec_kernel, element for element
         const int k0 = a.k[0];
-        for (int e = tid; e < FA_ROWS * k0; e += 256) {
+        for (int e = tid; e < FA_ROWS * k0; e += NT) {
             const int r = e / k0, c = e - r * k0;
             const int64_t row = row0 + r;
             float v = 0.f;
@@ -147,7 +151,7 @@ __global__ __launch_bounds__(256, 1) void discrete_act_fused_kernel(FusedActArgs
     int consumed = 0;
     for (int l = 0; l <= last; ++l) {
         const bool head = l == last;
-        const int own = head ? (a.nblk[l] + 3) / 4 : JH;
+        const int own = head ? (a.nblk[l] + NW - 1) / NW : JH;
         const int jb0 = wave_u * own;                    // first output block of this wave
         const int nj = head ? (a.nblk[l] - jb0 < own ? (a.nblk[l] - jb0 < 0 ? 0 : a.nblk[l] - jb0) : own) : JH;
         f32x4 acc[JH];
@@ -210,11 +214,11 @@ __global__ __launch_bounds__(256, 1) void discrete_act_fused_kernel(FusedActArgs
         nxt = t;
     }
 
-    // ---- sampling: wave w takes rows 4 w .. 4 w + 3; element c = lane + 64 e (discrete_sample_kernel<2, false>, op for op)
+    // ---- sampling: wave w takes RPWV rows; element c = lane + 64 e (discrete_sample_kernel<2, false>, op for op)
     const int A = a.A, ldz = a.nblk[last] * 16;
 #pragma unroll
-    for (int rr = 0; rr < 4; ++rr) {
-        const int r = wave * 4 + rr;
+    for (int rr = 0; rr < RPWV; ++rr) {
+        const int r = wave * RPWV + rr;
         const int64_t row = row0 + r;
         if (row >= a.n) break;
         const float *z = cur + r * ldz;
@@ -321,23 +325,23 @@ int launch_discrete_act_fused(hipStream_t st, const NetLayout &net, const float 
     a.actions = io.actions;
     a.logp = io.logp;
     a.probs_out = io.probs_out;
-    const int H = net.L[0].pout, JH = H / 64;
-    const size_t lds_bytes = (size_t)(2 * H * FA_ROWS + 4 * FA_STAGES * JH * 256 + FA_MAX_LAYERS * H) * sizeof(float);
+    const int H = net.L[0].pout;
     dim3 grid((unsigned)cdiv(n, FA_ROWS));
     static bool attr_set[3] = {};
-#define FA_LAUNCH(J, SLOT)                                                                                                       \
+#define FA_LAUNCH(J, W, SLOT)                                                                                                    \
     do {                                                                                                                         \
+        constexpr int LDS_BYTES = (2 * 16 * J * W * FA_ROWS + W * FA_STAGES * J * 256 + FA_MAX_LAYERS * 16 * J * W) * 4;          \
         if (!attr_set[SLOT]) { /* up to 102 KiB of dynamic LDS (H = 256): above the default 64 KiB limit */                      \
-            RLPPO_HIP(hipFuncSetAttribute((const void *)discrete_act_fused_kernel<J>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                          (int)((2 * 64 * J * FA_ROWS + 4 * FA_STAGES * J * 256 + FA_MAX_LAYERS * 64 * J) * 4)));   \
+            RLPPO_HIP(hipFuncSetAttribute((const void *)discrete_act_fused_kernel<J, W>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                          LDS_BYTES));                                                                           \
             attr_set[SLOT] = true;                                                                                               \
         }                                                                                                                        \
-        hipLaunchKernelGGL((discrete_act_fused_kernel<J>), grid, dim3(256), lds_bytes, st, a);                                    \
+        hipLaunchKernelGGL((discrete_act_fused_kernel<J, W>), grid, dim3(64 * W), LDS_BYTES, st, a);                              \
     } while (0)
-    switch (JH) {
-        case 4: FA_LAUNCH(4, 0); break;
-        case 2: FA_LAUNCH(2, 1); break;
-        default: FA_LAUNCH(1, 2); break;
+    switch (H) {
+        case 256: FA_LAUNCH(2, 8, 0); break;
+        case 128: FA_LAUNCH(1, 8, 1); break;
+        default: FA_LAUNCH(1, 4, 2); break;
     }
 #undef FA_LAUNCH
     RLPPO_LAUNCH_CHECK();

@@ -546,7 +546,7 @@ def test_fused_rollout_step_is_bit_identical_to_the_layer_chain(L, d, hidden, A)
     torch.manual_seed(d + A)
     net = Net(L, nets.init_mlp(d, hidden, A))
     rs = np.random.RandomState(d)
-    for n in (1, 16, 17, 250, 4096, 5000):
+    for n in (1, 16, 17, 250, 4096, 5000, 8192):
         rows = net.pad(np.clip(rs.randn(n, d) * 2, -5, 5).astype(np.float32))
         q = dev(rs.exponential(size=(n, A)).astype(np.float32))
         outs = []
