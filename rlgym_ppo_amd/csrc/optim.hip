@@ -291,13 +291,31 @@ __global__ __launch_bounds__(128) void welford_kernel(const float *__restrict__ 
     const int f = blockIdx.x * 128 + threadIdx.x;
     if (f >= d) return;
     T mu = mean[f], v = m2[f];
-    for (int64_t i = 0; i < n; ++i) {
+    // the recurrence is serial in mu / v, the loads are not: 16 samples are requested together ([r3]: with one dependent load
+    // per iteration 4096 samples took 0.86 ms, a third of a 4096-agent collect; the chain of IEEE divisions alone is ~0.1 ms)
+    constexpr int PF = 16;
+    int64_t i = 0;
+    for (; i + PF <= n; i += PF) {
+        float xs[PF];
+#pragma unroll
+        for (int u = 0; u < PF; ++u) xs[u] = x[(i + u) * ld + f];
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+            const long long prev = count0 + i + u;
+            const T cnt = (T)(prev + 1);
+            const T delta = (T)xs[u] - mu;            // delta   = sample - running_mean
+            const T dn = delta / cnt;                 // delta_n = delta / count
+            mu += dn;                                 // running_mean += delta_n
+            v += (delta * dn) * (T)prev;              // running_variance += delta * delta_n * (count - 1)
+        }
+    }
+    for (; i < n; ++i) {
         const long long prev = count0 + i;
         const T cnt = (T)(prev + 1);
-        const T delta = (T)x[i * ld + f] - mu;    // delta   = sample - running_mean
-        const T dn = delta / cnt;                 // delta_n = delta / count
-        mu += dn;                                 // running_mean += delta_n
-        v += (delta * dn) * (T)prev;              // running_variance += delta * delta_n * (count - 1)
+        const T delta = (T)x[i * ld + f] - mu;
+        const T dn = delta / cnt;
+        mu += dn;
+        v += (delta * dn) * (T)prev;
     }
     mean[f] = mu;
     m2[f] = v;

@@ -150,7 +150,8 @@ def gate(L, head, pol, val, obs, acts, old, adv, tgt, clip, ent, mb_ratio, got, 
         ref = ppo.minibatch_analytic(head, pol, val, obs, acts, old, adv, tgt, clip, ent, mb_ratio, var, mp, mv, w)
         out[who] = dict(err=grads_err(list(grads_p) + list(grads_v), ref["grad_policy"] + ref["grad_value"]), flips=flips,
                         ambiguity=grads_err(ref["grad_policy"] + ref["grad_value"], truth["grad_policy"] + truth["grad_value"]),
-                        ref=ref)
+                        ref=ref, w=w, masks=(mp, mv), grads=(grads_p, grads_v))
+    out["edge"] = edge
     e_hip, e_cpu = out["hip"]["err"], out["cpu"]["err"]
     print(f"[fp64 gate] {label or head}: n={n}  err(HIP, fp64)={e_hip:.2e}  err(CPU fp32 oracle, fp64)={e_cpu:.2e}  | ReLU decisions "
           f"differing from fp64: HIP {out['hip']['flips']}, CPU {out['cpu']['flips']} (worth {out['hip']['ambiguity']:.1e} / "
@@ -204,3 +205,27 @@ def gauss_logp_check(params, obs, eps, y_hip, act_hip, logp_hip, var=(0.1, 1.0),
           f"{res['hip'][2]:.1e}); CPU fp32 oracle {res['cpu'][0]:.1e} (= {res['cpu'][1]:.2f} of its bound)")
     assert res["hip"][1] <= 1.0, res
     return res
+
+
+def without_edge_rows(head, pol, val, obs, acts, old, adv, tgt, clip, ent, mb_ratio, var, grads_pol, masks, edge, w):
+    """The policy gradient of an implementation with the contributions of the clip-edge rows -- the only part a float32 rounding of
+    the ratio can legitimately switch on or off -- taken out: grad - sum_i w_i c_i, where c_i is row i's full-branch contribution
+    (float64, oracle/ppo.py::minibatch_analytic under the implementation's own ReLU masks: the gradient is linear in the branch
+    weights) and w_i the branch weight that implementation took for it (read off its output-layer gradient by the gate).  What is
+    left depends on no knife-edge decision, so two implementations can be compared on it DIRECTLY."""
+    n = np.asarray(obs).shape[0]
+    mp, mv = masks
+    w0 = np.full(n, np.nan)
+    w0[edge] = 0.0
+    base = ppo.minibatch_analytic(head, pol, val, obs, acts, old, adv, tgt, clip, ent, mb_ratio, var, mp, mv, w0)["grad_policy"]
+    out = [[np.asarray(gw, np.float64).copy(), np.asarray(gb, np.float64).copy()] for gw, gb in grads_pol]
+    for i in edge:
+        if w[i] == 0:
+            continue
+        wi = w0.copy()
+        wi[i] = 1.0
+        one = ppo.minibatch_analytic(head, pol, val, obs, acts, old, adv, tgt, clip, ent, mb_ratio, var, mp, mv, wi)["grad_policy"]
+        for l, ((ow, ob), (bw, bb)) in enumerate(zip(one, base)):
+            out[l][0] -= w[i] * (np.asarray(ow, np.float64) - np.asarray(bw, np.float64))
+            out[l][1] -= w[i] * (np.asarray(ob, np.float64) - np.asarray(bb, np.float64))
+    return out

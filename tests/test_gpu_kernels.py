@@ -763,6 +763,20 @@ def test_g4_discrete_minibatch_against_reference(L, golden):
     assert abs(stats2[2] - float(g["out.value_loss"])) < 1e-5 * abs(float(g["out.value_loss"]))
     for i, (gw, gb) in enumerate(gv2):
         assert relerr(gw, g[f"gv.model.{2 * i}.weight"]) < 1e-5
+    # [r3] ... and the POLICY gradients against the fixture's own gp.* tensors, directly: each implementation's gradient minus the
+    # contributions of the 32 clip-edge rows under the branch IT took for them (fp64_gate.without_edge_rows) depends on no
+    # knife-edge decision -- the HIP kernels and the reference's float32 autograd must agree on it to 1e-5 of every tensor.
+    fix_gp = [(torch.as_tensor(g[f"gp.model.{2 * i}.weight"]), torch.as_tensor(g[f"gp.model.{2 * i}.bias"])) for i in range(len(pol))]
+    edge, args = out["edge"], ("discrete", pol, val, g["obs"], g["acts"], g["old_logp"], g["adv"], g["targets"], 0.2, 0.005, 0.25, (0.1, 1.0))
+    w_fix = fp64_gate._edge_decisions(*args, out["cpu"]["masks"][0], out["cpu"]["masks"][1], fix_gp, edge, 96)
+    hip_part = fp64_gate.without_edge_rows(*args, gp2, out["hip"]["masks"], edge, out["hip"]["w"])
+    fix_part = fp64_gate.without_edge_rows(*args, fix_gp, out["cpu"]["masks"], edge, w_fix)
+    worst = 0.0
+    for (hw, hb), (fw, fb) in zip(hip_part, fix_part):
+        worst = max(worst, np.abs(hw - fw).max() / np.abs(fw).max(), np.abs(hb - fb).max() / np.abs(fb).max())
+    print(f"[fp64 gate] G4 policy gradients without the clip-edge rows' contributions, HIP vs the reference fixture directly: {worst:.2e} "
+          f"(branch decisions differing between the two on {int((out['hip']['w'][edge] != w_fix[edge]).sum())} of {len(edge)} edge rows)")
+    assert worst < 1e-5, worst
 
 
 @pytest.mark.parametrize("head,fixture", [("gaussian", "g9_continuous"), ("multidiscrete", "g9_multidiscrete")])

@@ -65,27 +65,34 @@ def test_learn_matches_reference_fixture(golden, name):
         pv = torch.nn.utils.parameters_to_vector(learner.policy.parameters())
         vv = torch.nn.utils.parameters_to_vector(learner.value_net.parameters())
         tp, tv, wp, wv = truth[s]
-        # Adam's step lr * m / (sqrt(v) + 1e-8) does not depend continuously on a gradient entry that is ~0: a parameter whose
-        # gradient was below 1e-4 of the largest one in some step turns a 3e-7 gradient rounding (what the minibatch gate
-        # measures) into up to lr * 3e-3 of parameter -- for the reference's float32 path exactly as for the kernels.  Those
-        # parameters (counted, a few percent) are held to the Adam-step bound, everything else to 1e-5.
+        # Adam's step lr * m / (sqrt(v) + 1e-8) is scale-free: to first order an absolute error d in a gradient entry g_i moves the
+        # step by lr * d / |g_i| (at most by the whole step).  With d = 1e-5 max|g| -- the gradient tolerance of the north star,
+        # which the minibatch gate holds both implementations to -- a parameter whose gradient fell to w_i max|g| in some step
+        # (w_i = `weakest` of oracle/ppo.py::learn64) may therefore be off by
+        #     bound_i = (steps so far) * lr * min(1, 1e-5 / w_i)
+        # whatever float32 implementation computed it; for w_i >= 1e-4 that is below a tenth of a step and the plain 1e-5
+        # parameter gate applies, below (2-3 % of the parameters) the DERIVED bound does -- the same one for the HIP kernels and
+        # for the reference's own float32 fixture, both reported as fractions of it.  [r3: replaces a flat 5 % of a step.]
         errs = {}
         for who, p_, v_ in (("hip", pv.detach().cpu().numpy().astype(np.float64), vv.detach().cpu().numpy().astype(np.float64)),
                             ("ref", g[f"step{s}.policy"].astype(np.float64), g[f"step{s}.value"].astype(np.float64))):
-            worst_good = worst_ill = 0.0
+            worst_good = worst_ill = frac_ill = 0.0
             for got, tr, weak in ((p_, tp, wp), (v_, tv, wv)):
-                d = np.abs(got - tr) / np.abs(tr).max()
+                d = np.abs(got - tr)
                 ill = weak < 1e-4
-                worst_good = max(worst_good, float(d[~ill].max()))
-                worst_ill = max(worst_ill, float(d[ill].max()) if ill.any() else 0.0)
-            errs[who] = (worst_good, worst_ill)
+                worst_good = max(worst_good, float(d[~ill].max() / np.abs(tr).max()))
+                if ill.any():
+                    bound = (s + 1) * cfg["lr"] * np.minimum(1.0, 1e-5 / np.maximum(weak[ill], 1e-300))
+                    worst_ill = max(worst_ill, float(d[ill].max() / np.abs(tr).max()))
+                    frac_ill = max(frac_ill, float((d[ill] / bound).max()))
+            errs[who] = (worst_good, worst_ill, frac_ill)
         n_ill = int((wp < 1e-4).sum() + (wv < 1e-4).sum())
         print(f"[fp64 gate] {name} after optimiser step {s}: err(HIP, fp64)={errs['hip'][0]:.2e}  err(reference fp32 fixture, fp64)="
               f"{errs['ref'][0]:.2e}  | {n_ill} of {wp.size + wv.size} parameters with an ill-conditioned Adam step: HIP "
-              f"{errs['hip'][1]:.1e}, reference {errs['ref'][1]:.1e}")
+              f"{errs['hip'][1]:.1e} = {errs['hip'][2]:.3f} of the derived bound, reference {errs['ref'][1]:.1e} = {errs['ref'][2]:.3f}")
         assert errs["hip"][0] <= max(1e-5, 1.5 * errs["ref"][0]), (name, s, errs)
         assert n_ill <= 0.05 * (wp.size + wv.size)
-        assert errs["hip"][1] <= (s + 1) * cfg["lr"] * 0.05 / min(np.abs(tp).max(), np.abs(tv).max()), (name, s, errs)
+        assert errs["hip"][2] <= 1.0 and errs["ref"][2] <= 1.0, (name, s, errs)
     assert learner.cumulative_model_updates == n_steps
     assert sorted(reports[0].keys()) == sorted([
         "PPO Batch Consumption Time", "Cumulative Model Updates", "Policy Entropy", "Mean KL Divergence",
