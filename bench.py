@@ -277,14 +277,23 @@ def rollout_bench(learner):
         torch.cuda.synchronize()
         return (time.perf_counter() - t) / reps
 
+    obs_pin = torch.from_numpy(obs).pin_memory().numpy()          # the same observations in page-locked host memory
     t_parity = timed(lambda: pol.get_action(obs))                 # host-drawn Exp(1) noise (reference's CPU stream)
     t_given = timed(lambda: pol.get_action(obs, noise=q_dev))     # noise already resident
+    t_pinned = timed(lambda: pol.get_action(obs_pin, noise=q_dev))
+    st = lambda: ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    rows = pol.arena.stage_obs(torch.from_numpy(obs).cuda())
+    t_kernel = time_region(lambda: pol.act_padded(rows, q_dev), 50, warm=5)   # the fused launch alone (HIP events)
     return dict(workload="4096 x 107 obs per step, 256x3 policy, 90 actions",
                 obs_per_s_host_noise=round(N_AGENTS / t_parity), ms_per_step_host_noise=round(t_parity * 1e3, 3),
                 obs_per_s_resident_noise=round(N_AGENTS / t_given), ms_per_step_resident_noise=round(t_given * 1e3, 3),
-                note="host_noise = the bit-exact action parity mode: Exp(1) noise of torch's CPU generator stream (librlppo's host "
-                     "implementation of torch's exponential_, drawn one step ahead on a helper thread; round 1: torch's serial kernel "
-                     "on the learner thread, 4.7 ms/step) + H2D/D2H included; resident_noise = noise already in HBM")
+                ms_per_step_resident_noise_pinned_obs=round(t_pinned * 1e3, 3), ms_fused_launch=round(t_kernel, 4),
+                note="one step = observations on the host -> actions + log-probs on the host through rlppo_discrete_step (pad + MLP + "
+                     "softmax + clamp + argmax(p/q) + log p in ONE launch that stores its results straight into pinned host memory; "
+                     "round 2: pad + 4 GEMM launches + sampling + two D2H copies).  host_noise = the bit-exact action parity mode: "
+                     "Exp(1) noise of torch's CPU generator stream (librlppo's host implementation of torch's exponential_, drawn one "
+                     "step ahead on a helper thread: ~0.36 ms per draw is the floor of that mode); resident_noise = noise already in "
+                     "HBM, observations in pageable / page-locked host memory; ms_fused_launch = the launch alone (device time)")
 
 
 def cpu_baseline(seed=123, reps=3):
@@ -523,6 +532,13 @@ def iteration_leg(iters=3):
     sync = torch.cuda.synchronize
     rows = []
     try:
+        learner.ppo_learner.policy.noise_mode = "device"   # (not the reference's CPU stream: no host work per step)
+        t_dev = []
+        for it in range(3):
+            sync(); t0 = time.perf_counter()
+            learner.agent.collect_timesteps(N_SAMPLES)
+            sync(); t_dev.append(time.perf_counter() - t0)
+        learner.ppo_learner.policy.noise_mode = "host"
         for it in range(iters + 1):
             sync(); t0 = time.perf_counter()
             exp, _, n, _ = learner.agent.collect_timesteps(N_SAMPLES)
@@ -540,7 +556,8 @@ def iteration_leg(iters=3):
     del learner
     torch.cuda.empty_cache()
     return dict(workload="4096 agents x 128 steps per iteration (configs[1] scale), synthetic vectorised environment, 10-epoch update",
-                collect_ms=round(c, 2), collect_ms_per_env_step=round(c / N_STEPS, 4), add_new_experience_ms=round(a, 3), learn_ms=round(l, 3),
+                collect_ms=round(c, 2), collect_ms_per_env_step=round(c / N_STEPS, 4),
+                collect_ms_device_noise=round(min(t_dev[1:]) * 1e3, 2), add_new_experience_ms=round(a, 3), learn_ms=round(l, 3),
                 iteration_ms=round(c + a + l, 2), steps_per_s=round(N_SAMPLES / (c + a + l) * 1e3),
                 note="collect = 128 x (policy inference on 4096 observations with the reference's CPU noise stream + the environment's "
                      "own step() + H2D of its observations); add_new_experience = value pass on 524,289 rows + GAE scan + ring-buffer "

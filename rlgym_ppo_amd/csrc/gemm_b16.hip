@@ -398,11 +398,230 @@ __global__ __launch_bounds__(TM * 2, TM == 256 ? 1 : 2) void gemm_nt_b16w_kernel
     }
 }
 
+// ------------------------------------------------------------------------------------------------ persistent form [r3]
+// The 256 x 256-tile kernel above spends HALF of a 512 -> 512 launch outside its K loop (tools/b16_k_sweep.py: the intercept of
+// time against K is 176 us of 351): with one workgroup per CU, a tile is [dispatch + bias / descriptors] -> [first stage's DMA
+// latency, nothing to multiply] -> K loop -> [relu / bitmask / rounding: ~800 vector instructions per lane] -> [park in LDS, read
+// back, store] -> workgroup exit, every bracket with the CU's MFMA pipe idle, 16 tiles per CU and launch (~11 us per tile).
+// Here ONE workgroup per CU stays resident and walks its tiles (same column tile every time: its 256 rows of W stay in L2, bias
+// and B descriptor are set up once); the first stage of tile t + 1 is requested BEFORE the epilogue of tile t starts, into the
+// stage buffer the epilogue does not use -- the tile is parked in two halves through the other one (8 KiB per wave) -- so the
+// DMA latency, the epilogue's vector work and its stores overlap, and the next K loop starts on data that is already in LDS.
+// Counted waits: at the first K step of a tile the wave's stage-0 pieces are complete when all but the younger operations --
+// the previous epilogue's 2 bitmask accesses and 16 tile stores -- are (vmcnt(18)); the first tile of a workgroup waits for
+// everything.  XCD-aware walk: workgroup b owns column tile (b % (8 nc)) / 8 and row tiles 8 (b / (8 nc)) + b % 8 + k * (rows
+// covered by the grid): the nc workgroups that share a row tile's A rows carry ids 8 apart, i.e. run on the same XCD.
+template <int MODE>
+__global__ __launch_bounds__(512, 1) void gemm_nt_b16p_kernel(const unsigned short *__restrict__ A, unsigned lda_b,
+                                                              const unsigned short *__restrict__ B, unsigned ldb_b,
+                                                              const float *__restrict__ bias, unsigned short *__restrict__ Cb,
+                                                              unsigned ldcb_b, int64_t M, int K, unsigned long long *__restrict__ bits,
+                                                              int row_tiles, int col_tiles, int row_tiles128) {
+    constexpr int TM = 256, TN = 256, BKT = 32, NW = 8, STAGE = (TM + TN) * BKT;  // floats per stage (64 KiB)
+    constexpr int CPR = BKT / 4, RPI = 64 / CPR, PASS = NW * RPI;                    // 8 chunks per row, 8 rows per instruction, 64 per pass
+    constexpr bool DX = MODE == B16_DX;
+    extern __shared__ __attribute__((aligned(16))) float wlds[];  // [2][A: TM x BKT | B: TN x BKT]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const int r16 = lane & 15, q = lane >> 4;
+    const int wr = wave_u >> 1, wc = wave_u & 1;
+    // this workgroup's column tile and its walk over the row tiles
+    const int b = blockIdx.x, group = 8 * col_tiles;
+    const int col_tile = (b % group) >> 3;
+    const int row_first = (b / group) * 8 + (b & 7), row_stride = (gridDim.x / group) * 8;
+    const int n0 = col_tile * TN;
+
+    const __amdgpu_buffer_rsrc_t b_rs = make_rsrc(reinterpret_cast<const char *>(B) + (int64_t)n0 * ldb_b,
+                                                  (unsigned)(TN - 1) * ldb_b + (unsigned)K * 2);
+    const int row_p = wave * RPI + lane / CPR, pch = lane % CPR;
+    const int lch = pch ^ (row_p & 7);  // the source side of dswz<32>
+    const unsigned a_off = (unsigned)row_p * lda_b + lch * 16;
+    const unsigned b_off = (unsigned)row_p * ldb_b + lch * 16;
+    const unsigned a_step = (unsigned)PASS * lda_b, b_step = (unsigned)PASS * ldb_b;
+    float *bias_l = wlds + 2 * STAGE;  // [256]: this column tile's bias (1 KiB behind the stages; registers are all taken)
+    if (!DX) {
+        if (tid < TN) bias_l[tid] = bias[n0 + tid];
+        __syncthreads();
+    }
+    const __amdgpu_buffer_rsrc_t bits_rs = make_rsrc(bits, (unsigned)((size_t)row_tiles128 * (col_tiles * 2) * 256 * 8));
+    auto a_rsrc = [&](int row_tile) {
+        const int64_t m0 = (int64_t)row_tile * TM;
+        const int rows_here = (int)((M - m0) < TM ? (M - m0) : TM);
+        return make_rsrc(reinterpret_cast<const char *>(A) + m0 * lda_b, (unsigned)(rows_here - 1) * lda_b + (unsigned)K * 2);
+    };
+    auto issue_tile = [&](const __amdgpu_buffer_rsrc_t &a_rs, int buf, unsigned kb) {
+        float *Ad = wlds + buf * STAGE + wave_u * RPI * BKT;
+        float *Bd = wlds + buf * STAGE + TM * BKT + wave_u * RPI * BKT;
+#pragma unroll
+        for (int i = 0; i < TM / PASS; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rs, Ad + i * PASS * BKT, 16, a_off, kb + i * a_step, 0, 0);
+#pragma unroll
+        for (int i = 0; i < TN / PASS; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(b_rs, Bd + i * PASS * BKT, 16, b_off, kb + i * b_step, 0, 0);
+    };
+    // byte offsets of this wave's two bitmask words of a row tile (128 x 128-tile layout of relu_bits); a slot past the last
+    // 128-row tile gets an offset outside the descriptor: the access is dropped but still counted
+    auto bits_off = [&](int row_tile, int h) -> unsigned {
+        const int rt128 = row_tile * 2 + (wr >> 1), ct128 = col_tile * 2 + wc, nct128 = col_tiles * 2;
+        return rt128 < row_tiles128 ? (unsigned)((((size_t)rt128 * nct128 + ct128) * 256 + ((2 * wr + h) & 3) * 64 + lane) * 8) : 0xFFFFFFF0u;
+    };
+
+    const int nk = K / (2 * BKT);
+    if (row_first >= row_tiles) return;  // (a grid larger than the work: nothing was issued)
+    __amdgpu_buffer_rsrc_t a_rs = a_rsrc(row_first);
+    issue_tile(a_rs, 0, 0);
+    bool first = true;
+    u32x2 mask_next[2];
+    if (DX) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) mask_next[h] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(bits_rs, bits_off(row_first, h), 0, 0));
+    }
+    for (int row_tile = row_first; row_tile < row_tiles; row_tile += row_stride) {
+        const int64_t m0 = (int64_t)row_tile * TM;
+        const int rows_here = (int)((M - m0) < TM ? (M - m0) : TM);
+        f32x4 acc[4][8];
+        u32x2 mask_word[2];
+        if (DX) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) mask_word[h] = mask_next[h];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                acc[0][j] = *reinterpret_cast<const f32x4 *>(&bias_l[wc * 128 + j * 16 + q * 4]);
+                acc[1][j] = acc[2][j] = acc[3][j] = acc[0][j];
+            }
+        }
+        for (int kt = 0; kt < nk; ++kt) {
+            const int cur = kt & 1;
+            // stage kt of this tile is in LDS: stage 0 was requested before the previous tile's epilogue (18 younger operations
+            // may still be in flight), every later stage one K step ago with nothing behind it
+            if (kt == 0 && !first) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();  // everybody's pieces of stage kt have landed; everybody is done with the other buffer
+            if (kt + 1 < nk) issue_tile(a_rs, cur ^ 1, (unsigned)(kt + 1) * (4u * BKT));
+            const float *Ac = wlds + cur * STAGE + (wr * 64) * BKT;
+            const float *Bc = wlds + cur * STAGE + TM * BKT + (wc * 128) * BKT;
+#pragma unroll
+            for (int kc = 0; kc < BKT / 16; ++kc) {
+                bf16x8 fa[4], fb[8];
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    fa[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4 *>(&Ac[dswz<BKT>(i * 16 + r16, kc * 4 + q)]));
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    fb[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4 *>(&Bc[dswz<BKT>(j * 16 + r16, kc * 4 + q)]));
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        first = false;
+        __syncthreads();  // every wave is done with the last stage: both buffers are free
+        // ---- the next tile's first stage goes into buffer 0 now; this tile leaves through buffer 1
+        const int next_tile = row_tile + row_stride;
+        const bool more = next_tile < row_tiles;
+        if (more) {
+            a_rs = a_rsrc(next_tile);
+            issue_tile(a_rs, 0, 0);
+        } else {  // keep the count of operations behind the (absent) stage uniform: nothing waits on it again
+        }
+        if (DX) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+                mask_next[h] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(bits_rs, more ? bits_off(next_tile, h) : 0xFFFFFFF0u, 0, 0));
+        }
+        const __amdgpu_buffer_rsrc_t o_rs = make_rsrc(reinterpret_cast<char *>(Cb) + m0 * ldcb_b + (int64_t)(n0 + wc * 128) * 2,
+                                                      (unsigned)(rows_here - 1) * ldcb_b + 128 * 2);
+        char *mine = reinterpret_cast<char *>(wlds + STAGE) + wave_u * (32 * 256);  // 8 KiB of buffer 1
+        const int rr = lane >> 4, c16 = lane & 15;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            // one rounding to bf16; forward: relu + bitmask first, dX: the forward's mask afterwards.  Written for the vector ALU: this
+            // used to be ~1500 instructions per lane and tile (two v_max, a compare + select + shift + or per bit, one conversion per
+            // element) = 5 us of a 20 us tile with the MFMA pipe idle; now relu is one v_max, a bit is v_sub (0 - r: sign set iff r > 0,
+            // +0 stays +0) + v_alignbit (shift the word left, take that sign), a PAIR converts with one v_cvt_pk_bf16_f32.
+            typedef float f32x2 __attribute__((ext_vector_type(2)));
+            typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+            u32x2 pk[2][8];
+            if (!DX) {
+                unsigned word[2];
+#pragma unroll
+                for (int ii = 0; ii < 2; ++ii) {
+                    unsigned w = 0;
+#pragma unroll
+                    for (int j = 7; j >= 0; --j) {  // descending: bit (ii * 8 + j) * 4 + e ends up at its own position
+                        float r[4];
+#pragma unroll
+                        for (int e = 3; e >= 0; --e) {
+                            const float x = acc[2 * h + ii][j][e];
+                            asm volatile("v_max_f32 %0, 0, %1" : "=v"(r[e]) : "v"(x));  // (the MFMAs are long complete: a barrier ago)
+                            w = __builtin_amdgcn_alignbit(w, __float_as_uint(0.f - r[e]), 31);
+                        }
+                        pk[ii][j] = u32x2{__builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{r[0], r[1]}, bf16x2)),
+                                          __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{r[2], r[3]}, bf16x2))};
+                    }
+                    word[ii] = w;
+                }
+                __builtin_amdgcn_raw_buffer_store_b64(u32x2{word[0], word[1]}, bits_rs, bits_off(row_tile, h), 0, 0);
+            } else {
+#pragma unroll
+                for (int ii = 0; ii < 2; ++ii) {
+                    const int w = (int)mask_word[h][ii];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        float r[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float x = acc[2 * h + ii][j][e];
+                            const unsigned m = (unsigned)__builtin_amdgcn_sbfe(w, j * 4 + e, 1);  // 0 or ~0
+                            r[e] = __uint_as_float(__float_as_uint(x) & m);  // masking before the rounding: a masked 0 stays +0
+                        }
+                        pk[ii][j] = u32x2{__builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{r[0], r[1]}, bf16x2)),
+                                          __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{r[2], r[3]}, bf16x2))};
+                    }
+                }
+            }
+            // park the wave's 32 x 128 half (16-byte chunk c of row r at chunk c ^ (r & 15)), read it back as rows: 16 bytes per
+            // lane, 4 rows x 256 contiguous bytes per wave-instruction (the wave reads only what it wrote: no barrier)
+            if (h == 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the first half's read-back is in registers
+#pragma unroll
+            for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int r = 16 * ii + r16, ch = (2 * j + (q >> 1)) ^ (r & 15);
+                    *reinterpret_cast<u32x2 *>(mine + r * 256 + ch * 16 + 8 * (q & 1)) = pk[ii][j];
+                }
+            typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+            const unsigned o_off = (unsigned)(wr * 64 + 32 * h + rr) * ldcb_b + c16 * 16;
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {  // (four rows of registers at a time: the accumulators of the other half are still live)
+                u32x4 v[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int r = 4 * (4 * g + t) + rr;
+                    v[t] = *reinterpret_cast<const u32x4 *>(mine + r * 256 + ((c16 ^ (r & 15)) * 16));
+                }
+#pragma unroll
+                for (int t = 0; t < 4; ++t) __builtin_amdgcn_raw_buffer_store_b128(v[t], o_rs, o_off, 4 * (4 * g + t) * ldcb_b, 0);
+            }
+        }
+    }
+}
+
 // Applicability of the bf16-in-memory forward: K a multiple of 64 (one LDS tile row = 64 k-values), hidden widths a multiple
 // of 128 (the bitmask tile geometry).  Everything else takes the fp32 kernels on the ROUNDED fp32 copies -- the same products
 // (a product of two bf16 values is exact in fp32), only slower -- followed by round_rows (optim.hip).
-static int g_b16_wide = 1;  // rlppo_dbg_set(23, .): 256 x 256 tiles for the hidden / dX products of the bf16 update precision (0: 128 x 128)
-void set_b16_wide_tiles(int on) { g_b16_wide = on != 0; }
+static int g_b16_wide = 2;  // rlppo_dbg_set(23, .): hidden / dX products of the bf16 update precision on 128 x 128 tiles (0), 256 x 256 tiles,
+                            // one workgroup per tile (1), or 256 x 256 tiles walked by persistent workgroups (2, default [r3])
+void set_b16_wide_tiles(int on) { g_b16_wide = on < 0 ? 0 : (on > 2 ? 2 : on); }
 bool nt_b16_ok(int N, int K, bool hidden) {
     if (K % 64 != 0) return false;
     return hidden ? N % 128 == 0 : (N % 128 == 0 || N == 96 || N == 64 || N == 32);
@@ -433,6 +652,35 @@ int launch_gemm_nt_b16(hipStream_t st, const unsigned short *A, int64_t lda, con
         static bool attr_set[2] = {false, false};
         const int which = mode == B16_DX ? 1 : 0;
         const int rt128 = (int)cdiv(M, 128);
+        if (g_b16_wide == 2 && !C && bits && N / 256 <= 8) {  // [r3] persistent workgroups (no fp32 copy of the output in this form)
+            static bool pattr_set[2] = {false, false};
+            constexpr int LDS_BYTES = 2 * (256 + 256) * 32 * 4 + 1024;  // two stages + the column tile's bias
+            static int cus = 0;
+            if (cus == 0) {
+                int dev = 0;
+                RLPPO_HIP(hipGetDevice(&dev));
+                RLPPO_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+            }
+            const int col_tiles = N / 256, row_tiles = (int)cdiv(M, 256), group = 8 * col_tiles;
+            int grid = cus / group * group;  // whole groups of 8 row tiles x all column tiles; never more workgroups than CUs
+            const int need = (int)cdiv(row_tiles, 8) * group;
+            grid = grid < group ? group : (grid > need ? need : grid);
+#define B16P(MODE_)                                                                                                          \
+    do {                                                                                                                     \
+        if (!pattr_set[which]) {                                                                                             \
+            RLPPO_HIP(hipFuncSetAttribute((const void *)gemm_nt_b16p_kernel<MODE_>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                          LDS_BYTES));                                                                       \
+            pattr_set[which] = true;                                                                                         \
+        }                                                                                                                    \
+        hipLaunchKernelGGL((gemm_nt_b16p_kernel<MODE_>), dim3((unsigned)grid), dim3(512), LDS_BYTES, st, A, la, B, lb, bias, Cb, lcb, M, \
+                           K, bits, row_tiles, col_tiles, rt128);                                                            \
+    } while (0)
+            if (which) B16P(B16_DX);
+            else B16P(B16_HIDDEN);
+#undef B16P
+            RLPPO_LAUNCH_CHECK();
+            return 0;
+        }
 #define B16W(MODE_)                                                                                                          \
     do {                                                                                                                     \
         constexpr int LDS_BYTES = 2 * (256 + 256) * 32 * 4; /* two 64 KiB stages; the epilogue parks 16 KiB per wave in them */ \

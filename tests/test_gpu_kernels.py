@@ -110,12 +110,13 @@ def test_gemm_nt_b16(L, M, N, K, hidden, epi, b16_tiles):
     assert torch.equal(D0, D1)
 
 
-@pytest.fixture(params=[1, 0], ids=["tile256", "tile128"])
+@pytest.fixture(params=[2, 1, 0], ids=["tile256_persistent", "tile256", "tile128"])
 def b16_tiles(L, request):
-    """Both tile shapes of the bf16 hidden / dX / dW products (rlppo_dbg_set(23)): 256 x 256 (default where it applies) and 128 x 128."""
+    """The forms of the bf16 hidden / dX / dW products (rlppo_dbg_set(23)): 256 x 256 tiles walked by persistent workgroups (default
+    where it applies [r3]), 256 x 256 tiles with one workgroup per tile, 128 x 128 tiles."""
     check(L, L.rlppo_dbg_set(23, request.param))
     yield request.param
-    check(L, L.rlppo_dbg_set(23, 1))
+    check(L, L.rlppo_dbg_set(23, 2))
 
 
 @pytest.mark.parametrize("M,N,K", [(3072, 512, 512), (4096 + 77, 256, 512), (700, 128, 64), (65536, 512, 512)])
