@@ -682,6 +682,58 @@ static int backward_b16(hipStream_t st, const NetLayout &net, const float *packe
     return rc;
 }
 
+// ---- [r3] paired launches: policy and critic bodies of the same widths (the reference's default: policy_layer_sizes ==
+// critic_layer_sizes, learner.py:54-55) run every hidden layer's forward, dX and dW product as ONE launch carrying both networks
+// (gemm.hip: NtAlt / TnPair), on one stream; only the two heads (a 90-wide GEMM + loss against a matrix-vector product + loss)
+// still fork onto the side stream, where the critic's HBM-bound kernels run beside the policy's MFMA-bound ones.  Same products,
+// same summation orders: bit-identical to the two-chain form.  Why: at the 65,536 rows of one rank of an 8-rank job a hidden-layer
+// launch is 1024 workgroups = exactly one round of the chip; two such launches on two streams cost two launch boundaries and run
+// at the efficiency of the small grid (0.77 of peak isolated against 0.83 at 524,288 rows), 34 launches per optimiser step;
+// paired they are 22 launches of two rounds each.  (That reasoning did not survive the measurement at the 8-rank size: see below.)
+// Measured (tools/ab_update.py, profiles/r03_ab_update.txt): at one rank (524,288 rows per pass) paired launches take 0.7 % off a
+// learn(); at the 65,536 rows of an 8-rank share they ADD 3 % -- with one chain every launch boundary drains the chip, with two
+// chains one network's boundary hides under the other's kernel -- so the pairing applies from PAIRED_MIN_ROWS rows per pass up.
+static int g_paired = 1;  // rlppo_dbg_set(29, 0 / 1 / 2): never / from PAIRED_MIN_ROWS rows / always (tests)
+constexpr int64_t PAIRED_MIN_ROWS = 262144;
+static bool twin_ok(const NetLayout &p, const NetLayout &v, int64_t mb) {
+    if (p.n_layers != v.n_layers || p.n_layers < 2) return false;
+    for (int l = 0; l + 1 < p.n_layers; ++l) {
+        const LayerLayout &a = p.L[l], &b = v.L[l];
+        if (a.in != b.in || a.out != b.out || a.pin != b.pin || a.pout != b.pout) return false;
+        if (a.pout % 128 != 0 || a.pin % 16 != 0 || nt_bits_floats(mb, a.pout) == 0) return false;
+    }
+    return true;
+}
+
+// output layer of one net, forward (mirrors forward()'s last iteration)
+static int head_forward(hipStream_t st, const NetLayout &net, const float *packed, const float *x, int64_t ldx, int64_t n, int out_tanh,
+                        float *out) {
+    const LayerLayout &L = net.L[net.n_layers - 1];
+    if (!out_tanh && gemv_head_ok(L.out, L.pin)) return launch_gemv_fwd(st, x, ldx, packed + L.off_w, packed + L.off_b, out, L.pout, n, L.pin, L.pout);
+    return launch_gemm_nt(st, x, ldx, packed + L.off_w, L.pin, packed + L.off_b, nullptr, 0, out, L.pout, n, L.pout, L.pin,
+                          out_tanh ? EPI_BIAS_TANH : EPI_BIAS);
+}
+// ... and backward: dW / db of the output layer and dX into dx_prev, masked by the last hidden layer's bitmask (backward()'s first iteration)
+static int head_backward(hipStream_t st, const NetLayout &net, const float *packed, const float *dY, const float *X, int64_t mb,
+                         float *dx_prev, float *grad, float *tn_ws, const unsigned long long *bits_prev) {
+    const int last = net.n_layers - 1;
+    const LayerLayout &L = net.L[last];
+    const int64_t ldx = net.L[last - 1].pout;
+    const bool gemv = gemv_head_ok(L.out, L.pin);
+    const size_t floats = tn_layer_floats(net, last, mb);
+    int rc = gemv ? launch_gemv_dw(st, dY, L.pout, X, ldx, grad + L.off_flat_w, grad + L.off_flat_b, L.in, L.pin, mb, tn_ws, floats)
+                  : launch_gemm_tn(st, dY, L.pout, L.pout, X, ldx, L.pin, grad + L.off_flat_w, grad + L.off_flat_b, L.out, L.in, mb, tn_ws, floats);
+    if (rc) return rc;
+    if (gemv) return launch_gemv_dx_bits(st, dY, L.pout, packed + L.off_w, bits_prev, dx_prev, L.pin, L.pin, mb);
+    rc = launch_gemm_nt_bits(st, dY, L.pout, packed + L.off_wt, L.pout, nullptr, dx_prev, L.pin, mb, L.pin, L.pout, EPI_MASK,
+                             const_cast<unsigned long long *>(bits_prev));
+    if (rc == -1) {
+        set_error("paired pass: the output layer's dX needs the bitmask form");
+        return RLPPO_ERR_ARG;
+    }
+    return rc;
+}
+
 int rlppo_ppo_minibatch(void *stream, const rlppo_minibatch_args *a) {
     RLPPO_CHECK_ARG(a != nullptr, "ppo_minibatch: null args");
     NetLayout pol, val;
@@ -835,6 +887,101 @@ int rlppo_ppo_minibatch(void *stream, const rlppo_minibatch_args *a) {
         side = g_side[slot];
         rc = order_after(side, st, g_ev_fork[slot]);
         if (rc) return rc;
+    }
+    const bool twin = !b16 && (g_paired == 2 || (g_paired == 1 && mb >= PAIRED_MIN_ROWS)) && twin_ok(pol, val, mb);
+    if (twin) {
+        const int H = pol.n_layers - 1;  // hidden layers (the same number in both networks)
+        const float *xp = fused_gather ? a->states : states, *xv = xp;
+        int64_t ldx = fused_gather ? a->ld_states : ld_states;
+        for (int l = 0; l < H; ++l) {
+            const LayerLayout &Lp = pol.L[l], &Lv = val.L[l];
+            NtAlt alt;
+            alt.A = xv;
+            alt.B = val_w + Lv.off_w;
+            alt.bias = val_w + Lv.off_b;
+            alt.C = vact[l];
+            alt.bits = vbits[l];
+            rc = launch_gemm_nt_bits(st, xp, ldx, pol_w + Lp.off_w, Lp.pin, pol_w + Lp.off_b, pact[l], Lp.pout, mb, Lp.pout, Lp.pin,
+                                     EPI_BIAS_RELU, pbits[l], l == 0 && fused_gather ? rowtab : nullptr, src_rows, &alt);
+            if (rc) {
+                if (rc == -1) set_error("paired pass: a hidden layer does not have the bitmask form");
+                return rc == -1 ? RLPPO_ERR_ARG : rc;
+            }
+            xp = pact[l];
+            xv = vact[l];
+            ldx = Lp.pout;
+        }
+        // the two heads: forward, loss, output-layer backward -- critic on the side stream
+        hipStream_t hs = st;
+        if (g_two_streams) {
+            hs = g_side[slot];
+            rc = order_after(hs, st, g_ev_fork[slot]);
+            if (rc) return rc;
+        }
+        LossCfg cfg;
+        cfg.clip = a->clip_range;
+        cfg.clip_lo = (float)(1.0 - (double)a->clip_range);
+        cfg.clip_hi = (float)(1.0 + (double)a->clip_range);
+        cfg.ent_coef = a->ent_coef;
+        cfg.mb_ratio = a->mb_ratio;
+        cfg.inv_mb = 1.0f / (float)mb;
+        cfg.var_m = a->var_m;
+        cfg.var_b = a->var_b;
+        cfg.ring_base = ring_base;
+        cfg.ring_cap = ring_cap;
+        float *pout = pact[H], *vout = vact[H];
+        const int64_t ldp = pol.L[H].pout, ldv = val.L[H].pout;
+        rc = head_forward(hs, val, val_w, xv, ldx, mb, 0, vout);
+        if (rc) return rc;
+        rc = launch_value_loss(hs, vout, ldv, nullptr, g_tgt, mb, cfg, a->stats);
+        if (rc) return rc;
+        rc = head_backward(hs, val, val_w, vout, xv, mb, vdx[H - 1], a->val_grad, val_tn_ws, vbits[H - 1]);
+        if (rc) return rc;
+        rc = head_forward(st, pol, pol_w, xp, ldx, mb, a->head == RLPPO_HEAD_GAUSSIAN, pout);
+        if (rc) return rc;
+        if (a->head == RLPPO_HEAD_DISCRETE)
+            rc = launch_discrete_loss(st, pout, ldp, n_out, nullptr, ldv, nullptr, g_act, g_old, g_tgt, g_adv, mb, cfg, a->stats);
+        else if (a->head == RLPPO_HEAD_GAUSSIAN)
+            rc = launch_gaussian_loss(st, pout, ldp, n_out / 2, nullptr, ldv, nullptr, g_act, g_old, g_tgt, g_adv, mb, cfg, a->stats);
+        else if (a->head == RLPPO_HEAD_MULTIDISCRETE)
+            rc = launch_multidiscrete_loss(st, pout, ldp, nullptr, ldv, nullptr, g_act, g_old, g_tgt, g_adv, mb, cfg, a->stats);
+        else {
+            set_error("ppo_minibatch: unknown head %d", a->head);
+            rc = RLPPO_ERR_ARG;
+        }
+        if (rc) return rc;
+        rc = head_backward(st, pol, pol_w, pout, xp, mb, pdx[H - 1], a->pol_grad, pol_tn_ws, pbits[H - 1]);
+        if (rc) return rc;
+        if (hs != st) {
+            rc = order_after(st, hs, g_ev_join[slot]);
+            if (rc) return rc;
+        }
+        // hidden layers, backward: dW (+ reduction) of both networks, then dX of both
+        for (int l = H - 1; l >= 0; --l) {
+            const LayerLayout &Lp = pol.L[l], &Lv = val.L[l];
+            const bool g0 = l == 0 && fused_gather;
+            const float *Xp = l > 0 ? pact[l - 1] : (g0 ? a->states : states), *Xv = l > 0 ? vact[l - 1] : Xp;
+            const int64_t ldxb = l > 0 ? pol.L[l - 1].pout : (g0 ? a->ld_states : ld_states);
+            TnPair pr;
+            pr.dY = vdx[l];
+            pr.X = Xv;
+            pr.dW = a->val_grad + Lv.off_flat_w;
+            pr.db = a->val_grad + Lv.off_flat_b;
+            pr.ws = val_tn_ws;
+            rc = launch_gemm_tn(st, pdx[l], Lp.pout, Lp.pout, Xp, ldxb, Lp.pin, a->pol_grad + Lp.off_flat_w, a->pol_grad + Lp.off_flat_b,
+                                Lp.out, Lp.in, mb, pol_tn_ws, tn_layer_floats(pol, l, mb), g0 ? rowtab : nullptr, src_rows, &pr);
+            if (rc) return rc;
+            if (l == 0) break;
+            NtAlt alt;
+            alt.A = vdx[l];
+            alt.B = val_w + Lv.off_wt;
+            alt.C = vdx[l - 1];
+            alt.bits = vbits[l - 1];
+            rc = launch_gemm_nt_bits(st, pdx[l], Lp.pout, pol_w + Lp.off_wt, Lp.pout, nullptr, pdx[l - 1], Lp.pin, mb, Lp.pin, Lp.pout,
+                                     EPI_MASK, pbits[l - 1], nullptr, 0, &alt);
+            if (rc) return rc == -1 ? RLPPO_ERR_ARG : rc;
+        }
+        return 0;
     }
     if (b16) {
         rc = forward_b16(side, val, val_w, reinterpret_cast<const unsigned short *>(a->val_wb16), states, states_b, ld_states, mb, 0,
@@ -1017,6 +1164,7 @@ int rlppo_dbg_set(int32_t key, int32_t value) {
         case 24: set_exp_fast_transform(value); return 0;
         case 26: g_fused_gather = value; return 0;
         case 27: g_fused_act = value; return 0;
+        case 29: g_paired = value; return 0;
         default: break;
     }
     set_error("dbg_set: unknown key %d", key);

@@ -74,9 +74,19 @@ int launch_gemm_nt(hipStream_t st, const float *A, int64_t lda, const float *B, 
 // the hidden-layer forward that also writes the ReLU bitmask (epi = EPI_BIAS_RELU) / the dX product masked by it (EPI_MASK);
 // returns -1 when that form does not apply (width not a multiple of 128)
 size_t nt_bits_floats(int64_t M, int N);
+// [r3] paired launches: two products of the same shape (a policy and a critic layer of equal widths) in one grid
+struct NtAlt {  // second operand set of a paired gemm_nt launch (M, N, K, leading dimensions and row table shared)
+    const float *A = nullptr, *B = nullptr, *bias = nullptr;
+    float *C = nullptr;
+    unsigned long long *bits = nullptr;
+};
+struct TnPair {  // second operand set of a paired gemm_tn launch + reduction (shapes shared; X unused with a row table)
+    const float *dY = nullptr, *X = nullptr;
+    float *dW = nullptr, *db = nullptr, *ws = nullptr;
+};
 int launch_gemm_nt_bits(hipStream_t st, const float *A, int64_t lda, const float *B, int64_t ldb, const float *bias, float *C,
                         int64_t ldc, int64_t M, int N, int K, int epi, unsigned long long *bits, const unsigned *rowtab = nullptr,
-                        int64_t src_rows = 0);
+                        int64_t src_rows = 0, const NtAlt *alt = nullptr);
 bool nt_gather_ok(int64_t lda, int64_t src_rows, int N, int K);  // can the forward fetch its rows through a row table?
 int launch_gemm_nt_bf16(hipStream_t st, const float *A, int64_t lda, const float *B, int64_t ldb, const float *bias, float *C,
                         int64_t ldc, int64_t M, int N, int nb, int K, int epi);
@@ -88,7 +98,7 @@ size_t tn_partial_floats(int out, int in, int64_t M);
 // rowtab: sample m is X[rowtab[m]] (fused minibatch gather)
 int launch_gemm_tn(hipStream_t st, const float *dY, int64_t ldy, int ny_valid, const float *X, int64_t ldx, int kx_valid,
                    float *dW, float *db, int out, int in, int64_t M, float *ws, size_t ws_floats, const unsigned *rowtab = nullptr,
-                   int64_t src_rows = 0);
+                   int64_t src_rows = 0, const TnPair *pair = nullptr);
 bool tn_gather_ok(int64_t ldx, int64_t src_rows);
 
 // gemm_b16.hip: the bf16 update precision, both operands bf16 in memory, fp32 accumulate ---------------------------------

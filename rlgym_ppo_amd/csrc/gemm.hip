@@ -39,7 +39,16 @@ __global__ __launch_bounds__(256, BKT == 16 ? 4 : 2) void gemm_nt_dma_kernel(con
                                                                               unsigned ldc_b, int64_t M, int K,
                                                                               unsigned long long *__restrict__ bits = nullptr,
                                                                               const unsigned *__restrict__ rowtab = nullptr,
-                                                                              unsigned src_rows = 0) {
+                                                                              unsigned src_rows = 0, NtAlt alt = NtAlt{}) {
+    // [r3] a launch may carry TWO products of the same shape (policy and critic layers of equal widths): blockIdx.z == 1 takes its
+    // operands from `alt` (scalar selects; M, K, leading dimensions, row table are shared)
+    if (blockIdx.z) {
+        A = alt.A;
+        B = alt.B;
+        bias = alt.bias;
+        C = alt.C;
+        bits = alt.bits;
+    }
     constexpr int BN = NB * 16;
     constexpr int CPR = BKT / 4;     // 16-byte chunks per tile row
     constexpr int RPW = 64 / CPR;    // tile rows one wave instruction fills
@@ -361,23 +370,25 @@ bool nt_gather_ok(int64_t lda, int64_t src_rows, int N, int K) {
 }
 int launch_gemm_nt_bits(hipStream_t st, const float *A, int64_t lda, const float *B, int64_t ldb, const float *bias, float *C,
                         int64_t ldc, int64_t M, int N, int K, int epi, unsigned long long *bits, const unsigned *rowtab,
-                        int64_t src_rows) {
+                        int64_t src_rows, const NtAlt *alt) {
     if (!bits || N % 128 != 0 || K % 16 != 0 || M <= 0) return -1;
     if (epi != EPI_BIAS_RELU && epi != EPI_MASK) return -1;
     const int64_t lim = (int64_t)1 << 31;
     if ((!rowtab && 129 * lda * 4 >= lim) || 129 * ldb * 4 >= lim || 129 * ldc * 4 >= lim) return -1;
-    dim3 grid((unsigned)cdiv(M, SBM), (unsigned)(N / 128));
+    RLPPO_CHECK_ARG(!alt || (alt->A && alt->B && alt->C && alt->bits), "gemm_nt: incomplete second operand set");
+    dim3 grid((unsigned)cdiv(M, SBM), (unsigned)(N / 128), alt ? 2u : 1u);
+    const NtAlt second = alt ? *alt : NtAlt{};
     const unsigned la = (unsigned)(lda * 4), lb = (unsigned)(ldb * 4), lc = (unsigned)(ldc * 4);
     if (rowtab) {
         RLPPO_CHECK_ARG(epi == EPI_BIAS_RELU && nt_gather_ok(lda, src_rows, N, K), "gemm_nt (gathered rows): unsupported shape");
         hipLaunchKernelGGL((gemm_nt_dma_kernel<8, EPI_BIAS_RELU, 16, true, true>), grid, dim3(256), 0, st, A, la, B, lb, bias, nullptr,
-                           0u, C, lc, M, K, bits, rowtab, (unsigned)src_rows);
+                           0u, C, lc, M, K, bits, rowtab, (unsigned)src_rows, second);
     } else if (epi == EPI_BIAS_RELU)
         hipLaunchKernelGGL((gemm_nt_dma_kernel<8, EPI_BIAS_RELU, 16, true>), grid, dim3(256), 0, st, A, la, B, lb, bias, nullptr,
-                           0u, C, lc, M, K, bits);
+                           0u, C, lc, M, K, bits, nullptr, 0u, second);
     else
         hipLaunchKernelGGL((gemm_nt_dma_kernel<8, EPI_MASK, 16, true>), grid, dim3(256), 0, st, A, la, B, lb, nullptr, nullptr, 0u,
-                           C, lc, M, K, bits);
+                           C, lc, M, K, bits, nullptr, 0u, second);
     RLPPO_LAUNCH_CHECK();
     return 0;
 }
@@ -461,7 +472,16 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_dma_kernel(const float *__rest
                                                                               bool with_db, int out, int in, int64_t M,
                                                                               int rows_per_wg, float *__restrict__ partial,
                                                                               const unsigned *__restrict__ rowtab,
-                                                                              unsigned src_rows) {
+                                                                              unsigned src_rows, TnAlt alt) {
+    // [r3] two products of the same shape in one launch: the upper half of the z range takes (dY, X, partial) from `alt`
+    const int splits_z = alt.dY ? gridDim.z / 2 : gridDim.z;
+    int zloc = blockIdx.z;
+    if (alt.dY && zloc >= splits_z) {
+        zloc -= splits_z;
+        dY = alt.dY;
+        if (!GATHER) X = alt.X;
+        partial = alt.partial;
+    }
     constexpr int WK = 4 / WN;
     constexpr int BNT = WN * NI * 16, BKX = WK * NJ * 16, TILE_F = NI * NJ * 1024;
     constexpr int PPW = TMT / 8;  // 1 KiB pieces per wave, per operand and stage
@@ -476,11 +496,11 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_dma_kernel(const float *__rest
     const int wn = wave / WK, wk = wave % WK;
     // XCD-aware order (see xcd_tile): the output tiles of one row split read the same dY / X rows, so they are given ids
     // that land on the same XCD back to back: id -> tile = (id % (8 T)) / 8, split = 8 (id / (8 T)) + id % 8
-    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    int bx = blockIdx.x, by = blockIdx.y, bz = zloc;
     {
         const int T = gridDim.x * gridDim.y;
-        if ((gridDim.z & 7) == 0 && T > 1) {
-            const int id = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x, g = id % (8 * T);
+        if ((splits_z & 7) == 0 && T > 1) {
+            const int id = (zloc * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x, g = id % (8 * T);
             const int tile = g >> 3;
             bz = (id / (8 * T)) * 8 + (g & 7);
             bx = tile % gridDim.x;
@@ -616,7 +636,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_dma_kernel(const float *__rest
 #pragma unroll
             for (int r = 0; r < 8; ++r) sum += red[r * 128 + tid];
             // column sums of this split: partial_db[split][n tile][128], behind the tile partials
-            partial[(size_t)gridDim.z * gridDim.y * gridDim.x * TILE_F + ((size_t)bz * gridDim.x + bx) * 128 + tid] = sum;
+            partial[(size_t)splits_z * gridDim.y * gridDim.x * TILE_F + ((size_t)bz * gridDim.x + bx) * 128 + tid] = sum;
         }
     }
     // The partial-tile stores are the LAST instructions of the wave: 16-byte buffer stores whose data registers are written
@@ -639,7 +659,12 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_dma_kernel(const float *__rest
 // geometry (a tile is geo.ni * geo.nj * 256 such elements: gridDim.x = geo.ni * geo.nj * 4 blocks per tile).
 __global__ __launch_bounds__(256) void tn_reduce_kernel(const float *__restrict__ partial, int splits, int tiles_x, int tiles,
                                                         float *__restrict__ dW, float *__restrict__ db, int out, int in,
-                                                        TnGeom geo) {
+                                                        TnGeom geo, TnRedAlt alt) {
+    if (blockIdx.z) {  // the second product of a paired launch
+        partial = alt.partial;
+        dW = alt.dW;
+        db = alt.db;
+    }
     __shared__ __attribute__((aligned(16))) float red[3][64][4];
     const int tile = blockIdx.y, e64 = threadIdx.x & 63, sl = threadIdx.x >> 6;
     const int elem4 = blockIdx.x * 64 + e64;  // 16-byte element of the tile: (i*NJ+j)*256 + tid
@@ -742,7 +767,7 @@ size_t tn_partial_floats(int out, int in, int64_t M) {
 bool tn_gather_ok(int64_t ldx, int64_t src_rows) { return ldx * 4 < 16384 && ldx % 4 == 0 && src_rows > 0 && src_rows < ((int64_t)1 << 32); }
 int launch_gemm_tn(hipStream_t st, const float *dY, int64_t ldy, int ny_valid, const float *X, int64_t ldx, int kx_valid,
                    float *dW, float *db, int out, int in, int64_t M, float *ws, size_t ws_floats, const unsigned *rowtab,
-                   int64_t src_rows) {
+                   int64_t src_rows, const TnPair *pair) {
     if (M <= 0) return 0;
     RLPPO_CHECK_ARG(ny_valid % 4 == 0 && kx_valid % 4 == 0 && ldy % 4 == 0 && ldx % 4 == 0 && ny_valid <= ldy &&
                         kx_valid <= ldx && out <= ny_valid && in <= kx_valid,
@@ -760,10 +785,14 @@ int launch_gemm_tn(hipStream_t st, const float *dY, int64_t ldy, int ny_valid, c
     RLPPO_CHECK_ARG((rows_per_wg + TM) * ldy * 4 < lim && (rowtab || (rows_per_wg + TM) * ldx * 4 < lim),
                     "gemm_tn: a leading dimension is too wide for 32-bit tile offsets");
     RLPPO_CHECK_ARG(!rowtab || tn_gather_ok(ldx, src_rows), "gemm_tn (gathered rows): unsupported row stride %ld", (long)ldx);
-    dim3 grid((unsigned)tiles_x, (unsigned)tiles_y, (unsigned)splits);
+    RLPPO_CHECK_ARG(!pair || (pair->dY && (rowtab || pair->X) && pair->dW && pair->ws && (pair->db != nullptr) == (db != nullptr)),
+                    "gemm_tn: incomplete second operand set");
+    dim3 grid((unsigned)tiles_x, (unsigned)tiles_y, (unsigned)(pair ? 2 * splits : splits));
+    TnAlt alt{};
+    if (pair) alt = TnAlt{pair->dY, pair->X, pair->ws};
 #define TN(NI_, NJ_, WN_, G_)                                                                                              \
     hipLaunchKernelGGL((gemm_tn_dma_kernel<TM, NI_, NJ_, WN_, G_>), grid, dim3(256), 0, st, dY, (unsigned)(ldy * 4), ny_valid, X, \
-                       (unsigned)(ldx * 4), kx_valid, db != nullptr, out, in, M, rows_per_wg, ws, rowtab, (unsigned)src_rows)
+                       (unsigned)(ldx * 4), kx_valid, db != nullptr, out, in, M, rows_per_wg, ws, rowtab, (unsigned)src_rows, alt)
     if (g.nj == 7) {
         if (rowtab) TN(2, 7, 4, true); else TN(2, 7, 4, false);
     } else if (g.ni == 3) {
@@ -774,12 +803,14 @@ int launch_gemm_tn(hipStream_t st, const float *dY, int64_t ldy, int ny_valid, c
     }
 #undef TN
     RLPPO_LAUNCH_CHECK();
-    return launch_tn_reduce(st, ws, splits, tiles_x, tiles_y, dW, db, out, in, g.ni, g.nj, g.wn);
+    TnRedAlt ralt{};
+    if (pair) ralt = TnRedAlt{pair->ws, pair->dW, pair->db};
+    return launch_tn_reduce(st, ws, splits, tiles_x, tiles_y, dW, db, out, in, g.ni, g.nj, g.wn, pair ? &ralt : nullptr);
 }
 int launch_tn_reduce(hipStream_t st, const float *partial, int splits, int tiles_x, int tiles_y, float *dW, float *db, int out, int in,
-                     int ni, int nj, int wn) {
-    hipLaunchKernelGGL(tn_reduce_kernel, dim3((unsigned)(ni * nj * 4), (unsigned)(tiles_x * tiles_y)), dim3(256), 0, st, partial, splits,
-                       tiles_x, tiles_x * tiles_y, dW, db, out, in, TnGeom{ni, nj, wn});
+                     int ni, int nj, int wn, const TnRedAlt *alt) {
+    hipLaunchKernelGGL(tn_reduce_kernel, dim3((unsigned)(ni * nj * 4), (unsigned)(tiles_x * tiles_y), alt ? 2u : 1u), dim3(256), 0, st,
+                       partial, splits, tiles_x, tiles_x * tiles_y, dW, db, out, in, TnGeom{ni, nj, wn}, alt ? *alt : TnRedAlt{});
     RLPPO_LAUNCH_CHECK();
     return 0;
 }

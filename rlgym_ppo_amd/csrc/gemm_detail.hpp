@@ -148,6 +148,14 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 // host side, shared by the two weight-gradient launchers (defined in gemm.hip / gemm_b16.hip)
 int64_t tn_partial_rows(int out, int in, int64_t M);           // rows per workgroup of the 128 x 128-tile forms
 int64_t tn_partial_rows_wide(int pout, int pin, int64_t M);    // ... of the 256 x 256-tile bf16 form
+struct TnAlt {     // device-side second operand set of a paired gemm_tn launch
+    const float *dY, *X;
+    float *partial;
+};
+struct TnRedAlt {  // ... and of its reduction
+    const float *partial;
+    float *dW, *db;
+};
 int launch_tn_reduce(hipStream_t st, const float *partial, int splits, int tiles_x, int tiles_y, float *dW, float *db, int out, int in,
-                     int ni = 4, int nj = 4, int wn = 2);  // tile geometry of the producing kernel (default: 128 x 128)
+                     int ni = 4, int nj = 4, int wn = 2, const TnRedAlt *alt = nullptr);  // tile geometry of the producing kernel (default: 128 x 128)
 }  // namespace rlppo

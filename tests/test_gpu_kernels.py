@@ -815,11 +815,12 @@ def test_minibatch_gather_and_accumulate_cfg2_shape(L):
                        label=f"cfg2 shape, 3000 gathered rows (slice {s})")
 
 
-def test_fused_gather_is_bitwise_neutral(L):
+def test_fused_gather_and_paired_launches_are_bitwise_neutral(L):
     """[r3] The first layer's four launches fetch their rows straight from the experience arrays through the row table (the
-    minibatch gather fused into the GEMMs' load stage).  That changes no product and no order of summation: gradients
-    and statistics must be BIT-identical to the separate gather pass (rlppo_dbg_set(26, 0)), on a ragged minibatch (1500 rows: a
-    partial row tile, a partial dW stage) drawn at random, with repeats, from a 5000-row buffer."""
+    minibatch gather fused into the GEMMs' load stage), and policy and critic layers of equal widths run as ONE launch
+    (csrc/api.hip, paired pass).  Neither changes a product or the order of a sum: gradients must be BIT-identical to the separate
+    gather pass (rlppo_dbg_set(26, 0)) and to one launch chain per network (rlppo_dbg_set(29, 0)), on a ragged minibatch (1500
+    rows: a partial row tile, a partial dW stage) drawn at random, with repeats, from a 5000-row buffer."""
     rs = np.random.RandomState(21)
     d, A, n, mb = 107, 90, 5000, 1500
     torch.manual_seed(21)
@@ -831,17 +832,20 @@ def test_fused_gather_is_bitwise_neutral(L):
     idx = rs.randint(0, n, mb)
     idx[:3] = [n - 1, 0, n - 1]
     runs = {}
-    for key, k26 in dict(fused=1, separate_gather=0).items():
+    for key, (k26, k29) in dict(fused=(1, 2), separate_gather=(0, 2), two_chains=(1, 0), round2=(0, 0)).items():
         check(L, L.rlppo_dbg_set(26, k26))
+        check(L, L.rlppo_dbg_set(29, k29))   # paired launches (policy + critic layer in one grid) against one chain per network
         try:
             runs[key] = run_minibatch(L, "discrete", pol, val, obs, acts, old, tgt, adv, idx, 0.2, 0.005, 0.25)
         finally:
             check(L, L.rlppo_dbg_set(26, 1))
+            check(L, L.rlppo_dbg_set(29, 1))
     gp0, gv0, st0 = runs["fused"]
-    gp, gv, st = runs["separate_gather"]
-    for (a, b), (c, e) in zip(gp0 + gv0, gp + gv):
-        assert torch.equal(a, c) and torch.equal(b, e)
-    assert np.array_equal(st0, st)
+    for key, (gp, gv, st) in runs.items():
+        for (a, b), (c, e) in zip(gp0 + gv0, gp + gv):
+            assert torch.equal(a, c) and torch.equal(b, e), key
+        # (the report statistics are double atomics of both chains: their order, hence the last bit, may differ)
+        np.testing.assert_allclose(st0, st, rtol=1e-12, atol=0, err_msg=key)
     # and the fused form is right (float64 truth), not merely self-consistent
     fp64_gate.gate(L, "discrete", pol, val, obs[idx], acts[idx], old[idx], adv[idx], tgt[idx], 0.2, 0.005, 0.25, runs["fused"],
                    label="fused gather, ragged 1500-row minibatch")

@@ -13,16 +13,18 @@ with contextlib.redirect_stdout(sys.stderr):
 L = N.lib()
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 configs = {
-    "all on": {},
+    "defaults": {},
+    "paired launches at every size (dbg 29=2)": {"dbg": (29, 2)},
     "separate gather pass (dbg 26=0)": {"dbg": (26, 0)},
     "optimiser tail as fill+norms+update": {"one_launch": False},
-    "both off (round 2 launch structure)": {"dbg2": ((26, 0),), "one_launch": False},
+    "one launch chain per network (dbg 29=0)": {"dbg": (29, 0)},
+    "all off (round 2 launch structure)": {"dbg2": ((26, 0), (29, 0)), "one_launch": False},
 }
 
 
 def apply(cfg, on):
     for key, val in ([cfg["dbg"]] if "dbg" in cfg else []) + list(cfg.get("dbg2", ())):
-        N.check(L.rlppo_dbg_set(key, val if on else 1))
+        N.check(L.rlppo_dbg_set(key, val if on else 1))  # (1 = the default of every switch used here)
     learner.one_launch_optimizer = cfg.get("one_launch", True) if on else True
 
 
