@@ -168,20 +168,20 @@ def kernel_breakdown(learner):
     return rows, dominant
 
 
-TRAFFIC_JSON = "r02_traffic.json"  # tools/pmc_traffic.py output of the committed PMC passes (tools/round_profile.sh)
+TRAFFIC_JSON = "r03_traffic.json"  # tools/pmc_traffic.py output of the committed PMC passes (tools/round_profile.sh)
 
 
 def pmc_traffic_for(kernel_label):
     """HBM bytes per launch of the dominant kernel, from the committed PMC passes (bench.py cannot run rocprofv3 on itself)."""
     path = os.path.join(ROOT, "profiles", TRAFFIC_JSON)
-    key = {"gemm_tn dW hidden 256x256 (x4)": "rlppo::gemm_tn_dma_kernel<32> {dW hidden 256x256}",
-           "gemm_tn dW L0 256x107 (x2), 128x112 tiles": "rlppo::gemm_tn_dma_kernel<32> {dW L0 256x107}",
-           "gemm_tn dW head 90x256, 96x128 tiles": "rlppo::gemm_tn_dma_kernel<32> {dW head 90x256}",
-           "gemm_nt fwd hidden 256->256 +bitmask (x4)": "rlppo::gemm_nt_dma_kernel<8, 1, 16, true> {fwd hidden 256->256}",
-           "gemm_nt fwd L0 112->256 +bitmask (x2 nets)": "rlppo::gemm_nt_dma_kernel<8, 1, 16, true> {fwd L0 128->256}",
-           "gemm_nt fwd head 256->96": "rlppo::gemm_nt_dma_kernel<6, 0, 16, false>",
-           "gemm_nt dX hidden 256->256 bitmask (x4)": "rlppo::gemm_nt_dma_kernel<8, 3, 16, true> {dX hidden 256->256}",
-           "gemm_nt dX head 96->256 bitmask": "rlppo::gemm_nt_dma_kernel<8, 3, 16, true> {dX head 96->256}"}.get(kernel_label)
+    key = {"gemm_tn dW hidden 256x256 (x4)": "rlppo::gemm_tn_dma_kernel<32, 4, 4, 2, false>",
+           "gemm_tn dW L0 256x107 (x2), 128x112 tiles": "rlppo::gemm_tn_dma_kernel<32, 2, 7, 4, false>",
+           "gemm_tn dW head 90x256, 96x128 tiles": "rlppo::gemm_tn_dma_kernel<32, 3, 4, 2, false>",
+           "gemm_nt fwd hidden 256->256 +bitmask (x4)": "rlppo::gemm_nt_dma_kernel<8, 1, 16, true, false> {fwd hidden 256->256}",
+           "gemm_nt fwd L0 112->256 +bitmask (x2 nets)": "rlppo::gemm_nt_dma_kernel<8, 1, 16, true, false> {fwd L0 112->256}",
+           "gemm_nt fwd head 256->96": "rlppo::gemm_nt_dma_kernel<6, 0, 16, false, false>",
+           "gemm_nt dX hidden 256->256 bitmask (x4)": "rlppo::gemm_nt_dma_kernel<8, 3, 16, true, false> {dX hidden 256->256}",
+           "gemm_nt dX head 96->256 bitmask": "rlppo::gemm_nt_dma_kernel<8, 3, 16, true, false> {dX head 96->256}"}.get(kernel_label)
     try:
         # tools/prof_kernels.py launches the same shapes as kernel_breakdown (M = 524,288 rows); tools/pmc_summary.py tells the
         # three dW shapes (same kernel, same grid) apart by their position in the launch cycle
@@ -193,7 +193,10 @@ def pmc_traffic_for(kernel_label):
 
 def gae_traffic():
     try:  # tools/prof_gae.py under rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, summarised by tools/pmc_traffic.py
-        return round(json.load(open(os.path.join(ROOT, "profiles", "r02_gae_traffic.json")))["rlppo::gae_lookback_kernel<false>"]["hbm_bytes"])
+        for tag in ("r03", "r02"):
+            p = os.path.join(ROOT, "profiles", tag + "_gae_traffic.json")
+            if os.path.exists(p):
+                return round(json.load(open(p))["rlppo::gae_lookback_kernel<false>"]["hbm_bytes"])
     except Exception:
         return None
 
@@ -430,7 +433,7 @@ def cfg5_traffic(bf16):
         except Exception:
             continue
         for k, v in t.items():
-            if "gemm_nt_b16" in k and ("<1," in k or "fwd" in k):
+            if "gemm_nt_b16" in k and ("<1," in k or "<1>" in k or "fwd" in k):
                 return round(v["hbm_bytes"])
     return None
 

@@ -16,7 +16,8 @@ M = int(os.environ.get("M", 524288))  # rows per launch: one GPU evaluates the 8
 st = lambda: ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 P = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
 dev = "cuda"
-A128, A256, A96, A32 = (torch.randn(M, k, device=dev) for k in (128, 256, 96, 32))
+K0 = int(L.rlppo_padded_width(107))  # 112: the first layer's padded contraction
+A128, A256, A96, A32 = (torch.randn(M, k, device=dev) for k in (K0, 256, 96, 32))
 A256b = torch.randn(M, 256, device=dev)  # second operand of dW / mask of dX: distinct memory, as in the update
 W = torch.randn(256, 256, device=dev) * 0.05
 bias = torch.zeros(256, device=dev)
@@ -30,12 +31,12 @@ bits = torch.zeros(int(L.rlppo_dbg_gemm_nt_bits_bytes(M, 256)), dtype=torch.uint
 reps = int(os.environ.get("REPS", 3))
 for _ in range(reps):
     N.check(L.rlppo_dbg_gemm_nt_bits(st(), P(A256), 256, P(W), 256, P(bias), P(C256), 256, M, 256, 256, 1, P(bits)))
-    N.check(L.rlppo_dbg_gemm_nt_bits(st(), P(A128), 128, P(W), 128, P(bias), P(C256), 256, M, 256, 128, 1, P(bits)))
+    N.check(L.rlppo_dbg_gemm_nt_bits(st(), P(A128), K0, P(W), K0, P(bias), P(C256), 256, M, 256, K0, 1, P(bits)))
     N.check(L.rlppo_dbg_gemm_nt(st(), P(A256), 256, P(W), 256, P(bias), None, 0, P(C96), 96, M, 96, 256, 0))
     N.check(L.rlppo_dbg_gemm_nt_bits(st(), P(A256), 256, P(W), 256, None, P(C256), 256, M, 256, 256, 3, P(bits)))
     N.check(L.rlppo_dbg_gemm_nt_bits(st(), P(A96), 96, P(W), 96, None, P(C256), 256, M, 256, 96, 3, P(bits)))
     N.check(L.rlppo_dbg_gemm_tn(st(), P(A256), 256, 256, P(A256b), 256, 256, P(dW), P(db), 256, 256, M, P(tn_ws), tn_ws.numel()))
-    N.check(L.rlppo_dbg_gemm_tn(st(), P(A256), 256, 256, P(A128), 128, 128, P(dW), P(db), 256, 107, M, P(tn_ws), tn_ws.numel()))
+    N.check(L.rlppo_dbg_gemm_tn(st(), P(A256), 256, 256, P(A128), K0, K0, P(dW), P(db), 256, 107, M, P(tn_ws), tn_ws.numel()))
     N.check(L.rlppo_dbg_gemm_tn(st(), P(A96), 96, 96, P(A256), 256, 256, P(dW), P(db), 90, 256, M, P(tn_ws), tn_ws.numel()))
 rs = np.random.RandomState(0)
 n = 8192 * 256

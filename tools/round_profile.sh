@@ -2,7 +2,7 @@
 # One GPU-box session that regenerates the evidence under profiles/: usage  tools/round_profile.sh <tag>   (run from the repo root)
 # Collects into gpurun_out/<tag>/; tools/collect_profiles.py then condenses it into profiles/<tag>_*.
 set -eo pipefail
-TAG=${1:-r02}
+TAG=${1:-r03}
 OUT=gpurun_out/$TAG
 rm -rf $OUT/cfg5_stats $OUT/cfg5_fetch $OUT/cfg5_write $OUT/cfg5_sq $OUT/stats $OUT/stats_single $OUT/iso $OUT/pmc_sq $OUT/pmc_fetch $OUT/pmc_write $OUT/gae_stats $OUT/gae_fetch $OUT/gae_write
 mkdir -p $OUT
@@ -28,7 +28,7 @@ RLPPO_TUNE=4=0 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/cfg5
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/cfg5_fetch -- python3 bench.py --config cfg5 --precision bf16 --steps 1 --warmup 0 --no-extras > $OUT/cfg5_fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/cfg5_write -- python3 bench.py --config cfg5 --precision bf16 --steps 1 --warmup 0 --no-extras > $OUT/cfg5_write.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_LDS_BANK_CONFLICT --output-format csv -d $OUT/cfg5_sq -- python3 bench.py --config cfg5 --precision bf16 --steps 1 --warmup 0 --no-extras > $OUT/cfg5_sq.log 2>&1
-export PMC_CYCLE='rlppo::gemm_tn_dma_kernel<32>=dW hidden 256x256,dW L0 256x107,dW head 90x256;rlppo::tn_reduce_kernel=hidden,L0,head;rlppo::gemm_nt_dma_kernel<8, 1, 16, true>=fwd hidden 256->256,fwd L0 128->256;rlppo::gemm_nt_dma_kernel<8, 3, 16, true>=dX hidden 256->256,dX head 96->256'
+export PMC_CYCLE='rlppo::tn_reduce_kernel=hidden,L0,head;rlppo::gemm_nt_dma_kernel<8, 1, 16, true, false>=fwd hidden 256->256,fwd L0 112->256;rlppo::gemm_nt_dma_kernel<8, 3, 16, true, false>=dX hidden 256->256,dX head 96->256'
 python tools/pmc_summary.py $OUT/pmc_sq > $OUT/pmc_sq.csv || true
 python tools/pmc_summary.py $OUT/pmc_fetch > $OUT/pmc_fetch.csv
 python tools/pmc_summary.py $OUT/pmc_write > $OUT/pmc_write.csv
@@ -41,6 +41,12 @@ PMC_CYCLE= python tools/pmc_summary.py $OUT/cfg5_write > $OUT/cfg5_pmc_write.csv
 PMC_CYCLE= python tools/pmc_summary.py $OUT/cfg5_sq > $OUT/cfg5_pmc_sq.csv
 python tools/pmc_traffic.py $OUT/cfg5_pmc_fetch.csv $OUT/cfg5_pmc_write.csv $OUT/cfg5_traffic.json
 python tools/rank_share.py > $OUT/rank_share.txt 2> $OUT/rank_share.log
+python tools/ab_update.py 3 > $OUT/ab_update.txt 2> $OUT/ab_update.log
+python tools/breakdown_rows.py > $OUT/breakdown_rows.txt 2> $OUT/breakdown_rows.log
+python tools/act_kernel_time.py > $OUT/act_kernel_time.txt 2> $OUT/act_kernel_time.log
+python tools/rollout_breakdown.py > $OUT/rollout_breakdown.txt 2> $OUT/rollout_breakdown.log
+rocprofv3 --kernel-trace --output-format csv -d $OUT/share8 -- python3 tools/rank_share.py 8 > $OUT/share8.log 2>&1
+python tools/step_gaps.py $OUT/share8 8 > $OUT/rank_share_step_gaps.txt
 python tools/gae_ab.py > $OUT/gae_floor.txt 2> $OUT/gae_floor.log
 python tools/b16_k_sweep.py > $OUT/b16_k_sweep.txt 2> $OUT/b16_k_sweep.log
 python tools/f32_k_sweep.py > $OUT/f32_k_sweep.txt 2> $OUT/f32_k_sweep.log
