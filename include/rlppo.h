@@ -349,10 +349,13 @@ int rlppo_net_pack_bf16(void *stream, const int32_t *dims, int32_t n_layers, con
  *   4 policy / critic chains of rlppo_ppo_minibatch on two streams [1]
  *  21 GAE look-back spin limit [-1 = default 2^20 | 0 = every wait times out at once (tests)]
  *  22 GAE grid [0 = at most the resident capacity, workgroups loop over chunks beyond it | 1 = one workgroup per chunk always]
- *  23 bf16 update precision, tile of the hidden-layer forward / dX / dW products [1 = 256 x 256, one workgroup per CU (default) |
- *     0 = 128 x 128]
+ *  23 bf16 update precision, form of the hidden-layer forward / dX / dW products [2 = 256 x 256 tiles walked by persistent workgroups
+ *     (forward / dX; default) | 1 = 256 x 256, one workgroup per tile | 0 = 128 x 128]
  *  24 rlppo_torch_cpu_exponential transform [1 = AVX2 logarithm certified element by element against float32 rounding, libm for the
- *     rest (default) | 0 = libm for every element] */
+ *     rest (default) | 0 = libm for every element]
+ *  26 minibatch gather [1 = fused into the first layer's GEMM launches through a row table (default) | 0 = a gather pass of its own]
+ *  27 rlppo_discrete_act / rlppo_discrete_step [1 = one fused launch where the network has that form (default) | 0 = layer chain]
+ *  29 policy + critic layers of equal widths as ONE launch [1 = from 262,144 rows per pass (default) | 0 = never | 2 = always] */
 int rlppo_dbg_set(int32_t key, int32_t value);
 /* Counter bumped by every call that changes which kernels later launches select (rlppo_dbg_set, rlppo_set_*_precision): a
  * host that caches captured graphs of library calls keys them on it (rlgym_ppo_amd/ppo/_mlp.py::ActGraph). */
