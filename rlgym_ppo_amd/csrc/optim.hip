@@ -524,7 +524,7 @@ __global__ __launch_bounds__(256) void adam_pack2_kernel(OptPair o) {
 // barrier (generation word).  While they wait the others already hold the Adam operands of their first elements in registers.
 // Agent-scope atomics only on the words that cross workgroups (cdna_hip_programming.md Guideline 16); the block needs no
 // per-launch memset: it is zeroed ONCE by its owner and every completed launch leaves it armed.  All workgroups are co-resident
-// (at most 4 of 256 threads per CU, no LDS to speak of); the spin is bounded, and a wait that gives up counts itself in the
+// (at most one of 256 threads per CU, no LDS to speak of); the spin is bounded, and a wait that gives up counts itself in the
 // block's timeout word and poisons that network's step with NaN (PPOLearner.learn reads the word back with its report and raises).
 struct FusedSync {
     unsigned count, gen, timeouts, pad[13];  // 64-byte header
@@ -532,7 +532,8 @@ struct FusedSync {
 };
 static_assert(sizeof(FusedSync) <= RLPPO_OPT_SYNC_BYTES, "RLPPO_OPT_SYNC_BYTES");
 constexpr int FUSED_EPT = 6;                    // elements per thread whose operands are fetched before the barrier
-constexpr int FUSED_MAX_BLOCKS = 512;           // per network
+constexpr int FUSED_MAX_BLOCKS = 128;           // per network: 256 workgroups per launch, so that even 8 processes sharing one GPU (the
+                                                // gloo tests) keep every launch's grid co-resident (2048 workgroup slots of 256 threads)
 constexpr unsigned FUSED_SPIN_LIMIT = 1u << 22;  // x (s_sleep 8 + one L2 round trip) ~ seconds
 
 __device__ __forceinline__ void adam_one(const OptNet &N, int64_t i, float gi, float mi, float vi, float p0, float coef) {
