@@ -580,6 +580,52 @@ def test_fused_rollout_step_is_bit_identical_to_the_layer_chain(L, d, hidden, A)
     assert (~same).sum().item() <= 2 and (logp.cpu() - ologp)[same].abs().max().item() < 1e-5
 
 
+@pytest.mark.parametrize("hidden", [(256, 256, 256), (64, 64), (96, 96)], ids=["fused256", "fused64", "chain_only"])
+def test_discrete_step_raw_observations_all_modes(L, hidden):
+    """[r3] rlppo_discrete_step -- raw observations (fp32 / fp64, ragged row stride) -> standardise (none / the reference's scalars of
+    feature 0 / per-feature vectors) + pad -> policy -> actions, the actions as floats, log-probs and the padded rows -- against the
+    launch-by-launch form it replaces (rlppo_pad_rows[_per_feature] + rlppo_discrete_act on the layer chain, rlppo_dbg_set(27, 0)):
+    every output BIT-identical, whether the network has the fused kernel's form (256- and 64-wide) or not (96-wide: the entry point
+    then runs the chain itself)."""
+    d, A, n = 107, 90, 777
+    torch.manual_seed(len(hidden) + hidden[0])
+    net = Net(L, nets.init_mlp(d, hidden, A))
+    rs = np.random.RandomState(hidden[0])
+    raw = (rs.randn(n, d + 5) * 3 + 0.7)          # ld_obs = d + 5: the observations are a column slice of a wider array
+    q = dev(rs.exponential(size=(n, A)).astype(np.float32))
+    mean_v, std_v = dev(rs.randn(d).astype(np.float32)), dev((0.5 + rs.rand(d)).astype(np.float32))
+    ws = torch.empty(int(L.rlppo_discrete_step_workspace_bytes(net.dims_c, net.nl, n)), dtype=torch.uint8, device="cuda")
+    for f64 in (False, True):
+        obs = dev(raw, torch.float64 if f64 else torch.float32)
+        for mode in (0, 1, 2):
+            outs = []
+            for fused in (1, 0):
+                act = torch.full((n,), -1, dtype=torch.int64, device="cuda")
+                actf = torch.full((n,), float("nan"), device="cuda")
+                logp = torch.full((n,), float("nan"), device="cuda")
+                rows = torch.full((n, net.ld_in + 16), float("nan"), device="cuda")   # ld_rows_out wider than the padded width
+                check(L, L.rlppo_dbg_set(27, fused))
+                try:
+                    check(L, L.rlppo_discrete_step(stream(), net.dims_c, net.nl, P(net.packed), P(obs), int(f64), d + 5, n, mode, 0.3, 1.7,
+                                                    P(mean_v) if mode == 2 else None, P(std_v) if mode == 2 else None, P(q), P(act), P(actf),
+                                                    P(logp), P(rows), rows.shape[1], P(ws), ws.numel()))
+                finally:
+                    check(L, L.rlppo_dbg_set(27, 1))
+                outs.append((act.cpu(), actf.cpu(), logp.cpu(), rows[:, :net.ld_in].cpu()))
+            for a, b in zip(outs[0], outs[1]):
+                assert torch.equal(a, b), (hidden, f64, mode)
+            act, actf, logp, rows = outs[0]
+            assert torch.equal(actf, act.float()) and (act >= 0).all() and (act < A).all()
+            # the padded rows: the reference's expression (batched_agent_manager.py:313-315) in fp32, zero padding
+            x = obs[:, :d].float().cpu()
+            want = x if mode == 0 else ((x - 0.3) / 1.7).clamp(-5, 5) if mode == 1 else ((x - mean_v.cpu()) / std_v.cpu()).clamp(-5, 5)
+            assert torch.allclose(rows[:, :d], want, rtol=2e-6, atol=2e-6) and (rows[:, d:] == 0).all()
+            if mode == 0:
+                assert torch.equal(rows[:, :d], want)
+    assert L.rlppo_discrete_step(stream(), net.dims_c, net.nl, P(net.packed), P(obs), 0, d - 1, n, 0, 0.0, 1.0, None, None, P(q), P(act), None,
+                                 P(logp), None, 0, P(ws), ws.numel()) != 0   # ld_obs < d is refused
+
+
 @pytest.mark.parametrize("A", [90, 300, 1000])
 def test_discrete_probs_and_deterministic_choice(L, golden, A):
     """rlppo_discrete_probs = DiscreteFF.get_output (softmax) and the deterministic branch of get_action: clamp(1e-11, 1), then
@@ -746,6 +792,17 @@ def run_minibatch(L, head, pol, val, obs_all, acts_all, old_all, tgt_all, adv_al
     check(L, L.rlppo_ppo_minibatch(stream(), ctypes.byref(a)))
     torch.cuda.synchronize()
     return nets.unflatten(gp.cpu(), pol), nets.unflatten(gv.cpu(), val), stats.cpu().numpy()
+
+
+def test_float64_truth_is_guarded_on_the_gpu_box_too(golden):
+    """Every GPU gate leans on oracle/ppo.py::minibatch_analytic (float64, hand-derived gradients = the formulas of csrc/heads.hip).
+    What breaks the common mode between it and the kernels is its check against the AUTOGRAD form of the same minibatch -- a CPU
+    test (tests/test_oracle_nets_ppo.py); it runs here as well, on the GPU box's host (another CPU, other ATen kernels), so that
+    the truth the `-m gpu` set measures against is verified in the same run."""
+    import test_oracle_nets_ppo as cpu
+    cpu.test_g4_discrete_loss_and_grads(golden)
+    cpu.test_g9_gaussian_head(golden)
+    cpu.test_g9_multidiscrete_head(golden)
 
 
 def test_g4_discrete_minibatch_against_reference(L, golden):

@@ -475,3 +475,30 @@ def test_get_action_graph_replay_other_heads():
             a0, l0 = pol.get_action(obs)
             assert torch.equal(a0, a1) and torch.equal(l0, l1)
         assert set(pol._graphs) == {16, 48, 512}
+
+
+def test_discrete_step_host_and_device_outputs():
+    """DiscreteFF.step [r3]: the same step with its results in pinned host memory (to_host=True: what get_action returns), with only the
+    action indices on the host (to_host="actions": the vectorised rollout) and on the device -- identical numbers, and identical to
+    get_action's; the optional device destinations (padded rows, float actions, log-probs) are filled."""
+    torch.manual_seed(3)
+    from rlgym_ppo_amd.ppo import DiscreteFF
+    pol = DiscreteFF(107, 90, (256, 256, 256), "cuda:0")
+    rs = np.random.RandomState(3)
+    obs = np.clip(rs.randn(300, 107), -5, 5).astype(np.float32)
+    q = torch.as_tensor(rs.exponential(size=(300, 90)).astype(np.float32))
+    a0, lp0 = pol.get_action(obs, noise=q)                      # ActGraph (n <= 1024, host input)
+    a1, lp1 = pol.step(obs, noise=q)                            # fused launch, pinned outputs
+    rows = torch.empty(300, pol.arena.ld_in, device="cuda")
+    af, lpd = torch.empty(300, device="cuda"), torch.empty(300, device="cuda")
+    a2, lp2 = pol.step(torch.from_numpy(obs).cuda(), noise=q.cuda(), rows_out=rows, actions_f32=af, logp_out=lpd, to_host="actions")
+    a3, lp3 = pol.step(obs, noise=q, to_host=False)
+    assert not a1.is_cuda and not a2.is_cuda and lp2.is_cuda and a3.is_cuda
+    for a, lp in ((a1, lp1), (a2, lp2), (a3, lp3)):
+        assert torch.equal(a.cpu(), a0) and torch.equal(lp.cpu(), lp0)
+    assert lp2.data_ptr() == lpd.data_ptr() and torch.equal(af.cpu(), a0.float())
+    assert torch.equal(rows, pol.arena.stage_obs(obs))
+    # standardisation fused in: the reference's scalars
+    b0, _ = pol.get_action(obs, noise=q, standardize=(0.25, 2.0))
+    b1, _ = pol.step(obs, noise=q, standardize=(0.25, 2.0))
+    assert torch.equal(b0, b1)
