@@ -404,6 +404,7 @@ class HostExponential:
     caller uploads them with an asynchronous copy and must have consumed a buffer before the next-but-one request."""
 
     RING = 3
+    LOOKAHEAD_MIN = 65536  # elements: below that the hand-over to the helper thread (~50 us) costs more than the draw itself (~1 ns per number)
 
     def __init__(self):
         import os
@@ -505,7 +506,7 @@ class HostExponential:
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream(out.device))
             rec["uploaded"][slot] = ev
-        if self.lookahead:
+        if self.lookahead and numel >= self.LOOKAHEAD_MIN:
             self._speculate(shape, numel, after)
         return out
 

@@ -32,7 +32,7 @@ def build_body(input_shape, layer_sizes, n_out, final_activation=None):
 class ActGraph:
     """One hipGraph of the whole rollout step of a policy head for up to `cap` observations, with no copy in it:
     rlppo_pad_rows reads the observations and the head's act entry point (forward + sampling) reads its noise straight from
-    pinned host memory (hipHostMalloc memory is mapped into the GPU's address space), and the actions / log-probabilities are
+    pinned host memory (the discrete head: ONE node, rlppo_discrete_step on the raw observations [r3]) (hipHostMalloc memory is mapped into the GPU's address space), and the actions / log-probabilities are
     written straight into pinned host memory.  At the reference's rollout scale (8-80 observations per call,
     batched_agent_manager.py:202-204) a call is nothing but latency -- ~7 launches, three copies and two blocking read-backs,
     ~140-250 us; one replay + one synchronisation does the same work, with no copy node at all.  Same kernels, same
@@ -42,15 +42,21 @@ class ActGraph:
         a = pol.arena
         dev, d = a.device, a.d_in
         self.cap = cap
+        self.dev = dev
         self.obs_pin = torch.zeros(cap, d).pin_memory()
         self.q_pin = torch.ones(pol._noise_shape(cap)).pin_memory()
         self.rows = torch.zeros(cap, a.ld_in, device=dev)
         self.act_pin = pol._action_buffer(cap).pin_memory()
         self.logp_pin = torch.zeros(cap, dtype=torch.float32).pin_memory()
-        self.ws = torch.empty(int(N.lib().rlppo_forward_workspace_bytes(a.dims_c, a.n_layers, cap)), dtype=torch.uint8, device=dev)
         L = N.lib()
+        raw = getattr(pol, "_act_launch_raw", None)  # [r3] a head whose whole step is one launch on raw observations
+        ws_bytes = max(int(L.rlppo_forward_workspace_bytes(a.dims_c, a.n_layers, cap)), raw(None, cap) if raw is not None else 0)
+        self.ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
 
         def body():
+            if raw is not None:
+                raw(self, cap)
+                return
             N.check(L.rlppo_pad_rows(stream_ptr(), ptr(self.obs_pin), 0, cap, d, d, ptr(self.rows), a.ld_in, 0, 0.0, 1.0))
             pol._act_launch(self.rows, cap, self.q_pin, self.act_pin, self.logp_pin, self.ws)
 
@@ -63,14 +69,17 @@ class ActGraph:
         # thread_local: the shuffle pipeline's helper threads may be issuing copies / events on their own stream right now
         with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
             body()
+        self.obs_np, self.q_np = self.obs_pin.numpy(), self.q_pin.view(-1).numpy()
+        self.act_np, self.logp_np = self.act_pin.numpy(), self.logp_pin.numpy()
 
     def run(self, obs, q, n):
-        self.obs_pin[:n].numpy()[...] = obs
-        # plain memcpy: Tensor.copy_ fans out to an OpenMP team above 32k elements (10 ms on a 256-thread host)
-        self.q_pin.view(-1)[:q.numel()].numpy()[...] = q.reshape(-1).numpy()
+        # plain memcpy through numpy views made once: Tensor.copy_ fans out to an OpenMP team above 32k elements (10 ms on a
+        # 256-thread host), and slicing tensors costs more than these copies at 8-80 rows
+        self.obs_np[:n] = obs
+        self.q_np[:q.numel()] = q.reshape(-1).numpy()
         self.graph.replay()
-        torch.cuda.current_stream().synchronize()
-        return self.act_pin[:n].clone(), self.logp_pin[:n].clone()
+        torch.cuda.current_stream(self.dev).synchronize()
+        return torch.from_numpy(self.act_np[:n].copy()), torch.from_numpy(self.logp_np[:n].copy())
 
 
 def _bucket(n):

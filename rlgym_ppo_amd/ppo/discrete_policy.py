@@ -139,6 +139,16 @@ class DiscreteFF(ArenaModule):
         N.check(N.lib().rlppo_discrete_act(stream_ptr(), a.dims_c, a.n_layers, ptr(a.packed), ptr(rows), rows.shape[1], n,
                                            ptr(noise), ptr(actions), ptr(logp), None, ptr(ws), ws.numel()))
 
+    def _act_launch_raw(self, g, cap):
+        """ActGraph's body as one node: rlppo_discrete_step on the graph's pinned observations / noise / outputs (g=None: the
+        workspace bytes that takes)."""
+        a = self.arena
+        L = N.lib()
+        if g is None:
+            return int(L.rlppo_discrete_step_workspace_bytes(a.dims_c, a.n_layers, cap))
+        N.check(L.rlppo_discrete_step(stream_ptr(), a.dims_c, a.n_layers, ptr(a.packed), ptr(g.obs_pin), 0, a.d_in, cap, 0, 0.0, 1.0,
+                                      None, None, ptr(g.q_pin), ptr(g.act_pin), None, ptr(g.logp_pin), None, 0, ptr(g.ws), g.ws.numel()))
+
     def act_padded(self, rows, noise=None):
         """Padded device rows [n, ld_in] -> (actions int64 [n], log_probs fp32 [n]) ON THE DEVICE: the part of get_action
         after staging, for callers that keep the rollout on the GPU (VectorAgentManager)."""

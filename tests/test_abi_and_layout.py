@@ -251,12 +251,13 @@ def test_host_exponential_is_torch_exponential_bit_for_bit():
     # the look-ahead pipeline: a rollout-like sequence with a foreign draw, a shape change and a re-seed in between
     def sequence(draw_):
         fn = lambda shape: draw_(shape).clone()         # the pipeline hands out views of recycled pinned buffers
+        big = (768, 90)                                 # >= HostExponential.LOOKAHEAD_MIN elements: drawn ahead; small shapes on the spot
         torch.manual_seed(3)
-        out = [fn((64, 90)), fn((64, 90)), fn((64, 90))]
+        out = [fn(big), fn(big), fn(big)]
         out.append(torch.randn(5))                      # somebody else uses the generator: the speculation must be dropped
-        out += [fn((64, 90)), fn((8 * 8, 3)), fn((64, 90)), fn((64, 90))]
+        out += [fn(big), fn((8 * 8, 3)), fn(big), fn(big), fn((64, 90)), fn((64, 90)), fn(big)]
         torch.manual_seed(4)                            # re-seeded
-        out += [fn((64, 90)), fn((64, 90))]
+        out += [fn(big), fn(big)]
         return out, torch.get_rng_state()
 
     ref, s_ref = sequence(lambda shape: torch.empty(shape).exponential_(1))
