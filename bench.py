@@ -781,8 +781,15 @@ def main():
         import select, signal, socket, threading
         rd, wr = socket.socketpair()
         wr.setblocking(False)
-        signal.signal(signal.SIGTERM, lambda *_: None)
-        signal.set_wakeup_fd(wr.fileno())
+        # A fault inside the A/B (SIGSEGV / SIGBUS in a library the direct route loads) wakes the watchdog the same way: CPython's C-level
+        # handler writes the signal number to the descriptor from signal context, the faulting thread keeps re-faulting, the
+        # watchdog prints the line and leaves.  (abort() cannot be held this way; the line is on stderr before the A/B starts.)
+        fatal = (signal.SIGTERM, signal.SIGSEGV, signal.SIGBUS)
+        for sig in fatal:
+            signal.signal(sig, lambda *_: None)
+        signal.set_wakeup_fd(wr.fileno(), warn_on_full_buffer=False)
+        if rank == 0:
+            log("headline before the exchange A/B: " + json.dumps({k: out[k] for k in ("value", "unit", "n_gpus", "ms_per_step")}))
 
         def bail():
             ready, _, _ = select.select([rd], [], [], 120.0)
@@ -796,7 +803,8 @@ def main():
         out["allreduce"] = allreduce_ab(learner, buf, max(1, min(args.steps, 5)), world, device, dist)
         wr.send(b"\0")
         signal.set_wakeup_fd(-1)
-        signal.signal(signal.SIGTERM, signal.SIG_DFL)
+        for sig in fatal:
+            signal.signal(sig, signal.SIG_DFL)
     if rank == 0 and world == 1 and not args.no_extras and args.config == "cfg5":
         out.update(cfg5_rooflines(value, bf16, learner))
     if rank == 0 and world == 1 and not args.no_extras and args.config == "cfg2":
