@@ -294,7 +294,8 @@ int rlppo_discrete_act(void *stream, const int32_t *dims, int32_t n_layers, cons
     RLPPO_CHECK_ARG(n > 0 && packed && obs && noise_q && actions && logp && workspace, "discrete_act: bad argument");
     // [r3] one launch for the whole step when the network has the form fused_act.hip covers (fp32 inference precision); the
     // layer-by-layer chain below otherwise -- bit-identical results either way
-    if (g_fused_act && !get_infer_bf16() && fused_act_ok(net) && n <= FUSED_ACT_MAX_ROWS && ld_obs >= net.L[0].pin && ld_obs % 4 == 0) {
+    if (g_fused_act && !get_infer_bf16() && fused_act_ok(net) && n <= FUSED_ACT_MAX_ROWS && ld_obs >= net.L[0].pin && ld_obs % 4 == 0 &&
+        (reinterpret_cast<uintptr_t>(obs) & 15) == 0) {  // (the kernel stages the padded rows with 16-byte loads)
         FusedActIO io;
         io.rows = obs;
         io.ld_rows = ld_obs;
@@ -448,17 +449,28 @@ int rlppo_gae(void *stream, const float *rews, const float *dones, const float *
 static int g_two_streams = 1;  // tuning: rlppo_dbg_set(4, 0/1)
 static int g_fused_gather = 1;  // rlppo_dbg_set(26, 0/1): first-layer launches fetch their rows through the row table
 static int g_update_bf16 = 0;   // rlppo_set_update_precision
-// Library-owned streams: slot s > 0 runs its policy chain on g_main[s]; every slot runs its critic chain on g_side[s].
-static hipStream_t g_main[RLPPO_MAX_SLOTS] = {}, g_side[RLPPO_MAX_SLOTS] = {};
-static hipEvent_t g_ev_fork[RLPPO_MAX_SLOTS] = {}, g_ev_join[RLPPO_MAX_SLOTS] = {}, g_ev_slot[RLPPO_MAX_SLOTS] = {};
-static bool g_slot_pending[RLPPO_MAX_SLOTS] = {};
-static int ensure_slot(int s) {
-    if (!g_side[s]) {
-        RLPPO_HIP(hipStreamCreateWithFlags(&g_side[s], hipStreamNonBlocking));
-        RLPPO_HIP(hipStreamCreateWithFlags(&g_main[s], hipStreamNonBlocking));
-        RLPPO_HIP(hipEventCreateWithFlags(&g_ev_fork[s], hipEventDisableTiming));
-        RLPPO_HIP(hipEventCreateWithFlags(&g_ev_join[s], hipEventDisableTiming));
-        RLPPO_HIP(hipEventCreateWithFlags(&g_ev_slot[s], hipEventDisableTiming));
+// Library-owned streams: slot s > 0 runs its policy chain on main[s]; every slot runs its critic chain on side[s].  One bank per
+// device id (streams and events belong to the device that was current when they were made; a process may drive several).
+struct SlotBank {
+    hipStream_t main[RLPPO_MAX_SLOTS] = {}, side[RLPPO_MAX_SLOTS] = {};
+    hipEvent_t ev_fork[RLPPO_MAX_SLOTS] = {}, ev_join[RLPPO_MAX_SLOTS] = {}, ev_slot[RLPPO_MAX_SLOTS] = {};
+    bool pending[RLPPO_MAX_SLOTS] = {};
+};
+static SlotBank g_banks[64];
+static int slot_bank(SlotBank **bank) {
+    int dev = 0;
+    RLPPO_HIP(hipGetDevice(&dev));
+    RLPPO_CHECK_ARG(dev >= 0 && dev < 64, "device id %d", dev);
+    *bank = &g_banks[dev];
+    return 0;
+}
+static int ensure_slot(SlotBank &b, int s) {
+    if (!b.side[s]) {
+        RLPPO_HIP(hipStreamCreateWithFlags(&b.side[s], hipStreamNonBlocking));
+        RLPPO_HIP(hipStreamCreateWithFlags(&b.main[s], hipStreamNonBlocking));
+        RLPPO_HIP(hipEventCreateWithFlags(&b.ev_fork[s], hipEventDisableTiming));
+        RLPPO_HIP(hipEventCreateWithFlags(&b.ev_join[s], hipEventDisableTiming));
+        RLPPO_HIP(hipEventCreateWithFlags(&b.ev_slot[s], hipEventDisableTiming));
     }
     return 0;
 }
@@ -767,15 +779,19 @@ int rlppo_ppo_minibatch(void *stream, const rlppo_minibatch_args *a) {
                     (long)a->ring_cap);
     const int slot = a->slot;
     RLPPO_CHECK_ARG(slot >= 0 && slot < RLPPO_MAX_SLOTS, "ppo_minibatch: slot %d not in [0, %d)", slot, RLPPO_MAX_SLOTS);
-    rc = ensure_slot(slot);
+    SlotBank *bank = nullptr;
+    rc = slot_bank(&bank);
+    if (rc) return rc;
+    SlotBank &bk = *bank;
+    rc = ensure_slot(bk, slot);
     if (rc) return rc;
     hipStream_t caller = (hipStream_t)stream;
     hipStream_t st = caller;
     if (slot > 0) {  // this minibatch's chains run beside the caller's stream; rlppo_ppo_join() brings them back
-        st = g_main[slot];
-        rc = order_after(st, caller, g_ev_slot[slot]);
+        st = bk.main[slot];
+        rc = order_after(st, caller, bk.ev_slot[slot]);
         if (rc) return rc;
-        g_slot_pending[slot] = true;
+        bk.pending[slot] = true;
     }
     float *w = reinterpret_cast<float *>(a->workspace);
     float *pact[RLPPO_MAX_LAYERS], *vact[RLPPO_MAX_LAYERS];
@@ -884,8 +900,8 @@ int rlppo_ppo_minibatch(void *stream, const rlppo_minibatch_args *a) {
     // ramp-up / tail leaves idle is worth more than any single-kernel tweak.
     hipStream_t side = st;
     if (g_two_streams) {
-        side = g_side[slot];
-        rc = order_after(side, st, g_ev_fork[slot]);
+        side = bk.side[slot];
+        rc = order_after(side, st, bk.ev_fork[slot]);
         if (rc) return rc;
     }
     const bool twin = !b16 && (g_paired == 2 || (g_paired == 1 && mb >= PAIRED_MIN_ROWS)) && twin_ok(pol, val, mb);
@@ -914,8 +930,8 @@ int rlppo_ppo_minibatch(void *stream, const rlppo_minibatch_args *a) {
         // the two heads: forward, loss, output-layer backward -- critic on the side stream
         hipStream_t hs = st;
         if (g_two_streams) {
-            hs = g_side[slot];
-            rc = order_after(hs, st, g_ev_fork[slot]);
+            hs = bk.side[slot];
+            rc = order_after(hs, st, bk.ev_fork[slot]);
             if (rc) return rc;
         }
         LossCfg cfg;
@@ -953,7 +969,7 @@ int rlppo_ppo_minibatch(void *stream, const rlppo_minibatch_args *a) {
         rc = head_backward(st, pol, pol_w, pout, xp, mb, pdx[H - 1], a->pol_grad, pol_tn_ws, pbits[H - 1]);
         if (rc) return rc;
         if (hs != st) {
-            rc = order_after(st, hs, g_ev_join[slot]);
+            rc = order_after(st, hs, bk.ev_join[slot]);
             if (rc) return rc;
         }
         // hidden layers, backward: dW (+ reduction) of both networks, then dX of both
@@ -1048,16 +1064,20 @@ int rlppo_ppo_minibatch(void *stream, const rlppo_minibatch_args *a) {
         rc = backward(st, pol, pol_w, states, ld_states, mb, pact, pdx, a->pol_grad, pol_tn_ws, pbits, phave, cp);
     }
     if (rc) return rc;
-    if (side != st) rc = order_after(st, side, g_ev_join[slot]);
+    if (side != st) rc = order_after(st, side, bk.ev_join[slot]);
     return rc;
 }
 
 int rlppo_ppo_join(void *stream) {
+    SlotBank *bank = nullptr;
+    int rc = slot_bank(&bank);
+    if (rc) return rc;
+    SlotBank &bk = *bank;
     for (int s = 1; s < RLPPO_MAX_SLOTS; ++s)
-        if (g_slot_pending[s]) {
-            int rc = order_after((hipStream_t)stream, g_main[s], g_ev_slot[s]);
+        if (bk.pending[s]) {
+            rc = order_after((hipStream_t)stream, bk.main[s], bk.ev_slot[s]);
             if (rc) return rc;
-            g_slot_pending[s] = false;
+            bk.pending[s] = false;
         }
     return 0;
 }

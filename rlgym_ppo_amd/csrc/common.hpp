@@ -4,6 +4,8 @@
 #include <stdint.h>
 #include <stdio.h>
 
+#include <atomic>
+
 #include "../../include/rlppo.h"
 
 namespace rlppo {
@@ -28,6 +30,35 @@ void set_error(const char *fmt, ...);
     } while (0)
 
 #define RLPPO_LAUNCH_CHECK() RLPPO_HIP(hipGetLastError())
+
+// Function attributes and device properties belong to a DEVICE, and one process may drive several (the design is one process per
+// GPU, but nothing in the C ABI forbids more): per-kernel set-up state is therefore a bit per device id, not a process-wide flag.
+struct PerDeviceOnce {
+    std::atomic<unsigned long long> done{0};
+};
+inline int set_dynamic_lds_once(const void *fn, int bytes, PerDeviceOnce &once) {
+    int dev = 0;
+    RLPPO_HIP(hipGetDevice(&dev));
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (!(once.done.load(std::memory_order_acquire) & bit)) {
+        RLPPO_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+        once.done.fetch_or(bit, std::memory_order_release);
+    }
+    return 0;
+}
+// compute units of the current device (cached per device id)
+inline int device_cu_count(int *cus) {
+    static std::atomic<int> by_dev[64];
+    int dev = 0;
+    RLPPO_HIP(hipGetDevice(&dev));
+    int n = by_dev[dev & 63].load(std::memory_order_relaxed);
+    if (n == 0) {
+        RLPPO_HIP(hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev));
+        by_dev[dev & 63].store(n, std::memory_order_relaxed);
+    }
+    *cus = n;
+    return 0;
+}
 // hipGetLastError() is per thread and sticky across libraries: an error another library left unread on this thread (seen on
 // the GPU box: PyTorch's device probing leaves hipErrorNoDevice behind when this library was loaded before the first
 // torch.cuda call) would be reported by the check after our next launch.  Every launch therefore clears the thread's

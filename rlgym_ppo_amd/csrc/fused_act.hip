@@ -3,14 +3,14 @@
 //
 // At rollout sizes (8 ... 4096 observations per call) the layer-by-layer chain of rlppo_discrete_act is latency, not work:
 // 4 GEMM launches of 64 workgroups each + the sampling kernel take 76 us for 1.5 GFLOP at 4096 rows
-// (tools/rollout_breakdown.py).  Here a workgroup of 4 waves owns 16 observation rows and carries them through every layer:
+// (tools/rollout_breakdown.py).  Here a workgroup of 4 or 8 waves owns 16 observation rows and carries them through every layer:
 //   * activations never leave the CU: a layer's output is written into LDS in exactly the K-step-major, swizzled image the
 //     next layer's MFMA fragments are read from (the A-tile image of gemm_nt_dma_kernel);
-//   * a wave computes its own quarter of a layer's outputs, so the weights it needs are its own: every wave streams ITS rows of
+//   * a wave computes its own share (1/4 or 1/8) of a layer's outputs, so the weights it needs are its own: every wave streams ITS rows of
 //     W (packed copy, 0.73 MB for the 256x3 policy: L2-resident) through a private ring of 4 LDS tiles by LDS-DMA, three K-steps
 //     ahead, ACROSS layer boundaries (weights do not depend on activations) and waits with counted vmcnt -- no workgroup barrier
 //     in the K loop, one per layer for the activations;
-//   * the head's logits go to LDS and the 4 waves sample 4 rows each with the code of discrete_sample_kernel.
+//   * the head's logits go to LDS and the waves sample 16 / NW rows each with the code of discrete_sample_kernel.
 // Arithmetic is that of the chain, operation for operation (accumulators start from the bias, k in tiles of 16 through the same
 // v_mfma_f32_16x16x4_f32 sequence, relu as v_med3, the same softmax / division / arg-max order): logits, actions and
 // log-probabilities are BIT-identical to the layer-by-layer path (tests/test_gpu_kernels.py).
@@ -327,15 +327,12 @@ int launch_discrete_act_fused(hipStream_t st, const NetLayout &net, const float 
     a.probs_out = io.probs_out;
     const int H = net.L[0].pout;
     dim3 grid((unsigned)cdiv(n, FA_ROWS));
-    static bool attr_set[3] = {};
+    static PerDeviceOnce attr_set[3];
 #define FA_LAUNCH(J, W, SLOT)                                                                                                    \
     do {                                                                                                                         \
         constexpr int LDS_BYTES = (2 * 16 * J * W * FA_ROWS + W * FA_STAGES * J * 256 + FA_MAX_LAYERS * 16 * J * W) * 4;          \
-        if (!attr_set[SLOT]) { /* up to 102 KiB of dynamic LDS (H = 256): above the default 64 KiB limit */                      \
-            RLPPO_HIP(hipFuncSetAttribute((const void *)discrete_act_fused_kernel<J, W>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                          LDS_BYTES));                                                                           \
-            attr_set[SLOT] = true;                                                                                               \
-        }                                                                                                                        \
+        /* up to 102 KiB of dynamic LDS (H = 256): above the default 64 KiB limit */                                             \
+        if (int rc_ = set_dynamic_lds_once((const void *)discrete_act_fused_kernel<J, W>, LDS_BYTES, attr_set[SLOT])) return rc_; \
         hipLaunchKernelGGL((discrete_act_fused_kernel<J, W>), grid, dim3(64 * W), LDS_BYTES, st, a);                              \
     } while (0)
     switch (H) {

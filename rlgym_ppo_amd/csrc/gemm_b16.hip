@@ -649,29 +649,21 @@ int launch_gemm_nt_b16(hipStream_t st, const unsigned short *A, int64_t lda, con
     const unsigned la = (unsigned)(lda * 2), lb = (unsigned)(ldb * 2), lc = (unsigned)(ldc * 4), lcb = (unsigned)(ldcb * 2);
     if (mode != B16_OUT && N % 256 == 0 && M >= 1024 && Cb && g_b16_wide && 257 * lda * 2 < lim && 257 * ldb * 2 < lim &&
         257 * ldc * 4 < lim && 257 * ldcb * 2 < lim) {  // 256 x 256 tiles
-        static bool attr_set[2] = {false, false};
+        static PerDeviceOnce attr_set[2];
         const int which = mode == B16_DX ? 1 : 0;
         const int rt128 = (int)cdiv(M, 128);
         if (g_b16_wide == 2 && !C && bits && N / 256 <= 8) {  // [r3] persistent workgroups (no fp32 copy of the output in this form)
-            static bool pattr_set[2] = {false, false};
+            static PerDeviceOnce pattr_set[2];
             constexpr int LDS_BYTES = 2 * (256 + 256) * 32 * 4 + 1024;  // two stages + the column tile's bias
-            static int cus = 0;
-            if (cus == 0) {
-                int dev = 0;
-                RLPPO_HIP(hipGetDevice(&dev));
-                RLPPO_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-            }
+            int cus = 0;
+            if (int rc_ = device_cu_count(&cus)) return rc_;
             const int col_tiles = N / 256, row_tiles = (int)cdiv(M, 256), group = 8 * col_tiles;
             int grid = cus / group * group;  // whole groups of 8 row tiles x all column tiles; never more workgroups than CUs
             const int need = (int)cdiv(row_tiles, 8) * group;
             grid = grid < group ? group : (grid > need ? need : grid);
 #define B16P(MODE_)                                                                                                          \
     do {                                                                                                                     \
-        if (!pattr_set[which]) {                                                                                             \
-            RLPPO_HIP(hipFuncSetAttribute((const void *)gemm_nt_b16p_kernel<MODE_>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                          LDS_BYTES));                                                                       \
-            pattr_set[which] = true;                                                                                         \
-        }                                                                                                                    \
+        if (int rc_ = set_dynamic_lds_once((const void *)gemm_nt_b16p_kernel<MODE_>, LDS_BYTES, pattr_set[which])) return rc_; \
         hipLaunchKernelGGL((gemm_nt_b16p_kernel<MODE_>), dim3((unsigned)grid), dim3(512), LDS_BYTES, st, A, la, B, lb, bias, Cb, lcb, M, \
                            K, bits, row_tiles, col_tiles, rt128);                                                            \
     } while (0)
@@ -684,11 +676,7 @@ int launch_gemm_nt_b16(hipStream_t st, const unsigned short *A, int64_t lda, con
 #define B16W(MODE_)                                                                                                          \
     do {                                                                                                                     \
         constexpr int LDS_BYTES = 2 * (256 + 256) * 32 * 4; /* two 64 KiB stages; the epilogue parks 16 KiB per wave in them */ \
-        if (!attr_set[which]) {                                                                                              \
-            RLPPO_HIP(hipFuncSetAttribute((const void *)gemm_nt_b16w_kernel<MODE_, 256, 32, 2>,                               \
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));                           \
-            attr_set[which] = true;                                                                                          \
-        }                                                                                                                    \
+        if (int rc_ = set_dynamic_lds_once((const void *)gemm_nt_b16w_kernel<MODE_, 256, 32, 2>, LDS_BYTES, attr_set[which])) return rc_; \
         hipLaunchKernelGGL((gemm_nt_b16w_kernel<MODE_, 256, 32, 2>), dim3((unsigned)cdiv(M, 256), (unsigned)(N / 256)),        \
                            dim3(512), LDS_BYTES, st, A, la, B, lb, bias, C, lc, Cb, lcb, M, K, bits, rt128);                 \
     } while (0)
@@ -1063,12 +1051,9 @@ int launch_gemm_tn_b16(hipStream_t st, const unsigned short *dY, int64_t ldy, co
         RLPPO_CHECK_ARG((rows_w + TNB_ROWS) * ldy * 2 < lim && (rows_w + TNB_ROWS) * ldx * 2 < lim,
                         "gemm_tn (bf16 in memory): a leading dimension is too wide for 32-bit tile offsets");
         splits = (int)cdiv(M, rows_w);
-        static bool attr_set = false;
+        static PerDeviceOnce attr_set;
         constexpr int LDS_BYTES = 2 * 4 * TNB_ROWS * 256;
-        if (!attr_set) {
-            RLPPO_HIP(hipFuncSetAttribute((const void *)gemm_tn_b16w_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-            attr_set = true;
-        }
+        if (int rc_ = set_dynamic_lds_once((const void *)gemm_tn_b16w_kernel, LDS_BYTES, attr_set)) return rc_;
         hipLaunchKernelGGL(gemm_tn_b16w_kernel, dim3((unsigned)(pout / 256), (unsigned)(pin / 256), (unsigned)splits), dim3(512), LDS_BYTES,
                            st, dY, (unsigned)(ldy * 2), X, (unsigned)(ldx * 2), db != nullptr, out, M, rows_w, ws);
     } else {
