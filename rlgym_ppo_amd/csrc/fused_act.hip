@@ -23,6 +23,7 @@ constexpr int FA_ROWS = 16;      // observation rows per workgroup (the MFMA's 1
 constexpr int FA_STAGES = 4;     // weight tiles per wave in flight / being read
 constexpr int FA_MAX_LAYERS = 6;
 constexpr float FA_PROB_MIN = 1e-11f;
+constexpr unsigned FA_OOR = 0x80000000u;  // a scalar offset no descriptor's range check passes
 }  // namespace
 
 struct FusedActArgs {
@@ -77,7 +78,10 @@ __global__ __launch_bounds__(64 * NW, 1) void discrete_act_fused_kernel(FusedAct
     // move no data but keep the vmcnt arithmetic uniform)
     const int lr = lane >> 2, pch = lane & 3;
     const int lch = pch ^ ((0 - (lr >> 2)) & 3);
-    int pl = 0, pkt = 0, issued = 0, pnk = a.k[0] / 16;
+    // [r3] every layer's step count is padded to a multiple of FA_STAGES (the padding steps move no data: an offset that fails the
+    // descriptor's range check; the consumer skips their products), so that a step's ring slot is its position in a group of four --
+    // a compile-time constant in the unrolled K loop below
+    int pl = 0, pkt = 0, issued = 0, prk = a.k[0] / 16, pnk = (prk + FA_STAGES - 1) & ~(FA_STAGES - 1);
     auto layer_rsrc = [&](int l) {
         const int own = l == last ? (a.nblk[l] + NW - 1) / NW : JH;      // blocks per wave in this layer
         int rows = a.nblk[l] * 16 - wave_u * own * 16;                     // rows of W this wave streams
@@ -90,15 +94,16 @@ __global__ __launch_bounds__(64 * NW, 1) void discrete_act_fused_kernel(FusedAct
     auto issue_next = [&]() {
         if (pl > last) return;  // past the network's end (the waits below count what is really in flight)
         float *dst = wr + (issued % FA_STAGES) * TILE;
+        const unsigned kb = pkt < prk ? (unsigned)pkt * 64u : FA_OOR;
 #pragma unroll
-        for (int i = 0; i < JH; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rs, dst + i * 256, 16, w_off, (unsigned)pkt * 64u + i * w_row16, 0, 0);
+        for (int i = 0; i < JH; ++i) __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rs, dst + i * 256, 16, w_off, kb + i * w_row16, 0, 0);
         ++issued;
         if (++pkt == pnk) {
             pkt = 0;
             ++pl;
             if (pl <= last) {
-                pnk = a.k[pl] / 16;
+                prk = a.k[pl] / 16;
+                pnk = (prk + FA_STAGES - 1) & ~(FA_STAGES - 1);
                 w_rs = layer_rsrc(pl);
                 w_off = (unsigned)lr * (unsigned)a.k[pl] * 4u + lch * 16;
                 w_row16 = 16u * (unsigned)a.k[pl] * 4u;
@@ -160,37 +165,48 @@ __global__ __launch_bounds__(64 * NW, 1) void discrete_act_fused_kernel(FusedAct
             acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
             if (j < nj) acc[j] = *reinterpret_cast<const f32x4 *>(&biasl[l * H + (jb0 + j) * 16 + q * 4]);
         }
+        // K loop in groups of FA_STAGES steps, unrolled: ring slot and activation K-step are immediates of the ds_reads, so a step is
+        // DMA issue (scalar), a counted wait, three ds_read_b128 and 4 JH MFMAs with NO vector ALU instruction (while the other wave
+        // of the SIMD streams MFMAs a VALU instruction of any kind takes ~400 cycles to issue, DESIGN section 5: the two address
+        // updates per step of the rolled loop were ~800 of its ~955 cycles); one pointer bump per group
         const int nk = a.k[l] / 16;
-        for (int kt = 0; kt < nk; ++kt) {
-            issue_next();  // keeps FA_STAGES - 1 tiles in flight behind the one about to be read
-            // all but the pieces of the `ahead` tiles issued behind this step's have landed: the tile of this step is in LDS
-            // (vmcnt immediates: ahead * JH; ahead < FA_STAGES - 1 only in the network's last steps)
-            const int ahead = issued - consumed - 1;
-            if (ahead >= 3) {
-                if (JH == 4) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-                else if (JH == 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-            } else if (ahead == 2) {
-                if (JH == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-                else if (JH == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-            } else if (ahead == 1) {
-                if (JH == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-                else if (JH == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-            } else {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const float *ag = cur + dswz<16>(r16, q);
+        const float *wg = wr + dswz<16>(r16, q);
+        for (int kt0 = 0; kt0 < nk; kt0 += FA_STAGES) {
+#pragma unroll
+            for (int d = 0; d < FA_STAGES; ++d) {
+                issue_next();  // keeps FA_STAGES - 1 tiles in flight behind the one about to be read
+                // all but the pieces of the `ahead` tiles issued behind this step's have landed: the tile of this step is in LDS
+                // (vmcnt immediates: ahead * JH; ahead < FA_STAGES - 1 only in the network's last steps)
+                const int ahead = issued - consumed - 1;
+                if (ahead >= 3) {
+                    if (JH == 4) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+                    else if (JH == 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+                } else if (ahead == 2) {
+                    if (JH == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                    else if (JH == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                } else if (ahead == 1) {
+                    if (JH == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                    else if (JH == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+                } else {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                ++consumed;  // (consumed % FA_STAGES == d: every layer starts a group)
+                if (kt0 + d < nk) {  // not a padding step
+                    const f32x4 fa = *reinterpret_cast<const f32x4 *>(&ag[d * 256]);
+                    f32x4 fb[JH];
+#pragma unroll
+                    for (int j = 0; j < JH; ++j) fb[j] = *reinterpret_cast<const f32x4 *>(&wg[d * TILE + j * 256]);
+#pragma unroll
+                    for (int s = 0; s < 4; ++s)
+#pragma unroll
+                        for (int j = 0; j < JH; ++j) acc[j] = MFMA16(fb[j][s], fa[s], acc[j]);
+                }
             }
-            const float *wt = wr + (consumed % FA_STAGES) * TILE;
-            ++consumed;
-            const f32x4 fa = *reinterpret_cast<const f32x4 *>(&cur[kt * 256 + dswz<16>(r16, q)]);
-            f32x4 fb[JH];
-#pragma unroll
-            for (int j = 0; j < JH; ++j) fb[j] = *reinterpret_cast<const f32x4 *>(&wt[dswz<16>(j * 16 + r16, q)]);
-#pragma unroll
-            for (int s = 0; s < 4; ++s)
-#pragma unroll
-                for (int j = 0; j < JH; ++j) acc[j] = MFMA16(fb[j][s], fa[s], acc[j]);
+            ag += FA_STAGES * 256;
         }
         if (!head) {
             // relu, then straight into the next layer's fragment image: block jb = k-step jb, row r16, chunk q
