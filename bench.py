@@ -287,7 +287,19 @@ def rollout_bench(learner):
     st = lambda: ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     rows = pol.arena.stage_obs(torch.from_numpy(obs).cuda())
     t_kernel = time_region(lambda: pol.act_padded(rows, q_dev), 50, warm=5)   # the fused launch alone (HIP events)
-    return dict(workload="4096 x 107 obs per step, 256x3 policy, 90 actions",
+
+    def call_us(n, reps=300):  # the reference's process-per-environment collector: 8-80 observations per get_action call
+        o = obs[:n].copy()
+        for _ in range(30):
+            pol.get_action(o)
+        ts = []
+        for _ in range(reps):
+            t = time.perf_counter()
+            pol.get_action(o)
+            ts.append(time.perf_counter() - t)
+        return round(1e6 * float(np.median(ts)), 1)
+    small = {"us_per_get_action_%d_obs" % n: call_us(n) for n in (8, 80)}
+    return dict(workload="4096 x 107 obs per step, 256x3 policy, 90 actions", **small,
                 obs_per_s_host_noise=round(N_AGENTS / t_parity), ms_per_step_host_noise=round(t_parity * 1e3, 3),
                 obs_per_s_resident_noise=round(N_AGENTS / t_given), ms_per_step_resident_noise=round(t_given * 1e3, 3),
                 ms_per_step_resident_noise_pinned_obs=round(t_pinned * 1e3, 3), ms_fused_launch=round(t_kernel, 4),
@@ -296,7 +308,9 @@ def rollout_bench(learner):
                      "round 2: pad + 4 GEMM launches + sampling + two D2H copies).  host_noise = the bit-exact action parity mode: "
                      "Exp(1) noise of torch's CPU generator stream (librlppo's host implementation of torch's exponential_, drawn one "
                      "step ahead on a helper thread: ~0.36 ms per draw is the floor of that mode); resident_noise = noise already in "
-                     "HBM, observations in pageable / page-locked host memory; ms_fused_launch = the launch alone (device time)")
+                     "HBM, observations in pageable / page-locked host memory; ms_fused_launch = the launch alone (device time); "
+                     "us_per_get_action_N_obs = wall clock of one get_action call of N host observations in the bit-exact mode (one "
+                     "hipGraph replay of the same kernel reading and writing pinned host memory)")
 
 
 def cpu_baseline(seed=123, reps=3):
