@@ -4,7 +4,7 @@
 set -eo pipefail
 TAG=${1:-r03}
 OUT=gpurun_out/$TAG
-rm -rf $OUT/cfg5_stats $OUT/cfg5_fetch $OUT/cfg5_write $OUT/cfg5_sq $OUT/stats $OUT/stats_single $OUT/iso $OUT/pmc_sq $OUT/pmc_fetch $OUT/pmc_write $OUT/gae_stats $OUT/gae_fetch $OUT/gae_write
+rm -rf $OUT/cfg5_stats $OUT/cfg5_fetch $OUT/cfg5_write $OUT/cfg5_sq $OUT/stats $OUT/stats_single $OUT/iso $OUT/pmc_sq $OUT/pmc_fetch $OUT/pmc_write $OUT/gae_stats $OUT/gae_fetch $OUT/gae_write $OUT/fa_depth $OUT/share8
 mkdir -p $OUT
 export TMPDIR=/tmp
 if [ "$2" != "profiles-only" ]; then
@@ -45,6 +45,9 @@ python tools/ab_update.py 3 > $OUT/ab_update.txt 2> $OUT/ab_update.log
 python tools/breakdown_rows.py > $OUT/breakdown_rows.txt 2> $OUT/breakdown_rows.log
 python tools/act_kernel_time.py > $OUT/act_kernel_time.txt 2> $OUT/act_kernel_time.log
 python tools/rollout_breakdown.py > $OUT/rollout_breakdown.txt 2> $OUT/rollout_breakdown.log
+python tools/small_batch_latency.py > $OUT/small_batch_latency.txt 2> $OUT/small_batch_latency.log
+rocprofv3 --kernel-trace --output-format csv -d $OUT/fa_depth -- python3 tools/fused_act_depth_time.py > $OUT/fa_depth.log 2>&1
+python tools/fused_act_depth_report.py $(find $OUT/fa_depth -name "*kernel_trace.csv" | head -1) > $OUT/fused_act_depth.txt
 rocprofv3 --kernel-trace --output-format csv -d $OUT/share8 -- python3 tools/rank_share.py 8 > $OUT/share8.log 2>&1
 python tools/step_gaps.py $OUT/share8 8 > $OUT/rank_share_step_gaps.txt
 python tools/gae_ab.py > $OUT/gae_floor.txt 2> $OUT/gae_floor.log
