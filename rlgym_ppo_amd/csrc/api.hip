@@ -453,7 +453,7 @@ static int g_update_bf16 = 0;   // rlppo_set_update_precision
 // device id (streams and events belong to the device that was current when they were made; a process may drive several).
 struct SlotBank {
     hipStream_t main[RLPPO_MAX_SLOTS] = {}, side[RLPPO_MAX_SLOTS] = {};
-    hipEvent_t ev_fork[RLPPO_MAX_SLOTS] = {}, ev_join[RLPPO_MAX_SLOTS] = {}, ev_slot[RLPPO_MAX_SLOTS] = {};
+    hipEvent_t ev_fork[RLPPO_MAX_SLOTS] = {}, ev_join[RLPPO_MAX_SLOTS] = {}, ev_slot[RLPPO_MAX_SLOTS] = {}, ev_mid[RLPPO_MAX_SLOTS] = {};
     bool pending[RLPPO_MAX_SLOTS] = {};
 };
 static SlotBank g_banks[64];
@@ -471,6 +471,7 @@ static int ensure_slot(SlotBank &b, int s) {
         RLPPO_HIP(hipEventCreateWithFlags(&b.ev_fork[s], hipEventDisableTiming));
         RLPPO_HIP(hipEventCreateWithFlags(&b.ev_join[s], hipEventDisableTiming));
         RLPPO_HIP(hipEventCreateWithFlags(&b.ev_slot[s], hipEventDisableTiming));
+        RLPPO_HIP(hipEventCreateWithFlags(&b.ev_mid[s], hipEventDisableTiming));
     }
     return 0;
 }
@@ -705,6 +706,7 @@ static int backward_b16(hipStream_t st, const NetLayout &net, const float *packe
 // Measured (tools/ab_update.py, profiles/r03_ab_update.txt): at one rank (524,288 rows per pass) paired launches take 0.7 % off a
 // learn(); at the 65,536 rows of an 8-rank share they ADD 3 % -- with one chain every launch boundary drains the chip, with two
 // chains one network's boundary hides under the other's kernel -- so the pairing applies from PAIRED_MIN_ROWS rows per pass up.
+static int g_head_order = 1;  // rlppo_dbg_set(31, 0/1): the critic's output-layer backward waits for the policy's loss kernel (both HBM-bound)
 static int g_paired = 1;  // rlppo_dbg_set(29, 0 / 1 / 2): never / from PAIRED_MIN_ROWS rows / always (tests)
 constexpr int64_t PAIRED_MIN_ROWS = 262144;
 static bool twin_ok(const NetLayout &p, const NetLayout &v, int64_t mb) {
@@ -951,8 +953,14 @@ int rlppo_ppo_minibatch(void *stream, const rlppo_minibatch_args *a) {
         if (rc) return rc;
         rc = launch_value_loss(hs, vout, ldv, nullptr, g_tgt, mb, cfg, a->stats);
         if (rc) return rc;
-        rc = head_backward(hs, val, val_w, vout, xv, mb, vdx[H - 1], a->val_grad, val_tn_ws, vbits[H - 1]);
-        if (rc) return rc;
+        // The critic's head kernels are matrix-vector products: HBM-bound, like the policy's loss kernel, unlike the policy head's
+        // GEMMs.  Ordered so that the two HBM-bound stretches do not meet: critic forward + loss beside the policy head's forward
+        // GEMM, the critic's output-layer backward only after the policy's loss, beside the policy head's dW / dX GEMMs.
+        const bool ordered = g_head_order && hs != st;
+        if (!ordered) {
+            rc = head_backward(hs, val, val_w, vout, xv, mb, vdx[H - 1], a->val_grad, val_tn_ws, vbits[H - 1]);
+            if (rc) return rc;
+        }
         rc = head_forward(st, pol, pol_w, xp, ldx, mb, a->head == RLPPO_HEAD_GAUSSIAN, pout);
         if (rc) return rc;
         if (a->head == RLPPO_HEAD_DISCRETE)
@@ -966,6 +974,12 @@ int rlppo_ppo_minibatch(void *stream, const rlppo_minibatch_args *a) {
             rc = RLPPO_ERR_ARG;
         }
         if (rc) return rc;
+        if (ordered) {
+            rc = order_after(hs, st, bk.ev_mid[slot]);
+            if (rc) return rc;
+            rc = head_backward(hs, val, val_w, vout, xv, mb, vdx[H - 1], a->val_grad, val_tn_ws, vbits[H - 1]);
+            if (rc) return rc;
+        }
         rc = head_backward(st, pol, pol_w, pout, xp, mb, pdx[H - 1], a->pol_grad, pol_tn_ws, pbits[H - 1]);
         if (rc) return rc;
         if (hs != st) {
@@ -1185,6 +1199,7 @@ int rlppo_dbg_set(int32_t key, int32_t value) {
         case 26: g_fused_gather = value; return 0;
         case 27: g_fused_act = value; return 0;
         case 29: g_paired = value; return 0;
+        case 31: g_head_order = value; return 0;
         default: break;
     }
     set_error("dbg_set: unknown key %d", key);

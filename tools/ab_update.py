@@ -18,6 +18,7 @@ configs = {
     "separate gather pass (dbg 26=0)": {"dbg": (26, 0)},
     "optimiser tail as fill+norms+update": {"one_launch": False},
     "one launch chain per network (dbg 29=0)": {"dbg": (29, 0)},
+    "critic head backward not ordered after the policy loss (dbg 31=0)": {"dbg": (31, 0)},
     "all off (round 2 launch structure)": {"dbg2": ((26, 0), (29, 0)), "one_launch": False},
 }
 
@@ -51,4 +52,4 @@ for r in range(rounds):
 print("%-44s %22s %26s" % ("configuration (ms per 10-epoch learn(), median / min)", "1 rank", "share of rank 0 of 8"))
 for name in configs:
     a, b = res[(name, 1)], res[(name, 8)]
-    print("%-52s %8.2f / %8.2f      %8.2f / %8.2f" % (name, np.median(a), min(a), np.median(b), min(b)))
+    print("%-68s %8.2f / %8.2f      %8.2f / %8.2f" % (name, np.median(a), min(a), np.median(b), min(b)))
