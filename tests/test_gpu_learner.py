@@ -385,26 +385,29 @@ def test_get_action_graph_replay_equals_eager_path():
     assert set(pol._graphs) == {16, 32, 80, 256, 1024, 48}
 
 
-def test_seeded_rollout_draws_the_reference_noise_stream():
-    """128 rollout steps of 64 agents from one seed: DiscreteFF.get_action's default noise (librlppo's host implementation of
-    torch's CPU exponential_, drawn one step ahead on a helper thread -- engine.HostExponential) is the stream the reference's
-    torch.multinomial consumes, so the action indices are the oracle's (identical noise; an index may only differ on a
-    near-tie of p/q caused by the ulp-level difference of the probabilities: none expected, margin stated) and the generator
-    ends in the reference's state."""
+@pytest.mark.parametrize("n_agents,steps", [(64, 128), (768, 24)], ids=["on_the_spot", "look_ahead"])
+def test_seeded_rollout_draws_the_reference_noise_stream(n_agents, steps):
+    """Rollout steps from one seed: DiscreteFF.get_action's default noise (librlppo's host implementation of torch's CPU
+    exponential_ -- engine.HostExponential) is the stream the reference's torch.multinomial consumes, so the action indices are
+    the oracle's (identical noise; an index may only differ on a near-tie of p/q caused by the ulp-level difference of the
+    probabilities: none expected, margin stated) and the generator ends in the reference's state.  64 agents x 90 actions: the
+    draw happens on the spot (below HostExponential.LOOKAHEAD_MIN numbers the hand-over to the helper thread costs more than
+    the draw); 768 agents: drawn one step ahead on the helper thread -- every step but the first is served from it."""
     from rlgym_ppo_amd import engine
     from rlgym_ppo_amd.ppo import DiscreteFF
     torch.manual_seed(77)
     pol = DiscreteFF(107, 90, (64, 64), "cuda:0")
     params = [(l.weight.detach().cpu(), l.bias.detach().cpu()) for l in pol.arena.linears]
     rs = np.random.RandomState(5)
-    obs = [np.clip(rs.randn(64, 107), -5, 5).astype(np.float32) for _ in range(128)]
+    obs = [np.clip(rs.randn(n_agents, 107), -5, 5).astype(np.float32) for _ in range(steps)]
     torch.manual_seed(1234)
     want = []
     for o in obs:
-        q = nets.draw_exp_noise(64, 90)
+        q = nets.draw_exp_noise(n_agents, 90)
         p = nets.discrete_probs(params, o)
         want.append((nets.discrete_sample(p, q), p, q))
     s_ref = torch.get_rng_state()
+    ahead = n_agents * 90 >= engine.HostExponential.LOOKAHEAD_MIN
     for graphs in (True, False):
         pol.act_graphs = graphs
         torch.manual_seed(1234)
@@ -421,7 +424,10 @@ def test_seeded_rollout_draws_the_reference_noise_stream():
             assert (lp[same] - lp_ref[same]).abs().max().item() < 1e-5
         assert mismatches <= 1
         assert torch.equal(torch.get_rng_state(), s_ref)
-        assert engine._HOST_EXP.hits >= 126                     # every step but the first was served from the look-ahead
+        if ahead:
+            assert engine._HOST_EXP.hits >= steps - 2           # every step but the first was served from the look-ahead
+        else:
+            assert engine._HOST_EXP.hits == 0 and engine._HOST_EXP.misses == steps
 
 
 def test_captured_act_graphs_follow_the_inference_precision():
