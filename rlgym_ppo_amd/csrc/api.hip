@@ -69,6 +69,8 @@ static int max_pout(const NetLayout &net) {
     return m;
 }
 
+static int g_fold_vhead = 1;  // rlppo_dbg_set(32, 0/1): a one-output head inside the last hidden layer's forward epilogue (update passes)
+
 // Forward pass.  acts[l] receives the output of layer l ([n][pout_l]); for inference the caller passes two
 // ping-pong buffers, for training one buffer per layer (they are the saved activations of the backward pass).
 // Training only: bits[l] (may be null) receives the ReLU bitmask of hidden layer l and have_bits[l] says whether it was
@@ -77,24 +79,40 @@ static int max_pout(const NetLayout &net) {
 // (the first layer fetches its rows through the table: nt_gather_ok must hold for it).
 static int forward(hipStream_t st, const NetLayout &net, const float *packed, const float *obs, int64_t ld_obs, int64_t n,
                    int out_tanh, float *const *acts, int bf16_operands = 0, unsigned long long *const *bits = nullptr,
-                   bool *have_bits = nullptr, const unsigned *rowtab = nullptr, int64_t src_rows = 0) {
+                   bool *have_bits = nullptr, const unsigned *rowtab = nullptr, int64_t src_rows = 0, bool *head_folded = nullptr) {
     if (have_bits)
         for (int l = 0; l < net.n_layers; ++l) have_bits[l] = false;
     const float *x = obs;
     int64_t ldx = ld_obs;
+    // head_folded != nullptr (update passes): a one-output head may be computed in the epilogue of the hidden layer that feeds it
+    // (NtDot, csrc/gemm.hip) -- acts[last] then holds the outputs COMPACT ([n], stride 1) and *head_folded says so
+    const int hl = net.n_layers - 1;
+    bool fold = head_folded && g_fold_vhead && hl >= 1 && !out_tanh && !bf16_operands && bits && bits[hl - 1] &&
+                gemv_head_ok(net.L[hl].out, net.L[hl].pin) && net.L[hl - 1].pout / 128 <= 2;
+    if (head_folded) *head_folded = false;
     for (int l = 0; l < net.n_layers; ++l) {
         const LayerLayout &L = net.L[l];
         const bool last = l == net.n_layers - 1;
         const int epi = last ? (out_tanh ? EPI_BIAS_TANH : EPI_BIAS) : EPI_BIAS_RELU;
         int rc;
+        if (last && head_folded && *head_folded) break;
         if (last && !out_tanh && gemv_head_ok(L.out, L.pin))  // one-output head: matrix-vector kernel (gemv.hip)
             rc = launch_gemv_fwd(st, x, ldx, packed + L.off_w, packed + L.off_b, acts[l], L.pout, n, L.pin, L.pout);
         else {
             rc = -1;
             if (!last && bits && bits[l] && !bf16_operands) {
+                NtDot dots[2];
+                const bool fold_here = fold && l == hl - 1;
+                if (fold_here) {
+                    RLPPO_HIP(hipMemsetAsync(acts[hl], 0, (size_t)n * sizeof(float), st));
+                    dots[0].w = packed + net.L[hl].off_w;
+                    dots[0].b = packed + net.L[hl].off_b;
+                    dots[0].out = acts[hl];
+                }
                 rc = launch_gemm_nt_bits(st, x, ldx, packed + L.off_w, L.pin, packed + L.off_b, acts[l], L.pout, n, L.pout, L.pin,
-                                         EPI_BIAS_RELU, bits[l], l == 0 ? rowtab : nullptr, src_rows);
+                                         EPI_BIAS_RELU, bits[l], l == 0 ? rowtab : nullptr, src_rows, nullptr, fold_here ? dots : nullptr);
                 if (rc == 0) have_bits[l] = true;
+                if (fold_here) *head_folded = rc == 0;  // (rc == -1: the layer has no bitmask form; the values stay zero-filled but unused)
             }
             if (l == 0 && rowtab && rc != 0) {
                 if (rc == -1) set_error("forward: the gathered first layer needs the bitmask form");
@@ -549,18 +567,19 @@ struct ChainCtx {
 // dL/d(acts[l-1]) = dY of layer l-1 (one buffer per layer: the dW launches read them later)
 static int backward(hipStream_t st, const NetLayout &net, const float *packed, const float *states, int64_t ld_states,
                     int64_t mb, float *const *acts, float *const *dx, float *grad, float *tn_ws,
-                    unsigned long long *const *bits, const bool *have_bits, const ChainCtx &cx) {
+                    unsigned long long *const *bits, const bool *have_bits, const ChainCtx &cx, bool head_folded = false) {
     const int last = net.n_layers - 1;
     int rc = 0;
     for (int l = last; l >= 0; --l) {
         const LayerLayout &L = net.L[l];
         const float *dY = l == last ? acts[last] : dx[l];
+        const int64_t ld_hy = head_folded ? 1 : L.pout;  // stride of a one-output head's dY (compact when it was folded, forward())
         const float *X = l > 0 ? acts[l - 1] : states;
         const int64_t ldx = l > 0 ? net.L[l - 1].pout : ld_states;
         const bool gemv = l == last && l > 0 && gemv_head_ok(L.out, L.pin);  // one-output head (gemv.hip)
         const size_t floats = tn_layer_floats(net, l, mb);
         if (gemv)
-            rc = launch_gemv_dw(st, dY, L.pout, X, ldx, grad + L.off_flat_w, grad + L.off_flat_b, L.in, L.pin, mb, tn_ws, floats);
+            rc = launch_gemv_dw(st, dY, ld_hy, X, ldx, grad + L.off_flat_w, grad + L.off_flat_b, L.in, L.pin, mb, tn_ws, floats);
         else if (l == 0 && cx.rowtab)
             rc = launch_gemm_tn(st, dY, L.pout, L.pout, cx.src, cx.ld_src, L.pin, grad + L.off_flat_w, grad + L.off_flat_b, L.out, L.in,
                                 mb, tn_ws, floats, cx.rowtab, cx.src_rows);
@@ -573,8 +592,8 @@ static int backward(hipStream_t st, const NetLayout &net, const float *packed, c
         // bitmask the forward left when there is one (no re-read of the activation), else the saved activation itself.
         rc = -1;
         if (gemv) {
-            if (have_bits[l - 1]) rc = launch_gemv_dx_bits(st, dY, L.pout, packed + L.off_w, bits[l - 1], dx[l - 1], L.pin, L.pin, mb);
-            if (rc == -1) rc = launch_gemv_dx(st, dY, L.pout, packed + L.off_w, acts[l - 1], L.pin, dx[l - 1], L.pin, L.pin, mb);
+            if (have_bits[l - 1]) rc = launch_gemv_dx_bits(st, dY, ld_hy, packed + L.off_w, bits[l - 1], dx[l - 1], L.pin, L.pin, mb);
+            if (rc == -1) rc = launch_gemv_dx(st, dY, ld_hy, packed + L.off_w, acts[l - 1], L.pin, dx[l - 1], L.pin, L.pin, mb);
         } else {
             if (have_bits[l - 1])
                 rc = launch_gemm_nt_bits(st, dY, L.pout, packed + L.off_wt, L.pout, nullptr, dx[l - 1], L.pin, mb, L.pin, L.pout,
@@ -729,16 +748,17 @@ static int head_forward(hipStream_t st, const NetLayout &net, const float *packe
 }
 // ... and backward: dW / db of the output layer and dX into dx_prev, masked by the last hidden layer's bitmask (backward()'s first iteration)
 static int head_backward(hipStream_t st, const NetLayout &net, const float *packed, const float *dY, const float *X, int64_t mb,
-                         float *dx_prev, float *grad, float *tn_ws, const unsigned long long *bits_prev) {
+                         float *dx_prev, float *grad, float *tn_ws, const unsigned long long *bits_prev, int64_t ld_dy = 0) {
     const int last = net.n_layers - 1;
     const LayerLayout &L = net.L[last];
     const int64_t ldx = net.L[last - 1].pout;
     const bool gemv = gemv_head_ok(L.out, L.pin);
     const size_t floats = tn_layer_floats(net, last, mb);
-    int rc = gemv ? launch_gemv_dw(st, dY, L.pout, X, ldx, grad + L.off_flat_w, grad + L.off_flat_b, L.in, L.pin, mb, tn_ws, floats)
+    if (!ld_dy) ld_dy = L.pout;  // (a one-output head folded into the last hidden layer's epilogue keeps its outputs compact: 1)
+    int rc = gemv ? launch_gemv_dw(st, dY, ld_dy, X, ldx, grad + L.off_flat_w, grad + L.off_flat_b, L.in, L.pin, mb, tn_ws, floats)
                   : launch_gemm_tn(st, dY, L.pout, L.pout, X, ldx, L.pin, grad + L.off_flat_w, grad + L.off_flat_b, L.out, L.in, mb, tn_ws, floats);
     if (rc) return rc;
-    if (gemv) return launch_gemv_dx_bits(st, dY, L.pout, packed + L.off_w, bits_prev, dx_prev, L.pin, L.pin, mb);
+    if (gemv) return launch_gemv_dx_bits(st, dY, ld_dy, packed + L.off_w, bits_prev, dx_prev, L.pin, L.pin, mb);
     rc = launch_gemm_nt_bits(st, dY, L.pout, packed + L.off_wt, L.pout, nullptr, dx_prev, L.pin, mb, L.pin, L.pout, EPI_MASK,
                              const_cast<unsigned long long *>(bits_prev));
     if (rc == -1) {
@@ -911,6 +931,13 @@ int rlppo_ppo_minibatch(void *stream, const rlppo_minibatch_args *a) {
         const int H = pol.n_layers - 1;  // hidden layers (the same number in both networks)
         const float *xp = fused_gather ? a->states : states, *xv = xp;
         int64_t ldx = fused_gather ? a->ld_states : ld_states;
+        // [r3] The critic's output layer is a dot product per row of activations this launch has in registers: folded into the last
+        // hidden layer's forward epilogue (NtDot) it costs no pass over the 4 x 256 B per row the matrix-vector kernel re-read
+        // (537 MB per 524,288-row pass, in the stretch of the pass that is HBM-bound).  Values land compact ([mb], stride 1).
+        const LayerLayout &Lvh = val.L[H];
+        const bool fold_v = g_fold_vhead && gemv_head_ok(Lvh.out, Lvh.pin) && val.L[H - 1].pout / 128 <= 2;
+        float *vout = vact[H];
+        const int64_t ldv = fold_v ? 1 : Lvh.pout;
         for (int l = 0; l < H; ++l) {
             const LayerLayout &Lp = pol.L[l], &Lv = val.L[l];
             NtAlt alt;
@@ -919,8 +946,17 @@ int rlppo_ppo_minibatch(void *stream, const rlppo_minibatch_args *a) {
             alt.bias = val_w + Lv.off_b;
             alt.C = vact[l];
             alt.bits = vbits[l];
+            NtDot dots[2];
+            const bool fold_here = fold_v && l == H - 1;
+            if (fold_here) {
+                RLPPO_HIP(hipMemsetAsync(vout, 0, (size_t)mb * sizeof(float), st));
+                dots[1].w = val_w + Lvh.off_w;
+                dots[1].out = vout;
+                dots[1].b = val_w + Lvh.off_b;
+            }
             rc = launch_gemm_nt_bits(st, xp, ldx, pol_w + Lp.off_w, Lp.pin, pol_w + Lp.off_b, pact[l], Lp.pout, mb, Lp.pout, Lp.pin,
-                                     EPI_BIAS_RELU, pbits[l], l == 0 && fused_gather ? rowtab : nullptr, src_rows, &alt);
+                                     EPI_BIAS_RELU, pbits[l], l == 0 && fused_gather ? rowtab : nullptr, src_rows, &alt,
+                                     fold_here ? dots : nullptr);
             if (rc) {
                 if (rc == -1) set_error("paired pass: a hidden layer does not have the bitmask form");
                 return rc == -1 ? RLPPO_ERR_ARG : rc;
@@ -947,10 +983,12 @@ int rlppo_ppo_minibatch(void *stream, const rlppo_minibatch_args *a) {
         cfg.var_b = a->var_b;
         cfg.ring_base = ring_base;
         cfg.ring_cap = ring_cap;
-        float *pout = pact[H], *vout = vact[H];
-        const int64_t ldp = pol.L[H].pout, ldv = val.L[H].pout;
-        rc = head_forward(hs, val, val_w, xv, ldx, mb, 0, vout);
-        if (rc) return rc;
+        float *pout = pact[H];
+        const int64_t ldp = pol.L[H].pout;
+        if (!fold_v) {
+            rc = head_forward(hs, val, val_w, xv, ldx, mb, 0, vout);
+            if (rc) return rc;
+        }
         rc = launch_value_loss(hs, vout, ldv, nullptr, g_tgt, mb, cfg, a->stats);
         if (rc) return rc;
         // The critic's head kernels are matrix-vector products: HBM-bound, like the policy's loss kernel, unlike the policy head's
@@ -958,7 +996,7 @@ int rlppo_ppo_minibatch(void *stream, const rlppo_minibatch_args *a) {
         // GEMM, the critic's output-layer backward only after the policy's loss, beside the policy head's dW / dX GEMMs.
         const bool ordered = g_head_order && hs != st;
         if (!ordered) {
-            rc = head_backward(hs, val, val_w, vout, xv, mb, vdx[H - 1], a->val_grad, val_tn_ws, vbits[H - 1]);
+            rc = head_backward(hs, val, val_w, vout, xv, mb, vdx[H - 1], a->val_grad, val_tn_ws, vbits[H - 1], ldv);
             if (rc) return rc;
         }
         rc = head_forward(st, pol, pol_w, xp, ldx, mb, a->head == RLPPO_HEAD_GAUSSIAN, pout);
@@ -977,7 +1015,7 @@ int rlppo_ppo_minibatch(void *stream, const rlppo_minibatch_args *a) {
         if (ordered) {
             rc = order_after(hs, st, bk.ev_mid[slot]);
             if (rc) return rc;
-            rc = head_backward(hs, val, val_w, vout, xv, mb, vdx[H - 1], a->val_grad, val_tn_ws, vbits[H - 1]);
+            rc = head_backward(hs, val, val_w, vout, xv, mb, vdx[H - 1], a->val_grad, val_tn_ws, vbits[H - 1], ldv);
             if (rc) return rc;
         }
         rc = head_backward(st, pol, pol_w, pout, xp, mb, pdx[H - 1], a->pol_grad, pol_tn_ws, pbits[H - 1]);
@@ -1013,6 +1051,7 @@ int rlppo_ppo_minibatch(void *stream, const rlppo_minibatch_args *a) {
         }
         return 0;
     }
+    bool v_folded = false;  // the critic's one-output head was computed in its last hidden layer's epilogue: compact outputs
     if (b16) {
         rc = forward_b16(side, val, val_w, reinterpret_cast<const unsigned short *>(a->val_wb16), states, states_b, ld_states, mb, 0,
                          vact, vactb, vbits, vhave, vf32);
@@ -1023,7 +1062,7 @@ int rlppo_ppo_minibatch(void *stream, const rlppo_minibatch_args *a) {
         const float *x0 = fused_gather ? a->states : states;
         const int64_t ld0 = fused_gather ? a->ld_states : ld_states;
         const unsigned *rt = fused_gather ? rowtab : nullptr;
-        rc = forward(side, val, val_w, x0, ld0, mb, 0, vact, 0, vbits, vhave, rt, src_rows);
+        rc = forward(side, val, val_w, x0, ld0, mb, 0, vact, 0, vbits, vhave, rt, src_rows, &v_folded);
         if (rc) return rc;
         rc = forward(st, pol, pol_w, x0, ld0, mb, a->head == RLPPO_HEAD_GAUSSIAN, pact, 0, pbits, phave, rt, src_rows);
     }
@@ -1043,7 +1082,7 @@ int rlppo_ppo_minibatch(void *stream, const rlppo_minibatch_args *a) {
     cfg.ring_base = ring_base;
     cfg.ring_cap = ring_cap;
     float *pout = pact[pol.n_layers - 1], *vout = vact[val.n_layers - 1];
-    const int64_t ldp = pol.L[pol.n_layers - 1].pout, ldv = val.L[val.n_layers - 1].pout;
+    const int64_t ldp = pol.L[pol.n_layers - 1].pout, ldv = v_folded ? 1 : val.L[val.n_layers - 1].pout;
     rc = launch_value_loss(side, vout, ldv, nullptr, g_tgt, mb, cfg, a->stats);
     if (rc) return rc;
     float *vjoint = nullptr;  // the loss kernels' joint form (policy + value in one launch) is not used by this entry point
@@ -1073,7 +1112,7 @@ int rlppo_ppo_minibatch(void *stream, const rlppo_minibatch_args *a) {
             cp.ld_src = cv.ld_src = a->ld_states;
             cp.src_rows = cv.src_rows = src_rows;
         }
-        rc = backward(side, val, val_w, states, ld_states, mb, vact, vdx, a->val_grad, val_tn_ws, vbits, vhave, cv);
+        rc = backward(side, val, val_w, states, ld_states, mb, vact, vdx, a->val_grad, val_tn_ws, vbits, vhave, cv, v_folded);
         if (rc) return rc;
         rc = backward(st, pol, pol_w, states, ld_states, mb, pact, pdx, a->pol_grad, pol_tn_ws, pbits, phave, cp);
     }
@@ -1200,6 +1239,7 @@ int rlppo_dbg_set(int32_t key, int32_t value) {
         case 27: g_fused_act = value; return 0;
         case 29: g_paired = value; return 0;
         case 31: g_head_order = value; return 0;
+        case 32: g_fold_vhead = value; return 0;
         default: break;
     }
     set_error("dbg_set: unknown key %d", key);

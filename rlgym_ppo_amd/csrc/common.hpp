@@ -111,13 +111,20 @@ struct NtAlt {  // second operand set of a paired gemm_nt launch (M, N, K, leadi
     float *C = nullptr;
     unsigned long long *bits = nullptr;
 };
+// [r3] a one-output head folded into the epilogue of the hidden layer that feeds it (the critic's value = h . w + b, value_estimator.py):
+// out[row] (compact, zero-filled by the caller) += the row's partial dot product over the workgroup's 128 columns (+ b from the
+// first column tile).  With at most two column tiles the sum of the partials does not depend on their order (0 + a + b == 0 + b + a).
+struct NtDot {
+    const float *w = nullptr, *b = nullptr;  // the head's weight row and its bias (device memory)
+    float *out = nullptr;
+};
 struct TnPair {  // second operand set of a paired gemm_tn launch + reduction (shapes shared; X unused with a row table)
     const float *dY = nullptr, *X = nullptr;
     float *dW = nullptr, *db = nullptr, *ws = nullptr;
 };
 int launch_gemm_nt_bits(hipStream_t st, const float *A, int64_t lda, const float *B, int64_t ldb, const float *bias, float *C,
                         int64_t ldc, int64_t M, int N, int K, int epi, unsigned long long *bits, const unsigned *rowtab = nullptr,
-                        int64_t src_rows = 0, const NtAlt *alt = nullptr);
+                        int64_t src_rows = 0, const NtAlt *alt = nullptr, const NtDot *dot = nullptr /* [2]: per operand set */);
 bool nt_gather_ok(int64_t lda, int64_t src_rows, int N, int K);  // can the forward fetch its rows through a row table?
 int launch_gemm_nt_bf16(hipStream_t st, const float *A, int64_t lda, const float *B, int64_t ldb, const float *bias, float *C,
                         int64_t ldc, int64_t M, int N, int nb, int K, int epi);

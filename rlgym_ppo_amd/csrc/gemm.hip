@@ -39,7 +39,8 @@ __global__ __launch_bounds__(256, BKT == 16 ? 4 : 2) void gemm_nt_dma_kernel(con
                                                                               unsigned ldc_b, int64_t M, int K,
                                                                               unsigned long long *__restrict__ bits = nullptr,
                                                                               const unsigned *__restrict__ rowtab = nullptr,
-                                                                              unsigned src_rows = 0, NtAlt alt = NtAlt{}) {
+                                                                              unsigned src_rows = 0, NtAlt alt = NtAlt{},
+                                                                              NtDot dot = NtDot{}, NtDot dot_alt = NtDot{}) {
     // [r3] a launch may carry TWO products of the same shape (policy and critic layers of equal widths): blockIdx.z == 1 takes its
     // operands from `alt` (scalar selects; M, K, leading dimensions, row table are shared)
     if (blockIdx.z) {
@@ -48,6 +49,7 @@ __global__ __launch_bounds__(256, BKT == 16 ? 4 : 2) void gemm_nt_dma_kernel(con
         bias = alt.bias;
         C = alt.C;
         bits = alt.bits;
+        dot = dot_alt;
     }
     constexpr int BN = NB * 16;
     constexpr int CPR = BKT / 4;     // 16-byte chunks per tile row
@@ -167,6 +169,29 @@ __global__ __launch_bounds__(256, BKT == 16 ? 4 : 2) void gemm_nt_dma_kernel(con
 #pragma unroll
                 for (int e = 0; e < 4; ++e) acc[i][j][e] = relu1(acc[i][j][e]);
         *bit_word = relu_bits<NB>(acc);
+        if (dot.w) {  // (scalar condition) the one-output head that reads this layer: partial dot products of the tile's rows
+            const __amdgpu_buffer_rsrc_t w_rs = make_rsrc(dot.w + n0, BN * 4);
+            float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                const f32x4 wv = ldb(w_rs, (unsigned)(q * 16), j * 64);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    s0 += acc[0][j][e] * wv[e];
+                    s1 += acc[1][j][e] * wv[e];
+                }
+            }
+            s0 += __shfl_xor(s0, 16);
+            s1 += __shfl_xor(s1, 16);
+            s0 += __shfl_xor(s0, 32);
+            s1 += __shfl_xor(s1, 32);
+            if (q == 0) {
+                const float b0 = col_tile == 0 ? dot.b[0] : 0.f;
+                const int r0 = wave * 32 + r16;
+                if (r0 < rows_here) atomicAdd(dot.out + m0 + r0, s0 + b0);
+                if (r0 + 16 < rows_here) atomicAdd(dot.out + m0 + r0 + 16, s1 + b0);
+            }
+        }
         nt_epilogue<NB, EPI_NONE>(acc, nullptr, 0, C, ldc_b, m0, n0, rows_here, wave, r16, q);
     } else {
         nt_epilogue<NB, EPI>(acc, mask_src, ldm_b, C, ldc_b, m0, n0, rows_here, wave, r16, q);
@@ -370,7 +395,7 @@ bool nt_gather_ok(int64_t lda, int64_t src_rows, int N, int K) {
 }
 int launch_gemm_nt_bits(hipStream_t st, const float *A, int64_t lda, const float *B, int64_t ldb, const float *bias, float *C,
                         int64_t ldc, int64_t M, int N, int K, int epi, unsigned long long *bits, const unsigned *rowtab,
-                        int64_t src_rows, const NtAlt *alt) {
+                        int64_t src_rows, const NtAlt *alt, const NtDot *dot) {
     if (!bits || N % 128 != 0 || K % 16 != 0 || M <= 0) return -1;
     if (epi != EPI_BIAS_RELU && epi != EPI_MASK) return -1;
     const int64_t lim = (int64_t)1 << 31;
@@ -378,14 +403,17 @@ int launch_gemm_nt_bits(hipStream_t st, const float *A, int64_t lda, const float
     RLPPO_CHECK_ARG(!alt || (alt->A && alt->B && alt->C && alt->bits), "gemm_nt: incomplete second operand set");
     dim3 grid((unsigned)cdiv(M, SBM), (unsigned)(N / 128), alt ? 2u : 1u);
     const NtAlt second = alt ? *alt : NtAlt{};
+    const NtDot d0 = dot ? dot[0] : NtDot{}, d1 = dot && alt ? dot[1] : NtDot{};
+    RLPPO_CHECK_ARG(!dot || (epi == EPI_BIAS_RELU && N / 128 <= 2 && (!d0.w || (d0.out && d0.b)) && (!d1.w || (d1.out && d1.b))),
+                    "gemm_nt: the folded one-output head needs the ReLU forward form and at most two column tiles");
     const unsigned la = (unsigned)(lda * 4), lb = (unsigned)(ldb * 4), lc = (unsigned)(ldc * 4);
     if (rowtab) {
         RLPPO_CHECK_ARG(epi == EPI_BIAS_RELU && nt_gather_ok(lda, src_rows, N, K), "gemm_nt (gathered rows): unsupported shape");
         hipLaunchKernelGGL((gemm_nt_dma_kernel<8, EPI_BIAS_RELU, 16, true, true>), grid, dim3(256), 0, st, A, la, B, lb, bias, nullptr,
-                           0u, C, lc, M, K, bits, rowtab, (unsigned)src_rows, second);
+                           0u, C, lc, M, K, bits, rowtab, (unsigned)src_rows, second, d0, d1);
     } else if (epi == EPI_BIAS_RELU)
         hipLaunchKernelGGL((gemm_nt_dma_kernel<8, EPI_BIAS_RELU, 16, true>), grid, dim3(256), 0, st, A, la, B, lb, bias, nullptr,
-                           0u, C, lc, M, K, bits, nullptr, 0u, second);
+                           0u, C, lc, M, K, bits, nullptr, 0u, second, d0, d1);
     else
         hipLaunchKernelGGL((gemm_nt_dma_kernel<8, EPI_MASK, 16, true>), grid, dim3(256), 0, st, A, la, B, lb, nullptr, nullptr, 0u,
                            C, lc, M, K, bits, nullptr, 0u, second);

@@ -889,23 +889,44 @@ def test_fused_gather_and_paired_launches_are_bitwise_neutral(L):
     idx = rs.randint(0, n, mb)
     idx[:3] = [n - 1, 0, n - 1]
     runs = {}
-    for key, (k26, k29) in dict(fused=(1, 2), separate_gather=(0, 2), two_chains=(1, 0), round2=(0, 0)).items():
+    forms = dict(fused=(1, 2, 0), separate_gather=(0, 2, 0), two_chains=(1, 0, 0), round2=(0, 0, 0), folded_value_head=(1, 2, 1))
+    for key, (k26, k29, k32) in forms.items():
         check(L, L.rlppo_dbg_set(26, k26))
         check(L, L.rlppo_dbg_set(29, k29))   # paired launches (policy + critic layer in one grid) against one chain per network
+        check(L, L.rlppo_dbg_set(32, k32))   # the critic's output layer inside the last hidden layer's forward epilogue
         try:
             runs[key] = run_minibatch(L, "discrete", pol, val, obs, acts, old, tgt, adv, idx, 0.2, 0.005, 0.25)
         finally:
             check(L, L.rlppo_dbg_set(26, 1))
             check(L, L.rlppo_dbg_set(29, 1))
+            check(L, L.rlppo_dbg_set(32, 1))
     gp0, gv0, st0 = runs["fused"]
     for key, (gp, gv, st) in runs.items():
+        if key == "folded_value_head":
+            continue
         for (a, b), (c, e) in zip(gp0 + gv0, gp + gv):
             assert torch.equal(a, c) and torch.equal(b, e), key
         # (the report statistics are double atomics of both chains: their order, hence the last bit, may differ)
         np.testing.assert_allclose(st0, st, rtol=1e-12, atol=0, err_msg=key)
-    # and the fused form is right (float64 truth), not merely self-consistent
-    fp64_gate.gate(L, "discrete", pol, val, obs[idx], acts[idx], old[idx], adv[idx], tgt[idx], 0.2, 0.005, 0.25, runs["fused"],
-                   label="fused gather, ragged 1500-row minibatch")
+    # The folded value head computes each value as two partial dot products over 128 activations each (+ bias) instead of the
+    # matrix-vector kernel's order: the policy's gradients cannot change, the critic's only by that rounding -- and the form is
+    # deterministic (two partial sums added to zero commute): a second run reproduces it bit for bit.
+    gp1, gv1, st1 = runs["folded_value_head"]
+    for (a, b), (c, e) in zip(gp0, gp1):
+        assert torch.equal(a, c) and torch.equal(b, e)
+    for (a, b), (c, e) in zip(gv0, gv1):
+        assert relerr(c, a) < 2e-6 and relerr(e, b) < 2e-6
+    check(L, L.rlppo_dbg_set(29, 2))
+    try:
+        gp2, gv2, _ = run_minibatch(L, "discrete", pol, val, obs, acts, old, tgt, adv, idx, 0.2, 0.005, 0.25)
+    finally:
+        check(L, L.rlppo_dbg_set(29, 1))
+    for (a, b), (c, e) in zip(gp1 + gv1, gp2 + gv2):
+        assert torch.equal(a, c) and torch.equal(b, e)
+    # and both forms are right (float64 truth), not merely self-consistent
+    for key in ("fused", "folded_value_head"):
+        fp64_gate.gate(L, "discrete", pol, val, obs[idx], acts[idx], old[idx], adv[idx], tgt[idx], 0.2, 0.005, 0.25, runs[key],
+                       label=key + ", ragged 1500-row minibatch")
 
 
 def test_minibatch_full_size_cfg2(L):

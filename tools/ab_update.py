@@ -19,7 +19,8 @@ configs = {
     "optimiser tail as fill+norms+update": {"one_launch": False},
     "one launch chain per network (dbg 29=0)": {"dbg": (29, 0)},
     "critic head backward not ordered after the policy loss (dbg 31=0)": {"dbg": (31, 0)},
-    "all off (round 2 launch structure)": {"dbg2": ((26, 0), (29, 0)), "one_launch": False},
+    "critic head as its own matrix-vector launch (dbg 32=0)": {"dbg": (32, 0)},
+    "all off (round 2 launch structure)": {"dbg2": ((26, 0), (29, 0), (31, 0), (32, 0)), "one_launch": False},
 }
 
 
