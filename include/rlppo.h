@@ -357,8 +357,9 @@ int rlppo_net_pack_bf16(void *stream, const int32_t *dims, int32_t n_layers, con
  *  27 rlppo_discrete_act / rlppo_discrete_step [1 = one fused launch where the network has that form (default) | 0 = layer chain]
  *  29 policy + critic layers of equal widths as ONE launch [1 = from 262,144 rows per pass (default) | 0 = never | 2 = always]
  *  31 paired pass: the critic's output-layer backward waits for the policy's loss kernel [1 (default) | 0 = both chains free-running]
- *  32 paired pass: a one-output critic head is computed in the last hidden layer's forward epilogue [1 (default) | 0 = its own
- *     matrix-vector launch] */
+ *  32 a one-output critic head is computed in the last hidden layer's forward epilogue [1 (default) | 0 = its own matrix-vector launch]
+ *  33 paired launches: the two products' tiles interleave in the grid (a row tile's workgroups of both networks back to back on one
+ *     XCD) [1 (default) | 0 = the second product stacked behind the first] */
 int rlppo_dbg_set(int32_t key, int32_t value);
 /* Counter bumped by every call that changes which kernels later launches select (rlppo_dbg_set, rlppo_set_*_precision): a
  * host that caches captured graphs of library calls keys them on it (rlgym_ppo_amd/ppo/_mlp.py::ActGraph). */

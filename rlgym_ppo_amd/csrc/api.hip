@@ -1240,6 +1240,7 @@ int rlppo_dbg_set(int32_t key, int32_t value) {
         case 29: g_paired = value; return 0;
         case 31: g_head_order = value; return 0;
         case 32: g_fold_vhead = value; return 0;
+        case 33: set_pair_interleave(value); return 0;
         default: break;
     }
     set_error("dbg_set: unknown key %d", key);

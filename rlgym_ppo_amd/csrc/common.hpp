@@ -110,6 +110,7 @@ struct NtAlt {  // second operand set of a paired gemm_nt launch (M, N, K, leadi
     const float *A = nullptr, *B = nullptr, *bias = nullptr;
     float *C = nullptr;
     unsigned long long *bits = nullptr;
+    int interleave = 0;  // 1: the two products share the grid's y range (column tiles of both, same XCD back to back) instead of z
 };
 // [r3] a one-output head folded into the epilogue of the hidden layer that feeds it (the critic's value = h . w + b, value_estimator.py):
 // out[row] (compact, zero-filled by the caller) += the row's partial dot product over the workgroup's 128 columns (+ b from the
@@ -129,6 +130,7 @@ bool nt_gather_ok(int64_t lda, int64_t src_rows, int N, int K);  // can the forw
 int launch_gemm_nt_bf16(hipStream_t st, const float *A, int64_t lda, const float *B, int64_t ldb, const float *bias, float *C,
                         int64_t ldc, int64_t M, int N, int nb, int K, int epi);
 void set_infer_bf16(int v);
+void set_pair_interleave(int v);
 int get_infer_bf16();
 // dW[n][k] += sum_m dY[m][n] X[m][k] ; db[n] += sum_m dY[m][n]: partial tiles in `ws` (>= tn_partial_floats(out, in, M)
 // floats) + a fixed-order reduction into the flat arena

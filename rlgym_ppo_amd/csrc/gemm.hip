@@ -43,14 +43,7 @@ __global__ __launch_bounds__(256, BKT == 16 ? 4 : 2) void gemm_nt_dma_kernel(con
                                                                               NtDot dot = NtDot{}, NtDot dot_alt = NtDot{}) {
     // [r3] a launch may carry TWO products of the same shape (policy and critic layers of equal widths): blockIdx.z == 1 takes its
     // operands from `alt` (scalar selects; M, K, leading dimensions, row table are shared)
-    if (blockIdx.z) {
-        A = alt.A;
-        B = alt.B;
-        bias = alt.bias;
-        C = alt.C;
-        bits = alt.bits;
-        dot = dot_alt;
-    }
+    // (the operand set is chosen below, once the tile is known)
     constexpr int BN = NB * 16;
     constexpr int CPR = BKT / 4;     // 16-byte chunks per tile row
     constexpr int RPW = 64 / CPR;    // tile rows one wave instruction fills
@@ -71,10 +64,27 @@ __global__ __launch_bounds__(256, BKT == 16 ? 4 : 2) void gemm_nt_dma_kernel(con
     const int r16 = lane & 15, q = lane >> 4;
     int row_tile, col_tile;
     xcd_tile(row_tile, col_tile);
+    // Interleaved pairing: the grid's y range holds the column tiles of BOTH products, so the workgroups that read one row tile of
+    // A -- for a gathered first layer both networks read the SAME rows of the experience buffer -- get consecutive ids on one XCD.
+    int nct = gridDim.y;
+    bool second = blockIdx.z != 0;
+    if (alt.interleave) {
+        nct >>= 1;
+        second = col_tile >= nct;
+        if (second) col_tile -= nct;
+    }
+    if (second) {  // (scalar selects)
+        A = alt.A;
+        B = alt.B;
+        bias = alt.bias;
+        C = alt.C;
+        bits = alt.bits;
+        dot = dot_alt;
+    }
     const int64_t m0 = (int64_t)row_tile * SBM;
     const int n0 = col_tile * BN;
     const int rows_here = (int)((M - m0) < SBM ? (M - m0) : SBM);
-    unsigned long long *const bit_word = BITS ? bits + ((size_t)row_tile * gridDim.y + col_tile) * 256 + tid : nullptr;
+    unsigned long long *const bit_word = BITS ? bits + ((size_t)row_tile * nct + col_tile) * 256 + tid : nullptr;
     unsigned long long mask_word = 0;
     if (BITS && EPI == EPI_MASK) mask_word = *bit_word;  // requested before the K loop: long arrived when the epilogue needs it
 
@@ -390,6 +400,8 @@ size_t nt_bits_floats(int64_t M, int N) {
 // (width not a multiple of 128, operands too wide for 32-bit tile offsets): the caller then uses launch_gemm_nt
 // and, for the forward, must not hand the bitmask to the backward pass.
 // rowtab != nullptr (forward only): row r of A is A[rowtab[r]] of a `src_rows`-row matrix -- the fused minibatch gather.
+static int g_pair_interleave = 1;  // rlppo_dbg_set(33, 0/1): paired launches interleave the two products' tiles (y range) instead of stacking them (z)
+void set_pair_interleave(int v) { g_pair_interleave = v; }
 bool nt_gather_ok(int64_t lda, int64_t src_rows, int N, int K) {
     return N % 128 == 0 && K % 16 == 0 && lda * 4 < 16384 && lda % 4 == 0 && src_rows > 0 && src_rows < ((int64_t)1 << 32);
 }
@@ -402,7 +414,12 @@ int launch_gemm_nt_bits(hipStream_t st, const float *A, int64_t lda, const float
     if ((!rowtab && 129 * lda * 4 >= lim) || 129 * ldb * 4 >= lim || 129 * ldc * 4 >= lim) return -1;
     RLPPO_CHECK_ARG(!alt || (alt->A && alt->B && alt->C && alt->bits), "gemm_nt: incomplete second operand set");
     dim3 grid((unsigned)cdiv(M, SBM), (unsigned)(N / 128), alt ? 2u : 1u);
-    const NtAlt second = alt ? *alt : NtAlt{};
+    NtAlt second = alt ? *alt : NtAlt{};
+    if (alt && g_pair_interleave) {
+        grid.y *= 2;
+        grid.z = 1;
+        second.interleave = 1;
+    }
     const NtDot d0 = dot ? dot[0] : NtDot{}, d1 = dot && alt ? dot[1] : NtDot{};
     RLPPO_CHECK_ARG(!dot || (epi == EPI_BIAS_RELU && N / 128 <= 2 && (!d0.w || (d0.out && d0.b)) && (!d1.w || (d1.out && d1.b))),
                     "gemm_nt: the folded one-output head needs the ReLU forward form and at most two column tiles");
@@ -504,8 +521,20 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_dma_kernel(const float *__rest
     // [r3] two products of the same shape in one launch: the upper half of the z range takes (dY, X, partial) from `alt`
     const int splits_z = alt.dY ? gridDim.z / 2 : gridDim.z;
     int zloc = blockIdx.z;
-    if (alt.dY && zloc >= splits_z) {
-        zloc -= splits_z;
+    bool second = alt.dY && !alt.interleave && zloc >= splits_z;
+    if (second) zloc -= splits_z;
+    // interleaved pairing (splits a multiple of 8): id -> (product, tile, split) in groups of 8 splits x 2 T tiles
+    int il_tile = -1, il_split = 0;
+    if (alt.dY && alt.interleave) {
+        const int T = gridDim.x * gridDim.y;
+        const int id = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x, g = id % (16 * T);
+        int t2 = g >> 3;
+        second = t2 >= T;
+        if (second) t2 -= T;
+        il_tile = t2;
+        il_split = (id / (16 * T)) * 8 + (g & 7);
+    }
+    if (second) {
         dY = alt.dY;
         if (!GATHER) X = alt.X;
         partial = alt.partial;
@@ -527,7 +556,11 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_dma_kernel(const float *__rest
     int bx = blockIdx.x, by = blockIdx.y, bz = zloc;
     {
         const int T = gridDim.x * gridDim.y;
-        if ((splits_z & 7) == 0 && T > 1) {
+        if (il_tile >= 0) {
+            bz = il_split;
+            bx = il_tile % gridDim.x;
+            by = il_tile / gridDim.x;
+        } else if ((splits_z & 7) == 0 && T > 1) {
             const int id = (zloc * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x, g = id % (8 * T);
             const int tile = g >> 3;
             bz = (id / (8 * T)) * 8 + (g & 7);
@@ -817,7 +850,7 @@ int launch_gemm_tn(hipStream_t st, const float *dY, int64_t ldy, int ny_valid, c
                     "gemm_tn: incomplete second operand set");
     dim3 grid((unsigned)tiles_x, (unsigned)tiles_y, (unsigned)(pair ? 2 * splits : splits));
     TnAlt alt{};
-    if (pair) alt = TnAlt{pair->dY, pair->X, pair->ws};
+    if (pair) alt = TnAlt{pair->dY, pair->X, pair->ws, (g_pair_interleave && splits % 8 == 0) ? 1 : 0};
 #define TN(NI_, NJ_, WN_, G_)                                                                                              \
     hipLaunchKernelGGL((gemm_tn_dma_kernel<TM, NI_, NJ_, WN_, G_>), grid, dim3(256), 0, st, dY, (unsigned)(ldy * 4), ny_valid, X, \
                        (unsigned)(ldx * 4), kx_valid, db != nullptr, out, in, M, rows_per_wg, ws, rowtab, (unsigned)src_rows, alt)

@@ -151,6 +151,8 @@ int64_t tn_partial_rows_wide(int pout, int pin, int64_t M);    // ... of the 256
 struct TnAlt {     // device-side second operand set of a paired gemm_tn launch
     const float *dY, *X;
     float *partial;
+    int interleave;  // 1: ids of both products' tiles interleave within a row split (same XCD back to back: a gathered first layer's two
+                     // products read the same rows of the experience buffer) instead of the second product taking the upper half of z
 };
 struct TnRedAlt {  // ... and of its reduction
     const float *partial;

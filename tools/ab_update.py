@@ -20,6 +20,7 @@ configs = {
     "one launch chain per network (dbg 29=0)": {"dbg": (29, 0)},
     "critic head backward not ordered after the policy loss (dbg 31=0)": {"dbg": (31, 0)},
     "critic head as its own matrix-vector launch (dbg 32=0)": {"dbg": (32, 0)},
+    "paired launches stacked in z, not interleaved (dbg 33=0)": {"dbg": (33, 0)},
     "all off (round 2 launch structure)": {"dbg2": ((26, 0), (29, 0), (31, 0), (32, 0)), "one_launch": False},
 }
 
