@@ -60,6 +60,10 @@ class ActGraph:
             N.check(L.rlppo_pad_rows(stream_ptr(), ptr(self.obs_pin), 0, cap, d, d, ptr(self.rows), a.ld_in, 0, 0.0, 1.0))
             pol._act_launch(self.rows, cap, self.q_pin, self.act_pin, self.logp_pin, self.ws)
 
+        self.body = body
+        # a body that is ONE launch (the discrete head) is issued as such on the pinned buffers: a replay of a one-node graph costs
+        # 2-3 us more than the launch (tools/small_batch_latency.py); RLPPO_ACT_EAGER=0/1 forces either form
+        self.eager = os.environ.get("RLPPO_ACT_EAGER", "1" if raw is not None else "0") == "1"
         side = torch.cuda.Stream(dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):
@@ -77,7 +81,10 @@ class ActGraph:
         # 256-thread host), and slicing tensors costs more than these copies at 8-80 rows
         self.obs_np[:n] = obs
         self.q_np[:q.numel()] = q.reshape(-1).numpy()
-        self.graph.replay()
+        if self.eager:
+            self.body()
+        else:
+            self.graph.replay()
         torch.cuda.current_stream(self.dev).synchronize()
         return torch.from_numpy(self.act_np[:n].copy()), torch.from_numpy(self.logp_np[:n].copy())
 
