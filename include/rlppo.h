@@ -297,6 +297,20 @@ int rlppo_apply_swap_targets(int64_t n, const uint32_t *targets, int64_t *out);
  * The serial MT19937 phase is vectorised and the double-precision log1p transform runs on `threads` threads: 4096 x 90 values
  * in ~0.5 ms instead of the ~4.7 ms of torch's serial kernel. */
 int rlppo_torch_cpu_exponential(void *state, int64_t state_bytes, int64_t n, double lambda, float *out, int32_t threads);
+/* The same draw in two calls, for callers that pipeline consecutive draws (the stream phase of the next draw needs only the state
+ * this one's stream phase leaves behind): _words fills words[2 n + 8] with the tempered MT19937 words and advances `state` exactly as
+ * the one-call form does; rlppo_exponential_from_words turns them into the identical n float32 values (no generator involved: any
+ * thread). */
+int rlppo_torch_cpu_exponential_words(void *state, int64_t state_bytes, int64_t n, uint32_t *words);
+int rlppo_exponential_from_words(const uint32_t *words, int64_t n, double lambda, float *out);
+/* One draw as one call that chains itself to its predecessor on another thread: link blocks are { int32 ready; padding to 64 bytes;
+ * the generator state (state_bytes) }.  The call waits (spinning, in C) until `link_in` -- the block its predecessor publishes as soon
+ * as that call's STREAM phase is done -- is ready (link_in == NULL: starts from `state`, which is not modified), runs its stream phase,
+ * publishes `link_out` (zero its first word beforehand) and then transforms into `out`; `words` is scratch of 2 n + 8 uint32.  The state
+ * after the draw is link_out's.  Values and states are those of rlppo_torch_cpu_exponential. */
+#define RLPPO_EXP_LINK_HEADER 64
+int rlppo_torch_cpu_exponential_chained(const void *state, int64_t state_bytes, int64_t n, double lambda, float *out, uint32_t *words,
+                                        void *link_in, void *link_out);
 
 /* dst[r][0..width) = src[idx[r]][0..width), fp32 rows, 16 bytes per thread (width, ld_src multiples of 4; dst rows are
  * `width` floats apart).  The minibatch gather of experience_buffer.py:82-87 (used inside rlppo_ppo_minibatch) and the

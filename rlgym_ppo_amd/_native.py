@@ -17,6 +17,7 @@ MAX_LAYERS = 16
 N_STATS = 8
 OPT_SYNC_BYTES = 16384  # RLPPO_OPT_SYNC_BYTES
 OPT_SYNC_TIMEOUT_WORD = 2  # uint32 index of the barrier-timeout counter in the sync block
+EXP_LINK_HEADER = 64  # RLPPO_EXP_LINK_HEADER
 MAX_SLOTS = 8
 STAT_ENTROPY, STAT_KL, STAT_VLOSS, STAT_CLIPFRAC, STAT_PLOSS = 0, 1, 2, 3, 4
 STAT_PASSES = 7  # host-side: passes of rlppo_ppo_minibatch behind the sums above (summed over ranks with them)
@@ -101,6 +102,9 @@ SIGNATURES = {
     "rlppo_mt19937_draw_targets": (c_int32, [POINTER(c_uint32), c_int64, c_void_p]),
     "rlppo_apply_swap_targets": (c_int32, [c_int64, c_void_p, c_void_p]),
     "rlppo_torch_cpu_exponential": (c_int32, [c_void_p, c_int64, c_int64, c_double, c_void_p, c_int32]),
+    "rlppo_torch_cpu_exponential_words": (c_int32, [c_void_p, c_int64, c_int64, c_void_p]),
+    "rlppo_exponential_from_words": (c_int32, [c_void_p, c_int64, c_double, c_void_p]),
+    "rlppo_torch_cpu_exponential_chained": (c_int32, [c_void_p, c_int64, c_int64, c_double, c_void_p, c_void_p, c_void_p, c_void_p]),
     "rlppo_gather_rows": (c_int32, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int32, c_int64]),
     "rlppo_welford_increment": (c_int32, [c_void_p, c_void_p, c_int64, c_int64, c_int32, c_void_p, c_void_p, c_int64, c_int32]),
     "rlppo_welford_merge": (c_int32, [c_void_p, c_int32, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int32]),

@@ -522,41 +522,16 @@ namespace rlppo {
 void set_exp_fast_transform(int on) { g_exp_fast = on != 0; }
 }  // namespace rlppo
 
-extern "C" int rlppo_torch_cpu_exponential(void *state, int64_t state_bytes, int64_t n, double lambda, float *out, int32_t threads) {
-    if (!state || state_bytes < (int64_t)sizeof(TorchState) || n < 0 || (n > 0 && !out) || !(lambda > 0.0)) return RLPPO_ERR_ARG;
-    if (n == 0) return 0;
-    TorchState *ts = reinterpret_cast<TorchState *>(state);
+namespace {
+// The stream phase: 2 n tempered MT19937 words, drawn exactly as c10::mt19937 would hand them out, into w; the serialised state
+// advances in place.  `published` (may be null) is told how many ELEMENTS have both their words in w.
+int exp_stream(TorchState *ts, int64_t n, uint32_t *w, std::atomic<int64_t> *published) {
     if (ts->left < 1 || ts->left > N || ts->next > (uint64_t)N) return RLPPO_ERR_ARG;
     static const bool have512 = __builtin_cpu_supports("avx512f") != 0;
     uint32_t mt[N + 16];
     for (int i = 0; i < N; i++) mt[i] = (uint32_t)ts->mt[i];
     int left = ts->left;
     uint32_t next = (uint32_t)ts->next;
-
-    // The stream phase (serial: MT19937 regeneration + tempering, ~0.9 ns per word) publishes the tempered words chunk by
-    // chunk; the transform phase (double-precision log1p, ~7 ns per element) runs on persistent helper threads that claim
-    // slices of 2048 elements as soon as their words are published -- the two phases overlap instead of adding up.
-    static thread_local std::vector<uint32_t> words;
-    words.resize((size_t)(2 * n) + 8);
-    uint32_t *w = words.data();
-    const double scale = -1.0 / lambda;
-    ExpJob job;
-    job.w = w;
-    job.out = out;
-    job.n = n;
-    job.scale = scale;
-    int t = threads < 1 ? 1 : (threads > 32 ? 32 : threads);
-    if ((int64_t)(t - 1) * ExpJob::SLICE > n) t = (int)(n / ExpJob::SLICE) + 1;
-    // With the vectorised transform (0.3-2 ns per element) the calling thread alone finishes the 4096 x 90 draw of a rollout step in
-    // 0.4 ms; helpers only add their wake-up and hand-shake latency to a draw of that size (0.6 ms with 2 threads, 1.1 ms with 8 on
-    // a busy host).  Large draws still spread over the pool.
-    if (g_exp_fast) {
-        const int by_size = 1 + (int)(n >> 20);  // one helper per 2^20 elements: none for the draw of a rollout step
-        t = t < by_size ? t : by_size;
-    }
-    ExpPool &pool = ExpPool::get();
-    if (t > 1) pool.start(&job, t - 1);
-
     int64_t need = 2 * n, got = 0;
     while (got < need) {
         // words still unread in the current block: state[next .. 623] are readable while left - 1 > 0 reads remain
@@ -582,12 +557,99 @@ extern "C" int rlppo_torch_cpu_exponential(void *state, int64_t state_bytes, int
         got += take;
         next += (uint32_t)take;
         left -= take;
-        job.published.store(got / 2, std::memory_order_release);
+        if (published) published->store(got / 2, std::memory_order_release);
     }
     for (int i = 0; i < N; i++) ts->mt[i] = mt[i];
     ts->left = left;
     ts->next = next;
+    return 0;
+}
+}  // namespace
+
+extern "C" int rlppo_torch_cpu_exponential(void *state, int64_t state_bytes, int64_t n, double lambda, float *out, int32_t threads) {
+    if (!state || state_bytes < (int64_t)sizeof(TorchState) || n < 0 || (n > 0 && !out) || !(lambda > 0.0)) return RLPPO_ERR_ARG;
+    if (n == 0) return 0;
+    TorchState *ts = reinterpret_cast<TorchState *>(state);
+    if (ts->left < 1 || ts->left > N || ts->next > (uint64_t)N) return RLPPO_ERR_ARG;
+
+    // The stream phase (serial: MT19937 regeneration + tempering, ~0.9 ns per word) publishes the tempered words chunk by
+    // chunk; the transform phase (double-precision log1p, ~7 ns per element) runs on persistent helper threads that claim
+    // slices of 2048 elements as soon as their words are published -- the two phases overlap instead of adding up.
+    static thread_local std::vector<uint32_t> words;
+    words.resize((size_t)(2 * n) + 8);
+    uint32_t *w = words.data();
+    const double scale = -1.0 / lambda;
+    ExpJob job;
+    job.w = w;
+    job.out = out;
+    job.n = n;
+    job.scale = scale;
+    int t = threads < 1 ? 1 : (threads > 32 ? 32 : threads);
+    if ((int64_t)(t - 1) * ExpJob::SLICE > n) t = (int)(n / ExpJob::SLICE) + 1;
+    // With the vectorised transform (0.3-2 ns per element) the calling thread alone finishes the 4096 x 90 draw of a rollout step in
+    // 0.4 ms; helpers only add their wake-up and hand-shake latency to a draw of that size (0.6 ms with 2 threads, 1.1 ms with 8 on
+    // a busy host).  Large draws still spread over the pool.
+    if (g_exp_fast) {
+        const int by_size = 1 + (int)(n >> 20);  // one helper per 2^20 elements: none for the draw of a rollout step
+        t = t < by_size ? t : by_size;
+    }
+    ExpPool &pool = ExpPool::get();
+    if (t > 1) pool.start(&job, t - 1);
+    const int rc = exp_stream(ts, n, w, &job.published);
+    if (rc) job.published.store(n, std::memory_order_release);  // (cannot happen: the state was checked above) never leave helpers waiting
     job.work();                  // the calling thread helps with what is left
     if (t > 1) pool.finish(&job);
+    return rc;
+}
+
+// [r3] The same draw as two calls, for a caller that pipelines consecutive draws (engine.HostExponential): the stream phase of draw
+// k + 1 needs nothing from draw k but the generator state its stream phase left behind, so it can run while draw k is still being
+// transformed on another thread.  rlppo_torch_cpu_exponential_words fills words[2 n (+ 8 of slack)] and advances the state exactly
+// as the one-call form does; rlppo_exponential_from_words turns them into the n float32 values -- the identical values.
+extern "C" int rlppo_torch_cpu_exponential_words(void *state, int64_t state_bytes, int64_t n, uint32_t *words) {
+    if (!state || state_bytes < (int64_t)sizeof(TorchState) || n < 0 || (n > 0 && !words)) return RLPPO_ERR_ARG;
+    if (n == 0) return 0;
+    return exp_stream(reinterpret_cast<TorchState *>(state), n, words, nullptr);
+}
+// [r3] One draw as ONE call that can be chained to its predecessor without the caller in between: `link_in` (may be null) is the
+// link block another thread's call publishes -- { int32 ready; pad to 64 bytes; state bytes } -- and this call spins (no GIL, no
+// syscall) until that call's STREAM phase has finished, takes the state it left behind, runs its own stream phase, publishes ITS
+// link block (`link_out`, required) and only then transforms.  Two threads alternating over consecutive draws therefore overlap
+// the transform of draw k with the stream phase (and the transform) of draw k + 1: one draw leaves the pair every half draw time.
+// With link_in == null the start state is `state` (not modified: the state after this draw is link_out's).
+extern "C" int rlppo_torch_cpu_exponential_chained(const void *state, int64_t state_bytes, int64_t n, double lambda, float *out,
+                                                   uint32_t *words, void *link_in, void *link_out) {
+    if (state_bytes < (int64_t)sizeof(TorchState) || n <= 0 || !out || !words || !link_out || !(lambda > 0.0) || (!state && !link_in))
+        return RLPPO_ERR_ARG;
+    auto ready_of = [](void *l) { return reinterpret_cast<std::atomic<int32_t> *>(l); };
+    auto state_of = [](void *l) { return reinterpret_cast<char *>(l) + 64; };
+    std::vector<char> local((size_t)state_bytes);
+    if (link_in) {
+        uint64_t spins = 0;
+        while (ready_of(link_in)->load(std::memory_order_acquire) == 0) {
+            _mm_pause();
+            if (++spins > (1ull << 33)) return RLPPO_ERR_ARG;  // (minutes: the predecessor died)
+        }
+        if (ready_of(link_in)->load(std::memory_order_acquire) < 0) {  // the predecessor failed: pass the failure on
+            ready_of(link_out)->store(-1, std::memory_order_release);
+            return RLPPO_ERR_ARG;
+        }
+        memcpy(local.data(), state_of(link_in), (size_t)state_bytes);
+    } else {
+        memcpy(local.data(), state, (size_t)state_bytes);
+    }
+    const int rc = exp_stream(reinterpret_cast<TorchState *>(local.data()), n, words, nullptr);
+    if (rc) {
+        ready_of(link_out)->store(-1, std::memory_order_release);
+        return rc;
+    }
+    memcpy(state_of(link_out), local.data(), (size_t)state_bytes);
+    ready_of(link_out)->store(1, std::memory_order_release);
+    exp_transform(words, out, 0, n, -1.0 / lambda);
+    return 0;
+}
+extern "C" int rlppo_exponential_from_words(const uint32_t *words, int64_t n, double lambda, float *out) {
+    if (n < 0 || (n > 0 && (!words || !out)) || !(lambda > 0.0)) return RLPPO_ERR_ARG;
+    if (n > 0) exp_transform(words, out, 0, n, -1.0 / lambda);
     return 0;
 }

@@ -396,22 +396,30 @@ class HostExponential:
     element against the float32 rounding, libm where it cannot be, instead of torch's serial 12-26 ns per number) and drawn one
     request AHEAD on a helper thread.
 
-    The look-ahead is speculative and transparent, the contract of LegacyPermutation: after a draw of `shape` the helper draws
-    the same shape again from the state the generator was left in, into a pinned buffer; the next request is served from it
-    only if the shape matches and torch's global generator is still in exactly that state (nobody else drew from it), and
-    then the generator is advanced to the state after the speculative draw -- otherwise the speculation is dropped and the
-    draw happens on the spot.  The observable stream never differs from torch's.  Buffers are pinned (a ring of 3): the
-    caller uploads them with an asynchronous copy and must have consumed a buffer before the next-but-one request."""
+    The look-ahead is speculative and transparent, the contract of LegacyPermutation: after a draw of `shape` the helpers draw
+    the same shape again -- `depth` requests deep [r3: a chain of two, was one] -- from the states the generator WILL be in if
+    nobody else uses it, into pinned buffers; a request is served from the head of the chain only if the shape matches and
+    torch's global generator is in exactly the predicted state, and then the generator is advanced to the state after that
+    draw -- otherwise the chain is dropped and the draw happens on the spot.  The observable stream never differs from torch's.
+    [r3] Each speculative draw is ONE call of rlppo_torch_cpu_exponential_chained on one of two helper threads: the call waits
+    (in C, spinning on a link block) until its predecessor's serial MT19937 stream phase is done, takes the state that phase
+    left behind, runs its own stream phase, publishes its link block and only then transforms -- so the transform of draw k
+    overlaps the whole of draw k + 1, and a 4096 x 90 draw leaves the pair every ~0.2 ms instead of every 0.36 ms, with no
+    Python (no GIL) between the phases.  Buffers are pinned (a ring of depth + 3): the caller uploads them with an
+    asynchronous copy and must have consumed a buffer before the ring comes round."""
 
-    RING = 3
+    DEPTH = 3  # with two helper threads: a third request always waits in their queue, so neither goes to sleep between draws (tools/host_noise_pipeline.py)
     LOOKAHEAD_MIN = 65536  # elements: below that the hand-over to the helper thread (~50 us) costs more than the draw itself (~1 ns per number)
 
     def __init__(self):
         import os
-        self.lookahead = os.environ.get("RLPPO_NOISE_LOOKAHEAD", "1") != "0"
+        look = os.environ.get("RLPPO_NOISE_LOOKAHEAD", "")
+        self.depth = self.DEPTH if look == "" else max(0, int(look))  # requests drawn ahead (0: on demand)
+        self.RING = self.depth + 3
+        self.workers = max(1, int(os.environ.get("RLPPO_NOISE_THREADS", "2")))  # helper threads the chain's draws alternate over
         self.threads = max(1, min(8, (os.cpu_count() or 2) // 2))  # an upper bound: the library uses one thread per 2^20 elements (0.35 ms per rollout-step draw)
         self._buf = {}       # numel -> dict(ring=[pinned float32 vectors], uploaded=[event or None], turn)
-        self._pending = None  # dict(shape, state_in, future -> state_out, buf, slot)
+        self._chain = []      # speculative requests in stream order: dict(shape, numel, state_in, link, future, buf, rec, slot)
         self.hits = self.misses = 0
         self.checked = False  # the one-time self-check against torch's own exponential_ (see _self_check)
         self.trusted = True
@@ -423,11 +431,11 @@ class HostExponential:
         if rec is None:
             pin = torch.cuda.is_available()
             rec = self._buf[numel] = dict(ring=[torch.empty(numel, dtype=torch.float32, pin_memory=pin) for _ in range(self.RING)],
-                                          uploaded=[None] * self.RING, turn=0)
-            if len(self._buf) > 8:  # shapes come and go (worker counts change): keep the cache small -- but never the ring a
-                busy = self._pending["numel"] if self._pending is not None else None  # pending speculation is writing into
+                                          scratch=[None] * self.RING, uploaded=[None] * self.RING, turn=0)
+            if len(self._buf) > 8:  # shapes come and go (worker counts change): keep the cache small -- but never a ring the
+                busy = {e["numel"] for e in self._chain}  # pending chain is writing into
                 for key in list(self._buf):
-                    if key != numel and key != busy:
+                    if key != numel and key not in busy:
                         self._buf.pop(key)
                         break
         rec["turn"] = slot = (rec["turn"] + 1) % self.RING
@@ -465,12 +473,50 @@ class HostExponential:
             warnings.warn("rlgym_ppo_amd: librlppo's host exponential_ does not reproduce this torch build's CPU stream; "
                           "falling back to torch.empty(shape).exponential_(1) for the rollout noise (slower, same results)")
 
-    def _speculate(self, shape, numel, state_in):
-        rec, slot = self._buffer(numel)
-        buf = rec["ring"][slot]
-        st = state_in.clone()
-        fut = _pool("noise", 1).submit(self._draw_into, st, buf, numel)
-        self._pending = dict(shape=tuple(shape), numel=numel, state_in=state_in, future=fut, buf=buf, rec=rec, slot=slot)
+    @property
+    def lookahead(self):
+        return self.depth > 0
+
+    @lookahead.setter
+    def lookahead(self, on):
+        self.depth = (self.depth or self.DEPTH) if on else 0
+
+    def _chained_draw(self, e, prev_link):
+        """Helper thread: one C call (waits for the predecessor's stream phase inside the library)."""
+        N.check(N.lib().rlppo_torch_cpu_exponential_chained(
+            ctypes.c_void_p(e["state_in"].data_ptr()) if prev_link is None else None, e["state_bytes"], e["numel"], 1.0,
+            ctypes.c_void_p(e["buf"].data_ptr()), ctypes.c_void_p(e["words"].ctypes.data),
+            ctypes.c_void_p(prev_link.ctypes.data) if prev_link is not None else None, ctypes.c_void_p(e["link"].ctypes.data)))
+
+    def _speculate(self, shape, numel, state_now):
+        """Top the chain up to `depth` requests of `shape`; the first one starts from state_now (the generator's state)."""
+        if self._chain and self._chain[-1]["shape"] != shape:
+            self._drain()
+        nbytes = state_now.numel()
+        while len(self._chain) < self.depth:
+            rec, slot = self._buffer(numel)
+            if rec["scratch"][slot] is None:  # (words, link block) of this ring slot
+                rec["scratch"][slot] = (np.empty(2 * numel + 8, np.uint32), np.zeros(N.EXP_LINK_HEADER + nbytes, np.uint8))
+            words, link = rec["scratch"][slot]
+            link[:4] = 0
+            prev = self._chain[-1] if self._chain else None
+            e = dict(shape=shape, numel=numel, state_bytes=nbytes, state_in=state_now if prev is None else None, prev=prev, link=link,
+                     words=words, buf=rec["ring"][slot], rec=rec, slot=slot)
+            e["future"] = _pool("noise", self.workers).submit(self._chained_draw, e, prev["link"] if prev is not None else None)
+            self._chain.append(e)
+
+    def _drain(self):
+        """Drop the chain: wait for everything in flight first (its buffers go back into rotation)."""
+        for e in self._chain:
+            try:
+                e["future"].result()
+            except Exception:  # noqa: BLE001 -- a failed speculation is simply not used
+                pass
+        self._chain = []
+
+    @staticmethod
+    def _link_state(e):
+        return torch.from_numpy(e["link"][N.EXP_LINK_HEADER:])
 
     def draw(self, shape, device=None):
         """Exp(1) noise of `shape`: a view of a pinned ring buffer, or -- with `device` -- its asynchronous upload on the current
@@ -487,14 +533,29 @@ class HostExponential:
             out = torch.empty(shape).exponential_(1)
             return out if device is None else out.to(device)
         state = torch.get_rng_state()
-        p, self._pending = self._pending, None
-        if p is not None and p["shape"] == shape and torch.equal(p["state_in"], state):
-            after = p["future"].result()
-            buf, rec, slot = p["buf"], p["rec"], p["slot"]
-            self.hits += 1
-        else:
-            if p is not None:
-                p["future"].result()  # let the helper finish before its buffer can be handed out again
+        head = self._chain[0] if self._chain else None
+        served = False
+        if head is not None and head["shape"] == shape:
+            # the state this request was drawn from: given for the first of a chain, else what its predecessor (already served:
+            # the generator was set to exactly that) left behind
+            ok = torch.equal(head["state_in"], state) if head["state_in"] is not None else torch.equal(head["prev_state"], state)
+            if ok:
+                try:
+                    head["future"].result()
+                    served = True
+                except Exception:  # noqa: BLE001 -- fall back to the draw on the spot
+                    served = False
+            if served:
+                self._chain.pop(0)
+                after = self._link_state(head).clone()
+                buf, rec, slot = head["buf"], head["rec"], head["slot"]
+                if self._chain:
+                    self._chain[0]["prev_state"] = after  # what the new head must find the generator in
+                    self._chain[0]["prev"] = None
+                self.hits += 1
+        if not served:
+            if self._chain:
+                self._drain()  # somebody else used the generator, or the shape changed: nothing drawn ahead is valid
             rec, slot = self._buffer(numel)
             buf = rec["ring"][slot]
             after = self._draw_into(state.clone(), buf, numel)
@@ -506,7 +567,7 @@ class HostExponential:
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream(out.device))
             rec["uploaded"][slot] = ev
-        if self.lookahead and numel >= self.LOOKAHEAD_MIN:
+        if self.depth > 0 and numel >= self.LOOKAHEAD_MIN:
             self._speculate(shape, numel, after)
         return out
 

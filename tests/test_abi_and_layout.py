@@ -267,6 +267,56 @@ def test_host_exponential_is_torch_exponential_bit_for_bit():
     assert engine._HOST_EXP.hits >= 3 and engine._HOST_EXP.misses >= 4   # both paths were exercised
 
 
+def test_host_exponential_split_and_chained_forms_reproduce_torch():
+    """[r3] The draw as two calls (stream phase / transform) and as chained one-call draws on two threads -- a call waits inside the
+    library for its predecessor's stream phase, takes the state it left, publishes its own -- give torch's values and torch's
+    generator states, draw after draw (engine.HostExponential pipelines consecutive rollout steps this way)."""
+    import threading
+    import torch
+    from rlgym_ppo_amd import _native as N
+    L = N.lib()
+    P = lambda a: ctypes.c_void_p(a.ctypes.data)
+    n, draws = 90 * 1500 + 7, 5
+    torch.manual_seed(31)
+    st0 = torch.get_rng_state().numpy().copy()
+    want, states = [], []
+    for _ in range(draws):
+        want.append(torch.empty(n).exponential_(1).numpy())
+        states.append(torch.get_rng_state().numpy().copy())
+    # two calls
+    st = st0.copy()
+    words, out = np.empty(2 * n + 8, np.uint32), np.empty(n, np.float32)
+    for k in range(draws):
+        N.check(L.rlppo_torch_cpu_exponential_words(P(st), st.size, n, P(words)))
+        N.check(L.rlppo_exponential_from_words(P(words), n, 1.0, P(out)))
+        assert np.array_equal(out, want[k]) and np.array_equal(st, states[k])
+    # chained: every draw on its own thread, started in REVERSE order so that every call really waits for its predecessor
+    links = [np.zeros(N.EXP_LINK_HEADER + st0.size, np.uint8) for _ in range(draws)]
+    outs = [np.empty(n, np.float32) for _ in range(draws)]
+    scratch = [np.empty(2 * n + 8, np.uint32) for _ in range(draws)]
+    rcs = [None] * draws
+
+    def run(k):
+        rcs[k] = L.rlppo_torch_cpu_exponential_chained(P(st0) if k == 0 else None, st0.size, n, 1.0, P(outs[k]), P(scratch[k]),
+                                                       P(links[k - 1]) if k else None, P(links[k]))
+    ths = [threading.Thread(target=run, args=(k,)) for k in reversed(range(draws))]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    assert rcs == [0] * draws
+    for k in range(draws):
+        assert np.array_equal(outs[k], want[k]) and np.array_equal(links[k][N.EXP_LINK_HEADER:], states[k]) and links[k][0] == 1
+    assert np.array_equal(st0, torch.manual_seed(31) and torch.get_rng_state().numpy())   # the start state was not modified
+    # a failed predecessor is passed down the chain instead of hanging it
+    bad = np.zeros(N.EXP_LINK_HEADER + st0.size, np.uint8)
+    bad[:4] = np.frombuffer(np.int32(-1).tobytes(), np.uint8)
+    nxt = np.zeros_like(bad)
+    assert L.rlppo_torch_cpu_exponential_chained(None, st0.size, n, 1.0, P(outs[0]), P(scratch[0]), P(bad), P(nxt)) != 0
+    assert np.frombuffer(nxt[:4].tobytes(), np.int32)[0] == -1
+    assert L.rlppo_torch_cpu_exponential_chained(None, st0.size, n, 1.0, P(outs[0]), P(scratch[0]), None, P(nxt)) != 0   # no start state
+
+
 def test_host_exponential_self_check_falls_back_to_torch(monkeypatch):
     """HostExponential verifies ONCE per process that librlppo's host exponential_ reproduces this torch build's stream (4096
     values and the generator state); a mismatch (another torch build) must not change the observable stream: torch's own
