@@ -306,8 +306,8 @@ def rollout_bench(learner):
                 note="one step = observations on the host -> actions + log-probs on the host through rlppo_discrete_step (pad + MLP + "
                      "softmax + clamp + argmax(p/q) + log p in ONE launch that stores its results straight into pinned host memory; "
                      "round 2: pad + 4 GEMM launches + sampling + two D2H copies).  host_noise = the bit-exact action parity mode: "
-                     "Exp(1) noise of torch's CPU generator stream (librlppo's host implementation of torch's exponential_, drawn one "
-                     "step ahead on a helper thread: ~0.36 ms per draw is the floor of that mode); resident_noise = noise already in "
+                     "Exp(1) noise of torch's CPU generator stream (librlppo's host implementation of torch's exponential_, three draws "
+                     "in flight over two helper threads, each chained to its predecessor's stream phase inside the library); resident_noise = noise already in "
                      "HBM, observations in pageable / page-locked host memory; ms_fused_launch = the launch alone (device time); "
                      "us_per_get_action_N_obs = wall clock of one get_action call of N host observations in the bit-exact mode (one "
                      "hipGraph replay of the same kernel reading and writing pinned host memory)")
