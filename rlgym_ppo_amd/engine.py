@@ -393,11 +393,11 @@ class HostExponential:
     in the reference's CPU rollout (discrete_policy.py:59), which is what makes a seeded run pick the reference's action
     indices -- produced by librlppo's host implementation (rlppo_torch_cpu_exponential: bit-identical values and generator
     advance, pinned by tests against torch itself; AVX-512 / AVX2 stream phase + a vectorised logarithm certified element by
-    element against the float32 rounding, libm where it cannot be, instead of torch's serial 12-26 ns per number) and drawn one
-    request AHEAD on a helper thread.
+    element against the float32 rounding, libm where it cannot be, instead of torch's serial 12-26 ns per number) and drawn
+    AHEAD on helper threads.
 
     The look-ahead is speculative and transparent, the contract of LegacyPermutation: after a draw of `shape` the helpers draw
-    the same shape again -- `depth` requests deep [r3: a chain of two, was one] -- from the states the generator WILL be in if
+    the same shape again -- `depth` requests deep [r3: a chain of three, was one] -- from the states the generator WILL be in if
     nobody else uses it, into pinned buffers; a request is served from the head of the chain only if the shape matches and
     torch's global generator is in exactly the predicted state, and then the generator is advanced to the state after that
     draw -- otherwise the chain is dropped and the draw happens on the spot.  The observable stream never differs from torch's.
