@@ -488,6 +488,15 @@ class HostExponential:
             ctypes.c_void_p(e["buf"].data_ptr()), ctypes.c_void_p(e["words"].ctypes.data),
             ctypes.c_void_p(prev_link.ctypes.data) if prev_link is not None else None, ctypes.c_void_p(e["link"].ctypes.data)))
 
+    def _guarded_draw(self, e, prev_link):
+        """Whatever goes wrong on the helper thread, the successor (spinning inside the library on this request's link block) is
+        released: a failed link passes the failure down the chain and draw() falls back to drawing on the spot."""
+        try:
+            self._chained_draw(e, prev_link)
+        except BaseException:
+            e["link"][:4] = np.frombuffer(np.int32(-1).tobytes(), np.uint8)
+            raise
+
     def _speculate(self, shape, numel, state_now):
         """Top the chain up to `depth` requests of `shape`; the first one starts from state_now (the generator's state)."""
         if self._chain and self._chain[-1]["shape"] != shape:
@@ -502,7 +511,7 @@ class HostExponential:
             prev = self._chain[-1] if self._chain else None
             e = dict(shape=shape, numel=numel, state_bytes=nbytes, state_in=state_now if prev is None else None, prev=prev, link=link,
                      words=words, buf=rec["ring"][slot], rec=rec, slot=slot)
-            e["future"] = _pool("noise", self.workers).submit(self._chained_draw, e, prev["link"] if prev is not None else None)
+            e["future"] = _pool("noise", self.workers).submit(self._guarded_draw, e, prev["link"] if prev is not None else None)
             self._chain.append(e)
 
     def _drain(self):

@@ -317,6 +317,31 @@ def test_host_exponential_split_and_chained_forms_reproduce_torch():
     assert L.rlppo_torch_cpu_exponential_chained(None, st0.size, n, 1.0, P(outs[0]), P(scratch[0]), None, P(nxt)) != 0   # no start state
 
 
+def test_host_exponential_survives_a_failing_look_ahead(monkeypatch):
+    """A speculative draw that fails on its helper thread (here: every second one raises) must not change the observable stream:
+    the request is drawn on the spot from the generator's real state, the chain is rebuilt, values and final state are torch's."""
+    import torch
+    from rlgym_ppo_amd import engine
+    shape = (900, 90)   # above LOOKAHEAD_MIN: drawn ahead
+    torch.manual_seed(44)
+    want = [torch.empty(shape).exponential_(1) for _ in range(9)]
+    s_want = torch.get_rng_state()
+    h = engine.HostExponential()
+    real, calls = h._chained_draw, [0]
+
+    def flaky(e, prev_link):
+        calls[0] += 1
+        if calls[0] % 2 == 0:
+            raise RuntimeError("injected failure")   # (before the library was even called: the guard must release the successor)
+        return real(e, prev_link)
+    monkeypatch.setattr(h, "_chained_draw", flaky)
+    torch.manual_seed(44)
+    got = [h.draw(shape).clone() for _ in range(9)]
+    h._drain()
+    assert all(torch.equal(a, b) for a, b in zip(want, got)) and torch.equal(s_want, torch.get_rng_state())
+    assert h.hits >= 1 and h.misses >= 2 and calls[0] >= 6
+
+
 def test_host_exponential_self_check_falls_back_to_torch(monkeypatch):
     """HostExponential verifies ONCE per process that librlppo's host exponential_ reproduces this torch build's stream (4096
     values and the generator state); a mismatch (another torch build) must not change the observable stream: torch's own
