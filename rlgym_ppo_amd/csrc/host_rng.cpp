@@ -628,7 +628,10 @@ extern "C" int rlppo_torch_cpu_exponential_chained(const void *state, int64_t st
         uint64_t spins = 0;
         while (ready_of(link_in)->load(std::memory_order_acquire) == 0) {
             _mm_pause();
-            if (++spins > (1ull << 33)) return RLPPO_ERR_ARG;  // (minutes: the predecessor died)
+            if (++spins > (1ull << 28)) {  // ~10 s: the predecessor died without publishing (it normally takes 0.1 ms)
+                ready_of(link_out)->store(-1, std::memory_order_release);
+                return RLPPO_ERR_ARG;
+            }
         }
         if (ready_of(link_in)->load(std::memory_order_acquire) < 0) {  // the predecessor failed: pass the failure on
             ready_of(link_out)->store(-1, std::memory_order_release);
