@@ -547,7 +547,8 @@ class HostExponential:
         if head is not None and head["shape"] == shape:
             # the state this request was drawn from: given for the first of a chain, else what its predecessor (already served:
             # the generator was set to exactly that) left behind
-            ok = torch.equal(head["state_in"], state) if head["state_in"] is not None else torch.equal(head["prev_state"], state)
+            drawn_from = head["state_in"] if head["state_in"] is not None else head.get("prev_state")
+            ok = drawn_from is not None and torch.equal(drawn_from, state)
             if ok:
                 try:
                     head["future"].result()
