@@ -889,17 +889,20 @@ def test_fused_gather_and_paired_launches_are_bitwise_neutral(L):
     idx = rs.randint(0, n, mb)
     idx[:3] = [n - 1, 0, n - 1]
     runs = {}
-    forms = dict(fused=(1, 2, 0), separate_gather=(0, 2, 0), two_chains=(1, 0, 0), round2=(0, 0, 0), folded_value_head=(1, 2, 1))
-    for key, (k26, k29, k32) in forms.items():
+    forms = dict(fused=(1, 2, 0, 1), separate_gather=(0, 2, 0, 1), two_chains=(1, 0, 0, 1), round2=(0, 0, 0, 1), stacked_pairs=(1, 2, 0, 0),
+                 folded_value_head=(1, 2, 1, 1))
+    for key, (k26, k29, k32, k33) in forms.items():
         check(L, L.rlppo_dbg_set(26, k26))
         check(L, L.rlppo_dbg_set(29, k29))   # paired launches (policy + critic layer in one grid) against one chain per network
         check(L, L.rlppo_dbg_set(32, k32))   # the critic's output layer inside the last hidden layer's forward epilogue
+        check(L, L.rlppo_dbg_set(33, k33))   # the two products' tiles interleaved in the grid / the second stacked behind the first
         try:
             runs[key] = run_minibatch(L, "discrete", pol, val, obs, acts, old, tgt, adv, idx, 0.2, 0.005, 0.25)
         finally:
             check(L, L.rlppo_dbg_set(26, 1))
             check(L, L.rlppo_dbg_set(29, 1))
             check(L, L.rlppo_dbg_set(32, 1))
+            check(L, L.rlppo_dbg_set(33, 1))
     gp0, gv0, st0 = runs["fused"]
     for key, (gp, gv, st) in runs.items():
         if key == "folded_value_head":
