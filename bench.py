@@ -192,8 +192,10 @@ def pmc_traffic_for(kernel_label):
 
 
 def gae_traffic():
-    try:  # tools/prof_gae.py under rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, summarised by tools/pmc_traffic.py
-        for tag in ("r03", "r02"):
+    """HBM bytes per scan from the committed PMC passes over tools/prof_gae.py (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE),
+    newest round first; round 4's passes rotate over GAE_SETS buffer sets exactly as the timed region below does."""
+    try:
+        for tag in ("r04", "r03", "r02"):
             p = os.path.join(ROOT, "profiles", tag + "_gae_traffic.json")
             if os.path.exists(p):
                 return round(json.load(open(p))["rlppo::gae_lookback_kernel<false>"]["hbm_bytes"])
@@ -201,11 +203,14 @@ def gae_traffic():
         return None
 
 
-def gae_bench():
-    """BASELINE configs[2]: 8192 trajectories x 256 steps, gamma .99 lambda .95, return_std 1.7, fp32, seed 0."""
-    from rlgym_ppo_amd.util import torch_functions
-    rs = np.random.RandomState(0)
-    n_seg, seg = 8192, 256
+GAE_SETS = 10  # buffer sets the cold measurement rotates over: 10 x 58.7 MB of inputs + outputs = 587 MB between two uses of a
+               # line, against 256 MiB of Infinity Cache (MI355X_MICROARCH.md) + 8 x 4 MiB of L2: every timed scan streams from HBM
+
+
+def gae_inputs(seed=0, n_seg=8192, seg=256):
+    """BASELINE configs[2] / SURVEY 8(d): 8192 segments x 256 steps, every segment ends in done or truncated (p = 0.5 each), iid
+    mid-segment dones p = 0.005, seed 0."""
+    rs = np.random.RandomState(seed)
     n = n_seg * seg
     rews = rs.randn(n).astype(np.float32)
     values = rs.randn(n + 1).astype(np.float32)
@@ -216,41 +221,102 @@ def gae_bench():
     dones[ends[is_done]] = 1
     dones[ends[~is_done]] = 0
     trunc[ends[~is_done]] = 1
-    d = lambda x: torch.as_tensor(x).cuda()
-    R, D, T, V = d(rews), d(dones), d(trunc), d(values)
+    return rews, dones, trunc, values
+
+
+def gae_sets(n_sets=GAE_SETS, host=None):
+    """n_sets independent copies of the configs[2] inputs AND outputs in HBM (distinct allocations) + one launch closure per set.
+    Returns (launchers, sets, n): launchers[i]() enqueues one rlppo_gae scan over set i on torch's current stream."""
     from rlgym_ppo_amd import _native as N
-    # the timed region is the entry point itself on preallocated outputs: torch_functions.gae_device allocates three output
-    # tensors per call (~15 us of Python on the host, about the duration of the scan it launches -- a host-bound measurement)
     L = N.lib()
-    vt, adv, ret = (torch.empty(n, device="cuda") for _ in range(3))
-    ws = torch.empty(int(L.rlppo_gae_workspace_bytes(n)), dtype=torch.uint8, device="cuda")
+    rews, dones, trunc, values = host if host is not None else gae_inputs()
+    n = rews.shape[0]
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-    cargs = [ctypes.c_void_p(t.data_ptr()) for t in (R, D, T, V)] + [n, 0.99, 0.95, float(np.float32(1.7))] + \
-            [ctypes.c_void_p(t.data_ptr()) for t in (vt, adv, ret, ws)] + [ws.numel()]
-    fn = lambda: N.check(L.rlppo_gae(st, *cargs))
-    fn()
+    ws = torch.zeros(int(L.rlppo_gae_workspace_bytes(n)), dtype=torch.uint8, device="cuda")
+    sets, launchers = [], []
+    for _ in range(n_sets):
+        ins = [torch.as_tensor(x).cuda() for x in (rews, dones, trunc, values)]
+        outs = [torch.empty(n, device="cuda") for _ in range(3)]
+        cargs = [ctypes.c_void_p(t.data_ptr()) for t in ins] + [n, 0.99, 0.95, float(np.float32(1.7))] + \
+                [ctypes.c_void_p(t.data_ptr()) for t in outs + [ws]] + [ws.numel()]
+        sets.append((ins, outs))
+        launchers.append(lambda cargs=cargs: N.check(L.rlppo_gae(st, *cargs)))
+    return launchers, sets, n
+
+
+def time_rotating(fns, cycles, warm_cycles=1):
+    """Average device time per call in ms of the launches fns[0], fns[1], ... taken round-robin, `cycles` times through the
+    list, HIP events on torch's current stream.  With every fn working on its own buffer set, a set is touched once per cycle."""
+    for _ in range(warm_cycles):
+        for fn in fns:
+            fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(cycles):
+        for fn in fns:
+            fn()
+    e1.record()
+    e1.synchronize()
+    return e0.elapsed_time(e1) / (cycles * len(fns))
+
+
+def gae_bench():
+    """BASELINE configs[2]: 8192 trajectories x 256 steps, gamma .99 lambda .95, return_std 1.7, fp32, seed 0.
+
+    COLD (the roofline number): the timed scans rotate over GAE_SETS independent input + output sets, so that no scan finds its
+    lines in the Infinity Cache or in L2 -- bytes / time is a rate against HBM.  HOT (`hot_frac`, rounds 1-3's number): the same
+    set scanned back to back, its 58.7 MB resident in the 256 MiB memory-side cache.  The device-copy probes beside them move
+    the same number of bytes (29.4 MB read + 29.4 MB written) cold and hot: the HBM floor of a launch of this size."""
+    from rlgym_ppo_amd import _native as N
+    from rlgym_ppo_amd.util import torch_functions
+    host = gae_inputs()
+    fns, sets, n = gae_sets(GAE_SETS, host)
+    L = N.lib()
+    for fn in fns:
+        fn()
+    (R, D, T, V), outs0 = sets[0]
     chk = torch_functions.gae_device(R, D, T, V, 0.99, 0.95, 1.7)
-    assert all(torch.equal(a, b) for a, b in zip((vt, adv, ret), chk))
-    time_region(fn, 1, warm_s=0.3)  # clock ramp
-    # A/B of the two implementations, interleaved in one process (cdna_hip_programming.md rule 24)
-    times = {0: [], 1: []}
+    for _, outs in sets:  # every set holds the same inputs: every scan of the rotation is checked against the product entry point
+        assert all(torch.equal(a, b) for a, b in zip(outs, chk))
+    time_region(fns[0], 1, warm_s=0.3)  # clock ramp
+    # the default (single launch, rows form) against the 8-consecutive-steps form of rounds 1-3 and the two-launch form, hot and
+    # cold, interleaved in one process (cdna_hip_programming.md rule 24)
+    hot, cold = {0: [], 1: [], 2: []}, {0: [], 1: [], 2: []}
     for _ in range(5):
-        for algo in (0, 1):
-            N.check(N.lib().rlppo_dbg_set(1, algo))
-            times[algo].append(time_region(fn, 20, warm=2))
-    N.check(N.lib().rlppo_dbg_set(1, 1))
-    ms = float(np.median(times[1]))
-    ms_two = float(np.median(times[0]))
+        for algo in (0, 1, 2):
+            N.check(L.rlppo_dbg_set(1, algo))
+            hot[algo].append(time_region(fns[0], 20, warm=2))
+            cold[algo].append(time_rotating(fns, 3))
+    N.check(L.rlppo_dbg_set(1, 2))
+    ms_hot, ms_cold = float(np.median(hot[2])), float(np.median(cold[2]))
+    # the same bytes through a device copy, cold (rotating) and hot
+    nb = 28 * n // 2
+    pairs = [(torch.empty(nb, dtype=torch.uint8, device="cuda"), torch.empty(nb, dtype=torch.uint8, device="cuda")) for _ in range(GAE_SETS)]
+    cps = [lambda a=a, b=b: b.copy_(a) for a, b in pairs]
+    cp_cold = float(np.median([time_rotating(cps, 3) for _ in range(5)]))
+    cp_hot = float(np.median([time_region(cps[0], 20, warm=2) for _ in range(5)]))
+    del pairs, cps
     alg_bytes = 28 * n
-    out = dict(workload="8192 trajectories x 256 steps fp32 (BASELINE configs[2])", steps=n, ms_per_scan=round(ms, 5),
-               steps_per_s=round(n / ms * 1e3), algorithm="single launch: chunk scan + raw look-ahead fast path, decoupled look-back with per-launch tags otherwise (no memset)",
-               ms_per_scan_two_launch=round(ms_two, 5),
-               roofline=dict(bound="hbm", achieved=round(alg_bytes / ms / 1e6, 1), peak=HBM_PEAK_GBS, unit="GB/s",
-                             frac=round(alg_bytes / ms / 1e6 / HBM_PEAK_GBS, 4), traffic=gae_traffic(), algorithmic_bytes=alg_bytes,
-                             note="achieved = 28 algorithmic B/step x steps / time per scan (HIP events around 20 back-to-back scans, "
-                                  "median of 5 rounds)"))
-    # CPU side: the C port and the interpreter-bound Python form (the reference runs a Python loop) on bounded samples
+    traffic = gae_traffic()
+    frac = lambda ms: round(alg_bytes / ms / 1e6 / HBM_PEAK_GBS, 4)
+    log("gae: cold %.2f us (%.3f of 8 TB/s), hot %.2f us (%.3f); 8-consecutive-steps form cold %.2f / hot %.2f us; two-launch form cold %.2f / hot %.2f us; device copy of the same "
+        "bytes cold %.2f us (%.3f) / hot %.2f us (%.3f).  cold = %d rotating input+output sets (%.0f MB between two uses of a line), "
+        "HIP events around 3 x %d back-to-back scans, median of 5 rounds; hot = one set scanned 20 x back to back"
+        % (ms_cold * 1e3, frac(ms_cold), ms_hot * 1e3, frac(ms_hot), float(np.median(cold[1])) * 1e3, float(np.median(hot[1])) * 1e3,
+           float(np.median(cold[0])) * 1e3, float(np.median(hot[0])) * 1e3,
+           cp_cold * 1e3, frac(cp_cold), cp_hot * 1e3, frac(cp_hot), GAE_SETS, GAE_SETS * alg_bytes / 1e6, GAE_SETS))
+    out = dict(workload="configs[2]: 8192 x 256 steps f32", steps=n, us_per_scan=round(ms_cold * 1e3, 2), us_per_scan_hot=round(ms_hot * 1e3, 2),
+               us_r3_form=round(float(np.median(cold[1])) * 1e3, 2), us_two_launch_form=round(float(np.median(cold[0])) * 1e3, 2), rotating_sets=GAE_SETS,
+               us_copy_same_bytes=round(cp_cold * 1e3, 2), us_copy_same_bytes_hot=round(cp_hot * 1e3, 2),
+               steps_per_s=round(n / ms_cold * 1e3),
+               roofline=dict(bound="hbm", achieved=round(alg_bytes / ms_cold / 1e6, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=frac(ms_cold),
+                             traffic=traffic, algorithmic_bytes=alg_bytes, hot_frac=frac(ms_hot), copy_frac=frac(cp_cold)))
+    del fns, sets
+    torch.cuda.empty_cache()
+    # CPU side: the C port and the interpreter-bound Python form (the reference runs a Python loop) on bounded samples, 1 thread
     from oracle import gae as ogae
+    rews, dones, trunc, values = host
     t = time.perf_counter()
     ogae.gae(rews, dones, trunc, values, 0.99, 0.95, 1.7, "f64")
     out["cpu_c_port_steps_per_s"] = round(n / (time.perf_counter() - t))
@@ -258,7 +324,7 @@ def gae_bench():
     t = time.perf_counter()
     ogae.gae_python(rews[:m], dones[:m], trunc[:m], values[:m + 1], 0.99, 0.95, 1.7)
     out["cpu_python_loop_steps_per_s"] = round(m / (time.perf_counter() - t))
-    out["cpu_sample"] = "C port: all 2,097,152 steps; Python-loop form: first 65,536 steps; 1 thread"
+    log("gae cpu: C port over all 2,097,152 steps, Python-loop form (what the reference runs) over the first 65,536 steps, 1 thread")
     return out
 
 

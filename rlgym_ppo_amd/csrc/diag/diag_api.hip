@@ -66,8 +66,13 @@ __global__ __launch_bounds__(256) void stream_floor_kernel(const float *__restri
     if (i >= n8) return;
     // shape 0: a thread owns 8 consecutive steps (two float4 at a 32-byte lane stride: the scan's shape); shape 1: a thread owns two
     // float4 groups 256 lanes apart, so that every wave-instruction moves 1 KiB of contiguous bytes
-    const long long base = shape ? (long long)blockIdx.x * 512 + threadIdx.x : 2 * i;
-    const long long step = shape ? 256 : 1;
+    // shapes 2 / 3 [r4]: lane-contiguous loads with 8-consecutive stores / the reverse (timing only: which half of the difference
+    // between shapes 0 and 1 belongs to the loads)
+    const bool lc = shape == 1 || shape == 2, sc = shape == 1 || shape == 3;
+    const long long base = lc ? (long long)blockIdx.x * 512 + threadIdx.x : 2 * i;
+    const long long step = lc ? 256 : 1;
+    const long long sbase = sc ? (long long)blockIdx.x * 512 + threadIdx.x : 2 * i;
+    const long long sstep = sc ? 256 : 1;
     const float4 *r4 = (const float4 *)r + base, *d4 = (const float4 *)d + base, *t4 = (const float4 *)t + base,
                  *v4 = (const float4 *)v + base;
     float4 a[2], b[2], c[2], e[2];
@@ -80,7 +85,7 @@ __global__ __launch_bounds__(256) void stream_floor_kernel(const float *__restri
         x.z = a[k].z + 0.99f * e[k].z * (1.f - b[k].z); x.w = a[k].w + 0.99f * e[k].w * (1.f - b[k].w);
         y.x = x.x * (1.f - c[k].x); y.y = x.y * (1.f - c[k].y); y.z = x.z * (1.f - c[k].z); y.w = x.w * (1.f - c[k].w);
         z.x = y.x + e[k].x; z.y = y.y + e[k].y; z.z = y.z + e[k].z; z.w = y.w + e[k].w;
-        ((float4 *)o0)[base + k * step] = x; ((float4 *)o1)[base + k * step] = y; ((float4 *)o2)[base + k * step] = z;
+        ((float4 *)o0)[sbase + k * sstep] = x; ((float4 *)o1)[sbase + k * sstep] = y; ((float4 *)o2)[sbase + k * sstep] = z;
     }
 }
 int launch_stream_floor(hipStream_t st, const float *r, const float *d, const float *t, const float *v, float *o0, float *o1,

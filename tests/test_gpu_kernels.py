@@ -287,17 +287,23 @@ def run_gae(L, rews, dones, trunc, values, gamma, lmbda, std):
     return vt.cpu().numpy(), adv.cpu().numpy(), ret.cpu().numpy()
 
 
-@pytest.fixture(params=[1, 0], ids=["lookback", "two_launch"], autouse=False)
+GAE_DEFAULT_FORM = 2
+
+
+@pytest.fixture(params=[2, 1, 0], ids=["rows", "lookback8", "two_launch"], autouse=False)
 def gae_algo(L, request):
-    """Both GAE implementations are held to the same checks: single-pass decoupled look-back (default) and the
-    two-launch summary + apply form."""
+    """All GAE implementations are held to the same checks: the single-pass decoupled look-back in its rows form (round 4's
+    default: lane-contiguous float4 rows, two interleaved wave scans) and in the 8-consecutive-steps-per-thread form of rounds
+    1-3, and the two-launch summary + apply form (what a stream capture gets)."""
     check(L, L.rlppo_dbg_set(1, request.param))
     yield request.param
-    check(L, L.rlppo_dbg_set(1, 1))
+    check(L, L.rlppo_dbg_set(1, GAE_DEFAULT_FORM))
 
 
-def test_gae_lookback_stress_repeated(L):
+@pytest.mark.parametrize("form", [2, 1], ids=["rows", "lookback8"])
+def test_gae_lookback_stress_repeated(L, form):
     # the look-back hand-off is timing dependent: repeat a many-chunk scan and demand bit-identical outputs every time
+    check(L, L.rlppo_dbg_set(1, form))
     rews, dones, trunc, values = synth_gae(8192, 256, seed=5, p_mid=0.0)
     dones[:] = 0
     trunc[:] = 0           # no trajectory ends at all: every chunk must chain through ALL chunks to its right
@@ -309,6 +315,28 @@ def test_gae_lookback_stress_repeated(L):
         again = run_gae(L, rews, dones, trunc, values, 0.999, 0.999, None)
         for a, b in zip(ref, again):
             assert np.array_equal(a, b)
+    check(L, L.rlppo_dbg_set(1, GAE_DEFAULT_FORM))
+
+
+def test_gae_forms_agree_bitwise_on_ragged_sizes(L):
+    """The rows form and the 8-consecutive form compose the same float64 maps in different association orders; both round once at
+    the store.  They agree to the last float32 bit or one ulp of it, on sizes that exercise the ragged tail of every row / lane
+    position (n mod 4, mod 256, mod 512, mod 2048 all non-zero) and the general look-back path (no trajectory end for long runs)."""
+    for n, p_mid in ((1, 0.0), (3, 0.0), (255, 0.01), (257, 0.0), (515, 0.02), (2047, 0.0), (2049, 0.0), (4099, 0.001), (70001, 0.0005), (300007, 0.0)):
+        rs = np.random.RandomState(n)
+        rews, values = rs.randn(n).astype(np.float32), rs.randn(n + 1).astype(np.float32)
+        dones = (rs.rand(n) < p_mid).astype(np.float32)
+        trunc = ((rs.rand(n) < p_mid) & (dones == 0)).astype(np.float32)
+        outs = {}
+        for form in (2, 1, 0):
+            check(L, L.rlppo_dbg_set(1, form))
+            outs[form] = run_gae(L, rews, dones, trunc, values, 0.995, 0.97, 1.3)
+        check(L, L.rlppo_dbg_set(1, GAE_DEFAULT_FORM))
+        o = ogae.gae(rews, dones, trunc, values, 0.995, 0.97, 1.3, "f64")
+        for k in range(3):
+            np.testing.assert_allclose(outs[2][k], np.asarray(o[k], np.float32), rtol=2e-6, atol=2e-6, err_msg=f"n={n} out {k}")
+            np.testing.assert_allclose(outs[2][k], outs[1][k], rtol=3e-7, atol=1e-6, err_msg=f"n={n} out {k}")
+            np.testing.assert_allclose(outs[2][k], outs[0][k], rtol=3e-7, atol=1e-6, err_msg=f"n={n} out {k}")
 
 
 def test_gae_golden_vectors(L, golden, gae_algo):
