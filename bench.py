@@ -148,45 +148,45 @@ def kernel_breakdown(learner):
     # layer shape: K = 107 observations, N = 90 actions).  The rates printed as `tflops` / `frac` are the algorithmic ones.
     f = lambda n, k: 2 * M * n * k
     shapes = [
-        ("gemm_nt fwd L0 %d->256 +bitmask (x2 nets)" % K0, 2, ntb(A0, K0, C256, 256, 256, K0, 1), f(256, K0), f(256, OBS)),
-        ("gemm_nt fwd hidden 256->256 +bitmask (x4)", 4, ntb(A256, 256, C256, 256, 256, 256, 1), f(256, 256), f(256, 256)),
-        ("gemm_nt fwd head 256->96", 1, nt(A256, 256, 256, C96, 96, 96, 256, 0), f(96, 256), f(ACT, 256)),
-        ("gemm_nt dX hidden 256->256 bitmask (x4)", 4, ntb(A256, 256, C256, 256, 256, 256, 3), f(256, 256), f(256, 256)),
-        ("gemm_nt dX head 96->256 bitmask", 1, ntb(A96, 96, C256, 256, 256, 96, 3), f(256, 96), f(256, ACT)),
-        ("gemm_tn dW hidden 256x256 (x4)", 4, tn(A256, 256, A256b, 256, 256, 256), f(256, 256), f(256, 256)),
-        ("gemm_tn dW L0 256x107 (x2), 128x112 tiles", 2, tn(A256, 256, A0, K0, 256, 107), f(256, K0), f(256, OBS)),
-        ("gemm_tn dW head 90x256, 96x128 tiles", 1, tn(A96, 96, A256, 256, 90, 256), f(96, 256), f(ACT, 256)),
+        ("fwd L0 %d->256" % K0, 2, ntb(A0, K0, C256, 256, 256, K0, 1), f(256, K0), f(256, OBS)),
+        ("fwd hidden 256->256", 4, ntb(A256, 256, C256, 256, 256, 256, 1), f(256, 256), f(256, 256)),
+        ("fwd head 256->96", 1, nt(A256, 256, 256, C96, 96, 96, 256, 0), f(96, 256), f(ACT, 256)),
+        ("dX hidden 256->256", 4, ntb(A256, 256, C256, 256, 256, 256, 3), f(256, 256), f(256, 256)),
+        ("dX head 96->256", 1, ntb(A96, 96, C256, 256, 256, 96, 3), f(256, 96), f(256, ACT)),
+        ("dW hidden 256x256", 4, tn(A256, 256, A256b, 256, 256, 256), f(256, 256), f(256, 256)),
+        ("dW L0 256x107", 2, tn(A256, 256, A0, K0, 256, 107), f(256, K0), f(256, OBS)),
+        ("dW head 90x256", 1, tn(A96, 96, A256, 256, 90, 256), f(96, 256), f(ACT, 256)),
     ]
     rows = []
     for name, count, fn, flop_exec, flop in shapes:
         ms = time_region(fn, 20, warm_s=0.3)
-        rows.append(dict(kernel=name, rows_per_launch=M, launches_per_minibatch=count, ms_per_launch=round(ms, 4),
-                         gflop_per_launch=round(flop / 1e9, 3), tflops=round(flop / ms / 1e9, 2),
-                         frac=round(flop / ms / 1e9 / MFMA_F32_PEAK_TF, 4),
-                         executed_gflop_per_launch=round(flop_exec / 1e9, 3), executed_tflops=round(flop_exec / ms / 1e9, 2)))
-    dominant = max(rows, key=lambda r: r["launches_per_minibatch"] * r["ms_per_launch"])
-    return rows, dominant
+        # compact keys (the driver keeps ~12 KB of the line): n = launches per pass, ms = per launch, tflops / frac on ALGORITHMIC flop
+        # (K = 107, N = 90), exec_tflops on the padded tile shape the kernel multiplies
+        rows.append(dict(kernel=name, n=count, ms=round(ms, 4), gflop=round(flop / 1e9, 2), tflops=round(flop / ms / 1e9, 1),
+                         frac=round(flop / ms / 1e9 / MFMA_F32_PEAK_TF, 3), exec_tflops=round(flop_exec / ms / 1e9, 1)))
+    dominant = max(rows, key=lambda r: r["n"] * r["ms"])
+    return rows, dominant, M
 
 
-TRAFFIC_JSON = "r03_traffic.json"  # tools/pmc_traffic.py output of the committed PMC passes (tools/round_profile.sh)
+TRAFFIC_JSON = "r04_traffic.json" if os.path.exists(os.path.join(ROOT, "profiles", "r04_traffic.json")) else "r03_traffic.json"  # tools/pmc_traffic.py output of the committed PMC passes (tools/round_profile.sh)
 
 
 def pmc_traffic_for(kernel_label):
     """HBM bytes per launch of the dominant kernel, from the committed PMC passes (bench.py cannot run rocprofv3 on itself)."""
     path = os.path.join(ROOT, "profiles", TRAFFIC_JSON)
-    key = {"gemm_tn dW hidden 256x256 (x4)": "rlppo::gemm_tn_dma_kernel<32, 4, 4, 2, false>",
-           "gemm_tn dW L0 256x107 (x2), 128x112 tiles": "rlppo::gemm_tn_dma_kernel<32, 2, 7, 4, false>",
-           "gemm_tn dW head 90x256, 96x128 tiles": "rlppo::gemm_tn_dma_kernel<32, 3, 4, 2, false>",
-           "gemm_nt fwd hidden 256->256 +bitmask (x4)": "rlppo::gemm_nt_dma_kernel<8, 1, 16, true, false> {fwd hidden 256->256}",
-           "gemm_nt fwd L0 112->256 +bitmask (x2 nets)": "rlppo::gemm_nt_dma_kernel<8, 1, 16, true, false> {fwd L0 112->256}",
-           "gemm_nt fwd head 256->96": "rlppo::gemm_nt_dma_kernel<6, 0, 16, false, false>",
-           "gemm_nt dX hidden 256->256 bitmask (x4)": "rlppo::gemm_nt_dma_kernel<8, 3, 16, true, false> {dX hidden 256->256}",
-           "gemm_nt dX head 96->256 bitmask": "rlppo::gemm_nt_dma_kernel<8, 3, 16, true, false> {dX head 96->256}"}.get(kernel_label)
+    key = {"dW hidden 256x256": "rlppo::gemm_tn_dma_kernel<32, 4, 4, 2, false>",
+           "dW L0 256x107": "rlppo::gemm_tn_dma_kernel<32, 2, 7, 4, false>",
+           "dW head 90x256": "rlppo::gemm_tn_dma_kernel<32, 3, 4, 2, false>",
+           "fwd hidden 256->256": "rlppo::gemm_nt_dma_kernel<8, 1, 16, true, false> {fwd hidden 256->256}",
+           "fwd L0 112->256": "rlppo::gemm_nt_dma_kernel<8, 1, 16, true, false> {fwd L0 112->256}",
+           "fwd head 256->96": "rlppo::gemm_nt_dma_kernel<6, 0, 16, false, false>",
+           "dX hidden 256->256": "rlppo::gemm_nt_dma_kernel<8, 3, 16, true, false> {dX hidden 256->256}",
+           "dX head 96->256": "rlppo::gemm_nt_dma_kernel<8, 3, 16, true, false> {dX head 96->256}"}.get(kernel_label)
     try:
         # tools/prof_kernels.py launches the same shapes as kernel_breakdown (M = 524,288 rows); tools/pmc_summary.py tells the
         # three dW shapes (same kernel, same grid) apart by their position in the launch cycle
         t = json.load(open(path))
-        return round(t[key]["hbm_bytes"]), "profiles/" + TRAFFIC_JSON + " (tools/prof_kernels.py, same launch shape)"
+        return round(t[key]["hbm_bytes"]), "profiles/" + TRAFFIC_JSON
     except Exception:
         return None, "no committed PMC pass for this kernel"
 
@@ -280,16 +280,15 @@ def gae_bench():
     for _, outs in sets:  # every set holds the same inputs: every scan of the rotation is checked against the product entry point
         assert all(torch.equal(a, b) for a, b in zip(outs, chk))
     time_region(fns[0], 1, warm_s=0.3)  # clock ramp
-    # the default (single launch, rows form) against the 8-consecutive-steps form of rounds 1-3 and the two-launch form, hot and
-    # cold, interleaved in one process (cdna_hip_programming.md rule 24)
-    hot, cold = {0: [], 1: [], 2: []}, {0: [], 1: [], 2: []}
+    # single launch (default) against the two-launch form, hot and cold, interleaved in one process (cdna_hip_programming.md rule 24)
+    hot, cold = {0: [], 1: []}, {0: [], 1: []}
     for _ in range(5):
-        for algo in (0, 1, 2):
+        for algo in (0, 1):
             N.check(L.rlppo_dbg_set(1, algo))
             hot[algo].append(time_region(fns[0], 20, warm=2))
             cold[algo].append(time_rotating(fns, 3))
-    N.check(L.rlppo_dbg_set(1, 2))
-    ms_hot, ms_cold = float(np.median(hot[2])), float(np.median(cold[2]))
+    N.check(L.rlppo_dbg_set(1, 1))
+    ms_hot, ms_cold = float(np.median(hot[1])), float(np.median(cold[1]))
     # the same bytes through a device copy, cold (rotating) and hot
     nb = 28 * n // 2
     pairs = [(torch.empty(nb, dtype=torch.uint8, device="cuda"), torch.empty(nb, dtype=torch.uint8, device="cuda")) for _ in range(GAE_SETS)]
@@ -300,14 +299,13 @@ def gae_bench():
     alg_bytes = 28 * n
     traffic = gae_traffic()
     frac = lambda ms: round(alg_bytes / ms / 1e6 / HBM_PEAK_GBS, 4)
-    log("gae: cold %.2f us (%.3f of 8 TB/s), hot %.2f us (%.3f); 8-consecutive-steps form cold %.2f / hot %.2f us; two-launch form cold %.2f / hot %.2f us; device copy of the same "
+    log("gae: cold %.2f us (%.3f of 8 TB/s), hot %.2f us (%.3f); two-launch form cold %.2f / hot %.2f us; device copy of the same "
         "bytes cold %.2f us (%.3f) / hot %.2f us (%.3f).  cold = %d rotating input+output sets (%.0f MB between two uses of a line), "
         "HIP events around 3 x %d back-to-back scans, median of 5 rounds; hot = one set scanned 20 x back to back"
-        % (ms_cold * 1e3, frac(ms_cold), ms_hot * 1e3, frac(ms_hot), float(np.median(cold[1])) * 1e3, float(np.median(hot[1])) * 1e3,
-           float(np.median(cold[0])) * 1e3, float(np.median(hot[0])) * 1e3,
+        % (ms_cold * 1e3, frac(ms_cold), ms_hot * 1e3, frac(ms_hot), float(np.median(cold[0])) * 1e3, float(np.median(hot[0])) * 1e3,
            cp_cold * 1e3, frac(cp_cold), cp_hot * 1e3, frac(cp_hot), GAE_SETS, GAE_SETS * alg_bytes / 1e6, GAE_SETS))
     out = dict(workload="configs[2]: 8192 x 256 steps f32", steps=n, us_per_scan=round(ms_cold * 1e3, 2), us_per_scan_hot=round(ms_hot * 1e3, 2),
-               us_r3_form=round(float(np.median(cold[1])) * 1e3, 2), us_two_launch_form=round(float(np.median(cold[0])) * 1e3, 2), rotating_sets=GAE_SETS,
+               us_two_launch_form=round(float(np.median(cold[0])) * 1e3, 2), rotating_sets=GAE_SETS,
                us_copy_same_bytes=round(cp_cold * 1e3, 2), us_copy_same_bytes_hot=round(cp_hot * 1e3, 2),
                steps_per_s=round(n / ms_cold * 1e3),
                roofline=dict(bound="hbm", achieved=round(alg_bytes / ms_cold / 1e6, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=frac(ms_cold),
@@ -365,18 +363,16 @@ def rollout_bench(learner):
             ts.append(time.perf_counter() - t)
         return round(1e6 * float(np.median(ts)), 1)
     small = {"us_per_get_action_%d_obs" % n: call_us(n) for n in (8, 80)}
-    return dict(workload="4096 x 107 obs per step, 256x3 policy, 90 actions", **small,
-                obs_per_s_host_noise=round(N_AGENTS / t_parity), ms_per_step_host_noise=round(t_parity * 1e3, 3),
-                obs_per_s_resident_noise=round(N_AGENTS / t_given), ms_per_step_resident_noise=round(t_given * 1e3, 3),
-                ms_per_step_resident_noise_pinned_obs=round(t_pinned * 1e3, 3), ms_fused_launch=round(t_kernel, 4),
-                note="one step = observations on the host -> actions + log-probs on the host through rlppo_discrete_step (pad + MLP + "
-                     "softmax + clamp + argmax(p/q) + log p in ONE launch that stores its results straight into pinned host memory; "
-                     "round 2: pad + 4 GEMM launches + sampling + two D2H copies).  host_noise = the bit-exact action parity mode: "
-                     "Exp(1) noise of torch's CPU generator stream (librlppo's host implementation of torch's exponential_, three draws "
-                     "in flight over two helper threads, each chained to its predecessor's stream phase inside the library); resident_noise = noise already in "
-                     "HBM, observations in pageable / page-locked host memory; ms_fused_launch = the launch alone (device time); "
-                     "us_per_get_action_N_obs = wall clock of one get_action call of N host observations in the bit-exact mode (one "
-                     "hipGraph replay of the same kernel reading and writing pinned host memory)")
+    log("rollout: one step = 4096 x 107 observations on the host -> actions + log-probs on the host through rlppo_discrete_step (pad + MLP + "
+        "softmax + clamp + argmax(p/q) + log p in ONE launch storing into pinned host memory).  host_noise = the bit-exact parity mode (Exp(1) "
+        "noise of torch's CPU generator stream drawn by librlppo's host implementation); resident_noise = noise already in HBM; pinned = the "
+        "observations in page-locked memory; fused_launch = the launch alone (HIP events); us_get_action_N = wall clock of one get_action "
+        "call of N host observations in the bit-exact mode (one hipGraph replay)")
+    return dict(workload="4096 x 107 obs/step, 256x3 policy, 90 actions", us_get_action_8=small["us_per_get_action_8_obs"],
+                us_get_action_80=small["us_per_get_action_80_obs"], obs_per_s_host_noise=round(N_AGENTS / t_parity),
+                ms_per_step_host_noise=round(t_parity * 1e3, 3), obs_per_s_resident_noise=round(N_AGENTS / t_given),
+                ms_per_step_resident_noise=round(t_given * 1e3, 3), ms_per_step_resident_noise_pinned_obs=round(t_pinned * 1e3, 3),
+                ms_fused_launch=round(t_kernel, 4))
 
 
 def cpu_baseline(seed=123, reps=3):
@@ -413,17 +409,33 @@ def cpu_baseline(seed=123, reps=3):
         per_threads[threads] = float(np.median(times))
     threads = min(per_threads, key=per_threads.get)
     return dict(value=round(n / per_threads[threads]), unit="samples/s", cores=threads, kind="port",
-                by_threads={str(k): round(n / v) for k, v in per_threads.items()}, host_cores=cores,
-                sample="1 optimiser step (1 epoch) over 131,072 samples of the cfg2 workload = 2 minibatches of 65,536, torch-CPU "
-                       "eager oracle; %d warm repetitions per thread count, median; thread counts %s both timed (samples/s in "
-                       "by_threads), value = the better one; %.1f s in total"
-                       % (reps, sorted(per_threads), time.perf_counter() - t_all))
+                by_threads={str(k): round(n / v) for k, v in per_threads.items()}, host_cores=cores, physical_cores=physical_cores(),
+                sample="1 optimiser step over 131,072 cfg2 samples (2 minibatches of 65,536), torch-CPU eager oracle, median of %d warm reps per "
+                       "thread count, best count reported; %.0f s" % (reps, time.perf_counter() - t_all))
+
+
+def physical_cores():
+    """Physical cores of the host (distinct (package, core) pairs in /proc/cpuinfo; os.cpu_count() counts hardware threads)."""
+    try:
+        pairs, phys, core = set(), None, None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("physical id"):
+                phys = line.split(":")[1].strip()
+            elif line.startswith("core id"):
+                core = line.split(":")[1].strip()
+            elif not line.strip():
+                if core is not None:
+                    pairs.add((phys, core))
+                phys = core = None
+        return len(pairs) or None
+    except Exception:
+        return None
 
 
 BF16_MFMA_PEAK_TF = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA peak (the 5 PF headline figure includes 2:1 sparsity)
 
 
-def cfg5_rooflines(value, bf16, learner):
+def cfg5_rooflines(value, bf16, learner, full=True):
     """BASELINE configs[4]: 10,435,584 algorithmic flop/sample; 968 algorithmic B/sample read by the update.
     Times the three hidden-layer launch shapes of a pass (512 -> 512 at the rows the update launches) through the diagnostic
     entry points and prices each against BOTH rooflines -- the MFMA peak of its arithmetic type and 8 TB/s of HBM over its
@@ -448,34 +460,34 @@ def cfg5_rooflines(value, bf16, learner):
     dYb = torch.randn(M, H, device=dev).bfloat16()
     dXb = torch.empty(M, H, dtype=torch.bfloat16, device=dev)
     f32_shapes = [
-        ("gemm_nt fwd hidden 512->512 +bitmask, fp32 MFMA", lambda: N.check(L.rlppo_dbg_gemm_nt_bits(st(), P(A), H, P(W), H, P(bias), P(C), H, M, H, H, 1, P(bits))),
+        ("fwd hidden 512->512 f32, +bitmask, fp32 MFMA", lambda: N.check(L.rlppo_dbg_gemm_nt_bits(st(), P(A), H, P(W), H, P(bias), P(C), H, M, H, H, 1, P(bits))),
          "f32", 4 * (2 * M * H + H * H) + M * H // 8),
-        ("gemm_nt dX hidden 512->512 bitmask, fp32 MFMA", lambda: N.check(L.rlppo_dbg_gemm_nt_bits(st(), P(A), H, P(W), H, None, P(C), H, M, H, H, 3, P(bits))),
+        ("dX hidden 512->512 f32, bitmask, fp32 MFMA", lambda: N.check(L.rlppo_dbg_gemm_nt_bits(st(), P(A), H, P(W), H, None, P(C), H, M, H, H, 3, P(bits))),
          "f32", 4 * (2 * M * H + H * H) + M * H // 8),
-        ("gemm_tn dW hidden 512x512 (+ reduction), fp32 MFMA", lambda: N.check(L.rlppo_dbg_gemm_tn(st(), P(A), H, H, P(A2), H, H, P(dW), P(db), H, H, M, P(tn_ws), tn_ws.numel())),
+        ("dW hidden 512x512 f32, + reduction, fp32 MFMA", lambda: N.check(L.rlppo_dbg_gemm_tn(st(), P(A), H, H, P(A2), H, H, P(dW), P(db), H, H, M, P(tn_ws), tn_ws.numel())),
          "f32", 4 * (2 * M * H + H * H)),
     ]
     b16_shapes = [
-        ("gemm_nt_b16w fwd hidden 512->512: bf16 operands in memory, bf16 MFMA, fp32 accumulate; writes bf16 + ReLU bitmask",
+        ("fwd hidden 512->512 bf16: bf16 operands in memory, bf16 MFMA, fp32 accumulate; writes bf16 + ReLU bitmask",
          lambda: N.check(L.rlppo_dbg_gemm_nt_b16(st(), P(Ab), H, P(Wb), H, P(bias), None, 0, P(Cb), H, M, H, H, 1, 1, P(bits))),
          "bf16", 2 * (M * H + H * H) + 2 * M * H + M * H // 8),
-        ("gemm_nt_b16w dX hidden 512->512: bf16 dY x bf16 W^T, rounded to bf16, masked by the bitmask",
+        ("dX hidden 512->512 bf16: bf16 dY x bf16 W^T, rounded to bf16, masked by the bitmask",
          lambda: N.check(L.rlppo_dbg_gemm_nt_b16(st(), P(dYb), H, P(Wb), H, None, None, 0, P(dXb), H, M, H, H, 3, 2, P(bits))),
          "bf16", 2 * (M * H + H * H) + 2 * M * H + M * H // 8),
-        ("gemm_tn_b16 dW hidden 512x512 (+ reduction): bf16 dY^T x bf16 X through transposing LDS reads",
+        ("dW hidden 512x512 bf16: + reduction, bf16 dY^T x bf16 X through transposing LDS reads",
          lambda: N.check(L.rlppo_dbg_gemm_tn_b16(st(), P(dYb), H, P(Ab), H, P(dW), P(db), H, H, H, H, M, P(tn_ws), tn_ws.numel())),
          "bf16", 2 * (2 * M * H) + 4 * H * H),
     ]
-    # the selected precision's kernels first (the first line is the roofline kernel), the other precision's for comparison
-    shapes = (b16_shapes + f32_shapes) if bf16 else (f32_shapes + b16_shapes)
+    # the selected precision's kernels (the first line is the roofline kernel); `full` adds the other precision's for comparison
+    shapes = (b16_shapes + (f32_shapes if full else [])) if bf16 else (f32_shapes + (b16_shapes if full else []))
     rows = []
     for name, fn, kind, nbytes in shapes:
         ms = time_region(fn, 10, warm_s=0.3)
         peak = BF16_MFMA_PEAK_TF if kind == "bf16" else MFMA_F32_PEAK_TF
         f_mfma, f_hbm = flop / ms / 1e9 / peak, nbytes / ms / 1e6 / HBM_PEAK_GBS
-        rows.append(dict(kernel=name, rows_per_launch=M, ms_per_launch=round(ms, 4), tflops=round(flop / ms / 1e9, 1), mfma_peak=peak,
-                         frac_mfma=round(f_mfma, 4), algorithmic_mb=round(nbytes / 1e6, 1), gb_per_s=round(nbytes / ms / 1e6, 1),
-                         frac_hbm=round(f_hbm, 4), binds="hbm" if f_hbm > f_mfma else "mfma"))
+        rows.append(dict(kernel=name.split(":")[0].split(",")[0], ms=round(ms, 4), tflops=round(flop / ms / 1e9, 1), mfma_peak=peak,
+                         frac_mfma=round(f_mfma, 3), alg_mb=round(nbytes / 1e6, 1), gb_per_s=round(nbytes / ms / 1e6, 1),
+                         frac_hbm=round(f_hbm, 3), binds="hbm" if f_hbm > f_mfma else "mfma"))
         log("  %-110s %8.4f ms  %7.1f TFLOP/s (%.2f of %s peak)  %7.1f GB/s (%.2f of HBM)" %
             (name[:110], ms, flop / ms / 1e9, f_mfma, kind, nbytes / ms / 1e6, f_hbm))
     fps = CFG5["flop_per_sample"]
@@ -484,20 +496,18 @@ def cfg5_rooflines(value, bf16, learner):
     # bf16 precision is priced against 2.5 PFLOP/s, where it sits far below the MFMA roofline because its kernels are HBM-side bound)
     peak = BF16_MFMA_PEAK_TF if bf16 else MFMA_F32_PEAK_TF
     out = {"kernel_breakdown": rows,
-           "update_flop_efficiency": dict(achieved=round(tf, 2), peak=peak, unit="TFLOP/s", frac=round(tf / peak, 4),
-                                          note="10,435,584 algorithmic flop/sample (SURVEY 8(d)) x measured samples/s, against the dense %s "
-                                               "MFMA peak" % ("bf16" if bf16 else "fp32"))}
+           "update_flop_efficiency": dict(achieved=round(tf, 1), peak=peak, unit="TFLOP/s", frac=round(tf / peak, 4))}
     dom = rows[0]
     bound = dom["binds"]
     out["roofline"] = dict(bound=bound, achieved=dom["gb_per_s"] if bound == "hbm" else dom["tflops"],
                            peak=HBM_PEAK_GBS if bound == "hbm" else dom["mfma_peak"], unit="GB/s" if bound == "hbm" else "TFLOP/s",
                            frac=dom["frac_hbm"] if bound == "hbm" else dom["frac_mfma"], traffic=cfg5_traffic(bf16), kernel=dom["kernel"],
-                           algorithmic_bytes=round(dom["algorithmic_mb"] * 1e6),
+                           algorithmic_bytes=round(dom["alg_mb"] * 1e6),
                            other_bound=dict(bound="mfma" if bound == "hbm" else "hbm", frac=dom["frac_mfma"] if bound == "hbm" else dom["frac_hbm"]),
-                           ms_per_launch=dom["ms_per_launch"],
-                           note="the hidden-layer forward of the selected update precision at the update's launch shape, priced against both "
-                                "rooflines (algorithmic bytes: operands once, outputs once); `bound` = the larger fraction.  HIP events on the "
-                                "launch stream, 10 launches after a 0.3 s clock ramp")
+                           ms_per_launch=dom["ms"])
+    log("cfg5 roofline: the hidden-layer forward of the selected update precision at the update's launch shape (M = %d rows), priced against "
+        "both rooflines (algorithmic bytes: operands once, outputs once; 10,435,584 algorithmic flop/sample for the whole update); `bound` = "
+        "the larger fraction.  HIP events on the launch stream, 10 launches after a 0.3 s clock ramp" % M)
     return out
 
 
@@ -542,17 +552,16 @@ def cfg5_leg(device, steps=2, warmup=1):
             dt = time.perf_counter() - t0
             value = steps * learner.n_epochs * BATCH / dt
             log("cfg5 %s: %.1f M samples/s" % (prec, value / 1e6))
-            leg = dict(value=round(value, 1), unit="samples/s", steps=steps, warmup=warmup, ms_per_step=round(dt / steps * 1e3, 3),
+            leg = dict(value=round(value, 1), unit="samples/s", steps=steps, ms_per_step=round(dt / steps * 1e3, 2),
                        dtype="bf16" if prec == "bf16" else "f32",
-                       parity="pinned to the reference by fixtures G9 (fp32 arithmetic)" if prec == "fp32" else
-                              "parity-unpinned: the reference has no mixed-precision mode; held to the repository's own restatement",
-                       last_report={k: (round(v, 6) if isinstance(v, float) else v) for k, v in report.items()})
-            leg.update(cfg5_rooflines(value, prec == "bf16", learner))
+                       parity="pinned: fixtures G9 (fp32 arithmetic)" if prec == "fp32" else
+                              "parity-unpinned: the reference has no mixed-precision mode",
+                       kl=round(float(report["Mean KL Divergence"]), 6), value_loss=round(float(report["Value Function Loss"]), 5))
+            leg.update(cfg5_rooflines(value, prec == "bf16", learner, full=False))
             out[prec] = leg
         finally:
             set_update_precision("fp32")
-    out["workload"] = ("BASELINE configs[4]: 524,288-sample buffer, obs 231 f32, Gaussian policy with 8 actions, 512x4 policy + 512x4 "
-                       "critic, ppo_batch 524,288, minibatch 65,536, 10 epochs per step")
+    out["workload"] = "configs[4]: 524,288 samples, obs 231, Gaussian 8 actions, 512x4 nets, batch 524,288, minibatch 65,536, 10 epochs/step"
     del learner, buf
     torch.cuda.empty_cache()
     return out
@@ -638,14 +647,13 @@ def iteration_leg(iters=3):
     c, a, l = (float(np.median([r[i] for r in rows])) * 1e3 for i in range(3))
     del learner
     torch.cuda.empty_cache()
-    return dict(workload="4096 agents x 128 steps per iteration (configs[1] scale), synthetic vectorised environment, 10-epoch update",
+    log("iteration: collect = 128 x (policy inference on 4096 observations with the reference's CPU noise stream + the environment's own "
+        "step() + H2D of its observations); add_new_experience = value pass on 524,289 rows + GAE scan + ring-buffer submit, all on the "
+        "device; learn = the headline metric's step; steps_per_s = agent-steps per second of the whole iteration; median of %d iterations" % iters)
+    return dict(workload="4096 agents x 128 steps/iteration (configs[1] scale), synthetic vector env, 10-epoch update",
                 collect_ms=round(c, 2), collect_ms_per_env_step=round(c / N_STEPS, 4),
                 collect_ms_device_noise=round(min(t_dev[1:]) * 1e3, 2), add_new_experience_ms=round(a, 3), learn_ms=round(l, 3),
-                iteration_ms=round(c + a + l, 2), steps_per_s=round(N_SAMPLES / (c + a + l) * 1e3),
-                note="collect = 128 x (policy inference on 4096 observations with the reference's CPU noise stream + the environment's "
-                     "own step() + H2D of its observations); add_new_experience = value pass on 524,289 rows + GAE scan + ring-buffer "
-                     "submit, all on the device; learn = the headline metric's step.  steps_per_s = agent-steps per second of the "
-                     "whole iteration; median of %d iterations" % iters)
+                iteration_ms=round(c + a + l, 2), steps_per_s=round(N_SAMPLES / (c + a + l) * 1e3))
 
 
 # ---------------------------------------------------------------------------------------------------- main
@@ -662,9 +670,11 @@ def parse_args(argv=None):
     ap.add_argument("--precision", choices=("fp32", "bf16"), default="fp32",
                     help="update precision: fp32 (parity mode, default) or bf16 = bf16-operand forward / fp32 master, accumulate "
                          "and backward (BASELINE configs[4]; rlppo_set_update_precision)")
-    ap.add_argument("--allreduce", choices=("torch", "direct", "ab"), default="ab",
-                    help="N > 1: gradient exchange through torch.distributed (RCCL), through librlppo's own RCCL communicator, or "
-                         "'ab' = the timed region uses torch.distributed and a short A/B of both follows (reported as `allreduce`)")
+    ap.add_argument("--allreduce", choices=("torch", "direct", "ab"), default="torch",
+                    help="N > 1: gradient exchange through torch.distributed (RCCL; the default and the product's default), through "
+                         "librlppo's own RCCL communicator, or 'ab' = the timed region uses torch.distributed, the JSON line is printed, "
+                         "and a short A/B of both routes follows on stderr (opt-in: the direct communicator has never run with more "
+                         "than one rank on this pool, so it stays out of the line the driver records)")
     return ap.parse_args(argv)
 
 
@@ -778,18 +788,55 @@ def main():
     torch.cuda.set_device(local_rank)
     device = f"cuda:{local_rank}"
     if world > 1:
+        import faulthandler
+        import threading
+        faulthandler.enable()  # a fault in a rank leaves a trace and kills it (the launcher then tears the job down): no handler games
+        # Watchdog around the rendezvous + communicator set-up + the first collective: if they do not finish within
+        # RLPPO_INIT_TIMEOUT seconds (default 90: RCCL's 8-rank bootstrap takes 5-20 s on a cold node) this rank says why in one
+        # line and exits non-zero instead of hanging until the driver's own limit.  (A thread + os._exit in THIS fresh process: a
+        # process that has touched the GPU is never re-exec'd.)
+        init_done = threading.Event()
+        limit = float(os.environ.get("RLPPO_INIT_TIMEOUT", 90))
+
+        def init_watchdog():
+            if not init_done.wait(limit):
+                log(f"bench.py rank {rank}/{world}: init_process_group / first all-reduce did not finish within {limit:.0f} s "
+                    f"(backend {'gloo' if dryrun else 'nccl'}, MASTER_ADDR={os.environ.get('MASTER_ADDR')}, MASTER_PORT={os.environ.get('MASTER_PORT')}, "
+                    f"device {device}, HSA_ENABLE_IPC_MODE_LEGACY={os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY')}); exiting 4")
+                os._exit(4)
+        threading.Thread(target=init_watchdog, daemon=True).start()
+        t_init = time.perf_counter()
         if dryrun:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(device))
+        t_pg = time.perf_counter() - t_init
         from rlgym_ppo_amd import dp
         dp.set_allreduce_backend("direct" if args.allreduce == "direct" else "torch")
-        # the number of ranks the collective really spans: a sum of ones through the backend the run uses
+        # the number of ranks the collective really spans: a sum of ones through the backend the run uses (the first collective
+        # of the job: RCCL builds its rings / trees here)
         ones = torch.ones(1, device=device)
+        t_first = time.perf_counter()
         dist.all_reduce(ones)
         n_seen = int(ones.item())
+        t_first = time.perf_counter() - t_first
+        # the exchange the update performs (the 1.37 MB [grad_policy | grad_value] arena), warm, before anything is timed
+        probe = torch.zeros(341_851, device=device)
+        for _ in range(3):
+            dp.all_reduce_sum(probe, dist)
+        torch.cuda.synchronize()
+        t_ar = time.perf_counter()
+        for _ in range(20):
+            dp.all_reduce_sum(probe, dist)
+        torch.cuda.synchronize()
+        t_ar = (time.perf_counter() - t_ar) / 20
+        init_done.set()
+        log(f"bench.py rank {rank}/{world} on {device}: init_process_group {t_pg:.2f} s, first all-reduce {t_first * 1e3:.1f} ms, n_seen {n_seen}, "
+            f"1.37 MB gradient all-reduce {t_ar * 1e6:.0f} us warm (backend {'gloo' if dryrun else 'nccl=RCCL'}, route {args.allreduce if args.allreduce != 'ab' else 'torch'})")
+        allreduce_us = round(t_ar * 1e6, 1)
     else:
         n_seen = 1
+        allreduce_us = None
 
     import contextlib
     with contextlib.redirect_stdout(sys.stderr):
@@ -821,12 +868,11 @@ def main():
     value = samples / dt
     bf16 = args.precision == "bf16"
     if args.config == "cfg2":
-        workload = ("BASELINE configs[1]: 4096 agents x 128 steps = 524,288-sample buffer, obs 107 f32, 90 discrete actions, "
-                    "256x3 policy + 256x3 critic; ppo_batch 524,288, minibatch 65,536")
+        workload = "configs[1]: 4096 agents x 128 steps = 524,288-sample buffer, obs 107 f32, 90 discrete actions, 256x3 policy + critic; batch 524,288, minibatch 65,536"
     else:
-        workload = ("BASELINE configs[4]: 524,288-sample buffer, obs 231 f32, Gaussian policy with 8 actions, 512x4 policy + 512x4 "
-                    "critic, " + ("bf16 update precision: bf16-operand products forward and backward (bf16 activations and activation gradients), fp32 accumulation, loss, dW/db, clip, Adam and master weights" if bf16 else "fp32 update") +
-                    "; ppo_batch 524,288, minibatch 65,536")
+        workload = ("configs[4]: 524,288-sample buffer, obs 231 f32, Gaussian 8 actions, 512x4 policy + critic, " +
+                    ("bf16 update precision (bf16 MFMA operands forward and backward, fp32 accumulate / loss / dW / Adam / master weights)" if bf16 else "fp32 update") +
+                    "; batch 524,288, minibatch 65,536")
     per_rank = 8 // world if 8 % world == 0 else 1
     out = {
         "metric": "ppo_update_samples_per_sec", "value": round(value, 1), "unit": "samples/s", "n_gpus": n_seen,
@@ -834,15 +880,14 @@ def main():
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "bf16" if bf16 else "f32",
         "data": "synthetic" + (" (DRY RUN: all ranks on one GPU over gloo, not a measurement)" if dryrun else ""),
         "config": {"workload": workload, "epochs_per_step": args.epochs, "samples_per_step": args.epochs * BATCH,
-                   "parallelism": f"dp{world}: {per_rank} consecutive minibatch slice(s) per rank and pass, 1 RCCL all-reduce/optimiser step"
+                   "parallelism": f"dp{world}: {per_rank} minibatch slice(s) per rank and pass, 1 RCCL all-reduce per optimiser step"
                                   + (f" ({args.allreduce if args.allreduce != 'ab' else 'torch'}.distributed)" if world > 1 else ""),
-                   "last_report": {k: (round(v, 6) if isinstance(v, float) else v) for k, v in report.items()}},
+                   "last_report": {k: (round(v, 5) if isinstance(v, float) else v) for k, v in report.items()}},
     }
     if world > 1 and args.config == "cfg2":  # achieved fraction of the MFMA roofline of the whole job (N x peak)
         out["update_flop_efficiency"] = dict(
             achieved=round(FLOP_PER_SAMPLE * value / 1e12, 2), peak=round(MFMA_F32_PEAK_TF * world, 1), unit="TFLOP/s",
-            frac=round(FLOP_PER_SAMPLE * value / 1e12 / (MFMA_F32_PEAK_TF * world), 4),
-            note="1,931,776 algorithmic flop/sample x measured whole-job samples/s against %d x the fp32 MFMA peak" % world)
+            frac=round(FLOP_PER_SAMPLE * value / 1e12 / (MFMA_F32_PEAK_TF * world), 4))  # 1,931,776 algorithmic flop/sample x whole-job samples/s vs N x the fp32 MFMA peak
     if args.config == "cfg5":
         pass  # kernel lines are added below (rank 0, one GPU)
 
@@ -853,56 +898,50 @@ def main():
             emitted.append(1)
             print(json.dumps(out), flush=True)
 
-    if world > 1 and args.allreduce == "ab" and dry != "2":  # (the one-GPU dry run walks through it too: both legs then go through gloo)
-        # The direct communicator has its first multi-rank run here.  Whatever happens to the A/B, every rank leaves and rank 0
-        # has printed the headline line: a watchdog thread prints it and exits the process if the A/B has not finished within
-        # 120 s, or as soon as SIGTERM arrives (the launcher tearing the job down because another rank died) -- the signal
-        # reaches the thread through a wake-up descriptor, so it is seen even while the main thread is blocked in a collective.
+    if world > 1:
+        out["allreduce_us"] = allreduce_us  # the update's 1.37 MB exchange alone, warm, measured before the timed region (rank 0's view)
+    if world > 1 and args.allreduce == "ab" and dry != "2":  # opt-in (the one-GPU dry run walks through it too: both legs then go through gloo)
+        # The direct communicator has its first multi-rank run here, so the JSON line is printed FIRST and the A/B reports on
+        # stderr.  A watchdog thread ends the process if the A/B has not finished within 120 s or as soon as SIGTERM arrives (the
+        # launcher tearing the job down because another rank died) -- SIGTERM only: a fault keeps its default disposition (the rank
+        # dies with faulthandler's trace, the launcher ends the job).
         import select, signal, socket, threading
+        emit()
         rd, wr = socket.socketpair()
         wr.setblocking(False)
-        # A fault inside the A/B (SIGSEGV / SIGBUS in a library the direct route loads) wakes the watchdog the same way: CPython's C-level
-        # handler writes the signal number to the descriptor from signal context, the faulting thread keeps re-faulting, the
-        # watchdog prints the line and leaves.  (abort() cannot be held this way; the line is on stderr before the A/B starts.)
-        fatal = (signal.SIGTERM, signal.SIGSEGV, signal.SIGBUS)
-        for sig in fatal:
-            signal.signal(sig, lambda *_: None)
+        signal.signal(signal.SIGTERM, lambda *_: None)
         signal.set_wakeup_fd(wr.fileno(), warn_on_full_buffer=False)
-        if rank == 0:
-            log("headline before the exchange A/B: " + json.dumps({k: out[k] for k in ("value", "unit", "n_gpus", "ms_per_step")}))
 
         def bail():
             ready, _, _ = select.select([rd], [], [], 120.0)
             got = rd.recv(16) if ready else b""
             if got[:1] == b"\0":  # the A/B finished
                 return
-            out["allreduce"] = {"error": "A/B skipped: " + ("terminated by signal %d" % got[0] if got else "not finished within 120 s")}
-            emit()
+            log("exchange A/B abandoned: " + ("terminated by signal %d" % got[0] if got else "not finished within 120 s"))
             os._exit(3)  # the headline line is out, but this process is stuck in (or was torn out of) a collective: not a clean exit
         threading.Thread(target=bail, daemon=True).start()
-        out["allreduce"] = allreduce_ab(learner, buf, max(1, min(args.steps, 5)), world, device, dist)
+        ab = allreduce_ab(learner, buf, max(1, min(args.steps, 5)), world, device, dist)
         wr.send(b"\0")
         signal.set_wakeup_fd(-1)
-        for sig in fatal:
-            signal.signal(sig, signal.SIG_DFL)
+        signal.signal(signal.SIGTERM, signal.SIG_DFL)
+        if rank == 0:
+            log("exchange A/B: " + json.dumps(ab))
     if rank == 0 and world == 1 and not args.no_extras and args.config == "cfg5":
         out.update(cfg5_rooflines(value, bf16, learner))
     if rank == 0 and world == 1 and not args.no_extras and args.config == "cfg2":
-        rows, dom = kernel_breakdown(learner)
+        rows, dom, M = kernel_breakdown(learner)
         for r in rows:
-            log("  %-44s x%d  %8.4f ms  %7.2f TFLOP/s" % (r["kernel"], r["launches_per_minibatch"], r["ms_per_launch"], r["tflops"]))
+            log("  %-24s x%d  %8.4f ms  %7.2f TFLOP/s (algorithmic), %7.2f executed" % (r["kernel"], r["n"], r["ms"], r["tflops"], r["exec_tflops"]))
         traffic, traffic_src = pmc_traffic_for(dom["kernel"])
+        log("roofline: dominant kernel of the timed region by total time; achieved = algorithmic flop per launch / mean launch duration (HIP "
+            "events on the launch stream, 20 launches after a 0.3 s clock ramp, same shape as in the update: M = %d rows per pass); traffic = "
+            "HBM bytes per launch from rocprofv3 PMC (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE): %s.  update_flop_efficiency = 1,931,776 "
+            "algorithmic flop/sample x measured samples/s (whole learn(), host shuffle included)" % (M, traffic_src))
         out["roofline"] = dict(bound="mfma", achieved=dom["tflops"], peak=MFMA_F32_PEAK_TF, unit="TFLOP/s",
                                frac=round(dom["tflops"] / MFMA_F32_PEAK_TF, 4), traffic=traffic, kernel=dom["kernel"],
-                               algorithmic_gflop_per_launch=dom["gflop_per_launch"], ms_per_launch=dom["ms_per_launch"],
-                               note=("dominant kernel of the timed region by total time; achieved = algorithmic flop per "
-                                    "launch / mean launch duration (HIP events on the launch stream, 20 launches, same "
-                                    "shape as in the update: M=%d rows per pass); traffic = HBM bytes per launch from rocprofv3 PMC "
-                                    "(FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), ") % dom["rows_per_launch"] + traffic_src)
-        out["update_flop_efficiency"] = dict(
-            achieved=round(FLOP_PER_SAMPLE * value / 1e12, 2), peak=MFMA_F32_PEAK_TF, unit="TFLOP/s",
-            frac=round(FLOP_PER_SAMPLE * value / 1e12 / MFMA_F32_PEAK_TF, 4),
-            note="1,931,776 algorithmic flop/sample x measured samples/s (whole learn(), host shuffle included)")
+                               algorithmic_gflop_per_launch=dom["gflop"], ms_per_launch=dom["ms"], rows_per_launch=M)
+        out["update_flop_efficiency"] = dict(achieved=round(FLOP_PER_SAMPLE * value / 1e12, 2), peak=MFMA_F32_PEAK_TF, unit="TFLOP/s",
+                                             frac=round(FLOP_PER_SAMPLE * value / 1e12 / MFMA_F32_PEAK_TF, 4))
         out["kernel_breakdown"] = rows
         out["gae"] = gae_bench()
         out["rollout"] = rollout_bench(learner)
@@ -911,6 +950,18 @@ def main():
         out["iteration"] = iteration_leg()
         out["cfg5"] = cfg5_leg(device)
         out["cpu_baseline"] = cpu_baseline()
+        # The scalars a reader wants first, once more at the END of the line (a truncated record keeps its tail)
+        g, ro, it = out["gae"], out["rollout"], out["iteration"]
+        out["summary"] = dict(
+            ppo_update_samples_per_s=out["value"], update_frac_of_f32_mfma_peak=out["update_flop_efficiency"]["frac"],
+            dominant_kernel_frac=out["roofline"]["frac"],
+            gae_us=g["us_per_scan"], gae_frac_hbm_cold=g["roofline"]["frac"], gae_frac_hbm_hot=g["roofline"]["hot_frac"],
+            gae_traffic_ratio=round(g["roofline"]["traffic"] / g["roofline"]["algorithmic_bytes"], 3) if g["roofline"]["traffic"] else None,
+            rollout_ms_host_noise=ro["ms_per_step_host_noise"], rollout_ms_resident=ro["ms_per_step_resident_noise"],
+            collect_ms=it["collect_ms"], iteration_steps_per_s=it["steps_per_s"],
+            cfg5_fp32_samples_per_s=out["cfg5"]["fp32"]["value"], cfg5_bf16_samples_per_s=out["cfg5"]["bf16"]["value"],
+            cfg5_bf16_update_frac_of_bf16_peak=out["cfg5"]["bf16"]["update_flop_efficiency"]["frac"],
+            cpu_port_samples_per_s=out["cpu_baseline"]["value"])
     emit()
     if world > 1:
         dist.destroy_process_group()

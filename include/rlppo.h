@@ -242,9 +242,13 @@ int rlppo_clip_adam(void *stream, float *params, float *grads, float *exp_avg, f
  * sync_ws: RLPPO_OPT_SYNC_BYTES of device memory, 16-byte aligned, owned by the caller and ZEROED ONCE when it is allocated
  * (never again: every completed call leaves it armed for the next): the state of
  * the grid barrier between the norm and the update (arrival counter, generation word, one partial-sum slot per workgroup, added
- * in a fixed order: the norm is bit-reproducible), and at byte offset 8 a uint32 that counts barrier waits that gave up
- * (then the affected network's parameters are poisoned with NaN; callers read the word back with their report).  Not
- * shareable between concurrent calls.  sync_ws == NULL selects the three-operation form (fill, norms, update). */
+ * in a fixed order: the norm is bit-reproducible), and at byte offset 8 a uint32 that counts barrier waits that gave up.
+ * Giving up is all or nothing: NO element of either network is then touched by that call (parameters, moments, gradients and
+ * `packed` stay as they were), the block is dead -- every later call on it skips its update at once and counts itself --
+ * until the caller has zeroed it again; callers read the word back with their report and can repeat the step with
+ * sync_ws == NULL.  The grid is clamped to what the device keeps resident (a device too small for one workgroup per network
+ * takes the three-operation form by itself).  Not shareable between concurrent calls.  sync_ws == NULL selects the
+ * three-operation form (fill, norms, update). */
 #define RLPPO_OPT_SYNC_BYTES 16384
 typedef struct rlppo_opt_net {
     const int32_t *dims;  /* layer widths, n_layers + 1 entries */

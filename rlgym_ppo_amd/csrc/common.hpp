@@ -224,6 +224,8 @@ size_t gae_workspace_bytes(int64_t n);
 void set_gae_algo(int algo);
 void set_gae_spin_limit(int v);
 void set_gae_oversubscribe(int v);
+void set_fused_spin_limit(int v);
+void set_fused_test_hold(int v);
 int launch_gae(hipStream_t, const float *, const float *, const float *, const float *, int64_t, double, double, float,
                float *, float *, float *, void *, size_t);
 

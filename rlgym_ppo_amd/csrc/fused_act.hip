@@ -307,7 +307,24 @@ bool fused_act_ok(const NetLayout &net) {
     const LayerLayout &o = net.L[net.n_layers - 1];
     if (o.out > 128 || o.pout > 128 || o.pout > H) return false;
     if (net.L[0].pin > H || net.L[0].pin % 16 != 0) return false;
-    return true;
+    // the kernel's dynamic LDS (up to 102 KiB at H = 256) against what THIS device grants a workgroup: a device with a 64 KiB
+    // limit takes the bit-identical layer chain instead of failing the launch (advisor finding, round 3)
+    const int J = H == 256 ? 2 : 1, W = H == 64 ? 4 : 8;
+    const size_t need = (size_t)(2 * 16 * J * W * FA_ROWS + W * FA_STAGES * J * 256 + FA_MAX_LAYERS * 16 * J * W) * 4;
+    static std::atomic<long> lds_limit[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
+    long lim = lds_limit[dev].load(std::memory_order_acquire);
+    if (lim == 0) {
+        int v = 0;
+        // (the opt-in maximum: hipFuncSetAttribute raises a kernel's limit up to it)
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) != hipSuccess || v <= 0) v = 65536;
+        int vo = 0;
+        if (hipDeviceGetAttribute(&vo, hipDeviceAttributeSharedMemPerBlockOptin, dev) == hipSuccess && vo > v) v = vo;
+        lim = v;
+        lds_limit[dev].store(lim, std::memory_order_release);
+    }
+    return need <= (size_t)lim;
 }
 
 int launch_discrete_act_fused(hipStream_t st, const NetLayout &net, const float *packed, const FusedActIO &io, int64_t n) {

@@ -78,32 +78,6 @@ __device__ __forceinline__ Aff2 wave_suffix_scan(Aff2 v, int lane) {
     return compose(v, right);
 }
 
-// R independent suffix scans at once, written level by level so that the chains interleave in ONE basic block (the nested
-// struct select at the end of wave_suffix_scan compiles to branches, which would put the scans one after the other).
-template <int R>
-__device__ __forceinline__ void wave_suffix_scan_rows(Aff2 (&v)[R], int lane) {
-#pragma unroll
-    for (int h = 0; h < R; ++h) v[h] = compose(v[h], dpp_aff<0x101>(v[h]));
-#pragma unroll
-    for (int h = 0; h < R; ++h) v[h] = compose(v[h], dpp_aff<0x102>(v[h]));
-#pragma unroll
-    for (int h = 0; h < R; ++h) v[h] = compose(v[h], dpp_aff<0x104>(v[h]));
-#pragma unroll
-    for (int h = 0; h < R; ++h) v[h] = compose(v[h], dpp_aff<0x108>(v[h]));
-    const int row = lane >> 4;
-#pragma unroll
-    for (int h = 0; h < R; ++h) {
-        const Aff2 t1 = readlane_aff(v[h], 16), t2 = readlane_aff(v[h], 32), t3 = readlane_aff(v[h], 48);
-        const Aff2 t23 = compose(t2, t3), t123 = compose(t1, t23);
-        Aff2 right;  // scalar selects, component by component
-        right.a = row == 0 ? t123.a : (row == 1 ? t23.a : (row == 2 ? t3.a : 1.0));
-        right.b = row == 0 ? t123.b : (row == 1 ? t23.b : (row == 2 ? t3.b : 0.0));
-        right.c = row == 0 ? t123.c : (row == 1 ? t23.c : (row == 2 ? t3.c : 1.0));
-        right.d = row == 0 ? t123.d : (row == 1 ? t23.d : (row == 2 ? t3.d : 0.0));
-        v[h] = compose(v[h], right);
-    }
-}
-
 struct GaeParams {
     double gamma, gl;  // gamma, gamma*lambda
     float ret_std;
@@ -113,11 +87,13 @@ struct GaeParams {
 // Loads the GAE_EPT steps of this thread and turns them into per-step coefficients.
 struct Steps {
     double b_adv[GAE_EPT];
-    // nd * nt of every step is 0 or 1 for 0/1 flags: one bit each (bit e), plus a "past the end of the data" marker (bit 16 + e:
-    // identity step, a_adv = a_ret = 1); a_adv = gamma*lambda*m and a_ret = gamma*m are formed on use.  (Eight floats here
-    // were what pushed the single-pass kernel 3 registers over its 128-VGPR budget: 12 bytes of scratch per lane = 3.1 MB of
-    // extra HBM writes per 8192 x 256 scan.)  The reference's flags are exactly 0.0 / 1.0 (batched_agent_manager.py:145,
-    // experience_buffer.py:47-48); launch_gae's contract says so.
+    // nd * nt of every step is 0 or 1 for 0/1 flags: ONE bit each (bit e); a_adv = gamma*lambda*m and a_ret = gamma*m are formed
+    // on use with one select.  (Eight floats here were what pushed the single-pass kernel 3 registers over its 128-VGPR budget: 12
+    // bytes of scratch per lane = 3.1 MB of extra HBM writes per 8192 x 256 scan.)  The reference's flags are exactly 0.0 / 1.0
+    // (batched_agent_manager.py:145, experience_buffer.py:47-48); launch_gae's contract says so.
+    // [r4] A step past the end of the data is the ZERO map (a = 0, b = 0, r = 0: bit clear), not the identity: x = 0 beyond the
+    // last step either way, and the coefficient selects lose a level (rounds 1-3 kept a second marker bit per step: 12 more
+    // vector instructions per step and use on the path of every full chunk).
     unsigned mbits;
     float r[GAE_EPT], v[GAE_EPT];
 };
@@ -170,16 +146,14 @@ __device__ __forceinline__ void make_steps(const RawSteps &w, int64_t t0, int64_
 #pragma unroll
     for (int e = 0; e < GAE_EPT; ++e) {
         if (t0 + e < n) {
-            const double nd = (double)(1.0f - d[e]);
-            const double nt = (double)(1.0f - tr[e]);
+            const float ndf = 1.0f - d[e], ntf = 1.0f - tr[e];
             float rn = r[e];
             if (p.use_std) rn = fminf(fmaxf(r[e] / p.ret_std, -10.f), 10.f);
-            s.b_adv[e] = ((double)rn + p.gamma * (double)v[e + 1] * nd) - (double)v[e];
-            s.mbits |= ((float)(nd * nt) != 0.f ? 1u : 0u) << e;
+            s.b_adv[e] = ((double)rn + p.gamma * (double)v[e + 1] * (double)ndf) - (double)v[e];
+            s.mbits |= (ndf * ntf != 0.f ? 1u : 0u) << e;  // (0/1 flags: the float product is the exact 0/1 the reference's double one is)
             s.r[e] = r[e];
-        } else {  // past the end: identity, so partial blocks need no special casing downstream
+        } else {  // past the end: the zero map
             s.b_adv[e] = 0.0;
-            s.mbits |= 0x10000u << e;  // marker: a_adv = a_ret = 1
             s.r[e] = 0.f;
         }
         s.v[e] = v[e];
@@ -194,12 +168,8 @@ __device__ __forceinline__ void load_steps(const float *__restrict__ rews, const
     make_steps(w, t0, n, p, s);
 }
 
-__device__ __forceinline__ double coef_adv(const Steps &s, int e, const GaeParams &p) {
-    return (s.mbits >> (16 + e)) & 1u ? 1.0 : ((s.mbits >> e) & 1u ? p.gl : 0.0);
-}
-__device__ __forceinline__ double coef_ret(const Steps &s, int e, const GaeParams &p) {
-    return (s.mbits >> (16 + e)) & 1u ? 1.0 : ((s.mbits >> e) & 1u ? p.gamma : 0.0);
-}
+__device__ __forceinline__ double coef_adv(const Steps &s, int e, const GaeParams &p) { return (s.mbits >> e) & 1u ? p.gl : 0.0; }
+__device__ __forceinline__ double coef_ret(const Steps &s, int e, const GaeParams &p) { return (s.mbits >> e) & 1u ? p.gamma : 0.0; }
 
 __device__ __forceinline__ Aff2 thread_composite(const Steps &s, const GaeParams &p) {
     Aff2 c = aff_identity();
@@ -439,6 +409,10 @@ __device__ __forceinline__ void resolve_carry(const int chunk, const int n_block
 
 // LOOP = false: one chunk per workgroup (the grid covers every chunk; the usual case) -- without the loop-carried state the
 // kernel fits its 128-VGPR budget with no scratch at all.
+#ifndef GAE_STORE_T_V
+#define GAE_STORE_T_V 1
+#endif
+constexpr bool STORE_T = GAE_STORE_T_V;  // lane-contiguous output stores through an in-wave LDS transpose ([r4]; 0 = rounds 1-3's shape, for A/B builds)
 template <bool LOOP>
 __global__ __launch_bounds__(GAE_THREADS, 4) void gae_lookback_kernel(const float *__restrict__ rews,
                                                                     const float *__restrict__ dones,
@@ -453,6 +427,8 @@ __global__ __launch_bounds__(GAE_THREADS, 4) void gae_lookback_kernel(const floa
     __shared__ Aff2 wave_tot[4];
     __shared__ Aff2 wave_la[4];  // look-ahead window of the next chunk: per-wave composites (64 steps each)
     __shared__ double s_carry[2];
+    constexpr int WAVE_SPAN = 64 * GAE_EPT;                                    // 512 consecutive steps per wave
+    __shared__ __attribute__((aligned(16))) float o_lds[STORE_T ? 4 * 3 * WAVE_SPAN : 4];  // output transpose, 6 KiB per wave
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // Tags are unique per launch without a memset: `tag` is a kernel argument drawn from a process-wide host counter
     // (launch_gae), so every workgroup of a launch holds the same tag whatever its dispatch time, and records of earlier
@@ -483,7 +459,7 @@ __global__ __launch_bounds__(GAE_THREADS, 4) void gae_lookback_kernel(const floa
     RawSteps raw;
     load_raw(rews, dones, trunc, values, t0, n, raw);
     {   // the window's composite while the chunk's own loads are still in flight (the window's were issued first)
-        Aff2 l1 = aff_identity();  // steps past the end: identity (x = 0 there is handled by covers_all below)
+        Aff2 l1 = aff_identity();  // steps past the end: identity (x = 0 there is handled by covers_all in resolve_carry)
         if (l_ok) l1 = step_affine(l_r, l_d, l_t, l_v, l_v1, p);
         const Aff2 ls = wave_suffix_scan(l1, lane);
         if (lane == 0) wave_la[wave] = ls;
@@ -501,10 +477,11 @@ __global__ __launch_bounds__(GAE_THREADS, 4) void gae_lookback_kernel(const floa
     const Aff2 inc = wave_suffix_scan(mine, lane);
     if (lane == 0) wave_tot[wave] = inc;
     __syncthreads();
-    const Aff2 agg = compose(compose(wave_tot[0], wave_tot[1]), compose(wave_tot[2], wave_tot[3]));
-    u64 *rec = state + (size_t)chunk * LB_STRIDE;
-
-    resolve_carry(chunk, n_blocks, n, lane, wave, wave_la, agg, prefix_open, rec, state, TAG_AGG, TAG_INC, spin_limit, slow_word, s_carry);
+    if (wave == 0) {  // (the aggregate and the records are wave 0's business alone)
+        const Aff2 agg = compose(compose(wave_tot[0], wave_tot[1]), compose(wave_tot[2], wave_tot[3]));
+        u64 *rec = state + (size_t)chunk * LB_STRIDE;
+        resolve_carry(chunk, n_blocks, n, lane, wave, wave_la, agg, prefix_open, rec, state, TAG_AGG, TAG_INC, spin_limit, slow_word, s_carry);
+    }
 
     // ---- exclusive suffix of this thread within the chunk, then the carry
     __syncthreads();  // publishes s_carry
@@ -515,225 +492,66 @@ __global__ __launch_bounds__(GAE_THREADS, 4) void gae_lookback_kernel(const floa
     double x_adv = after.b + after.a * carry_adv;
     double x_ret = after.d + after.c * carry_ret;
 
-    float o_adv[GAE_EPT], o_vt[GAE_EPT], o_ret[GAE_EPT];
-#pragma unroll
-    for (int e = GAE_EPT - 1; e >= 0; --e) {
-        x_adv = s.b_adv[e] + coef_adv(s, e, p) * x_adv;
-        x_ret = (double)s.r[e] + coef_ret(s, e, p) * x_ret;
-        o_adv[e] = (float)x_adv;
-        o_vt[e] = (float)((double)s.v[e] + x_adv);
-        o_ret[e] = (float)x_ret;
-    }
-    if (t0 + GAE_EPT <= n) {
-        typedef float f4 __attribute__((ext_vector_type(4)));
-#pragma unroll
-        for (int h = 0; h < GAE_EPT / 4; ++h) {
-            *reinterpret_cast<f4 *>(adv_out + t0 + 4 * h) = f4{o_adv[4 * h], o_adv[4 * h + 1], o_adv[4 * h + 2], o_adv[4 * h + 3]};
-            *reinterpret_cast<f4 *>(vt_out + t0 + 4 * h) = f4{o_vt[4 * h], o_vt[4 * h + 1], o_vt[4 * h + 2], o_vt[4 * h + 3]};
-            *reinterpret_cast<f4 *>(ret_out + t0 + 4 * h) = f4{o_ret[4 * h], o_ret[4 * h + 1], o_ret[4 * h + 2], o_ret[4 * h + 3]};
-        }
-    } else {
-#pragma unroll
-        for (int e = 0; e < GAE_EPT; ++e)
-            if (t0 + e < n) {
-                adv_out[t0 + e] = o_adv[e];
-                vt_out[t0 + e] = o_vt[e];
-                ret_out[t0 + e] = o_ret[e];
-            }
-    }
-    __syncthreads();  // LDS (lds4, wave_tot, s_carry) is reused by the next round
-    }
-}
-
-// ------------------------------------------------------------------------------------------ rows form [r4]
-// The same single-pass algorithm with a different step -> lane map.  Above, a thread owns GAE_EPT = 8 CONSECUTIVE steps: a
-// wave-instruction of its float4 loads touches 64 x 16 bytes at a 32-byte stride, i.e. half of each of sixteen 128-byte lines,
-// and the second instruction fetches the other halves.  Re-scanning one 58.7 MB buffer set in the Infinity Cache (what rounds 1-3
-// timed) hides that; streaming from HBM it does not: with the same seven streams and no scan at all the 8-consecutive shape
-// takes 15.0 us per launch, the lane-contiguous one 13.4 us (tools/gae_ab.py, profiles/r04_gae_floor.txt).
-// Here a wave owns 512 consecutive steps as GAE_ROWS = 2 rows of 256: lane l holds steps [4l, 4l + 4) of each row, so every
-// load and store instruction of a wave covers 1 KiB of contiguous bytes.  A wave then runs TWO suffix scans over 4-step thread
-// composites (independent, so their dependent DPP / fp64 chains interleave), the per-thread chains are 4 long instead of 8, and
-// the rows are joined with one extra composition (row 0's carry passes through row 1's total).
-constexpr int GAE_ROWS = GAE_EPT / 4;
-constexpr int ROW_STEPS = 64 * 4;                  // 256 steps: one float4 per lane
-constexpr int WAVE_STEPS = GAE_ROWS * ROW_STEPS;   // 512 consecutive steps per wave
-static_assert(GAE_EPT % 4 == 0 && GAE_THREADS / 64 * WAVE_STEPS == GAE_BLOCK, "rows form: chunk = 4 waves x rows x 256 steps");
-
-template <bool LOOP>
-__global__ __launch_bounds__(GAE_THREADS, 4) void gae_rows_kernel(const float *__restrict__ rews, const float *__restrict__ dones,
-                                                                  const float *__restrict__ trunc, const float *__restrict__ values,
-                                                                  int64_t n, GaeParams p, u64 *__restrict__ state, const unsigned tag,
-                                                                  const unsigned spin_limit, unsigned *__restrict__ slow_word,
-                                                                  int n_blocks, float *__restrict__ vt_out, float *__restrict__ adv_out,
-                                                                  float *__restrict__ ret_out) {
     typedef float f4 __attribute__((ext_vector_type(4)));
-    __shared__ Aff2 wave_tot[4];
-    __shared__ Aff2 wave_la[4];
-    __shared__ double s_carry[2];
-    // b of the advantage recurrence, one double per step, parked in LDS between the composite and the output phase (thread-
-    // private slots, step-major so that a wave's ds_write_b64 / ds_read_b64 covers 512 contiguous bytes): 16 KiB per workgroup.
-    // Held in registers, the eight doubles put the kernel 16 dwords over the 128-VGPR budget of 4 workgroups per CU (scratch =
-    // HBM traffic); re-formed from their float ingredients, the ingredients cost as much.
-    __shared__ double b_lds[GAE_EPT * GAE_THREADS];
-    __shared__ float v_lds[GAE_EPT * GAE_THREADS];  // V_t likewise (only the value-target output needs it again): 8 KiB
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int chunk = n_blocks - 1 - (int)blockIdx.x; chunk >= 0; chunk = LOOP ? chunk - (int)gridDim.x : -1) {
-    const int64_t tb = (int64_t)chunk * GAE_BLOCK + wave * WAVE_STEPS + lane * 4;  // first step of this lane in row 0
-
-    // look-ahead window (one raw step of the next chunk per thread), requested first: see gae_lookback_kernel
-    const int64_t lt0 = (int64_t)(chunk + 1) * GAE_BLOCK + threadIdx.x;
-    const bool l_ok = chunk + 1 < n_blocks && lt0 < n;
-    float l_r = 0.f, l_d = 0.f, l_t = 0.f, l_v = 0.f, l_v1 = 0.f;
-    if (l_ok) {
-        l_r = rews[lt0];
-        l_d = dones[lt0];
-        l_t = trunc[lt0];
-        l_v = values[lt0];
-        l_v1 = values[lt0 + 1];
-    }
-    float r[GAE_ROWS][4], d[GAE_ROWS][4], tr[GAE_ROWS][4], v[GAE_ROWS][5];
-    if (tb + (GAE_ROWS - 1) * ROW_STEPS + 4 <= n) {  // ONE branch for all rows: every row's loads are requested together
+    const int64_t wbase = ((int64_t)chunk * GAE_THREADS + wave * 64) * GAE_EPT;  // first step of this wave
+    const bool full_wave = STORE_T && wbase + WAVE_SPAN <= n;                     // (wave-uniform)
+    // [r4] The outputs leave LANE-CONTIGUOUS.  As the scan holds them a wave-instruction would store 64 x 16 bytes at a 32-byte
+    // stride -- half of each of sixteen 128-byte lines, the other halves one instruction later -- and on data that streams from
+    // and to HBM (not the Infinity-Cache-resident re-scan rounds 1-3 timed) it is the STORE shape that costs: same seven streams,
+    // no scan, 8-consecutive loads: 14.9 us with 8-consecutive stores, 13.4 us with lane-contiguous ones; the load shape changes
+    // nothing (14.9 us; profiles/r04_gae_floor.txt).  Each wave transposes its 512 steps per output through 2 KiB of its own LDS
+    // (in-wave: the LDS operations of a wave execute in order, no workgroup barrier) and stores 1 KiB of contiguous bytes per
+    // instruction.  A group of four steps goes to LDS as soon as it is formed (12 live output registers, not 24).
+    float *o = o_lds + (STORE_T ? wave * (3 * WAVE_SPAN) : 0);
 #pragma unroll
-        for (int h = 0; h < GAE_ROWS; ++h) {
-            const int64_t t = tb + h * ROW_STEPS;
-            const f4 r4 = *reinterpret_cast<const f4 *>(rews + t);
-            const f4 d4 = *reinterpret_cast<const f4 *>(dones + t);
-            const f4 t4 = *reinterpret_cast<const f4 *>(trunc + t);
-            const f4 v4 = *reinterpret_cast<const f4 *>(values + t);
-            v[h][4] = values[t + 4];  // (t + 4 <= n and values holds n + 1 entries)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                r[h][j] = r4[j];
-                d[h][j] = d4[j];
-                tr[h][j] = t4[j];
-                v[h][j] = v4[j];
-            }
-        }
-    } else {  // the ragged end of the data: element by element
-#pragma unroll
-        for (int h = 0; h < GAE_ROWS; ++h) {
-            const int64_t t = tb + h * ROW_STEPS;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const bool ok = t + j < n;
-                r[h][j] = ok ? rews[t + j] : 0.f;
-                d[h][j] = ok ? dones[t + j] : 0.f;
-                tr[h][j] = ok ? trunc[t + j] : 0.f;
-                v[h][j] = ok ? values[t + j] : 0.f;
-            }
-            v[h][4] = 0.f;
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                if (t + j + 1 <= n) v[h][j + 1] = values[t + j + 1];
-        }
-    }
-    {   // the window's composite while the chunk's own loads are still in flight
-        Aff2 l1 = aff_identity();
-        if (l_ok) l1 = step_affine(l_r, l_d, l_t, l_v, l_v1, p);
-        const Aff2 ls = wave_suffix_scan(l1, lane);
-        if (lane == 0) wave_la[wave] = ls;
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    // per-step coefficients: the 0/1 factor nd * nt as one bit per step (bit e, e = h * 4 + j), a "past the end of the data" marker
-    // (bit 16 + e: identity step); b goes to LDS as it is formed.  The flags are exactly 0.0 / 1.0 (launch_gae's contract).
-    unsigned mbits = 0;
-    Aff2 mine[GAE_ROWS];
-#pragma unroll
-    for (int h = 0; h < GAE_ROWS; ++h) {
-        const int64_t t = tb + h * ROW_STEPS;
-        double bq[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int e = h * 4 + j;
-            // selects, no branches: a step past the end of the data was loaded as zeros (the return recurrence adds r = 0) and gets
-            // b = 0 and its marker
-            const bool ok = t + j < n;
-            const float nd = 1.0f - d[h][j], nt = 1.0f - tr[h][j];
-            const float rn = p.use_std ? fminf(fmaxf(r[h][j] / p.ret_std, -10.f), 10.f) : r[h][j];
-            // ((double)rn + gamma * (double)V_{t+1} * nd) - (double)V_t: the reference's operation order
-            bq[j] = ok ? ((double)rn + p.gamma * (double)v[h][j + 1] * (double)nd) - (double)v[h][j] : 0.0;  // (V_n sits in the first step past the end)
-            b_lds[e * GAE_THREADS + threadIdx.x] = bq[j];
-            v_lds[e * GAE_THREADS + threadIdx.x] = v[h][j];
-            mbits |= (ok ? ((float)((double)nd * (double)nt) != 0.f ? 1u : 0u) : 0x10000u) << e;
-        }
-        Aff2 c = aff_identity();
-#pragma unroll
-        for (int j = 3; j >= 0; --j) {  // right to left: c <- step_j o c
-            const int e = h * 4 + j;
-            const bool ident = (mbits >> (16 + e)) & 1u, open = (mbits >> e) & 1u;
-            const double aa = ident ? 1.0 : (open ? p.gl : 0.0), ar = ident ? 1.0 : (open ? p.gamma : 0.0);
-            c.b = bq[j] + aa * c.b;
-            c.a = aa * c.a;
-            c.d = (double)r[h][j] + ar * c.d;
-            c.c = ar * c.c;
-        }
-        mine[h] = c;
-    }
-    // Who will ever read this chunk's records?  Only the chunk to the left, and only if its look-ahead over OUR first LOOKAHEAD
-    // (= ROW_STEPS) steps -- row 0 of wave 0 -- finds no trajectory end.  Tested per 4-step composite (exactly zero iff one of its
-    // steps ends a trajectory), as the 8-consecutive form tests per thread.
-    static_assert(LOOKAHEAD == ROW_STEPS, "the left neighbour's look-ahead window = row 0 of wave 0");
-    const bool prefix_open = wave != 0 || (__ballot(mine[0].a == 0.0 && mine[0].c == 0.0) == 0ull);
-    Aff2 inc[GAE_ROWS];
-#pragma unroll
-    for (int h = 0; h < GAE_ROWS; ++h) inc[h] = mine[h];
-    wave_suffix_scan_rows<GAE_ROWS>(inc, lane);  // independent chains, interleaved level by level
-    Aff2 rows_right[GAE_ROWS];  // composite of the rows to the right of row h inside this wave (row totals sit in lane 0)
-    rows_right[GAE_ROWS - 1] = aff_identity();
-#pragma unroll
-    for (int h = GAE_ROWS - 2; h >= 0; --h) rows_right[h] = compose(readlane_aff(inc[h + 1], 0), rows_right[h + 1]);
-    if (lane == 0) wave_tot[wave] = compose(inc[0], rows_right[0]);
-    __syncthreads();
-    const Aff2 agg = compose(compose(wave_tot[0], wave_tot[1]), compose(wave_tot[2], wave_tot[3]));
-    u64 *rec = state + (size_t)chunk * LB_STRIDE;
-    resolve_carry(chunk, n_blocks, n, lane, wave, wave_la, agg, prefix_open, rec, state, tag, tag, spin_limit, slow_word, s_carry);
-    __syncthreads();  // publishes s_carry
-    Aff2 waves_right = aff_identity();
-    for (int w = 3; w > wave; --w) waves_right = compose(wave_tot[w], waves_right);
-    const double xw_adv = waves_right.b + waves_right.a * s_carry[0];  // x at the first step to the right of this wave
-    const double xw_ret = waves_right.d + waves_right.c * s_carry[1];
-#pragma unroll
-    for (int h = 0; h < GAE_ROWS; ++h) {
-        const int64_t t = tb + h * ROW_STEPS;
-        const double xr_adv = rows_right[h].b + rows_right[h].a * xw_adv;  // x at the first step to the right of this row
-        const double xr_ret = rows_right[h].d + rows_right[h].c * xw_ret;
-        Aff2 after = shfl_down_aff(inc[h], 1);  // lanes lane + 1 .. 63 of this row
-        if (lane == 63) after = aff_identity();
-        double x_adv = after.b + after.a * xr_adv;
-        double x_ret = after.d + after.c * xr_ret;
-        float o_adv[4], o_vt[4], o_ret[4];
+    for (int h = GAE_EPT / 4 - 1; h >= 0; --h) {
+        f4 q_adv, q_vt, q_ret;
 #pragma unroll
         for (int j = 3; j >= 0; --j) {
-            const int e = h * 4 + j;
-            const bool ident = (mbits >> (16 + e)) & 1u, open = (mbits >> e) & 1u;
-            x_adv = b_lds[e * GAE_THREADS + threadIdx.x] + (ident ? 1.0 : (open ? p.gl : 0.0)) * x_adv;
-            x_ret = (double)r[h][j] + (ident ? 1.0 : (open ? p.gamma : 0.0)) * x_ret;
-            o_adv[j] = (float)x_adv;
-            o_vt[j] = (float)((double)v_lds[e * GAE_THREADS + threadIdx.x] + x_adv);
-            o_ret[j] = (float)x_ret;
+            const int e = 4 * h + j;
+            x_adv = s.b_adv[e] + coef_adv(s, e, p) * x_adv;
+            x_ret = (double)s.r[e] + coef_ret(s, e, p) * x_ret;
+            q_adv[j] = (float)x_adv;
+            q_vt[j] = (float)((double)s.v[e] + x_adv);
+            q_ret[j] = (float)x_ret;
         }
-        if (t + 4 <= n) {
-            *reinterpret_cast<f4 *>(adv_out + t) = f4{o_adv[0], o_adv[1], o_adv[2], o_adv[3]};
-            *reinterpret_cast<f4 *>(vt_out + t) = f4{o_vt[0], o_vt[1], o_vt[2], o_vt[3]};
-            *reinterpret_cast<f4 *>(ret_out + t) = f4{o_ret[0], o_ret[1], o_ret[2], o_ret[3]};
+        if (full_wave) {
+            *reinterpret_cast<f4 *>(o + lane * GAE_EPT + 4 * h) = q_adv;
+            *reinterpret_cast<f4 *>(o + WAVE_SPAN + lane * GAE_EPT + 4 * h) = q_vt;
+            *reinterpret_cast<f4 *>(o + 2 * WAVE_SPAN + lane * GAE_EPT + 4 * h) = q_ret;
+        } else if (t0 + GAE_EPT <= n) {
+            *reinterpret_cast<f4 *>(adv_out + t0 + 4 * h) = q_adv;
+            *reinterpret_cast<f4 *>(vt_out + t0 + 4 * h) = q_vt;
+            *reinterpret_cast<f4 *>(ret_out + t0 + 4 * h) = q_ret;
         } else {
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                if (t + j < n) {
-                    adv_out[t + j] = o_adv[j];
-                    vt_out[t + j] = o_vt[j];
-                    ret_out[t + j] = o_ret[j];
+                if (t0 + 4 * h + j < n) {
+                    adv_out[t0 + 4 * h + j] = q_adv[j];
+                    vt_out[t0 + 4 * h + j] = q_vt[j];
+                    ret_out[t0 + 4 * h + j] = q_ret[j];
                 }
         }
     }
-    __syncthreads();  // LDS is reused by the next round
+    if (full_wave) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int h = 0; h < GAE_EPT / 4; ++h) {
+            const int k = h * 256 + lane * 4;
+            *reinterpret_cast<f4 *>(adv_out + wbase + k) = *reinterpret_cast<const f4 *>(o + k);
+            *reinterpret_cast<f4 *>(vt_out + wbase + k) = *reinterpret_cast<const f4 *>(o + WAVE_SPAN + k);
+            *reinterpret_cast<f4 *>(ret_out + wbase + k) = *reinterpret_cast<const f4 *>(o + 2 * WAVE_SPAN + k);
+        }
+    }
+    __syncthreads();  // LDS (lds4, wave_tot, s_carry, o_lds) is reused by the next round
     }
 }
 
 static int g_gae_oversubscribe = 0;  // rlppo_dbg_set(22, 0/1)
 void set_gae_oversubscribe(int v) { g_gae_oversubscribe = v; }
-static int g_gae_algo = 2;  // 2 = single pass, rows form (default [r4]); 1 = single pass, 8 consecutive steps per thread; 0 = two launches
+static int g_gae_algo = 1;  // 1 = single-pass look-back (default), 0 = two launches (summary + apply)
 void set_gae_algo(int a) { g_gae_algo = a; }
 static unsigned g_gae_spin_limit = LB_SPIN_LIMIT;  // rlppo_dbg_set(21, v): tests set 0 to force the timeout path
 void set_gae_spin_limit(int v) { g_gae_spin_limit = v < 0 ? LB_SPIN_LIMIT : (unsigned)v; }
@@ -805,8 +623,7 @@ int launch_gae(hipStream_t st, const float *rews, const float *dones, const floa
         }
         unsigned tag = g_tag.fetch_add(1, std::memory_order_relaxed) + 1;
         if (tag == 0) tag = g_tag.fetch_add(1, std::memory_order_relaxed) + 1;
-        auto *kern = g_gae_algo == 2 ? (grid == nb ? gae_rows_kernel<false> : gae_rows_kernel<true>)
-                                     : (grid == nb ? gae_lookback_kernel<false> : gae_lookback_kernel<true>);
+        auto *kern = grid == nb ? gae_lookback_kernel<false> : gae_lookback_kernel<true>;
         hipLaunchKernelGGL(kern, dim3(grid), dim3(GAE_THREADS), 0, st, rews, dones, trunc, values, n, p, state, tag, g_gae_spin_limit,
                            hdr + 1, nb, vt, adv, ret);
         RLPPO_LAUNCH_CHECK();

@@ -1,5 +1,7 @@
 // optim.hip -- parameter-side kernels: packing the flat arena into tile-padded W / W^T / b, observation row
 // padding (+ the reference's scalar standardisation), gradient-norm clip + Adam on the flat arena.
+#include <atomic>
+
 #include "common.hpp"
 
 namespace rlppo {
@@ -523,9 +525,14 @@ __global__ __launch_bounds__(256) void adam_pack2_kernel(OptPair o) {
 // atomically accumulated doubles are not), publishes the totals to the nets' gnorm2 outputs, re-arms the counter and opens the
 // barrier (generation word).  While they wait the others already hold the Adam operands of their first elements in registers.
 // Agent-scope atomics only on the words that cross workgroups (cdna_hip_programming.md Guideline 16); the block needs no
-// per-launch memset: it is zeroed ONCE by its owner and every completed launch leaves it armed.  All workgroups are co-resident
-// (at most one of 256 threads per CU, no LDS to speak of); the spin is bounded, and a wait that gives up counts itself in the
-// block's timeout word and poisons that network's step with NaN (PPOLearner.learn reads the word back with its report and raises).
+// per-launch memset: it is zeroed ONCE by its owner and every completed launch leaves it armed.  All workgroups must be
+// co-resident: the grid is clamped per device to (occupancy x CUs - one workgroup per CU of margin) / 2 per network and to
+// FUSED_MAX_BLOCKS (launch_clip_adam_pack2; below one workgroup the three-operation form runs instead).
+// [r4] A wait that gives up is ALL OR NOTHING and leaves no NaN behind: opening the barrier and giving up are both compare-and-swaps
+// on the generation word (g0 -> g0 + 1 | g0 -> FUSED_DEAD), so exactly one of them happens; after FUSED_DEAD every workgroup of this
+// launch -- waiting, arriving late, or the last arriver itself -- skips its update: parameters, moments and gradients of BOTH
+// networks stay as they were, the block's timeout word counts the event, and every later launch on that block skips at once
+// until its owner has zeroed it again.  (Round 3 poisoned the step with NaN, which could not be recovered from: advisor finding.)
 struct FusedSync {
     unsigned count, gen, timeouts, pad[13];  // 64-byte header
     double slot[2][512];                     // per network, per workgroup: partial sum of squares of this launch
@@ -535,6 +542,11 @@ constexpr int FUSED_EPT = 6;                    // elements per thread whose ope
 constexpr int FUSED_MAX_BLOCKS = 128;           // per network: 256 workgroups per launch, so that even 8 processes sharing one GPU (the
                                                 // gloo tests) keep every launch's grid co-resident (2048 workgroup slots of 256 threads)
 constexpr unsigned FUSED_SPIN_LIMIT = 1u << 22;  // x (s_sleep 8 + one L2 round trip) ~ seconds
+constexpr unsigned FUSED_DEAD = 0xFFFFFFFFu;     // generation word of a block whose barrier was given up (sticky until re-zeroed)
+static unsigned g_fused_spin_limit = FUSED_SPIN_LIMIT;  // rlppo_dbg_set(34, v): tests force the give-up path with 0
+void set_fused_spin_limit(int v) { g_fused_spin_limit = v < 0 ? FUSED_SPIN_LIMIT : (unsigned)v; }
+static int g_fused_test_hold = 0;  // rlppo_dbg_set(35, 1): test hook -- workgroup (0, 0) never arrives (a grid that is not co-resident)
+void set_fused_test_hold(int v) { g_fused_test_hold = v; }
 
 __device__ __forceinline__ void adam_one(const OptNet &N, int64_t i, float gi, float mi, float vi, float p0, float coef) {
     gi *= coef;
@@ -559,7 +571,7 @@ __device__ __forceinline__ void adam_one(const OptNet &N, int64_t i, float gi, f
     }
 }
 
-__global__ __launch_bounds__(256) void adam_fused_kernel(OptPair o, FusedSync *__restrict__ sy) {
+__global__ __launch_bounds__(256) void adam_fused_kernel(OptPair o, FusedSync *__restrict__ sy, const unsigned spin_limit, const int test_hold) {
     const int k = blockIdx.y, tid = threadIdx.x;
     const OptNet &N = o.net[k];
     const unsigned nblocks = gridDim.x * gridDim.y;
@@ -589,28 +601,50 @@ __global__ __launch_bounds__(256) void adam_fused_kernel(OptPair o, FusedSync *_
     for (int s = 32; s > 0; s >>= 1) acc += __shfl_xor(acc, s);
     __shared__ double red[4];
     __shared__ float s_total;
-    __shared__ int s_last;
+    __shared__ int s_last, s_ok;
+    __shared__ unsigned s_g0;
     if ((tid & 63) == 0) red[tid >> 6] = acc;
     __syncthreads();
-    bool ok = true;
     if (tid == 0) {
+        int ok = 1, last = 0;
         const unsigned g0 = __hip_atomic_load(&sy->gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // read BEFORE arriving
-        __hip_atomic_store(&sy->slot[k][blockIdx.x], (red[0] + red[1]) + (red[2] + red[3]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        // arrival: the release half orders our slot before the count, the acquire half lets the last arriver see everybody's
-        const unsigned old = __hip_atomic_fetch_add(&sy->count, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-        s_last = old == nblocks - 1;
-        if (!s_last) {
-            unsigned spins = 0;
-            while (__hip_atomic_load(&sy->gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == g0) {
-                __builtin_amdgcn_s_sleep(8);
-                if (++spins > FUSED_SPIN_LIMIT) {
-                    __hip_atomic_fetch_add(&sy->timeouts, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    ok = false;
-                    break;
+        s_g0 = g0;
+        if (g0 == FUSED_DEAD) {  // an earlier launch on this block gave up and its owner has not re-zeroed it: nothing to wait for
+            ok = 0;
+            if (blockIdx.x == 0 && k == 0) __hip_atomic_fetch_add(&sy->timeouts, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else if (test_hold && blockIdx.x == 0 && k == 0) {
+            // test hook: this workgroup behaves like one that was never scheduled while the others wait -- it does not arrive; it
+            // only watches the generation word until the waiters have given up, so that the launch ends
+            while (__hip_atomic_load(&sy->gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == g0) __builtin_amdgcn_s_sleep(8);
+            ok = 0;
+        } else {
+            __hip_atomic_store(&sy->slot[k][blockIdx.x], (red[0] + red[1]) + (red[2] + red[3]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // arrival: the release half orders our slot before the count, the acquire half lets the last arriver see everybody's
+            const unsigned old = __hip_atomic_fetch_add(&sy->count, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+            last = old == nblocks - 1;
+            if (!last) {
+                unsigned spins = 0, cur;
+                while ((cur = __hip_atomic_load(&sy->gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == g0) {
+                    __builtin_amdgcn_s_sleep(8);
+                    if (++spins > spin_limit) {
+                        // give up -- unless the barrier opens in this very moment: ONE compare-and-swap decides for the whole launch
+                        unsigned expect = g0;
+                        if (__hip_atomic_compare_exchange_strong(&sy->gen, &expect, FUSED_DEAD, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                                 __HIP_MEMORY_SCOPE_AGENT)) {
+                            __hip_atomic_fetch_add(&sy->timeouts, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            cur = FUSED_DEAD;
+                        } else {
+                            cur = expect;  // somebody else decided first: opened (g0 + 1) or dead
+                        }
+                        break;
+                    }
                 }
+                ok = cur != FUSED_DEAD;
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             }
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         }
+        s_last = last;
+        s_ok = ok;
     }
     __syncthreads();
     if (s_last) {  // the whole workgroup adds the slots: thread t takes slots t, t + 256 of each network; fixed tree afterwards
@@ -629,18 +663,22 @@ __global__ __launch_bounds__(256) void adam_fused_kernel(OptPair o, FusedSync *_
                 __hip_atomic_store(o.net[j].gnorm2, (part[j][0] + part[j][1]) + (part[j][2] + part[j][3]), __ATOMIC_RELAXED,
                                    __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(&sy->count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_fetch_add(&sy->gen, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);  // opens the barrier
+            // opens the barrier -- unless a waiter gave up first (then nobody updates, this workgroup included)
+            unsigned expect = s_g0;
+            const unsigned next = s_g0 + 1 == FUSED_DEAD ? 0u : s_g0 + 1;
+            s_ok = __hip_atomic_compare_exchange_strong(&sy->gen, &expect, next, __ATOMIC_RELEASE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
     if (tid == 0) {
         const double t = __hip_atomic_load(N.gnorm2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        s_total = ok ? (float)sqrt(t) : __builtin_nanf("");
+        s_total = (float)sqrt(t);
     }
     __syncthreads();
+    if (!s_ok) return;  // given up: parameters, moments and gradients stay as they were (the timeout word says so)
     // ---- phase 2: adam_pack2_kernel, element for element
     const float total = s_total;
     float coef = N.max_norm / (total + 1e-6f);
-    coef = coef > 1.f ? 1.f : coef;   // (a NaN total stays NaN: a timed-out barrier must not pass for an update)
+    coef = coef > 1.f ? 1.f : coef;
 #pragma unroll
     for (int e = 0; e < FUSED_EPT; ++e) {
         const int64_t i = i0 + e * stride;
@@ -676,11 +714,34 @@ int launch_clip_adam_pack2(hipStream_t st, const NetLayout *nets, float *const *
     }
     if (sync_ws) {  // one launch (the caller owns a zero-initialised sync block)
         RLPPO_CHECK_ARG(((uintptr_t)sync_ws & 15) == 0, "clip_adam_pack2: the sync block must be 16-byte aligned");
-        int64_t blocks = cdiv(nmax, 256 * FUSED_EPT);
-        blocks = blocks < 1 ? 1 : (blocks > FUSED_MAX_BLOCKS ? FUSED_MAX_BLOCKS : blocks);
-        hipLaunchKernelGGL(adam_fused_kernel, dim3((unsigned)blocks, 2), dim3(256), 0, st, o, reinterpret_cast<FusedSync *>(sync_ws));
-        RLPPO_LAUNCH_CHECK();
-        return 0;
+        // The grid barrier needs every workgroup of the launch resident at once: per device (queried once for each device id),
+        // workgroups per network <= (occupancy x CUs - one workgroup per CU of margin for kernels of other streams) / 2.  On an
+        // MI355X that is (8 x 256 - 256) / 2 = 896, far above FUSED_MAX_BLOCKS; a small or partitioned device gets a smaller
+        // grid, and one that cannot hold a single workgroup per network the three-operation form below.
+        static std::atomic<int> cap_by_dev[64];
+        int dev = 0;
+        RLPPO_HIP(hipGetDevice(&dev));
+        RLPPO_CHECK_ARG(dev >= 0 && dev < 64, "clip_adam_pack2: device id %d", dev);
+        int cap = cap_by_dev[dev].load(std::memory_order_acquire);
+        if (cap == 0) {
+            int per_cu = 0;
+            hipDeviceProp_t prop;
+            RLPPO_HIP(hipGetDeviceProperties(&prop, dev));
+            RLPPO_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, adam_fused_kernel, 256, 0));
+            per_cu = per_cu > 7 ? 7 : per_cu;  // (the occupancy API over-reports by one in the 8-per-CU regime: MI355X_MICROARCH.md)
+            cap = (per_cu * prop.multiProcessorCount - prop.multiProcessorCount) / 2;
+            cap = cap < 1 ? -1 : cap;
+            cap_by_dev[dev].store(cap, std::memory_order_release);
+        }
+        if (cap >= 1) {
+            int64_t blocks = cdiv(nmax, 256 * FUSED_EPT);
+            blocks = blocks < 1 ? 1 : (blocks > FUSED_MAX_BLOCKS ? FUSED_MAX_BLOCKS : blocks);
+            blocks = blocks > cap ? cap : blocks;
+            hipLaunchKernelGGL(adam_fused_kernel, dim3((unsigned)blocks, 2), dim3(256), 0, st, o, reinterpret_cast<FusedSync *>(sync_ws),
+                               g_fused_spin_limit, g_fused_test_hold);
+            RLPPO_LAUNCH_CHECK();
+            return 0;
+        }
     }
     if (gnorm2[1] == gnorm2[0] + 1 || gnorm2[0] == gnorm2[1] + 1) {  // adjacent accumulators (PPOLearner's): one fill
         RLPPO_HIP(hipMemsetAsync(gnorm2[0] < gnorm2[1] ? gnorm2[0] : gnorm2[1], 0, 2 * sizeof(double), st));

@@ -215,14 +215,19 @@ class Learner(object):
             torch.as_tensor(np.ascontiguousarray(np.asarray(x, dtype=np.float32))).to(dev)
         rews_d, dones_d, trunc_d = up(rewards), up(dones), up(truncated)
         ret_std = self.return_stats.std[0] if self.standardize_returns else None
-        value_targets, advantages, returns = torch_functions.gae_device(
+        value_targets, advantages, returns, gae_timeouts = torch_functions.gae_device_deferred(
             rews_d, dones_d, trunc_d, val_preds, gamma=self.gae_gamma, lmbda=self.gae_lambda, return_std=ret_std)
 
+        # ONE device-to-host read per call: the scan's timeout counter travels with the min(150, N) returns the statistics need
+        n_to_increment = min(self.max_returns_per_stats_increment, n) if self.standardize_returns else 0
+        parts = [returns[:n_to_increment]] + ([gae_timeouts.float()] if gae_timeouts is not None else [])
+        host = torch.cat(parts).cpu().numpy()
+        if gae_timeouts is not None:
+            torch_functions.raise_if_timed_out(host[-1])   # GAETimeout: NaN advantages must never reach the buffer
         if self.standardize_returns:
-            n_to_increment = min(self.max_returns_per_stats_increment, n)
-            head = returns[:n_to_increment].cpu().numpy()
-            if np.isnan(head).any():  # rlppo_gae poisons what a timed-out look-back wait would have got wrong (include/rlppo.h)
-                raise RuntimeError("GAE produced NaN returns (look-back timeout or NaN inputs): refusing to train on them")
+            head = host[:n_to_increment]
+            if np.isnan(head).any():
+                raise RuntimeError("GAE produced NaN returns (NaN inputs): refusing to train on them")
             self.return_stats.increment(head, n_to_increment)
 
         self.experience_buffer._d = d_logical  # logical width of the padded rows

@@ -108,6 +108,10 @@ class FusedAdam(torch.optim.Adam):
             self._expose_state()
 
 
+class OptimizerBarrierTimeout(RuntimeError):
+    """The one-launch optimiser tail's grid barrier gave up; see PPOLearner.learn (the learner has already recovered)."""
+
+
 class PPOLearner(object):
     def __init__(self, obs_space_size, act_space_size, policy_type, policy_layer_sizes, critic_layer_sizes,
                  continuous_var_range, batch_size, n_epochs, policy_lr, critic_lr, clip_range, ent_coef, mini_batch_size,
@@ -179,6 +183,7 @@ class PPOLearner(object):
         # in launches that are k times larger.  RLPPO_FUSE=1 keeps one pass per minibatch.
         self.max_fused_minibatches = max(1, int(os.environ.get("RLPPO_FUSE", 8)))
         self.fused_optimizer_step = os.environ.get("RLPPO_FUSED_OPT", "1") != "0"  # rlppo_clip_adam_pack2 (False: FusedAdam.step x2)
+        self.grad_probe = None  # callable(flat [grad_policy | grad_value]) before every optimiser step (tests)
         self.one_launch_optimizer = os.environ.get("RLPPO_OPT_ONE_LAUNCH", "1") != "0"  # ... as ONE launch with a grid barrier
 
     # --------------------------------------------------------------------------------------------- learn
@@ -288,6 +293,8 @@ class PPOLearner(object):
                     n_minibatch_iterations += n_slices
                     if world > 1:
                         yield self._grad_all  # summed over the ranks (RCCL over xGMI) before clipping
+                    if self.grad_probe is not None:  # test hook: the batch gradient clip_grad_norm_ / Adam are about to see
+                        self.grad_probe(self._grad_all)
                     if self.fused_optimizer_step:
                         # both clip + Adam steps, the re-pack of both weight copies and the next batch's zero_grad: 3 stream
                         # operations instead of 9 (csrc/optim.hip)
@@ -314,9 +321,20 @@ class PPOLearner(object):
         # update magnitudes (ppo_learner.py:214-222: fp32 norms) travel with the statistics: ONE device->host sync per learn()
         mags = torch.stack(((policy_before - pa.flat).norm(), (critic_before - va.flat).norm()))
         stats = torch.cat((self._stats, mags.double(), self._opt_sync[N.OPT_SYNC_TIMEOUT_WORD:N.OPT_SYNC_TIMEOUT_WORD + 1].double())).cpu().numpy()
-        if stats[N.N_STATS + 2] != 0:  # a barrier wait of the fused optimiser step gave up: that step wrote NaN parameters
-            raise RuntimeError("rlppo_clip_adam_pack2: %d grid-barrier wait(s) timed out; the parameters of the affected "
-                               "network are NaN (GPU shared with a kernel that never yields, or a defect)" % int(stats[N.N_STATS + 2]))
+        if stats[N.N_STATS + 2] != 0:
+            # A grid-barrier wait of the one-launch optimiser step gave up (GPU shared with a kernel that never yields, a
+            # partitioned device, or a defect).  Giving up is all or nothing (include/rlppo.h): that step and every later one of
+            # this call were SKIPPED -- parameters and Adam moments are those of the last completed step, finite and consistent on
+            # every rank -- and the gradient arena still holds the skipped batches' sums.  Recover the state a caller can continue
+            # from (zero gradients, a re-armed block, the three-operation form from now on) and report loudly.
+            n_to = int(stats[N.N_STATS + 2])
+            self._grad_all.zero_()
+            self._opt_sync.zero_()
+            self.one_launch_optimizer = False
+            raise OptimizerBarrierTimeout(
+                "rlppo_clip_adam_pack2: the optimiser's grid barrier gave up (%d event(s)); the affected optimiser steps of this "
+                "learn() were skipped -- parameters and Adam state are those of the last completed step, no NaN was written -- "
+                "gradients are zeroed and this learner now uses the three-operation optimiser tail: calling learn() again is safe" % n_to)
         elapsed = time.time() - t1
         n_iter_r = max(n_iterations, 1)
         n_mb_r = max(float(stats[N.STAT_PASSES]), 1.0)

@@ -17,7 +17,9 @@ _ws = {}
 
 
 def _workspace(device, nbytes):
-    key = str(device)
+    # one workspace per (device, stream): the header's timeout counter is cleared and read per call, so two streams (or two
+    # threads on their own streams) running GAE concurrently must not share one (advisor finding, round 3)
+    key = (str(device), torch.cuda.current_stream(device).cuda_stream)
     if key not in _ws:
         _ws[key] = Workspace(device)
     return _ws[key].get(nbytes)
@@ -25,6 +27,38 @@ def _workspace(device, nbytes):
 
 class GAETimeout(RuntimeError):
     """A look-back wait of rlppo_gae gave up: the affected advantages / value targets / returns are NaN (include/rlppo.h)."""
+
+
+def raise_if_timed_out(timeouts):
+    timeouts = int(timeouts)
+    if timeouts:
+        raise GAETimeout(f"rlppo_gae: {timeouts} look-back wait(s) timed out; the outputs of the affected chunks are NaN "
+                         f"and must not be trained on (GPU shared with a long-running kernel, or a defect)")
+
+
+def gae_device_deferred(rews, dones, truncated, values, gamma=0.99, lmbda=0.95, return_std=1):
+    """gae_device without its synchronisation: returns (value_targets, advantages, returns, timeouts) where `timeouts` is a
+    one-element int32 DEVICE tensor -- this call's own snapshot of the workspace header's counter, taken on the stream right
+    behind the scan -- that the caller MUST hand to raise_if_timed_out() once it has the value on the host (e.g. folded into a
+    device-to-host read it performs anyway: Learner.add_new_experience reads it with the first 150 returns).  None under stream
+    capture (the stateless two-launch form runs there and no wait exists)."""
+    n = rews.shape[0]
+    dev = rews.device
+    assert values.shape[0] == n + 1 and dones.shape[0] == n and truncated.shape[0] == n
+    vt = torch.empty(n, dtype=torch.float32, device=dev)
+    adv = torch.empty(n, dtype=torch.float32, device=dev)
+    ret = torch.empty(n, dtype=torch.float32, device=dev)
+    if n == 0:
+        return vt, adv, ret, None
+    std = float("nan") if return_std is None else float(np.float32(return_std))
+    ws = _workspace(dev, N.lib().rlppo_gae_workspace_bytes(n))
+    capturing = torch.cuda.is_current_stream_capturing()
+    hdr = ws[:16].view(torch.int32)
+    if not capturing:
+        hdr.zero_()  # word 1 = look-back waits that timed out (a grown / recycled workspace holds anything)
+    N.check(N.lib().rlppo_gae(stream_ptr(), ptr(rews), ptr(dones), ptr(truncated), ptr(values), n, float(gamma),
+                              float(lmbda), std, ptr(vt), ptr(adv), ptr(ret), ptr(ws), ws.numel()))
+    return vt, adv, ret, (None if capturing else hdr[1:2].clone())
 
 
 def gae_device(rews, dones, truncated, values, gamma=0.99, lmbda=0.95, return_std=1, check=True):
@@ -35,30 +69,12 @@ def gae_device(rews, dones, truncated, values, gamma=0.99, lmbda=0.95, return_st
     workgroups publish; if a wait ever gives up the kernel poisons that chunk's outputs with NaN and counts the event in the
     workspace header.  That must never reach the buffer silently (NaN advantages -> Adam -> the weights are gone), so the
     counter is cleared before the launch and read back after it -- one 4-byte read-back, the only synchronisation of this
-    call -- and a non-zero count raises GAETimeout for EVERY caller (compute_gae, Learner.add_new_experience, user code),
-    whatever part of the outputs the caller looks at.  check=False leaves the call asynchronous (timing loops; under stream
-    capture, where the stateless two-launch form runs and no wait exists, the check is skipped by itself)."""
-    n = rews.shape[0]
-    dev = rews.device
-    assert values.shape[0] == n + 1 and dones.shape[0] == n and truncated.shape[0] == n
-    vt = torch.empty(n, dtype=torch.float32, device=dev)
-    adv = torch.empty(n, dtype=torch.float32, device=dev)
-    ret = torch.empty(n, dtype=torch.float32, device=dev)
-    if n == 0:
-        return vt, adv, ret
-    std = float("nan") if return_std is None else float(np.float32(return_std))
-    ws = _workspace(dev, N.lib().rlppo_gae_workspace_bytes(n))
-    check = check and not torch.cuda.is_current_stream_capturing()
-    hdr = ws[:16].view(torch.int32)
-    if check:
-        hdr.zero_()  # word 1 = look-back waits that timed out (a grown / recycled workspace holds anything)
-    N.check(N.lib().rlppo_gae(stream_ptr(), ptr(rews), ptr(dones), ptr(truncated), ptr(values), n, float(gamma),
-                              float(lmbda), std, ptr(vt), ptr(adv), ptr(ret), ptr(ws), ws.numel()))
-    if check:
-        timeouts = int(hdr[1].item())
-        if timeouts:
-            raise GAETimeout(f"rlppo_gae: {timeouts} look-back wait(s) timed out; the outputs of the affected chunks are NaN "
-                             f"and must not be trained on (GPU shared with a long-running kernel, or a defect)")
+    call -- and a non-zero count raises GAETimeout for EVERY caller (compute_gae, user code), whatever part of the outputs the
+    caller looks at.  check=False leaves the call asynchronous (timing loops); a caller with a device-to-host read of its own
+    uses gae_device_deferred and folds the counter into it (Learner.add_new_experience)."""
+    vt, adv, ret, timeouts = gae_device_deferred(rews, dones, truncated, values, gamma, lmbda, return_std)
+    if check and timeouts is not None:
+        raise_if_timed_out(timeouts.item())
     return vt, adv, ret
 
 

@@ -178,10 +178,13 @@ def _ref_cfg3(fuse):
     """The 1-rank update of the configs[3] workload with `fuse` minibatches per pass (8: one 524,288-row pass per optimiser step,
     the one-GPU default; 1: eight 65,536-row passes accumulating into .grad, the reference's own structure, ppo_learner.py:134-193)."""
     import contextlib
+    grads = []
     with contextlib.redirect_stdout(open(os.devnull, "w")):
         ref, ref_buf = _build_cfg3()
         ref.max_fused_minibatches = fuse
+        ref.grad_probe = lambda g: grads.append(g.detach().cpu().clone()) if len(grads) < 2 else None
         report = ref.learn(ref_buf)
+    _ref_cfg3.grads = grads  # the first two optimiser steps' batch gradients (before clip + Adam)
     out = (ref.policy.arena.flat.cpu(), ref.value_net.arena.flat.cpu(), report, ref._fused_rows)
     del ref, ref_buf
     torch.cuda.empty_cache()
@@ -227,10 +230,12 @@ def _worker_cfg3(rank, world, port, out):
     import contextlib
     import torch.distributed as dist
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    grads = []
     with contextlib.redirect_stdout(open(os.devnull, "w")):
         learner, buf = _build_cfg3()
+        learner.grad_probe = lambda g: grads.append(g.detach().cpu().clone()) if len(grads) < 2 else None
         report = learner.learn(buf)
-    out[rank] = (learner.policy.arena.flat.cpu(), learner.value_net.arena.flat.cpu(), report, learner._fused_rows)
+    out[rank] = (learner.policy.arena.flat.cpu(), learner.value_net.arena.flat.cpu(), report, learner._fused_rows, grads)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -244,9 +249,18 @@ def test_configs3_shape_four_process_ranks():
     mgr = mp.Manager()
     out = mgr.dict()
     mp.spawn(_worker_cfg3, args=(4, _free_port(), out), nprocs=4, join=True)
+    ref_grads = _ref_cfg3.grads
     for rank in range(4):
-        p, v, report, rows = out[rank]
+        p, v, report, rows, grads = out[rank]
         assert rows == 131072
+        # The exchange itself, held tightly (advisor finding, round 3: the parameter comparison below is loose by necessity): the
+        # batch gradient every rank hands to clip + Adam -- the gloo sum of the four ranks' passes -- against the 1-rank run's, for
+        # the first optimiser step (same parameters on both sides) and the second (parameters already through one Adam step
+        # each).  A dealing or scaling slip of a percent would be 1e-2 here; summation order is worth ~1e-6.
+        for step, (g, rg) in enumerate(zip(grads, ref_grads)):
+            err = ((g - rg).abs().max() / rg.abs().max()).item()
+            print(f"[exchange] rank {rank} step {step}: reduced gradient vs 1-rank gradient: {err:.2e} of max|g|")
+            assert err < (5e-6 if step == 0 else 5e-4), (rank, step, err)
         # the four partial gradients are the 1-rank run's own, bit for bit; gloo adds them in another order than the 1-rank run's
         # accumulation into .grad, and Adam turns that into up to a few percent of a step for entries that cancel (_adam_noise)
         _same_update(p, v, report, ref_p, ref_v, ref_report, CFG3["epochs"], tol=float("inf"))

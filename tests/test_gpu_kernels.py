@@ -287,23 +287,20 @@ def run_gae(L, rews, dones, trunc, values, gamma, lmbda, std):
     return vt.cpu().numpy(), adv.cpu().numpy(), ret.cpu().numpy()
 
 
-GAE_DEFAULT_FORM = 2
+GAE_DEFAULT_FORM = 1
 
 
-@pytest.fixture(params=[2, 1, 0], ids=["rows", "lookback8", "two_launch"], autouse=False)
+@pytest.fixture(params=[1, 0], ids=["lookback", "two_launch"], autouse=False)
 def gae_algo(L, request):
-    """All GAE implementations are held to the same checks: the single-pass decoupled look-back in its rows form (round 4's
-    default: lane-contiguous float4 rows, two interleaved wave scans) and in the 8-consecutive-steps-per-thread form of rounds
-    1-3, and the two-launch summary + apply form (what a stream capture gets)."""
+    """Both GAE implementations are held to the same checks: single-pass decoupled look-back (default) and the
+    two-launch summary + apply form (what a stream capture gets)."""
     check(L, L.rlppo_dbg_set(1, request.param))
     yield request.param
     check(L, L.rlppo_dbg_set(1, GAE_DEFAULT_FORM))
 
 
-@pytest.mark.parametrize("form", [2, 1], ids=["rows", "lookback8"])
-def test_gae_lookback_stress_repeated(L, form):
+def test_gae_lookback_stress_repeated(L):
     # the look-back hand-off is timing dependent: repeat a many-chunk scan and demand bit-identical outputs every time
-    check(L, L.rlppo_dbg_set(1, form))
     rews, dones, trunc, values = synth_gae(8192, 256, seed=5, p_mid=0.0)
     dones[:] = 0
     trunc[:] = 0           # no trajectory ends at all: every chunk must chain through ALL chunks to its right
@@ -315,28 +312,27 @@ def test_gae_lookback_stress_repeated(L, form):
         again = run_gae(L, rews, dones, trunc, values, 0.999, 0.999, None)
         for a, b in zip(ref, again):
             assert np.array_equal(a, b)
-    check(L, L.rlppo_dbg_set(1, GAE_DEFAULT_FORM))
 
 
-def test_gae_forms_agree_bitwise_on_ragged_sizes(L):
-    """The rows form and the 8-consecutive form compose the same float64 maps in different association orders; both round once at
-    the store.  They agree to the last float32 bit or one ulp of it, on sizes that exercise the ragged tail of every row / lane
-    position (n mod 4, mod 256, mod 512, mod 2048 all non-zero) and the general look-back path (no trajectory end for long runs)."""
-    for n, p_mid in ((1, 0.0), (3, 0.0), (255, 0.01), (257, 0.0), (515, 0.02), (2047, 0.0), (2049, 0.0), (4099, 0.001), (70001, 0.0005), (300007, 0.0)):
+def test_gae_forms_agree_on_ragged_sizes(L):
+    """The single-pass and the two-launch form compose the same float64 maps in different association orders; both round once at
+    the store.  They agree to the last float32 bit or one ulp of it, on sizes that exercise the ragged tail of every lane / wave /
+    chunk position (n mod 4, mod 8, mod 512, mod 2048 all non-zero: full waves leave through the LDS transpose, a ragged wave
+    element by element) and the general look-back path (no trajectory end for long runs)."""
+    for n, p_mid in ((1, 0.0), (3, 0.0), (255, 0.01), (257, 0.0), (515, 0.02), (1030, 0.0), (2047, 0.0), (2049, 0.0), (4099, 0.001), (70001, 0.0005), (300007, 0.0)):
         rs = np.random.RandomState(n)
         rews, values = rs.randn(n).astype(np.float32), rs.randn(n + 1).astype(np.float32)
         dones = (rs.rand(n) < p_mid).astype(np.float32)
         trunc = ((rs.rand(n) < p_mid) & (dones == 0)).astype(np.float32)
         outs = {}
-        for form in (2, 1, 0):
+        for form in (1, 0):
             check(L, L.rlppo_dbg_set(1, form))
             outs[form] = run_gae(L, rews, dones, trunc, values, 0.995, 0.97, 1.3)
         check(L, L.rlppo_dbg_set(1, GAE_DEFAULT_FORM))
         o = ogae.gae(rews, dones, trunc, values, 0.995, 0.97, 1.3, "f64")
         for k in range(3):
-            np.testing.assert_allclose(outs[2][k], np.asarray(o[k], np.float32), rtol=2e-6, atol=2e-6, err_msg=f"n={n} out {k}")
-            np.testing.assert_allclose(outs[2][k], outs[1][k], rtol=3e-7, atol=1e-6, err_msg=f"n={n} out {k}")
-            np.testing.assert_allclose(outs[2][k], outs[0][k], rtol=3e-7, atol=1e-6, err_msg=f"n={n} out {k}")
+            np.testing.assert_allclose(outs[1][k], np.asarray(o[k], np.float32), rtol=2e-6, atol=2e-6, err_msg=f"n={n} out {k}")
+            np.testing.assert_allclose(outs[1][k], outs[0][k], rtol=3e-7, atol=1e-6, err_msg=f"n={n} out {k}")
 
 
 def test_gae_golden_vectors(L, golden, gae_algo):
@@ -1092,3 +1088,53 @@ def test_clip_adam_pack2_equals_separate_launches(L, one_launch):
         assert w[0] == 0 and w[1] == 5 and w[2] == 0, w[:4]
     bad = N.OptNet()
     assert L.rlppo_clip_adam_pack2(stream(), ctypes.byref(bad), ctypes.byref(descs[1][0]), P(sync)) != 0
+    if not one_launch:
+        return
+    # A barrier wait that gives up is ALL OR NOTHING (advisor finding, round 3: it used to write NaN).  rlppo_dbg_set(35, 1) keeps one
+    # workgroup from ever arriving (a grid that is not co-resident), rlppo_dbg_set(34, 0) makes the waiters give up at once: no
+    # element of either network changes, gradients included; the block counts the event and is dead -- the next call on it skips
+    # too -- until its owner zeroes it; after that, and with the hooks off, the same step goes through and equals the
+    # three-operation form's.
+    snap = lambda: [[st["b"][k].clone() for k in ("p", "m", "v", "packed")] for st in state]
+    for (d, gb), st in zip(descs, state):
+        gb.copy_(torch.randn(st["nf"], device="cuda"))
+        d.step = 6
+    before, g_before = snap(), [gb.clone() for _, gb in descs]
+    check(L, L.rlppo_dbg_set(34, 0))
+    check(L, L.rlppo_dbg_set(35, 1))
+    try:
+        check(L, L.rlppo_clip_adam_pack2(stream(), ctypes.byref(descs[0][0]), ctypes.byref(descs[1][0]), P(sync)))
+        torch.cuda.synchronize()
+    finally:
+        check(L, L.rlppo_dbg_set(35, 0))
+        check(L, L.rlppo_dbg_set(34, -1))
+    w = sync.cpu().numpy()
+    assert w[2] >= 1 and np.uint32(w[1]) == np.uint32(0xFFFFFFFF), w[:4]
+    for b0, b1 in zip(before, snap()):
+        assert all(torch.equal(x, y) for x, y in zip(b0, b1))
+    assert all(torch.equal(g0, gb) for g0, (_, gb) in zip(g_before, descs))
+    assert all(torch.isfinite(st["b"]["p"]).all() for st in state)
+    check(L, L.rlppo_clip_adam_pack2(stream(), ctypes.byref(descs[0][0]), ctypes.byref(descs[1][0]), P(sync)))   # dead block: skips at once
+    torch.cuda.synchronize()
+    assert int(sync[2].item()) > int(w[2])
+    for b0, b1 in zip(before, snap()):
+        assert all(torch.equal(x, y) for x, y in zip(b0, b1))
+    sync.zero_()                                                                                                 # the owner re-arms it
+    ref = []
+    for (d, gb), st in zip(descs, state):  # the three-operation form on copies = what the repeated step must give
+        c = {k: st["b"][k].clone() for k in ("p", "m", "v", "packed")}
+        gc, gn = gb.clone(), torch.zeros(1, dtype=torch.float64, device="cuda")
+        d2 = N.OptNet()
+        d2.dims, d2.n_layers = d.dims, d.n_layers
+        d2.params, d2.grads, d2.exp_avg, d2.exp_avg_sq = c["p"].data_ptr(), gc.data_ptr(), c["m"].data_ptr(), c["v"].data_ptr()
+        d2.packed, d2.gnorm2 = c["packed"].data_ptr(), gn.data_ptr()
+        d2.max_norm, d2.lr, d2.beta1, d2.beta2, d2.eps, d2.step = 0.5, 3e-4, 0.9, 0.999, 1e-8, 6
+        ref.append((d2, c, gc, gn))
+    check(L, L.rlppo_clip_adam_pack2(stream(), ctypes.byref(ref[0][0]), ctypes.byref(ref[1][0]), None))
+    check(L, L.rlppo_clip_adam_pack2(stream(), ctypes.byref(descs[0][0]), ctypes.byref(descs[1][0]), P(sync)))
+    torch.cuda.synchronize()
+    for st, (_, c, _, _), (_, gb) in zip(state, ref, descs):
+        for k in ("p", "m", "v", "packed"):
+            assert torch.equal(st["b"][k], c[k]), k
+        assert (gb == 0).all()
+    assert int(sync[2].item()) == 0

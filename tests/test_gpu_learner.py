@@ -508,3 +508,50 @@ def test_discrete_step_host_and_device_outputs():
     b0, _ = pol.get_action(obs, noise=q, standardize=(0.25, 2.0))
     b1, _ = pol.step(obs, noise=q, standardize=(0.25, 2.0))
     assert torch.equal(b0, b1)
+
+
+@pytest.mark.gpu
+def test_learn_recovers_from_an_optimiser_barrier_that_gives_up():
+    """PPOLearner.learn with the one-launch optimiser tail when its grid barrier gives up (forced with the library's test hooks):
+    the call raises OptimizerBarrierTimeout, parameters and Adam moments are untouched and finite (no NaN, nothing half-applied),
+    gradients are zeroed, the learner has switched to the three-operation tail, and the NEXT learn() on the same buffer gives
+    exactly what a learner that never met the failure gives."""
+    from rlgym_ppo_amd import _native as N
+    from rlgym_ppo_amd.ppo import ExperienceBuffer, PPOLearner
+    from rlgym_ppo_amd.ppo.ppo_learner import OptimizerBarrierTimeout
+    L = N.lib()
+
+    def make():
+        torch.manual_seed(11)
+        np.random.seed(11)
+        lr = PPOLearner(20, 6, 0, (64, 64), (64, 64), (0.1, 1.0), 512, 2, 3e-4, 3e-4, 0.2, 0.005, 256, "cuda:0")
+        rs = np.random.RandomState(3)
+        obs = rs.randn(1024, 20).astype(np.float32)
+        act, logp = lr.policy.get_action(obs, noise=torch.empty(1024, 6).exponential_(1, generator=torch.Generator().manual_seed(5)).cuda())
+        buf = ExperienceBuffer(1024, 7, "cpu")
+        z = np.zeros(1024, np.float32)
+        buf.submit_experience(obs, act.numpy().astype(np.float32), logp.numpy(), z, obs, z, z, rs.randn(1024).astype(np.float32), rs.randn(1024).astype(np.float32))
+        return lr, buf
+
+    a, buf_a = make()
+    b, buf_b = make()
+    flat = lambda lr: torch.cat([torch.nn.utils.parameters_to_vector(lr.policy.parameters()), torch.nn.utils.parameters_to_vector(lr.value_net.parameters())]).clone()
+    p0 = flat(a)
+    assert a.one_launch_optimizer
+    N.check(L.rlppo_dbg_set(34, 0))
+    N.check(L.rlppo_dbg_set(35, 1))
+    try:
+        with pytest.raises(OptimizerBarrierTimeout):
+            a.learn(buf_a)
+    finally:
+        N.check(L.rlppo_dbg_set(35, 0))
+        N.check(L.rlppo_dbg_set(34, -1))
+    assert torch.equal(flat(a), p0) and torch.isfinite(flat(a)).all()
+    assert not a.one_launch_optimizer and int(a._grad_all.abs().sum().item()) == 0 and int(a._opt_sync.abs().sum().item()) == 0
+    # the failed call consumed the buffer's permutations as a completed one would have (same generator on both learners)
+    b.one_launch_optimizer = False
+    buf_b.epoch_indices(); buf_b.epoch_indices()
+    ra, rb = a.learn(buf_a), b.learn(buf_b)
+    assert torch.equal(flat(a), flat(b))
+    for k in ("Policy Entropy", "Mean KL Divergence", "Value Function Loss", "SB3 Clip Fraction"):
+        assert ra[k] == rb[k], k

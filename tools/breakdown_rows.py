@@ -8,9 +8,9 @@ with contextlib.redirect_stdout(sys.stderr):
     learner, buf = bench.build_workload("cuda:0")
 for M in ([int(x) for x in sys.argv[1:]] or [65536, 524288]):
     learner._fused_rows = M
-    rows, dom = bench.kernel_breakdown(learner)
-    tot = sum(r["launches_per_minibatch"] * r["ms_per_launch"] for r in rows)
+    rows, dom, _ = bench.kernel_breakdown(learner)
+    tot = sum(r["n"] * r["ms"] for r in rows)
     print(f"rows per pass {M}:")
     for r in rows:
-        print("  %-46s x%d  %8.4f ms  %7.2f TFLOP/s algorithmic (%.3f of peak)" % (r["kernel"], r["launches_per_minibatch"], r["ms_per_launch"], r["tflops"], r["frac"]))
+        print("  %-46s x%d  %8.4f ms  %7.2f TFLOP/s algorithmic (%.3f of peak)" % (r["kernel"], r["n"], r["ms"], r["tflops"], r["frac"]))
     print("  GEMM launches of one pass, isolated, summed: %.3f ms  (%.3f ms per 65,536 rows)" % (tot, tot * 65536 / M))

@@ -19,7 +19,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
     med = lambda ts: float(np.median(ts)) * 1e3
     line = lambda name, cold, hot: print(f"{name:>110s}: cold {cold:6.2f} us {28 * n / cold / 1e6:5.2f} TB/s ({28 * n / cold / 8e6:.3f} of 8 TB/s) | "
                                          f"hot {hot:6.2f} us ({28 * n / hot / 8e6:.3f})", flush=True)
-    FORMS = {2: "rows form (lane-contiguous float4 rows, two interleaved scans) [r4 default]", 1: "8 consecutive steps per thread (rounds 1-3)"}
+    FORMS = {1: "single launch"}
     res = {(a, o, k): [] for a in FORMS for o in (0, 1) for k in "ch"}
     for _ in range(7):
         for algo in FORMS:
@@ -30,7 +30,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
                 res[(algo, over, "c")].append(bench.time_rotating(fns, 3))
                 assert all(torch.equal(o[1], ref) for _, o in sets)
     N.check(L.rlppo_dbg_set(22, 0))
-    N.check(L.rlppo_dbg_set(1, 2))
+    N.check(L.rlppo_dbg_set(1, 1))
     if not os.environ.get("RLPPO_LIB"):  # once: what the memory system allows for a launch of this size and byte count
         sys.path.insert(0, os.path.join(ROOT, "tools"))
         import _diag
