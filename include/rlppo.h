@@ -315,6 +315,17 @@ int rlppo_exponential_from_words(const uint32_t *words, int64_t n, double lambda
 #define RLPPO_EXP_LINK_HEADER 64
 int rlppo_torch_cpu_exponential_chained(const void *state, int64_t state_bytes, int64_t n, double lambda, float *out, uint32_t *words,
                                         void *link_in, void *link_out);
+/* [r4] A run of chained draws on the calling thread: of a burst of `count` consecutive draws of n values each, the draws first,
+ * first + step, ... (`step` threads share a burst, one call each, first = 0 .. step - 1).  Draw i writes out + i * out_stride floats
+ * and publishes the link block links + i * link_stride bytes, laid out as above with one more word: { int32 ready; int32 done
+ * (1: the values are complete; -1: failed or cancelled); padding to 64 bytes; state }; zero the first 8 bytes of every block
+ * beforehand.  Draw 0 starts from `state` (not modified), or from `link_in0` -- the block an earlier chained call publishes -- when
+ * that is not NULL.  `cancel`: caller-owned int32 read before every draw; non-zero ends the run (remaining draws marked failed).
+ * Values and states are those of `count` consecutive rlppo_torch_cpu_exponential calls.  (engine.HostExponential.prefetch: the
+ * next rollout's noise, drawn while PPOLearner.learn runs -- learner.py:257-270, discrete_policy.py:59.) */
+int rlppo_torch_cpu_exponential_burst(const void *state, void *link_in0, int64_t state_bytes, int64_t n, double lambda, float *out,
+                                      int64_t out_stride, void *links, int64_t link_stride, int32_t first, int32_t step, int32_t count,
+                                      const int32_t *cancel);
 
 /* dst[r][0..width) = src[idx[r]][0..width), fp32 rows, 16 bytes per thread (width, ld_src multiples of 4; dst rows are
  * `width` floats apart).  The minibatch gather of experience_buffer.py:82-87 (used inside rlppo_ppo_minibatch) and the

@@ -105,6 +105,8 @@ SIGNATURES = {
     "rlppo_torch_cpu_exponential_words": (c_int32, [c_void_p, c_int64, c_int64, c_void_p]),
     "rlppo_exponential_from_words": (c_int32, [c_void_p, c_int64, c_double, c_void_p]),
     "rlppo_torch_cpu_exponential_chained": (c_int32, [c_void_p, c_int64, c_int64, c_double, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "rlppo_torch_cpu_exponential_burst": (c_int32, [c_void_p, c_void_p, c_int64, c_int64, c_double, c_void_p, c_int64, c_void_p, c_int64,
+                                                    c_int32, c_int32, c_int32, c_void_p]),
     "rlppo_gather_rows": (c_int32, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int32, c_int64]),
     "rlppo_welford_increment": (c_int32, [c_void_p, c_void_p, c_int64, c_int64, c_int32, c_void_p, c_void_p, c_int64, c_int32]),
     "rlppo_welford_merge": (c_int32, [c_void_p, c_int32, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int32]),

@@ -68,10 +68,17 @@ class VectorAgentManager(object):
     def _standardize_scalars(self):
         if not self.standardize_obs:
             return None
+        key = (id(self.obs_stats), self.obs_stats.count, id(self.obs_stats.running_mean), self.per_feature_obs_standardization)
+        cached = getattr(self, "_scalars_cache", None)
+        if cached is not None and cached[0] == key:   # the statistics have not moved since (they move every 6th step)
+            return cached[1]
         if self.per_feature_obs_standardization:  # device vectors -> rlppo_pad_rows_per_feature
-            return (torch.from_numpy(np.asarray(self.obs_stats.mean, np.float32).reshape(-1).copy()),
-                    torch.from_numpy(np.asarray(self.obs_stats.std, np.float32).reshape(-1).copy()))
-        return float(self.obs_stats.mean[0]), float(self.obs_stats.std[0])
+            out = (torch.from_numpy(np.asarray(self.obs_stats.mean, np.float32).reshape(-1).copy()),
+                   torch.from_numpy(np.asarray(self.obs_stats.std, np.float32).reshape(-1).copy()))
+        else:
+            out = (float(self.obs_stats.mean[0]), float(self.obs_stats.std[0]))
+        self._scalars_cache = (key, out)
+        return out
 
     @torch.no_grad()
     def collect_timesteps(self, n):
@@ -95,25 +102,31 @@ class VectorAgentManager(object):
         S = torch.empty((T + 1, na, ld), dtype=torch.float32, device=dev)     # S[t] = policy-input rows of step t; S[T]: the next collect's
         acts_tm = torch.empty((T, na), dtype=torch.float32, device=dev)
         logp_tm = torch.empty((T, na), dtype=torch.float32, device=dev)
-        rews = np.empty((na, T), np.float32)
-        dones = np.empty((na, T), np.float32)
-        trunc = np.empty((na, T), np.float32)
+        # [r4] the host side of a step is kept as small as the launch: rewards / flags are TIME-major too (row t is one contiguous
+        # write; round 3 wrote three stride-T columns per step) and transposed on the device once per collect; the raw observations
+        # go through a small ring of page-locked staging rows (asynchronous upload: a pageable source is copied synchronously);
+        # the standardisation scalars are recomputed only when the statistics moved; the episode-reward average runs over the
+        # ended agents' values as Python floats (same operations in the same order, no numpy scalar per agent).
+        rdt = np.empty((3, T, na), np.float32)                                # rewards, dones, truncated of step t: rdt[:, t]
         metrics = []
         if self._pending_obs is None:  # first collect: the reset observations are acted on RAW (batched_agent_manager.py:366-384)
             self._pending_obs = (torch.from_numpy(np.ascontiguousarray(self._initial_obs)).to(dev), None)
         obs_dev, scalars = self._pending_obs
+        stage = self._obs_staging(na, arena.d_in)
         for t in range(T):
             a_host, _ = self.policy.step(obs_dev, standardize=scalars, rows_out=S[t], actions_f32=acts_tm[t], logp_out=logp_tm[t],
                                          to_host="actions")
             step = self.env.step(a_host.numpy().astype(np.float32).reshape(na, -1))
             if len(step) == 4:
                 obs, r, d, info = step
-                tr = np.zeros(na, np.float32)
+                tr = 0.0
             else:
                 obs, r, d, tr, info = step
-            obs = np.asarray(obs, dtype=np.float32)
-            obs_dev = torch.from_numpy(np.ascontiguousarray(obs)).to(dev, non_blocking=True)   # raw observations: one upload per step
-            rews[:, t], dones[:, t], trunc[:, t] = r, d, tr
+            pin_t, pin_np = stage[t % len(stage)]   # (reused three steps later: every step ends in a stream synchronisation)
+            np.copyto(pin_np, obs, casting="unsafe")
+            obs_dev = pin_t.to(dev, non_blocking=True)                         # raw observations: one asynchronous upload per step
+            row = rdt[:, t]
+            row[0], row[1], row[2] = r, d, tr
             if self.collect_metrics_fn is not None:
                 metrics.append(self.collect_metrics_fn(info["state"]))
             scalars = self._standardize_scalars()  # fetched BEFORE this step's increment (batched_agent_manager.py:230-235)
@@ -123,21 +136,36 @@ class VectorAgentManager(object):
                     self.steps_since_obs_stats_update = 0
                 else:
                     self.steps_since_obs_stats_update += 1
-            self._track_rewards(rews[:, t], (dones[:, t] + trunc[:, t]) > 0)
+            self._track_rewards(row[0], (row[1] + row[2]) > 0)
         arena.stage_obs(obs_dev, scalars, out=S[T])          # the rows the agents act on next = next_states of the last step
         self._pending_obs = (obs_dev, scalars)
+        if getattr(self.policy, "noise_mode", None) == "host" and hasattr(self.policy, "prefetch_noise"):
+            # the NEXT collect's T draws of the reference's CPU noise stream, produced on the helper threads while the value pass,
+            # the GAE scan and PPOLearner.learn run (none of them touches torch's CPU generator; if anything does, the chain is
+            # dropped at the next draw: engine.HostExponential)
+            self.policy.prefetch_noise(na, T)
         flat = torch.empty((N_ + 1, ld), dtype=torch.float32, device=dev)
         nxt_flat = torch.empty((N_, ld), dtype=torch.float32, device=dev)
         flat[:N_].view(na, T, ld).copy_(S[:T].transpose(0, 1))               # time-major -> trajectory-major, once
         nxt_flat.view(na, T, ld).copy_(S[1:].transpose(0, 1))
         flat[N_].copy_(S[T][na - 1])                         # next_states[-1]: what add_new_experience appends (learner.py:347)
-        trunc[:, T - 1] = np.where(dones[:, T - 1] == 0, 1.0, 0.0)   # flush rule (quirk Q4)
-        up = lambda x: torch.from_numpy(np.ascontiguousarray(x.reshape(-1))).to(dev)
+        rdt[2, T - 1] = np.where(rdt[1, T - 1] == 0, 1.0, 0.0)   # flush rule (quirk Q4)
+        rdt_dev = torch.from_numpy(rdt).to(dev).transpose(1, 2).contiguous()   # [3, na, T]: trajectory-major, transposed on the device
         self.value_input_rows = flat
         self._next_rows = S[T]
         self.cumulative_timesteps += N_
-        experience = (flat[:N_], acts_tm.t().reshape(N_, 1), logp_tm.t().reshape(N_), up(rews), nxt_flat, up(dones), up(trunc))
+        experience = (flat[:N_], acts_tm.t().reshape(N_, 1), logp_tm.t().reshape(N_), rdt_dev[0].reshape(N_), nxt_flat,
+                      rdt_dev[1].reshape(N_), rdt_dev[2].reshape(N_))
         return experience, metrics, N_, time.perf_counter() - t1
+
+    def _obs_staging(self, na, d):
+        """Three page-locked [na, d] float32 staging buffers (tensor, numpy view), allocated once."""
+        st = getattr(self, "_stage", None)
+        if st is None or st[0][0].shape != (na, d):
+            pin = torch.cuda.is_available()
+            ts = [torch.empty((na, d), dtype=torch.float32, pin_memory=pin) for _ in range(3)]
+            st = self._stage = [(t, t.numpy()) for t in ts]
+        return st
 
     def _collect_chain(self, n):
         t1 = time.perf_counter()
@@ -203,14 +231,17 @@ class VectorAgentManager(object):
         device_stats.increment(self.obs_stats, obs_dev)
 
     def _track_rewards(self, r, ended):
-        """Episode-reward average as batched_agent_manager.py:377-399 keeps it, one agent = one stream."""
+        """Episode-reward average as batched_agent_manager.py:377-399 keeps it, one agent = one stream: the ended agents' episode
+        sums enter the 0.9 / 0.1 average in agent order (Python floats, the reference's operations in the reference's order)."""
         self._ep_rews += r
-        for a in np.flatnonzero(ended):
-            if self.average_reward is None:
-                self.average_reward = float(self._ep_rews[a])
-            else:
-                self.average_reward = self.average_reward * 0.9 + float(self._ep_rews[a]) * 0.1
-            self._ep_rews[a] = 0.0
+        idx = np.flatnonzero(ended)
+        if idx.size == 0:
+            return
+        avg = self.average_reward
+        for x in self._ep_rews[idx].tolist():
+            avg = x if avg is None else avg * 0.9 + x * 0.1
+        self.average_reward = avg
+        self._ep_rews[idx] = 0.0
 
     def cleanup(self):
         if self.env is not None and hasattr(self.env, "close"):

@@ -651,6 +651,39 @@ extern "C" int rlppo_torch_cpu_exponential_chained(const void *state, int64_t st
     exp_transform(words, out, 0, n, -1.0 / lambda);
     return 0;
 }
+// [r4] A RUN of chained draws on the calling thread, for a caller that knows many draws ahead what it will need (the rollout of the
+// next iteration: 128 draws of [4096, 90], which the two helper threads produce while PPOLearner.learn keeps the GPU busy and the
+// collect critical path then only uploads).  Of a burst of `count` consecutive draws of n values each, this call performs draws
+// first, first + step, first + 2 step, ... -- `step` threads, one call each with first = 0 .. step - 1, share the burst exactly as
+// two alternating rlppo_torch_cpu_exponential_chained callers would, but with no hop through the caller between draws.
+// Draw i writes out + i * out_stride (floats) and publishes links + i * link_stride (bytes): { int32 ready (stream phase done, state
+// valid); int32 done (values complete; -1: failed or cancelled); padding to 64 bytes; state }.  Draw 0 starts from `state`, or from
+// `link_in0` (a link block an earlier chained call publishes) when that is given.  `cancel`: a caller-owned word checked before
+// every draw; once non-zero the remaining draws of this call are marked failed and the call returns.
+extern "C" int rlppo_torch_cpu_exponential_burst(const void *state, void *link_in0, int64_t state_bytes, int64_t n, double lambda,
+                                                 float *out, int64_t out_stride, void *links, int64_t link_stride, int32_t first,
+                                                 int32_t step, int32_t count, const int32_t *cancel) {
+    if (state_bytes < (int64_t)sizeof(TorchState) || n <= 0 || !out || !links || !(lambda > 0.0) || (!state && !link_in0) || first < 0 ||
+        step < 1 || count < 1 || out_stride < n || link_stride < 64 + state_bytes || !cancel)
+        return RLPPO_ERR_ARG;
+    static thread_local std::vector<uint32_t> words;
+    words.resize((size_t)(2 * n) + 8);
+    auto link = [&](int i) { return reinterpret_cast<char *>(links) + (int64_t)i * link_stride; };
+    auto done_of = [&](int i) { return reinterpret_cast<std::atomic<int32_t> *>(link(i) + 4); };
+    auto ready_of = [&](int i) { return reinterpret_cast<std::atomic<int32_t> *>(link(i)); };
+    int rc = 0;
+    for (int i = first; i < count; i += step) {
+        if (rc == 0 && __atomic_load_n(cancel, __ATOMIC_ACQUIRE) != 0) rc = RLPPO_ERR_ARG;
+        if (rc == 0) {
+            rc = rlppo_torch_cpu_exponential_chained(i == 0 && !link_in0 ? state : nullptr, state_bytes, n, lambda, out + (int64_t)i * out_stride,
+                                                     words.data(), i == 0 ? link_in0 : link(i - 1), link(i));
+        } else {
+            ready_of(i)->store(-1, std::memory_order_release);  // the successor (another thread's run) must not wait for us
+        }
+        done_of(i)->store(rc == 0 ? 1 : -1, std::memory_order_release);
+    }
+    return rc;
+}
 extern "C" int rlppo_exponential_from_words(const uint32_t *words, int64_t n, double lambda, float *out) {
     if (n < 0 || (n > 0 && (!words || !out)) || !(lambda > 0.0)) return RLPPO_ERR_ARG;
     if (n > 0) exp_transform(words, out, 0, n, -1.0 / lambda);

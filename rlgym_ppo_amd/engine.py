@@ -406,7 +406,12 @@ class HostExponential:
     left behind, runs its own stream phase, publishes its link block and only then transforms -- so the transform of draw k
     overlaps the whole of draw k + 1, and a 4096 x 90 draw leaves the pair every ~0.2 ms instead of every 0.36 ms, with no
     Python (no GIL) between the phases.  Buffers are pinned (a ring of depth + 3): the caller uploads them with an
-    asynchronous copy and must have consumed a buffer before the ring comes round."""
+    asynchronous copy and must have consumed a buffer before the ring comes round.
+    [r4] prefetch(shape, count): a caller that knows its next `count` draws (the rollout of the NEXT iteration: 128 draws of
+    [4096, 90]) extends the chain to that length in one go -- two C calls (rlppo_torch_cpu_exponential_burst), one per helper
+    thread, that walk the burst's draws alternately into one pinned block -- so that the draws happen while PPOLearner.learn
+    keeps the GPU busy (learn() does not touch torch's CPU generator) and the collect's critical path only uploads.  Same
+    contract: every entry is served only from exactly the predicted generator state, anything else drops the chain."""
 
     DEPTH = 3  # with two helper threads: a third request always waits in their queue, so neither goes to sleep between draws (tools/host_noise_pipeline.py)
     LOOKAHEAD_MIN = 65536  # elements: below that the hand-over to the helper thread (~50 us) costs more than the draw itself (~1 ns per number)
@@ -420,6 +425,8 @@ class HostExponential:
         self.threads = max(1, min(8, (os.cpu_count() or 2) // 2))  # an upper bound: the library uses one thread per 2^20 elements (0.35 ms per rollout-step draw)
         self._buf = {}       # numel -> dict(ring=[pinned float32 vectors], uploaded=[event or None], turn)
         self._chain = []      # speculative requests in stream order: dict(shape, numel, state_in, link, future, buf, rec, slot)
+        self._burst = {}      # numel -> dict(out=[cap, numel] pinned, links, cancel, uploaded, futures): storage of prefetch()
+        self.burst_bytes = int(os.environ.get("RLPPO_NOISE_PREFETCH_MB", "256")) << 20  # byte budget of one prefetched burst
         self.hits = self.misses = 0
         self.checked = False  # the one-time self-check against torch's own exponential_ (see _self_check)
         self.trusted = True
@@ -516,16 +523,98 @@ class HostExponential:
 
     def _drain(self):
         """Drop the chain: wait for everything in flight first (its buffers go back into rotation)."""
+        for b in self._burst.values():  # a burst in flight stops at its next draw (the remaining ones are marked failed)
+            b["cancel"][0] = 1
         for e in self._chain:
             try:
                 e["future"].result()
             except Exception:  # noqa: BLE001 -- a failed speculation is simply not used
                 pass
+        for b in self._burst.values():
+            for f in b["futures"]:
+                try:
+                    f.result()
+                except Exception:  # noqa: BLE001
+                    pass
+            b["futures"] = []
         self._chain = []
 
     @staticmethod
     def _link_state(e):
         return torch.from_numpy(e["link"][N.EXP_LINK_HEADER:])
+
+    class _BurstSlot:
+        """Stands in for the future of one draw of a burst: result() returns once the draw's values are complete."""
+
+        def __init__(self, link):
+            self.link = link.view(np.int32)
+
+        def result(self):
+            import time
+            spins = 0
+            while self.link[1] == 0:   # normally long done (the burst ran during learn())
+                spins += 1
+                time.sleep(0 if spins < 200 else 0.0001)
+            if self.link[1] < 0:
+                raise RuntimeError("burst draw failed or was cancelled")
+
+    def _burst_run(self, b, state_in, link_in0, nbytes, numel, first, count):
+        N.check(N.lib().rlppo_torch_cpu_exponential_burst(
+            ctypes.c_void_p(state_in.data_ptr()) if state_in is not None else None,
+            ctypes.c_void_p(link_in0.ctypes.data) if link_in0 is not None else None, nbytes, numel, 1.0,
+            ctypes.c_void_p(b["out"].data_ptr()), numel, ctypes.c_void_p(b["links"].ctypes.data), b["links"].shape[1],
+            first, self.workers, count, ctypes.c_void_p(b["cancel"].ctypes.data)))
+
+    def prefetch(self, shape, count):
+        """The caller's next `count` draws will be of `shape`, and nothing else will use torch's CPU generator before them (if
+        something does, the chain is dropped at the next draw as ever: transparent).  Extends the speculative chain to `count`
+        requests -- capped by `burst_bytes` -- and returns the number of requests added.  Returns at once: the draws run on the
+        helper threads (two C calls, no Python between draws)."""
+        shape = tuple(int(x) for x in shape)
+        numel = 1
+        for x in shape:
+            numel *= x
+        if self.depth == 0 or numel < self.LOOKAHEAD_MIN or count <= 0:
+            return 0
+        if not self.checked:
+            self._self_check()
+        if not self.trusted:
+            return 0
+        if self._chain and self._chain[-1]["shape"] != shape:
+            self._drain()
+        count = min(int(count), self.burst_bytes // (4 * numel))
+        need = count - len(self._chain)
+        if need <= 0:
+            return 0
+        state_now = torch.get_rng_state()
+        nbytes = state_now.numel()
+        b = self._burst.get(numel)
+        if b is not None and (b["futures"] or any(e.get("rec") is b for e in self._chain)):
+            if any(e.get("rec") is b for e in self._chain) or not all(f.done() for f in b["futures"]):
+                return 0  # the previous burst on this storage is still being produced or served
+            b["futures"] = []
+        if b is None or b["out"].shape[0] < need:
+            pin = torch.cuda.is_available()
+            b = self._burst[numel] = dict(out=torch.empty((need, numel), dtype=torch.float32, pin_memory=pin),
+                                          links=np.zeros((need, N.EXP_LINK_HEADER + nbytes), np.uint8), cancel=np.zeros(1, np.int32),
+                                          uploaded=[None] * need, futures=[])
+        for i, ev in enumerate(b["uploaded"]):  # uploads of the previous burst's slots (stream-ordered: normally long complete)
+            if ev is not None:
+                ev.synchronize()
+                b["uploaded"][i] = None
+        b["links"][:need, :8] = 0
+        b["cancel"][0] = 0
+        prev = self._chain[-1] if self._chain else None
+        pool = _pool("noise", self.workers)
+        b["futures"] = [pool.submit(self._burst_run, b, state_now if prev is None else None, prev["link"] if prev is not None else None,
+                                    nbytes, numel, j, need) for j in range(min(self.workers, need))]
+        for i in range(need):
+            link = b["links"][i]
+            e = dict(shape=shape, numel=numel, state_bytes=nbytes, state_in=state_now if (prev is None and i == 0) else None, prev=prev,
+                     link=link, words=None, buf=b["out"][i], rec=b, slot=i, future=HostExponential._BurstSlot(link))
+            self._chain.append(e)
+            prev = e
+        return need
 
     def draw(self, shape, device=None):
         """Exp(1) noise of `shape`: a view of a pinned ring buffer, or -- with `device` -- its asynchronous upload on the current
@@ -583,6 +672,14 @@ class HostExponential:
 
 
 _HOST_EXP = None
+
+
+def host_exponential_prefetch(shape, count):
+    """HostExponential.prefetch on the process-wide instance (see there): `count` upcoming draws of `shape` are produced ahead."""
+    global _HOST_EXP
+    if _HOST_EXP is None:
+        _HOST_EXP = HostExponential()
+    return _HOST_EXP.prefetch(shape, count)
 
 
 def host_exponential(shape, device=None):

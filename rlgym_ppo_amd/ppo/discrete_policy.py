@@ -9,7 +9,7 @@ import torch
 import torch.nn as nn
 
 from .. import _native as N
-from ..engine import host_exponential, ptr, stream_ptr
+from ..engine import host_exponential, host_exponential_prefetch, ptr, stream_ptr
 from ._mlp import ArenaModule, build_body
 
 
@@ -123,6 +123,11 @@ class DiscreteFF(ArenaModule):
             torch.cuda.current_stream(a.device).synchronize()
             return actions.clone(), (logp.clone() if to_host is True else logp)
         return actions, logp
+
+    def prefetch_noise(self, n, count):
+        """The next `count` calls of step() / get_action() will each act on n observations with the reference's CPU noise stream:
+        have those draws produced ahead on the helper threads (engine.HostExponential.prefetch; transparent speculation)."""
+        return host_exponential_prefetch((int(n), self.n_actions), int(count))
 
     # ---- hooks of the graph-replayed rollout step (ppo/_mlp.py::ActGraph)
     def _noise_shape(self, n):

@@ -317,6 +317,80 @@ def test_host_exponential_split_and_chained_forms_reproduce_torch():
     assert L.rlppo_torch_cpu_exponential_chained(None, st0.size, n, 1.0, P(outs[0]), P(scratch[0]), None, P(nxt)) != 0   # no start state
 
 
+def test_host_exponential_burst_prefetch_reproduces_torch_and_stays_transparent():
+    """[r4] rlppo_torch_cpu_exponential_burst / HostExponential.prefetch: the next rollout's draws produced ahead in one go (two C
+    calls walking the burst alternately).  (1) the C entry point alone: a burst of 7 draws over 2 and over 3 threads gives torch's
+    values and torch's generator states, from a start state and from an earlier call's link block; a cancelled run marks its
+    remaining draws failed.  (2) through HostExponential: draw, prefetch 11 more, 'learn' (no generator use), draw 12 -- values and
+    the final generator state are torch's, every draw a hit; prefetch twice in a row is refused while the first is being served;
+    (3) something else uses the generator between prefetch and the draws: the chain is dropped, the stream is still torch's."""
+    import threading
+    import torch
+    from rlgym_ppo_amd import _native as N, engine
+    L = N.lib()
+    P = lambda a: ctypes.c_void_p(a.ctypes.data)
+    n, draws = 90 * 1100 + 3, 7
+    torch.manual_seed(77)
+    st0 = torch.get_rng_state().numpy().copy()
+    want, states = [], []
+    for _ in range(draws):
+        want.append(torch.empty(n).exponential_(1).numpy())
+        states.append(torch.get_rng_state().numpy().copy())
+    stride = N.EXP_LINK_HEADER + st0.size
+    for threads in (2, 3):
+        out, links, cancel = np.empty((draws, n), np.float32), np.zeros((draws, stride), np.uint8), np.zeros(1, np.int32)
+        rcs = [None] * threads
+        def run(j):
+            rcs[j] = L.rlppo_torch_cpu_exponential_burst(P(st0), None, st0.size, n, 1.0, P(out), n, P(links), stride, j, threads, draws, P(cancel))
+        ths = [threading.Thread(target=run, args=(j,)) for j in reversed(range(threads))]
+        [t.start() for t in ths]
+        [t.join() for t in ths]
+        assert rcs == [0] * threads
+        for k in range(draws):
+            assert np.array_equal(out[k], want[k]) and np.array_equal(links[k][N.EXP_LINK_HEADER:], states[k])
+            assert links[k].view(np.int32)[0] == 1 and links[k].view(np.int32)[1] == 1
+    # continuing from an earlier call's link block: draws 3.. from the block draw 2 published
+    out2, links2, cancel = np.empty((draws - 3, n), np.float32), np.zeros((draws - 3, stride), np.uint8), np.zeros(1, np.int32)
+    assert L.rlppo_torch_cpu_exponential_burst(None, P(links[2]), st0.size, n, 1.0, P(out2), n, P(links2), stride, 0, 1, draws - 3, P(cancel)) == 0
+    assert all(np.array_equal(out2[k], want[k + 3]) for k in range(draws - 3)) and np.array_equal(links2[-1][N.EXP_LINK_HEADER:], states[-1])
+    # cancelled before it starts: every draw marked failed, nobody left waiting
+    links3, cancel = np.zeros((draws, stride), np.uint8), np.ones(1, np.int32)
+    assert L.rlppo_torch_cpu_exponential_burst(P(st0), None, st0.size, n, 1.0, P(out), n, P(links3), stride, 0, 1, draws, P(cancel)) != 0
+    assert (links3.view(np.int32)[:, 1] == -1).all() and (links3.view(np.int32)[:, 0] == -1).all()
+    assert L.rlppo_torch_cpu_exponential_burst(None, None, st0.size, n, 1.0, P(out), n, P(links3), stride, 0, 1, draws, P(cancel)) != 0  # no start
+
+    # (2) through HostExponential
+    shape = (1100, 90)
+    torch.manual_seed(91)
+    ref = [torch.empty(shape).exponential_(1) for _ in range(13)]
+    s_ref = torch.get_rng_state()
+    torch.manual_seed(91)
+    h = engine.HostExponential()
+    got = [h.draw(shape).clone()]
+    added = h.prefetch(shape, 12)
+    assert added == 12 - h.depth and len(h._chain) == 12
+    assert h.prefetch(shape, 12) == 0 and h.prefetch(shape, 40) == 0        # already that long / storage busy: refused, nothing breaks
+    got += [h.draw(shape).clone() for _ in range(12)]
+    h._drain()
+    assert all(torch.equal(a, b) for a, b in zip(ref, got)) and torch.equal(s_ref, torch.get_rng_state())
+    assert h.hits == 12 and h.misses == 1
+    # (3) an intruder between prefetch and the draws
+    torch.manual_seed(92)
+    ref = [torch.empty(shape).exponential_(1)]
+    x_ref = torch.rand(5)
+    ref += [torch.empty(shape).exponential_(1) for _ in range(4)]
+    s_ref = torch.get_rng_state()
+    torch.manual_seed(92)
+    h = engine.HostExponential()
+    got = [h.draw(shape).clone()]
+    h.prefetch(shape, 9)
+    x = torch.rand(5)                                                          # not ours: the prediction no longer holds
+    got += [h.draw(shape).clone() for _ in range(4)]
+    h._drain()
+    assert torch.equal(x, x_ref) and all(torch.equal(a, b) for a, b in zip(ref, got)) and torch.equal(s_ref, torch.get_rng_state())
+    assert h.misses >= 2 and all(not f.running() for b in h._burst.values() for f in b["futures"])
+
+
 def test_host_exponential_survives_a_failing_look_ahead(monkeypatch):
     """A speculative draw that fails on its helper thread (here: every second one raises) must not change the observable stream:
     the request is drawn on the spot from the generator's real state, the chain is rebuilt, values and final state are torch's."""
