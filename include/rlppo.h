@@ -393,6 +393,10 @@ int rlppo_dbg_set(int32_t key, int32_t value);
 /* Counter bumped by every call that changes which kernels later launches select (rlppo_dbg_set, rlppo_set_*_precision): a
  * host that caches captured graphs of library calls keys them on it (rlgym_ppo_amd/ppo/_mlp.py::ActGraph). */
 int64_t rlppo_selection_epoch(void);
+/* Which form calls took so far in this process (tests assert that the kernel they mean to pin is the one that ran): 0 = rollout steps
+ * served by the one-launch kernel (rlppo_discrete_act / rlppo_discrete_step), 1 = by the layer chain, 2 = rlppo_ppo_minibatch passes,
+ * 3 = of them with paired policy + critic launches, 4 = of them with the gather fused into the first layer; -1 for an unknown key. */
+int64_t rlppo_dbg_counter(int32_t key);
 /* Single-kernel entry points used by tests/ and bench.py to check / time each GEMM flavour in isolation.
  * epilogue: 0 bias, 1 bias+relu, 2 bias+tanh, 3 relu-mask (mask_src > 0).  Shapes as in csrc/gemm.hip. */
 int rlppo_dbg_gemm_nt(void *stream, const float *A, int64_t lda, const float *B, int64_t ldb, const float *bias,

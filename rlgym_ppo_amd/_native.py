@@ -117,6 +117,7 @@ SIGNATURES = {
     "rlppo_net_pack_bf16": (c_int32, [c_void_p, _P32, c_int32, c_void_p, c_void_p, c_void_p]),
     "rlppo_dbg_set": (c_int32, [c_int32, c_int32]),
     "rlppo_selection_epoch": (c_int64, []),
+    "rlppo_dbg_counter": (c_int64, [c_int32]),
     "rlppo_dbg_gemm_nt": (c_int32, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_int64,
                                     c_int64, c_int32, c_int32, c_int32]),
     "rlppo_dbg_gemm_nt_bits_bytes": (c_size_t, [c_int64, c_int32]),

@@ -233,6 +233,8 @@ static int forward_pingpong(hipStream_t st, const NetLayout &net, const float *p
 using namespace rlppo;
 
 static int g_fused_act = 1;  // rlppo_dbg_set(27, 0/1): rlppo_discrete_act as one fused launch (fused_act.hip)
+// rlppo_dbg_counter: which form a call took (tests assert that the kernel they mean to pin is the one that ran)
+static std::atomic<long long> g_cnt_fused_act{0}, g_cnt_act_chain{0}, g_cnt_paired_pass{0}, g_cnt_gather_fused_pass{0}, g_cnt_pass{0};
 // One workgroup per 16 rows and one workgroup per CU (102 KiB of LDS): a launch is rounds of 4096 rows at ~25 us each, whatever
 // the round's fill.  Measured (tools/act_kernel_time.py): 64 rows 26 us (chain 70), 4096 rows 29 us (chain 75), 16,384 rows 100 us
 // (chain 86): beyond two rounds the layer-by-layer GEMMs, which fill the chip, win.
@@ -321,8 +323,10 @@ int rlppo_discrete_act(void *stream, const int32_t *dims, int32_t n_layers, cons
         io.actions = actions;
         io.logp = logp;
         io.probs_out = probs_out;
+        ++g_cnt_fused_act;
         return launch_discrete_act_fused((hipStream_t)stream, net, packed, io, n);
     }
+    ++g_cnt_act_chain;
     const float *o;
     int64_t ldo;
     rc = forward_pingpong((hipStream_t)stream, net, packed, obs, ld_obs, n, 0, workspace, ws_bytes, nullptr, &o, &ldo);
@@ -367,8 +371,10 @@ int rlppo_discrete_step(void *stream, const int32_t *dims, int32_t n_layers, con
         io.actions = actions;
         io.actions_f32 = actions_f32;
         io.logp = logp;
+        ++g_cnt_fused_act;
         return launch_discrete_act_fused(st, net, packed, io, n);
     }
+    ++g_cnt_act_chain;
     // the same step launch by launch: pad (+ standardise) into rows_out (or the head of the workspace), forward chain, sample
     float *rows = rows_out;
     int64_t ld_rows = ld_rows_out;
@@ -927,6 +933,9 @@ int rlppo_ppo_minibatch(void *stream, const rlppo_minibatch_args *a) {
         if (rc) return rc;
     }
     const bool twin = !b16 && (g_paired == 2 || (g_paired == 1 && mb >= PAIRED_MIN_ROWS)) && twin_ok(pol, val, mb);
+    ++g_cnt_pass;
+    if (twin) ++g_cnt_paired_pass;
+    if (fused_gather) ++g_cnt_gather_fused_pass;
     if (twin) {
         const int H = pol.n_layers - 1;  // hidden layers (the same number in both networks)
         const float *xp = fused_gather ? a->states : states, *xv = xp;
@@ -1249,6 +1258,16 @@ int rlppo_dbg_set(int32_t key, int32_t value) {
     return RLPPO_ERR_ARG;
 }
 int64_t rlppo_selection_epoch(void) { return g_selection_epoch; }
+int64_t rlppo_dbg_counter(int32_t key) {
+    switch (key) {
+        case 0: return g_cnt_fused_act;
+        case 1: return g_cnt_act_chain;
+        case 2: return g_cnt_pass;
+        case 3: return g_cnt_paired_pass;
+        case 4: return g_cnt_gather_fused_pass;
+        default: return -1;
+    }
+}
 size_t rlppo_dbg_gemm_nt_bits_bytes(int64_t M, int32_t N) { return nt_bits_floats(M, N) * sizeof(float); }
 int rlppo_dbg_gemm_nt_bits(void *stream, const float *A, int64_t lda, const float *B, int64_t ldb, const float *bias, float *C,
                            int64_t ldc, int64_t M, int32_t N, int32_t K, int32_t epilogue, void *bits) {

@@ -327,7 +327,10 @@ class PPOLearner(object):
             # this call were SKIPPED -- parameters and Adam moments are those of the last completed step, finite and consistent on
             # every rank -- and the gradient arena still holds the skipped batches' sums.  Recover the state a caller can continue
             # from (zero gradients, a re-armed block, the three-operation form from now on) and report loudly.
-            n_to = int(stats[N.N_STATS + 2])
+            n_to = int(stats[N.N_STATS + 2])   # = the number of skipped optimiser steps: the give-up counts once, every later launch on the dead block once
+            for opt in (self.policy_optimizer, self.value_optimizer):
+                opt.step_count = max(0, opt.step_count - n_to)   # Adam's bias corrections must not count steps that never happened
+            self.cumulative_model_updates += max(0, n_iterations - n_to)
             self._grad_all.zero_()
             self._opt_sync.zero_()
             self.one_launch_optimizer = False

@@ -87,6 +87,92 @@ def g1_g2_forward(R):
     save("g2_value_forward", obs=obs, values=values, values_from_f64=values64, **params_of(val, "v."))
 
 
+def g1bc_forward_fused_shapes(R):
+    """G1b / G1c [r4]: DiscreteFF.get_action (discrete_policy.py:44-62) on network shapes the ONE-LAUNCH rollout kernel covers
+    (csrc/fused_act.hip: hidden widths 64 / 128 / 256; G1's 32-wide nets only ever pass through the layer chain): (64, 64) and the
+    BASELINE configs[1] shape (256, 256, 256), 64 rows each, the Exp(1) noise recorded as in G1."""
+    for tag, layers, seed in (("g1b_discrete_forward_64x2", (64, 64), 12), ("g1c_discrete_forward_256x3", (256, 256, 256), 13)):
+        torch.manual_seed(seed)
+        pol = R["DiscreteFF"](107, 90, layers, "cpu")
+        rs = np.random.RandomState(seed)
+        obs = np.clip(rs.randn(64, 107), -5, 5).astype(np.float32)
+        with torch.no_grad():
+            probs = torch.clamp(pol.get_output(obs).view(-1, 90), min=1e-11, max=1)
+            st = torch.get_rng_state()
+            actions, logp = pol.get_action(obs)
+            torch.set_rng_state(st)
+            q = torch.empty(64, 90).exponential_(1)
+        # margin of every row's selection: the two largest p/q (a near-tie may legitimately go the other way in another fp32 forward)
+        ratio = (probs / q).numpy().astype(np.float64)
+        top2 = np.sort(ratio, axis=1)[:, -2:]
+        save(tag, obs=obs, q=q, probs=probs, actions=actions, logp=logp, margin=(top2[:, 1] - top2[:, 0]) / top2[:, 1],
+             layers=np.asarray(layers), **params_of(pol, "p."))
+
+
+def param_hash(vec):
+    """Order-sensitive exact hash of a float32 vector's BITS (uint64 wrap-around arithmetic: the same on every host)."""
+    bits = np.ascontiguousarray(np.asarray(vec, np.float32)).view(np.uint32).astype(np.uint64)
+    mult = (np.arange(bits.size, dtype=np.uint64) * np.uint64(2654435761) + np.uint64(0x9E3779B97F4A7C15)) | np.uint64(1)
+    with np.errstate(over="ignore"):
+        return np.bitwise_xor.reduce(bits * mult) ^ np.uint64(bits.size)
+
+
+def g5big_inputs(cfg):
+    """The experience of G5big from seeds alone (numpy legacy generators: the same bits on every host), so that a test can rebuild
+    it where the fixture cannot hold it (262,144 x 107 states = 112 MB).  Actions are uniform, the 'old' log-probabilities a
+    noisy log(1/A): ratios spread over both clip edges from the first step on.  Returned in submit_experience order."""
+    rs = np.random.RandomState(cfg["seed"] + 1)
+    n, d, A = cfg["n"], cfg["d"], cfg["n_act"]
+    states = np.clip(rs.randn(n, d), -5, 5).astype(np.float32)
+    actions = rs.randint(0, A, n).astype(np.float32)
+    log_probs = (np.log(1.0 / A) + 0.15 * rs.randn(n)).astype(np.float32)
+    rewards = rs.randn(n).astype(np.float32)
+    dones = (rs.rand(n) < 0.03).astype(np.float32)
+    trunc = ((rs.rand(n) < 0.03) & (dones == 0)).astype(np.float32)
+    values = rs.randn(n).astype(np.float32)
+    adv = rs.randn(n).astype(np.float32)
+    return states, actions, log_probs, rewards, states[:1].repeat(n, 0), dones, trunc, values, adv
+
+
+def g5big_learn(R):
+    """G5big [r4]: PPOLearner.learn (ppo_learner.py:92-238) at the size where the product's paired / gather-fused launches engage
+    (csrc/api.hip: from 262,144 rows per pass): 256x3 nets, n = B = 262,144, MB = 65,536, 2 epochs = 2 optimiser steps of 4
+    minibatches.  The inputs come from seeds (g5big_inputs: a test rebuilds them); stored: an exact bit hash + the first 64 values
+    of the initial parameters, the first 64 values + plain sums after step 0, the FULL parameter vectors after the last step, the
+    report.  ~2 minutes on one thread."""
+    cfg = dict(policy_type=0, d=107, n_act=90, layers=(256, 256, 256), n=262144, B=262144, MB=65536, epochs=2, seed=321,
+               lr=3e-4, clip=0.2, ent=0.005)
+    torch.manual_seed(cfg["seed"])
+    np.random.seed(cfg["seed"])
+    learner = R["PPOLearner"](cfg["d"], cfg["n_act"], 0, cfg["layers"], cfg["layers"], (0.1, 1.0), cfg["B"], cfg["epochs"], cfg["lr"],
+                              cfg["lr"], cfg["clip"], cfg["ent"], cfg["MB"], "cpu")
+    vec = lambda m: torch.nn.utils.parameters_to_vector(m.parameters()).detach().clone().numpy()
+    out = {"p0.hash": param_hash(vec(learner.policy)), "v0.hash": param_hash(vec(learner.value_net)),
+           "p0.head": vec(learner.policy)[:64], "v0.head": vec(learner.value_net)[:64]}
+    buf = R["ExperienceBuffer"](cfg["n"], cfg["seed"], "cpu")
+    exp = g5big_inputs(cfg)
+    out["exp.hash"] = np.asarray([param_hash(x.reshape(-1)) for x in exp[:3] + exp[7:]])
+    buf.submit_experience(*exp)
+    step_no = [0]
+    orig = learner.value_optimizer.step
+
+    def rec(*a, **k):  # the value optimiser steps last (ppo_learner.py:192-193)
+        r = orig(*a, **k)
+        s = step_no[0]
+        p, v = vec(learner.policy), vec(learner.value_net)
+        out[f"step{s}.policy_head"], out[f"step{s}.value_head"] = p[:64], v[:64]
+        out[f"step{s}.policy_sum"], out[f"step{s}.value_sum"] = np.float64(p.astype(np.float64).sum()), np.float64(v.astype(np.float64).sum())
+        if s == cfg["epochs"] * (cfg["n"] // cfg["B"]) - 1:
+            out[f"step{s}.policy"], out[f"step{s}.value"] = p, v
+        step_no[0] += 1
+        return r
+    learner.value_optimizer.step = rec
+    report = learner.learn(buf)
+    report.pop("PPO Batch Consumption Time")
+    out.update({"report." + k: np.float64(v) for k, v in report.items()})
+    save("g5big_learn_discrete_256x3", **out, n_steps=np.int64(step_no[0]), cfg=np.array(json.dumps(cfg)))
+
+
 def make_gae_inputs(n, seed, trunc_dtype):
     rs = np.random.RandomState(seed)
     rews = rs.randn(n).astype(np.float32) * 2.0
@@ -443,20 +529,15 @@ def g11_wire(R):
 
 
 def main():
+    only = sys.argv[1:]  # e.g. `make_golden.py g5big_learn`: regenerate the named fixtures only
     if not os.path.isdir(REF):
         raise SystemExit("reference tree not present: fixtures can only be regenerated in the build container")
     R = _import_reference()
     torch.set_num_threads(1)  # deterministic reduction order in the CPU GEMMs that produce the fixtures
-    g1_g2_forward(R)
-    g3_gae(R)
-    g4_discrete_loss(R)
-    g5_learn(R)
-    g6_shuffle(R)
-    g7_welford(R)
-    g8_fifo(R)
-    g9_other_heads(R)
-    g10_checkpoint(R)
-    g11_wire(R)
+    for fn in (g1_g2_forward, g1bc_forward_fused_shapes, g3_gae, g4_discrete_loss, g5_learn, g5big_learn, g6_shuffle, g7_welford, g8_fifo,
+               g9_other_heads, g10_checkpoint, g11_wire):
+        if not only or fn.__name__ in only:
+            fn(R)
 
 
 if __name__ == "__main__":

@@ -1,6 +1,7 @@
 """GPU parity of the reference-shaped host classes (PPOLearner / ExperienceBuffer / policies / compute_gae) against
 the golden fixtures produced by the reference itself and against the CPU oracle."""
 import json
+import os
 
 import numpy as np
 import pytest
@@ -107,6 +108,101 @@ def test_learn_matches_reference_fixture(golden, name):
     assert float(osd["state"][0]["step"]) == float(g["adam_step"])
     assert relerr(osd["state"][0]["exp_avg"], g["adam_exp_avg0"]) < 1e-4
     assert relerr(osd["state"][0]["exp_avg_sq"], g["adam_exp_avg_sq0"]) < 1e-4
+
+
+def test_learn_at_the_paired_launch_size_matches_the_reference_fixture(golden):
+    """[r4] G5big: the reference's PPOLearner.learn at 256x3, n = B = 262,144, MB = 65,536, 2 epochs -- the size from which the update
+    runs its PAIRED policy + critic launches with the minibatch gather FUSED into the first layer (csrc/api.hip), which until
+    round 4 no reference-held vector ever reached.  The experience is rebuilt from seeds by the generator's own function (its bit
+    hashes are in the fixture), the seeded construction must give the reference's initial parameters bit for bit (hash + first 64
+    values), a library counter says which launch form ran, and the parameters after both optimiser steps go through the same
+    float64-yardstick gate as the small learn() fixtures: HIP and the reference's own float32 result, both against
+    oracle/ppo.py::learn64, well-conditioned parameters at max(1e-5, 1.5 x reference), ill-conditioned ones under the derived
+    Adam bound.  After step 0 the fixture holds 64 + 64 values and two plain sums: compared under the same bound."""
+    import importlib.util
+    from rlgym_ppo_amd import _native as N
+    from rlgym_ppo_amd.ppo import ExperienceBuffer
+    spec = importlib.util.spec_from_file_location("make_golden", os.path.join(os.path.dirname(__file__), "golden", "make_golden.py"))
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)
+    L = N.lib()
+    g = golden("g5big_learn_discrete_256x3")
+    cfg = json.loads(str(g["cfg"]))
+    learner = make_learner(cfg)
+    vec = lambda m: torch.nn.utils.parameters_to_vector(m.parameters()).detach().cpu().numpy()
+    p0, v0 = vec(learner.policy), vec(learner.value_net)
+    assert mg.param_hash(p0) == g["p0.hash"] and mg.param_hash(v0) == g["v0.hash"]      # the reference's initial weights, bit for bit
+    assert np.array_equal(p0[:64], g["p0.head"]) and np.array_equal(v0[:64], g["v0.head"])
+    exp = mg.g5big_inputs(cfg)
+    assert np.array_equal(np.asarray([mg.param_hash(x.reshape(-1)) for x in exp[:3] + exp[7:]]), g["exp.hash"])   # the same experience
+    buf = ExperienceBuffer(cfg["n"], cfg["seed"], "cpu")
+    buf.submit_experience(*exp)
+
+    # float64 truth of both optimiser steps (CPU oracle, ~1 TFLOP of float64)
+    layers = [cfg["d"]] + list(cfg["layers"])
+    def split(flat, outs):
+        params, o = [], 0
+        dims = layers + [outs]
+        for i in range(len(dims) - 1):
+            w = flat[o:o + dims[i + 1] * dims[i]].reshape(dims[i + 1], dims[i]); o += w.size
+            b = flat[o:o + dims[i + 1]]; o += b.size
+            params.append((torch.as_tensor(w.copy()), torch.as_tensor(b.copy())))
+        return params
+    truth, weakest = {}, {}
+    ppo.learn64("discrete", split(p0, cfg["n_act"]), split(v0, 1),
+                dict(states=exp[0], actions=exp[1], log_probs=exp[2], values=exp[7], advantages=exp[8]), cfg["B"], cfg["MB"], cfg["epochs"],
+                cfg["clip"], cfg["ent"], cfg["lr"], cfg["lr"], np.random.RandomState(cfg["seed"]), weakest=weakest,
+                on_step=lambda i, p, v: truth.__setitem__(i, (np.concatenate([t.ravel() for wb in p for t in wb]),
+                                                              np.concatenate([t.ravel() for wb in v for t in wb]),
+                                                              weakest["pol"].copy(), weakest["val"].copy())))
+    n_steps = int(g["n_steps"])
+    assert n_steps == 2 and sorted(truth) == [0, 1]
+    learner.n_epochs = 1
+    passes0, paired0, gfused0 = (int(L.rlppo_dbg_counter(k)) for k in (2, 3, 4))
+    reports = []
+    for s in range(n_steps):
+        reports.append(learner.learn(buf))
+        assert learner._fused_rows == 262144                               # the 4 minibatches of a batch in ONE pass
+        pv, vv = vec(learner.policy).astype(np.float64), vec(learner.value_net).astype(np.float64)
+        tp, tv, wp, wv = truth[s]
+        bound = lambda weak: np.where(weak < 1e-4, (s + 1) * cfg["lr"] * np.minimum(1.0, 1e-5 / np.maximum(weak, 1e-300)), 0.0)
+        if s < n_steps - 1:   # heads + sums only
+            for got, ref_head, ref_sum, tr, weak in ((pv, g[f"step{s}.policy_head"], float(g[f"step{s}.policy_sum"]), tp, wp),
+                                                     (vv, g[f"step{s}.value_head"], float(g[f"step{s}.value_sum"]), tv, wv)):
+                scale = np.abs(tr).max()
+                tol = np.maximum(1e-5 * scale, bound(weak))
+                e_hip, e_ref = np.abs(got[:64] - tr[:64]), np.abs(ref_head.astype(np.float64) - tr[:64])
+                assert (e_hip <= np.maximum(tol[:64], 1.5 * e_ref.max())).all(), (s, e_hip.max(), e_ref.max())
+                # a plain sum moves by at most the sum of the per-parameter allowances
+                d_hip, d_ref = abs(got.sum() - tr.sum()), abs(ref_sum - tr.sum())
+                print(f"[fp64 gate] g5big step {s}: head err HIP {e_hip.max() / scale:.2e} reference {e_ref.max() / scale:.2e} of max|p|; "
+                      f"|sum - sum64| HIP {d_hip:.3e} reference {d_ref:.3e} (allowance {tol.sum():.3e})")
+                assert d_hip <= max(tol.sum(), 1.5 * d_ref)
+            continue
+        errs = {}
+        for who, p_, v_ in (("hip", pv, vv), ("ref", g[f"step{s}.policy"].astype(np.float64), g[f"step{s}.value"].astype(np.float64))):
+            worst_good = worst_ill = frac_ill = 0.0
+            for got, tr, weak in ((p_, tp, wp), (v_, tv, wv)):
+                d = np.abs(got - tr)
+                ill = weak < 1e-4
+                worst_good = max(worst_good, float(d[~ill].max() / np.abs(tr).max()))
+                if ill.any():
+                    worst_ill = max(worst_ill, float(d[ill].max() / np.abs(tr).max()))
+                    frac_ill = max(frac_ill, float((d[ill] / bound(weak)[ill]).max()))
+            errs[who] = (worst_good, worst_ill, frac_ill)
+        n_ill = int((wp < 1e-4).sum() + (wv < 1e-4).sum())
+        print(f"[fp64 gate] g5big_learn_discrete_256x3 after optimiser step {s}: err(HIP, fp64)={errs['hip'][0]:.2e}  err(reference fp32 "
+              f"fixture, fp64)={errs['ref'][0]:.2e}  | {n_ill} of {wp.size + wv.size} parameters with an ill-conditioned Adam step: HIP "
+              f"{errs['hip'][1]:.1e} = {errs['hip'][2]:.3f} of the derived bound, reference {errs['ref'][1]:.1e} = {errs['ref'][2]:.3f}")
+        assert errs["hip"][0] <= max(1e-5, 1.5 * errs["ref"][0]), errs
+        assert n_ill <= 0.05 * (wp.size + wv.size)
+        assert errs["hip"][2] <= 1.0 and errs["ref"][2] <= 1.0, errs
+    passes, paired, gfused = (int(L.rlppo_dbg_counter(k)) for k in (2, 3, 4))
+    assert passes - passes0 == n_steps and paired - paired0 == n_steps and gfused - gfused0 == n_steps, \
+        "the paired / gather-fused launches did not run: (passes, paired, gather-fused) = %s" % ((passes - passes0, paired - paired0, gfused - gfused0),)
+    for key in ("Policy Entropy", "Mean KL Divergence", "Value Function Loss", "SB3 Clip Fraction"):
+        got, ref = float(np.mean([r[key] for r in reports])), float(g["report." + key])
+        assert abs(got - ref) <= 2e-5 * max(abs(ref), 1e-4) + 1e-7, (key, got, ref)
 
 
 def test_learn_single_call_report_and_magnitudes(golden):
