@@ -323,7 +323,7 @@ def learn(head, pol, val, buf, batch_size, mini_batch_size, n_epochs, clip, ent_
 
 # --------------------------------------------------------------------------------------- full learn, float64
 def learn64(head, pol, val, buf, batch_size, mini_batch_size, n_epochs, clip, ent_coef, policy_lr, critic_lr, rng,
-            var_range=(0.1, 1.0), on_step=None, weakest=None):
+            var_range=(0.1, 1.0), on_step=None, weakest=None, on_grad=None):
     """The same loop as learn() evaluated in float64 end to end (minibatch_analytic gradients, clip coefficient, Adam):
     the truth both float32 implementations -- the reference's CPU path and the HIP kernels -- are measured against in
     tests/test_gpu_learner.py.  Returns float64 parameter lists; `on_step(i, pol, val)` after every optimiser step.
@@ -356,6 +356,8 @@ def learn64(head, pol, val, buf, batch_size, mini_batch_size, n_epochs, clip, en
                         aw += w
                         ab += b
             step += 1
+            if on_grad is not None:  # the batch gradient clip_grad_norm_ / Adam are about to see (float64), flat per network
+                on_grad(step - 1, np.concatenate([g.ravel() for wb in gp for g in wb]), np.concatenate([g.ravel() for wb in gv for g in wb]))
             bc1, bc2 = 1 - ADAM_B1 ** step, 1 - ADAM_B2 ** step
             for key, params, grads, lr in (("val", val, gv, critic_lr), ("pol", pol, gp, policy_lr)):
                 if weakest is not None:

@@ -89,9 +89,9 @@ def g1_g2_forward(R):
 
 def g1bc_forward_fused_shapes(R):
     """G1b / G1c [r4]: DiscreteFF.get_action (discrete_policy.py:44-62) on network shapes the ONE-LAUNCH rollout kernel covers
-    (csrc/fused_act.hip: hidden widths 64 / 128 / 256; G1's 32-wide nets only ever pass through the layer chain): (64, 64) and the
+    (csrc/fused_act.hip: hidden widths 64 / 128 / 256; G1's 32-wide nets only ever pass through the layer chain): (128, 128) -- with 107 observations the first padded width, 112, must fit the hidden width -- and the
     BASELINE configs[1] shape (256, 256, 256), 64 rows each, the Exp(1) noise recorded as in G1."""
-    for tag, layers, seed in (("g1b_discrete_forward_64x2", (64, 64), 12), ("g1c_discrete_forward_256x3", (256, 256, 256), 13)):
+    for tag, layers, seed in (("g1b_discrete_forward_128x2", (128, 128), 12), ("g1c_discrete_forward_256x3", (256, 256, 256), 13)):
         torch.manual_seed(seed)
         pol = R["DiscreteFF"](107, 90, layers, "cpu")
         rs = np.random.RandomState(seed)
@@ -138,8 +138,8 @@ def g5big_learn(R):
     """G5big [r4]: PPOLearner.learn (ppo_learner.py:92-238) at the size where the product's paired / gather-fused launches engage
     (csrc/api.hip: from 262,144 rows per pass): 256x3 nets, n = B = 262,144, MB = 65,536, 2 epochs = 2 optimiser steps of 4
     minibatches.  The inputs come from seeds (g5big_inputs: a test rebuilds them); stored: an exact bit hash + the first 64 values
-    of the initial parameters, the first 64 values + plain sums after step 0, the FULL parameter vectors after the last step, the
-    report.  ~2 minutes on one thread."""
+    of the initial parameters, every 8th entry + norms of the first step's batch gradient (before clipping), the first 64 values +
+    plain sums of the parameters after step 0, the FULL parameter vectors after the last step, the report.  ~2 minutes on one thread."""
     cfg = dict(policy_type=0, d=107, n_act=90, layers=(256, 256, 256), n=262144, B=262144, MB=65536, epochs=2, seed=321,
                lr=3e-4, clip=0.2, ent=0.005)
     torch.manual_seed(cfg["seed"])
@@ -167,7 +167,25 @@ def g5big_learn(R):
         step_no[0] += 1
         return r
     learner.value_optimizer.step = rec
-    report = learner.learn(buf)
+    # the batch gradient of the FIRST optimiser step as clip_grad_norm_ receives it (ppo_learner.py:187-190: the value net first,
+    # then the policy), before it is scaled: every 8th entry + norms (the object the 1e-5 gradient tolerance is about; parameters
+    # after Adam only show it through a scale-free, ill-conditioned step)
+    real_clip, seen = torch.nn.utils.clip_grad_norm_, []
+
+    def spy(parameters, max_norm, *a, **k):
+        parameters = list(parameters)
+        if len(seen) < 2:
+            seen.append(torch.cat([p.grad.detach().reshape(-1) for p in parameters]).clone().numpy())
+        return real_clip(parameters, max_norm, *a, **k)
+    torch.nn.utils.clip_grad_norm_ = spy
+    try:
+        report = learner.learn(buf)
+    finally:
+        torch.nn.utils.clip_grad_norm_ = real_clip
+    for tag, gvec in zip(("value", "policy"), seen):
+        out[f"grad0.{tag}_every8"] = gvec[::8]
+        out[f"grad0.{tag}_l2"] = np.float64(np.sqrt((gvec.astype(np.float64) ** 2).sum()))
+        out[f"grad0.{tag}_max"] = np.float64(np.abs(gvec).max())
     report.pop("PPO Batch Consumption Time")
     out.update({"report." + k: np.float64(v) for k, v in report.items()})
     save("g5big_learn_discrete_256x3", **out, n_steps=np.int64(step_no[0]), cfg=np.array(json.dumps(cfg)))

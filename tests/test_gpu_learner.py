@@ -117,8 +117,13 @@ def test_learn_at_the_paired_launch_size_matches_the_reference_fixture(golden):
     hashes are in the fixture), the seeded construction must give the reference's initial parameters bit for bit (hash + first 64
     values), a library counter says which launch form ran, and the parameters after both optimiser steps go through the same
     float64-yardstick gate as the small learn() fixtures: HIP and the reference's own float32 result, both against
-    oracle/ppo.py::learn64, well-conditioned parameters at max(1e-5, 1.5 x reference), ill-conditioned ones under the derived
-    Adam bound.  After step 0 the fixture holds 64 + 64 values and two plain sums: compared under the same bound."""
+    oracle/ppo.py::learn64.  The sharp comparison is the first step's batch GRADIENT (what the north star's 1e-5 is about; the
+    fixture holds every 8th entry + norms of what the reference handed to clip_grad_norm_): err(HIP, fp64) <= max(1e-5, 1.5 x
+    err(reference, fp64)) of max|g|.  Parameters after Adam show a gradient only through a scale-free step: on this workload
+    (uniform actions, noise advantages: the gradient is a few outliers -- the head's biases -- over a sea of cancelling sums, 13 %
+    of the entries below 1e-4 of the largest) the reference's own float32 parameters sit 1.5e-3 of max|p| from float64 truth
+    after two steps, so the parameter gate is the yardstick alone: well-conditioned and ill-conditioned parameters each within
+    1.5 x the reference's own distance (the derived-bound fractions are printed for both)."""
     import importlib.util
     from rlgym_ppo_amd import _native as N
     from rlgym_ppo_amd.ppo import ExperienceBuffer
@@ -148,16 +153,19 @@ def test_learn_at_the_paired_launch_size_matches_the_reference_fixture(golden):
             b = flat[o:o + dims[i + 1]]; o += b.size
             params.append((torch.as_tensor(w.copy()), torch.as_tensor(b.copy())))
         return params
-    truth, weakest = {}, {}
+    truth, weakest, grad64 = {}, {}, {}
     ppo.learn64("discrete", split(p0, cfg["n_act"]), split(v0, 1),
                 dict(states=exp[0], actions=exp[1], log_probs=exp[2], values=exp[7], advantages=exp[8]), cfg["B"], cfg["MB"], cfg["epochs"],
                 cfg["clip"], cfg["ent"], cfg["lr"], cfg["lr"], np.random.RandomState(cfg["seed"]), weakest=weakest,
+                on_grad=lambda i, gp, gv: grad64.__setitem__(i, (gp.copy(), gv.copy())),
                 on_step=lambda i, p, v: truth.__setitem__(i, (np.concatenate([t.ravel() for wb in p for t in wb]),
                                                               np.concatenate([t.ravel() for wb in v for t in wb]),
                                                               weakest["pol"].copy(), weakest["val"].copy())))
     n_steps = int(g["n_steps"])
     assert n_steps == 2 and sorted(truth) == [0, 1]
     learner.n_epochs = 1
+    hip_grads = []
+    learner.grad_probe = lambda gr: hip_grads.append(gr.detach().cpu().numpy().astype(np.float64))
     passes0, paired0, gfused0 = (int(L.rlppo_dbg_counter(k)) for k in (2, 3, 4))
     reports = []
     for s in range(n_steps):
@@ -195,11 +203,22 @@ def test_learn_at_the_paired_launch_size_matches_the_reference_fixture(golden):
               f"fixture, fp64)={errs['ref'][0]:.2e}  | {n_ill} of {wp.size + wv.size} parameters with an ill-conditioned Adam step: HIP "
               f"{errs['hip'][1]:.1e} = {errs['hip'][2]:.3f} of the derived bound, reference {errs['ref'][1]:.1e} = {errs['ref'][2]:.3f}")
         assert errs["hip"][0] <= max(1e-5, 1.5 * errs["ref"][0]), errs
-        assert n_ill <= 0.05 * (wp.size + wv.size)
-        assert errs["hip"][2] <= 1.0 and errs["ref"][2] <= 1.0, errs
+        assert errs["hip"][1] <= max(1e-5, 1.5 * errs["ref"][1]), errs
     passes, paired, gfused = (int(L.rlppo_dbg_counter(k)) for k in (2, 3, 4))
     assert passes - passes0 == n_steps and paired - paired0 == n_steps and gfused - gfused0 == n_steps, \
         "the paired / gather-fused launches did not run: (passes, paired, gather-fused) = %s" % ((passes - passes0, paired - paired0, gfused - gfused0),)
+    # the first step's batch gradient: [grad_policy | grad_value] of the product against the reference's, both against float64
+    n_pol = p0.size
+    for tag, mine, t64 in (("policy", hip_grads[0][:n_pol], grad64[0][0]), ("value", hip_grads[0][n_pol:], grad64[0][1])):
+        ref8 = g[f"grad0.{tag}_every8"].astype(np.float64)
+        scale = np.abs(t64).max()
+        e_hip_all, e_hip8, e_ref8 = np.abs(mine - t64).max() / scale, np.abs(mine[::8] - t64[::8]).max() / scale, np.abs(ref8 - t64[::8]).max() / scale
+        l2_hip, l2_ref, l2_64 = np.sqrt((mine ** 2).sum()), float(g[f"grad0.{tag}_l2"]), np.sqrt((t64 ** 2).sum())
+        print(f"[fp64 gate] g5big first-step {tag} gradient: err(HIP, fp64) = {e_hip_all:.2e} of max|g| over all entries, {e_hip8:.2e} over every "
+              f"8th; err(reference, fp64) = {e_ref8:.2e} over every 8th; |g|2 HIP {l2_hip:.8e} reference {l2_ref:.8e} float64 {l2_64:.8e}")
+        assert e_hip_all <= max(1e-5, 1.5 * e_ref8), (tag, e_hip_all, e_ref8)
+        assert abs(l2_hip - l2_64) <= max(1e-5 * l2_64, 1.5 * abs(l2_ref - l2_64))
+        assert abs(float(g[f"grad0.{tag}_max"]) - scale) <= 1e-4 * scale
     for key in ("Policy Entropy", "Mean KL Divergence", "Value Function Loss", "SB3 Clip Fraction"):
         got, ref = float(np.mean([r[key] for r in reports])), float(g["report." + key])
         assert abs(got - ref) <= 2e-5 * max(abs(ref), 1e-4) + 1e-7, (key, got, ref)
