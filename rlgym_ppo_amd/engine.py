@@ -426,6 +426,9 @@ class HostExponential:
         self._buf = {}       # numel -> dict(ring=[pinned float32 vectors], uploaded=[event or None], turn)
         self._chain = []      # speculative requests in stream order: dict(shape, numel, state_in, link, future, buf, rec, slot)
         self._burst = {}      # numel -> dict(out=[cap, numel] pinned, links, cancel, uploaded, futures): storage of prefetch()
+        self._side = {}       # device -> the stream a finished burst is uploaded on
+        self._burst_lock = threading.Lock()
+        self.resident_hits = 0  # draws served from a burst that was already in HBM
         self.burst_bytes = int(os.environ.get("RLPPO_NOISE_PREFETCH_MB", "256")) << 20  # byte budget of one prefetched burst
         self.hits = self.misses = 0
         self.checked = False  # the one-time self-check against torch's own exponential_ (see _self_check)
@@ -549,6 +552,9 @@ class HostExponential:
         def __init__(self, link):
             self.link = link.view(np.int32)
 
+        def done(self):
+            return self.link[1] != 0
+
         def result(self):
             import time
             spins = 0
@@ -564,12 +570,33 @@ class HostExponential:
             ctypes.c_void_p(link_in0.ctypes.data) if link_in0 is not None else None, nbytes, numel, 1.0,
             ctypes.c_void_p(b["out"].data_ptr()), numel, ctypes.c_void_p(b["links"].ctypes.data), b["links"].shape[1],
             first, self.workers, count, ctypes.c_void_p(b["cancel"].ctypes.data)))
+        pend = b.get("dev_pending")
+        if pend is not None:
+            with self._burst_lock:
+                pend[0] -= 1
+                last = pend[0] == 0
+            if last and b["cancel"][0] == 0:  # every run of the burst is complete: ONE copy of the whole block, on the side stream
+                n_rows, dev = pend[1], pend[2]
+                with torch.cuda.device(dev):
+                    side = self._side.get(str(dev))
+                    if side is None:
+                        side = self._side[str(dev)] = torch.cuda.Stream(device=dev)
+                    side.wait_event(b["dev_free"])
+                    with torch.cuda.stream(side):
+                        b["dev"][:n_rows].copy_(b["out"][:n_rows], non_blocking=True)
+                        ev = torch.cuda.Event()
+                        ev.record(side)
+                b["dev_event"], b["dev_waited"] = ev, False
+                b["uploaded"][0] = ev      # the pinned block is not redrawn into before the copy has run (prefetch waits on it)
+                b["dev_ok"] = True
 
-    def prefetch(self, shape, count):
+    def prefetch(self, shape, count, device=None):
         """The caller's next `count` draws will be of `shape`, and nothing else will use torch's CPU generator before them (if
         something does, the chain is dropped at the next draw as ever: transparent).  Extends the speculative chain to `count`
         requests -- capped by `burst_bytes` -- and returns the number of requests added.  Returns at once: the draws run on the
-        helper threads (two C calls, no Python between draws)."""
+        helper threads (two C calls, no Python between draws).  With `device` (a CUDA device) the finished burst is copied to HBM in
+        ONE asynchronous copy on a side stream, enqueued by the helper thread that finishes last: the draws it serves then cost
+        neither a copy nor an event per step.  (Speculative too: values that are never served are simply never read.)"""
         shape = tuple(int(x) for x in shape)
         numel = 1
         for x in shape:
@@ -606,6 +633,17 @@ class HostExponential:
         b["cancel"][0] = 0
         prev = self._chain[-1] if self._chain else None
         pool = _pool("noise", self.workers)
+        b["dev_ok"] = False
+        if device is not None and torch.device(device).type == "cuda" and torch.cuda.is_available():
+            dev = torch.device(device)
+            if b.get("dev") is None or b["dev"].device != dev or b["dev"].shape[0] < b["out"].shape[0]:
+                b["dev"] = torch.empty(b["out"].shape, dtype=torch.float32, device=dev)
+            # the block is rewritten only behind everything launched so far (the kernels that read the previous burst)
+            b["dev_free"] = torch.cuda.Event()
+            b["dev_free"].record(torch.cuda.current_stream(dev))
+            b["dev_pending"] = [min(self.workers, need), need, dev]
+        else:
+            b["dev_pending"] = None
         b["futures"] = [pool.submit(self._burst_run, b, state_now if prev is None else None, prev["link"] if prev is not None else None,
                                     nbytes, numel, j, need) for j in range(min(self.workers, need))]
         for i in range(need):
@@ -633,6 +671,7 @@ class HostExponential:
         state = torch.get_rng_state()
         head = self._chain[0] if self._chain else None
         served = False
+        pre = None  # (burst record, index) when the served request's values are already in HBM
         if head is not None and head["shape"] == shape:
             # the state this request was drawn from: given for the first of a chain, else what its predecessor (already served:
             # the generator was set to exactly that) left behind
@@ -648,6 +687,7 @@ class HostExponential:
                 self._chain.pop(0)
                 after = self._link_state(head).clone()
                 buf, rec, slot = head["buf"], head["rec"], head["slot"]
+                pre = (rec, slot) if rec.get("dev") is not None and rec.get("dev_ok") else None
                 if self._chain:
                     self._chain[0]["prev_state"] = after  # what the new head must find the generator in
                     self._chain[0]["prev"] = None
@@ -661,7 +701,16 @@ class HostExponential:
             self.misses += 1
         torch.set_rng_state(after)
         out = buf.view(shape)
-        if device is not None and torch.device(device).type == "cuda":
+        on_gpu = device is not None and torch.device(device).type == "cuda"
+        if on_gpu and pre is not None and pre[0]["dev"].device == torch.device(device):
+            # [r4] the whole burst went to HBM when its last draw finished (during learn()): no copy, no event per step
+            b_, i_ = pre
+            if not b_["dev_waited"]:
+                torch.cuda.current_stream(b_["dev"].device).wait_event(b_["dev_event"])
+                b_["dev_waited"] = True
+            out = b_["dev"][i_].view(shape)
+            self.resident_hits += 1
+        elif on_gpu:
             out = out.to(device, non_blocking=True)
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream(out.device))
@@ -674,12 +723,13 @@ class HostExponential:
 _HOST_EXP = None
 
 
-def host_exponential_prefetch(shape, count):
-    """HostExponential.prefetch on the process-wide instance (see there): `count` upcoming draws of `shape` are produced ahead."""
+def host_exponential_prefetch(shape, count, device=None):
+    """HostExponential.prefetch on the process-wide instance (see there): `count` upcoming draws of `shape` are produced ahead
+    (and, with `device`, parked in HBM as soon as they are complete)."""
     global _HOST_EXP
     if _HOST_EXP is None:
         _HOST_EXP = HostExponential()
-    return _HOST_EXP.prefetch(shape, count)
+    return _HOST_EXP.prefetch(shape, count, device)
 
 
 def host_exponential(shape, device=None):

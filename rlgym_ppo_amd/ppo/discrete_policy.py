@@ -127,7 +127,7 @@ class DiscreteFF(ArenaModule):
     def prefetch_noise(self, n, count):
         """The next `count` calls of step() / get_action() will each act on n observations with the reference's CPU noise stream:
         have those draws produced ahead on the helper threads (engine.HostExponential.prefetch; transparent speculation)."""
-        return host_exponential_prefetch((int(n), self.n_actions), int(count))
+        return host_exponential_prefetch((int(n), self.n_actions), int(count), device=self.arena.device)
 
     # ---- hooks of the graph-replayed rollout step (ppo/_mlp.py::ActGraph)
     def _noise_shape(self, n):

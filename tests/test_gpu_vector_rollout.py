@@ -60,6 +60,62 @@ def test_vector_rollout_matches_trajectory_assembly(standardize):
     mgr.cleanup()
 
 
+def test_collect_learn_collect_consumes_the_reference_noise_stream_with_prefetch():
+    """[r4] The next collect's noise is drawn AHEAD, during add_new_experience + learn (engine.HostExponential.prefetch, called at the
+    end of a collect) and parked in HBM in one copy when the burst is complete; both are speculative and must be transparent.  A
+    collect -> add_new_experience -> learn -> collect sequence of the product (768 agents x 90 actions: above the look-ahead
+    threshold) against the oracle's lock-step rollout that draws torch.empty(n, 90).exponential_(1) step by step: the second
+    collect's action indices are the oracle's (only a learn() that left the CPU generator alone, and a prefetch that predicted
+    its states exactly, give that), the generator ends in the reference's state, and every draw of the second collect was served
+    from the chain (hits), the prefetched ones with their noise already resident in HBM (resident_hits)."""
+    from rlgym_ppo_amd import Learner, engine
+    na, T = 768, 6
+    mk = lambda: synthetic_env.SyntheticVectorEnv(n_agents=na, seed=9)
+    import contextlib, io
+    with contextlib.redirect_stdout(io.StringIO()):
+        learner = Learner(mk, vector_env=True, n_proc=1, timestep_limit=10**9, exp_buffer_size=na * T, ts_per_iteration=na * T,
+                          ppo_epochs=2, ppo_batch_size=na * T, ppo_minibatch_size=na * T // 2, policy_layer_sizes=(64, 64),
+                          critic_layer_sizes=(64, 64), checkpoints_save_folder=None, checkpoint_load_folder=None, save_every_ts=10**12,
+                          log_to_wandb=False, random_seed=5, standardize_obs=False)
+    try:
+        pol = learner.ppo_learner.policy
+        assert pol.noise_mode == "host"
+        engine._HOST_EXP = None
+        torch.manual_seed(4321)
+        exp1, _, n1, _ = learner.agent.collect_timesteps(na * T)
+        h = engine._HOST_EXP
+        assert len(h._chain) == T                     # the next collect's T draws are in the chain before learn() starts
+        a1 = exp1[1].cpu().numpy().copy()
+        params1 = [(l.weight.detach().cpu().clone(), l.bias.detach().cpu().clone()) for l in pol.arena.linears]
+        learner.add_new_experience(exp1)
+        with contextlib.redirect_stdout(io.StringIO()):
+            learner.ppo_learner.learn(learner.experience_buffer)
+        params2 = [(l.weight.detach().cpu().clone(), l.bias.detach().cpu().clone()) for l in pol.arena.linears]
+        hits0, pre0 = h.hits, h.resident_hits
+        exp2, _, n2, _ = learner.agent.collect_timesteps(na * T)
+        a2 = exp2[1].cpu().numpy().copy()
+        s_got = torch.get_rng_state()
+        assert h.hits - hits0 == T and h.misses == 1 and h.resident_hits - pre0 == T - h.depth   # (the first `depth` draws: the ordinary look-ahead)
+    finally:
+        learner.agent.cleanup()
+    # the oracle: the same interaction, noise drawn on the spot from the same seed
+    env = mk()
+    torch.manual_seed(4321)
+    state, acts = None, []
+    reset_obs = env.reset()
+    for params in (params1, params2):
+        def act_fn(obs, params=params):
+            probs = nets.discrete_probs(params, obs)
+            a, lp = nets.discrete_sample(probs, nets.draw_exp_noise(obs.shape[0], 90))
+            return a.numpy().astype(np.float32).reshape(-1, 1), lp.numpy()
+        ref, state = host.lockstep_rollout(reset_obs, lambda a: env.step(a)[:4], act_fn, T, standardize=False, state=state)
+        acts.append(ref[1])
+    assert torch.equal(s_got, torch.get_rng_state())                 # 2 T draws of [768, 90], nothing else, in the reference's order
+    for got, want in zip((a1, a2), acts):
+        diff = (got.reshape(-1) != want.reshape(-1)).sum()
+        assert diff <= 2, diff                                       # (a near-tie of p/q may flip under an ulp of the probabilities)
+
+
 def test_learner_loop_on_vector_env(tmp_path, capsys):
     from rlgym_ppo_amd import Learner
     learner = Learner(synthetic_env.make_vector_env, vector_env=True, n_proc=1, timestep_limit=1500, exp_buffer_size=1024,
