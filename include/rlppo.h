@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define RLPPO_ABI_VERSION 3
+#define RLPPO_ABI_VERSION 4
 #define RLPPO_MAX_LAYERS 16
 
 #define RLPPO_OK 0

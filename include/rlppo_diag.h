@@ -33,6 +33,12 @@ int rlppo_dbg_gemm_nt_stamped(void *stream, const float *A, int64_t lda, const f
  * 256 lanes apart, so every wave-instruction moves 1 KiB of contiguous bytes. */
 int rlppo_dbg_stream_floor(void *stream, const float *r, const float *d, const float *t, const float *v, float *o0, float *o1,
                            float *o2, int64_t n, int32_t shape);
+/* EXPERIMENT (round 4): C[M][256] = relu(A[M][K] . W[256][K]^T + bias) with fp32 A in memory and the products on the
+ * bf16 MFMA pipe: A split on the fly into three bf16 pieces (exact), W pre-split into three bf16 planes in stage-major order
+ * w_split[K / 32][3][256][32]; `terms` piece products kept per 32-wide K block (6 = all with a piece-index sum <= 2; 4, 3, 1: fewer,
+ * to see what each costs / buys).  store = 0 drops the output stores (K loop alone).  M % 256 == 0, K % 32 == 0. */
+int rlppo_dbg_gemm_nt_split(void *stream, const float *A, int64_t lda, const void *w_split, const float *bias, float *C, int64_t ldc, int64_t M,
+                            int32_t N, int32_t K, int32_t terms, int32_t store);
 #ifdef __cplusplus
 }
 #endif

@@ -11,7 +11,7 @@ from ctypes import POINTER, c_char_p, c_double, c_float, c_int32, c_int64, c_siz
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("RLPPO_LIB") or os.path.join(HERE, "librlppo.so")  # RLPPO_LIB: an alternative build (A/B of compile-time variants)
-ABI_VERSION = 3
+ABI_VERSION = 4
 COMM_ID_BYTES = 128  # RLPPO_COMM_ID_BYTES
 MAX_LAYERS = 16
 N_STATS = 8

@@ -11,4 +11,6 @@ int launch_probe2(hipStream_t st, int mode, int threads, int blocks, const float
 int launch_mfma_probe(hipStream_t st, float *out, int blocks, int iters, unsigned long long *clocks);
 int launch_stream_floor(hipStream_t st, const float *r, const float *d, const float *t, const float *v, float *o0, float *o1,
                         float *o2, long long n, int shape);
+int launch_gemm_nt_split(hipStream_t st, const float *A, int64_t lda, const unsigned short *Ws, const float *bias, float *C, int64_t ldc,
+                         int64_t M, int N, int K, int terms, int store);
 }  // namespace rlppo

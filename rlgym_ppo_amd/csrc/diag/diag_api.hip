@@ -122,4 +122,8 @@ int rlppo_dbg_stream_floor(void *stream, const float *r, const float *d, const f
     if (n <= 0 || n % 2048) return 1001;
     return launch_stream_floor((hipStream_t)stream, r, d, t, v, o0, o1, o2, (long long)n, shape);
 }
+int rlppo_dbg_gemm_nt_split(void *stream, const float *A, int64_t lda, const void *w_split, const float *bias, float *C, int64_t ldc, int64_t M,
+                            int32_t N, int32_t K, int32_t terms, int32_t store) {
+    return launch_gemm_nt_split((hipStream_t)stream, A, lda, reinterpret_cast<const unsigned short *>(w_split), bias, C, ldc, M, N, K, terms, store);
+}
 }

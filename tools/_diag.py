@@ -14,6 +14,7 @@ SIGNATURES = {
     "rlppo_dbg_gemm_nt_stamped": [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int64, c_int32,
                                   c_int32, c_void_p, c_int32],
     "rlppo_dbg_stream_floor": [c_void_p] * 8 + [c_int64, c_int32],
+    "rlppo_dbg_gemm_nt_split": [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int32, c_int32, c_int32, c_int32],
 }
 
 

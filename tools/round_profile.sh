@@ -2,7 +2,7 @@
 # One GPU-box session that regenerates the evidence under profiles/: usage  tools/round_profile.sh <tag>   (run from the repo root)
 # Collects into gpurun_out/<tag>/; tools/collect_profiles.py then condenses it into profiles/<tag>_*.
 set -eo pipefail
-TAG=${1:-r03}
+TAG=${1:-r04}
 OUT=gpurun_out/$TAG
 rm -rf $OUT/cfg5_stats $OUT/cfg5_fetch $OUT/cfg5_write $OUT/cfg5_sq $OUT/stats $OUT/stats_single $OUT/iso $OUT/pmc_sq $OUT/pmc_fetch $OUT/pmc_write $OUT/gae_stats $OUT/gae_fetch $OUT/gae_write $OUT/fa_depth $OUT/share8
 mkdir -p $OUT
