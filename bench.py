@@ -517,7 +517,7 @@ def cfg5_traffic(bf16):
     kernels are the cfg2 ones at K = 512: no pass of their own)."""
     if not bf16:
         return None
-    for tag in ("r03", "r02"):
+    for tag in ("r04", "r03", "r02"):
         try:
             t = json.load(open(os.path.join(ROOT, "profiles", tag + "_cfg5_bf16_traffic.json")))
         except Exception:

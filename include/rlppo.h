@@ -388,7 +388,9 @@ int rlppo_net_pack_bf16(void *stream, const int32_t *dims, int32_t n_layers, con
  *  31 paired pass: the critic's output-layer backward waits for the policy's loss kernel [1 (default) | 0 = both chains free-running]
  *  32 a one-output critic head is computed in the last hidden layer's forward epilogue [1 (default) | 0 = its own matrix-vector launch]
  *  33 paired launches: the two products' tiles interleave in the grid (a row tile's workgroups of both networks back to back on one
- *     XCD) [1 (default) | 0 = the second product stacked behind the first] */
+ *     XCD) [1 (default) | 0 = the second product stacked behind the first]
+ *  34 rlppo_clip_adam_pack2 grid-barrier spin limit [-1 = default 2^22 | 0 = a waiter gives up at once (tests)]
+ *  35 rlppo_clip_adam_pack2 test hook [0 | 1 = workgroup (0, 0) never arrives at the barrier: a grid that is not co-resident] */
 int rlppo_dbg_set(int32_t key, int32_t value);
 /* Counter bumped by every call that changes which kernels later launches select (rlppo_dbg_set, rlppo_set_*_precision): a
  * host that caches captured graphs of library calls keys them on it (rlgym_ppo_amd/ppo/_mlp.py::ActGraph). */
