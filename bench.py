@@ -432,6 +432,48 @@ def physical_cores():
         return None
 
 
+def x3_leg(learner, buf, epochs, steps=3, warmup=1):
+    """OPT-IN extra, never the headline: the same learn() on the same workload with rlppo_set_update_precision(2) -- fp32 data,
+    losses, dW, clip, Adam and fp32-grade products, but the hidden forward / dX launches on the bf16 MFMA pipe from three bf16
+    pieces per operand (csrc/gemm_split.hip; held to the same float64 gates as the fp32 precision by tests/test_gpu_kernels.py and
+    tests/test_gpu_learner.py).  Also times the 256 -> 256 forward of both forms at the update's launch shape."""
+    from rlgym_ppo_amd import _native as N
+    from rlgym_ppo_amd.engine import set_update_precision
+    L = N.lib()
+    set_update_precision("x3")
+    try:
+        for _ in range(warmup):
+            learner.learn(buf)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            learner.learn(buf)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    finally:
+        set_update_precision("fp32")
+    value = steps * epochs * BATCH / dt
+    M = int(getattr(learner, "_fused_rows", MINIBATCH))
+    st = lambda: ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    P = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
+    A = torch.randn(M, 256, device=learner._dev).clamp_(min=0)
+    W = torch.randn(256, 256, device=learner._dev) * 0.05
+    bias = torch.zeros(256, device=learner._dev)
+    C = torch.empty(M, 256, device=learner._dev)
+    bits = torch.zeros(max(int(L.rlppo_dbg_gemm_nt_bits_bytes(M, 256)), 8), dtype=torch.uint8, device=learner._dev)
+    planes = torch.zeros(3 * 256 * 256, dtype=torch.bfloat16, device=learner._dev)
+    N.check(L.rlppo_dbg_pack_x3(st(), P(W), 256, 256, 256, P(planes)))
+    ms3 = time_region(lambda: N.check(L.rlppo_dbg_gemm_nt_x3(st(), P(A), 256, P(planes), P(bias), P(C), 256, M, 256, 256, 0, P(bits))), 20, warm_s=0.3)
+    ms32 = time_region(lambda: N.check(L.rlppo_dbg_gemm_nt_bits(st(), P(A), 256, P(W), 256, P(bias), P(C), 256, M, 256, 256, 1, P(bits))), 20, warm_s=0.3)
+    flop = 2 * M * 256 * 256
+    log("update_x3 (opt-in): %.1f M samples/s; hidden forward %.4f ms split-bf16 (%.1f fp32-equivalent TFLOP/s) vs %.4f ms fp32 MFMA (%.1f)"
+        % (value / 1e6, ms3, flop / ms3 / 1e9, ms32, flop / ms32 / 1e9))
+    return dict(value=round(value, 1), unit="samples/s", ms_per_step=round(dt / steps * 1e3, 3), steps=steps,
+                precision="opt-in: fp32 data and results, hidden forward / dX products as six bf16-piece MFMAs (rlppo_set_update_precision(2)); NOT the headline",
+                equivalent_frac_of_f32_mfma_peak=round(FLOP_PER_SAMPLE * value / 1e12 / MFMA_F32_PEAK_TF, 4),
+                fwd_hidden_ms=round(ms3, 4), fwd_hidden_ms_fp32_mfma=round(ms32, 4), fwd_hidden_tflops_fp32_equivalent=round(flop / ms3 / 1e9, 1))
+
+
 BF16_MFMA_PEAK_TF = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA peak (the 5 PF headline figure includes 2:1 sparsity)
 
 
@@ -667,9 +709,10 @@ def parse_args(argv=None):
     ap.add_argument("--config", choices=("cfg2", "cfg5"), default="cfg2",
                     help="cfg2 = BASELINE configs[1] (the headline metric); cfg5 = configs[4] shape (Gaussian policy, obs 231, "
                          "512x4 nets) -- update throughput only, no extra legs")
-    ap.add_argument("--precision", choices=("fp32", "bf16"), default="fp32",
-                    help="update precision: fp32 (parity mode, default) or bf16 = bf16-operand forward / fp32 master, accumulate "
-                         "and backward (BASELINE configs[4]; rlppo_set_update_precision)")
+    ap.add_argument("--precision", choices=("fp32", "bf16", "x3"), default="fp32",
+                    help="update precision: fp32 (parity mode, default), bf16 = bf16-operand forward / fp32 master, accumulate "
+                         "and backward (BASELINE configs[4]; rlppo_set_update_precision), x3 = fp32 data and results with the hidden "
+                         "forward / dX products on the bf16 MFMA pipe from three-piece operands (opt-in, DESIGN 4.5)")
     ap.add_argument("--allreduce", choices=("torch", "direct", "ab"), default="torch",
                     help="N > 1: gradient exchange through torch.distributed (RCCL; the default and the product's default), through "
                          "librlppo's own RCCL communicator, or 'ab' = the timed region uses torch.distributed, the JSON line is printed, "
@@ -842,9 +885,9 @@ def main():
     with contextlib.redirect_stdout(sys.stderr):
         learner, buf = build_workload(device, config=args.config)
     learner.n_epochs = args.epochs
-    if args.precision == "bf16":
+    if args.precision != "fp32":
         from rlgym_ppo_amd.engine import set_update_precision
-        set_update_precision("bf16")
+        set_update_precision(args.precision)
 
     def barrier():
         if world > 1:
@@ -877,7 +920,8 @@ def main():
     out = {
         "metric": "ppo_update_samples_per_sec", "value": round(value, 1), "unit": "samples/s", "n_gpus": n_seen,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
-        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "bf16" if bf16 else "f32",
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "bf16" if bf16 else ("f32 (hidden forward / dX products split into bf16 pieces, opt-in)" if args.precision == "x3" else "f32"),
         "data": "synthetic" + (" (DRY RUN: all ranks on one GPU over gloo, not a measurement)" if dryrun else ""),
         "config": {"workload": workload, "epochs_per_step": args.epochs, "samples_per_step": args.epochs * BATCH,
                    "parallelism": f"dp{world}: {per_rank} minibatch slice(s) per rank and pass, 1 RCCL all-reduce per optimiser step"
@@ -943,6 +987,7 @@ def main():
         out["update_flop_efficiency"] = dict(achieved=round(FLOP_PER_SAMPLE * value / 1e12, 2), peak=MFMA_F32_PEAK_TF, unit="TFLOP/s",
                                              frac=round(FLOP_PER_SAMPLE * value / 1e12 / MFMA_F32_PEAK_TF, 4))
         out["kernel_breakdown"] = rows
+        out["update_x3"] = x3_leg(learner, buf, args.epochs)
         out["gae"] = gae_bench()
         out["rollout"] = rollout_bench(learner)
         del learner, buf  # the other legs build their own workloads
@@ -961,7 +1006,7 @@ def main():
             collect_ms=it["collect_ms"], iteration_steps_per_s=it["steps_per_s"],
             cfg5_fp32_samples_per_s=out["cfg5"]["fp32"]["value"], cfg5_bf16_samples_per_s=out["cfg5"]["bf16"]["value"],
             cfg5_bf16_update_frac_of_bf16_peak=out["cfg5"]["bf16"]["update_flop_efficiency"]["frac"],
-            cpu_port_samples_per_s=out["cpu_baseline"]["value"])
+            cpu_port_samples_per_s=out["cpu_baseline"]["value"], update_x3_optin_samples_per_s=out["update_x3"]["value"])
     emit()
     if world > 1:
         dist.destroy_process_group()

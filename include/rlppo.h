@@ -170,7 +170,8 @@ typedef struct rlppo_minibatch_args {
     const int32_t *val_dims;      /* HOST */
     const float *pol_packed;
     const float *val_packed;
-    const float *pol_packed_r;    /* bf16 update precision only (else NULL): rlppo_net_pack_bf16's images of both networks */
+    const float *pol_packed_r;    /* bf16 update precision only (else NULL): rlppo_net_pack_bf16's images of both networks; in the
+                                   * split-bf16 precision (mode 2) pol_wb16 / val_wb16 hold rlppo_net_pack_x3's planes instead */
     const float *val_packed_r;
     const void *pol_wb16;
     const void *val_wb16;
@@ -353,7 +354,7 @@ int rlppo_welford_merge(void *stream, int32_t d, void *mean, void *m2, int64_t c
 int rlppo_set_inference_precision(int32_t mode);
 
 /* Precision of the PPO UPDATE (rlppo_ppo_minibatch): 0 = fp32 (default; the parity mode: fp32 losses/grads within 1e-5 of the
- * reference), 1 = BASELINE configs[4] "bf16 fwd / fp32 master weights" = mixed-precision training as torch writes it:
+ * reference), 2 = fp32 with split-bf16 hidden products (below), 1 = BASELINE configs[4] "bf16 fwd / fp32 master weights" = mixed-precision training as torch writes it:
  *   - every forward product of both networks multiplies bf16-rounded operands (activations and weights, round-to-nearest-even)
  *     on the bf16 MFMA pipe and accumulates in fp32; bias and activation in fp32; the hidden activations are stored as bf16;
  *   - the gradient with respect to each hidden activation is therefore a bf16 tensor too (rounded once, after the fp32
@@ -371,6 +372,25 @@ int rlppo_set_update_precision(int32_t mode);
 int rlppo_get_update_precision(void);
 int64_t rlppo_wb16_elems(const int32_t *dims, int32_t n_layers);
 int rlppo_net_pack_bf16(void *stream, const int32_t *dims, int32_t n_layers, const float *flat, float *packed_r, void *wb16);
+/* [r4] mode 2 (OPT-IN, not the default and not what bench.py's headline runs): the update stays fp32 in memory and in meaning --
+ * activations, gradients, losses, dW, clip, Adam exactly as mode 0 -- but the hidden-layer FORWARD and dX products (widths that are
+ * multiples of 256, contraction a multiple of 32, layers >= 1) run on the bf16 MFMA pipe from three-piece operands: every fp32
+ * value x = x_h + x_m + x_l (bf16 pieces, rounded to nearest), six piece products per element pair, the five small ones summed
+ * apart from the accumulator (csrc/gemm_split.hip).  gfx950's fp32-input MFMA has 1/16 of the bf16 rate; this form is 1.35 x
+ * faster per launch and, against float64, MORE accurate than the fp32 MFMA's fmaf chain (0.43-0.46 x its error at K = 256).  The
+ * gradients then differ from mode 0's by fp32 rounding noise only (tests/test_gpu_kernels.py, tests/test_gpu_learner.py hold
+ * mode 2 to the same float64 gates as mode 0).  Needs, per network, the image rlppo_net_pack_x3 derives from the PACKED copy
+ * after every optimiser step: rlppo_x3_elems bf16 values (the stage-major planes [K / 32][3][N][32] of W for every covered
+ * forward and of W^T for every covered dX), handed over in rlppo_minibatch_args.pol_wb16 / val_wb16.  Policy and critic run as two
+ * chains in this mode (no paired launches, the critic's head as its own matrix-vector launch). */
+int64_t rlppo_x3_elems(const int32_t *dims, int32_t n_layers);
+int rlppo_net_pack_x3(void *stream, const int32_t *dims, int32_t n_layers, const float *packed, void *planes);
+/* single-kernel entry points of that precision (tests, bench.py): planes[C / 32][3][R][32] <- the pieces of S[R][C] (row stride ld);
+ * C[M][N] = relu(A[M][K] . W^T + bias) with bits <- [C > 0] (mode 0) or (A . B^T) masked by bits (mode 1); N % 256 == 0, K % 32 == 0,
+ * bits as rlppo_dbg_gemm_nt_bits_bytes(M, N). */
+int rlppo_dbg_pack_x3(void *stream, const float *S, int64_t ld, int32_t R, int32_t C, void *planes);
+int rlppo_dbg_gemm_nt_x3(void *stream, const float *A, int64_t lda, const void *planes, const float *bias, float *C, int64_t ldc, int64_t M,
+                         int32_t N, int32_t K, int32_t mode, void *bits);
 
 /* ------------------------------------------------------------------------------------------ diagnostics */
 /* A/B switches for measurements and tests (also RLPPO_TUNE="key=value,..." in the Python host).  Defaults in brackets.

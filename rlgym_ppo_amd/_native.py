@@ -115,6 +115,11 @@ SIGNATURES = {
     "rlppo_get_update_precision": (c_int32, []),
     "rlppo_wb16_elems": (c_int64, [_P32, c_int32]),
     "rlppo_net_pack_bf16": (c_int32, [c_void_p, _P32, c_int32, c_void_p, c_void_p, c_void_p]),
+    "rlppo_x3_elems": (c_int64, [_P32, c_int32]),
+    "rlppo_net_pack_x3": (c_int32, [c_void_p, _P32, c_int32, c_void_p, c_void_p]),
+    "rlppo_dbg_pack_x3": (c_int32, [c_void_p, c_void_p, c_int64, c_int32, c_int32, c_void_p]),
+    "rlppo_dbg_gemm_nt_x3": (c_int32, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int32, c_int32, c_int32,
+                                        c_void_p]),
     "rlppo_dbg_set": (c_int32, [c_int32, c_int32]),
     "rlppo_selection_epoch": (c_int64, []),
     "rlppo_dbg_counter": (c_int64, [c_int32]),

@@ -69,6 +69,31 @@ static int max_pout(const NetLayout &net) {
     return m;
 }
 
+// [r4] The weight image of the split-bf16 update precision (rlppo_set_update_precision(2), csrc/gemm_split.hip): for every hidden
+// layer l >= 1 whose shape the split kernels cover, the three bf16 planes of W_l in stage-major order (forward), and for every
+// layer l >= 1 whose dX they cover (the output layer included, unless it is a one-output head) the planes of W_l^T.  Offsets in
+// bf16 elements; -1 = that product keeps its fp32 kernel.
+struct X3Layout {
+    int64_t fwd[RLPPO_MAX_LAYERS], dx[RLPPO_MAX_LAYERS], total;
+};
+static void x3_layout(const NetLayout &net, X3Layout *o) {
+    int64_t off = 0;
+    const int last = net.n_layers - 1;
+    for (int l = 0; l < net.n_layers; ++l) {
+        const LayerLayout &L = net.L[l];
+        o->fwd[l] = o->dx[l] = -1;
+        if (l >= 1 && l < last && nt_split_ok(L.pout, L.pin)) {
+            o->fwd[l] = off;
+            off += (int64_t)3 * L.pout * L.pin;
+        }
+        if (l >= 1 && !(l == last && gemv_head_ok(L.out, L.pin)) && nt_split_ok(L.pin, L.pout)) {
+            o->dx[l] = off;
+            off += (int64_t)3 * L.pin * L.pout;
+        }
+    }
+    o->total = off;
+}
+
 static int g_fold_vhead = 1;  // rlppo_dbg_set(32, 0/1): a one-output head inside the last hidden layer's forward epilogue (update passes)
 
 // Forward pass.  acts[l] receives the output of layer l ([n][pout_l]); for inference the caller passes two
@@ -79,7 +104,10 @@ static int g_fold_vhead = 1;  // rlppo_dbg_set(32, 0/1): a one-output head insid
 // (the first layer fetches its rows through the table: nt_gather_ok must hold for it).
 static int forward(hipStream_t st, const NetLayout &net, const float *packed, const float *obs, int64_t ld_obs, int64_t n,
                    int out_tanh, float *const *acts, int bf16_operands = 0, unsigned long long *const *bits = nullptr,
-                   bool *have_bits = nullptr, const unsigned *rowtab = nullptr, int64_t src_rows = 0, bool *head_folded = nullptr) {
+                   bool *have_bits = nullptr, const unsigned *rowtab = nullptr, int64_t src_rows = 0, bool *head_folded = nullptr,
+                   const unsigned short *x3 = nullptr) {
+    X3Layout xl;
+    if (x3) x3_layout(net, &xl);
     if (have_bits)
         for (int l = 0; l < net.n_layers; ++l) have_bits[l] = false;
     const float *x = obs;
@@ -89,6 +117,7 @@ static int forward(hipStream_t st, const NetLayout &net, const float *packed, co
     const int hl = net.n_layers - 1;
     bool fold = head_folded && g_fold_vhead && hl >= 1 && !out_tanh && !bf16_operands && bits && bits[hl - 1] &&
                 gemv_head_ok(net.L[hl].out, net.L[hl].pin) && net.L[hl - 1].pout / 128 <= 2;
+    if (x3 && hl >= 1 && xl.fwd[hl - 1] >= 0) fold = false;  // (the split forward has no dot-product epilogue: the head keeps its own launch)
     if (head_folded) *head_folded = false;
     for (int l = 0; l < net.n_layers; ++l) {
         const LayerLayout &L = net.L[l];
@@ -100,7 +129,10 @@ static int forward(hipStream_t st, const NetLayout &net, const float *packed, co
             rc = launch_gemv_fwd(st, x, ldx, packed + L.off_w, packed + L.off_b, acts[l], L.pout, n, L.pin, L.pout);
         else {
             rc = -1;
-            if (!last && bits && bits[l] && !bf16_operands) {
+            if (!last && bits && bits[l] && x3 && xl.fwd[l] >= 0) {  // [r4] fp32 data, bf16 MFMA pipe, fp32-grade result
+                rc = launch_gemm_nt_split(st, x, ldx, x3 + xl.fwd[l], packed + L.off_b, acts[l], L.pout, n, L.pout, L.pin, 0, bits[l]);
+                if (rc == 0) have_bits[l] = true;
+            } else if (!last && bits && bits[l] && !bf16_operands) {
                 NtDot dots[2];
                 const bool fold_here = fold && l == hl - 1;
                 if (fold_here) {
@@ -513,7 +545,7 @@ static size_t tn_layer_floats(const NetLayout &net, int l, int64_t mb) {
         const size_t g = (size_t)cdiv(mb, 64) * (size_t)(net.L[l].pin + 4);  // upper bound: at least 64 rows per block
         if (g > f) f = g;
     }
-    if (g_update_bf16 && l == net.n_layers - 1) {  // narrow head of the bf16 precision: per-lane partials of thin_dw_b16
+    if (g_update_bf16 == 1 && l == net.n_layers - 1) {  // narrow head of the bf16 precision: per-lane partials of thin_dw_b16
         const size_t g = thin_dw_ws_floats(net.L[l].out, net.L[l].pin, mb);
         if (g > f) f = g;
     }
@@ -546,7 +578,7 @@ static size_t train_ws_floats(const NetLayout &pol, const NetLayout &val, int64_
     for (int l = 0; l + 1 < pol.n_layers; ++l) bits += nt_bits_floats(mb, pol.L[l].pout);
     for (int l = 0; l + 1 < val.n_layers; ++l) bits += nt_bits_floats(mb, val.L[l].pout);
     size_t b16 = 0;  // bf16 update precision: the gathered states, every hidden activation and its gradient as bf16 (2 B/element)
-    if (g_update_bf16) {
+    if (g_update_bf16 == 1) {
         size_t el = pol.L[0].pin;  // + per hidden layer: the activation and its gradient
         for (int l = 0; l + 1 < pol.n_layers; ++l) el += 2 * (size_t)pol.L[l].pout;
         for (int l = 0; l + 1 < val.n_layers; ++l) el += 2 * (size_t)val.L[l].pout;
@@ -573,9 +605,12 @@ struct ChainCtx {
 // dL/d(acts[l-1]) = dY of layer l-1 (one buffer per layer: the dW launches read them later)
 static int backward(hipStream_t st, const NetLayout &net, const float *packed, const float *states, int64_t ld_states,
                     int64_t mb, float *const *acts, float *const *dx, float *grad, float *tn_ws,
-                    unsigned long long *const *bits, const bool *have_bits, const ChainCtx &cx, bool head_folded = false) {
+                    unsigned long long *const *bits, const bool *have_bits, const ChainCtx &cx, bool head_folded = false,
+                    const unsigned short *x3 = nullptr) {
     const int last = net.n_layers - 1;
     int rc = 0;
+    X3Layout xl;
+    if (x3) x3_layout(net, &xl);
     for (int l = last; l >= 0; --l) {
         const LayerLayout &L = net.L[l];
         const float *dY = l == last ? acts[last] : dx[l];
@@ -601,7 +636,9 @@ static int backward(hipStream_t st, const NetLayout &net, const float *packed, c
             if (have_bits[l - 1]) rc = launch_gemv_dx_bits(st, dY, ld_hy, packed + L.off_w, bits[l - 1], dx[l - 1], L.pin, L.pin, mb);
             if (rc == -1) rc = launch_gemv_dx(st, dY, ld_hy, packed + L.off_w, acts[l - 1], L.pin, dx[l - 1], L.pin, L.pin, mb);
         } else {
-            if (have_bits[l - 1])
+            if (have_bits[l - 1] && x3 && xl.dx[l] >= 0)  // [r4] split-bf16 dX
+                rc = launch_gemm_nt_split(st, dY, L.pout, x3 + xl.dx[l], nullptr, dx[l - 1], L.pin, mb, L.pin, L.pout, 1, bits[l - 1]);
+            else if (have_bits[l - 1])
                 rc = launch_gemm_nt_bits(st, dY, L.pout, packed + L.off_wt, L.pout, nullptr, dx[l - 1], L.pin, mb, L.pin, L.pout,
                                          EPI_MASK, bits[l - 1]);
             if (rc == -1)
@@ -870,7 +907,8 @@ int rlppo_ppo_minibatch(void *stream, const rlppo_minibatch_args *a) {
     unsigned *const rowtab = reinterpret_cast<unsigned *>(w);  // physical buffer row of every row of the pass (gather_meta_kernel)
     w += (size_t)mb;
     // bf16 update precision: bf16 copies of the gathered rows and of the hidden activations, and the rounded weight images
-    const bool b16 = g_update_bf16 != 0;
+    const bool b16 = g_update_bf16 == 1;
+    const bool x3 = g_update_bf16 == 2;  // [r4] split-bf16 hidden forward / dX (csrc/gemm_split.hip); everything else as fp32
     unsigned short *states_b = nullptr, *pactb[RLPPO_MAX_LAYERS] = {}, *vactb[RLPPO_MAX_LAYERS] = {};
     unsigned short *pdxb[RLPPO_MAX_LAYERS] = {}, *vdxb[RLPPO_MAX_LAYERS] = {};
     if (b16) {
@@ -932,7 +970,10 @@ int rlppo_ppo_minibatch(void *stream, const rlppo_minibatch_args *a) {
         rc = order_after(side, st, bk.ev_fork[slot]);
         if (rc) return rc;
     }
-    const bool twin = !b16 && (g_paired == 2 || (g_paired == 1 && mb >= PAIRED_MIN_ROWS)) && twin_ok(pol, val, mb);
+    const bool twin = !b16 && !x3 && (g_paired == 2 || (g_paired == 1 && mb >= PAIRED_MIN_ROWS)) && twin_ok(pol, val, mb);
+    const unsigned short *pol_x3 = x3 ? reinterpret_cast<const unsigned short *>(a->pol_wb16) : nullptr;
+    const unsigned short *val_x3 = x3 ? reinterpret_cast<const unsigned short *>(a->val_wb16) : nullptr;
+    if (x3) RLPPO_CHECK_ARG(pol_x3 && val_x3, "ppo_minibatch: the split-bf16 update precision needs the rlppo_net_pack_x3 images of both networks (pol_wb16 / val_wb16)");
     ++g_cnt_pass;
     if (twin) ++g_cnt_paired_pass;
     if (fused_gather) ++g_cnt_gather_fused_pass;
@@ -1071,9 +1112,9 @@ int rlppo_ppo_minibatch(void *stream, const rlppo_minibatch_args *a) {
         const float *x0 = fused_gather ? a->states : states;
         const int64_t ld0 = fused_gather ? a->ld_states : ld_states;
         const unsigned *rt = fused_gather ? rowtab : nullptr;
-        rc = forward(side, val, val_w, x0, ld0, mb, 0, vact, 0, vbits, vhave, rt, src_rows, &v_folded);
+        rc = forward(side, val, val_w, x0, ld0, mb, 0, vact, 0, vbits, vhave, rt, src_rows, &v_folded, val_x3);
         if (rc) return rc;
-        rc = forward(st, pol, pol_w, x0, ld0, mb, a->head == RLPPO_HEAD_GAUSSIAN, pact, 0, pbits, phave, rt, src_rows);
+        rc = forward(st, pol, pol_w, x0, ld0, mb, a->head == RLPPO_HEAD_GAUSSIAN, pact, 0, pbits, phave, rt, src_rows, nullptr, pol_x3);
     }
     if (rc) return rc;
     // loss epilogue: outputs -> output gradients in place, report statistics accumulated on device.  The value loss only
@@ -1121,9 +1162,9 @@ int rlppo_ppo_minibatch(void *stream, const rlppo_minibatch_args *a) {
             cp.ld_src = cv.ld_src = a->ld_states;
             cp.src_rows = cv.src_rows = src_rows;
         }
-        rc = backward(side, val, val_w, states, ld_states, mb, vact, vdx, a->val_grad, val_tn_ws, vbits, vhave, cv, v_folded);
+        rc = backward(side, val, val_w, states, ld_states, mb, vact, vdx, a->val_grad, val_tn_ws, vbits, vhave, cv, v_folded, val_x3);
         if (rc) return rc;
-        rc = backward(st, pol, pol_w, states, ld_states, mb, pact, pdx, a->pol_grad, pol_tn_ws, pbits, phave, cp);
+        rc = backward(st, pol, pol_w, states, ld_states, mb, pact, pdx, a->pol_grad, pol_tn_ws, pbits, phave, cp, false, pol_x3);
     }
     if (rc) return rc;
     if (side != st) rc = order_after(st, side, bk.ev_join[slot]);
@@ -1221,9 +1262,47 @@ int rlppo_net_pack_bf16(void *stream, const int32_t *dims, int32_t n_layers, con
     RLPPO_CHECK_ARG(flat && packed_r && wb16, "net_pack_bf16: null pointer");
     return launch_pack_bf16((hipStream_t)stream, net, flat, packed_r, reinterpret_cast<unsigned short *>(wb16));
 }
+int64_t rlppo_x3_elems(const int32_t *dims, int32_t n_layers) {
+    NetLayout net;
+    if (make_layout(dims, n_layers, &net)) return -1;
+    X3Layout xl;
+    x3_layout(net, &xl);
+    return xl.total;
+}
+int rlppo_net_pack_x3(void *stream, const int32_t *dims, int32_t n_layers, const float *packed, void *planes) {
+    NetLayout net;
+    int rc = make_layout(dims, n_layers, &net);
+    if (rc) return rc;
+    X3Layout xl;
+    x3_layout(net, &xl);
+    if (xl.total == 0) return 0;
+    RLPPO_CHECK_ARG(packed && planes, "net_pack_x3: null pointer");
+    unsigned short *pl = reinterpret_cast<unsigned short *>(planes);
+    for (int l = 0; l < net.n_layers; ++l) {
+        const LayerLayout &L = net.L[l];
+        if (xl.fwd[l] >= 0) {  // W [pout][pin]: the forward's B operand
+            rc = launch_pack_split((hipStream_t)stream, packed + L.off_w, L.pin, L.pout, L.pin, pl + xl.fwd[l]);
+            if (rc) return rc;
+        }
+        if (xl.dx[l] >= 0) {  // W^T [pin][pout]: dX's B operand
+            rc = launch_pack_split((hipStream_t)stream, packed + L.off_wt, L.pout, L.pin, L.pout, pl + xl.dx[l]);
+            if (rc) return rc;
+        }
+    }
+    return 0;
+}
+// single-kernel entry points of the split-bf16 products (tests, bench.py)
+int rlppo_dbg_pack_x3(void *stream, const float *S, int64_t ld, int32_t R, int32_t C, void *planes) {
+    return launch_pack_split((hipStream_t)stream, S, ld, R, C, reinterpret_cast<unsigned short *>(planes));
+}
+int rlppo_dbg_gemm_nt_x3(void *stream, const float *A, int64_t lda, const void *planes, const float *bias, float *C, int64_t ldc, int64_t M,
+                         int32_t N, int32_t K, int32_t mode, void *bits) {
+    return launch_gemm_nt_split((hipStream_t)stream, A, lda, reinterpret_cast<const unsigned short *>(planes), bias, C, ldc, M, N, K, mode,
+                                reinterpret_cast<unsigned long long *>(bits));
+}
 static int64_t g_selection_epoch = 0;  // bumped by every call that changes which kernels later launches select
 int rlppo_set_update_precision(int32_t mode) {
-    RLPPO_CHECK_ARG(mode == 0 || mode == 1, "set_update_precision: mode %d (0 = fp32, 1 = bf16-operand forward)", mode);
+    RLPPO_CHECK_ARG(mode >= 0 && mode <= 2, "set_update_precision: mode %d (0 = fp32, 1 = bf16 mixed precision, 2 = split-bf16 products)", mode);
     g_update_bf16 = mode;
     ++g_selection_epoch;
     return 0;

@@ -145,6 +145,10 @@ bool tn_gather_ok(int64_t ldx, int64_t src_rows);
 // (A: activations / activation gradients, B: rlppo_net_pack_bf16's W or W^T blocks)
 // hidden: relu, rounded output as bf16 (Cb) + fp32 (C) + ReLU bitmask; output layer (!hidden): fp32 C, epi bias / bias+tanh
 bool nt_b16_ok(int N, int K, bool hidden);
+bool nt_split_ok(int N, int K);  // gemm_split.hip [r4]
+int launch_pack_split(hipStream_t st, const float *S, int64_t ld, int R, int Cc, unsigned short *planes);
+int launch_gemm_nt_split(hipStream_t st, const float *A, int64_t lda, const unsigned short *planes, const float *bias, float *C, int64_t ldc,
+                         int64_t M, int N, int K, int mode, unsigned long long *bits);
 int launch_gemm_nt_b16(hipStream_t st, const unsigned short *A, int64_t lda, const unsigned short *B, int64_t ldb, const float *bias,
                        float *C, int64_t ldc, unsigned short *Cb, int64_t ldcb, int64_t M, int N, int K, int epi, int mode,
                        unsigned long long *bits);  // mode: 0 output layer, 1 hidden layer, 2 rounded + masked dX

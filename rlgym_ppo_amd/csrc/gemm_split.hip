@@ -1,0 +1,271 @@
+// gemm_split.hip -- [r4, OPT-IN: rlppo_set_update_precision(2)] the hidden-layer forward and dX products of the PPO update with fp32
+// data in memory and fp32-grade results, computed on the bf16 MFMA pipe.
+//
+// gfx950's fp32-input MFMA runs at 1/16 of its bf16 rate (157 vs 2500 TFLOP/s), and the fp32 update sits at 0.78 of that peak.  A
+// product that must stay fp32-accurate can still use the fast pipe: split every fp32 operand into three bf16 pieces,
+//     x = x_h + x_m + x_l     (x_h = bf16(x), x_m = bf16(x - x_h), x_l = bf16(x - x_h - x_m): |x_m| <= 2^-9 |x|, |x_l| <= 2^-18 |x|),
+// and keep the six piece products whose index sum is <= 2:
+//     x . w  ~=  x_h.w_h + (x_h.w_m + x_m.w_h + x_m.w_m + x_h.w_l + x_l.w_h)           (dropped: <= 2^-26 |x||w|)
+// Each is one v_mfma_f32_16x16x32_bf16 with fp32 accumulation.  The five small products of a 32-wide K block are summed among
+// THEMSELVES first (a chain that starts from 0: its roundings are 2^-8 of the large product's) and enter the accumulator with one
+// addition, so the accumulator sees ONE MFMA and one add per K block: measured against float64 this is MORE accurate than the
+// fp32 MFMA's fmaf chain (0.43-0.46 x its error at K = 256, profiles/r04_split_bf16_probe.txt) at 1.35 x its speed.
+//
+// Operands: A [M][K] fp32 exactly as the update stores its activations / activation gradients -- split ON THE FLY, per MFMA
+// fragment, in registers (v_cvt_pk_bf16_f32 + shift / mask + subtract: 5.5 vector instructions per value); the weights pre-split
+// by rlppo_net_pack_x3 after every optimiser step into three bf16 planes in STAGE-MAJOR order [K / 32][3][N][32], so that the 48 KiB
+// a K step needs are contiguous in memory.  One 256 x 256 output tile per workgroup (8 waves as 4 x 2, 128 accumulator registers
+// per lane, one workgroup per CU), two stages of 80 KiB: A 256 x 32 fp32 (the 128-byte-row image and swizzle of the bf16 kernels)
+// + three 16 KiB weight planes.  The tile leaves through LDS, 16 rows per wave at a time (2 x 512 contiguous bytes per
+// wave-instruction).  FWD: C = relu(A . W^T + b) and the ReLU bitmask in the layout every other kernel of the update reads
+// (128 x 128 tiles, one 64-bit word per lane); DX: C = (A . B^T) masked by the bitmask of the layer below.
+#include "gemm_detail.hpp"
+
+namespace rlppo {
+namespace {
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+// three bf16x8 MFMA fragments (8 consecutive k of one row) from 8 fp32 values, pieces rounded to nearest even
+__device__ __forceinline__ void split8(const f32x4 &lo, const f32x4 &hi, bf16x8 &ph, bf16x8 &pm, bf16x8 &pl) {
+    u32x4 h, m, l;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const float x0 = p < 2 ? lo[2 * p] : hi[2 * p - 4], x1 = p < 2 ? lo[2 * p + 1] : hi[2 * p - 3];
+        const unsigned hp = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{x0, x1}, bf16x2));
+        const float r0 = x0 - __uint_as_float(hp << 16), r1 = x1 - __uint_as_float(hp & 0xFFFF0000u);  // exact
+        const unsigned mp = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{r0, r1}, bf16x2));
+        const float s0 = r0 - __uint_as_float(mp << 16), s1 = r1 - __uint_as_float(mp & 0xFFFF0000u);  // exact
+        h[p] = hp;
+        m[p] = mp;
+        l[p] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{s0, s1}, bf16x2));
+    }
+    ph = __builtin_bit_cast(bf16x8, h);
+    pm = __builtin_bit_cast(bf16x8, m);
+    pl = __builtin_bit_cast(bf16x8, l);
+}
+
+constexpr int TM = 256, TN = 256, BK = 32;   // tile, K step
+constexpr int A_STAGE = TM * BK * 4;         // 32 KiB
+constexpr int W_PLANE = TN * BK * 2;         // 16 KiB
+constexpr int STAGE = A_STAGE + 3 * W_PLANE; // 80 KiB
+enum { SPLIT_FWD = 0, SPLIT_DX = 1 };
+
+// planes: the N_total x K weight matrix as [K / 32][3][N_total][32] bf16; this workgroup's column tile is rows n0 .. n0 + 255 of every
+// [N_total][32] block.  grid = (row tiles, column tiles).
+template <int MODE>
+__global__ __launch_bounds__(512, 1) void gemm_nt_split_kernel(const float *__restrict__ A, unsigned lda_b, const unsigned short *__restrict__ planes,
+                                                               int n_total, const float *__restrict__ bias, float *__restrict__ C, unsigned ldc_b,
+                                                               int64_t M, int K, unsigned long long *__restrict__ bits, int row_tiles128) {
+    constexpr bool DX = MODE == SPLIT_DX;
+    extern __shared__ __attribute__((aligned(16))) char lds[];  // [2][A 256 x 128 B swizzled | 3 x W plane 256 x 64 B]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const int r16 = lane & 15, q = lane >> 4;
+    const int wr = wave_u >> 1, wc = wave_u & 1;
+    const int row_tile = blockIdx.x, col_tile = blockIdx.y;
+    const int64_t m0 = (int64_t)row_tile * TM;
+    const int n0 = col_tile * TN;
+    const int rows_here = (int)((M - m0) < TM ? (M - m0) : TM);
+    const int nk = K / BK;
+    const __amdgpu_buffer_rsrc_t a_rs = make_rsrc(reinterpret_cast<const char *>(A) + m0 * lda_b, (unsigned)(rows_here - 1) * lda_b + (unsigned)K * 4);
+    // a K step's planes of this column tile: plane p at byte (kt * 3 + p) * n_total * 64 + n0 * 64, 16 KiB contiguous each
+    const unsigned plane_stride = (unsigned)n_total * 64u;
+    const __amdgpu_buffer_rsrc_t w_rs = make_rsrc(reinterpret_cast<const char *>(planes) + (int64_t)n0 * 64, (unsigned)nk * 3u * plane_stride);
+    // A pieces: 8 rows x 128 B per instruction (lane -> row lane / 8, chunk lane % 8, swizzled on the source side), 4 per wave and stage
+    const int row_p = wave * 8 + lane / 8, pch = lane % 8, lch = pch ^ (row_p & 7);
+    const unsigned a_off = (unsigned)row_p * lda_b + lch * 16;
+    auto issue = [&](int buf, int kt) {
+        char *Ad = lds + buf * STAGE + wave_u * (8 * 128);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rs, reinterpret_cast<float *>(Ad + i * (64 * 128)), 16, a_off, (unsigned)kt * 128u + i * 64u * lda_b, 0, 0);
+        // weights: 48 pieces of 1 KiB per stage, 6 per wave: piece g = plane g / 16, KiB g % 16 of it
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const int g = wave_u * 6 + i;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rs, reinterpret_cast<float *>(lds + buf * STAGE + A_STAGE + g * 1024), 16, (unsigned)lane * 16u,
+                                                     ((unsigned)kt * 3u + (unsigned)(g >> 4)) * plane_stride + (unsigned)(g & 15) * 1024u, 0, 0);
+        }
+    };
+    // bitmask words of this wave's two 32-row lane slots (128 x 128-tile layout of relu_bits, as gemm_nt_b16w_kernel)
+    size_t widx[2];
+    bool wlive[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int rt128 = row_tile * (TM / 128) + (wr >> 1), ct128 = col_tile * 2 + wc, nct128 = gridDim.y * 2;
+        widx[h] = ((size_t)rt128 * nct128 + ct128) * 256 + ((2 * wr + h) & 3) * 64 + lane;
+        wlive[h] = rt128 < row_tiles128;
+    }
+    f32x4 acc[4][8];
+    unsigned long long mask_word[2] = {0, 0};
+    if (DX) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+            if (wlive[h]) mask_word[h] = bits[widx[h]];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            acc[0][j] = *reinterpret_cast<const f32x4 *>(&bias[n0 + wc * 128 + j * 16 + q * 4]);
+            acc[1][j] = acc[2][j] = acc[3][j] = acc[0][j];
+        }
+    }
+    issue(0, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (kt + 1 < nk) issue(cur ^ 1, kt + 1);
+        const char *Ac = lds + cur * STAGE;
+        const char *Wc = Ac + A_STAGE;
+        bf16x8 ah[4], am[4], al[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = wr * 64 + i * 16 + r16;
+            const f32x4 lo = *reinterpret_cast<const f32x4 *>(Ac + row * 128 + (((2 * q) ^ (row & 7)) * 16));
+            const f32x4 hi = *reinterpret_cast<const f32x4 *>(Ac + row * 128 + (((2 * q + 1) ^ (row & 7)) * 16));
+            split8(lo, hi, ah[i], am[i], al[i]);
+        }
+#pragma unroll
+        for (int jh = 0; jh < 2; ++jh) {
+            bf16x8 wh[4], wm[4], wl[4];
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const int col = wc * 128 + (jh * 4 + jj) * 16 + r16;
+                wh[jj] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4 *>(Wc + col * 64 + q * 16));
+                wm[jj] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4 *>(Wc + W_PLANE + col * 64 + q * 16));
+                wl[jj] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4 *>(Wc + 2 * W_PLANE + col * 64 + q * 16));
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    f32x4 t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[jj], al[i], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                    t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[jj], ah[i], t, 0, 0, 0);
+                    t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm[jj], am[i], t, 0, 0, 0);
+                    t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[jj], am[i], t, 0, 0, 0);
+                    t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm[jj], ah[i], t, 0, 0, 0);
+                    f32x4 c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[jj], ah[i], acc[i][jh * 4 + jj], 0, 0, 0);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) c[e] += t[e];
+                    acc[i][jh * 4 + jj] = c;
+                }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    // ---- epilogue: relu + bitmask (FWD) or the mask of the layer below (DX), in place
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        unsigned lo, hi;
+        if (DX) {
+            lo = (unsigned)mask_word[h];
+            hi = (unsigned)(mask_word[h] >> 32);
+        } else {
+            lo = hi = 0;
+        }
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int b = (ii * 8 + j) * 4 + e;
+                    if (DX) {
+                        const unsigned m = 0u - (((b < 32 ? lo : hi) >> (b & 31)) & 1u);
+                        acc[2 * h + ii][j][e] = __uint_as_float(__float_as_uint(acc[2 * h + ii][j][e]) & m);
+                    } else {
+                        const float x = relu1(acc[2 * h + ii][j][e]);
+                        acc[2 * h + ii][j][e] = x;
+                        const unsigned v = x > 0.f ? 1u : 0u;
+                        if (b < 32) lo |= v << b;
+                        else hi |= v << (b - 32);
+                    }
+                }
+        if (!DX && bits && wlive[h]) bits[widx[h]] = ((unsigned long long)hi << 32) | lo;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- the fp32 tile leaves through LDS, 16 rows of the wave's 64 x 128 sub-tile at a time: a lane holds 4 consecutive columns of
+    // one row (a wave-instruction would store 16 rows x 64 bytes); parked in 8 KiB of the wave's own (16-byte chunk c of row r at
+    // chunk c ^ r) and read back as rows it leaves as 2 rows x 512 contiguous bytes per wave-instruction.  In-wave: no barrier.
+    __syncthreads();  // every wave is done with the last stage
+    char *mine = lds + wave_u * (16 * 512);
+    const __amdgpu_buffer_rsrc_t c_rs = make_rsrc(reinterpret_cast<char *>(C) + m0 * ldc_b + (int64_t)(n0 + wc * 128) * 4, (unsigned)(rows_here - 1) * ldc_b + 128 * 4);
+    const int rr = lane >> 5, c32 = lane & 31;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if (i) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the previous quarter's read-back is in registers
+#pragma unroll
+        for (int j = 0; j < 8; ++j) *reinterpret_cast<f32x4 *>(mine + r16 * 512 + (((j * 4 + q) ^ r16) * 16)) = acc[i][j];
+        f32x4 v[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const int r = 2 * t + rr;
+            v[t] = *reinterpret_cast<const f32x4 *>(mine + r * 512 + ((c32 ^ r) * 16));
+        }
+        const unsigned c_off = (unsigned)(wr * 64 + i * 16 + rr) * ldc_b + c32 * 16;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) stb(c_rs, c_off, 2 * t * ldc_b, v[t]);
+    }
+}
+
+// planes[(ks * 3 + p) * R + r][t] = piece p of S[r][ks * 32 + t]   (S: R x Cc fp32, row stride ld; Cc % 32 == 0)
+__global__ __launch_bounds__(256) void pack_split_kernel(const float *__restrict__ S, int64_t ld, int R, int Cc, unsigned short *__restrict__ planes) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (int64_t)R * Cc) return;
+    const int r = (int)(i / Cc), c = (int)(i % Cc);
+    const float x = S[(int64_t)r * ld + c];
+    const __bf16 h = (__bf16)x;
+    const float r1 = x - (float)h;
+    const __bf16 m = (__bf16)r1;
+    const float r2 = r1 - (float)m;
+    const __bf16 l = (__bf16)r2;
+    const int ks = c >> 5, t = c & 31;
+    const int64_t base = ((int64_t)ks * 3 * R + r) * 32 + t;
+    planes[base] = __builtin_bit_cast(unsigned short, h);
+    planes[base + (int64_t)R * 32] = __builtin_bit_cast(unsigned short, m);
+    planes[base + (int64_t)2 * R * 32] = __builtin_bit_cast(unsigned short, l);
+}
+}  // namespace
+
+bool nt_split_ok(int N, int K) { return N > 0 && N % 256 == 0 && K >= 32 && K % 32 == 0; }
+
+int launch_pack_split(hipStream_t st, const float *S, int64_t ld, int R, int Cc, unsigned short *planes) {
+    RLPPO_CHECK_ARG(S && planes && R > 0 && Cc > 0 && Cc % 32 == 0 && ld >= Cc, "pack_split: R=%d C=%d ld=%ld", R, Cc, (long)ld);
+    const int64_t n = (int64_t)R * Cc;
+    hipLaunchKernelGGL(pack_split_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st, S, ld, R, Cc, planes);
+    RLPPO_LAUNCH_CHECK();
+    return 0;
+}
+
+// mode 0: C[M][N] = relu(A[M][K] . W^T + bias), bits <- [C > 0]; mode 1: C = (A . B^T) masked by bits (bias unused)
+int launch_gemm_nt_split(hipStream_t st, const float *A, int64_t lda, const unsigned short *planes, const float *bias, float *C, int64_t ldc,
+                         int64_t M, int N, int K, int mode, unsigned long long *bits) {
+    if (M <= 0) return 0;
+    RLPPO_CHECK_ARG(nt_split_ok(N, K) && A && planes && C && bits && (bias || mode == SPLIT_DX) && (mode == SPLIT_FWD || mode == SPLIT_DX) &&
+                        lda >= K && ldc >= N && lda % 4 == 0 && ldc % 4 == 0,
+                    "gemm_nt_split: N=%d K=%d mode=%d lda=%ld ldc=%ld", N, K, mode, (long)lda, (long)ldc);
+    const int64_t lim = (int64_t)1 << 31;
+    RLPPO_CHECK_ARG(257 * lda * 4 < lim && 257 * ldc * 4 < lim && (int64_t)(K / 32) * 3 * N * 64 < lim, "gemm_nt_split: operand too wide for 32-bit offsets");
+    static PerDeviceOnce attr[2];
+    constexpr int LDS_BYTES = 2 * STAGE;
+    const dim3 grid((unsigned)cdiv(M, 256), (unsigned)(N / 256));
+    const int rt128 = (int)cdiv(M, 128);
+    if (mode == SPLIT_FWD) {
+        if (int rc_ = set_dynamic_lds_once((const void *)gemm_nt_split_kernel<SPLIT_FWD>, LDS_BYTES, attr[0])) return rc_;
+        hipLaunchKernelGGL((gemm_nt_split_kernel<SPLIT_FWD>), grid, dim3(512), LDS_BYTES, st, A, (unsigned)(lda * 4), planes, N, bias, C,
+                           (unsigned)(ldc * 4), M, K, bits, rt128);
+    } else {
+        if (int rc_ = set_dynamic_lds_once((const void *)gemm_nt_split_kernel<SPLIT_DX>, LDS_BYTES, attr[1])) return rc_;
+        hipLaunchKernelGGL((gemm_nt_split_kernel<SPLIT_DX>), grid, dim3(512), LDS_BYTES, st, A, (unsigned)(lda * 4), planes, N, bias, C,
+                           (unsigned)(ldc * 4), M, K, bits, rt128);
+    }
+    RLPPO_LAUNCH_CHECK();
+    return 0;
+}
+}  // namespace rlppo

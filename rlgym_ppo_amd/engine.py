@@ -72,6 +72,8 @@ class NetArena:
         self.ws = Workspace(device)
         self.packed_r = self.wb16 = None  # bf16 update precision: rounded images (rlppo_net_pack_bf16), built on first use
         self._packed_bf16_key = None
+        self.x3 = None  # split-bf16 update precision: the three-plane images of the covered layers (rlppo_net_pack_x3)
+        self._packed_x3_key = None
         self._packed_key = None
         self.native_epoch = 0  # bumped whenever a kernel rewrites `flat` behind torch's back (Adam)
         self.bind()
@@ -125,6 +127,21 @@ class NetArena:
                                                 ptr(self.wb16)))
             self._packed_bf16_key = key
         return self.packed_r, self.wb16
+
+    def ensure_packed_x3(self):
+        """[r4] The weight image of the split-bf16 update precision (set_update_precision("x3")): for every hidden forward / dX product
+        the split kernels cover, the layer's weights as three bf16 planes in stage-major order (include/rlppo.h, rlppo_net_pack_x3),
+        derived from the PACKED copy and rebuilt whenever the master weights changed.  Returns the image (a bf16 tensor)."""
+        if not self.is_bound():
+            self.bind()
+        self.ensure_packed()
+        if self.x3 is None:
+            self.x3 = torch.zeros(max(int(N.lib().rlppo_x3_elems(self.dims_c, self.n_layers)), 8), dtype=torch.bfloat16, device=self.device)
+        key = self._pack_key()
+        if key != self._packed_x3_key:
+            N.check(N.lib().rlppo_net_pack_x3(stream_ptr(), self.dims_c, self.n_layers, ptr(self.packed), ptr(self.x3)))
+            self._packed_x3_key = key
+        return self.x3
 
     def _pack_key(self):
         # bind() re-points every Parameter with `p.data = view`, which gives it a version counter of its own: in-place updates
@@ -755,11 +772,11 @@ def set_update_precision(mode):
     BASELINE configs[4] "bf16 fwd / fp32 master weights", i.e. mixed-precision training: forward AND backward products on bf16
     operands (bf16 activations and activation gradients, bf16 MFMA, fp32 accumulate), fp32 losses / dW, db accumulation / clip /
     Adam on the fp32 master arena (include/rlppo.h)."""
-    N.check(N.lib().rlppo_set_update_precision({"fp32": 0, "bf16": 1}[mode]))
+    N.check(N.lib().rlppo_set_update_precision({"fp32": 0, "bf16": 1, "x3": 2}[mode]))
 
 
 def update_precision():
-    return "bf16" if N.lib().rlppo_get_update_precision() else "fp32"
+    return {0: "fp32", 1: "bf16", 2: "x3"}[int(N.lib().rlppo_get_update_precision())]
 
 
 def set_inference_precision(mode):

@@ -196,7 +196,11 @@ class PPOLearner(object):
         a.pol_dims = ctypes.cast(pa.dims_c, ctypes.POINTER(ctypes.c_int32))
         a.val_dims = ctypes.cast(va.dims_c, ctypes.POINTER(ctypes.c_int32))
         a.pol_packed, a.val_packed = pa.packed.data_ptr(), va.packed.data_ptr()
-        self._bf16 = bool(N.lib().rlppo_get_update_precision())  # bf16-operand forward: the rounded weight images travel too
+        prec = int(N.lib().rlppo_get_update_precision())
+        self._bf16 = prec == 1  # bf16-operand forward: the rounded weight images travel too
+        self._x3 = prec == 2    # [r4] fp32 update with split-bf16 hidden forward / dX products: the three-plane images travel
+        if self._x3:
+            a.pol_wb16, a.val_wb16 = pa.ensure_packed_x3().data_ptr(), va.ensure_packed_x3().data_ptr()
         if self._bf16:
             (pr, pw), (vr, vw) = pa.ensure_packed_bf16(), va.ensure_packed_bf16()
             a.pol_packed_r, a.val_packed_r, a.pol_wb16, a.val_wb16 = pr.data_ptr(), vr.data_ptr(), pw.data_ptr(), vw.data_ptr()
@@ -280,6 +284,9 @@ class PPOLearner(object):
                     if self._bf16:  # re-round the master weights the optimiser step just moved (one small launch per net)
                         pa.ensure_packed_bf16()
                         va.ensure_packed_bf16()
+                    if self._x3:    # re-split them (two small launches per covered layer)
+                        pa.ensure_packed_x3()
+                        va.ensure_packed_x3()
                     for k, (j, cnt) in enumerate(fuse_runs(slices_for_rank(n_slices, rank, world), self.max_fused_minibatches)):
                         args.slot = k % self.n_slots
                         args.workspace = self._slot_ws[args.slot]

@@ -35,9 +35,11 @@ def grads_err(got, want):
     return max(max(_rel(gw, ww), _rel(gb, wb)) for (gw, gb), (ww, wb) in zip(got, want))
 
 
-def hip_masks(L, params, obs):
+def hip_masks(L, params, obs, x3=False):
     """[h_l > 0] of every hidden layer as the HIP forward computes it: the product's own gemm_nt kernels, layer by layer,
-    through the C ABI (rlppo_dbg_gemm_nt with the bias+ReLU epilogue on the packed weights)."""
+    through the C ABI (rlppo_dbg_gemm_nt with the bias+ReLU epilogue on the packed weights).  x3: the split-bf16 update precision --
+    layers >= 1 whose shape its kernel covers (width % 256 == 0, contraction % 32 == 0) go through rlppo_dbg_gemm_nt_x3, as in
+    rlppo_ppo_minibatch."""
     from rlgym_ppo_amd import _native as N
     P = lambda t: ctypes.c_void_p(t.data_ptr())
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -57,7 +59,13 @@ def hip_masks(L, params, obs):
         w_ptr = ctypes.c_void_p(packed.data_ptr() + 4 * off)
         b_ptr = ctypes.c_void_p(packed.data_ptr() + 4 * (off + 2 * pout * pin))
         out = torch.empty(n, pout, device="cuda")
-        N.check(L.rlppo_dbg_gemm_nt(st, P(h), pin, w_ptr, pin, b_ptr, None, 0, P(out), pout, n, pout, pin, 1))
+        if x3 and l >= 1 and pout % 256 == 0 and pin % 32 == 0:
+            planes = torch.zeros(3 * pout * pin, dtype=torch.bfloat16, device="cuda")
+            bits = torch.zeros(max(int(L.rlppo_dbg_gemm_nt_bits_bytes(n, pout)), 8), dtype=torch.uint8, device="cuda")
+            N.check(L.rlppo_dbg_pack_x3(st, w_ptr, pin, pout, pin, P(planes)))
+            N.check(L.rlppo_dbg_gemm_nt_x3(st, P(h), pin, P(planes), b_ptr, P(out), pout, n, pout, pin, 0, P(bits)))
+        else:
+            N.check(L.rlppo_dbg_gemm_nt(st, P(h), pin, w_ptr, pin, b_ptr, None, 0, P(out), pout, n, pout, pin, 1))
         masks.append((out[:, :dims[l + 1]] > 0).cpu().numpy())
         off += 2 * pout * pin + pout
         h, pin = out, pout
@@ -122,7 +130,7 @@ def _edge_decisions(head, pol, val, obs, acts, old, adv, tgt, clip, ent, mb_rati
     return w
 
 
-def gate(L, head, pol, val, obs, acts, old, adv, tgt, clip, ent, mb_ratio, got, var=(0.1, 1.0), label="", floor=1e-5):
+def gate(L, head, pol, val, obs, acts, old, adv, tgt, clip, ent, mb_ratio, got, var=(0.1, 1.0), label="", floor=1e-5, x3=False):
     """got = (grad_policy, grad_value, stats[>=5]) of the HIP minibatch over exactly these rows.  Returns the measured errors."""
     gp, gv, stats = got
     obs = np.asarray(obs, np.float32)
@@ -141,7 +149,7 @@ def gate(L, head, pol, val, obs, acts, old, adv, tgt, clip, ent, mb_ratio, got, 
                                  torch.as_tensor(np.asarray(adv, np.float32)), torch.as_tensor(np.asarray(tgt, np.float32)), clip, ent,
                                  mb_ratio, var)
     out = {"n": n, "edge_rows": len(edge)}
-    for who, grads_p, grads_v, mp, mv in (("hip", gp, gv, hip_masks(L, pol, obs), hip_masks(L, val, obs)),
+    for who, grads_p, grads_v, mp, mv in (("hip", gp, gv, hip_masks(L, pol, obs, x3), hip_masks(L, val, obs, x3)),
                                           ("cpu", cpu["grad_policy"], cpu["grad_value"], cpu_masks(pol, obs), cpu_masks(val, obs))):
         flips = _check_flips(pol, mp, det["pol"], who) + _check_flips(val, mv, det["val"], who)
         w = None

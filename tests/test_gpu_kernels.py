@@ -829,6 +829,12 @@ def run_minibatch(L, head, pol, val, obs_all, acts_all, old_all, tgt_all, adv_al
             return run_minibatch(L, head, pol, val, obs_all, acts_all, old_all, tgt_all, adv_all, idx, clip, ent, mb_ratio, var, "bf16*")
         finally:
             check(L, L.rlppo_set_update_precision(0))
+    if precision == "x3":  # [r4] the split-bf16 hidden products (rlppo_set_update_precision(2)): same call with the three-plane images
+        check(L, L.rlppo_set_update_precision(2))
+        try:
+            return run_minibatch(L, head, pol, val, obs_all, acts_all, old_all, tgt_all, adv_all, idx, clip, ent, mb_ratio, var, "x3*")
+        finally:
+            check(L, L.rlppo_set_update_precision(0))
     P_, V_ = Net(L, pol), Net(L, val)
     states = P_.pad(obs_all)
     acts = dev(np.asarray(acts_all, np.float32).reshape(len(obs_all), -1))
@@ -853,6 +859,13 @@ def run_minibatch(L, head, pol, val, obs_all, acts_all, old_all, tgt_all, adv_al
             check(L, L.rlppo_net_pack_bf16(stream(), net.dims_c, net.nl, P(net.flat), P(pr), P(wb)))
             imgs += [pr, wb]
         a.pol_packed_r, a.pol_wb16, a.val_packed_r, a.val_wb16 = (t.data_ptr() for t in imgs)
+    if precision == "x3*":
+        imgs = []
+        for net in (P_, V_):
+            pl = torch.zeros(max(int(L.rlppo_x3_elems(net.dims_c, net.nl)), 8), dtype=torch.bfloat16, device="cuda")
+            check(L, L.rlppo_net_pack_x3(stream(), net.dims_c, net.nl, P(net.packed), P(pl)))
+            imgs.append(pl)
+        a.pol_wb16, a.val_wb16 = (t.data_ptr() for t in imgs)
     a.states, a.ld_states, a.n_rows, a.actions = states.data_ptr(), states.shape[1], states.shape[0], acts.data_ptr()
     a.old_logp, a.targets, a.advantages, a.idx, a.mb = old.data_ptr(), tgt.data_ptr(), adv.data_ptr(), idxd.data_ptr(), mb
     a.clip_range, a.ent_coef, a.mb_ratio = clip, ent, mb_ratio
@@ -1062,6 +1075,97 @@ def test_fused_pass_full_size_cfg2(L):
         for k in (0, 1):
             assert relerr(whole[k], parts[k]) < 1e-5
     np.testing.assert_allclose(st[:5], st_sum / 8, rtol=1e-5, atol=1e-8)
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 256, 32), (1000, 256, 96), (4227, 512, 256), (65536, 256, 256)])
+def test_gemm_nt_x3_forward_and_dx(L, M, N, K):
+    """[r4] The split-bf16 hidden products (csrc/gemm_split.hip; OPT-IN update precision 2): fp32 operands in memory, three bf16
+    pieces each, six piece products on the bf16 MFMA pipe, the five small ones summed apart from the accumulator.  Against float64:
+    the forward (bias + relu) and the masked dX must be AT LEAST as accurate as the product's fp32-MFMA kernels on the same
+    operands (max and rms error, 5 % of slack for the rms); the ReLU bitmask the forward writes is the one every other kernel of
+    the update reads -- word for word the fp32 kernel's except where a pre-activation sits within rounding of 0 -- and the dX form
+    applies a bitmask written by the fp32 kernel exactly as the fp32 dX kernel does; the packed planes add up to the weights
+    (2^-24 relative: the third piece rounds the second residual).  Ragged row counts, two column tiles, K = 32 ... 256."""
+    g = torch.Generator(device="cuda").manual_seed(M + K)
+    A = (torch.randn(M, K, device="cuda", generator=g).clamp_(min=0) * torch.rand(M, K, device="cuda", generator=g)).contiguous()
+    W = ((torch.rand(N, K, device="cuda", generator=g) * 2 - 1) / np.sqrt(K)).contiguous()
+    bias = ((torch.rand(N, device="cuda", generator=g) - 0.5) * 0.2).contiguous()
+    planes = torch.zeros(3 * N * K, dtype=torch.bfloat16, device="cuda")
+    check(L, L.rlppo_dbg_pack_x3(stream(), P(W), K, N, K, P(planes)))
+    pl = planes.view(K // 32, 3, N, 32).float()
+    rebuilt = (pl[:, 0] + pl[:, 1] + pl[:, 2]).permute(1, 0, 2).reshape(N, K)
+    assert (rebuilt - W).abs().max().item() <= 2.0 ** -24 * W.abs().max().item()
+    nb = max(int(L.rlppo_dbg_gemm_nt_bits_bytes(M, N)), 8)
+    bits32, bits3 = torch.zeros(nb, dtype=torch.uint8, device="cuda"), torch.zeros(nb, dtype=torch.uint8, device="cuda")
+    C32, C3 = torch.empty(M, N, device="cuda"), torch.full((M, N), float("nan"), device="cuda")
+    check(L, L.rlppo_dbg_gemm_nt_bits(stream(), P(A), K, P(W), K, P(bias), P(C32), N, M, N, K, 1, P(bits32)))
+    check(L, L.rlppo_dbg_gemm_nt_x3(stream(), P(A), K, P(planes), P(bias), P(C3), N, M, N, K, 0, P(bits3)))
+    rows = torch.arange(0, M, max(1, M // 2048), device="cuda")
+    pre = A[rows].double() @ W.double().t() + bias.double()
+    truth = torch.relu(pre)
+    scale = truth.abs().max().item()
+    e32, e3 = (C32[rows].double() - truth).abs(), (C3[rows].double() - truth).abs()
+    print(f"[x3] forward {M}x{N}x{K}: err vs float64 (of max|C|) split-bf16 max {e3.max().item() / scale:.2e} rms {e3.pow(2).mean().sqrt().item() / scale:.2e}; "
+          f"fp32 MFMA max {e32.max().item() / scale:.2e} rms {e32.pow(2).mean().sqrt().item() / scale:.2e}")
+    assert torch.isfinite(C3).all()
+    assert e3.max().item() <= max(1.0 * e32.max().item(), 2e-7 * scale) and e3.pow(2).mean().sqrt().item() <= 1.05 * e32.pow(2).mean().sqrt().item() + 1e-9 * scale
+    # bitmask: the same words as the fp32 kernel's but for pre-activations within rounding of zero
+    diff = (bits32 != bits3)
+    n_diff_bits = int(sum(bin(int(x)).count("1") for x in (bits32[diff] ^ bits3[diff]).cpu().numpy()))
+    near_zero = int((pre.abs() < 1e-6 * scale).sum().item()) * max(1, M // rows.numel()) + 8
+    assert n_diff_bits <= near_zero, (n_diff_bits, near_zero)
+    # dX through the FP32 kernel's bitmask: dX[M][K'] = (dY[M][N'] . Wd[N'][K']) masked; here dY = C32 (N' = N), K' = N2
+    N2 = 256
+    Wd = ((torch.rand(N2, N, device="cuda", generator=g) * 2 - 1) / np.sqrt(N)).contiguous()   # B operand [out cols N2][contraction N]
+    planes_d = torch.zeros(3 * N2 * N, dtype=torch.bfloat16, device="cuda")
+    check(L, L.rlppo_dbg_pack_x3(stream(), P(Wd), N, N2, N, P(planes_d)))
+    dY = torch.randn(M, N, device="cuda", generator=g)
+    mask_src = torch.randn(M, N2, device="cuda", generator=g)
+    nb2 = max(int(L.rlppo_dbg_gemm_nt_bits_bytes(M, N2)), 8)
+    mbits = torch.zeros(nb2, dtype=torch.uint8, device="cuda")
+    scratch = torch.empty(M, N2, device="cuda")
+    zero_b = torch.zeros(N2, device="cuda")
+    # a bitmask in the library's layout for `mask_src > 0`: the fp32 forward kernel with identity weights would need K = N2; instead let
+    # it write the mask of relu(mask_src . I + 0) -- the fp32 kernel, K = N2
+    eye = torch.eye(N2, device="cuda").contiguous()
+    check(L, L.rlppo_dbg_gemm_nt_bits(stream(), P(mask_src), N2, P(eye), N2, P(zero_b), P(scratch), N2, M, N2, N2, 1, P(mbits)))
+    dX32, dX3 = torch.empty(M, N2, device="cuda"), torch.full((M, N2), float("nan"), device="cuda")
+    check(L, L.rlppo_dbg_gemm_nt_bits(stream(), P(dY), N, P(Wd), N, None, P(dX32), N2, M, N2, N, 3, P(mbits)))
+    check(L, L.rlppo_dbg_gemm_nt_x3(stream(), P(dY), N, P(planes_d), None, P(dX3), N2, M, N2, N, 1, P(mbits)))
+    tr = (dY[rows].double() @ Wd.double().t()) * (mask_src[rows] > 0)
+    sc = tr.abs().max().item()
+    d32, d3 = (dX32[rows].double() - tr).abs(), (dX3[rows].double() - tr).abs()
+    print(f"[x3] dX {M}x{N2}x{N}: split-bf16 max {d3.max().item() / sc:.2e} rms {d3.pow(2).mean().sqrt().item() / sc:.2e}; fp32 MFMA max {d32.max().item() / sc:.2e} rms {d32.pow(2).mean().sqrt().item() / sc:.2e}")
+    assert torch.equal(dX3 == 0, dX32 == 0) or ((dX3 == 0) != (dX32 == 0)).sum().item() <= 4   # the same entries masked
+    assert d3.max().item() <= max(1.0 * d32.max().item(), 2e-7 * sc) and d3.pow(2).mean().sqrt().item() <= 1.05 * d32.pow(2).mean().sqrt().item() + 1e-9 * sc
+
+
+def test_minibatch_x3_precision_cfg2_shape(L):
+    """[r4] rlppo_ppo_minibatch in the split-bf16 update precision at the cfg2 shape (256x3 nets, obs 107, 90 actions; hidden
+    forwards of layers 1-2, their dX and the head's dX on the split kernels), 3000 gathered rows and the full 65,536-row
+    minibatch: through the SAME float64 gate as the fp32 precision (err(HIP, fp64) <= max(1e-5, 1.5 x the CPU fp32 oracle's),
+    masks read through the split kernel), and the gradients within fp32 rounding noise of the fp32 precision's own."""
+    torch.manual_seed(123)
+    pol = nets.init_mlp(107, (256, 256, 256), 90)
+    val = nets.init_mlp(107, (256, 256, 256), 1)
+    rs = np.random.RandomState(1)
+    n = 70000
+    obs = np.clip(rs.randn(n, 107), -5, 5).astype(np.float32)
+    probs = nets.discrete_probs(pol, obs)
+    act, logp = nets.discrete_sample(probs, nets.draw_exp_noise(n, 90))
+    old = (logp + torch.as_tensor(rs.randn(n).astype(np.float32) * 0.2)).numpy()
+    adv = rs.randn(n).astype(np.float32)
+    tgt = rs.randn(n).astype(np.float32)
+    perm = rs.permutation(n)
+    for rows, ratio in ((3000, 0.5), (65536, 1.0)):
+        idx = perm[:rows]
+        got3 = run_minibatch(L, "discrete", pol, val, obs, act.numpy(), old, tgt, adv, idx, 0.2, 0.005, ratio, precision="x3")
+        got32 = run_minibatch(L, "discrete", pol, val, obs, act.numpy(), old, tgt, adv, idx, 0.2, 0.005, ratio)
+        fp64_gate.gate(L, "discrete", pol, val, obs[idx], act.numpy()[idx], old[idx], adv[idx], tgt[idx], 0.2, 0.005, ratio, got3,
+                       label=f"cfg2 shape, {rows} rows, split-bf16 update precision", x3=True)
+        worst = max(max(relerr(a[0], b[0]), relerr(a[1], b[1])) for a, b in zip(got3[0] + got3[1], got32[0] + got32[1]))
+        print(f"[x3] {rows} rows: gradients of the split-bf16 precision vs the fp32 precision's: {worst:.2e} of max|g| per tensor")
+        assert worst < 2e-3   # (a ReLU decision within rounding of 0 may differ between the two: O(1/sqrt(rows)) of a first-layer row)
 
 
 def test_clip_adam_matches_oracle(L):

@@ -110,8 +110,11 @@ def test_learn_matches_reference_fixture(golden, name):
     assert relerr(osd["state"][0]["exp_avg_sq"], g["adam_exp_avg_sq0"]) < 1e-4
 
 
-def test_learn_at_the_paired_launch_size_matches_the_reference_fixture(golden):
-    """[r4] G5big: the reference's PPOLearner.learn at 256x3, n = B = 262,144, MB = 65,536, 2 epochs -- the size from which the update
+@pytest.mark.parametrize("precision", ["fp32", "x3"])
+def test_learn_at_the_paired_launch_size_matches_the_reference_fixture(golden, precision):
+    """(precision "x3": the same fixture and the same gates with rlppo_set_update_precision(2) -- the hidden forward / dX products
+    on the bf16 MFMA pipe from three-piece operands, policy and critic as two chains)
+    [r4] G5big: the reference's PPOLearner.learn at 256x3, n = B = 262,144, MB = 65,536, 2 epochs -- the size from which the update
     runs its PAIRED policy + critic launches with the minibatch gather FUSED into the first layer (csrc/api.hip), which until
     round 4 no reference-held vector ever reached.  The experience is rebuilt from seeds by the generator's own function (its bit
     hashes are in the fixture), the seeded construction must give the reference's initial parameters bit for bit (hash + first 64
@@ -164,6 +167,15 @@ def test_learn_at_the_paired_launch_size_matches_the_reference_fixture(golden):
     n_steps = int(g["n_steps"])
     assert n_steps == 2 and sorted(truth) == [0, 1]
     learner.n_epochs = 1
+    from rlgym_ppo_amd.engine import set_update_precision
+    set_update_precision(precision)
+    try:
+        _g5big_body(L, g, cfg, learner, buf, truth, grad64, n_steps, p0, vec, precision)
+    finally:
+        set_update_precision("fp32")
+
+
+def _g5big_body(L, g, cfg, learner, buf, truth, grad64, n_steps, p0, vec, precision):
     hip_grads = []
     learner.grad_probe = lambda gr: hip_grads.append(gr.detach().cpu().numpy().astype(np.float64))
     passes0, paired0, gfused0 = (int(L.rlppo_dbg_counter(k)) for k in (2, 3, 4))
@@ -183,7 +195,7 @@ def test_learn_at_the_paired_launch_size_matches_the_reference_fixture(golden):
                 assert (e_hip <= np.maximum(tol[:64], 1.5 * e_ref.max())).all(), (s, e_hip.max(), e_ref.max())
                 # a plain sum moves by at most the sum of the per-parameter allowances
                 d_hip, d_ref = abs(got.sum() - tr.sum()), abs(ref_sum - tr.sum())
-                print(f"[fp64 gate] g5big step {s}: head err HIP {e_hip.max() / scale:.2e} reference {e_ref.max() / scale:.2e} of max|p|; "
+                print(f"[fp64 gate] g5big ({precision}) step {s}: head err HIP {e_hip.max() / scale:.2e} reference {e_ref.max() / scale:.2e} of max|p|; "
                       f"|sum - sum64| HIP {d_hip:.3e} reference {d_ref:.3e} (allowance {tol.sum():.3e})")
                 assert d_hip <= max(tol.sum(), 1.5 * d_ref)
             continue
@@ -199,13 +211,13 @@ def test_learn_at_the_paired_launch_size_matches_the_reference_fixture(golden):
                     frac_ill = max(frac_ill, float((d[ill] / bound(weak)[ill]).max()))
             errs[who] = (worst_good, worst_ill, frac_ill)
         n_ill = int((wp < 1e-4).sum() + (wv < 1e-4).sum())
-        print(f"[fp64 gate] g5big_learn_discrete_256x3 after optimiser step {s}: err(HIP, fp64)={errs['hip'][0]:.2e}  err(reference fp32 "
+        print(f"[fp64 gate] g5big_learn_discrete_256x3 ({precision}) after optimiser step {s}: err(HIP, fp64)={errs['hip'][0]:.2e}  err(reference fp32 "
               f"fixture, fp64)={errs['ref'][0]:.2e}  | {n_ill} of {wp.size + wv.size} parameters with an ill-conditioned Adam step: HIP "
               f"{errs['hip'][1]:.1e} = {errs['hip'][2]:.3f} of the derived bound, reference {errs['ref'][1]:.1e} = {errs['ref'][2]:.3f}")
         assert errs["hip"][0] <= max(1e-5, 1.5 * errs["ref"][0]), errs
         assert errs["hip"][1] <= max(1e-5, 1.5 * errs["ref"][1]), errs
     passes, paired, gfused = (int(L.rlppo_dbg_counter(k)) for k in (2, 3, 4))
-    assert passes - passes0 == n_steps and paired - paired0 == n_steps and gfused - gfused0 == n_steps, \
+    assert passes - passes0 == n_steps and paired - paired0 == (n_steps if precision == "fp32" else 0) and gfused - gfused0 == n_steps, \
         "the paired / gather-fused launches did not run: (passes, paired, gather-fused) = %s" % ((passes - passes0, paired - paired0, gfused - gfused0),)
     # the first step's batch gradient: [grad_policy | grad_value] of the product against the reference's, both against float64
     n_pol = p0.size
@@ -214,7 +226,7 @@ def test_learn_at_the_paired_launch_size_matches_the_reference_fixture(golden):
         scale = np.abs(t64).max()
         e_hip_all, e_hip8, e_ref8 = np.abs(mine - t64).max() / scale, np.abs(mine[::8] - t64[::8]).max() / scale, np.abs(ref8 - t64[::8]).max() / scale
         l2_hip, l2_ref, l2_64 = np.sqrt((mine ** 2).sum()), float(g[f"grad0.{tag}_l2"]), np.sqrt((t64 ** 2).sum())
-        print(f"[fp64 gate] g5big first-step {tag} gradient: err(HIP, fp64) = {e_hip_all:.2e} of max|g| over all entries, {e_hip8:.2e} over every "
+        print(f"[fp64 gate] g5big ({precision}) first-step {tag} gradient: err(HIP, fp64) = {e_hip_all:.2e} of max|g| over all entries, {e_hip8:.2e} over every "
               f"8th; err(reference, fp64) = {e_ref8:.2e} over every 8th; |g|2 HIP {l2_hip:.8e} reference {l2_ref:.8e} float64 {l2_64:.8e}")
         assert e_hip_all <= max(1e-5, 1.5 * e_ref8), (tag, e_hip_all, e_ref8)
         assert abs(l2_hip - l2_64) <= max(1e-5 * l2_64, 1.5 * abs(l2_ref - l2_64))
