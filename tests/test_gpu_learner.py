@@ -233,7 +233,9 @@ def _g5big_body(L, g, cfg, learner, buf, truth, grad64, n_steps, p0, vec, precis
         assert abs(float(g[f"grad0.{tag}_max"]) - scale) <= 1e-4 * scale
     for key in ("Policy Entropy", "Mean KL Divergence", "Value Function Loss", "SB3 Clip Fraction"):
         got, ref = float(np.mean([r[key] for r in reports])), float(g["report." + key])
-        assert abs(got - ref) <= 2e-5 * max(abs(ref), 1e-4) + 1e-7, (key, got, ref)
+        # (the clip fraction is a count: a row whose ratio sits within float32 rounding of a clip edge may fall either way -- 4 rows)
+        tol = 4.0 / cfg["B"] if key == "SB3 Clip Fraction" else 2e-5 * max(abs(ref), 1e-4) + 1e-7
+        assert abs(got - ref) <= tol, (key, got, ref)
 
 
 def test_learn_single_call_report_and_magnitudes(golden):
