@@ -410,7 +410,8 @@ int rlppo_dbg_gemm_nt_x3(void *stream, const float *A, int64_t lda, const void *
  *  33 paired launches: the two products' tiles interleave in the grid (a row tile's workgroups of both networks back to back on one
  *     XCD) [1 (default) | 0 = the second product stacked behind the first]
  *  34 rlppo_clip_adam_pack2 grid-barrier spin limit [-1 = default 2^22 | 0 = a waiter gives up at once (tests)]
- *  35 rlppo_clip_adam_pack2 test hook [0 | 1 = workgroup (0, 0) never arrives at the barrier: a grid that is not co-resident] */
+ *  35 rlppo_clip_adam_pack2 test hook [0 | 1 = workgroup (0, 0) never arrives at the barrier: a grid that is not co-resident]
+ *  36 split-bf16 products (update precision 2) [1 = persistent workgroups for large launches (default) | 0 = one workgroup per tile] */
 int rlppo_dbg_set(int32_t key, int32_t value);
 /* Counter bumped by every call that changes which kernels later launches select (rlppo_dbg_set, rlppo_set_*_precision): a
  * host that caches captured graphs of library calls keys them on it (rlgym_ppo_amd/ppo/_mlp.py::ActGraph). */

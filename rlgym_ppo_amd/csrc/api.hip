@@ -1323,6 +1323,7 @@ int rlppo_dbg_set(int32_t key, int32_t value) {
         case 22: set_gae_oversubscribe(value); return 0;
         case 34: set_fused_spin_limit(value); return 0;
         case 35: set_fused_test_hold(value); return 0;
+        case 36: set_split_persistent(value); return 0;
         case 23: set_b16_wide_tiles(value); return 0;
         case 24: set_exp_fast_transform(value); return 0;
         case 26: g_fused_gather = value; return 0;

@@ -146,6 +146,7 @@ bool tn_gather_ok(int64_t ldx, int64_t src_rows);
 // hidden: relu, rounded output as bf16 (Cb) + fp32 (C) + ReLU bitmask; output layer (!hidden): fp32 C, epi bias / bias+tanh
 bool nt_b16_ok(int N, int K, bool hidden);
 bool nt_split_ok(int N, int K);  // gemm_split.hip [r4]
+void set_split_persistent(int v);
 int launch_pack_split(hipStream_t st, const float *S, int64_t ld, int R, int Cc, unsigned short *planes);
 int launch_gemm_nt_split(hipStream_t st, const float *A, int64_t lda, const unsigned short *planes, const float *bias, float *C, int64_t ldc,
                          int64_t M, int N, int K, int mode, unsigned long long *bits);

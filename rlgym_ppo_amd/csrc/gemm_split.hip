@@ -214,6 +214,192 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_split_kernel(const float *__re
     }
 }
 
+// ---- persistent form: ONE workgroup per CU walks the row tiles of its column tile (as gemm_nt_b16p_kernel, csrc/gemm_b16.hip).  The
+// first stage of tile t + 1 is requested BEFORE the epilogue of tile t (into buffer 0; the tile leaves through buffer 1), so the
+// DMA latency, the epilogue's vector work and its 32 tile stores overlap, and the next K loop starts on data already in LDS -- with
+// a counted wait (the stage's 10 pieces are older than the epilogue's 2 bitmask accesses and 32 stores, which stay in flight).
+// Every step issues the same number of pieces: a stage that does not exist is requested outside its descriptor (dropped, still
+// counted), because the compiler's own waits for the register loads in between take the minimum over paths.  The forward adds its
+// bias in the EPILOGUE (fetched behind the K loop, ahead of the next head: 8 loads the compiler waits for while the head stays in
+// flight): 32 persistent bias registers would not fit beside 128 accumulators and 96 fragment registers.
+template <int MODE>
+__global__ __launch_bounds__(512, 1) void gemm_nt_split_p_kernel(const float *__restrict__ A, unsigned lda_b, const unsigned short *__restrict__ planes,
+                                                                 int n_total, const float *__restrict__ bias, float *__restrict__ C, unsigned ldc_b,
+                                                                 int64_t M, int K, unsigned long long *__restrict__ bits, int row_tiles, int col_tiles,
+                                                                 int row_tiles128) {
+    constexpr bool DX = MODE == SPLIT_DX;
+    constexpr unsigned DROPPED = 0x80000000u;
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const int r16 = lane & 15, q = lane >> 4;
+    const int wr = wave_u >> 1, wc = wave_u & 1;
+    const int b = blockIdx.x, group = 8 * col_tiles;
+    const int col_tile = (b % group) >> 3;
+    const int row_first = (b / group) * 8 + (b & 7), row_stride = (gridDim.x / group) * 8;
+    const int n0 = col_tile * TN;
+    const int nk = K / BK;
+    if (row_first >= row_tiles) return;
+    const unsigned plane_stride = (unsigned)n_total * 64u;
+    const __amdgpu_buffer_rsrc_t w_rs = make_rsrc(reinterpret_cast<const char *>(planes) + (int64_t)n0 * 64, (unsigned)nk * 3u * plane_stride);
+    const __amdgpu_buffer_rsrc_t bits_rs = make_rsrc(bits, (unsigned)((size_t)row_tiles128 * (col_tiles * 2) * 256 * 8));
+    const int row_p = wave * 8 + lane / 8, pch = lane % 8, lch = pch ^ (row_p & 7);
+    const unsigned a_off = (unsigned)row_p * lda_b + lch * 16;
+    auto a_rsrc = [&](int row_tile) {
+        const int64_t m0 = (int64_t)row_tile * TM;
+        const int rows_here = (int)((M - m0) < TM ? (M - m0) : TM);
+        return make_rsrc(reinterpret_cast<const char *>(A) + m0 * lda_b, (unsigned)(rows_here - 1) * lda_b + (unsigned)K * 4);
+    };
+    auto issue = [&](const __amdgpu_buffer_rsrc_t &a_rs, int buf, int kt, bool real) {
+        char *Ad = lds + buf * STAGE + wave_u * (8 * 128);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rs, reinterpret_cast<float *>(Ad + i * (64 * 128)), 16, a_off,
+                                                     real ? (unsigned)kt * 128u + i * 64u * lda_b : DROPPED, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const int g = wave_u * 6 + i;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rs, reinterpret_cast<float *>(lds + buf * STAGE + A_STAGE + g * 1024), 16, (unsigned)lane * 16u,
+                                                     real ? ((unsigned)kt * 3u + (unsigned)(g >> 4)) * plane_stride + (unsigned)(g & 15) * 1024u : DROPPED, 0, 0);
+        }
+    };
+    auto bits_off = [&](int row_tile, int h) -> unsigned {  // byte offset of this wave's bitmask word of slot h; outside the descriptor past the end
+        const int rt128 = row_tile * 2 + (wr >> 1), ct128 = col_tile * 2 + wc, nct128 = col_tiles * 2;
+        return rt128 < row_tiles128 ? (unsigned)((((size_t)rt128 * nct128 + ct128) * 256 + ((2 * wr + h) & 3) * 64 + lane) * 8) : 0xFFFFFFF0u;
+    };
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    __amdgpu_buffer_rsrc_t a_rs = a_rsrc(row_first);
+    issue(a_rs, 0, 0, true);
+    bool first = true;
+    u32x2 mask_next[2];
+    if (DX) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) mask_next[h] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(bits_rs, bits_off(row_first, h), 0, 0));
+    }
+    for (int row_tile = row_first; row_tile < row_tiles; row_tile += row_stride) {
+        const int64_t m0 = (int64_t)row_tile * TM;
+        const int rows_here = (int)((M - m0) < TM ? (M - m0) : TM);
+        f32x4 acc[4][8];
+        u32x2 mask_word[2];
+        if (DX) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) mask_word[h] = mask_next[h];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int kt = 0; kt < nk; ++kt) {
+            const int cur = kt & 1;
+            // stage kt is in LDS: stage 0 was requested before the previous epilogue (its 2 bitmask accesses + 32 stores -- or, for the
+            // first tile of the DX form, the 2 mask loads -- are younger and stay in flight), every later stage one step ago
+            if (kt == 0 && !first) asm volatile("s_waitcnt vmcnt(34)" ::: "memory");
+            else if (kt == 0 && DX) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();  // raw (no fence): each wave waited for its own pieces; everybody is done with the other buffer
+            issue(a_rs, cur ^ 1, kt + 1, kt + 1 < nk);
+            const char *Ac = lds + cur * STAGE;
+            const char *Wc = Ac + A_STAGE;
+            bf16x8 ah[4], am[4], al[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = wr * 64 + i * 16 + r16;
+                const f32x4 lo = *reinterpret_cast<const f32x4 *>(Ac + row * 128 + (((2 * q) ^ (row & 7)) * 16));
+                const f32x4 hi = *reinterpret_cast<const f32x4 *>(Ac + row * 128 + (((2 * q + 1) ^ (row & 7)) * 16));
+                split8(lo, hi, ah[i], am[i], al[i]);
+            }
+#pragma unroll
+            for (int jq = 0; jq < 4; ++jq) {  // two column blocks at a time: 24 weight-fragment registers (four at a time spill)
+                bf16x8 wh[2], wm[2], wl[2];
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) {
+                    const int col = wc * 128 + (jq * 2 + jj) * 16 + r16;
+                    wh[jj] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4 *>(Wc + col * 64 + q * 16));
+                    wm[jj] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4 *>(Wc + W_PLANE + col * 64 + q * 16));
+                    wl[jj] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4 *>(Wc + 2 * W_PLANE + col * 64 + q * 16));
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int jj = 0; jj < 2; ++jj) {
+                        f32x4 t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[jj], al[i], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                        t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[jj], ah[i], t, 0, 0, 0);
+                        t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm[jj], am[i], t, 0, 0, 0);
+                        t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[jj], am[i], t, 0, 0, 0);
+                        t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm[jj], ah[i], t, 0, 0, 0);
+                        f32x4 c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[jj], ah[i], acc[i][jq * 2 + jj], 0, 0, 0);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) c[e] += t[e];
+                        acc[i][jq * 2 + jj] = c;
+                    }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        first = false;
+        __syncthreads();  // every wave is done with the last stage (only dropped pieces are outstanding): both buffers are free
+        // ---- forward: the bias, ahead of the next head in this wave's queue (the compiler's wait for it leaves the head in flight)
+        f32x4 bias4[8];
+        if (!DX) {
+            asm volatile("" ::: "memory");  // (not hoisted into the K loop: 32 more live registers there spill)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) bias4[j] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(&bias[n0 + wc * 128 + j * 16 + q * 4]));
+            asm volatile("" ::: "memory");
+        }
+        // ---- the next tile's first stage goes into buffer 0 now; this tile leaves through buffer 1
+        const int next_tile = row_tile + row_stride;
+        const bool more = next_tile < row_tiles;
+        if (more) a_rs = a_rsrc(next_tile);
+        issue(a_rs, 0, 0, more);
+        if (DX) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+                mask_next[h] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(bits_rs, more ? bits_off(next_tile, h) : 0xFFFFFFF0u, 0, 0));
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            unsigned lo = DX ? mask_word[h][0] : 0u, hi = DX ? mask_word[h][1] : 0u;
+#pragma unroll
+            for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int bb = (ii * 8 + j) * 4 + e;
+                        if (DX) {
+                            const unsigned m = 0u - (((bb < 32 ? lo : hi) >> (bb & 31)) & 1u);
+                            acc[2 * h + ii][j][e] = __uint_as_float(__float_as_uint(acc[2 * h + ii][j][e]) & m);
+                        } else {
+                            const float x = relu1(acc[2 * h + ii][j][e] + bias4[j][e]);
+                            acc[2 * h + ii][j][e] = x;
+                            const unsigned v = x > 0.f ? 1u : 0u;
+                            if (bb < 32) lo |= v << bb;
+                            else hi |= v << (bb - 32);
+                        }
+                    }
+            if (!DX) __builtin_amdgcn_raw_buffer_store_b64(u32x2{lo, hi}, bits_rs, bits_off(row_tile, h), 0, 0);  // (dropped past the end, still counted)
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        char *mine = lds + STAGE + wave_u * (16 * 512);  // 8 KiB of buffer 1
+        const __amdgpu_buffer_rsrc_t c_rs = make_rsrc(reinterpret_cast<char *>(C) + m0 * ldc_b + (int64_t)(n0 + wc * 128) * 4, (unsigned)(rows_here - 1) * ldc_b + 128 * 4);
+        const int rr = lane >> 5, c32 = lane & 31;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (i) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int j = 0; j < 8; ++j) *reinterpret_cast<f32x4 *>(mine + r16 * 512 + (((j * 4 + q) ^ r16) * 16)) = acc[i][j];
+            f32x4 v[8];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const int r = 2 * t + rr;
+                v[t] = *reinterpret_cast<const f32x4 *>(mine + r * 512 + ((c32 ^ r) * 16));
+            }
+            const unsigned c_off = (unsigned)(wr * 64 + i * 16 + rr) * ldc_b + c32 * 16;
+#pragma unroll
+            for (int t = 0; t < 8; ++t) stb(c_rs, c_off, 2 * t * ldc_b, v[t]);
+        }
+    }
+}
+
 // planes[(ks * 3 + p) * R + r][t] = piece p of S[r][ks * 32 + t]   (S: R x Cc fp32, row stride ld; Cc % 32 == 0)
 __global__ __launch_bounds__(256) void pack_split_kernel(const float *__restrict__ S, int64_t ld, int R, int Cc, unsigned short *__restrict__ planes) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -233,6 +419,8 @@ __global__ __launch_bounds__(256) void pack_split_kernel(const float *__restrict
 }
 }  // namespace
 
+static int g_split_persistent = 1;  // rlppo_dbg_set(36, 0/1): the split-bf16 products walked by persistent workgroups (large launches)
+void set_split_persistent(int v) { g_split_persistent = v; }
 bool nt_split_ok(int N, int K) { return N > 0 && N % 256 == 0 && K >= 32 && K % 32 == 0; }
 
 int launch_pack_split(hipStream_t st, const float *S, int64_t ld, int R, int Cc, unsigned short *planes) {
@@ -252,10 +440,31 @@ int launch_gemm_nt_split(hipStream_t st, const float *A, int64_t lda, const unsi
                     "gemm_nt_split: N=%d K=%d mode=%d lda=%ld ldc=%ld", N, K, mode, (long)lda, (long)ldc);
     const int64_t lim = (int64_t)1 << 31;
     RLPPO_CHECK_ARG(257 * lda * 4 < lim && 257 * ldc * 4 < lim && (int64_t)(K / 32) * 3 * N * 64 < lim, "gemm_nt_split: operand too wide for 32-bit offsets");
-    static PerDeviceOnce attr[2];
+    static PerDeviceOnce attr[4];
     constexpr int LDS_BYTES = 2 * STAGE;
-    const dim3 grid((unsigned)cdiv(M, 256), (unsigned)(N / 256));
     const int rt128 = (int)cdiv(M, 128);
+    const int row_tiles = (int)cdiv(M, 256), col_tiles = N / 256;
+    int cus = 0;
+    if (int rc_ = device_cu_count(&cus)) return rc_;
+    if (g_split_persistent && row_tiles >= 2 * (cus / (8 * col_tiles) > 0 ? cus / (8 * col_tiles) : 1) * 8 && col_tiles <= 8) {
+        // persistent workgroups: whole groups of 8 row tiles x all column tiles, never more workgroups than CUs (or than the work)
+        const int group = 8 * col_tiles;
+        int grid = cus / group * group;
+        const int need = (int)cdiv(row_tiles, 8) * group;
+        grid = grid < group ? group : (grid > need ? need : grid);
+        if (mode == SPLIT_FWD) {
+            if (int rc_ = set_dynamic_lds_once((const void *)gemm_nt_split_p_kernel<SPLIT_FWD>, LDS_BYTES, attr[2])) return rc_;
+            hipLaunchKernelGGL((gemm_nt_split_p_kernel<SPLIT_FWD>), dim3((unsigned)grid), dim3(512), LDS_BYTES, st, A, (unsigned)(lda * 4), planes, N, bias,
+                               C, (unsigned)(ldc * 4), M, K, bits, row_tiles, col_tiles, rt128);
+        } else {
+            if (int rc_ = set_dynamic_lds_once((const void *)gemm_nt_split_p_kernel<SPLIT_DX>, LDS_BYTES, attr[3])) return rc_;
+            hipLaunchKernelGGL((gemm_nt_split_p_kernel<SPLIT_DX>), dim3((unsigned)grid), dim3(512), LDS_BYTES, st, A, (unsigned)(lda * 4), planes, N, bias,
+                               C, (unsigned)(ldc * 4), M, K, bits, row_tiles, col_tiles, rt128);
+        }
+        RLPPO_LAUNCH_CHECK();
+        return 0;
+    }
+    const dim3 grid((unsigned)row_tiles, (unsigned)col_tiles);
     if (mode == SPLIT_FWD) {
         if (int rc_ = set_dynamic_lds_once((const void *)gemm_nt_split_kernel<SPLIT_FWD>, LDS_BYTES, attr[0])) return rc_;
         hipLaunchKernelGGL((gemm_nt_split_kernel<SPLIT_FWD>), grid, dim3(512), LDS_BYTES, st, A, (unsigned)(lda * 4), planes, N, bias, C,

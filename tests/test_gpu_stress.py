@@ -108,7 +108,48 @@ def test_bf16_products_repeatable_under_gpu_sharing():
         bg.wait()
 
 
-@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_split_bf16_products_repeatable_under_gpu_sharing():
+    """[r4] The same regression for the kernels of the split-bf16 update precision (csrc/gemm_split.hip: 16-byte buffer stores of a
+    tile parked in LDS, the 8-byte bitmask stores): no atomics, so every run of the same product is bitwise the same while another
+    process backs up the memory pipeline -- forward (values and bitmask) and masked dX, a full and a ragged row count."""
+    from rlgym_ppo_amd import _native as N
+    L = N.lib()
+    st = lambda: ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    P = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
+    torch.manual_seed(2)
+    bg = subprocess.Popen([sys.executable, "-c", LOAD, "20"])
+    try:
+        time.sleep(4.0)
+        for (M, n, k) in [(4096, 256, 256), (4096 + 77, 512, 96)]:
+            A = torch.randn(M, k, device="cuda")
+            W = torch.randn(n, k, device="cuda") * 0.1
+            bias = torch.randn(n, device="cuda") * 0.1
+            planes = torch.zeros(3 * n * k, dtype=torch.bfloat16, device="cuda")
+            N.check(L.rlppo_dbg_pack_x3(st(), P(W), k, n, k, P(planes)))
+            H = torch.empty(M, n, device="cuda")
+            bits = torch.zeros(int(L.rlppo_dbg_gemm_nt_bits_bytes(M, n)), dtype=torch.uint8, device="cuda")
+            fwd = lambda: N.check(L.rlppo_dbg_gemm_nt_x3(st(), P(A), k, P(planes), P(bias), P(H), n, M, n, k, 0, P(bits)))
+            mbits = torch.zeros_like(bits).random_(0, 256)
+            dX = torch.empty(M, n, device="cuda")
+            bwd = lambda: N.check(L.rlppo_dbg_gemm_nt_x3(st(), P(A), k, P(planes), None, P(dX), n, M, n, k, 1, P(mbits)))
+            for run, outs in ((fwd, (H, bits)), (bwd, (dX,))):
+                for o in outs:
+                    o.zero_()
+                run()
+                refs = [o.clone() for o in outs]
+                differ = torch.zeros((), dtype=torch.int64, device="cuda")
+                for _ in range(400):
+                    for o in outs:
+                        o.zero_()
+                    run()
+                    for o, r in zip(outs, refs):
+                        differ += (o != r).any()
+                assert int(differ.item()) == 0, (M, n, k, int(differ.item()))
+    finally:
+        bg.wait()
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16", "x3"])
 def test_update_is_bit_reproducible(precision):
     """Weight and bias gradients go through partial tiles / block partials summed in a fixed order (no fp32 atomics whose
     arrival order would leak into the sums), so two runs of the same update from the same state end in bit-identical
