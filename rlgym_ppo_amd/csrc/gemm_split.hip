@@ -52,6 +52,11 @@ constexpr int A_STAGE = TM * BK * 4;         // 32 KiB
 constexpr int W_PLANE = TN * BK * 2;         // 16 KiB
 constexpr int STAGE = A_STAGE + 3 * W_PLANE; // 80 KiB
 enum { SPLIT_FWD = 0, SPLIT_DX = 1 };
+// The image of a weight plane's 16-column block (1 KiB: 16 columns x 32 k) in memory and in LDS: the 16-byte chunk (column r16, k quarter
+// q) at chunk wpos(r16, q).  A fragment read is one ds_read_b128 with lane = q * 16 + r16, served in four groups of 16 lanes
+// ({0-3, 12-15, 20-27}, ...: MI355X_MICROARCH.md, LDS); with plain rows (chunk r16 * 4 + q) columns r16 and r16 + 4 k of a group meet
+// on a bank -- 2-way conflicts, 8 cycles per read; rotating q by -(r16 / 4) gives every group 16 distinct chunk residues mod 16.
+__host__ __device__ constexpr int wpos(int r16, int q) { return r16 * 4 + (q ^ ((0 - (r16 >> 2)) & 3)); }
 
 // planes: the N_total x K weight matrix as [K / 32][3][N_total][32] bf16; this workgroup's column tile is rows n0 .. n0 + 255 of every
 // [N_total][32] block.  grid = (row tiles, column tiles).
@@ -138,9 +143,10 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_split_kernel(const float *__re
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj) {
                 const int col = wc * 128 + (jh * 4 + jj) * 16 + r16;
-                wh[jj] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4 *>(Wc + col * 64 + q * 16));
-                wm[jj] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4 *>(Wc + W_PLANE + col * 64 + q * 16));
-                wl[jj] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4 *>(Wc + 2 * W_PLANE + col * 64 + q * 16));
+                const int at = (col & ~15) * 64 + wpos(r16, q) * 16;
+                wh[jj] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4 *>(Wc + at));
+                wm[jj] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4 *>(Wc + W_PLANE + at));
+                wl[jj] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4 *>(Wc + 2 * W_PLANE + at));
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i)
@@ -214,14 +220,34 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_split_kernel(const float *__re
     }
 }
 
-// ---- persistent form: ONE workgroup per CU walks the row tiles of its column tile (as gemm_nt_b16p_kernel, csrc/gemm_b16.hip).  The
-// first stage of tile t + 1 is requested BEFORE the epilogue of tile t (into buffer 0; the tile leaves through buffer 1), so the
-// DMA latency, the epilogue's vector work and its 32 tile stores overlap, and the next K loop starts on data already in LDS -- with
-// a counted wait (the stage's 10 pieces are older than the epilogue's 2 bitmask accesses and 32 stores, which stay in flight).
-// Every step issues the same number of pieces: a stage that does not exist is requested outside its descriptor (dropped, still
-// counted), because the compiler's own waits for the register loads in between take the minimum over paths.  The forward adds its
-// bias in the EPILOGUE (fetched behind the K loop, ahead of the next head: 8 loads the compiler waits for while the head stays in
-// flight): 32 persistent bias registers would not fit beside 128 accumulators and 96 fragment registers.
+// ---- persistent form: ONE workgroup per CU walks the row tiles of its column tile (as gemm_nt_b16p_kernel, csrc/gemm_b16.hip), and
+// a K step's split runs in the SHADOW of the previous step's MFMAs.
+//
+// Where the one-tile kernel's K step goes (profiles/r04_split_turn_taking_experiment.txt): 6 x 1060 cycles of MFMAs at the pipe's
+// full rate and, before them, 2700 cycles in which no MFMA issues -- 8 fragment reads, the split of four A fragments (176 vector
+// instructions per wave, every fragment split by the two waves that share its rows), the stage requests, the barrier.  Here a wave
+// owns 32 rows x ALL 256 columns: no row is split twice (88 instructions per wave and step), its two A fragments fit a SECOND
+// 24-register set, and the fragments of step s + 1 are read and split between the MFMAs of step s -- by the same wave, so both
+// waves of a SIMD multiply at all times.  The price is LDS reads: every wave streams all three weight planes of the stage
+// (48 ds_read_b128 per step, double-buffered one 16-column block ahead; 416 KiB per step and CU = a quarter of the step's LDS
+// cycles now that the plane image is conflict-free, see wpos()).  The stage's two parts travel on their own schedules: step s
+// requests W(s + 1) and A(s + 2), because A(s + 1) is consumed DURING step s; two A buffers suffice (A(s)'s was freed by step s - 1).
+// The head of tile t + 1 -- W(0), A(0), A(1) -- is requested BEFORE the epilogue of tile t, which leaves through the other W buffer
+// (4 KiB per wave, 16 rows x 64 columns at a time: 4 rows x 256 contiguous bytes per wave-instruction), with a counted wait (the head's
+// 14 pieces are older than the epilogue's 2 bitmask accesses and 32 stores, which stay in flight).  Every step issues the same
+// number of pieces: a stage that does not exist is requested outside its descriptor (dropped, still counted), because the compiler's
+// own waits for register loads take the minimum over paths.  The forward adds its bias in the epilogue.  K / 32 must be even.
+struct SplitFrags {
+    bf16x8 h[2], m[2], l[2];
+};
+__device__ __forceinline__ void split2(float x0, float x1, unsigned &hp, unsigned &mp, unsigned &lp) {
+    hp = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{x0, x1}, bf16x2));
+    const float r0 = x0 - __uint_as_float(hp << 16), r1 = x1 - __uint_as_float(hp & 0xFFFF0000u);  // exact
+    mp = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{r0, r1}, bf16x2));
+    const float s0 = r0 - __uint_as_float(mp << 16), s1 = r1 - __uint_as_float(mp & 0xFFFF0000u);  // exact
+    lp = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{s0, s1}, bf16x2));
+}
+
 template <int MODE>
 __global__ __launch_bounds__(512, 1) void gemm_nt_split_p_kernel(const float *__restrict__ A, unsigned lda_b, const unsigned short *__restrict__ planes,
                                                                  int n_total, const float *__restrict__ bias, float *__restrict__ C, unsigned ldc_b,
@@ -229,11 +255,10 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_split_p_kernel(const float *__
                                                                  int row_tiles128) {
     constexpr bool DX = MODE == SPLIT_DX;
     constexpr unsigned DROPPED = 0x80000000u;
-    extern __shared__ __attribute__((aligned(16))) char lds[];
+    extern __shared__ __attribute__((aligned(16))) char lds[];  // [2][A 256 x 128 B swizzled | 3 x W plane]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);  // rows wave_u * 32 .. + 31 of the tile
     const int r16 = lane & 15, q = lane >> 4;
-    const int wr = wave_u >> 1, wc = wave_u & 1;
     const int b = blockIdx.x, group = 8 * col_tiles;
     const int col_tile = (b % group) >> 3;
     const int row_first = (b / group) * 8 + (b & 7), row_stride = (gridDim.x / group) * 8;
@@ -250,12 +275,14 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_split_p_kernel(const float *__
         const int rows_here = (int)((M - m0) < TM ? (M - m0) : TM);
         return make_rsrc(reinterpret_cast<const char *>(A) + m0 * lda_b, (unsigned)(rows_here - 1) * lda_b + (unsigned)K * 4);
     };
-    auto issue = [&](const __amdgpu_buffer_rsrc_t &a_rs, int buf, int kt, bool real) {
+    auto issue_a = [&](const __amdgpu_buffer_rsrc_t &a_rs, int buf, int kt, bool real) {  // 4 pieces per wave: 8 rows x 128 B each
         char *Ad = lds + buf * STAGE + wave_u * (8 * 128);
 #pragma unroll
         for (int i = 0; i < 4; ++i)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rs, reinterpret_cast<float *>(Ad + i * (64 * 128)), 16, a_off,
                                                      real ? (unsigned)kt * 128u + i * 64u * lda_b : DROPPED, 0, 0);
+    };
+    auto issue_w = [&](int buf, int kt, bool real) {  // 6 pieces per wave: KiB g % 16 of plane g / 16
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
             const int g = wave_u * 6 + i;
@@ -263,100 +290,146 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_split_p_kernel(const float *__
                                                      real ? ((unsigned)kt * 3u + (unsigned)(g >> 4)) * plane_stride + (unsigned)(g & 15) * 1024u : DROPPED, 0, 0);
         }
     };
-    auto bits_off = [&](int row_tile, int h) -> unsigned {  // byte offset of this wave's bitmask word of slot h; outside the descriptor past the end
-        const int rt128 = row_tile * 2 + (wr >> 1), ct128 = col_tile * 2 + wc, nct128 = col_tiles * 2;
-        return rt128 < row_tiles128 ? (unsigned)((((size_t)rt128 * nct128 + ct128) * 256 + ((2 * wr + h) & 3) * 64 + lane) * 8) : 0xFFFFFFF0u;
+    // the bitmask word of this wave's 32 rows in column half hc (128 x 128-tile layout of relu_bits); outside the descriptor past the end
+    auto bits_off = [&](int row_tile, int hc) -> unsigned {
+        const int rt128 = row_tile * 2 + (wave_u >> 2), ct128 = col_tile * 2 + hc, nct128 = col_tiles * 2;
+        return rt128 < row_tiles128 ? (unsigned)((((size_t)rt128 * nct128 + ct128) * 256 + (wave_u & 3) * 64 + lane) * 8) : 0xFFFFFFF0u;
     };
     typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
     __amdgpu_buffer_rsrc_t a_rs = a_rsrc(row_first);
-    issue(a_rs, 0, 0, true);
+    issue_w(0, 0, true);
+    issue_a(a_rs, 0, 0, true);
+    issue_a(a_rs, 1, 1, true);
     bool first = true;
     u32x2 mask_next[2];
     if (DX) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) mask_next[h] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(bits_rs, bits_off(row_first, h), 0, 0));
     }
+    const int a_row0 = wave_u * 32 + r16;                     // fragment i: row a_row0 + 16 i (same swizzle key: 16 i does not touch row & 7)
+    const int a_lo = a_row0 * 128 + (((2 * q) ^ (a_row0 & 7)) * 16), a_hi = a_row0 * 128 + (((2 * q + 1) ^ (a_row0 & 7)) * 16);
+    const int w_frag = wpos(r16, q) * 16;                     // + plane * W_PLANE + block * 1024
     for (int row_tile = row_first; row_tile < row_tiles; row_tile += row_stride) {
         const int64_t m0 = (int64_t)row_tile * TM;
         const int rows_here = (int)((M - m0) < TM ? (M - m0) : TM);
-        f32x4 acc[4][8];
+        f32x4 acc[2][16];
         u32x2 mask_word[2];
         if (DX) {
 #pragma unroll
             for (int h = 0; h < 2; ++h) mask_word[h] = mask_next[h];
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        for (int kt = 0; kt < nk; ++kt) {
-            const int cur = kt & 1;
-            // stage kt is in LDS: stage 0 was requested before the previous epilogue (its 2 bitmask accesses + 32 stores -- or, for the
-            // first tile of the DX form, the 2 mask loads -- are younger and stay in flight), every later stage one step ago
-            if (kt == 0 && !first) asm volatile("s_waitcnt vmcnt(34)" ::: "memory");
-            else if (kt == 0 && DX) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();  // raw (no fence): each wave waited for its own pieces; everybody is done with the other buffer
-            issue(a_rs, cur ^ 1, kt + 1, kt + 1 < nk);
-            const char *Ac = lds + cur * STAGE;
-            const char *Wc = Ac + A_STAGE;
-            bf16x8 ah[4], am[4], al[4];
+            for (int j = 0; j < 16; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // the head is in LDS (its younger neighbours stay in flight: the previous epilogue's 2 bitmask accesses + 32 stores, or the
+        // first tile's 2 mask loads of the DX form)
+        if (!first) asm volatile("s_waitcnt vmcnt(34)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DX ? 2 : 0) : "memory");
+        __builtin_amdgcn_s_barrier();  // raw (no fence) throughout: a wave waits for ITS pieces before the barrier behind which they are read
+        SplitFrags sp0, sp1;
+        {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int row = wr * 64 + i * 16 + r16;
-                const f32x4 lo = *reinterpret_cast<const f32x4 *>(Ac + row * 128 + (((2 * q) ^ (row & 7)) * 16));
-                const f32x4 hi = *reinterpret_cast<const f32x4 *>(Ac + row * 128 + (((2 * q + 1) ^ (row & 7)) * 16));
-                split8(lo, hi, ah[i], am[i], al[i]);
+            for (int i = 0; i < 2; ++i) {
+                const f32x4 lo = *reinterpret_cast<const f32x4 *>(lds + a_lo + i * (16 * 128)), hi = *reinterpret_cast<const f32x4 *>(lds + a_hi + i * (16 * 128));
+                split8(lo, hi, sp0.h[i], sp0.m[i], sp0.l[i]);
             }
+        }
+        auto step = [&](const SplitFrags &cur, SplitFrags &nxt, int s) {
+            if (s) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // W(s), A(s + 1): requested a step ago
+            __builtin_amdgcn_s_barrier();                            // everybody is done with W(s - 1) and with A(s)
+            issue_a(a_rs, s & 1, s + 2, s + 2 < nk);
+            issue_w((s + 1) & 1, s + 1, s + 1 < nk);
+            const char *Wc = lds + (s & 1) * STAGE + A_STAGE + w_frag;
+            const char *An = lds + ((s + 1) & 1) * STAGE;  // (the last step splits a stale stage into fragments nobody uses: no branch)
+            f32x4 raw[2][2];
 #pragma unroll
-            for (int jq = 0; jq < 4; ++jq) {  // two column blocks at a time: 24 weight-fragment registers (four at a time spill)
-                bf16x8 wh[2], wm[2], wl[2];
+            for (int i = 0; i < 2; ++i) {
+                raw[i][0] = *reinterpret_cast<const f32x4 *>(An + a_lo + i * (16 * 128));
+                raw[i][1] = *reinterpret_cast<const f32x4 *>(An + a_hi + i * (16 * 128));
+            }
+            bf16x8 w[2][3];
 #pragma unroll
-                for (int jj = 0; jj < 2; ++jj) {
-                    const int col = wc * 128 + (jq * 2 + jj) * 16 + r16;
-                    wh[jj] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4 *>(Wc + col * 64 + q * 16));
-                    wm[jj] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4 *>(Wc + W_PLANE + col * 64 + q * 16));
-                    wl[jj] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4 *>(Wc + 2 * W_PLANE + col * 64 + q * 16));
+            for (int p = 0; p < 3; ++p) w[0][p] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4 *>(Wc + p * W_PLANE));
+            u32x4 nh[2], nm[2], nl[2];
+            f32x4 tp0, tp1;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                if (j + 1 < 16) {
+#pragma unroll
+                    for (int p = 0; p < 3; ++p)
+                        w[(j + 1) & 1][p] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4 *>(Wc + p * W_PLANE + (j + 1) * 1024));
                 }
+                const bf16x8 wh = w[j & 1][0], wm = w[j & 1][1], wl = w[j & 1][2];
+                const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                // the five small products of a K block summed among themselves, the two fragments' chains interleaved
+                f32x4 t0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, cur.l[0], z, 0, 0, 0);
+                f32x4 t1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, cur.l[1], z, 0, 0, 0);
+                f32x4 c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, cur.h[0], acc[0][j], 0, 0, 0);
+                f32x4 c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, cur.h[1], acc[1][j], 0, 0, 0);
+                t0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, cur.h[0], t0, 0, 0, 0);
+                t1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, cur.h[1], t1, 0, 0, 0);
+                t0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, cur.m[0], t0, 0, 0, 0);
+                t1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, cur.m[1], t1, 0, 0, 0);
+                t0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, cur.m[0], t0, 0, 0, 0);
+                t1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, cur.m[1], t1, 0, 0, 0);
+                t0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, cur.h[0], t0, 0, 0, 0);
+                t1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, cur.h[1], t1, 0, 0, 0);
+                acc[0][j] = c0;
+                acc[1][j] = c1;
+                if (j > 0) {  // the previous block's small sum enters its accumulator now: its chain has long finished
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int jj = 0; jj < 2; ++jj) {
-                        f32x4 t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[jj], al[i], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-                        t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[jj], ah[i], t, 0, 0, 0);
-                        t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm[jj], am[i], t, 0, 0, 0);
-                        t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[jj], am[i], t, 0, 0, 0);
-                        t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm[jj], ah[i], t, 0, 0, 0);
-                        f32x4 c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[jj], ah[i], acc[i][jq * 2 + jj], 0, 0, 0);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) c[e] += t[e];
-                        acc[i][jq * 2 + jj] = c;
-                    }
+                    for (int e = 0; e < 4; ++e) acc[0][j - 1][e] += tp0[e], acc[1][j - 1][e] += tp1[e];
+                }
+                tp0 = t0;
+                tp1 = t1;
+                if (j >= 2 && j < 10) {  // one eighth of the next step's split: 2 values of fragment (j - 2) / 4
+                    const int f = (j - 2) >> 2, pp = (j - 2) & 3;
+                    const f32x4 src = raw[f][pp >> 1];
+                    unsigned hp, mp, lp;
+                    split2(src[2 * (pp & 1)], src[2 * (pp & 1) + 1], hp, mp, lp);
+                    nh[f][pp] = hp, nm[f][pp] = mp, nl[f][pp] = lp;
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
-            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[0][15][e] += tp0[e], acc[1][15][e] += tp1[e];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                nxt.h[i] = __builtin_bit_cast(bf16x8, nh[i]);
+                nxt.m[i] = __builtin_bit_cast(bf16x8, nm[i]);
+                nxt.l[i] = __builtin_bit_cast(bf16x8, nl[i]);
+            }
+        };
+#pragma unroll 1
+        for (int s = 0; s < nk; s += 2) {
+            step(sp0, sp1, s);
+            step(sp1, sp0, s + 1);
         }
         first = false;
         __syncthreads();  // every wave is done with the last stage (only dropped pieces are outstanding): both buffers are free
         // ---- forward: the bias, ahead of the next head in this wave's queue (the compiler's wait for it leaves the head in flight)
-        f32x4 bias4[8];
+        f32x4 bias4[16];
         if (!DX) {
-            asm volatile("" ::: "memory");  // (not hoisted into the K loop: 32 more live registers there spill)
+            asm volatile("" ::: "memory");
 #pragma unroll
-            for (int j = 0; j < 8; ++j) bias4[j] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(&bias[n0 + wc * 128 + j * 16 + q * 4]));
+            for (int j = 0; j < 16; ++j) bias4[j] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(&bias[n0 + j * 16 + q * 4]));
             asm volatile("" ::: "memory");
         }
-        // ---- the next tile's first stage goes into buffer 0 now; this tile leaves through buffer 1
+        // ---- the next tile's head goes into W buffer 0 and both A buffers now; this tile leaves through W buffer 1
         const int next_tile = row_tile + row_stride;
         const bool more = next_tile < row_tiles;
         if (more) a_rs = a_rsrc(next_tile);
-        issue(a_rs, 0, 0, more);
+        issue_w(0, 0, more);
+        issue_a(a_rs, 0, 0, more);
+        issue_a(a_rs, 1, 1, more);
         if (DX) {
 #pragma unroll
             for (int h = 0; h < 2; ++h)
                 mask_next[h] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(bits_rs, more ? bits_off(next_tile, h) : 0xFFFFFFF0u, 0, 0));
         }
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
+        for (int h = 0; h < 2; ++h) {  // column half h: bit (ii * 8 + j) * 4 + e = row block ii, column block j of the half, element e
             unsigned lo = DX ? mask_word[h][0] : 0u, hi = DX ? mask_word[h][1] : 0u;
 #pragma unroll
             for (int ii = 0; ii < 2; ++ii)
@@ -367,10 +440,10 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_split_p_kernel(const float *__
                         const int bb = (ii * 8 + j) * 4 + e;
                         if (DX) {
                             const unsigned m = 0u - (((bb < 32 ? lo : hi) >> (bb & 31)) & 1u);
-                            acc[2 * h + ii][j][e] = __uint_as_float(__float_as_uint(acc[2 * h + ii][j][e]) & m);
+                            acc[ii][h * 8 + j][e] = __uint_as_float(__float_as_uint(acc[ii][h * 8 + j][e]) & m);
                         } else {
-                            const float x = relu1(acc[2 * h + ii][j][e] + bias4[j][e]);
-                            acc[2 * h + ii][j][e] = x;
+                            const float x = relu1(acc[ii][h * 8 + j][e] + bias4[h * 8 + j][e]);
+                            acc[ii][h * 8 + j][e] = x;
                             const unsigned v = x > 0.f ? 1u : 0u;
                             if (bb < 32) lo |= v << bb;
                             else hi |= v << (bb - 32);
@@ -379,28 +452,35 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_split_p_kernel(const float *__
             if (!DX) __builtin_amdgcn_raw_buffer_store_b64(u32x2{lo, hi}, bits_rs, bits_off(row_tile, h), 0, 0);  // (dropped past the end, still counted)
         }
         __builtin_amdgcn_sched_barrier(0);
-        char *mine = lds + STAGE + wave_u * (16 * 512);  // 8 KiB of buffer 1
-        const __amdgpu_buffer_rsrc_t c_rs = make_rsrc(reinterpret_cast<char *>(C) + m0 * ldc_b + (int64_t)(n0 + wc * 128) * 4, (unsigned)(rows_here - 1) * ldc_b + 128 * 4);
-        const int rr = lane >> 5, c32 = lane & 31;
+        // a lane holds 4 consecutive columns of one row: 16 rows x 64 columns are parked in 4 KiB of the wave's own (16-byte chunk c of
+        // row r at chunk c ^ r) and read back as 4 rows x 256 contiguous bytes per wave-instruction.  In-wave: no barrier.
+        int le = lane;
+        asm volatile("" : "+v"(le));  // the addresses below are recomputed per tile: hoisted out of the tile loop they are spilled, and a
+                                      // scratch reload is a vmcnt(0) wait in the middle of the epilogue
+        const int er = le & 15, eq = le >> 4;
+        char *mine = lds + STAGE + A_STAGE + wave_u * 4096;
+        const __amdgpu_buffer_rsrc_t c_rs = make_rsrc(reinterpret_cast<char *>(C) + m0 * ldc_b + (int64_t)n0 * 4, (unsigned)(rows_here - 1) * ldc_b + 256 * 4);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            if (i) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        for (int it = 0; it < 8; ++it) {
+            const int i = it >> 2, cq = it & 3;
+            if (it) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the previous piece's read-back is in registers
 #pragma unroll
-            for (int j = 0; j < 8; ++j) *reinterpret_cast<f32x4 *>(mine + r16 * 512 + (((j * 4 + q) ^ r16) * 16)) = acc[i][j];
-            f32x4 v[8];
+            for (int jj = 0; jj < 4; ++jj) *reinterpret_cast<f32x4 *>(mine + er * 256 + (((jj * 4 + eq) ^ er) * 16)) = acc[i][cq * 4 + jj];
+            f32x4 v[4];
 #pragma unroll
-            for (int t = 0; t < 8; ++t) {
-                const int r = 2 * t + rr;
-                v[t] = *reinterpret_cast<const f32x4 *>(mine + r * 512 + ((c32 ^ r) * 16));
+            for (int t = 0; t < 4; ++t) {
+                const int r = 4 * t + eq;
+                v[t] = *reinterpret_cast<const f32x4 *>(mine + r * 256 + ((er ^ r) * 16));
             }
-            const unsigned c_off = (unsigned)(wr * 64 + i * 16 + rr) * ldc_b + c32 * 16;
+            const unsigned c_off = (unsigned)(wave_u * 32 + i * 16 + eq) * ldc_b + cq * 256 + er * 16;
 #pragma unroll
-            for (int t = 0; t < 8; ++t) stb(c_rs, c_off, 2 * t * ldc_b, v[t]);
+            for (int t = 0; t < 4; ++t) stb(c_rs, c_off, 4 * t * ldc_b, v[t]);
         }
     }
 }
 
-// planes[(ks * 3 + p) * R + r][t] = piece p of S[r][ks * 32 + t]   (S: R x Cc fp32, row stride ld; Cc % 32 == 0)
+// planes[(ks * 3 + p) * R + 16 (r / 16)] + chunk wpos(r % 16, t / 8), element t % 8  =  piece p of S[r][ks * 32 + t]
+// (S: R x Cc fp32, row stride ld; R % 16 == 0, Cc % 32 == 0)
 __global__ __launch_bounds__(256) void pack_split_kernel(const float *__restrict__ S, int64_t ld, int R, int Cc, unsigned short *__restrict__ planes) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= (int64_t)R * Cc) return;
@@ -412,7 +492,7 @@ __global__ __launch_bounds__(256) void pack_split_kernel(const float *__restrict
     const float r2 = r1 - (float)m;
     const __bf16 l = (__bf16)r2;
     const int ks = c >> 5, t = c & 31;
-    const int64_t base = ((int64_t)ks * 3 * R + r) * 32 + t;
+    const int64_t base = ((int64_t)ks * 3 * R + (r & ~15)) * 32 + wpos(r & 15, t >> 3) * 8 + (t & 7);
     planes[base] = __builtin_bit_cast(unsigned short, h);
     planes[base + (int64_t)R * 32] = __builtin_bit_cast(unsigned short, m);
     planes[base + (int64_t)2 * R * 32] = __builtin_bit_cast(unsigned short, l);
@@ -424,7 +504,7 @@ void set_split_persistent(int v) { g_split_persistent = v; }
 bool nt_split_ok(int N, int K) { return N > 0 && N % 256 == 0 && K >= 32 && K % 32 == 0; }
 
 int launch_pack_split(hipStream_t st, const float *S, int64_t ld, int R, int Cc, unsigned short *planes) {
-    RLPPO_CHECK_ARG(S && planes && R > 0 && Cc > 0 && Cc % 32 == 0 && ld >= Cc, "pack_split: R=%d C=%d ld=%ld", R, Cc, (long)ld);
+    RLPPO_CHECK_ARG(S && planes && R > 0 && R % 16 == 0 && Cc > 0 && Cc % 32 == 0 && ld >= Cc, "pack_split: R=%d C=%d ld=%ld", R, Cc, (long)ld);
     const int64_t n = (int64_t)R * Cc;
     hipLaunchKernelGGL(pack_split_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st, S, ld, R, Cc, planes);
     RLPPO_LAUNCH_CHECK();
@@ -446,7 +526,7 @@ int launch_gemm_nt_split(hipStream_t st, const float *A, int64_t lda, const unsi
     const int row_tiles = (int)cdiv(M, 256), col_tiles = N / 256;
     int cus = 0;
     if (int rc_ = device_cu_count(&cus)) return rc_;
-    if (g_split_persistent && row_tiles >= 2 * (cus / (8 * col_tiles) > 0 ? cus / (8 * col_tiles) : 1) * 8 && col_tiles <= 8) {
+    if (g_split_persistent && (K / 32) % 2 == 0 && row_tiles >= 2 * (cus / (8 * col_tiles) > 0 ? cus / (8 * col_tiles) : 1) * 8 && col_tiles <= 8) {
         // persistent workgroups: whole groups of 8 row tiles x all column tiles, never more workgroups than CUs (or than the work)
         const int group = 8 * col_tiles;
         int grid = cus / group * group;
