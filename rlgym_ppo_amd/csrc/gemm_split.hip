@@ -13,13 +13,30 @@
 //
 // Operands: A [M][K] fp32 exactly as the update stores its activations / activation gradients -- split ON THE FLY, per MFMA
 // fragment, in registers (v_cvt_pk_bf16_f32 + shift / mask + subtract: 5.5 vector instructions per value); the weights pre-split
-// by rlppo_net_pack_x3 after every optimiser step into three bf16 planes in STAGE-MAJOR order [K / 32][3][N][32], so that the 48 KiB
-// a K step needs are contiguous in memory.  One 256 x 256 output tile per workgroup (8 waves as 4 x 2, 128 accumulator registers
-// per lane, one workgroup per CU), two stages of 80 KiB: A 256 x 32 fp32 (the 128-byte-row image and swizzle of the bf16 kernels)
-// + three 16 KiB weight planes.  The tile leaves through LDS, 16 rows per wave at a time (2 x 512 contiguous bytes per
-// wave-instruction).  FWD: C = relu(A . W^T + b) and the ReLU bitmask in the layout every other kernel of the update reads
-// (128 x 128 tiles, one 64-bit word per lane); DX: C = (A . B^T) masked by the bitmask of the layer below.
+// by rlppo_net_pack_x3 after every optimiser step into three bf16 planes in STAGE-MAJOR order [K / 32][3][N / 16][1 KiB block], so
+// that the 48 KiB a K step needs are contiguous in memory, every 16-column block in the chunk order wpos() that makes its fragment
+// reads bank-conflict-free.  One 256 x 256 output tile per workgroup and pass, 8 waves, 128 accumulator registers per lane, one
+// workgroup per CU, two stages of 80 KiB: A 256 x 32 fp32 (the 128-byte-row image and swizzle of the bf16 kernels) + three 16 KiB
+// weight planes.  Two kernels: gemm_nt_split_kernel, one tile per workgroup (waves 4 x 2, small launches, any K % 32 == 0), and the
+// persistent gemm_nt_split_p_kernel (a wave owns 32 rows x 256 columns and splits step s + 1 under the MFMAs of step s).  The tile
+// leaves through LDS in row pieces.  FWD: C = relu(A . W^T + b) and the ReLU bitmask in the layout every other kernel of the update
+// reads (128 x 128 tiles, one 64-bit word per lane); DX: C = (A . B^T) masked by the bitmask of the layer below.
+//
+// Where a launch's time goes (M = 524,288, 256 -> 256; profiles/r04_split_ablation.txt, PMC in the same file): 1.07 GB of HBM traffic
+// (floor ~230 us at the rate a copy reaches) against 166 us of MFMA-pipe time (25.2 M MFMAs x 16 cycles / 1,024 SIMDs at 2.36 GHz);
+// the launch takes 345-375 us = 0.48 MFMA-busy.  The K loop alone (no traffic, no epilogue, no barrier) runs 219 us: at 16 cycles
+// per MFMA, 8 of which hold the SIMD's vector issue, a wave-step's 218 vector instructions, 52 fragment reads and 10 stage requests
+// (60+ cycles of issue each) do not fit the gaps of its 192 MFMAs; the epilogue's vector work adds 23 us, barriers and request
+// issue 18 us, and the memory system 70-110 us that the loop does not hide (stores 32 us: every wave's 32 tile stores must be
+// acknowledged before its next counted wait can pass, vmcnt being in order).
 #include "gemm_detail.hpp"
+// -DSPLIT_ABL=bits builds TIMING-ONLY variants of the persistent kernel (results are garbage) for tools/split_ablation.sh, which
+// prices the parts of a K step by leaving them out: 1 the steps' stage requests go outside their descriptors (no traffic, still
+// issued and counted), 2 no split of the next step's fragments, 8 only the large product, 16 the tile's stores dropped, 32 no epilogue
+// work, 64 no stage-request instructions at all, 128 no barrier per step.  0 (the default) is the product.
+#ifndef SPLIT_ABL
+#define SPLIT_ABL 0
+#endif
 
 namespace rlppo {
 namespace {
@@ -337,9 +354,11 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_split_p_kernel(const float *__
         }
         auto step = [&](const SplitFrags &cur, SplitFrags &nxt, int s) {
             if (s) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // W(s), A(s + 1): requested a step ago
-            __builtin_amdgcn_s_barrier();                            // everybody is done with W(s - 1) and with A(s)
-            issue_a(a_rs, s & 1, s + 2, s + 2 < nk);
-            issue_w((s + 1) & 1, s + 1, s + 1 < nk);
+            if (!(SPLIT_ABL & 128)) __builtin_amdgcn_s_barrier();    // everybody is done with W(s - 1) and with A(s)
+            if (!(SPLIT_ABL & 64)) {
+                issue_a(a_rs, s & 1, s + 2, !(SPLIT_ABL & 1) && s + 2 < nk);
+                issue_w((s + 1) & 1, s + 1, !(SPLIT_ABL & 1) && s + 1 < nk);
+            }
             const char *Wc = lds + (s & 1) * STAGE + A_STAGE + w_frag;
             const char *An = lds + ((s + 1) & 1) * STAGE;  // (the last step splits a stale stage into fragments nobody uses: no branch)
             f32x4 raw[2][2];
@@ -360,6 +379,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_split_p_kernel(const float *__
                     for (int p = 0; p < 3; ++p)
                         w[(j + 1) & 1][p] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4 *>(Wc + p * W_PLANE + (j + 1) * 1024));
                 }
+                __builtin_amdgcn_sched_barrier(0);  // the reads stay AHEAD of this block's MFMAs (left alone the scheduler sinks them to the block's end)
                 const bf16x8 wh = w[j & 1][0], wm = w[j & 1][1], wl = w[j & 1][2];
                 const f32x4 z = {0.f, 0.f, 0.f, 0.f};
                 // the five small products of a K block summed among themselves, the two fragments' chains interleaved
@@ -367,14 +387,16 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_split_p_kernel(const float *__
                 f32x4 t1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, cur.l[1], z, 0, 0, 0);
                 f32x4 c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, cur.h[0], acc[0][j], 0, 0, 0);
                 f32x4 c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, cur.h[1], acc[1][j], 0, 0, 0);
-                t0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, cur.h[0], t0, 0, 0, 0);
-                t1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, cur.h[1], t1, 0, 0, 0);
-                t0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, cur.m[0], t0, 0, 0, 0);
-                t1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, cur.m[1], t1, 0, 0, 0);
-                t0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, cur.m[0], t0, 0, 0, 0);
-                t1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, cur.m[1], t1, 0, 0, 0);
-                t0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, cur.h[0], t0, 0, 0, 0);
-                t1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, cur.h[1], t1, 0, 0, 0);
+                if (!(SPLIT_ABL & 8)) {
+                    t0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, cur.h[0], t0, 0, 0, 0);
+                    t1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, cur.h[1], t1, 0, 0, 0);
+                    t0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, cur.m[0], t0, 0, 0, 0);
+                    t1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, cur.m[1], t1, 0, 0, 0);
+                    t0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, cur.m[0], t0, 0, 0, 0);
+                    t1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, cur.m[1], t1, 0, 0, 0);
+                    t0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, cur.h[0], t0, 0, 0, 0);
+                    t1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, cur.h[1], t1, 0, 0, 0);
+                }
                 acc[0][j] = c0;
                 acc[1][j] = c1;
                 if (j > 0) {  // the previous block's small sum enters its accumulator now: its chain has long finished
@@ -383,7 +405,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_split_p_kernel(const float *__
                 }
                 tp0 = t0;
                 tp1 = t1;
-                if (j >= 2 && j < 10) {  // one eighth of the next step's split: 2 values of fragment (j - 2) / 4
+                if (j >= 2 && j < 10 && !(SPLIT_ABL & 2)) {  // one eighth of the next step's split: 2 values of fragment (j - 2) / 4
                     const int f = (j - 2) >> 2, pp = (j - 2) & 3;
                     const f32x4 src = raw[f][pp >> 1];
                     unsigned hp, mp, lp;
@@ -394,6 +416,10 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_split_p_kernel(const float *__
             }
 #pragma unroll
             for (int e = 0; e < 4; ++e) acc[0][15][e] += tp0[e], acc[1][15][e] += tp1[e];
+            if (SPLIT_ABL & 2) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) nh[i] = __builtin_bit_cast(u32x4, raw[i][0]), nm[i] = __builtin_bit_cast(u32x4, raw[i][1]), nl[i] = nh[i] ^ nm[i];
+            }
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 nxt.h[i] = __builtin_bit_cast(bf16x8, nh[i]);
@@ -428,6 +454,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_split_p_kernel(const float *__
             for (int h = 0; h < 2; ++h)
                 mask_next[h] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(bits_rs, more ? bits_off(next_tile, h) : 0xFFFFFFF0u, 0, 0));
         }
+        if (!(SPLIT_ABL & 32))
 #pragma unroll
         for (int h = 0; h < 2; ++h) {  // column half h: bit (ii * 8 + j) * 4 + e = row block ii, column block j of the half, element e
             unsigned lo = DX ? mask_word[h][0] : 0u, hi = DX ? mask_word[h][1] : 0u;
@@ -459,7 +486,8 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_split_p_kernel(const float *__
                                       // scratch reload is a vmcnt(0) wait in the middle of the epilogue
         const int er = le & 15, eq = le >> 4;
         char *mine = lds + STAGE + A_STAGE + wave_u * 4096;
-        const __amdgpu_buffer_rsrc_t c_rs = make_rsrc(reinterpret_cast<char *>(C) + m0 * ldc_b + (int64_t)n0 * 4, (unsigned)(rows_here - 1) * ldc_b + 256 * 4);
+        const __amdgpu_buffer_rsrc_t c_rs = make_rsrc(reinterpret_cast<char *>(C) + m0 * ldc_b + (int64_t)n0 * 4, (SPLIT_ABL & 16) ? 0u : (unsigned)(rows_here - 1) * ldc_b + 256 * 4);
+        if (!(SPLIT_ABL & 32))
 #pragma unroll
         for (int it = 0; it < 8; ++it) {
             const int i = it >> 2, cq = it & 3;
@@ -475,6 +503,12 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_split_p_kernel(const float *__
             const unsigned c_off = (unsigned)(wave_u * 32 + i * 16 + eq) * ldc_b + cq * 256 + er * 16;
 #pragma unroll
             for (int t = 0; t < 4; ++t) stb(c_rs, c_off, 4 * t * ldc_b, v[t]);
+        }
+        if (SPLIT_ABL & 32) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 16; ++j) asm volatile("" ::"v"(acc[i][j]));
         }
     }
 }

@@ -1084,15 +1084,18 @@ def test_gemm_nt_x3_forward_and_dx(L, M, N, K):
     the forward (bias + relu) and the masked dX must be AT LEAST as accurate as the product's fp32-MFMA kernels on the same
     operands (max and rms error, 5 % of slack for the rms); the ReLU bitmask the forward writes is the one every other kernel of
     the update reads -- word for word the fp32 kernel's except where a pre-activation sits within rounding of 0 -- and the dX form
-    applies a bitmask written by the fp32 kernel exactly as the fp32 dX kernel does; the packed planes add up to the weights
-    (2^-24 relative: the third piece rounds the second residual).  Ragged row counts, two column tiles, K = 32 ... 256."""
+    applies a bitmask written by the fp32 kernel exactly as the fp32 dX kernel does; the packed planes (read back through the
+    bank-conflict-free chunk order of their LDS image) add up to the weights (2^-24 relative: the third piece rounds the second residual).  Ragged row counts, two column tiles, K = 32 ... 256."""
     g = torch.Generator(device="cuda").manual_seed(M + K)
     A = (torch.randn(M, K, device="cuda", generator=g).clamp_(min=0) * torch.rand(M, K, device="cuda", generator=g)).contiguous()
     W = ((torch.rand(N, K, device="cuda", generator=g) * 2 - 1) / np.sqrt(K)).contiguous()
     bias = ((torch.rand(N, device="cuda", generator=g) - 0.5) * 0.2).contiguous()
     planes = torch.zeros(3 * N * K, dtype=torch.bfloat16, device="cuda")
     check(L, L.rlppo_dbg_pack_x3(stream(), P(W), K, N, K, P(planes)))
-    pl = planes.view(K // 32, 3, N, 32).float()
+    # a plane's 16-column block is 64 chunks of 8 k: (column r, k quarter q) at chunk r * 4 + (q ^ (-(r // 4) & 3))  (wpos(), gemm_split.hip)
+    r16, q4 = torch.arange(16).view(16, 1), torch.arange(4).view(1, 4)
+    pos = (r16 * 4 + (q4 ^ ((-(r16 // 4)) & 3))).reshape(-1).cuda()
+    pl = planes.view(K // 32, 3, N // 16, 64, 8).float()[:, :, :, pos].reshape(K // 32, 3, N, 32)
     rebuilt = (pl[:, 0] + pl[:, 1] + pl[:, 2]).permute(1, 0, 2).reshape(N, K)
     assert (rebuilt - W).abs().max().item() <= 2.0 ** -24 * W.abs().max().item()
     nb = max(int(L.rlppo_dbg_gemm_nt_bits_bytes(M, N)), 8)
