@@ -6,6 +6,11 @@
 // The `w` forms work on 256 x 256 output tiles (one workgroup of 8 waves per CU, 128 KiB of dynamic LDS).  Staging, swizzles, bitmask
 // layout, partial-tile layout and the reduction are those of the fp32 kernels (gemm.hip, gemm_detail.hpp).
 #include "gemm_detail.hpp"
+// -DB16_ABL=bits builds TIMING-ONLY variants of the persistent kernel (results are garbage) for tools/b16_ablation.py: 1 the K steps'
+// stage requests go outside their descriptors (issued and counted, no traffic), 16 the tile's stores dropped, 32 no epilogue work.
+#ifndef B16_ABL
+#define B16_ABL 0
+#endif
 
 namespace rlppo {
 
@@ -504,7 +509,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_b16p_kernel(const unsigned sho
             if (kt == 0 && !first) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();  // everybody's pieces of stage kt have landed; everybody is done with the other buffer
-            if (kt + 1 < nk) issue_tile(a_rs, cur ^ 1, (unsigned)(kt + 1) * (4u * BKT));
+            if (kt + 1 < nk) issue_tile(a_rs, cur ^ 1, (B16_ABL & 1) ? 0x80000000u : (unsigned)(kt + 1) * (4u * BKT));
             const float *Ac = wlds + cur * STAGE + (wr * 64) * BKT;
             const float *Bc = wlds + cur * STAGE + TM * BKT + (wc * 128) * BKT;
 #pragma unroll
@@ -539,9 +544,15 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_b16p_kernel(const unsigned sho
                 mask_next[h] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(bits_rs, more ? bits_off(next_tile, h) : 0xFFFFFFF0u, 0, 0));
         }
         const __amdgpu_buffer_rsrc_t o_rs = make_rsrc(reinterpret_cast<char *>(Cb) + m0 * ldcb_b + (int64_t)(n0 + wc * 128) * 2,
-                                                      (unsigned)(rows_here - 1) * ldcb_b + 128 * 2);
+                                                      (B16_ABL & 16) ? 0u : (unsigned)(rows_here - 1) * ldcb_b + 128 * 2);
         char *mine = reinterpret_cast<char *>(wlds + STAGE) + wave_u * (32 * 256);  // 8 KiB of buffer 1
         const int rr = lane >> 4, c16 = lane & 15;
+        if (B16_ABL & 32) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) asm volatile("" ::"v"(acc[i][j]));
+        } else
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             // one rounding to bf16; forward: relu + bitmask first, dX: the forward's mask afterwards.  Written for the vector ALU: this
