@@ -1077,7 +1077,7 @@ def test_fused_pass_full_size_cfg2(L):
     np.testing.assert_allclose(st[:5], st_sum / 8, rtol=1e-5, atol=1e-8)
 
 
-@pytest.mark.parametrize("M,N,K", [(256, 256, 32), (1000, 256, 96), (4227, 512, 256), (65536, 256, 256)])
+@pytest.mark.parametrize("M,N,K", [(256, 256, 32), (1000, 256, 96), (4227, 512, 256), (65536, 256, 256), (140037, 256, 256), (70001, 512, 128)])
 def test_gemm_nt_x3_forward_and_dx(L, M, N, K):
     """[r4] The split-bf16 hidden products (csrc/gemm_split.hip; OPT-IN update precision 2): fp32 operands in memory, three bf16
     pieces each, six piece products on the bf16 MFMA pipe, the five small ones summed apart from the accumulator.  Against float64:
@@ -1103,7 +1103,7 @@ def test_gemm_nt_x3_forward_and_dx(L, M, N, K):
     C32, C3 = torch.empty(M, N, device="cuda"), torch.full((M, N), float("nan"), device="cuda")
     check(L, L.rlppo_dbg_gemm_nt_bits(stream(), P(A), K, P(W), K, P(bias), P(C32), N, M, N, K, 1, P(bits32)))
     check(L, L.rlppo_dbg_gemm_nt_x3(stream(), P(A), K, P(planes), P(bias), P(C3), N, M, N, K, 0, P(bits3)))
-    rows = torch.arange(0, M, max(1, M // 2048), device="cuda")
+    rows = torch.unique(torch.cat([torch.arange(0, M, max(1, M // 2048), device="cuda"), torch.arange(max(0, M - 300), M, device="cuda")]))
     pre = A[rows].double() @ W.double().t() + bias.double()
     truth = torch.relu(pre)
     scale = truth.abs().max().item()
