@@ -380,12 +380,13 @@ int rlppo_net_pack_bf16(void *stream, const int32_t *dims, int32_t n_layers, con
  * faster per launch and, against float64, MORE accurate than the fp32 MFMA's fmaf chain (0.43-0.46 x its error at K = 256).  The
  * gradients then differ from mode 0's by fp32 rounding noise only (tests/test_gpu_kernels.py, tests/test_gpu_learner.py hold
  * mode 2 to the same float64 gates as mode 0).  Needs, per network, the image rlppo_net_pack_x3 derives from the PACKED copy
- * after every optimiser step: rlppo_x3_elems bf16 values (the stage-major planes [K / 32][3][N][32] of W for every covered
- * forward and of W^T for every covered dX), handed over in rlppo_minibatch_args.pol_wb16 / val_wb16.  Policy and critic run as two
+ * after every optimiser step: rlppo_x3_elems bf16 values (the stage-major planes [K / 32][3][N / 16][1 KiB block] of W for every
+ * covered forward and of W^T for every covered dX; inside a 16-row block the 16-byte chunk (row r, k quarter q) at chunk
+ * 4 r + (q ^ (-(r / 4) & 3)): the image the kernels' LDS fragment reads are bank-conflict-free on), handed over in rlppo_minibatch_args.pol_wb16 / val_wb16.  Policy and critic run as two
  * chains in this mode (no paired launches, the critic's head as its own matrix-vector launch). */
 int64_t rlppo_x3_elems(const int32_t *dims, int32_t n_layers);
 int rlppo_net_pack_x3(void *stream, const int32_t *dims, int32_t n_layers, const float *packed, void *planes);
-/* single-kernel entry points of that precision (tests, bench.py): planes[C / 32][3][R][32] <- the pieces of S[R][C] (row stride ld);
+/* single-kernel entry points of that precision (tests, bench.py): planes[C / 32][3][R / 16][1 KiB block, chunk order as above] <- the pieces of S[R][C] (row stride ld; R % 16 == 0);
  * C[M][N] = relu(A[M][K] . W^T + bias) with bits <- [C > 0] (mode 0) or (A . B^T) masked by bits (mode 1); N % 256 == 0, K % 32 == 0,
  * bits as rlppo_dbg_gemm_nt_bits_bytes(M, N). */
 int rlppo_dbg_pack_x3(void *stream, const float *S, int64_t ld, int32_t R, int32_t C, void *planes);
