@@ -168,9 +168,11 @@ __global__ __launch_bounds__(256, BKT == 16 ? 4 : 2) void gemm_nt_dma_kernel(con
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of the next tile have landed in LDS
         __syncthreads();
     }
+    // the stage buffers are free (the loop's last barrier has passed): 8 KiB per wave for the tile's way out (nt_store_parked)
+    char *const park = reinterpret_cast<char *>(lds) + wave_u * 8192;
     if (BITS && EPI == EPI_MASK) {
         apply_bits<NB>(acc, mask_word);
-        nt_epilogue<NB, EPI_NONE>(acc, nullptr, 0, C, ldc_b, m0, n0, rows_here, wave, r16, q);
+        nt_epilogue<NB, EPI_NONE>(acc, nullptr, 0, C, ldc_b, m0, n0, rows_here, wave, r16, q, park);
     } else if (BITS && EPI == EPI_BIAS_RELU) {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -202,9 +204,9 @@ __global__ __launch_bounds__(256, BKT == 16 ? 4 : 2) void gemm_nt_dma_kernel(con
                 if (r0 + 16 < rows_here) atomicAdd(dot.out + m0 + r0 + 16, s1 + b0);
             }
         }
-        nt_epilogue<NB, EPI_NONE>(acc, nullptr, 0, C, ldc_b, m0, n0, rows_here, wave, r16, q);
+        nt_epilogue<NB, EPI_NONE>(acc, nullptr, 0, C, ldc_b, m0, n0, rows_here, wave, r16, q, park);
     } else {
-        nt_epilogue<NB, EPI>(acc, mask_src, ldm_b, C, ldc_b, m0, n0, rows_here, wave, r16, q);
+        nt_epilogue<NB, EPI>(acc, mask_src, ldm_b, C, ldc_b, m0, n0, rows_here, wave, r16, q, park);
     }
 }
 
