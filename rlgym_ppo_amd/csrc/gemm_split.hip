@@ -316,6 +316,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_split_p_kernel(const float *__
     __amdgpu_buffer_rsrc_t a_rs = a_rsrc(row_first);
     issue_w(0, 0, true);
     issue_a(a_rs, 0, 0, true);
+    issue_a(a_rs, 1, 1, true);
     bool first = true;
     u32x2 mask_next[2];
     if (DX) {
@@ -343,7 +344,6 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_split_p_kernel(const float *__
         if (!first) asm volatile("s_waitcnt vmcnt(34)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DX ? 2 : 0) : "memory");
         __builtin_amdgcn_s_barrier();  // raw (no fence) throughout: a wave waits for ITS pieces before the barrier behind which they are read
-        issue_a(a_rs, 1, 1, true);     // A(1): its buffer was the previous tile's way out; it has this tile's first split + step 0 (~4 us) to land
         SplitFrags sp0, sp1;
         {
 #pragma unroll
@@ -448,6 +448,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_split_p_kernel(const float *__
         if (more) a_rs = a_rsrc(next_tile);
         issue_w(0, 0, more);
         issue_a(a_rs, 0, 0, more);
+        issue_a(a_rs, 1, 1, more);
         if (DX) {
 #pragma unroll
             for (int h = 0; h < 2; ++h)
@@ -484,25 +485,24 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_split_p_kernel(const float *__
         asm volatile("" : "+v"(le));  // the addresses below are recomputed per tile: hoisted out of the tile loop they are spilled, and a
                                       // scratch reload is a vmcnt(0) wait in the middle of the epilogue
         const int er = le & 15, eq = le >> 4;
-        char *mine = lds + STAGE + wave_u * 8192;  // 8 KiB of buffer 1 (free: the head went into buffer 0)
+        char *mine = lds + STAGE + A_STAGE + wave_u * 4096;
         const __amdgpu_buffer_rsrc_t c_rs = make_rsrc(reinterpret_cast<char *>(C) + m0 * ldc_b + (int64_t)n0 * 4, (SPLIT_ABL & 16) ? 0u : (unsigned)(rows_here - 1) * ldc_b + 256 * 4);
-        const int err = le >> 5, ec32 = le & 31;
         if (!(SPLIT_ABL & 32))
 #pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const int i = it >> 1, hc = it & 1;
+        for (int it = 0; it < 8; ++it) {
+            const int i = it >> 2, cq = it & 3;
             if (it) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the previous piece's read-back is in registers
 #pragma unroll
-            for (int jj = 0; jj < 8; ++jj) *reinterpret_cast<f32x4 *>(mine + er * 512 + (((jj * 4 + eq) ^ er) * 16)) = acc[i][hc * 8 + jj];
-            f32x4 v[8];
+            for (int jj = 0; jj < 4; ++jj) *reinterpret_cast<f32x4 *>(mine + er * 256 + (((jj * 4 + eq) ^ er) * 16)) = acc[i][cq * 4 + jj];
+            f32x4 v[4];
 #pragma unroll
-            for (int t = 0; t < 8; ++t) {
-                const int r = 2 * t + err;
-                v[t] = *reinterpret_cast<const f32x4 *>(mine + r * 512 + ((ec32 ^ r) * 16));
+            for (int t = 0; t < 4; ++t) {
+                const int r = 4 * t + eq;
+                v[t] = *reinterpret_cast<const f32x4 *>(mine + r * 256 + ((er ^ r) * 16));
             }
-            const unsigned c_off = (unsigned)(wave_u * 32 + i * 16 + err) * ldc_b + hc * 512 + ec32 * 16;
+            const unsigned c_off = (unsigned)(wave_u * 32 + i * 16 + eq) * ldc_b + cq * 256 + er * 16;
 #pragma unroll
-            for (int t = 0; t < 8; ++t) stb(c_rs, c_off, 2 * t * ldc_b, v[t]);
+            for (int t = 0; t < 4; ++t) stb(c_rs, c_off, 4 * t * ldc_b, v[t]);
         }
         if (SPLIT_ABL & 32) {
 #pragma unroll
