@@ -40,7 +40,10 @@ __device__ __forceinline__ float relu1(float x) { return __builtin_amdgcn_fmed3f
 // (the launches whose output is most of their traffic gain most): 7.81 -> 7.69 ms of GEMM launches per pass.
 __device__ __forceinline__ void nt_store_parked(f32x4 (&acc)[2][8], char *park, float *C, unsigned ldc_b, int64_t m0, int n0, int rows_here,
                                                 int wave, int lane) {
-    const __amdgpu_buffer_rsrc_t c_rs = make_rsrc(reinterpret_cast<char *>(C) + m0 * ldc_b + (int64_t)n0 * 4, (unsigned)(rows_here - 1) * ldc_b + 128 * 4);
+#ifndef NT_ABL  // -DNT_ABL=16: timing-only build whose 128-column tile stores are dropped by the descriptor (profiles/r04_nt_parked_stores.txt)
+#define NT_ABL 0
+#endif
+    const __amdgpu_buffer_rsrc_t c_rs = make_rsrc(reinterpret_cast<char *>(C) + m0 * ldc_b + (int64_t)n0 * 4, (NT_ABL & 16) ? 0u : (unsigned)(rows_here - 1) * ldc_b + 128 * 4);
     const int r16 = lane & 15, q = lane >> 4, rr = lane >> 5, c32 = lane & 31;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
