@@ -296,16 +296,15 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_split_p_kernel(const float *__
         char *Ad = lds + buf * STAGE + wave_u * (8 * 128);
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rs, reinterpret_cast<float *>(Ad + i * (64 * 128)), 16, a_off + (real ? 0u : DROPPED),
-                                                     real ? (unsigned)kt * 128u + i * 64u * lda_b : 0u, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rs, reinterpret_cast<float *>(Ad + i * (64 * 128)), 16, a_off,
+                                                     real ? (unsigned)kt * 128u + i * 64u * lda_b : DROPPED, 0, 0);
     };
     auto issue_w = [&](int buf, int kt, bool real) {  // 6 pieces per wave: KiB g % 16 of plane g / 16
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
             const int g = wave_u * 6 + i;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rs, reinterpret_cast<float *>(lds + buf * STAGE + A_STAGE + g * 1024), 16,
-                                                     (unsigned)lane * 16u + (real ? 0u : DROPPED),
-                                                     real ? ((unsigned)kt * 3u + (unsigned)(g >> 4)) * plane_stride + (unsigned)(g & 15) * 1024u : 0u, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rs, reinterpret_cast<float *>(lds + buf * STAGE + A_STAGE + g * 1024), 16, (unsigned)lane * 16u,
+                                                     real ? ((unsigned)kt * 3u + (unsigned)(g >> 4)) * plane_stride + (unsigned)(g & 15) * 1024u : DROPPED, 0, 0);
         }
     };
     // the bitmask word of this wave's 32 rows in column half hc (128 x 128-tile layout of relu_bits); outside the descriptor past the end
