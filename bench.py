@@ -144,6 +144,22 @@ def kernel_breakdown(learner):
         return lambda: N.check(L.rlppo_dbg_gemm_tn(st(), P(dY), ny, ny, P(X), kx, kx, P(dW), P(db), out, in_, M, P(tn_ws),
                                                     tn_ws.numel()))
 
+    # [r5] the update launches every weight-gradient product of a pass as ONE grouped launch + ONE reduction (csrc/gemm.hip,
+    # rlppo_dbg_set(37)): 2 first-layer, 4 hidden, 1 policy-head product (the critic's one-output head is a matrix-vector kernel)
+    gshapes = [(256, OBS, A256, 256, A0, K0), (256, 256, A256, 256, A256b, 256), (256, 256, A256b, 256, A256, 256), (ACT, 256, A96, 96, A256, 256),
+               (256, OBS, A256b, 256, A0, K0), (256, 256, A256, 256, A256b, 256), (256, 256, A256b, 256, A256, 256)]
+    gprods = (N.TnProduct * len(gshapes))()
+    gkeep = []
+    for q, (out, in_, dY, ny, X, kx) in zip(gprods, gshapes):
+        gw, gb = torch.zeros(out * in_, device=dev), torch.zeros(out, device=dev)
+        gkeep.append((gw, gb))
+        q.dY, q.ldy, q.ny_valid, q.X, q.ldx, q.kx_valid = dY.data_ptr(), ny, ny, X.data_ptr(), kx, kx
+        q.dW, q.db, q.out, q.in_, q.rowtab, q.src_rows = gw.data_ptr(), gb.data_ptr(), out, in_, None, 0
+    g_ws = torch.empty(max(int(L.rlppo_dbg_gemm_tn_group_workspace_bytes(gprods, len(gshapes), M)), 1), dtype=torch.uint8, device=dev)
+    tn_group = lambda: N.check(L.rlppo_dbg_gemm_tn_group(st(), gprods, len(gshapes), M, P(g_ws), g_ws.numel()))
+    g_exec = sum(f2 for f2 in (2 * M * 256 * K0, 2 * M * 256 * 256, 2 * M * 256 * 256, 2 * M * 96 * 256, 2 * M * 256 * K0, 2 * M * 256 * 256, 2 * M * 256 * 256))
+    g_alg = sum(2 * M * o * i for o, i, *_ in gshapes)
+
     # (name, launches per pass, launch, EXECUTED flop = the padded tile shape the kernel multiplies, ALGORITHMIC flop = the logical
     # layer shape: K = 107 observations, N = 90 actions).  The rates printed as `tflops` / `frac` are the algorithmic ones.
     f = lambda n, k: 2 * M * n * k
@@ -153,9 +169,11 @@ def kernel_breakdown(learner):
         ("fwd head 256->96", 1, nt(A256, 256, 256, C96, 96, 96, 256, 0), f(96, 256), f(ACT, 256)),
         ("dX hidden 256->256", 4, ntb(A256, 256, C256, 256, 256, 256, 3), f(256, 256), f(256, 256)),
         ("dX head 96->256", 1, ntb(A96, 96, C256, 256, 256, 96, 3), f(256, 96), f(256, ACT)),
-        ("dW hidden 256x256", 4, tn(A256, 256, A256b, 256, 256, 256), f(256, 256), f(256, 256)),
-        ("dW L0 256x107", 2, tn(A256, 256, A0, K0, 256, 107), f(256, K0), f(256, OBS)),
-        ("dW head 90x256", 1, tn(A96, 96, A256, 256, 90, 256), f(96, 256), f(ACT, 256)),
+        ("dW all 7 products, grouped + reduce", 1, tn_group, g_exec, g_alg),
+        # the per-layer form (one launch + reduction per product; what rounds 1-4 ran, rlppo_dbg_set(37, 0)): n = 0, not part of a pass
+        ("dW hidden 256x256 (per-layer form)", 0, tn(A256, 256, A256b, 256, 256, 256), f(256, 256), f(256, 256)),
+        ("dW L0 256x107 (per-layer form)", 0, tn(A256, 256, A0, K0, 256, 107), f(256, K0), f(256, OBS)),
+        ("dW head 90x256 (per-layer form)", 0, tn(A96, 96, A256, 256, 90, 256), f(96, 256), f(ACT, 256)),
     ]
     rows = []
     for name, count, fn, flop_exec, flop in shapes:
@@ -412,6 +430,106 @@ def cpu_baseline(seed=123, reps=3):
                 by_threads={str(k): round(n / v) for k, v in per_threads.items()}, host_cores=cores, physical_cores=physical_cores(),
                 sample="1 optimiser step over 131,072 cfg2 samples (2 minibatches of 65,536), torch-CPU eager oracle, median of %d warm reps per "
                        "thread count, best count reported; %.0f s" % (reps, time.perf_counter() - t_all))
+
+
+REF_BATCH, REF_BUFFER = 50_000, 150_000  # /root/reference: learner.py:34-53 (ppo_batch_size 50,000, minibatch = batch), example.py:74-88 (buffer 150,000)
+
+
+def ref_defaults_leg(device, seed=123):
+    """[r5] The reference's OWN configuration, like for like: PPOLearner.learn at ppo_batch_size = ppo_minibatch_size = 50,000
+    over a 150,000-sample buffer (example.py:74-88; Learner's defaults, learner.py:34-53, have the same batch / minibatch), 256x3
+    nets, obs 107, 90 actions; 1 epoch (example.py) and 10 epochs (Learner's default ppo_epochs) -- 3 and 30 optimiser steps of ONE
+    50,000-row pass each (390.6 row tiles: ragged launches, no minibatch fusion, no paired launches).  The CPU oracle runs the
+    IDENTICAL full workload beside it on this host's cores (same initial weights, same buffer, same numpy permutation stream), so
+    the GPU/CPU pair is the first one of this repository that is not a bounded slice against a full job -- and the two results are
+    compared (parameters after the 1-epoch learn(); the oracle is the checker here, never the thing shipped)."""
+    from oracle import nets, ppo
+    from rlgym_ppo_amd.ppo import ExperienceBuffer, PPOLearner
+    import contextlib
+    n, B = REF_BUFFER, REF_BATCH
+    rs = np.random.RandomState(seed)
+    obs = np.clip(rs.randn(n, OBS), -5, 5).astype(np.float32)
+    adv, tgt = rs.randn(n).astype(np.float32), rs.randn(n).astype(np.float32)
+    out = {}
+
+    def fresh():
+        torch.manual_seed(seed)
+        with contextlib.redirect_stdout(sys.stderr):
+            lr_ = PPOLearner(OBS, ACT, 0, HID, HID, (0.1, 1.0), B, 1, 3e-4, 3e-4, 0.2, 0.005, B, device)
+        pol0 = [(l.weight.detach().cpu().clone(), l.bias.detach().cpu().clone()) for l in lr_.policy.arena.linears]
+        val0 = [(l.weight.detach().cpu().clone(), l.bias.detach().cpu().clone()) for l in lr_.value_net.arena.linears]
+        return lr_, pol0, val0
+
+    learner, pol0, val0 = fresh()
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():  # actions sampled by the policy at its initial weights (ratio ~ 1 at the first step), on the host: both sides get the same
+        a, lp = nets.discrete_sample(nets.discrete_probs(pol0, torch.as_tensor(obs)), torch.empty(n, ACT).exponential_(1, generator=g))
+    acts, logp = a.numpy().astype(np.float32), lp.numpy()
+    z = np.zeros(n, np.float32)
+
+    def gpu_buffer():
+        buf = ExperienceBuffer(n, seed, "cpu")
+        buf.submit_experience(obs, acts, logp, z, obs[:1].repeat(n, 0), z, z, tgt, adv)
+        return buf
+
+    cpu_buf = dict(states=torch.as_tensor(obs), actions=torch.as_tensor(acts), log_probs=torch.as_tensor(logp), values=torch.as_tensor(tgt),
+                   advantages=torch.as_tensor(adv))
+    # ---- parity of the full workload (1 epoch = 3 optimiser steps), then timing of both sides
+    buf = gpu_buffer()
+    report = learner.learn(buf)
+    torch.set_num_threads(min(os.cpu_count() or 1, 16))
+    opol, oval = [(w.clone(), b.clone()) for w, b in pol0], [(w.clone(), b.clone()) for w, b in val0]
+    t = time.perf_counter()
+    oreport, _, _ = ppo.learn("discrete", opol, oval, cpu_buf, B, B, 1, 0.2, 0.005, 3e-4, 3e-4, np.random.RandomState(seed))
+    cpu_1 = [time.perf_counter() - t]
+    got_p = torch.nn.utils.parameters_to_vector(learner.policy.parameters()).cpu()
+    got_v = torch.nn.utils.parameters_to_vector(learner.value_net.parameters()).cpu()
+    rel = lambda x, y: float((x - y).abs().max() / y.abs().max())
+    out["parity_vs_cpu_oracle"] = dict(
+        policy_params_rel=float("%.3g" % rel(got_p, nets.flatten(opol))), critic_params_rel=float("%.3g" % rel(got_v, nets.flatten(oval))),
+        report_rel={k: float("%.3g" % (abs(report[k] - oreport[k]) / max(abs(oreport[k]), 1e-12)))
+                    for k in ("Policy Entropy", "Mean KL Divergence", "Value Function Loss", "SB3 Clip Fraction")},
+        note="after the identical 1-epoch learn() (3 optimiser steps of one 50,000-row pass), max |GPU - CPU oracle| / max |CPU oracle|")
+    for epochs, steps in ((1, 10), (10, 3)):
+        learner.n_epochs = epochs
+        learner.learn(buf)
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        for _ in range(steps):
+            learner.learn(buf)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t) / steps
+        samples = epochs * (n // B) * B
+        out["epochs_%d" % epochs] = dict(value=round(samples / dt, 1), unit="samples/s", ms_per_learn=round(dt * 1e3, 3),
+                                         optimiser_steps=epochs * (n // B), samples_per_learn=samples,
+                                         frac_of_f32_mfma_peak=round(FLOP_PER_SAMPLE * samples / dt / 1e12 / MFMA_F32_PEAK_TF, 4))
+    # the CPU side: the same full workloads (1 epoch: 2 more repetitions, median of 3; 10 epochs: once)
+    for _ in range(2):
+        opol, oval = [(w.clone(), b.clone()) for w, b in pol0], [(w.clone(), b.clone()) for w, b in val0]
+        t = time.perf_counter()
+        ppo.learn("discrete", opol, oval, cpu_buf, B, B, 1, 0.2, 0.005, 3e-4, 3e-4, np.random.RandomState(seed))
+        cpu_1.append(time.perf_counter() - t)
+    opol, oval = [(w.clone(), b.clone()) for w, b in pol0], [(w.clone(), b.clone()) for w, b in val0]
+    t = time.perf_counter()
+    ppo.learn("discrete", opol, oval, cpu_buf, B, B, 10, 0.2, 0.005, 3e-4, 3e-4, np.random.RandomState(seed))
+    cpu_10 = time.perf_counter() - t
+    thr = torch.get_num_threads()
+    out["cpu_baseline"] = dict(kind="port", cores=thr, unit="samples/s", epochs_1=round(n / float(np.median(cpu_1))), epochs_10=round(10 * n / cpu_10),
+                               sample="the IDENTICAL full workloads (150,000-sample buffer, B = MB = 50,000; 1 epoch: median of 3 runs; 10 epochs: 1 run), "
+                                      "torch-CPU eager oracle at %d threads, %.0f s" % (thr, sum(cpu_1) + cpu_10))
+    out["gpu_over_cpu"] = dict(epochs_1=round(out["epochs_1"]["value"] / out["cpu_baseline"]["epochs_1"], 1),
+                               epochs_10=round(out["epochs_10"]["value"] / out["cpu_baseline"]["epochs_10"], 1))
+    # the launch shapes of a 50,000-row pass, isolated (the same table as kernel_breakdown, compact)
+    learner._fused_rows = B
+    rows, dom, _ = kernel_breakdown(learner)
+    out["kernel_breakdown_50000_rows"] = [dict(kernel=r["kernel"], n=r["n"], ms=r["ms"], frac=r["frac"]) for r in rows if r["n"]]
+    out["roofline"] = dict(bound="mfma", achieved=dom["tflops"], peak=MFMA_F32_PEAK_TF, unit="TFLOP/s", frac=round(dom["tflops"] / MFMA_F32_PEAK_TF, 4),
+                           traffic=None, kernel=dom["kernel"], ms_per_launch=dom["ms"], rows_per_launch=B)
+    out["workload"] = "reference defaults: buffer 150,000, ppo_batch_size = ppo_minibatch_size = 50,000, 256x3 policy + critic, obs 107, 90 actions, fp32"
+    log("ref_defaults: GPU %.2f M samples/s (1 epoch) / %.2f M (10 epochs); CPU oracle, identical workload: %.0f / %.0f samples/s; params rel %.2e / %.2e"
+        % (out["epochs_1"]["value"] / 1e6, out["epochs_10"]["value"] / 1e6, out["cpu_baseline"]["epochs_1"], out["cpu_baseline"]["epochs_10"],
+           out["parity_vs_cpu_oracle"]["policy_params_rel"], out["parity_vs_cpu_oracle"]["critic_params_rel"]))
+    return out
 
 
 def physical_cores():
@@ -995,6 +1113,7 @@ def main():
         out["iteration"] = iteration_leg()
         out["cfg5"] = cfg5_leg(device)
         out["cpu_baseline"] = cpu_baseline()
+        out["ref_defaults"] = ref_defaults_leg(device)
         # The scalars a reader wants first, once more at the END of the line (a truncated record keeps its tail)
         g, ro, it = out["gae"], out["rollout"], out["iteration"]
         out["summary"] = dict(
@@ -1006,7 +1125,10 @@ def main():
             collect_ms=it["collect_ms"], iteration_steps_per_s=it["steps_per_s"],
             cfg5_fp32_samples_per_s=out["cfg5"]["fp32"]["value"], cfg5_bf16_samples_per_s=out["cfg5"]["bf16"]["value"],
             cfg5_bf16_update_frac_of_bf16_peak=out["cfg5"]["bf16"]["update_flop_efficiency"]["frac"],
-            cpu_port_samples_per_s=out["cpu_baseline"]["value"], update_x3_optin_samples_per_s=out["update_x3"]["value"])
+            cpu_port_samples_per_s=out["cpu_baseline"]["value"], update_x3_optin_samples_per_s=out["update_x3"]["value"],
+            ref_defaults_samples_per_s_1_epoch=out["ref_defaults"]["epochs_1"]["value"],
+            ref_defaults_samples_per_s_10_epochs=out["ref_defaults"]["epochs_10"]["value"],
+            ref_defaults_cpu_samples_per_s_10_epochs=out["ref_defaults"]["cpu_baseline"]["epochs_10"])
     emit()
     if world > 1:
         dist.destroy_process_group()

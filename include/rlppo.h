@@ -31,8 +31,11 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* The export table: the library is built with -fvisibility=hidden, and exactly the functions declared between this push and
+ * the matching pop have default visibility (`nm -D` shows them and nothing else of the library's own; tests/test_abi_and_layout.py). */
+#pragma GCC visibility push(default)
 
-#define RLPPO_ABI_VERSION 4
+#define RLPPO_ABI_VERSION 5
 #define RLPPO_MAX_LAYERS 16
 
 #define RLPPO_OK 0
@@ -158,6 +161,12 @@ int rlppo_gae(void *stream, const float *rews, const float *dones, const float *
 
 size_t rlppo_minibatch_workspace_bytes(const int32_t *pol_dims, int32_t pol_layers, const int32_t *val_dims,
                                        int32_t val_layers, int64_t mb);
+#define RLPPO_PRECISION_DEFAULT 0
+#define RLPPO_PRECISION_FP32 1
+#define RLPPO_PRECISION_BF16 2
+#define RLPPO_PRECISION_X3 3
+size_t rlppo_minibatch_workspace_bytes_for(const int32_t *pol_dims, int32_t pol_layers, const int32_t *val_dims, int32_t val_layers,
+                                           int64_t mb, int32_t precision);
 
 typedef struct rlppo_minibatch_args {
     int32_t head;                 /* RLPPO_HEAD_* */
@@ -166,6 +175,10 @@ typedef struct rlppo_minibatch_args {
     int32_t act_dim;              /* floats per action row in `actions` (1, 8, k) */
     int32_t slot;                 /* 0..RLPPO_MAX_SLOTS-1: minibatches given different slots (and different workspaces) may run
                                      concurrently on library-owned streams; rlppo_ppo_join() makes `stream` wait for all of them */
+    int32_t precision;            /* [r5] update precision of THIS call: RLPPO_PRECISION_DEFAULT (0: what rlppo_set_update_precision
+                                     chose for the process) or 1 + mode (RLPPO_PRECISION_FP32 / _BF16 / _X3): two learners of one
+                                     process may train in different precisions; size the workspace with
+                                     rlppo_minibatch_workspace_bytes_for(..., precision) */
     const int32_t *pol_dims;      /* HOST */
     const int32_t *val_dims;      /* HOST */
     const float *pol_packed;
@@ -412,14 +425,18 @@ int rlppo_dbg_gemm_nt_x3(void *stream, const float *A, int64_t lda, const void *
  *     XCD) [1 (default) | 0 = the second product stacked behind the first]
  *  34 rlppo_clip_adam_pack2 grid-barrier spin limit [-1 = default 2^22 | 0 = a waiter gives up at once (tests)]
  *  35 rlppo_clip_adam_pack2 test hook [0 | 1 = workgroup (0, 0) never arrives at the barrier: a grid that is not co-resident]
- *  36 split-bf16 products (update precision 2) [1 = persistent workgroups for large launches (default) | 0 = one workgroup per tile] */
+ *  36 split-bf16 products (update precision 2) [1 = persistent workgroups for large launches (default) | 0 = one workgroup per tile]
+ *  37 [r5] the weight-gradient products of a pass [1 = ONE grouped launch + ONE reduction after the chains have joined (default; fp32 and
+ *     split-bf16 precisions) | 0 = one launch + reduction per layer inside the chains]
+ *  38 [r5] workgroups of a grouped weight-gradient launch [0 = two per CU (default) | n] */
 int rlppo_dbg_set(int32_t key, int32_t value);
 /* Counter bumped by every call that changes which kernels later launches select (rlppo_dbg_set, rlppo_set_*_precision): a
  * host that caches captured graphs of library calls keys them on it (rlgym_ppo_amd/ppo/_mlp.py::ActGraph). */
 int64_t rlppo_selection_epoch(void);
 /* Which form calls took so far in this process (tests assert that the kernel they mean to pin is the one that ran): 0 = rollout steps
  * served by the one-launch kernel (rlppo_discrete_act / rlppo_discrete_step), 1 = by the layer chain, 2 = rlppo_ppo_minibatch passes,
- * 3 = of them with paired policy + critic launches, 4 = of them with the gather fused into the first layer; -1 for an unknown key. */
+ * 3 = of them with paired policy + critic launches, 4 = of them with the gather fused into the first layer, 5 = of them with the
+ * grouped weight-gradient launch; -1 for an unknown key. */
 int64_t rlppo_dbg_counter(int32_t key);
 /* Single-kernel entry points used by tests/ and bench.py to check / time each GEMM flavour in isolation.
  * epilogue: 0 bias, 1 bias+relu, 2 bias+tanh, 3 relu-mask (mask_src > 0).  Shapes as in csrc/gemm.hip. */
@@ -457,6 +474,27 @@ size_t rlppo_dbg_gemm_tn_workspace_bytes(int32_t out, int32_t in, int64_t M);
 int rlppo_dbg_gemm_tn(void *stream, const float *dY, int64_t ldy, int32_t ny_valid, const float *X, int64_t ldx,
                       int32_t kx_valid, float *dW, float *db, int32_t out, int32_t in, int64_t M, void *ws, size_t ws_bytes);
 
+/* [r5] Every weight-gradient product of a pass as ONE launch + ONE fixed-order reduction (the form rlppo_ppo_minibatch uses from
+ * round 5 on, rlppo_dbg_set(37)): product i is dW_i[out][in] += dY_i^T . X_i, db_i[out] += colsum(dY_i) over the same M rows (db may be
+ * NULL); rowtab != NULL: sample m of product i is X_i[rowtab[m]] of a src_rows-row matrix (the fused minibatch gather of
+ * experience_buffer.py:82-87).  The row splits of each product are sized so that every workgroup of the grid multiplies the same
+ * number of MFMA blocks; the result depends on the SET of shapes and M, not on the order of the products. */
+typedef struct rlppo_tn_product {
+    const float *dY;
+    int64_t ldy;
+    int32_t ny_valid;
+    const float *X;
+    int64_t ldx;
+    int32_t kx_valid;
+    float *dW, *db;
+    int32_t out, in;
+    const uint32_t *rowtab;
+    int64_t src_rows;
+} rlppo_tn_product;
+size_t rlppo_dbg_gemm_tn_group_workspace_bytes(const rlppo_tn_product *p, int32_t n, int64_t M);
+int rlppo_dbg_gemm_tn_group(void *stream, const rlppo_tn_product *p, int32_t n, int64_t M, void *ws, size_t ws_bytes);
+
+#pragma GCC visibility pop
 #ifdef __cplusplus
 }
 #endif

@@ -11,6 +11,9 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* The export table: the library is built with -fvisibility=hidden, and exactly the functions declared between this push and
+ * the matching pop have default visibility (`nm -D` shows them and nothing else of the library's own; tests/test_abi_and_layout.py). */
+#pragma GCC visibility push(default)
 const char *rlppo_diag_last_error(void);
 /* Register-only fp32 MFMA loop: out[blocks*256] floats, clocks[2*blocks] = {shader cycles, 100 MHz ticks} per block. */
 int rlppo_dbg_mfma_probe(void *stream, float *out, int32_t blocks, int32_t iters, uint64_t *clocks);
@@ -39,6 +42,7 @@ int rlppo_dbg_stream_floor(void *stream, const float *r, const float *d, const f
  * to see what each costs / buys).  store = 0 drops the output stores (K loop alone).  M % 256 == 0, K % 32 == 0. */
 int rlppo_dbg_gemm_nt_split(void *stream, const float *A, int64_t lda, const void *w_split, const float *bias, float *C, int64_t ldc, int64_t M,
                             int32_t N, int32_t K, int32_t terms, int32_t store);
+#pragma GCC visibility pop
 #ifdef __cplusplus
 }
 #endif

@@ -11,7 +11,7 @@ from ctypes import POINTER, c_char_p, c_double, c_float, c_int32, c_int64, c_siz
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("RLPPO_LIB") or os.path.join(HERE, "librlppo.so")  # RLPPO_LIB: an alternative build (A/B of compile-time variants)
-ABI_VERSION = 4
+ABI_VERSION = 5
 COMM_ID_BYTES = 128  # RLPPO_COMM_ID_BYTES
 MAX_LAYERS = 16
 N_STATS = 8
@@ -22,6 +22,7 @@ MAX_SLOTS = 8
 STAT_ENTROPY, STAT_KL, STAT_VLOSS, STAT_CLIPFRAC, STAT_PLOSS = 0, 1, 2, 3, 4
 STAT_PASSES = 7  # host-side: passes of rlppo_ppo_minibatch behind the sums above (summed over ranks with them)
 HEAD_DISCRETE, HEAD_MULTIDISCRETE, HEAD_GAUSSIAN = 0, 1, 2
+PRECISION_DEFAULT, PRECISION_FP32, PRECISION_BF16, PRECISION_X3 = 0, 1, 2, 3  # rlppo_minibatch_args.precision (1 + mode)
 
 
 class NativeLibraryMissing(RuntimeError):
@@ -39,10 +40,18 @@ class OptNet(ctypes.Structure):
     ]
 
 
+class TnProduct(ctypes.Structure):
+    """struct rlppo_tn_product (include/rlppo.h)."""
+    _fields_ = [
+        ("dY", c_void_p), ("ldy", c_int64), ("ny_valid", c_int32), ("X", c_void_p), ("ldx", c_int64), ("kx_valid", c_int32),
+        ("dW", c_void_p), ("db", c_void_p), ("out", c_int32), ("in_", c_int32), ("rowtab", c_void_p), ("src_rows", c_int64),
+    ]
+
+
 class MinibatchArgs(ctypes.Structure):
     """struct rlppo_minibatch_args (include/rlppo.h)."""
     _fields_ = [
-        ("head", c_int32), ("pol_layers", c_int32), ("val_layers", c_int32), ("act_dim", c_int32), ("slot", c_int32),
+        ("head", c_int32), ("pol_layers", c_int32), ("val_layers", c_int32), ("act_dim", c_int32), ("slot", c_int32), ("precision", c_int32),
         ("pol_dims", POINTER(c_int32)), ("val_dims", POINTER(c_int32)),
         ("pol_packed", c_void_p), ("val_packed", c_void_p),
         ("pol_packed_r", c_void_p), ("val_packed_r", c_void_p), ("pol_wb16", c_void_p), ("val_wb16", c_void_p), ("pol_grad", c_void_p), ("val_grad", c_void_p),
@@ -87,6 +96,7 @@ SIGNATURES = {
     "rlppo_gae": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_double, c_double, c_float,
                             c_void_p, c_void_p, c_void_p, c_void_p, c_size_t]),
     "rlppo_minibatch_workspace_bytes": (c_size_t, [_P32, c_int32, _P32, c_int32, c_int64]),
+    "rlppo_minibatch_workspace_bytes_for": (c_size_t, [_P32, c_int32, _P32, c_int32, c_int64, c_int32]),
     "rlppo_ppo_minibatch": (c_int32, [c_void_p, POINTER(MinibatchArgs)]),
     "rlppo_ppo_join": (c_int32, [c_void_p]),
     "rlppo_clip_adam": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_double, c_double,
@@ -135,6 +145,8 @@ SIGNATURES = {
     "rlppo_dbg_thin_head_workspace_bytes": (c_size_t, [c_int32, c_int32, c_int64]),
     "rlppo_dbg_thin_head_b16": (c_int32, [c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p,
                                           c_void_p, c_void_p, c_int32, c_int32, c_int64, c_void_p, c_size_t]),
+    "rlppo_dbg_gemm_tn_group_workspace_bytes": (c_size_t, [POINTER(TnProduct), c_int32, c_int64]),
+    "rlppo_dbg_gemm_tn_group": (c_int32, [c_void_p, POINTER(TnProduct), c_int32, c_int64, c_void_p, c_size_t]),
     "rlppo_dbg_gemm_tn_workspace_bytes": (c_size_t, [c_int32, c_int32, c_int64]),
     "rlppo_dbg_gemm_tn": (c_int32, [c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_int64, c_int32, c_void_p, c_void_p,
                                     c_int32, c_int32, c_int64, c_void_p, c_size_t]),

@@ -266,7 +266,7 @@ using namespace rlppo;
 
 static int g_fused_act = 1;  // rlppo_dbg_set(27, 0/1): rlppo_discrete_act as one fused launch (fused_act.hip)
 // rlppo_dbg_counter: which form a call took (tests assert that the kernel they mean to pin is the one that ran)
-static std::atomic<long long> g_cnt_fused_act{0}, g_cnt_act_chain{0}, g_cnt_paired_pass{0}, g_cnt_gather_fused_pass{0}, g_cnt_pass{0};
+static std::atomic<long long> g_cnt_fused_act{0}, g_cnt_act_chain{0}, g_cnt_paired_pass{0}, g_cnt_gather_fused_pass{0}, g_cnt_pass{0}, g_cnt_group_dw{0};
 // One workgroup per 16 rows and one workgroup per CU (102 KiB of LDS): a launch is rounds of 4096 rows at ~25 us each, whatever
 // the round's fill.  Measured (tools/act_kernel_time.py): 64 rows 26 us (chain 70), 4096 rows 29 us (chain 75), 16,384 rows 100 us
 // (chain 86): beyond two rounds the layer-by-layer GEMMs, which fill the chip, win.
@@ -539,13 +539,13 @@ static int order_after(hipStream_t to, hipStream_t from, hipEvent_t ev) {
 }
 
 // partial-tile workspace of one weight-gradient launch of a net
-static size_t tn_layer_floats(const NetLayout &net, int l, int64_t mb) {
+static size_t tn_layer_floats(const NetLayout &net, int l, int64_t mb, int prec) {
     size_t f = tn_partial_floats(net.L[l].out, net.L[l].in, mb);
     if (net.L[l].out == 1) {  // one-output head: block partials of gemv_dw_kernel (64 rows per block)
         const size_t g = (size_t)cdiv(mb, 64) * (size_t)(net.L[l].pin + 4);  // upper bound: at least 64 rows per block
         if (g > f) f = g;
     }
-    if (g_update_bf16 == 1 && l == net.n_layers - 1) {  // narrow head of the bf16 precision: per-lane partials of thin_dw_b16
+    if (prec == 1 && l == net.n_layers - 1) {  // narrow head of the bf16 precision: per-lane partials of thin_dw_b16
         const size_t g = thin_dw_ws_floats(net.L[l].out, net.L[l].pin, mb);
         if (g > f) f = g;
     }
@@ -556,16 +556,43 @@ static size_t tn_layer_floats(const NetLayout &net, int l, int64_t mb) {
 // a reduction depends on its dW launch only and nothing waits for it before the optimiser step.  The GPU is throughput-bound
 // with two chains in flight, so taking them out of the chain saved nothing and their HBM / atomic traffic beside the same
 // chain's GEMMs cost 0.6 ms per 10-epoch learn() at one rank and 0.5 ms at the 8-rank share: profiles/r03_ab_update_side_streams.txt.)
-static size_t tn_ws_floats(const NetLayout &net, int64_t mb) {
+static size_t tn_ws_floats(const NetLayout &net, int64_t mb, int prec) {
     size_t m = 0;
     for (int l = 0; l < net.n_layers; ++l) {
-        const size_t f = tn_layer_floats(net, l, mb);
+        const size_t f = tn_layer_floats(net, l, mb, prec);
         m = f > m ? f : m;
     }
     return m;
 }
+// [r5] grouped weight gradients (gemm.hip: launch_gemm_tn_group): every dW / db product of a pass that is a GEMM (all layers of both
+// networks but a one-output head, which is a matrix-vector kernel) is collected while the chains run their forward / dX launches and
+// launched ONCE, after the chains have joined.  The group's partial tiles live in the two chains' partial buffers taken as one region.
+static int g_group_dw = 1;  // rlppo_dbg_set(37, 0/1)
+struct DwList {
+    TnProduct p[2 * RLPPO_MAX_LAYERS];
+    int n = 0;
+    void add(const float *dY, int64_t ldy, int ny, const float *X, int64_t ldx, int kx, float *dW, float *db, int out, int in,
+             const unsigned *rowtab = nullptr, int64_t src_rows = 0) {
+        TnProduct &q = p[n++];
+        q.dY = dY; q.ldy = ldy; q.ny_valid = ny; q.X = X; q.ldx = ldx; q.kx_valid = kx; q.dW = dW; q.db = db; q.out = out; q.in = in;
+        q.rowtab = rowtab; q.src_rows = src_rows;
+    }
+};
+static bool dw_is_gemv(const NetLayout &net, int l) { return l == net.n_layers - 1 && l > 0 && gemv_head_ok(net.L[l].out, net.L[l].pin); }
+static size_t tn_region_floats(const NetLayout &pol, const NetLayout &val, int64_t mb, int prec) {
+    const size_t chains = tn_ws_floats(pol, mb, prec) + tn_ws_floats(val, mb, prec);
+    int outs[2 * RLPPO_MAX_LAYERS], ins[2 * RLPPO_MAX_LAYERS], n = 0;
+    for (const NetLayout *net : {&pol, &val})
+        for (int l = 0; l < net->n_layers; ++l)
+            if (!dw_is_gemv(*net, l)) {
+                outs[n] = net->L[l].out;
+                ins[n++] = net->L[l].in;
+            }
+    const size_t group = tn_group_floats(outs, ins, n, mb);
+    return chains > group ? chains : group;
+}
 
-static size_t train_ws_floats(const NetLayout &pol, const NetLayout &val, int64_t mb) {
+static size_t train_ws_floats(const NetLayout &pol, const NetLayout &val, int64_t mb, int prec) {
     size_t per_row = 0;
     for (int l = 0; l < pol.n_layers; ++l) per_row += pol.L[l].pout;
     for (int l = 0; l < val.n_layers; ++l) per_row += val.L[l].pout;
@@ -578,20 +605,31 @@ static size_t train_ws_floats(const NetLayout &pol, const NetLayout &val, int64_
     for (int l = 0; l + 1 < pol.n_layers; ++l) bits += nt_bits_floats(mb, pol.L[l].pout);
     for (int l = 0; l + 1 < val.n_layers; ++l) bits += nt_bits_floats(mb, val.L[l].pout);
     size_t b16 = 0;  // bf16 update precision: the gathered states, every hidden activation and its gradient as bf16 (2 B/element)
-    if (g_update_bf16 == 1) {
+    if (prec == 1) {
         size_t el = pol.L[0].pin;  // + per hidden layer: the activation and its gradient
         for (int l = 0; l + 1 < pol.n_layers; ++l) el += 2 * (size_t)pol.L[l].pout;
         for (int l = 0; l + 1 < val.n_layers; ++l) el += 2 * (size_t)val.L[l].pout;
         b16 = (el * (size_t)mb + 1) / 2 + 4;
     }
-    return per_row * (size_t)mb + tn_ws_floats(pol, mb) + tn_ws_floats(val, mb) + bits + b16 + 2;  // + one partial-tile buffer per chain
+    return per_row * (size_t)mb + tn_region_floats(pol, val, mb, prec) + bits + b16 + 2;  // + one partial-tile buffer per chain (one region for the grouped launch)
 }
 
+// update precision of a call: RLPPO_PRECISION_DEFAULT = what rlppo_set_update_precision chose for the process, else 1 + mode
+static int resolve_precision(int32_t precision, int *mode) {
+    RLPPO_CHECK_ARG(precision >= 0 && precision <= 3, "update precision %d (0 = process default, 1 = fp32, 2 = bf16 mixed precision, 3 = split-bf16 products)", precision);
+    *mode = precision == RLPPO_PRECISION_DEFAULT ? g_update_bf16 : precision - 1;
+    return 0;
+}
+size_t rlppo_minibatch_workspace_bytes_for(const int32_t *pol_dims, int32_t pol_layers, const int32_t *val_dims, int32_t val_layers,
+                                           int64_t mb, int32_t precision) {
+    NetLayout pol, val;
+    int prec = 0;
+    if (make_layout(pol_dims, pol_layers, &pol) || make_layout(val_dims, val_layers, &val) || resolve_precision(precision, &prec)) return 0;
+    return train_ws_floats(pol, val, mb > 0 ? mb : 0, prec) * sizeof(float) + 256;
+}
 size_t rlppo_minibatch_workspace_bytes(const int32_t *pol_dims, int32_t pol_layers, const int32_t *val_dims,
                                        int32_t val_layers, int64_t mb) {
-    NetLayout pol, val;
-    if (make_layout(pol_dims, pol_layers, &pol) || make_layout(val_dims, val_layers, &val)) return 0;
-    return train_ws_floats(pol, val, mb > 0 ? mb : 0) * sizeof(float) + 256;
+    return rlppo_minibatch_workspace_bytes_for(pol_dims, pol_layers, val_dims, val_layers, mb, RLPPO_PRECISION_DEFAULT);
 }
 
 // How a chain's first layer finds its rows [r3].
@@ -606,7 +644,7 @@ struct ChainCtx {
 static int backward(hipStream_t st, const NetLayout &net, const float *packed, const float *states, int64_t ld_states,
                     int64_t mb, float *const *acts, float *const *dx, float *grad, float *tn_ws,
                     unsigned long long *const *bits, const bool *have_bits, const ChainCtx &cx, bool head_folded = false,
-                    const unsigned short *x3 = nullptr) {
+                    const unsigned short *x3 = nullptr, DwList *defer = nullptr) {
     const int last = net.n_layers - 1;
     int rc = 0;
     X3Layout xl;
@@ -618,9 +656,13 @@ static int backward(hipStream_t st, const NetLayout &net, const float *packed, c
         const float *X = l > 0 ? acts[l - 1] : states;
         const int64_t ldx = l > 0 ? net.L[l - 1].pout : ld_states;
         const bool gemv = l == last && l > 0 && gemv_head_ok(L.out, L.pin);  // one-output head (gemv.hip)
-        const size_t floats = tn_layer_floats(net, l, mb);
+        const size_t floats = tn_layer_floats(net, l, mb, 0);  // (fp32 / split-bf16 precisions: the bf16 one has backward_b16)
         if (gemv)
             rc = launch_gemv_dw(st, dY, ld_hy, X, ldx, grad + L.off_flat_w, grad + L.off_flat_b, L.in, L.pin, mb, tn_ws, floats);
+        else if (defer && l == 0 && cx.rowtab)  // [r5] collected: launched with every other product of the pass once the chains have joined
+            defer->add(dY, L.pout, L.pout, cx.src, cx.ld_src, L.pin, grad + L.off_flat_w, grad + L.off_flat_b, L.out, L.in, cx.rowtab, cx.src_rows);
+        else if (defer)
+            defer->add(dY, L.pout, L.pout, X, ldx, L.pin, grad + L.off_flat_w, grad + L.off_flat_b, L.out, L.in);
         else if (l == 0 && cx.rowtab)
             rc = launch_gemm_tn(st, dY, L.pout, L.pout, cx.src, cx.ld_src, L.pin, grad + L.off_flat_w, grad + L.off_flat_b, L.out, L.in,
                                 mb, tn_ws, floats, cx.rowtab, cx.src_rows);
@@ -791,15 +833,18 @@ static int head_forward(hipStream_t st, const NetLayout &net, const float *packe
 }
 // ... and backward: dW / db of the output layer and dX into dx_prev, masked by the last hidden layer's bitmask (backward()'s first iteration)
 static int head_backward(hipStream_t st, const NetLayout &net, const float *packed, const float *dY, const float *X, int64_t mb,
-                         float *dx_prev, float *grad, float *tn_ws, const unsigned long long *bits_prev, int64_t ld_dy = 0) {
+                         float *dx_prev, float *grad, float *tn_ws, const unsigned long long *bits_prev, int64_t ld_dy = 0,
+                         DwList *defer = nullptr) {
     const int last = net.n_layers - 1;
     const LayerLayout &L = net.L[last];
     const int64_t ldx = net.L[last - 1].pout;
     const bool gemv = gemv_head_ok(L.out, L.pin);
-    const size_t floats = tn_layer_floats(net, last, mb);
+    const size_t floats = tn_layer_floats(net, last, mb, 0);
     if (!ld_dy) ld_dy = L.pout;  // (a one-output head folded into the last hidden layer's epilogue keeps its outputs compact: 1)
-    int rc = gemv ? launch_gemv_dw(st, dY, ld_dy, X, ldx, grad + L.off_flat_w, grad + L.off_flat_b, L.in, L.pin, mb, tn_ws, floats)
-                  : launch_gemm_tn(st, dY, L.pout, L.pout, X, ldx, L.pin, grad + L.off_flat_w, grad + L.off_flat_b, L.out, L.in, mb, tn_ws, floats);
+    int rc = 0;
+    if (gemv) rc = launch_gemv_dw(st, dY, ld_dy, X, ldx, grad + L.off_flat_w, grad + L.off_flat_b, L.in, L.pin, mb, tn_ws, floats);
+    else if (defer) defer->add(dY, L.pout, L.pout, X, ldx, L.pin, grad + L.off_flat_w, grad + L.off_flat_b, L.out, L.in);
+    else rc = launch_gemm_tn(st, dY, L.pout, L.pout, X, ldx, L.pin, grad + L.off_flat_w, grad + L.off_flat_b, L.out, L.in, mb, tn_ws, floats);
     if (rc) return rc;
     if (gemv) return launch_gemv_dx_bits(st, dY, ld_dy, packed + L.off_w, bits_prev, dx_prev, L.pin, L.pin, mb);
     rc = launch_gemm_nt_bits(st, dY, L.pout, packed + L.off_wt, L.pout, nullptr, dx_prev, L.pin, mb, L.pin, L.pout, EPI_MASK,
@@ -820,6 +865,9 @@ int rlppo_ppo_minibatch(void *stream, const rlppo_minibatch_args *a) {
     if (rc) return rc;
     const int64_t mb = a->mb;
     if (mb == 0) return 0;
+    int prec = 0;  // [r5] the precision is an argument of the call (two learners of one process may differ); the process-wide switch is its default
+    rc = resolve_precision(a->precision, &prec);
+    if (rc) return rc;
     RLPPO_CHECK_ARG(mb > 0 && a->pol_packed && a->val_packed && a->pol_grad && a->val_grad && a->states && a->actions &&
                         a->old_logp && a->targets && a->advantages && a->idx && a->stats && a->workspace,
                     "ppo_minibatch: null pointer");
@@ -827,8 +875,8 @@ int rlppo_ppo_minibatch(void *stream, const rlppo_minibatch_args *a) {
     RLPPO_CHECK_ARG(pol.L[0].in == val.L[0].in, "ppo_minibatch: policy and critic observe different sizes");
     RLPPO_CHECK_ARG(a->ld_states >= pol.L[0].pin && a->ld_states % 4 == 0, "ppo_minibatch: ld_states=%ld < %d",
                     (long)a->ld_states, pol.L[0].pin);
-    if (a->ws_bytes < train_ws_floats(pol, val, mb) * sizeof(float)) {
-        set_error("ppo_minibatch: workspace %zu < %zu bytes", a->ws_bytes, train_ws_floats(pol, val, mb) * sizeof(float));
+    if (a->ws_bytes < train_ws_floats(pol, val, mb, prec) * sizeof(float)) {
+        set_error("ppo_minibatch: workspace %zu < %zu bytes", a->ws_bytes, train_ws_floats(pol, val, mb, prec) * sizeof(float));
         return RLPPO_ERR_WORKSPACE;
     }
     const int n_out = pol.L[pol.n_layers - 1].out;
@@ -879,10 +927,12 @@ int rlppo_ppo_minibatch(void *stream, const rlppo_minibatch_args *a) {
         w += (size_t)mb * m;
     }
 
-    float *pol_tn_ws = w;  // partial dW tiles, one buffer per chain
-    w += tn_ws_floats(pol, mb);
-    float *val_tn_ws = w;
-    w += tn_ws_floats(val, mb);
+    float *pol_tn_ws = w;  // partial dW tiles, one buffer per chain; the grouped launch takes the whole region
+    float *val_tn_ws = w + tn_ws_floats(pol, mb, prec);
+    const size_t tn_region = tn_region_floats(pol, val, mb, prec);
+    w += tn_region;
+    DwList dws;
+    DwList *defer = (g_group_dw && prec != 1) ? &dws : nullptr;
     // ReLU bitmasks of the hidden layers, 8-byte aligned (the workspace base is 256-byte aligned by contract of the host)
     if ((reinterpret_cast<uintptr_t>(w) & 7) != 0) ++w;
     unsigned long long *pbits[RLPPO_MAX_LAYERS] = {}, *vbits[RLPPO_MAX_LAYERS] = {};
@@ -907,8 +957,8 @@ int rlppo_ppo_minibatch(void *stream, const rlppo_minibatch_args *a) {
     unsigned *const rowtab = reinterpret_cast<unsigned *>(w);  // physical buffer row of every row of the pass (gather_meta_kernel)
     w += (size_t)mb;
     // bf16 update precision: bf16 copies of the gathered rows and of the hidden activations, and the rounded weight images
-    const bool b16 = g_update_bf16 == 1;
-    const bool x3 = g_update_bf16 == 2;  // [r4] split-bf16 hidden forward / dX (csrc/gemm_split.hip); everything else as fp32
+    const bool b16 = prec == 1;
+    const bool x3 = prec == 2;  // [r4] split-bf16 hidden forward / dX (csrc/gemm_split.hip); everything else as fp32
     unsigned short *states_b = nullptr, *pactb[RLPPO_MAX_LAYERS] = {}, *vactb[RLPPO_MAX_LAYERS] = {};
     unsigned short *pdxb[RLPPO_MAX_LAYERS] = {}, *vdxb[RLPPO_MAX_LAYERS] = {};
     if (b16) {
@@ -1046,7 +1096,7 @@ int rlppo_ppo_minibatch(void *stream, const rlppo_minibatch_args *a) {
         // GEMM, the critic's output-layer backward only after the policy's loss, beside the policy head's dW / dX GEMMs.
         const bool ordered = g_head_order && hs != st;
         if (!ordered) {
-            rc = head_backward(hs, val, val_w, vout, xv, mb, vdx[H - 1], a->val_grad, val_tn_ws, vbits[H - 1], ldv);
+            rc = head_backward(hs, val, val_w, vout, xv, mb, vdx[H - 1], a->val_grad, val_tn_ws, vbits[H - 1], ldv, defer);
             if (rc) return rc;
         }
         rc = head_forward(st, pol, pol_w, xp, ldx, mb, a->head == RLPPO_HEAD_GAUSSIAN, pout);
@@ -1065,10 +1115,10 @@ int rlppo_ppo_minibatch(void *stream, const rlppo_minibatch_args *a) {
         if (ordered) {
             rc = order_after(hs, st, bk.ev_mid[slot]);
             if (rc) return rc;
-            rc = head_backward(hs, val, val_w, vout, xv, mb, vdx[H - 1], a->val_grad, val_tn_ws, vbits[H - 1], ldv);
+            rc = head_backward(hs, val, val_w, vout, xv, mb, vdx[H - 1], a->val_grad, val_tn_ws, vbits[H - 1], ldv, defer);
             if (rc) return rc;
         }
-        rc = head_backward(st, pol, pol_w, pout, xp, mb, pdx[H - 1], a->pol_grad, pol_tn_ws, pbits[H - 1]);
+        rc = head_backward(st, pol, pol_w, pout, xp, mb, pdx[H - 1], a->pol_grad, pol_tn_ws, pbits[H - 1], 0, defer);
         if (rc) return rc;
         if (hs != st) {
             rc = order_after(st, hs, bk.ev_join[slot]);
@@ -1086,8 +1136,14 @@ int rlppo_ppo_minibatch(void *stream, const rlppo_minibatch_args *a) {
             pr.dW = a->val_grad + Lv.off_flat_w;
             pr.db = a->val_grad + Lv.off_flat_b;
             pr.ws = val_tn_ws;
-            rc = launch_gemm_tn(st, pdx[l], Lp.pout, Lp.pout, Xp, ldxb, Lp.pin, a->pol_grad + Lp.off_flat_w, a->pol_grad + Lp.off_flat_b,
-                                Lp.out, Lp.in, mb, pol_tn_ws, tn_layer_floats(pol, l, mb), g0 ? rowtab : nullptr, src_rows, &pr);
+            if (defer) {
+                defer->add(pdx[l], Lp.pout, Lp.pout, Xp, ldxb, Lp.pin, a->pol_grad + Lp.off_flat_w, a->pol_grad + Lp.off_flat_b, Lp.out, Lp.in,
+                           g0 ? rowtab : nullptr, g0 ? src_rows : 0);
+                defer->add(vdx[l], Lv.pout, Lv.pout, Xv, ldxb, Lv.pin, a->val_grad + Lv.off_flat_w, a->val_grad + Lv.off_flat_b, Lv.out, Lv.in,
+                           g0 ? rowtab : nullptr, g0 ? src_rows : 0);
+            } else
+                rc = launch_gemm_tn(st, pdx[l], Lp.pout, Lp.pout, Xp, ldxb, Lp.pin, a->pol_grad + Lp.off_flat_w, a->pol_grad + Lp.off_flat_b,
+                                    Lp.out, Lp.in, mb, pol_tn_ws, tn_layer_floats(pol, l, mb, 0), g0 ? rowtab : nullptr, src_rows, &pr);
             if (rc) return rc;
             if (l == 0) break;
             NtAlt alt;
@@ -1098,6 +1154,10 @@ int rlppo_ppo_minibatch(void *stream, const rlppo_minibatch_args *a) {
             rc = launch_gemm_nt_bits(st, pdx[l], Lp.pout, pol_w + Lp.off_wt, Lp.pout, nullptr, pdx[l - 1], Lp.pin, mb, Lp.pin, Lp.pout,
                                      EPI_MASK, pbits[l - 1], nullptr, 0, &alt);
             if (rc) return rc == -1 ? RLPPO_ERR_ARG : rc;
+        }
+        if (defer && dws.n) {
+            ++g_cnt_group_dw;
+            return launch_gemm_tn_group(st, dws.p, dws.n, mb, pol_tn_ws, tn_region);
         }
         return 0;
     }
@@ -1150,10 +1210,10 @@ int rlppo_ppo_minibatch(void *stream, const rlppo_minibatch_args *a) {
 
     if (b16) {
         rc = backward_b16(side, val, val_w, reinterpret_cast<const unsigned short *>(a->val_wb16), states, states_b, ld_states, mb, vact,
-                          vactb, vdx, vdxb, a->val_grad, val_tn_ws, tn_ws_floats(val, mb), vbits, vhave, vf32);
+                          vactb, vdx, vdxb, a->val_grad, val_tn_ws, tn_ws_floats(val, mb, prec), vbits, vhave, vf32);
         if (rc) return rc;
         rc = backward_b16(st, pol, pol_w, reinterpret_cast<const unsigned short *>(a->pol_wb16), states, states_b, ld_states, mb, pact,
-                          pactb, pdx, pdxb, a->pol_grad, pol_tn_ws, tn_ws_floats(pol, mb), pbits, phave, pf32);
+                          pactb, pdx, pdxb, a->pol_grad, pol_tn_ws, tn_ws_floats(pol, mb, prec), pbits, phave, pf32);
     } else {
         ChainCtx cp, cv;
         if (fused_gather) {
@@ -1162,12 +1222,17 @@ int rlppo_ppo_minibatch(void *stream, const rlppo_minibatch_args *a) {
             cp.ld_src = cv.ld_src = a->ld_states;
             cp.src_rows = cv.src_rows = src_rows;
         }
-        rc = backward(side, val, val_w, states, ld_states, mb, vact, vdx, a->val_grad, val_tn_ws, vbits, vhave, cv, v_folded, val_x3);
+        rc = backward(side, val, val_w, states, ld_states, mb, vact, vdx, a->val_grad, val_tn_ws, vbits, vhave, cv, v_folded, val_x3, defer);
         if (rc) return rc;
-        rc = backward(st, pol, pol_w, states, ld_states, mb, pact, pdx, a->pol_grad, pol_tn_ws, pbits, phave, cp, false, pol_x3);
+        rc = backward(st, pol, pol_w, states, ld_states, mb, pact, pdx, a->pol_grad, pol_tn_ws, pbits, phave, cp, false, pol_x3, defer);
     }
     if (rc) return rc;
     if (side != st) rc = order_after(st, side, bk.ev_join[slot]);
+    if (rc) return rc;
+    if (defer && dws.n) {  // [r5] every GEMM-shaped weight gradient of the pass: one launch + one reduction, after the chains have joined
+        ++g_cnt_group_dw;
+        rc = launch_gemm_tn_group(st, dws.p, dws.n, mb, pol_tn_ws, tn_region);
+    }
     return rc;
 }
 
@@ -1332,6 +1397,8 @@ int rlppo_dbg_set(int32_t key, int32_t value) {
         case 31: g_head_order = value; return 0;
         case 32: g_fold_vhead = value; return 0;
         case 33: set_pair_interleave(value); return 0;
+        case 37: g_group_dw = value; return 0;
+        case 38: set_tn_group_budget(value); return 0;
         default: break;
     }
     set_error("dbg_set: unknown key %d", key);
@@ -1345,6 +1412,7 @@ int64_t rlppo_dbg_counter(int32_t key) {
         case 2: return g_cnt_pass;
         case 3: return g_cnt_paired_pass;
         case 4: return g_cnt_gather_fused_pass;
+        case 5: return g_cnt_group_dw;
         default: return -1;
     }
 }
@@ -1387,6 +1455,30 @@ int rlppo_dbg_thin_head_b16(void *stream, const float *dY, int64_t ldy, int32_t 
     rc = launch_thin_dw_b16((hipStream_t)stream, dY, ldy, reinterpret_cast<const unsigned short *>(hb), ldh, dW, db, out, in, kp, M,
                             (float *)ws, ws_bytes / sizeof(float));
     return rc == -1 ? RLPPO_ERR_ARG : rc;
+}
+static int tn_products(const rlppo_tn_product *p, int32_t n, TnProduct *q) {
+    RLPPO_CHECK_ARG(p && n > 0 && n <= 2 * RLPPO_MAX_LAYERS, "gemm_tn_group: %d products (1..%d)", n, 2 * RLPPO_MAX_LAYERS);
+    for (int i = 0; i < n; ++i) {
+        q[i].dY = p[i].dY; q[i].ldy = p[i].ldy; q[i].ny_valid = p[i].ny_valid; q[i].X = p[i].X; q[i].ldx = p[i].ldx;
+        q[i].kx_valid = p[i].kx_valid; q[i].dW = p[i].dW; q[i].db = p[i].db; q[i].out = p[i].out; q[i].in = p[i].in;
+        q[i].rowtab = p[i].rowtab; q[i].src_rows = p[i].src_rows;
+    }
+    return 0;
+}
+size_t rlppo_dbg_gemm_tn_group_workspace_bytes(const rlppo_tn_product *p, int32_t n, int64_t M) {
+    if (!p || n <= 0 || n > 2 * RLPPO_MAX_LAYERS) return 0;
+    int outs[2 * RLPPO_MAX_LAYERS], ins[2 * RLPPO_MAX_LAYERS];
+    for (int i = 0; i < n; ++i) {
+        outs[i] = p[i].out;
+        ins[i] = p[i].in;
+    }
+    return tn_group_floats(outs, ins, n, M) * sizeof(float);
+}
+int rlppo_dbg_gemm_tn_group(void *stream, const rlppo_tn_product *p, int32_t n, int64_t M, void *ws, size_t ws_bytes) {
+    TnProduct q[2 * RLPPO_MAX_LAYERS];
+    const int rc = tn_products(p, n, q);
+    if (rc) return rc;
+    return launch_gemm_tn_group((hipStream_t)stream, q, n, M, (float *)ws, ws_bytes / sizeof(float));
 }
 size_t rlppo_dbg_gemm_tn_workspace_bytes(int32_t out, int32_t in, int64_t M) { return tn_partial_floats(out, in, M) * sizeof(float); }
 int rlppo_dbg_gemm_tn(void *stream, const float *dY, int64_t ldy, int32_t ny_valid, const float *X, int64_t ldx,

@@ -140,6 +140,25 @@ int launch_gemm_tn(hipStream_t st, const float *dY, int64_t ldy, int ny_valid, c
                    float *dW, float *db, int out, int in, int64_t M, float *ws, size_t ws_floats, const unsigned *rowtab = nullptr,
                    int64_t src_rows = 0, const TnPair *pair = nullptr);
 bool tn_gather_ok(int64_t ldx, int64_t src_rows);
+// [r5] ALL weight-gradient products of a pass as ONE launch + ONE reduction (the products of a backward pass feed nothing but the
+// optimiser step, so they need not run where autograd would run them): one round of two workgroups per CU whose (product, tile,
+// split) items are sized to equal MFMA work, so the partial tiles of the whole pass are what ONE per-layer launch used to write.
+struct TnProduct {
+    const float *dY = nullptr;
+    int64_t ldy = 0;
+    int ny_valid = 0;
+    const float *X = nullptr;      // [M][ldx], or the experience buffer's state matrix when rowtab != nullptr
+    int64_t ldx = 0;
+    int kx_valid = 0;
+    float *dW = nullptr, *db = nullptr;
+    int out = 0, in = 0;
+    const unsigned *rowtab = nullptr;
+    int64_t src_rows = 0;
+};
+constexpr int TN_GROUP_MAX = 2 * RLPPO_MAX_LAYERS;
+size_t tn_group_floats(const int *outs, const int *ins, int n, int64_t M);  // workspace floats of launch_gemm_tn_group for these shapes
+int launch_gemm_tn_group(hipStream_t st, const TnProduct *prods, int n, int64_t M, float *ws, size_t ws_floats);
+void set_tn_group_budget(int workgroups);  // rlppo_dbg_set(38): workgroups of a grouped launch (0 = two per CU)
 
 // gemm_b16.hip: the bf16 update precision, both operands bf16 in memory, fp32 accumulate ---------------------------------
 // (A: activations / activation gradients, B: rlppo_net_pack_bf16's W or W^T blocks)

@@ -512,39 +512,20 @@ static TnGeom tn_geometry(int out, int in) {
     return TnGeom{4, 4, 2};
 }
 
+// One (split, tile) work item of a weight-gradient product: the body shared by the per-product launch (gemm_tn_dma_kernel) and the
+// grouped launch (gemm_tn_group_kernel, all products of a pass in one grid).  `lds`: the workgroup's stage buffers (the kernels own
+// the allocation: a static array per instantiation of this body would add up).  (bx, by, bz) = (row tile of dW, column tile, split);
+// tiles_x / tiles_y / splits_z = the product's tile and split counts (they place the partial tile and the db column sums in `partial`).
+constexpr int TN_LDS_FLOATS = 2 * 2 * 32 * 128;
 template <int TMT, int NI, int NJ, int WN, bool GATHER>
-__global__ __launch_bounds__(256, 2) void gemm_tn_dma_kernel(const float *__restrict__ dY, unsigned ldy_b,
-                                                                              int ny_valid, const float *__restrict__ X,
-                                                                              unsigned ldx_b, int kx_valid,
-                                                                              bool with_db, int out, int in, int64_t M,
-                                                                              int rows_per_wg, float *__restrict__ partial,
-                                                                              const unsigned *__restrict__ rowtab,
-                                                                              unsigned src_rows, TnAlt alt) {
-    // [r3] two products of the same shape in one launch: the upper half of the z range takes (dY, X, partial) from `alt`
-    const int splits_z = alt.dY ? gridDim.z / 2 : gridDim.z;
-    int zloc = blockIdx.z;
-    bool second = alt.dY && !alt.interleave && zloc >= splits_z;
-    if (second) zloc -= splits_z;
-    // interleaved pairing (splits a multiple of 8): id -> (product, tile, split) in groups of 8 splits x 2 T tiles
-    int il_tile = -1, il_split = 0;
-    if (alt.dY && alt.interleave) {
-        const int T = gridDim.x * gridDim.y;
-        const int id = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x, g = id % (16 * T);
-        int t2 = g >> 3;
-        second = t2 >= T;
-        if (second) t2 -= T;
-        il_tile = t2;
-        il_split = (id / (16 * T)) * 8 + (g & 7);
-    }
-    if (second) {
-        dY = alt.dY;
-        if (!GATHER) X = alt.X;
-        partial = alt.partial;
-    }
+__device__ __forceinline__ void tn_tile(float *lds, const float *__restrict__ dY, unsigned ldy_b, int ny_valid,
+                                        const float *__restrict__ X, unsigned ldx_b, int kx_valid, bool with_db, int out, int64_t M,
+                                        int rows_per_wg, float *__restrict__ partial, const unsigned *__restrict__ rowtab,
+                                        unsigned src_rows, int bx, int by, int bz, int tiles_x, int tiles_y, int splits_z) {
     constexpr int WK = 4 / WN;
     constexpr int BNT = WN * NI * 16, BKX = WK * NJ * 16, TILE_F = NI * NJ * 1024;
     constexpr int PPW = TMT / 8;  // 1 KiB pieces per wave, per operand and stage
-    __shared__ __attribute__((aligned(16))) float lds[2 * 2 * TMT * 128 < 8 * 128 ? 8 * 128 : 2 * 2 * TMT * 128];
+    static_assert(2 * 2 * TMT * 128 <= TN_LDS_FLOATS && 8 * 128 <= TN_LDS_FLOATS, "stage buffers");
     float *Ys = lds;                 // [2][TMT][128]
     float *Xs = lds + 2 * TMT * 128;  // [2][TMT][128]
 
@@ -553,23 +534,6 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_dma_kernel(const float *__rest
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     const int r16 = lane & 15, q = lane >> 4;
     const int wn = wave / WK, wk = wave % WK;
-    // XCD-aware order (see xcd_tile): the output tiles of one row split read the same dY / X rows, so they are given ids
-    // that land on the same XCD back to back: id -> tile = (id % (8 T)) / 8, split = 8 (id / (8 T)) + id % 8
-    int bx = blockIdx.x, by = blockIdx.y, bz = zloc;
-    {
-        const int T = gridDim.x * gridDim.y;
-        if (il_tile >= 0) {
-            bz = il_split;
-            bx = il_tile % gridDim.x;
-            by = il_tile / gridDim.x;
-        } else if ((splits_z & 7) == 0 && T > 1) {
-            const int id = (zloc * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x, g = id % (8 * T);
-            const int tile = g >> 3;
-            bz = (id / (8 * T)) * 8 + (g & 7);
-            bx = tile % gridDim.x;
-            by = tile / gridDim.x;
-        }
-    }
     const int n0 = bx * BNT, k0 = by * BKX;
     const int64_t mbeg = (int64_t)bz * rows_per_wg;
     const int rows = (int)((M - mbeg) < rows_per_wg ? (M - mbeg) : rows_per_wg);  // >= 1
@@ -699,14 +663,14 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_dma_kernel(const float *__rest
 #pragma unroll
             for (int r = 0; r < 8; ++r) sum += red[r * 128 + tid];
             // column sums of this split: partial_db[split][n tile][128], behind the tile partials
-            partial[(size_t)splits_z * gridDim.y * gridDim.x * TILE_F + ((size_t)bz * gridDim.x + bx) * 128 + tid] = sum;
+            partial[(size_t)splits_z * tiles_y * tiles_x * TILE_F + ((size_t)bz * tiles_x + bx) * 128 + tid] = sum;
         }
     }
     // The partial-tile stores are the LAST instructions of the wave: 16-byte buffer stores whose data registers are written
     // again soon afterwards can pick up the new values (the hazard of section 5 / tests/test_gpu_stress.py); here the
     // accumulators are never touched after them.
     {
-        const size_t tile_id = (size_t)bz * (gridDim.x * gridDim.y) + (size_t)by * gridDim.x + bx;
+        const size_t tile_id = (size_t)bz * (tiles_x * tiles_y) + (size_t)by * tiles_x + bx;
         const __amdgpu_buffer_rsrc_t p_rs = make_rsrc(partial + tile_id * TILE_F, TILE_F * 4);
 #pragma unroll
         for (int i = 0; i < NI; ++i)
@@ -715,22 +679,68 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_dma_kernel(const float *__rest
     }
 }
 
+template <int TMT, int NI, int NJ, int WN, bool GATHER>
+__global__ __launch_bounds__(256, 2) void gemm_tn_dma_kernel(const float *__restrict__ dY, unsigned ldy_b,
+                                                                              int ny_valid, const float *__restrict__ X,
+                                                                              unsigned ldx_b, int kx_valid,
+                                                                              bool with_db, int out, int in, int64_t M,
+                                                                              int rows_per_wg, float *__restrict__ partial,
+                                                                              const unsigned *__restrict__ rowtab,
+                                                                              unsigned src_rows, TnAlt alt) {
+    __shared__ __attribute__((aligned(16))) float lds[TN_LDS_FLOATS];
+    // [r3] two products of the same shape in one launch: the upper half of the z range takes (dY, X, partial) from `alt`
+    const int splits_z = alt.dY ? gridDim.z / 2 : gridDim.z;
+    int zloc = blockIdx.z;
+    bool second = alt.dY && !alt.interleave && zloc >= splits_z;
+    if (second) zloc -= splits_z;
+    // interleaved pairing (splits a multiple of 8): id -> (product, tile, split) in groups of 8 splits x 2 T tiles
+    int il_tile = -1, il_split = 0;
+    if (alt.dY && alt.interleave) {
+        const int T = gridDim.x * gridDim.y;
+        const int id = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x, g = id % (16 * T);
+        int t2 = g >> 3;
+        second = t2 >= T;
+        if (second) t2 -= T;
+        il_tile = t2;
+        il_split = (id / (16 * T)) * 8 + (g & 7);
+    }
+    if (second) {
+        dY = alt.dY;
+        if (!GATHER) X = alt.X;
+        partial = alt.partial;
+    }
+    // XCD-aware order (see xcd_tile): the output tiles of one row split read the same dY / X rows, so they are given ids
+    // that land on the same XCD back to back: id -> tile = (id % (8 T)) / 8, split = 8 (id / (8 T)) + id % 8
+    int bx = blockIdx.x, by = blockIdx.y, bz = zloc;
+    {
+        const int T = gridDim.x * gridDim.y;
+        if (il_tile >= 0) {
+            bz = il_split;
+            bx = il_tile % gridDim.x;
+            by = il_tile / gridDim.x;
+        } else if ((splits_z & 7) == 0 && T > 1) {
+            const int id = (zloc * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x, g = id % (8 * T);
+            const int tile = g >> 3;
+            bz = (id / (8 * T)) * 8 + (g & 7);
+            bx = tile % gridDim.x;
+            by = tile / gridDim.x;
+        }
+    }
+    tn_tile<TMT, NI, NJ, WN, GATHER>(lds, dY, ldy_b, ny_valid, X, ldx_b, kx_valid, with_db, out, M, rows_per_wg, partial, rowtab, src_rows,
+                                     bx, by, bz, (int)gridDim.x, (int)gridDim.y, splits_z);
+}
+
+
 // Sums the partial tiles of gemm_tn_dma_kernel over the splits and adds the result into dW[out][in].
 // Block = 64 consecutive 16-byte elements of one tile x 4 split lanes (one wave each: 1 KiB coalesced per load, 8 loads
 // in flight); the four partial sums meet in LDS.  The final add is an atomic only so that launches of different
 // minibatches that share dW stay safe; there is exactly one per element and launch.  geo: the producing kernel's tile
 // geometry (a tile is geo.ni * geo.nj * 256 such elements: gridDim.x = geo.ni * geo.nj * 4 blocks per tile).
-__global__ __launch_bounds__(256) void tn_reduce_kernel(const float *__restrict__ partial, int splits, int tiles_x, int tiles,
-                                                        float *__restrict__ dW, float *__restrict__ db, int out, int in,
-                                                        TnGeom geo, TnRedAlt alt) {
-    if (blockIdx.z) {  // the second product of a paired launch
-        partial = alt.partial;
-        dW = alt.dW;
-        db = alt.db;
-    }
-    __shared__ __attribute__((aligned(16))) float red[3][64][4];
-    const int tile = blockIdx.y, e64 = threadIdx.x & 63, sl = threadIdx.x >> 6;
-    const int elem4 = blockIdx.x * 64 + e64;  // 16-byte element of the tile: (i*NJ+j)*256 + tid
+__device__ __forceinline__ void tn_reduce_tile(const float *__restrict__ partial, int splits, int tiles_x, int tiles,
+                                               float *__restrict__ dW, float *__restrict__ db, int out, int in, TnGeom geo, int tile,
+                                               int bxi, int nbx, float (*red)[64][4], float *dbh) {
+    const int e64 = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const int elem4 = bxi * 64 + e64;  // 16-byte element of the tile: (i*NJ+j)*256 + tid
     const int tile4 = geo.tile_floats() / 4;
     const f32x4 *base = reinterpret_cast<const f32x4 *>(partial) + (size_t)tile * tile4 + elem4;
     const size_t stride = (size_t)tiles * tile4;
@@ -743,13 +753,19 @@ __global__ __launch_bounds__(256) void tn_reduce_kernel(const float *__restrict_
 #pragma unroll
         for (int u = 0; u < 8; ++u) acc += v[u];
     }
+    for (; sp + 12 < splits; sp += 16) {  // (a grouped launch has ~24 splits per product: keep four loads in flight there too)
+        f32x4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = __builtin_nontemporal_load(base + (size_t)(sp + 4 * u) * stride);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc += v[u];
+    }
     for (; sp < splits; sp += 4) acc += __builtin_nontemporal_load(base + (size_t)sp * stride);
     if (sl > 0) *reinterpret_cast<f32x4 *>(&red[sl - 1][e64][0]) = acc;
     // bias gradient (one block per n tile): 128 columns x 2 halves of the splits, 16 loads in flight per thread, every
     // partial combined in a fixed order
-    __shared__ float dbh[128];
     const int bnt = geo.bnt(), bkx = geo.bkx();
-    const bool db_block = db && blockIdx.x == gridDim.x - 1 && tile < tiles_x;
+    const bool db_block = db && bxi == nbx - 1 && tile < tiles_x;
     float sdb = 0.f;
     if (db_block) {
         const int c = threadIdx.x & 127, half = threadIdx.x >> 7;
@@ -791,6 +807,19 @@ __global__ __launch_bounds__(256) void tn_reduce_kernel(const float *__restrict_
         for (int e = 0; e < 4; ++e)
             if (nb + e < out) atomicAdd(dW + (size_t)(nb + e) * in + k, acc[e]);
     }
+}
+
+__global__ __launch_bounds__(256) void tn_reduce_kernel(const float *__restrict__ partial, int splits, int tiles_x, int tiles,
+                                                        float *__restrict__ dW, float *__restrict__ db, int out, int in,
+                                                        TnGeom geo, TnRedAlt alt) {
+    if (blockIdx.z) {  // the second product of a paired launch
+        partial = alt.partial;
+        dW = alt.dW;
+        db = alt.db;
+    }
+    __shared__ __attribute__((aligned(16))) float red[3][64][4];
+    __shared__ float dbh[128];
+    tn_reduce_tile(partial, splits, tiles_x, tiles, dW, db, out, in, geo, (int)blockIdx.y, (int)blockIdx.x, (int)gridDim.x, red, dbh);
 }
 
 // rows per workgroup: no atomic traffic to trade against, so simply two workgroups per CU
@@ -875,6 +904,240 @@ int launch_tn_reduce(hipStream_t st, const float *partial, int splits, int tiles
     hipLaunchKernelGGL(tn_reduce_kernel, dim3((unsigned)(ni * nj * 4), (unsigned)(tiles_x * tiles_y), alt ? 2u : 1u), dim3(256), 0, st,
                        partial, splits, tiles_x, tiles_x * tiles_y, dW, db, out, in, TnGeom{ni, nj, wn}, alt ? *alt : TnRedAlt{});
     RLPPO_LAUNCH_CHECK();
+    return 0;
+}
+// ------------------------------------------------------------------------------------------------ [r5] grouped weight gradients
+// Every dW / db product of a pass in ONE launch.  Why: a per-layer launch at the 65,536 rows of one rank of an 8-rank job wrote 32 MB
+// of partial tiles (128 splits x 4 tiles x 64 KB) and was followed by a reduction launch that read them back -- 7 such pairs per
+// optimiser step, 232 us of 1155 in reductions alone, the dW products at 0.50-0.72 of the MFMA peak against 0.89 for the same kernel
+// at 524,288 rows.  The products of a backward pass have no consumer before the optimiser step, so they can all run at its end: one
+// grid of (about) two workgroups per CU, each workgroup one (product, output tile, row split) item, the splits of a product sized
+// so that every item is the same number of MFMA blocks (rows x NI x NJ).  A split is then thousands of rows long (the K loop's
+// prologue / epilogue amortised as in the large launch), the partial tiles of the WHOLE pass are 512 x 64 KB = 32 MB, and one
+// reduction launch sums them -- in split order, so the gradient stays bit-reproducible.
+struct TnWork {  // device-side view of one product
+    const float *dY, *X;
+    float *partial;
+    const unsigned *rowtab;
+    unsigned ldy_b, ldx_b, src_rows;
+    int ny_valid, kx_valid, out, rows_per_wg, splits, tiles_x, tiles_y, with_db, geom, wg_begin;
+};
+struct TnGroupArgs {
+    int n;
+    int64_t M;
+    TnWork w[TN_GROUP_MAX];
+};
+__global__ __launch_bounds__(256, 2) void gemm_tn_group_kernel(TnGroupArgs g) {
+    __shared__ __attribute__((aligned(16))) float lds[TN_LDS_FLOATS];
+    const int id = blockIdx.x;
+    int p = 0;
+    for (int i = 1; i < g.n; ++i)
+        if (id >= g.w[i].wg_begin) p = i;  // (uniform: scalar loads from the kernel arguments)
+    const TnWork &w = g.w[p];
+    const int loc = id - w.wg_begin, T = w.tiles_x * w.tiles_y, S8 = w.splits & ~7;
+    // XCD-aware order inside a product (its first id is a multiple of 8): whole groups of 8 splits put the T tiles of a split on
+    // ONE XCD (they read the same dY / X rows), id -> tile = (id % (8 T)) / 8, split = 8 (id / (8 T)) + id % 8; the splits left
+    // over are laid out tile by tile
+    int tile, bz;
+    if (loc < S8 * T) {
+        const int gq = loc % (8 * T);
+        tile = gq >> 3;
+        bz = (loc / (8 * T)) * 8 + (gq & 7);
+    } else {
+        const int r = loc - S8 * T, R = w.splits - S8;
+        if (R <= 0 || r >= R * T) return;  // padding up to the next product's first id
+        tile = r / R;
+        bz = S8 + r % R;
+    }
+    const int bx = tile % w.tiles_x, by = tile / w.tiles_x;
+#define TN_ITEM(NI_, NJ_, WN_, G_)                                                                                                     \
+    tn_tile<TM, NI_, NJ_, WN_, G_>(lds, w.dY, w.ldy_b, w.ny_valid, w.X, w.ldx_b, w.kx_valid, w.with_db != 0, w.out, g.M, w.rows_per_wg, \
+                                   w.partial, w.rowtab, w.src_rows, bx, by, bz, w.tiles_x, w.tiles_y, w.splits)
+    switch (w.geom) {
+        case 0: TN_ITEM(4, 4, 2, false); break;
+        case 1: TN_ITEM(4, 4, 2, true); break;
+        case 2: TN_ITEM(3, 4, 2, false); break;
+        case 3: TN_ITEM(2, 7, 4, false); break;
+        default: TN_ITEM(2, 7, 4, true); break;
+    }
+#undef TN_ITEM
+}
+
+struct TnRedWork {
+    const float *partial;
+    float *dW, *db;
+    int splits, tiles_x, tiles, out, in, tile_begin;
+    TnGeom geo;
+};
+struct TnRedGroupArgs {
+    int n;
+    TnRedWork w[TN_GROUP_MAX];
+};
+__global__ __launch_bounds__(256) void tn_reduce_group_kernel(TnRedGroupArgs g) {
+    __shared__ __attribute__((aligned(16))) float red[3][64][4];
+    __shared__ float dbh[128];
+    const int t = blockIdx.y;
+    int p = 0;
+    for (int i = 1; i < g.n; ++i)
+        if (t >= g.w[i].tile_begin) p = i;
+    const TnRedWork &w = g.w[p];
+    const int nbx = w.geo.ni * w.geo.nj * 4;
+    if ((int)blockIdx.x >= nbx) return;
+    tn_reduce_tile(w.partial, w.splits, w.tiles_x, w.tiles, w.dW, w.db, w.out, w.in, w.geo, t - w.tile_begin, (int)blockIdx.x, nbx, red, dbh);
+}
+
+// The plan of a grouped launch: splits per product such that every workgroup multiplies (about) the same number of 16 x 16 x 4
+// blocks and the grid is at most `budget` workgroups (one round at two per CU).  Depends on the SET of shapes and M only.
+static int g_tn_group_budget = 0;  // rlppo_dbg_set(38, n): 0 = two per CU
+constexpr int TN_MAX_CHAIN = 8192;  // longest row split (fp32 accumulation chain) of a grouped launch
+void set_tn_group_budget(int v) { g_tn_group_budget = v; }
+struct TnPlanItem {
+    TnGeom g;
+    int tiles_x, tiles_y, splits, rows_per_wg, wg_begin;
+    size_t partial_off, floats;
+};
+static int tn_group_plan(const int *outs, const int *ins, int n, int64_t M, int budget, TnPlanItem *it, int *total_wgs, size_t *total_floats) {
+    for (int p = 0; p < n; ++p) {
+        it[p].g = tn_geometry(outs[p], ins[p]);
+        it[p].tiles_x = (int)cdiv(outs[p], it[p].g.bnt());
+        it[p].tiles_y = (int)cdiv(ins[p], it[p].g.bkx());
+    }
+    const int64_t max_splits = cdiv(M, 32);
+    auto fill = [&](double t) {  // t: MFMA blocks x rows per workgroup
+        int64_t wgs = 0;
+        for (int p = 0; p < n; ++p) {
+            const int blocks = it[p].g.ni * it[p].g.nj;
+            int64_t rows = (int64_t)(t / blocks);
+            rows = round_up(rows < 32 ? 32 : rows, 32);
+            int64_t sp = cdiv(M, rows);
+            if (sp > max_splits) sp = max_splits;
+            rows = round_up(cdiv(M, sp), 32);
+            it[p].rows_per_wg = (int)rows;
+            it[p].splits = (int)cdiv(M, rows);
+            wgs += round_up((int64_t)it[p].splits * it[p].tiles_x * it[p].tiles_y, 8);
+        }
+        return wgs;
+    };
+    // One round of the grid when the splits stay short enough; else 2, 3, ... whole rounds: a split is ONE fp32 accumulation chain
+    // per output element, and its rounding error grows with the square root of its length -- the per-layer launches of rounds 1-4
+    // never ran more than 4096 rows per split, TN_MAX_CHAIN keeps the grouped launch within sqrt(2) of that at any M (524,288 rows:
+    // three rounds of 7,296-row splits).  (An explicit budget -- rlppo_dbg_set(38), tests -- is taken as it is.)
+    for (int rounds = 1;; ++rounds) {
+        const int64_t cap = (int64_t)budget * rounds;
+        double lo = 32.0, hi = (double)round_up(M, 32) * 32.0;  // fill(hi): one split per product
+        if (fill(lo) > cap) {
+            for (int i = 0; i < 60; ++i) {
+                const double mid = 0.5 * (lo + hi);
+                if (fill(mid) > cap) lo = mid; else hi = mid;
+            }
+            fill(hi);
+        }
+        int longest = 0;
+        for (int p = 0; p < n; ++p) longest = it[p].rows_per_wg > longest ? it[p].rows_per_wg : longest;
+        if (longest <= TN_MAX_CHAIN || g_tn_group_budget > 0 || rounds >= 64) break;
+    }
+    int wg = 0;
+    size_t off = 0;
+    for (int p = 0; p < n; ++p) {
+        it[p].wg_begin = wg;
+        wg += (int)round_up((int64_t)it[p].splits * it[p].tiles_x * it[p].tiles_y, 8);
+        it[p].partial_off = off;
+        it[p].floats = (size_t)it[p].splits * it[p].tiles_x * it[p].tiles_y * (size_t)it[p].g.tile_floats() + (size_t)it[p].splits * it[p].tiles_x * 128;
+        off += (it[p].floats + 3) / 4 * 4;
+    }
+    *total_wgs = wg;
+    *total_floats = off;
+    return 0;
+}
+static int tn_group_budget() {
+    if (g_tn_group_budget > 0) return g_tn_group_budget;
+    int cus = 0;
+    if (device_cu_count(&cus) || cus <= 0) cus = 256;
+    return 2 * cus;
+}
+size_t tn_group_floats(const int *outs, const int *ins, int n, int64_t M) {
+    if (n <= 0 || M <= 0) return 0;
+    size_t total = 0;
+    for (int b = 0; b < n; b += TN_GROUP_MAX) {  // (more products than one launch carries: consecutive launches share the buffer)
+        TnPlanItem it[TN_GROUP_MAX];
+        int wgs = 0;
+        size_t f = 0;
+        const int m = n - b < TN_GROUP_MAX ? n - b : TN_GROUP_MAX;
+        tn_group_plan(outs + b, ins + b, m, M, tn_group_budget(), it, &wgs, &f);
+        total = f > total ? f : total;
+    }
+    return total;
+}
+int launch_gemm_tn_group(hipStream_t st, const TnProduct *prods, int n, int64_t M, float *ws, size_t ws_floats) {
+    if (M <= 0 || n <= 0) return 0;
+    for (int b = 0; b < n; b += TN_GROUP_MAX) {
+        const int m = n - b < TN_GROUP_MAX ? n - b : TN_GROUP_MAX;
+        const TnProduct *pr = prods + b;
+        int outs[TN_GROUP_MAX], ins[TN_GROUP_MAX];
+        for (int p = 0; p < m; ++p) {
+            outs[p] = pr[p].out;
+            ins[p] = pr[p].in;
+        }
+        TnPlanItem it[TN_GROUP_MAX];
+        int wgs = 0;
+        size_t floats = 0;
+        tn_group_plan(outs, ins, m, M, tn_group_budget(), it, &wgs, &floats);
+        if (!ws || ws_floats < floats) {
+            set_error("gemm_tn_group: workspace %zu < %zu floats", ws ? ws_floats : (size_t)0, floats);
+            return RLPPO_ERR_WORKSPACE;
+        }
+        TnGroupArgs ga{};
+        TnRedGroupArgs ra{};
+        ga.n = ra.n = m;
+        ga.M = M;
+        const int64_t lim = (int64_t)1 << 30;
+        int tile_begin = 0;
+        for (int p = 0; p < m; ++p) {
+            const TnProduct &q = pr[p];
+            RLPPO_CHECK_ARG(q.dY && q.X && q.dW && q.ny_valid % 4 == 0 && q.kx_valid % 4 == 0 && q.ldy % 4 == 0 && q.ldx % 4 == 0 &&
+                                q.ny_valid <= q.ldy && q.kx_valid <= q.ldx && q.out <= q.ny_valid && q.in <= q.kx_valid,
+                            "gemm_tn_group: bad shapes (product %d) ny=%d kx=%d ldy=%ld ldx=%ld out=%d in=%d", p, q.ny_valid, q.kx_valid,
+                            (long)q.ldy, (long)q.ldx, q.out, q.in);
+            RLPPO_CHECK_ARG(((int64_t)it[p].rows_per_wg + TM) * q.ldy * 4 < lim && (q.rowtab || ((int64_t)it[p].rows_per_wg + TM) * q.ldx * 4 < lim),
+                            "gemm_tn_group: a leading dimension is too wide for 32-bit tile offsets");
+            RLPPO_CHECK_ARG(!q.rowtab || tn_gather_ok(q.ldx, q.src_rows), "gemm_tn_group (gathered rows): unsupported row stride %ld", (long)q.ldx);
+            RLPPO_CHECK_ARG(!(q.rowtab && it[p].g.ni == 3), "gemm_tn_group (gathered rows): the 96-row tile has no gathered form");
+            TnWork &w = ga.w[p];
+            w.dY = q.dY;
+            w.X = q.X;
+            w.partial = ws + it[p].partial_off;
+            w.rowtab = q.rowtab;
+            w.ldy_b = (unsigned)(q.ldy * 4);
+            w.ldx_b = (unsigned)(q.ldx * 4);
+            w.src_rows = (unsigned)q.src_rows;
+            w.ny_valid = q.ny_valid;
+            w.kx_valid = q.kx_valid;
+            w.out = q.out;
+            w.rows_per_wg = it[p].rows_per_wg;
+            w.splits = it[p].splits;
+            w.tiles_x = it[p].tiles_x;
+            w.tiles_y = it[p].tiles_y;
+            w.with_db = q.db != nullptr;
+            w.geom = it[p].g.nj == 7 ? (q.rowtab ? 4 : 3) : it[p].g.ni == 3 ? 2 : (q.rowtab ? 1 : 0);
+            w.wg_begin = it[p].wg_begin;
+            TnRedWork &r = ra.w[p];
+            r.partial = w.partial;
+            r.dW = q.dW;
+            r.db = q.db;
+            r.splits = it[p].splits;
+            r.tiles_x = it[p].tiles_x;
+            r.tiles = it[p].tiles_x * it[p].tiles_y;
+            r.out = q.out;
+            r.in = q.in;
+            r.tile_begin = tile_begin;
+            r.geo = it[p].g;
+            tile_begin += r.tiles;
+        }
+        hipLaunchKernelGGL(gemm_tn_group_kernel, dim3((unsigned)wgs), dim3(256), 0, st, ga);
+        RLPPO_LAUNCH_CHECK();
+        hipLaunchKernelGGL(tn_reduce_group_kernel, dim3(64u, (unsigned)tile_begin), dim3(256), 0, st, ra);
+        RLPPO_LAUNCH_CHECK();
+    }
     return 0;
 }
 }  // namespace rlppo

@@ -534,7 +534,7 @@ __global__ __launch_bounds__(256) void adam_pack2_kernel(OptPair o) {
 // networks stay as they were, the block's timeout word counts the event, and every later launch on that block skips at once
 // until its owner has zeroed it again.  (Round 3 poisoned the step with NaN, which could not be recovered from: advisor finding.)
 struct FusedSync {
-    unsigned count, gen, timeouts, pad[13];  // 64-byte header
+    unsigned count, gen, timeouts, counted_seq, pad[12];  // 64-byte header; counted_seq: the last launch that added itself to `timeouts`
     double slot[2][512];                     // per network, per workgroup: partial sum of squares of this launch
 };
 static_assert(sizeof(FusedSync) <= RLPPO_OPT_SYNC_BYTES, "RLPPO_OPT_SYNC_BYTES");
@@ -571,7 +571,15 @@ __device__ __forceinline__ void adam_one(const OptNet &N, int64_t i, float gi, f
     }
 }
 
-__global__ __launch_bounds__(256) void adam_fused_kernel(OptPair o, FusedSync *__restrict__ sy, const unsigned spin_limit, const int test_hold) {
+// `timeouts` counts SKIPPED OPTIMISER STEPS (the host rewinds Adam's step count by it), so a launch adds itself at most once:
+// the waiter that wins the give-up and workgroup (0, 0) finding the block dead can be the same launch (a late-dispatched (0, 0)
+// on a grid that was not co-resident -- exactly the give-up case); whoever swaps the launch's sequence number in first counts.
+__device__ __forceinline__ void count_skipped_once(FusedSync *sy, unsigned seq) {
+    if (__hip_atomic_exchange(&sy->counted_seq, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != seq)
+        __hip_atomic_fetch_add(&sy->timeouts, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__global__ __launch_bounds__(256) void adam_fused_kernel(OptPair o, FusedSync *__restrict__ sy, const unsigned spin_limit, const int test_hold, const unsigned seq) {
     const int k = blockIdx.y, tid = threadIdx.x;
     const OptNet &N = o.net[k];
     const unsigned nblocks = gridDim.x * gridDim.y;
@@ -611,7 +619,7 @@ __global__ __launch_bounds__(256) void adam_fused_kernel(OptPair o, FusedSync *_
         s_g0 = g0;
         if (g0 == FUSED_DEAD) {  // an earlier launch on this block gave up and its owner has not re-zeroed it: nothing to wait for
             ok = 0;
-            if (blockIdx.x == 0 && k == 0) __hip_atomic_fetch_add(&sy->timeouts, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (blockIdx.x == 0 && k == 0) count_skipped_once(sy, seq);
         } else if (test_hold && blockIdx.x == 0 && k == 0) {
             // test hook: this workgroup behaves like one that was never scheduled while the others wait -- it does not arrive; it
             // only watches the generation word until the waiters have given up, so that the launch ends
@@ -631,7 +639,7 @@ __global__ __launch_bounds__(256) void adam_fused_kernel(OptPair o, FusedSync *_
                         unsigned expect = g0;
                         if (__hip_atomic_compare_exchange_strong(&sy->gen, &expect, FUSED_DEAD, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
                                                                  __HIP_MEMORY_SCOPE_AGENT)) {
-                            __hip_atomic_fetch_add(&sy->timeouts, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            count_skipped_once(sy, seq);
                             cur = FUSED_DEAD;
                         } else {
                             cur = expect;  // somebody else decided first: opened (g0 + 1) or dead
@@ -737,8 +745,11 @@ int launch_clip_adam_pack2(hipStream_t st, const NetLayout *nets, float *const *
             int64_t blocks = cdiv(nmax, 256 * FUSED_EPT);
             blocks = blocks < 1 ? 1 : (blocks > FUSED_MAX_BLOCKS ? FUSED_MAX_BLOCKS : blocks);
             blocks = blocks > cap ? cap : blocks;
+            static std::atomic<unsigned> launch_seq{0};  // per-launch sequence number, never 0 (a zeroed block's counted_seq)
+            unsigned seq = launch_seq.fetch_add(1, std::memory_order_relaxed) + 1;
+            if (seq == 0) seq = launch_seq.fetch_add(1, std::memory_order_relaxed) + 1;
             hipLaunchKernelGGL(adam_fused_kernel, dim3((unsigned)blocks, 2), dim3(256), 0, st, o, reinterpret_cast<FusedSync *>(sync_ws),
-                               g_fused_spin_limit, g_fused_test_hold);
+                               g_fused_spin_limit, g_fused_test_hold, seq);
             RLPPO_LAUNCH_CHECK();
             return 0;
         }

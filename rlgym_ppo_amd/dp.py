@@ -113,12 +113,16 @@ def run_virtual_ranks(learners, buffers):
             total += t
         for t in pending:
             t.copy_(total)
-        nxt = []
+        nxt, failed = [], None
         for r, g in enumerate(gens):
             try:
                 nxt.append(g.send(None))
             except StopIteration as done:
                 reports[r] = done.value
+            except Exception as e:  # noqa: BLE001 -- a collective failure (OptimizerBarrierTimeout) is raised by every rank: let each recover
+                failed = failed or e
+        if failed is not None:
+            raise failed
         if len(nxt) == 0:
             return reports
         if len(nxt) != world:

@@ -25,6 +25,14 @@ def require_gpu(device):
     return dev
 
 
+def _resolve_device(device):
+    """torch.device with its index filled in ("cuda" -> the current device): what a tensor's .device compares equal to."""
+    dev = torch.device(device)
+    if dev.type == "cuda" and dev.index is None:
+        dev = torch.device("cuda", torch.cuda.current_device())
+    return dev
+
+
 def stream_ptr():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
@@ -158,7 +166,7 @@ class NetArena:
     def invalidate(self):
         """Force a re-pack before the next kernel reads the weights (for writers that bypass both version counters, e.g.
         a raw pointer write into the arena)."""
-        self._packed_key = None
+        self._packed_key = self._packed_bf16_key = self._packed_x3_key = None  # (the bf16 / split-bf16 images derive from the same weights)
 
     # ------------------------------------------------------------------------------------------ inference
     def stage_obs(self, obs, standardize=None, out=None):
@@ -566,22 +574,49 @@ class HostExponential:
     class _BurstSlot:
         """Stands in for the future of one draw of a burst: result() returns once the draw's values are complete."""
 
-        def __init__(self, link):
+        TIMEOUT_S = 10.0  # the bound of the chained C path's own waits
+
+        def __init__(self, link, rec=None, run=0):
             self.link = link.view(np.int32)
+            self.rec, self.run = rec, run   # the burst record and the index of the helper-thread run that produces this draw
 
         def done(self):
             return self.link[1] != 0
 
         def result(self):
             import time
-            spins = 0
+            spins, t0 = 0, None
             while self.link[1] == 0:   # normally long done (the burst ran during learn())
                 spins += 1
-                time.sleep(0 if spins < 200 else 0.0001)
+                if spins >= 200:
+                    # [r5, advisor] never an unbounded wait: a run that died before marking its links (an early argument-check
+                    # return of the C call, a helper thread that never reached it) leaves them 0 -- its pool future then says so
+                    fut = self.rec["futures"][self.run] if self.rec is not None and self.run < len(self.rec["futures"]) else None
+                    if fut is not None and fut.done() and self.link[1] == 0:
+                        raise RuntimeError("burst draw failed: its helper-thread run ended without producing it (%r)" % (fut.exception(),))
+                    t0 = t0 or time.monotonic()
+                    if time.monotonic() - t0 > self.TIMEOUT_S:
+                        raise RuntimeError("burst draw timed out after %.0f s" % self.TIMEOUT_S)
+                    time.sleep(0.0001)
+                else:
+                    time.sleep(0)
             if self.link[1] < 0:
                 raise RuntimeError("burst draw failed or was cancelled")
 
     def _burst_run(self, b, state_in, link_in0, nbytes, numel, first, count):
+        try:
+            self._burst_run_inner(b, state_in, link_in0, nbytes, numel, first, count)
+        except BaseException:
+            # [r5, advisor] whatever went wrong, nobody may wait for this run's draws: mark every link it owns that is not complete
+            # as failed (ready = -1 lets a successor chained to it stop too) before the exception goes to the pool future
+            links = b["links"]
+            for i in range(first, count, self.workers):
+                w = links[i].view(np.int32)
+                if w[1] == 0:
+                    w[0], w[1] = -1, -1
+            raise
+
+    def _burst_run_inner(self, b, state_in, link_in0, nbytes, numel, first, count):
         N.check(N.lib().rlppo_torch_cpu_exponential_burst(
             ctypes.c_void_p(state_in.data_ptr()) if state_in is not None else None,
             ctypes.c_void_p(link_in0.ctypes.data) if link_in0 is not None else None, nbytes, numel, 1.0,
@@ -652,7 +687,7 @@ class HostExponential:
         pool = _pool("noise", self.workers)
         b["dev_ok"] = False
         if device is not None and torch.device(device).type == "cuda" and torch.cuda.is_available():
-            dev = torch.device(device)
+            dev = _resolve_device(device)  # ("cuda" and "cuda:0" must compare equal with a tensor's device: advisor)
             if b.get("dev") is None or b["dev"].device != dev or b["dev"].shape[0] < b["out"].shape[0]:
                 b["dev"] = torch.empty(b["out"].shape, dtype=torch.float32, device=dev)
             # the block is rewritten only behind everything launched so far (the kernels that read the previous burst)
@@ -666,7 +701,8 @@ class HostExponential:
         for i in range(need):
             link = b["links"][i]
             e = dict(shape=shape, numel=numel, state_bytes=nbytes, state_in=state_now if (prev is None and i == 0) else None, prev=prev,
-                     link=link, words=None, buf=b["out"][i], rec=b, slot=i, future=HostExponential._BurstSlot(link))
+                     link=link, words=None, buf=b["out"][i], rec=b, slot=i,
+                     future=HostExponential._BurstSlot(link, b, i % min(self.workers, need)))
             self._chain.append(e)
             prev = e
         return need
@@ -719,7 +755,7 @@ class HostExponential:
         torch.set_rng_state(after)
         out = buf.view(shape)
         on_gpu = device is not None and torch.device(device).type == "cuda"
-        if on_gpu and pre is not None and pre[0]["dev"].device == torch.device(device):
+        if on_gpu and pre is not None and pre[0]["dev"].device == _resolve_device(device):
             # [r4] the whole burst went to HBM when its last draw finished (during learn()): no copy, no event per step
             b_, i_ = pre
             if not b_["dev_waited"]:

@@ -185,6 +185,9 @@ class PPOLearner(object):
         self.fused_optimizer_step = os.environ.get("RLPPO_FUSED_OPT", "1") != "0"  # rlppo_clip_adam_pack2 (False: FusedAdam.step x2)
         self.grad_probe = None  # callable(flat [grad_policy | grad_value]) before every optimiser step (tests)
         self.one_launch_optimizer = os.environ.get("RLPPO_OPT_ONE_LAUNCH", "1") != "0"  # ... as ONE launch with a grid barrier
+        # [r5] update precision of THIS learner (rlppo_minibatch_args.precision): None = the process default chosen with
+        # engine.set_update_precision, else "fp32" / "bf16" / "x3" -- two learners of one process may differ
+        self.update_precision = None
 
     # --------------------------------------------------------------------------------------------- learn
     def _minibatch_args(self, exp, rank=0, world=1):
@@ -196,7 +199,11 @@ class PPOLearner(object):
         a.pol_dims = ctypes.cast(pa.dims_c, ctypes.POINTER(ctypes.c_int32))
         a.val_dims = ctypes.cast(va.dims_c, ctypes.POINTER(ctypes.c_int32))
         a.pol_packed, a.val_packed = pa.packed.data_ptr(), va.packed.data_ptr()
-        prec = int(N.lib().rlppo_get_update_precision())
+        if self.update_precision is None:
+            prec, a.precision = int(N.lib().rlppo_get_update_precision()), N.PRECISION_DEFAULT
+        else:
+            prec = {"fp32": 0, "bf16": 1, "x3": 2}[self.update_precision]
+            a.precision = 1 + prec
         self._bf16 = prec == 1  # bf16-operand forward: the rounded weight images travel too
         self._x3 = prec == 2    # [r4] fp32 update with split-bf16 hidden forward / dX products: the three-plane images travel
         if self._x3:
@@ -221,7 +228,7 @@ class PPOLearner(object):
         n_slices = self.batch_size // self.mini_batch_size
         runs = fuse_runs(slices_for_rank(max(1, n_slices), rank, world), self.max_fused_minibatches)
         self._fused_rows = self.mini_batch_size * max([cnt for _, cnt in runs] or [1])
-        nbytes = int(N.lib().rlppo_minibatch_workspace_bytes(pa.dims_c, pa.n_layers, va.dims_c, va.n_layers, self._fused_rows))
+        nbytes = int(N.lib().rlppo_minibatch_workspace_bytes_for(pa.dims_c, pa.n_layers, va.dims_c, va.n_layers, self._fused_rows, a.precision))
         nbytes = (nbytes + 255) // 256 * 256
         ws = self._ws.get(nbytes * self.n_slots)
         self._slot_ws = [ws.data_ptr() + i * nbytes for i in range(self.n_slots)]
@@ -323,28 +330,63 @@ class PPOLearner(object):
         # every pass added one mean to each report statistic; the number of passes travels with the sums, so the report is the
         # mean over the passes of ALL ranks even when the slices do not divide evenly over them (3 slices on 2 ranks)
         self._stats[N.STAT_PASSES] += float(n_passes)
+        to_word = self._opt_sync[N.OPT_SYNC_TIMEOUT_WORD:N.OPT_SYNC_TIMEOUT_WORD + 1].double()  # optimiser steps THIS rank's barrier skipped
+        to_all = to_word
         if world > 1:
-            yield self._stats
+            # the give-up count travels with the statistics: a give-up on ANY rank is known to EVERY rank after this exchange
+            ex = torch.cat((self._stats, to_word))
+            yield ex
+            self._stats.copy_(ex[:N.N_STATS])
+            to_all = ex[N.N_STATS:]
         # update magnitudes (ppo_learner.py:214-222: fp32 norms) travel with the statistics: ONE device->host sync per learn()
         mags = torch.stack(((policy_before - pa.flat).norm(), (critic_before - va.flat).norm()))
-        stats = torch.cat((self._stats, mags.double(), self._opt_sync[N.OPT_SYNC_TIMEOUT_WORD:N.OPT_SYNC_TIMEOUT_WORD + 1].double())).cpu().numpy()
-        if stats[N.N_STATS + 2] != 0:
-            # A grid-barrier wait of the one-launch optimiser step gave up (GPU shared with a kernel that never yields, a
-            # partitioned device, or a defect).  Giving up is all or nothing (include/rlppo.h): that step and every later one of
-            # this call were SKIPPED -- parameters and Adam moments are those of the last completed step, finite and consistent on
-            # every rank -- and the gradient arena still holds the skipped batches' sums.  Recover the state a caller can continue
-            # from (zero gradients, a re-armed block, the three-operation form from now on) and report loudly.
-            n_to = int(stats[N.N_STATS + 2])   # = the number of skipped optimiser steps: the give-up counts once, every later launch on the dead block once
+        stats = torch.cat((self._stats, mags.double(), to_word, to_all)).cpu().numpy()
+        if stats[N.N_STATS + 3] != 0:
+            # A grid-barrier wait of the one-launch optimiser step gave up on some rank (GPU shared with a kernel that never yields,
+            # a partitioned device, or a defect).  Giving up is all or nothing (include/rlppo.h): on the rank it happened, that step
+            # and every later one of this call were SKIPPED -- its parameters and Adam moments are those of its last completed step,
+            # finite -- and its gradient arena still holds the skipped batches' sums.  Recover the state a caller can continue from
+            # (zero gradients, a re-armed block, the three-operation form from now on) and report loudly.
+            n_to = int(stats[N.N_STATS + 2])   # skipped optimiser steps of THIS rank (a launch counts itself once: csrc/optim.hip)
             for opt in (self.policy_optimizer, self.value_optimizer):
                 opt.step_count = max(0, opt.step_count - n_to)   # Adam's bias corrections must not count steps that never happened
             self.cumulative_model_updates += max(0, n_iterations - n_to)
             self._grad_all.zero_()
             self._opt_sync.zero_()
             self.one_launch_optimizer = False
+            where = "the affected optimiser steps of this learn() were skipped -- parameters and Adam state are those of the last completed step, no NaN was written"
+            if world > 1:
+                # [r5, advisor] Data-parallel: the rank that gave up skipped steps the others applied, so the replicas have DIVERGED
+                # (parameters, moments, step counts).  The outcome is made collective: every rank takes this branch (the count was
+                # summed over the ranks above) and adopts rank 0's state -- one more exchange in which only rank 0 contributes, so
+                # the sum IS its state, bit for bit -- before raising on every rank.
+                opts = (self.policy_optimizer, self.value_optimizer)
+                pieces = [pa.flat, va.flat] + [t for o in opts for t in (o.exp_avg, o.exp_avg_sq)]
+                sync = torch.cat([t.reshape(-1) for t in pieces])
+                counts = torch.tensor([float(o.step_count) for o in opts] + [float(self.cumulative_model_updates)], dtype=torch.float64,
+                                      device=self._dev)
+                if rank != 0:
+                    sync.zero_()
+                    counts.zero_()
+                yield sync
+                yield counts
+                off = 0
+                for t in pieces:
+                    t.copy_(sync[off:off + t.numel()].view_as(t))
+                    off += t.numel()
+                c = counts.cpu().numpy()
+                self.policy_optimizer.step_count, self.value_optimizer.step_count = int(c[0]), int(c[1])
+                self.cumulative_model_updates = int(c[2])
+                pa.native_epoch += 1  # `flat` was rewritten behind torch's back: re-pack before the next kernel reads the weights
+                va.native_epoch += 1
+                pa.invalidate()
+                va.invalidate()
+                where = ("the rank(s) it happened on skipped optimiser steps the others applied; every rank has now adopted rank 0's "
+                         "parameters, Adam moments and step counts (bit-identical replicas again), no NaN was written")
             raise OptimizerBarrierTimeout(
-                "rlppo_clip_adam_pack2: the optimiser's grid barrier gave up (%d event(s)); the affected optimiser steps of this "
-                "learn() were skipped -- parameters and Adam state are those of the last completed step, no NaN was written -- "
-                "gradients are zeroed and this learner now uses the three-operation optimiser tail: calling learn() again is safe" % n_to)
+                "rlppo_clip_adam_pack2: the optimiser's grid barrier gave up (%d skipped step(s) over all ranks); %s -- gradients are "
+                "zeroed and this learner now uses the three-operation optimiser tail: calling learn() again is safe"
+                % (int(stats[N.N_STATS + 3]), where))
         elapsed = time.time() - t1
         n_iter_r = max(n_iterations, 1)
         n_mb_r = max(float(stats[N.STAT_PASSES]), 1.0)

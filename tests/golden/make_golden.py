@@ -191,6 +191,102 @@ def g5big_learn(R):
     save("g5big_learn_discrete_256x3", **out, n_steps=np.int64(step_no[0]), cfg=np.array(json.dumps(cfg)))
 
 
+def g5bigb_inputs(cfg, actions, log_probs):
+    """The experience of G5big-b [r5]: a WELL-CONDITIONED workload at the paired-launch size.  States, advantages and value targets
+    come from seeds alone with IEEE adds / multiplies of numpy legacy draws (the same bits on every host: a test rebuilds them);
+    `actions` (what the reference's policy sampled at its initial weights) and `log_probs` (that sample's log-probability + N(0, 0.1),
+    nudged off the clip edges) come from the fixture, which holds them (uint8 / float32).  Advantages carry a per-action and a
+    per-state signal (c[a] + 0.7 sign(s[a]) + 0.3 noise) and the targets a function of the state, so the batch gradient is a
+    coherent sum, not a few outliers over cancelling noise as in G5big.  Returned in submit_experience order."""
+    rs = np.random.RandomState(cfg["seed"] + 1)
+    n, d, A = cfg["n"], cfg["d"], cfg["n_act"]
+    states = np.clip(rs.randn(n, d), -5, 5).astype(np.float32)
+    rewards = rs.randn(n).astype(np.float32)
+    dones = (rs.rand(n) < 0.03).astype(np.float32)
+    trunc = ((rs.rand(n) < 0.03) & (dones == 0)).astype(np.float32)
+    c = 0.5 * rs.randn(A)
+    noise_a, noise_v = rs.randn(n), rs.randn(n)
+    a = np.asarray(actions).astype(np.int64)
+    s_a = np.sign(states[np.arange(n), a].astype(np.float64))
+    adv = (c[a] + 0.7 * s_a + 0.3 * noise_a).astype(np.float32)
+    values = (1.5 * np.sign(states[:, 0].astype(np.float64)) + 0.5 * states[:, 1].astype(np.float64) + 0.3 * noise_v).astype(np.float32)
+    return (states, a.astype(np.float32), np.asarray(log_probs, np.float32), rewards, states[:1].repeat(n, 0), dones, trunc, values, adv)
+
+
+def g5bigb_learn(R):
+    """G5big-b [r5]: the size of G5big (256x3, n = B = 262,144, MB = 65,536, 2 optimiser steps: paired + gather-fused launches)
+    on a well-conditioned workload (g5bigb_inputs), so that the product's first-step batch gradient can be held to the REFERENCE's
+    own gradient directly -- 1e-5 of max|g|, the north star's number -- instead of through a float64 yardstick.  Actions are sampled
+    by the reference's policy at its initial weights (DiscreteFF.get_action, discrete_policy.py:44-62, in 4 chunks), the old
+    log-probabilities are that sample's + N(0, 0.1); rows whose first-step ratio would sit within 1e-3 of a clip edge (where one
+    float32 rounding decides whether the row's gradient is kept: the G4 fixture's knife-edge rows) get their old log-probability
+    moved by 0.01.  Stored: the actions (uint8), the log-probabilities, and the same outputs as G5big."""
+    cfg = dict(policy_type=0, d=107, n_act=90, layers=(256, 256, 256), n=262144, B=262144, MB=65536, epochs=2, seed=4321,
+               lr=3e-4, clip=0.2, ent=0.005)
+    torch.manual_seed(cfg["seed"])
+    np.random.seed(cfg["seed"])
+    learner = R["PPOLearner"](cfg["d"], cfg["n_act"], 0, cfg["layers"], cfg["layers"], (0.1, 1.0), cfg["B"], cfg["epochs"], cfg["lr"],
+                              cfg["lr"], cfg["clip"], cfg["ent"], cfg["MB"], "cpu")
+    vec = lambda m: torch.nn.utils.parameters_to_vector(m.parameters()).detach().clone().numpy()
+    out = {"p0.hash": param_hash(vec(learner.policy)), "v0.hash": param_hash(vec(learner.value_net)),
+           "p0.head": vec(learner.policy)[:64], "v0.head": vec(learner.value_net)[:64]}
+    states = g5bigb_inputs(cfg, np.zeros(cfg["n"], np.uint8), np.zeros(cfg["n"], np.float32))[0]
+    acts, lps = [], []
+    with torch.no_grad():
+        for s in range(0, cfg["n"], 65536):
+            a, lp = learner.policy.get_action(states[s:s + 65536])
+            acts.append(a.numpy().reshape(-1))
+            lps.append(lp.numpy().reshape(-1).astype(np.float64))
+    actions, lp_pol = np.concatenate(acts).astype(np.uint8), np.concatenate(lps)
+    rs = np.random.RandomState(cfg["seed"] + 2)
+    old = lp_pol + 0.1 * rs.randn(cfg["n"])
+    ratio = np.exp(lp_pol - old)
+    edge = (np.abs(ratio - (1 - cfg["clip"])) < 1e-3) | (np.abs(ratio - (1 + cfg["clip"])) < 1e-3)
+    old[edge] += 0.01
+    ratio = np.exp(lp_pol - old.astype(np.float32).astype(np.float64))
+    assert not ((np.abs(ratio - (1 - cfg["clip"])) < 5e-4) | (np.abs(ratio - (1 + cfg["clip"])) < 5e-4)).any()
+    log_probs = old.astype(np.float32)
+    out["exp.actions_u8"], out["exp.log_probs"] = actions, log_probs
+    out["exp.first_step_clip_fraction"] = np.float64(((ratio < 1 - cfg["clip"]) | (ratio > 1 + cfg["clip"])).mean())
+    buf = R["ExperienceBuffer"](cfg["n"], cfg["seed"], "cpu")
+    exp = g5bigb_inputs(cfg, actions, log_probs)
+    out["exp.hash"] = np.asarray([param_hash(x.reshape(-1)) for x in exp[:3] + exp[7:]])
+    buf.submit_experience(*exp)
+    step_no = [0]
+    orig = learner.value_optimizer.step
+
+    def rec(*a, **k):  # the value optimiser steps last (ppo_learner.py:192-193)
+        r = orig(*a, **k)
+        s = step_no[0]
+        p, v = vec(learner.policy), vec(learner.value_net)
+        out[f"step{s}.policy_head"], out[f"step{s}.value_head"] = p[:64], v[:64]
+        out[f"step{s}.policy_sum"], out[f"step{s}.value_sum"] = np.float64(p.astype(np.float64).sum()), np.float64(v.astype(np.float64).sum())
+        if s == cfg["epochs"] * (cfg["n"] // cfg["B"]) - 1:
+            out[f"step{s}.policy"], out[f"step{s}.value"] = p, v
+        step_no[0] += 1
+        return r
+    learner.value_optimizer.step = rec
+    real_clip, seen = torch.nn.utils.clip_grad_norm_, []
+
+    def spy(parameters, max_norm, *a, **k):  # the first step's batch gradient as clip_grad_norm_ receives it (value net first)
+        parameters = list(parameters)
+        if len(seen) < 2:
+            seen.append(torch.cat([p.grad.detach().reshape(-1) for p in parameters]).clone().numpy())
+        return real_clip(parameters, max_norm, *a, **k)
+    torch.nn.utils.clip_grad_norm_ = spy
+    try:
+        report = learner.learn(buf)
+    finally:
+        torch.nn.utils.clip_grad_norm_ = real_clip
+    for tag, gvec in zip(("value", "policy"), seen):
+        out[f"grad0.{tag}_every8"] = gvec[::8]
+        out[f"grad0.{tag}_l2"] = np.float64(np.sqrt((gvec.astype(np.float64) ** 2).sum()))
+        out[f"grad0.{tag}_max"] = np.float64(np.abs(gvec).max())
+    report.pop("PPO Batch Consumption Time")
+    out.update({"report." + k: np.float64(v) for k, v in report.items()})
+    save("g5bigb_learn_discrete_256x3", **out, n_steps=np.int64(step_no[0]), cfg=np.array(json.dumps(cfg)))
+
+
 def make_gae_inputs(n, seed, trunc_dtype):
     rs = np.random.RandomState(seed)
     rews = rs.randn(n).astype(np.float32) * 2.0
@@ -552,7 +648,7 @@ def main():
         raise SystemExit("reference tree not present: fixtures can only be regenerated in the build container")
     R = _import_reference()
     torch.set_num_threads(1)  # deterministic reduction order in the CPU GEMMs that produce the fixtures
-    for fn in (g1_g2_forward, g1bc_forward_fused_shapes, g3_gae, g4_discrete_loss, g5_learn, g5big_learn, g6_shuffle, g7_welford, g8_fifo,
+    for fn in (g1_g2_forward, g1bc_forward_fused_shapes, g3_gae, g4_discrete_loss, g5_learn, g5big_learn, g5bigb_learn, g6_shuffle, g7_welford, g8_fifo,
                g9_other_heads, g10_checkpoint, g11_wire):
         if not only or fn.__name__ in only:
             fn(R)

@@ -276,6 +276,74 @@ def test_gemm_tn(L, M, out, in_):
     assert torch.equal(results[0], results[1]) and torch.equal(results[0], results[2])
 
 
+def _tn_group_case(L, M, shapes, seed, gather_first=False, budget=0, reverse=False):
+    """dW / db of several products through ONE rlppo_dbg_gemm_tn_group call; returns ([(dW, db)], [(refW, refb)] in float64).
+    reverse: the same products (same data) handed over in reverse order."""
+    from rlgym_ppo_amd import _native as N
+    g = torch.Generator().manual_seed(seed)
+    prods = (N.TnProduct * len(shapes))()
+    keep, outs, refs = [], [], []
+    n_src = 3 * M + 7
+    rowtab = torch.randint(0, n_src, (M,), generator=g).to(torch.int32)
+    for i, (out, in_) in enumerate(shapes):
+        ny, kx = int(L.rlppo_padded_out(out)), int(L.rlppo_padded_out(in_))
+        dY = torch.zeros(M, ny)
+        dY[:, :out] = torch.randn(M, out, generator=g)
+        gathered = gather_first and i == 0
+        rows = n_src if gathered else M
+        X = torch.zeros(rows, kx)
+        X[:, :in_] = torch.randn(rows, in_, generator=g)
+        dW0, db0 = torch.randn(out, in_, generator=g), torch.randn(out, generator=g)
+        dYd, Xd, dW, db = dev(dY), dev(X), dev(dW0), dev(db0)
+        rt = rowtab.cuda() if gathered else None
+        keep.append((dYd, Xd, rt))
+        q = prods[len(shapes) - 1 - i if reverse else i]
+        q.dY, q.ldy, q.ny_valid, q.X, q.ldx, q.kx_valid = dYd.data_ptr(), ny, ny, Xd.data_ptr(), kx, kx
+        q.dW, q.db, q.out, q.in_ = dW.data_ptr(), db.data_ptr(), out, in_
+        q.rowtab, q.src_rows = (rt.data_ptr(), rows) if gathered else (None, 0)
+        Xr = X[rowtab.long()] if gathered else X
+        outs.append((dW, db))
+        refs.append((dW0.double() + dY[:, :out].double().T @ Xr[:, :in_].double(), db0.double() + dY[:, :out].double().sum(0)))
+    check(L, L.rlppo_dbg_set(38, budget))
+    try:
+        ws = torch.empty(int(L.rlppo_dbg_gemm_tn_group_workspace_bytes(prods, len(shapes), M)), dtype=torch.uint8, device="cuda")
+        assert ws.numel() > 0
+        ws.fill_(0xFF)  # NaN patterns: slots the kernels do not write must not reach the sums
+        check(L, L.rlppo_dbg_gemm_tn_group(stream(), prods, len(shapes), M, P(ws), ws.numel()))
+        torch.cuda.synchronize()
+    finally:
+        check(L, L.rlppo_dbg_set(38, 0))
+    return outs, refs
+
+
+@pytest.mark.parametrize("M,shapes,gather_first,budget", [
+    (65536, [(256, 107), (256, 256), (256, 256), (90, 256), (256, 107), (256, 256), (256, 256)], True, 0),   # the update's own set (cfg2, one rank of 8)
+    (1500, [(256, 107), (256, 256), (90, 256)], True, 0),          # ragged: partial stages, fewer rows than a full split
+    (33, [(90, 256), (21, 32), (300, 130)], False, 0),             # hardly any rows: one or two splits per product
+    (5000, [(512, 231), (16, 512), (256, 256)], False, 0),
+    (70001, [(256, 256), (90, 256)], False, 24),                   # a small grid: many rows per split, splits that are not multiples of 8
+    (4096, [(256, 256)] * 20, False, 0),                           # many products: the kernel-argument table well filled
+    (300000, [(256, 256), (256, 107), (90, 256)], True, 0),        # more rows than one round of 8192-row splits holds: several rounds
+])
+def test_gemm_tn_group(L, M, shapes, gather_first, budget):
+    """[r5] Every weight-gradient product of a pass in ONE launch + ONE fixed-order reduction (rlppo_dbg_gemm_tn_group, the form
+    rlppo_ppo_minibatch uses): each product against float64, accumulated on top of existing gradients, the first one through a row
+    table (the fused minibatch gather); bit-identical from run to run and whatever the ORDER of the products in the call."""
+    outs, refs = _tn_group_case(L, M, shapes, seed=M + len(shapes), gather_first=gather_first, budget=budget)
+    # (a forced small grid makes every split one fp32 chain of ~17,500 rows: its rounding grows with the square root of that length;
+    # the library's own plans keep a split within 8192 rows)
+    tol = 1e-5 if budget else 2e-6
+    for (dW, db), (rW, rb) in zip(outs, refs):
+        assert relerr(dW, rW) < tol and relerr(db, rb) < tol
+    again, _ = _tn_group_case(L, M, shapes, seed=M + len(shapes), gather_first=gather_first, budget=budget)
+    for (a, b), (c, e) in zip(outs, again):
+        assert torch.equal(a, c) and torch.equal(b, e)
+    if len(shapes) <= 16:  # the plan depends on the SET of shapes: the same products in reverse order, the same bits
+        rev, _ = _tn_group_case(L, M, shapes, seed=M + len(shapes), gather_first=gather_first, budget=budget, reverse=True)
+        for (a, b), (c, e) in zip(outs, rev):
+            assert torch.equal(a, c) and torch.equal(b, e)
+
+
 # -------------------------------------------------------------------------------------------------- GAE
 def run_gae(L, rews, dones, trunc, values, gamma, lmbda, std):
     n = len(rews)
@@ -1008,8 +1076,22 @@ def test_fused_gather_and_paired_launches_are_bitwise_neutral(L):
         check(L, L.rlppo_dbg_set(29, 1))
     for (a, b), (c, e) in zip(gp1 + gv1, gp2 + gv2):
         assert torch.equal(a, c) and torch.equal(b, e)
+    # [r5] every form above ran its weight gradients as ONE grouped launch (the default; the library counts them): the plan of that
+    # launch depends on the set of products and the row count only, which is why the forms stay bit-identical.  Against one launch +
+    # reduction per layer (rlppo_dbg_set(37, 0)) the gradients differ by the order of their row sums only.
+    c5 = L.rlppo_dbg_counter(5)
+    assert c5 > 0
+    check(L, L.rlppo_dbg_set(37, 0))
+    try:
+        gp3, gv3, _ = run_minibatch(L, "discrete", pol, val, obs, acts, old, tgt, adv, idx, 0.2, 0.005, 0.25)
+    finally:
+        check(L, L.rlppo_dbg_set(37, 1))
+    assert L.rlppo_dbg_counter(5) == c5
+    for (a, b), (c, e) in zip(gp0 + gv0, gp3 + gv3):
+        assert relerr(c, a) < 2e-6 and relerr(e, b) < 2e-6
+    runs["per_layer_dw"] = (gp3, gv3, st0)
     # and both forms are right (float64 truth), not merely self-consistent
-    for key in ("fused", "folded_value_head"):
+    for key in ("fused", "folded_value_head", "per_layer_dw"):
         fp64_gate.gate(L, "discrete", pol, val, obs[idx], acts[idx], old[idx], adv[idx], tgt[idx], 0.2, 0.005, 0.25, runs[key],
                        label=key + ", ragged 1500-row minibatch")
 

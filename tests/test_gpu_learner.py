@@ -238,6 +238,155 @@ def _g5big_body(L, g, cfg, learner, buf, truth, grad64, n_steps, p0, vec, precis
         assert abs(got - ref) <= tol, (key, got, ref)
 
 
+def test_g5bigb_paired_launch_gradient_against_the_reference_directly(golden):
+    """[r5] G5big-b: the reference's PPOLearner.learn at the paired-launch size (256x3, n = B = 262,144, MB = 65,536, 2 optimiser steps)
+    on a WELL-CONDITIONED workload -- actions sampled by the reference's policy at its initial weights, old log-probabilities that
+    sample's + N(0, 0.1) kept 5e-4 away from both clip edges at the first step, advantages and targets with a per-action / per-state
+    signal (tests/golden/make_golden.py::g5bigb_inputs) -- so that no float64 yardstick is needed: the first step's batch gradient
+    (grouped weight-gradient launch, paired forward / dX launches, fused gather: counters checked) is held to the REFERENCE's own
+    gradient, 1e-5 of max|g| (north_star's number; the fixture holds every 8th entry + norms), and the parameters after both steps
+    to the reference's own parameters, 1e-5 of max|p| on every entry whose Adam steps were well-conditioned in float64 (smallest
+    |g_i| / max|g| over the steps >= 1e-4; oracle/ppo.py::learn64 says which -- the others stay within the derived bound)."""
+    import importlib.util
+    from rlgym_ppo_amd import _native as N
+    from rlgym_ppo_amd.ppo import ExperienceBuffer
+    spec = importlib.util.spec_from_file_location("make_golden", os.path.join(os.path.dirname(__file__), "golden", "make_golden.py"))
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)
+    L = N.lib()
+    g = golden("g5bigb_learn_discrete_256x3")
+    cfg = json.loads(str(g["cfg"]))
+    learner = make_learner(cfg)
+    vec = lambda m: torch.nn.utils.parameters_to_vector(m.parameters()).detach().cpu().numpy()
+    p0, v0 = vec(learner.policy), vec(learner.value_net)
+    assert mg.param_hash(p0) == g["p0.hash"] and mg.param_hash(v0) == g["v0.hash"]      # the reference's initial weights, bit for bit
+    exp = mg.g5bigb_inputs(cfg, g["exp.actions_u8"], g["exp.log_probs"])
+    assert np.array_equal(np.asarray([mg.param_hash(x.reshape(-1)) for x in exp[:3] + exp[7:]]), g["exp.hash"])   # the same experience
+    buf = ExperienceBuffer(cfg["n"], cfg["seed"], "cpu")
+    buf.submit_experience(*exp)
+    layers = [cfg["d"]] + list(cfg["layers"])
+
+    def split(flat, outs):
+        params, o = [], 0
+        dims = layers + [outs]
+        for i in range(len(dims) - 1):
+            w = flat[o:o + dims[i + 1] * dims[i]].reshape(dims[i + 1], dims[i]); o += w.size
+            b = flat[o:o + dims[i + 1]]; o += b.size
+            params.append((torch.as_tensor(w.copy()), torch.as_tensor(b.copy())))
+        return params
+    truth, weakest, grad64 = {}, {}, {}
+    ppo.learn64("discrete", split(p0, cfg["n_act"]), split(v0, 1),
+                dict(states=exp[0], actions=exp[1], log_probs=exp[2], values=exp[7], advantages=exp[8]), cfg["B"], cfg["MB"], cfg["epochs"],
+                cfg["clip"], cfg["ent"], cfg["lr"], cfg["lr"], np.random.RandomState(cfg["seed"]), weakest=weakest,
+                on_grad=lambda i, gp, gv: grad64.__setitem__(i, (gp.copy(), gv.copy())),
+                on_step=lambda i, p, v: truth.__setitem__(i, (np.concatenate([t.ravel() for wb in p for t in wb]),
+                                                              np.concatenate([t.ravel() for wb in v for t in wb]),
+                                                              weakest["pol"].copy(), weakest["val"].copy())))
+    n_steps = int(g["n_steps"])
+    assert n_steps == 2
+    hip_grads = []
+    learner.grad_probe = lambda gr: hip_grads.append(gr.detach().cpu().numpy().astype(np.float64))
+    learner.n_epochs = 1
+    c0 = [int(L.rlppo_dbg_counter(k)) for k in (2, 3, 4, 5)]
+    reports = [learner.learn(buf) for _ in range(n_steps)]
+    assert [int(L.rlppo_dbg_counter(k)) - c for k, c in zip((2, 3, 4, 5), c0)] == [n_steps] * 4, "paired / gather-fused / grouped launches did not run"
+    # ---- the first step's batch gradient against the reference's own
+    n_pol = p0.size
+    for tag, mine, t64 in (("policy", hip_grads[0][:n_pol], grad64[0][0]), ("value", hip_grads[0][n_pol:], grad64[0][1])):
+        ref8 = g[f"grad0.{tag}_every8"].astype(np.float64)
+        scale = float(g[f"grad0.{tag}_max"])
+        d_ref = np.abs(mine[::8] - ref8).max() / scale
+        e_hip, e_ref = np.abs(mine - t64).max() / scale, np.abs(ref8 - t64[::8]).max() / scale
+        l2_hip, l2_ref = np.sqrt((mine ** 2).sum()), float(g[f"grad0.{tag}_l2"])
+        small = float((np.abs(t64) < 1e-4 * np.abs(t64).max()).mean())
+        print(f"[direct gate] g5bigb first-step {tag} gradient: |HIP - reference| = {d_ref:.2e} of max|g| (every 8th entry); against float64: HIP {e_hip:.2e} "
+              f"(all entries), reference {e_ref:.2e}; |g|2 HIP {l2_hip:.8e} reference {l2_ref:.8e}; {small:.1%} of the entries below 1e-4 of max|g|")
+        assert d_ref <= 1e-5, (tag, d_ref)
+        assert abs(l2_hip - l2_ref) <= 1e-5 * l2_ref
+        assert abs(np.abs(t64).max() - scale) <= 1e-4 * scale
+    # ---- parameters after both steps against the reference's own (well-conditioned entries: directly)
+    s = n_steps - 1
+    pv, vv = vec(learner.policy).astype(np.float64), vec(learner.value_net).astype(np.float64)
+    tp, tv, wp, wv = truth[s]
+    for tag, got, ref, tr, weak in (("policy", pv, g[f"step{s}.policy"].astype(np.float64), tp, wp), ("value", vv, g[f"step{s}.value"].astype(np.float64), tv, wv)):
+        scale = np.abs(ref).max()
+        d = np.abs(got - ref) / scale
+        ill = weak < 1e-4
+        bound = (s + 1) * cfg["lr"] * np.minimum(1.0, 1e-5 / np.maximum(weak, 1e-300)) / scale
+        frac_hip = float((np.abs(got - tr)[ill] / scale / bound[ill]).max()) if ill.any() else 0.0
+        frac_ref = float((np.abs(ref - tr)[ill] / scale / bound[ill]).max()) if ill.any() else 0.0
+        print(f"[direct gate] g5bigb {tag} parameters after step {s}: |HIP - reference| = {d[~ill].max():.2e} of max|p| on the {int((~ill).sum())} well-conditioned "
+              f"entries, {d[ill].max() if ill.any() else 0.0:.2e} on the {int(ill.sum())} ill-conditioned ones (against float64: HIP {frac_hip:.3f}, reference "
+              f"{frac_ref:.3f} of the derived bound)")
+        assert d[~ill].max() <= 1e-5, (tag, float(d[~ill].max()))
+        assert ill.mean() <= 0.12, (tag, float(ill.mean()))           # (dead units and unused head rows keep some gradients tiny whatever the workload)
+        if ill.any():
+            assert (np.abs(got - ref)[ill] / scale <= 2 * bound[ill] + 1e-5).all()
+    for key in ("Policy Entropy", "Mean KL Divergence", "Value Function Loss", "SB3 Clip Fraction"):
+        got, ref = float(np.mean([r[key] for r in reports])), float(g["report." + key])
+        tol = 4.0 / cfg["B"] if key == "SB3 Clip Fraction" else 2e-5 * max(abs(ref), 1e-4) + 1e-7
+        assert abs(got - ref) <= tol, (key, got, ref)
+
+
+def test_reference_default_batch_of_50000_rows_against_the_oracle():
+    """[r5] The reference's own configuration (learner.py:34-53: ppo_batch_size 50,000, minibatch = batch, buffer 100,000; 256x3): one
+    learn() = 2 optimiser steps of ONE 50,000-row pass each -- 390.6 row tiles (ragged forward / dX launches), no minibatch fusion,
+    no paired launches, the grouped weight-gradient launch on a row count that is no multiple of anything -- against the CPU oracle
+    (the reference's op sequence) on identical inputs: parameters, report and the first step's batch gradient (float64 yardstick
+    for the gradient; the workload is the well-conditioned one of G5big-b, actions uniform)."""
+    from rlgym_ppo_amd import _native as N
+    from rlgym_ppo_amd.ppo import ExperienceBuffer, PPOLearner
+    L = N.lib()
+    n, B, d, A, seed = 100_000, 50_000, 107, 90, 77
+    torch.manual_seed(seed)
+    learner = PPOLearner(d, A, 0, (256, 256, 256), (256, 256, 256), (0.1, 1.0), B, 1, 3e-4, 3e-4, 0.2, 0.005, B, "cuda:0")
+    pol0 = [(l.weight.detach().cpu().clone(), l.bias.detach().cpu().clone()) for l in learner.policy.arena.linears]
+    val0 = [(l.weight.detach().cpu().clone(), l.bias.detach().cpu().clone()) for l in learner.value_net.arena.linears]
+    rs = np.random.RandomState(seed)
+    obs = np.clip(rs.randn(n, d), -5, 5).astype(np.float32)
+    acts = rs.randint(0, A, n)
+    with torch.no_grad():
+        lp = torch.log(nets.discrete_probs(pol0, torch.as_tensor(obs)))[torch.arange(n), torch.as_tensor(acts)].numpy()
+    old = (lp + 0.1 * rs.randn(n)).astype(np.float32)
+    adv = (0.5 * rs.randn(A)[acts] + 0.7 * np.sign(obs[np.arange(n), acts]) + 0.3 * rs.randn(n)).astype(np.float32)
+    tgt = (1.5 * np.sign(obs[:, 0]) + 0.5 * obs[:, 1] + 0.3 * rs.randn(n)).astype(np.float32)
+    z = np.zeros(n, np.float32)
+    buf = ExperienceBuffer(n, seed, "cpu")
+    buf.submit_experience(obs, acts.astype(np.float32), old, z, obs[:1].repeat(n, 0), z, z, tgt, adv)
+    hip_grads = []
+    learner.grad_probe = lambda gr: hip_grads.append(gr.detach().cpu().numpy().astype(np.float64))
+    c0 = [int(L.rlppo_dbg_counter(k)) for k in (2, 3, 5)]
+    report = learner.learn(buf)
+    assert learner._fused_rows == B
+    assert [int(L.rlppo_dbg_counter(k)) - c for k, c in zip((2, 3, 5), c0)] == [2, 0, 2]   # 2 passes, unpaired, grouped weight gradients
+    obuf = dict(states=torch.as_tensor(obs), actions=torch.as_tensor(acts.astype(np.float32)), log_probs=torch.as_tensor(old),
+                values=torch.as_tensor(tgt), advantages=torch.as_tensor(adv))
+    opol, oval = [(w.clone(), b.clone()) for w, b in pol0], [(w.clone(), b.clone()) for w, b in val0]
+    oreport, _, _ = ppo.learn("discrete", opol, oval, obuf, B, B, 1, 0.2, 0.005, 3e-4, 3e-4, np.random.RandomState(seed),
+                              on_step=None)
+    got_p = torch.nn.utils.parameters_to_vector(learner.policy.parameters()).cpu()
+    got_v = torch.nn.utils.parameters_to_vector(learner.value_net.parameters()).cpu()
+    ep, ev = relerr(got_p, nets.flatten(opol)), relerr(got_v, nets.flatten(oval))
+    print(f"[50,000-row learn()] parameters after 2 optimiser steps, HIP against the CPU oracle: policy {ep:.2e}, critic {ev:.2e} of max|p|")
+    # float64 first-step gradient: HIP must be as close to it as the north star asks (1e-5 of max|g|)
+    grad64 = {}
+    ppo.learn64("discrete", pol0, val0, dict(states=obs, actions=acts.astype(np.float32), log_probs=old, values=tgt, advantages=adv), B, B, 1,
+                0.2, 0.005, 3e-4, 3e-4, np.random.RandomState(seed), on_grad=lambda i, gp, gv: grad64.__setitem__(i, (gp.copy(), gv.copy())))
+    n_pol = got_p.numel()
+    for tag, mine, t64 in (("policy", hip_grads[0][:n_pol], grad64[0][0]), ("value", hip_grads[0][n_pol:], grad64[0][1])):
+        e = np.abs(mine - t64).max() / np.abs(t64).max()
+        print(f"[50,000-row learn()] first-step {tag} gradient, HIP against float64: {e:.2e} of max|g|")
+        assert e <= 1e-5, (tag, e)
+    # Adam's normalised step amplifies gradient rounding on the few entries with a tiny gradient: both float32 results get the
+    # same allowance there (2 steps of lr); everything else agrees to 1e-5 of max|p|
+    for tag, got, ref in (("policy", got_p, nets.flatten(opol)), ("value", got_v, nets.flatten(oval))):
+        dd = (got - ref).abs().numpy() / float(ref.abs().max())
+        assert np.quantile(dd, 0.98) <= 1e-5 and dd.max() <= 2 * 3e-4 / float(ref.abs().max()) + 1e-5, (tag, float(np.quantile(dd, 0.98)), float(dd.max()))
+    for k in ("Policy Entropy", "Mean KL Divergence", "Value Function Loss", "SB3 Clip Fraction"):
+        tol = 4.0 / B if k == "SB3 Clip Fraction" else 2e-5 * max(abs(oreport[k]), 1e-4) + 1e-7
+        assert abs(report[k] - oreport[k]) <= tol, (k, report[k], oreport[k])
+
+
 def test_learn_single_call_report_and_magnitudes(golden):
     from rlgym_ppo_amd.ppo import ExperienceBuffer
     g = golden("g5_learn_discrete")
