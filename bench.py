@@ -186,13 +186,17 @@ def kernel_breakdown(learner):
     return rows, dominant, M
 
 
-TRAFFIC_JSON = "r04_traffic.json" if os.path.exists(os.path.join(ROOT, "profiles", "r04_traffic.json")) else "r03_traffic.json"  # tools/pmc_traffic.py output of the committed PMC passes (tools/round_profile.sh)
+# tools/pmc_traffic.py output of the committed PMC passes (tools/round_profile.sh), newest round first.  Every `traffic` on the JSON
+# line is READ FROM THESE FILES (builder-run rocprofv3 --pmc passes: bench.py cannot profile itself) and carries a `traffic_source`.
+TRAFFIC_JSON = next((t + "_traffic.json" for t in ("r05", "r04", "r03") if os.path.exists(os.path.join(ROOT, "profiles", t + "_traffic.json"))), "r03_traffic.json")
+PMC_NOTE = " (builder-run rocprofv3 --pmc pass, not measured in this run)"
 
 
 def pmc_traffic_for(kernel_label):
     """HBM bytes per launch of the dominant kernel, from the committed PMC passes (bench.py cannot run rocprofv3 on itself)."""
     path = os.path.join(ROOT, "profiles", TRAFFIC_JSON)
-    key = {"dW hidden 256x256": "rlppo::gemm_tn_dma_kernel<32, 4, 4, 2, false>",
+    key = {"dW all 7 products, grouped + reduce": "rlppo::gemm_tn_group_kernel",
+           "dW hidden 256x256": "rlppo::gemm_tn_dma_kernel<32, 4, 4, 2, false>",
            "dW L0 256x107": "rlppo::gemm_tn_dma_kernel<32, 2, 7, 4, false>",
            "dW head 90x256": "rlppo::gemm_tn_dma_kernel<32, 3, 4, 2, false>",
            "fwd hidden 256->256": "rlppo::gemm_nt_dma_kernel<8, 1, 16, true, false> {fwd hidden 256->256}",
@@ -204,21 +208,48 @@ def pmc_traffic_for(kernel_label):
         # tools/prof_kernels.py launches the same shapes as kernel_breakdown (M = 524,288 rows); tools/pmc_summary.py tells the
         # three dW shapes (same kernel, same grid) apart by their position in the launch cycle
         t = json.load(open(path))
-        return round(t[key]["hbm_bytes"]), "profiles/" + TRAFFIC_JSON
+        return round(t[key]["hbm_bytes"]), "profiles/" + TRAFFIC_JSON + PMC_NOTE
     except Exception:
         return None, "no committed PMC pass for this kernel"
+
+
+def non_gemm_tail():
+    """The update's non-GEMM kernels (loss, the critic head's matrix-vector kernels, reductions, optimiser tail, gather) per epoch,
+    from the newest committed single-stream kernel trace of `bench.py --steps 2 --warmup 1 --no-extras` (3 learn() x 10 epochs = 30
+    passes; tools/round_profile.sh): {kernel: us per epoch}.  Like `traffic`, read from profiles/ -- bench.py cannot trace itself."""
+    import csv
+    for tag in ("r05", "r04", "r03"):
+        path = os.path.join(ROOT, "profiles", tag + "_bench_kernel_stats_single_stream.csv")
+        if not os.path.exists(path):
+            continue
+        try:
+            rows, tail = list(csv.DictReader(open(path))), {}
+            adam = [r for r in rows if "adam_fused_kernel" in r["Name"] or "adam_pack2_kernel" in r["Name"]]
+            passes = int(adam[0]["Calls"]) if adam else 30
+            for r in rows:
+                name = r["Name"].replace("void ", "")
+                if not name.startswith("rlppo::") or "gemm_nt" in name or "gemm_tn" in name or int(r["Calls"]) < passes:
+                    continue
+                short = name.split("(")[0].replace("rlppo::", "")
+                tail[short] = round(tail.get(short, 0.0) + float(r["TotalDurationNs"]) / passes / 1e3, 1)
+            return dict(us_per_epoch=tail, total_us_per_epoch=round(sum(tail.values()), 1),
+                        source="profiles/" + tag + "_bench_kernel_stats_single_stream.csv (builder-run rocprofv3 --kernel-trace --stats, single stream)")
+        except Exception:
+            continue
+    return dict(us_per_epoch=None, source="no committed kernel trace")
 
 
 def gae_traffic():
     """HBM bytes per scan from the committed PMC passes over tools/prof_gae.py (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE),
     newest round first; round 4's passes rotate over GAE_SETS buffer sets exactly as the timed region below does."""
     try:
-        for tag in ("r04", "r03", "r02"):
+        for tag in ("r05", "r04", "r03", "r02"):
             p = os.path.join(ROOT, "profiles", tag + "_gae_traffic.json")
             if os.path.exists(p):
-                return round(json.load(open(p))["rlppo::gae_lookback_kernel<false>"]["hbm_bytes"])
+                return round(json.load(open(p))["rlppo::gae_lookback_kernel<false>"]["hbm_bytes"]), "profiles/" + tag + "_gae_traffic.json" + PMC_NOTE
     except Exception:
-        return None
+        pass
+    return None, "no committed PMC pass"
 
 
 GAE_SETS = 10  # buffer sets the cold measurement rotates over: 10 x 58.7 MB of inputs + outputs = 587 MB between two uses of a
@@ -315,7 +346,7 @@ def gae_bench():
     cp_hot = float(np.median([time_region(cps[0], 20, warm=2) for _ in range(5)]))
     del pairs, cps
     alg_bytes = 28 * n
-    traffic = gae_traffic()
+    traffic, traffic_src = gae_traffic()
     frac = lambda ms: round(alg_bytes / ms / 1e6 / HBM_PEAK_GBS, 4)
     log("gae: cold %.2f us (%.3f of 8 TB/s), hot %.2f us (%.3f); two-launch form cold %.2f / hot %.2f us; device copy of the same "
         "bytes cold %.2f us (%.3f) / hot %.2f us (%.3f).  cold = %d rotating input+output sets (%.0f MB between two uses of a line), "
@@ -327,7 +358,7 @@ def gae_bench():
                us_copy_same_bytes=round(cp_cold * 1e3, 2), us_copy_same_bytes_hot=round(cp_hot * 1e3, 2),
                steps_per_s=round(n / ms_cold * 1e3),
                roofline=dict(bound="hbm", achieved=round(alg_bytes / ms_cold / 1e6, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=frac(ms_cold),
-                             traffic=traffic, algorithmic_bytes=alg_bytes, hot_frac=frac(ms_hot), copy_frac=frac(cp_cold)))
+                             traffic=traffic, traffic_source=traffic_src, algorithmic_bytes=alg_bytes, hot_frac=frac(ms_hot), copy_frac=frac(cp_cold)))
     del fns, sets
     torch.cuda.empty_cache()
     # CPU side: the C port and the interpreter-bound Python form (the reference runs a Python loop) on bounded samples, 1 thread
@@ -524,7 +555,7 @@ def ref_defaults_leg(device, seed=123):
     rows, dom, _ = kernel_breakdown(learner)
     out["kernel_breakdown_50000_rows"] = [dict(kernel=r["kernel"], n=r["n"], ms=r["ms"], frac=r["frac"]) for r in rows if r["n"]]
     out["roofline"] = dict(bound="mfma", achieved=dom["tflops"], peak=MFMA_F32_PEAK_TF, unit="TFLOP/s", frac=round(dom["tflops"] / MFMA_F32_PEAK_TF, 4),
-                           traffic=None, kernel=dom["kernel"], ms_per_launch=dom["ms"], rows_per_launch=B)
+                           traffic=None, traffic_source="no PMC pass at this row count", kernel=dom["kernel"], ms_per_launch=dom["ms"], rows_per_launch=B)
     out["workload"] = "reference defaults: buffer 150,000, ppo_batch_size = ppo_minibatch_size = 50,000, 256x3 policy + critic, obs 107, 90 actions, fp32"
     log("ref_defaults: GPU %.2f M samples/s (1 epoch) / %.2f M (10 epochs); CPU oracle, identical workload: %.0f / %.0f samples/s; params rel %.2e / %.2e"
         % (out["epochs_1"]["value"] / 1e6, out["epochs_10"]["value"] / 1e6, out["cpu_baseline"]["epochs_1"], out["cpu_baseline"]["epochs_10"],
@@ -659,9 +690,10 @@ def cfg5_rooflines(value, bf16, learner, full=True):
            "update_flop_efficiency": dict(achieved=round(tf, 1), peak=peak, unit="TFLOP/s", frac=round(tf / peak, 4))}
     dom = rows[0]
     bound = dom["binds"]
+    c5_traffic, c5_src = cfg5_traffic(bf16)
     out["roofline"] = dict(bound=bound, achieved=dom["gb_per_s"] if bound == "hbm" else dom["tflops"],
                            peak=HBM_PEAK_GBS if bound == "hbm" else dom["mfma_peak"], unit="GB/s" if bound == "hbm" else "TFLOP/s",
-                           frac=dom["frac_hbm"] if bound == "hbm" else dom["frac_mfma"], traffic=cfg5_traffic(bf16), kernel=dom["kernel"],
+                           frac=dom["frac_hbm"] if bound == "hbm" else dom["frac_mfma"], traffic=c5_traffic, traffic_source=c5_src, kernel=dom["kernel"],
                            algorithmic_bytes=round(dom["alg_mb"] * 1e6),
                            other_bound=dict(bound="mfma" if bound == "hbm" else "hbm", frac=dom["frac_mfma"] if bound == "hbm" else dom["frac_hbm"]),
                            ms_per_launch=dom["ms"])
@@ -676,16 +708,16 @@ def cfg5_traffic(bf16):
     (tools/round_profile.sh: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), newest round first; None for the fp32 precision (its
     kernels are the cfg2 ones at K = 512: no pass of their own)."""
     if not bf16:
-        return None
-    for tag in ("r04", "r03", "r02"):
+        return None, "no PMC pass (the fp32 precision runs the cfg2 kernels at K = 512)"
+    for tag in ("r05", "r04", "r03", "r02"):
         try:
             t = json.load(open(os.path.join(ROOT, "profiles", tag + "_cfg5_bf16_traffic.json")))
         except Exception:
             continue
         for k, v in t.items():
             if "gemm_nt_b16" in k and ("<1," in k or "<1>" in k or "fwd" in k):
-                return round(v["hbm_bytes"])
-    return None
+                return round(v["hbm_bytes"]), "profiles/" + tag + "_cfg5_bf16_traffic.json" + PMC_NOTE
+    return None, "no committed PMC pass"
 
 
 def cfg5_leg(device, steps=2, warmup=1):
@@ -1020,10 +1052,19 @@ def main():
         report = learner.learn(buf)
     barrier()
     dt = time.perf_counter() - t0
+    per_rank = None
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        # every rank's own time travels to every rank (a sum of one-hot vectors): the line reports the MAX (the contract) and the
+        # spread, so a straggler is visible in the driver's record
+        t = torch.zeros(world, dtype=torch.float64, device=device)
+        t[rank] = dt
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        ts = [float(x) for x in t.tolist()]
+        dt = max(ts)
+        per_rank = dict(min=round(min(ts) / args.steps * 1e3, 3), max=round(dt / args.steps * 1e3, 3),
+                        all=[round(x / args.steps * 1e3, 3) for x in ts])
+        if rank == 0:
+            log("per-rank ms per step: " + ", ".join("%.3f" % x for x in per_rank["all"]) + " (value uses the max)")
 
     samples = args.steps * args.epochs * (N_SAMPLES // BATCH) * BATCH
     value = samples / dt
@@ -1034,7 +1075,7 @@ def main():
         workload = ("configs[4]: 524,288-sample buffer, obs 231 f32, Gaussian 8 actions, 512x4 policy + critic, " +
                     ("bf16 update precision (bf16 MFMA operands forward and backward, fp32 accumulate / loss / dW / Adam / master weights)" if bf16 else "fp32 update") +
                     "; batch 524,288, minibatch 65,536")
-    per_rank = 8 // world if 8 % world == 0 else 1
+    slices_per_rank = 8 // world if 8 % world == 0 else 1
     out = {
         "metric": "ppo_update_samples_per_sec", "value": round(value, 1), "unit": "samples/s", "n_gpus": n_seen,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
@@ -1042,7 +1083,7 @@ def main():
         "dtype": "bf16" if bf16 else ("f32 (hidden forward / dX products split into bf16 pieces, opt-in)" if args.precision == "x3" else "f32"),
         "data": "synthetic" + (" (DRY RUN: all ranks on one GPU over gloo, not a measurement)" if dryrun else ""),
         "config": {"workload": workload, "epochs_per_step": args.epochs, "samples_per_step": args.epochs * BATCH,
-                   "parallelism": f"dp{world}: {per_rank} minibatch slice(s) per rank and pass, 1 RCCL all-reduce per optimiser step"
+                   "parallelism": f"dp{world}: {slices_per_rank} minibatch slice(s) per rank and pass, 1 RCCL all-reduce per optimiser step"
                                   + (f" ({args.allreduce if args.allreduce != 'ab' else 'torch'}.distributed)" if world > 1 else ""),
                    "last_report": {k: (round(v, 5) if isinstance(v, float) else v) for k, v in report.items()}},
     }
@@ -1062,6 +1103,7 @@ def main():
 
     if world > 1:
         out["allreduce_us"] = allreduce_us  # the update's 1.37 MB exchange alone, warm, measured before the timed region (rank 0's view)
+        out["per_rank_ms_per_step"] = per_rank
     if world > 1 and args.allreduce == "ab" and dry != "2":  # opt-in (the one-GPU dry run walks through it too: both legs then go through gloo)
         # The direct communicator has its first multi-rank run here, so the JSON line is printed FIRST and the A/B reports on
         # stderr.  A watchdog thread ends the process if the A/B has not finished within 120 s or as soon as SIGTERM arrives (the
@@ -1100,11 +1142,12 @@ def main():
             "HBM bytes per launch from rocprofv3 PMC (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE): %s.  update_flop_efficiency = 1,931,776 "
             "algorithmic flop/sample x measured samples/s (whole learn(), host shuffle included)" % (M, traffic_src))
         out["roofline"] = dict(bound="mfma", achieved=dom["tflops"], peak=MFMA_F32_PEAK_TF, unit="TFLOP/s",
-                               frac=round(dom["tflops"] / MFMA_F32_PEAK_TF, 4), traffic=traffic, kernel=dom["kernel"],
+                               frac=round(dom["tflops"] / MFMA_F32_PEAK_TF, 4), traffic=traffic, traffic_source=traffic_src, kernel=dom["kernel"],
                                algorithmic_gflop_per_launch=dom["gflop"], ms_per_launch=dom["ms"], rows_per_launch=M)
         out["update_flop_efficiency"] = dict(achieved=round(FLOP_PER_SAMPLE * value / 1e12, 2), peak=MFMA_F32_PEAK_TF, unit="TFLOP/s",
                                              frac=round(FLOP_PER_SAMPLE * value / 1e12 / MFMA_F32_PEAK_TF, 4))
         out["kernel_breakdown"] = rows
+        out["non_gemm_tail"] = non_gemm_tail()
         out["update_x3"] = x3_leg(learner, buf, args.epochs)
         out["gae"] = gae_bench()
         out["rollout"] = rollout_bench(learner)

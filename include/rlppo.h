@@ -47,6 +47,13 @@ extern "C" {
 #define RLPPO_HEAD_MULTIDISCRETE 1
 #define RLPPO_HEAD_GAUSSIAN 2
 
+/* precision of a call (rlppo_act_opts.precision, rlppo_minibatch_args.precision): 0 = the process default set with
+ * rlppo_set_inference_precision / rlppo_set_update_precision, else 1 + that setter's mode */
+#define RLPPO_PRECISION_DEFAULT 0
+#define RLPPO_PRECISION_FP32 1
+#define RLPPO_PRECISION_BF16 2
+#define RLPPO_PRECISION_X3 3   /* update only: fp32 with split-bf16 hidden products */
+
 int rlppo_abi_version(void);
 const char *rlppo_last_error(void);
 
@@ -79,6 +86,26 @@ int rlppo_pad_rows_per_feature(void *stream, const void *src, int32_t src_is_f64
 
 /* ------------------------------------------------------------------------------------ rollout inference */
 
+/* [r5] Per-call options of the rollout entry points below (their last parameter; NULL = all defaults).
+ *   precision: the inference precision of THIS call -- RLPPO_PRECISION_DEFAULT (what rlppo_set_inference_precision chose for the
+ *     process), RLPPO_PRECISION_FP32 or RLPPO_PRECISION_BF16 (operands rounded to bf16, fp32 accumulate): two policies of one
+ *     process may act in different precisions.
+ *   done_words / done_value: completion without a stream synchronisation.  done_words (optional) points at rlppo_act_done_words(n)
+ *     uint32 in HOST-VISIBLE memory (pinned / page-locked, coherent); word b receives done_value -- stored with release semantics
+ *     at system scope -- once every output of rows 16 b .. 16 b + 15 is visible to the host (the one-launch kernel of
+ *     rlppo_discrete_act / _step stores it itself, workgroup by workgroup; the layer chains append one tiny launch that stores them
+ *     all).  A host whose outputs live in pinned memory clears the words, makes the call and polls them (rlppo_host_wait_words)
+ *     instead of hipStreamSynchronize: batched_agent_manager.py:202-204 calls get_action on 8-80 observations per environment
+ *     step, where the synchronisation was a third of the call. */
+typedef struct rlppo_act_opts {
+    int32_t precision;
+    uint32_t done_value;
+    uint32_t *done_words;
+} rlppo_act_opts;
+int64_t rlppo_act_done_words(int64_t n);
+/* HOST: spins until words[0..count) all hold `value` (acquire loads) or timeout_us has passed; 0 = all there, 1 = timed out. */
+int rlppo_host_wait_words(const uint32_t *words, int64_t count, uint32_t value, int64_t timeout_us);
+
 /* Bytes of workspace needed by the forward entry points for `n` rows. */
 size_t rlppo_forward_workspace_bytes(const int32_t *dims, int32_t n_layers, int64_t n);
 
@@ -86,7 +113,7 @@ size_t rlppo_forward_workspace_bytes(const int32_t *dims, int32_t n_layers, int6
  * Replaces nn.Sequential.forward of value_estimator.py:30-36 / the body of *_policy.get_output. */
 int rlppo_mlp_forward(void *stream, const int32_t *dims, int32_t n_layers, const float *packed,
                       const float *obs, int64_t ld_obs, int64_t n, int32_t out_tanh,
-                      float *out, int64_t ld_out, void *workspace, size_t ws_bytes);
+                      float *out, int64_t ld_out, void *workspace, size_t ws_bytes, const rlppo_act_opts *opts);
 
 /* DiscreteFF.get_action (discrete_policy.py:44-62): forward, softmax, clamp(1e-11,1), action =
  * argmax_a(p_a / q_a) with the caller's Exp(1) noise q[n][n_actions] (== torch.multinomial(p,1,True), SURVEY
@@ -94,7 +121,7 @@ int rlppo_mlp_forward(void *stream, const int32_t *dims, int32_t n_layers, const
  * probs_out (optional, may be NULL): float[n][n_actions]. */
 int rlppo_discrete_act(void *stream, const int32_t *dims, int32_t n_layers, const float *packed,
                        const float *obs, int64_t ld_obs, int64_t n, const float *noise_q,
-                       int64_t *actions, float *logp, float *probs_out, void *workspace, size_t ws_bytes);
+                       int64_t *actions, float *logp, float *probs_out, void *workspace, size_t ws_bytes, const rlppo_act_opts *opts);
 
 /* The whole rollout step of the discrete policy [r3] (discrete_policy.py:35-62 behind batched_agent_manager.py:202-204,303-315):
  * raw observations as the environment hands them over ([n][ld_obs] fp32 or fp64, d = dims[0] features) -> standardise
@@ -109,7 +136,7 @@ size_t rlppo_discrete_step_workspace_bytes(const int32_t *dims, int32_t n_layers
 int rlppo_discrete_step(void *stream, const int32_t *dims, int32_t n_layers, const float *packed, const void *obs, int32_t obs_is_f64,
                         int64_t ld_obs, int64_t n, int32_t standardize, float mean0, float std0, const float *mean_v,
                         const float *std_v, const float *noise_q, int64_t *actions, float *actions_f32, float *logp, float *rows_out,
-                        int64_t ld_rows_out, void *workspace, size_t ws_bytes);
+                        int64_t ld_rows_out, void *workspace, size_t ws_bytes, const rlppo_act_opts *opts);
 
 /* DiscreteFF.get_output (discrete_policy.py:34-42) and the deterministic branch of get_action (:52-57).
  * probs_out (optional): float[n][ld_probs] = softmax of the head (clamp_probs = 0, get_output) or clamp(softmax, 1e-11, 1)
@@ -118,7 +145,7 @@ int rlppo_discrete_step(void *stream, const int32_t *dims, int32_t n_layers, con
  * n * n_actions < 2^32).  At least one of the two outputs must be given.  Workspace: rlppo_forward_workspace_bytes. */
 int rlppo_discrete_probs(void *stream, const int32_t *dims, int32_t n_layers, const float *packed,
                          const float *obs, int64_t ld_obs, int64_t n, int32_t clamp_probs, float *probs_out,
-                         int64_t ld_probs, int64_t *flat_argmax, void *workspace, size_t ws_bytes);
+                         int64_t ld_probs, int64_t *flat_argmax, void *workspace, size_t ws_bytes, const rlppo_act_opts *opts);
 
 /* The selection step alone on caller-supplied probabilities p[n][ld_p] (used by tests to show index equality
  * is exact given identical probs, and by the multi-discrete head with n*8 rows of 3). */
@@ -131,13 +158,13 @@ int rlppo_categorical_select(void *stream, const float *probs, int64_t ld_p, int
  * dims[n_layers] == 2k.  actions: float[n][k]; logp: float[n]. */
 int rlppo_gaussian_act(void *stream, const int32_t *dims, int32_t n_layers, const float *packed,
                        const float *obs, int64_t ld_obs, int64_t n, const float *noise_eps, float var_m, float var_b,
-                       float *actions, float *logp, void *workspace, size_t ws_bytes);
+                       float *actions, float *logp, void *workspace, size_t ws_bytes, const rlppo_act_opts *opts);
 
 /* MultiDiscreteFF.get_action (multi_discrete_policy.py:46-74, torch_functions.py:93-122): 21 logits -> 8
  * categoricals (5x3 + 3x2); noise_q[n*8][3] as Categorical.sample draws it; actions int64[n][8]; logp[n]. */
 int rlppo_multidiscrete_act(void *stream, const int32_t *dims, int32_t n_layers, const float *packed,
                             const float *obs, int64_t ld_obs, int64_t n, const float *noise_q,
-                            int64_t *actions, float *logp, void *workspace, size_t ws_bytes);
+                            int64_t *actions, float *logp, void *workspace, size_t ws_bytes, const rlppo_act_opts *opts);
 
 /* ---------------------------------------------------------------------------------------------- GAE */
 
@@ -161,10 +188,6 @@ int rlppo_gae(void *stream, const float *rews, const float *dones, const float *
 
 size_t rlppo_minibatch_workspace_bytes(const int32_t *pol_dims, int32_t pol_layers, const int32_t *val_dims,
                                        int32_t val_layers, int64_t mb);
-#define RLPPO_PRECISION_DEFAULT 0
-#define RLPPO_PRECISION_FP32 1
-#define RLPPO_PRECISION_BF16 2
-#define RLPPO_PRECISION_X3 3
 size_t rlppo_minibatch_workspace_bytes_for(const int32_t *pol_dims, int32_t pol_layers, const int32_t *val_dims, int32_t val_layers,
                                            int64_t mb, int32_t precision);
 
@@ -392,7 +415,11 @@ int rlppo_net_pack_bf16(void *stream, const int32_t *dims, int32_t n_layers, con
  * apart from the accumulator (csrc/gemm_split.hip).  gfx950's fp32-input MFMA has 1/16 of the bf16 rate; this form is 1.35 x
  * faster per launch and, against float64, MORE accurate than the fp32 MFMA's fmaf chain (0.43-0.46 x its error at K = 256).  The
  * gradients then differ from mode 0's by fp32 rounding noise only (tests/test_gpu_kernels.py, tests/test_gpu_learner.py hold
- * mode 2 to the same float64 gates as mode 0).  Needs, per network, the image rlppo_net_pack_x3 derives from the PACKED copy
+ * mode 2 to the same float64 gates as mode 0) -- for FINITE operands of ordinary magnitude: a +-inf, a NaN or a finite
+ * |x| >= 3.396e38 (it rounds to a bf16 infinity) makes x - bf16(x) an inf - inf, so every output of that ROW is NaN where the fp32 MFMA
+ * returns +-inf (or a finite product); pieces of |x| below ~1e-33 fall under bf16's normal range and lose low bits (an error relative
+ * to 1e-38, not to the data).  Clipped observations and ReLU activations never get there; test_gemm_nt_x3_special_values
+ * (tests/test_gpu_kernels.py) pins this behaviour.  Needs, per network, the image rlppo_net_pack_x3 derives from the PACKED copy
  * after every optimiser step: rlppo_x3_elems bf16 values (the stage-major planes [K / 32][3][N / 16][1 KiB block] of W for every
  * covered forward and of W^T for every covered dX; inside a 16-row block the 16-byte chunk (row r, k quarter q) at chunk
  * 4 r + (q ^ (-(r / 4) & 3)): the image the kernels' LDS fragment reads are bank-conflict-free on), handed over in rlppo_minibatch_args.pol_wb16 / val_wb16.  Policy and critic run as two

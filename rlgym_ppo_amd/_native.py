@@ -40,6 +40,11 @@ class OptNet(ctypes.Structure):
     ]
 
 
+class ActOpts(ctypes.Structure):
+    """struct rlppo_act_opts (include/rlppo.h)."""
+    _fields_ = [("precision", c_int32), ("done_value", c_uint32), ("done_words", c_void_p)]
+
+
 class TnProduct(ctypes.Structure):
     """struct rlppo_tn_product (include/rlppo.h)."""
     _fields_ = [
@@ -64,6 +69,7 @@ class MinibatchArgs(ctypes.Structure):
 
 
 _P32 = POINTER(c_int32)
+_PACT = POINTER(ActOpts)
 # name -> (restype, argtypes); kept in one table so tests can check it against the header's declarations
 SIGNATURES = {
     "rlppo_abi_version": (c_int32, []),
@@ -79,19 +85,21 @@ SIGNATURES = {
                                              c_void_p]),
     "rlppo_forward_workspace_bytes": (c_size_t, [_P32, c_int32, c_int64]),
     "rlppo_mlp_forward": (c_int32, [c_void_p, _P32, c_int32, c_void_p, c_void_p, c_int64, c_int64, c_int32, c_void_p,
-                                    c_int64, c_void_p, c_size_t]),
+                                    c_int64, c_void_p, c_size_t, _PACT]),
     "rlppo_discrete_act": (c_int32, [c_void_p, _P32, c_int32, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p,
-                                     c_void_p, c_void_p, c_void_p, c_size_t]),
+                                     c_void_p, c_void_p, c_void_p, c_size_t, _PACT]),
     "rlppo_discrete_step_workspace_bytes": (c_size_t, [_P32, c_int32, c_int64]),
     "rlppo_discrete_step": (c_int32, [c_void_p, _P32, c_int32, c_void_p, c_void_p, c_int32, c_int64, c_int64, c_int32, c_float, c_float,
-                                      c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_size_t]),
+                                      c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_size_t, _PACT]),
     "rlppo_discrete_probs": (c_int32, [c_void_p, _P32, c_int32, c_void_p, c_void_p, c_int64, c_int64, c_int32, c_void_p,
-                                       c_int64, c_void_p, c_void_p, c_size_t]),
+                                       c_int64, c_void_p, c_void_p, c_size_t, _PACT]),
     "rlppo_categorical_select": (c_int32, [c_void_p, c_void_p, c_int64, c_int64, c_int32, c_void_p, c_void_p, c_void_p]),
     "rlppo_gaussian_act": (c_int32, [c_void_p, _P32, c_int32, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_float,
-                                     c_float, c_void_p, c_void_p, c_void_p, c_size_t]),
+                                     c_float, c_void_p, c_void_p, c_void_p, c_size_t, _PACT]),
     "rlppo_multidiscrete_act": (c_int32, [c_void_p, _P32, c_int32, c_void_p, c_void_p, c_int64, c_int64, c_void_p,
-                                          c_void_p, c_void_p, c_void_p, c_size_t]),
+                                          c_void_p, c_void_p, c_void_p, c_size_t, _PACT]),
+    "rlppo_act_done_words": (c_int64, [c_int64]),
+    "rlppo_host_wait_words": (c_int32, [c_void_p, c_int64, c_uint32, c_int64]),
     "rlppo_gae_workspace_bytes": (c_size_t, [c_int64]),
     "rlppo_gae": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_double, c_double, c_float,
                             c_void_p, c_void_p, c_void_p, c_void_p, c_size_t]),

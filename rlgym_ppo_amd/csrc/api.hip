@@ -105,7 +105,7 @@ static int g_fold_vhead = 1;  // rlppo_dbg_set(32, 0/1): a one-output head insid
 static int forward(hipStream_t st, const NetLayout &net, const float *packed, const float *obs, int64_t ld_obs, int64_t n,
                    int out_tanh, float *const *acts, int bf16_operands = 0, unsigned long long *const *bits = nullptr,
                    bool *have_bits = nullptr, const unsigned *rowtab = nullptr, int64_t src_rows = 0, bool *head_folded = nullptr,
-                   const unsigned short *x3 = nullptr) {
+                   const unsigned short *x3 = nullptr, bool head_prezeroed = false) {
     X3Layout xl;
     if (x3) x3_layout(net, &xl);
     if (have_bits)
@@ -136,7 +136,7 @@ static int forward(hipStream_t st, const NetLayout &net, const float *packed, co
                 NtDot dots[2];
                 const bool fold_here = fold && l == hl - 1;
                 if (fold_here) {
-                    RLPPO_HIP(hipMemsetAsync(acts[hl], 0, (size_t)n * sizeof(float), st));
+                    if (!head_prezeroed) RLPPO_HIP(hipMemsetAsync(acts[hl], 0, (size_t)n * sizeof(float), st));
                     dots[0].w = packed + net.L[hl].off_w;
                     dots[0].b = packed + net.L[hl].off_b;
                     dots[0].out = acts[hl];
@@ -241,7 +241,7 @@ static size_t forward_ws_floats(const NetLayout &net, int64_t n) { return (size_
 // runs the net with ping-pong buffers from the workspace and returns the pointer/ld of the last layer's output
 static int forward_pingpong(hipStream_t st, const NetLayout &net, const float *packed, const float *obs, int64_t ld_obs,
                             int64_t n, int out_tanh, void *ws, size_t ws_bytes, float *final_out, const float **out,
-                            int64_t *ld_out) {
+                            int64_t *ld_out, int bf16_operands) {
     if (ws_bytes < forward_ws_floats(net, n) * sizeof(float)) {
         set_error("forward: workspace %zu < %zu bytes", ws_bytes, forward_ws_floats(net, n) * sizeof(float));
         return RLPPO_ERR_WORKSPACE;
@@ -253,7 +253,7 @@ static int forward_pingpong(hipStream_t st, const NetLayout &net, const float *p
     float *acts[RLPPO_MAX_LAYERS];
     for (int l = 0; l < net.n_layers; ++l) acts[l] = (l & 1) ? b1 : b0;
     if (final_out) acts[net.n_layers - 1] = final_out;
-    int rc = forward(st, net, packed, obs, ld_obs, n, out_tanh, acts, get_infer_bf16());  // inference only
+    int rc = forward(st, net, packed, obs, ld_obs, n, out_tanh, acts, bf16_operands);  // inference only
     if (rc) return rc;
     *out = acts[net.n_layers - 1];
     *ld_out = net.L[net.n_layers - 1].pout;
@@ -271,6 +271,28 @@ static std::atomic<long long> g_cnt_fused_act{0}, g_cnt_act_chain{0}, g_cnt_pair
 // the round's fill.  Measured (tools/act_kernel_time.py): 64 rows 26 us (chain 70), 4096 rows 29 us (chain 75), 16,384 rows 100 us
 // (chain 86): beyond two rounds the layer-by-layer GEMMs, which fill the chip, win.
 constexpr int64_t FUSED_ACT_MAX_ROWS = 8192;
+
+// [r5] per-call options of the rollout entry points (rlppo_act_opts): the inference precision of THIS call, and the words the call
+// stores into host-visible memory once every output is visible (the host polls them instead of synchronising the stream)
+struct ActCtx {
+    int bf16 = 0;
+    unsigned *done = nullptr;
+    unsigned done_value = 0;
+};
+static int act_ctx(const rlppo_act_opts *o, ActCtx *c) {
+    c->bf16 = get_infer_bf16();
+    if (!o) return 0;
+    RLPPO_CHECK_ARG(o->precision == RLPPO_PRECISION_DEFAULT || o->precision == RLPPO_PRECISION_FP32 || o->precision == RLPPO_PRECISION_BF16,
+                    "act options: inference precision %d (0 = process default, 1 = fp32, 2 = bf16 operands)", o->precision);
+    if (o->precision != RLPPO_PRECISION_DEFAULT) c->bf16 = o->precision == RLPPO_PRECISION_BF16;
+    c->done = o->done_words;
+    c->done_value = o->done_value;
+    return 0;
+}
+// the completion words of a call whose last launch does not write them itself: one more (tiny) launch behind it
+static int act_done(hipStream_t st, const ActCtx &c, int64_t n) {
+    return c.done ? launch_signal_words(st, c.done, (int)rlppo_act_done_words(n), c.done_value) : 0;
+}
 
 extern "C" {
 
@@ -323,9 +345,12 @@ size_t rlppo_forward_workspace_bytes(const int32_t *dims, int32_t n_layers, int6
 
 int rlppo_mlp_forward(void *stream, const int32_t *dims, int32_t n_layers, const float *packed, const float *obs,
                       int64_t ld_obs, int64_t n, int32_t out_tanh, float *out, int64_t ld_out, void *workspace,
-                      size_t ws_bytes) {
+                      size_t ws_bytes, const rlppo_act_opts *opts) {
     NetLayout net;
     int rc = make_layout(dims, n_layers, &net);
+    if (rc) return rc;
+    ActCtx cx;
+    rc = act_ctx(opts, &cx);
     if (rc) return rc;
     if (n == 0) return 0;
     RLPPO_CHECK_ARG(n > 0 && packed && obs && out && workspace, "mlp_forward: bad argument");
@@ -333,20 +358,24 @@ int rlppo_mlp_forward(void *stream, const int32_t *dims, int32_t n_layers, const
                     (long)ld_out, net.L[n_layers - 1].pout);
     const float *o;
     int64_t ldo;
-    return forward_pingpong((hipStream_t)stream, net, packed, obs, ld_obs, n, out_tanh, workspace, ws_bytes, out, &o, &ldo);
+    rc = forward_pingpong((hipStream_t)stream, net, packed, obs, ld_obs, n, out_tanh, workspace, ws_bytes, out, &o, &ldo, cx.bf16);
+    return rc ? rc : act_done((hipStream_t)stream, cx, n);
 }
 
 int rlppo_discrete_act(void *stream, const int32_t *dims, int32_t n_layers, const float *packed, const float *obs,
                        int64_t ld_obs, int64_t n, const float *noise_q, int64_t *actions, float *logp, float *probs_out,
-                       void *workspace, size_t ws_bytes) {
+                       void *workspace, size_t ws_bytes, const rlppo_act_opts *opts) {
     NetLayout net;
     int rc = make_layout(dims, n_layers, &net);
+    if (rc) return rc;
+    ActCtx cx;
+    rc = act_ctx(opts, &cx);
     if (rc) return rc;
     if (n == 0) return 0;
     RLPPO_CHECK_ARG(n > 0 && packed && obs && noise_q && actions && logp && workspace, "discrete_act: bad argument");
     // [r3] one launch for the whole step when the network has the form fused_act.hip covers (fp32 inference precision); the
     // layer-by-layer chain below otherwise -- bit-identical results either way
-    if (g_fused_act && !get_infer_bf16() && fused_act_ok(net) && n <= FUSED_ACT_MAX_ROWS && ld_obs >= net.L[0].pin && ld_obs % 4 == 0 &&
+    if (g_fused_act && !cx.bf16 && fused_act_ok(net) && n <= FUSED_ACT_MAX_ROWS && ld_obs >= net.L[0].pin && ld_obs % 4 == 0 &&
         (reinterpret_cast<uintptr_t>(obs) & 15) == 0) {  // (the kernel stages the padded rows with 16-byte loads)
         FusedActIO io;
         io.rows = obs;
@@ -355,15 +384,18 @@ int rlppo_discrete_act(void *stream, const int32_t *dims, int32_t n_layers, cons
         io.actions = actions;
         io.logp = logp;
         io.probs_out = probs_out;
+        io.done_words = cx.done;
+        io.done_value = cx.done_value;
         ++g_cnt_fused_act;
         return launch_discrete_act_fused((hipStream_t)stream, net, packed, io, n);
     }
     ++g_cnt_act_chain;
     const float *o;
     int64_t ldo;
-    rc = forward_pingpong((hipStream_t)stream, net, packed, obs, ld_obs, n, 0, workspace, ws_bytes, nullptr, &o, &ldo);
+    rc = forward_pingpong((hipStream_t)stream, net, packed, obs, ld_obs, n, 0, workspace, ws_bytes, nullptr, &o, &ldo, cx.bf16);
     if (rc) return rc;
-    return launch_discrete_sample_logits((hipStream_t)stream, o, ldo, n, dims[n_layers], noise_q, actions, logp, probs_out);
+    rc = launch_discrete_sample_logits((hipStream_t)stream, o, ldo, n, dims[n_layers], noise_q, actions, logp, probs_out);
+    return rc ? rc : act_done((hipStream_t)stream, cx, n);
 }
 
 size_t rlppo_discrete_step_workspace_bytes(const int32_t *dims, int32_t n_layers, int64_t n) {
@@ -376,9 +408,12 @@ size_t rlppo_discrete_step_workspace_bytes(const int32_t *dims, int32_t n_layers
 int rlppo_discrete_step(void *stream, const int32_t *dims, int32_t n_layers, const float *packed, const void *obs, int32_t obs_is_f64,
                         int64_t ld_obs, int64_t n, int32_t standardize, float mean0, float std0, const float *mean_v,
                         const float *std_v, const float *noise_q, int64_t *actions, float *actions_f32, float *logp, float *rows_out,
-                        int64_t ld_rows_out, void *workspace, size_t ws_bytes) {
+                        int64_t ld_rows_out, void *workspace, size_t ws_bytes, const rlppo_act_opts *opts) {
     NetLayout net;
     int rc = make_layout(dims, n_layers, &net);
+    if (rc) return rc;
+    ActCtx cx;
+    rc = act_ctx(opts, &cx);
     if (rc) return rc;
     if (n == 0) return 0;
     const int d = net.L[0].in, pin = net.L[0].pin;
@@ -387,7 +422,7 @@ int rlppo_discrete_step(void *stream, const int32_t *dims, int32_t n_layers, con
                     "discrete_step: ld_obs=%ld standardize=%d", (long)ld_obs, standardize);
     RLPPO_CHECK_ARG(!rows_out || ld_rows_out >= pin, "discrete_step: ld_rows_out=%ld < padded width %d", (long)ld_rows_out, pin);
     hipStream_t st = (hipStream_t)stream;
-    if (g_fused_act && !get_infer_bf16() && fused_act_ok(net) && n <= FUSED_ACT_MAX_ROWS) {
+    if (g_fused_act && !cx.bf16 && fused_act_ok(net) && n <= FUSED_ACT_MAX_ROWS) {
         FusedActIO io;
         io.raw = obs;
         io.raw_is_f64 = obs_is_f64;
@@ -403,6 +438,8 @@ int rlppo_discrete_step(void *stream, const int32_t *dims, int32_t n_layers, con
         io.actions = actions;
         io.actions_f32 = actions_f32;
         io.logp = logp;
+        io.done_words = cx.done;
+        io.done_value = cx.done_value;
         ++g_cnt_fused_act;
         return launch_discrete_act_fused(st, net, packed, io, n);
     }
@@ -426,18 +463,21 @@ int rlppo_discrete_step(void *stream, const int32_t *dims, int32_t n_layers, con
     if (rc) return rc;
     const float *o;
     int64_t ldo;
-    rc = forward_pingpong(st, net, packed, rows, ld_rows, n, 0, ws, ws_bytes, nullptr, &o, &ldo);
+    rc = forward_pingpong(st, net, packed, rows, ld_rows, n, 0, ws, ws_bytes, nullptr, &o, &ldo, cx.bf16);
     if (rc) return rc;
     rc = launch_discrete_sample_logits(st, o, ldo, n, dims[n_layers], noise_q, actions, logp, nullptr);
-    if (rc || !actions_f32) return rc;
-    return launch_i64_to_f32(st, actions, actions_f32, n);
+    if (rc == 0 && actions_f32) rc = launch_i64_to_f32(st, actions, actions_f32, n);
+    return rc ? rc : act_done(st, cx, n);
 }
 
 int rlppo_discrete_probs(void *stream, const int32_t *dims, int32_t n_layers, const float *packed, const float *obs,
                          int64_t ld_obs, int64_t n, int32_t clamp_probs, float *probs_out, int64_t ld_probs,
-                         int64_t *flat_argmax, void *workspace, size_t ws_bytes) {
+                         int64_t *flat_argmax, void *workspace, size_t ws_bytes, const rlppo_act_opts *opts) {
     NetLayout net;
     int rc = make_layout(dims, n_layers, &net);
+    if (rc) return rc;
+    ActCtx cx;
+    rc = act_ctx(opts, &cx);
     if (rc) return rc;
     if (n == 0) return 0;
     RLPPO_CHECK_ARG(n > 0 && packed && obs && workspace && (probs_out || flat_argmax), "discrete_probs: bad argument");
@@ -445,9 +485,10 @@ int rlppo_discrete_probs(void *stream, const int32_t *dims, int32_t n_layers, co
                     dims[n_layers]);
     const float *o;
     int64_t ldo;
-    rc = forward_pingpong((hipStream_t)stream, net, packed, obs, ld_obs, n, 0, workspace, ws_bytes, nullptr, &o, &ldo);
+    rc = forward_pingpong((hipStream_t)stream, net, packed, obs, ld_obs, n, 0, workspace, ws_bytes, nullptr, &o, &ldo, cx.bf16);
     if (rc) return rc;
-    return launch_discrete_probs((hipStream_t)stream, o, ldo, n, dims[n_layers], clamp_probs != 0, probs_out, ld_probs, flat_argmax);
+    rc = launch_discrete_probs((hipStream_t)stream, o, ldo, n, dims[n_layers], clamp_probs != 0, probs_out, ld_probs, flat_argmax);
+    return rc ? rc : act_done((hipStream_t)stream, cx, n);
 }
 
 int rlppo_categorical_select(void *stream, const float *probs, int64_t ld_p, int64_t n, int32_t n_cat,
@@ -459,35 +500,45 @@ int rlppo_categorical_select(void *stream, const float *probs, int64_t ld_p, int
 
 int rlppo_gaussian_act(void *stream, const int32_t *dims, int32_t n_layers, const float *packed, const float *obs,
                        int64_t ld_obs, int64_t n, const float *noise_eps, float var_m, float var_b, float *actions,
-                       float *logp, void *workspace, size_t ws_bytes) {
+                       float *logp, void *workspace, size_t ws_bytes, const rlppo_act_opts *opts) {
     NetLayout net;
     int rc = make_layout(dims, n_layers, &net);
+    if (rc) return rc;
+    ActCtx cx;
+    rc = act_ctx(opts, &cx);
     if (rc) return rc;
     if (n == 0) return 0;
     RLPPO_CHECK_ARG(n > 0 && packed && obs && noise_eps && actions && logp && workspace, "gaussian_act: bad argument");
     RLPPO_CHECK_ARG(dims[n_layers] % 2 == 0, "gaussian_act: output width %d must be 2k", dims[n_layers]);
     const float *o;
     int64_t ldo;
-    rc = forward_pingpong((hipStream_t)stream, net, packed, obs, ld_obs, n, 1, workspace, ws_bytes, nullptr, &o, &ldo);
+    rc = forward_pingpong((hipStream_t)stream, net, packed, obs, ld_obs, n, 1, workspace, ws_bytes, nullptr, &o, &ldo, cx.bf16);
     if (rc) return rc;
-    return launch_gaussian_sample((hipStream_t)stream, o, ldo, n, dims[n_layers] / 2, noise_eps, var_m, var_b, actions, logp);
+    rc = launch_gaussian_sample((hipStream_t)stream, o, ldo, n, dims[n_layers] / 2, noise_eps, var_m, var_b, actions, logp);
+    return rc ? rc : act_done((hipStream_t)stream, cx, n);
 }
 
 int rlppo_multidiscrete_act(void *stream, const int32_t *dims, int32_t n_layers, const float *packed, const float *obs,
                             int64_t ld_obs, int64_t n, const float *noise_q, int64_t *actions, float *logp,
-                            void *workspace, size_t ws_bytes) {
+                            void *workspace, size_t ws_bytes, const rlppo_act_opts *opts) {
     NetLayout net;
     int rc = make_layout(dims, n_layers, &net);
+    if (rc) return rc;
+    ActCtx cx;
+    rc = act_ctx(opts, &cx);
     if (rc) return rc;
     if (n == 0) return 0;
     RLPPO_CHECK_ARG(n > 0 && packed && obs && noise_q && actions && logp && workspace, "multidiscrete_act: bad argument");
     RLPPO_CHECK_ARG(dims[n_layers] == 21, "multidiscrete_act: output width %d must be 21", dims[n_layers]);
     const float *o;
     int64_t ldo;
-    rc = forward_pingpong((hipStream_t)stream, net, packed, obs, ld_obs, n, 0, workspace, ws_bytes, nullptr, &o, &ldo);
+    rc = forward_pingpong((hipStream_t)stream, net, packed, obs, ld_obs, n, 0, workspace, ws_bytes, nullptr, &o, &ldo, cx.bf16);
     if (rc) return rc;
-    return launch_multidiscrete_sample((hipStream_t)stream, o, ldo, n, noise_q, actions, logp);
+    rc = launch_multidiscrete_sample((hipStream_t)stream, o, ldo, n, noise_q, actions, logp);
+    return rc ? rc : act_done((hipStream_t)stream, cx, n);
 }
+
+int64_t rlppo_act_done_words(int64_t n) { return n > 0 ? cdiv(n, 16) : 0; }
 
 size_t rlppo_gae_workspace_bytes(int64_t n) { return gae_workspace_bytes(n) + 256; }
 
@@ -1006,8 +1057,9 @@ int rlppo_ppo_minibatch(void *stream, const rlppo_minibatch_args *a) {
     // the minibatch's per-row scalars, gathered once (the loss kernels stream them)
     RLPPO_CHECK_ARG(a->act_dim >= 1 && a->act_dim <= pol.L[pol.n_layers - 1].pout, "ppo_minibatch: act_dim=%d", a->act_dim);
     float *g_old = wmeta, *g_adv = wmeta + mb, *g_tgt = wmeta + 2 * (size_t)mb, *g_act = wmeta + 3 * (size_t)mb;
+    // ([r5] it also zeroes the first mb floats of the critic's output buffer: a folded value head accumulates into them)
     rc = launch_gather_meta(st, a->idx, a->actions, a->act_dim, a->old_logp, a->advantages, a->targets, g_act, g_old, g_adv, g_tgt, mb,
-                            ring_base, ring_cap, fused_gather ? rowtab : nullptr);
+                            ring_base, ring_cap, fused_gather ? rowtab : nullptr, vact[val.n_layers - 1]);
     if (rc) return rc;
     // forward of both nets
     // The two networks are independent until the loss epilogue and again after it, so their launch chains run on
@@ -1048,8 +1100,7 @@ int rlppo_ppo_minibatch(void *stream, const rlppo_minibatch_args *a) {
             alt.bits = vbits[l];
             NtDot dots[2];
             const bool fold_here = fold_v && l == H - 1;
-            if (fold_here) {
-                RLPPO_HIP(hipMemsetAsync(vout, 0, (size_t)mb * sizeof(float), st));
+            if (fold_here) {  // (vout was zeroed by gather_meta_kernel)
                 dots[1].w = val_w + Lvh.off_w;
                 dots[1].out = vout;
                 dots[1].b = val_w + Lvh.off_b;
@@ -1172,7 +1223,7 @@ int rlppo_ppo_minibatch(void *stream, const rlppo_minibatch_args *a) {
         const float *x0 = fused_gather ? a->states : states;
         const int64_t ld0 = fused_gather ? a->ld_states : ld_states;
         const unsigned *rt = fused_gather ? rowtab : nullptr;
-        rc = forward(side, val, val_w, x0, ld0, mb, 0, vact, 0, vbits, vhave, rt, src_rows, &v_folded, val_x3);
+        rc = forward(side, val, val_w, x0, ld0, mb, 0, vact, 0, vbits, vhave, rt, src_rows, &v_folded, val_x3, true);
         if (rc) return rc;
         rc = forward(st, pol, pol_w, x0, ld0, mb, a->head == RLPPO_HEAD_GAUSSIAN, pact, 0, pbits, phave, rt, src_rows, nullptr, pol_x3);
     }

@@ -239,6 +239,8 @@ struct FusedActIO {
     int64_t *actions = nullptr;
     float *actions_f32 = nullptr;  // optional
     float *logp = nullptr, *probs_out = nullptr;
+    unsigned *done_words = nullptr;  // [r5] optional, host-visible: word b <- done_value once the outputs of rows 16 b .. 16 b + 15 are visible
+    unsigned done_value = 0;
 };
 bool fused_act_ok(const NetLayout &net);
 int launch_discrete_act_fused(hipStream_t st, const NetLayout &net, const float *packed, const FusedActIO &io, int64_t n);
@@ -273,8 +275,9 @@ int launch_gather_rows(hipStream_t st, const float *src, int64_t ld_src, const i
                        int64_t ring_base = 0, int64_t ring_cap = INT64_MAX);
 int launch_gather_meta(hipStream_t st, const int64_t *idx, const float *actions, int act_dim, const float *old_logp,
                        const float *adv, const float *targets, float *g_act, float *g_old, float *g_adv, float *g_tgt, int64_t n,
-                       int64_t ring_base, int64_t ring_cap, unsigned *rowtab = nullptr);
+                       int64_t ring_base, int64_t ring_cap, unsigned *rowtab = nullptr, float *zero_n = nullptr);
 int launch_i64_to_f32(hipStream_t st, const int64_t *src, float *dst, int64_t n);
+int launch_signal_words(hipStream_t st, unsigned *words, int count, unsigned value);  // words[0..count) <- value, released at system scope
 int launch_pad_rows(hipStream_t, const void *, int, int64_t, int64_t, int64_t, float *, int64_t, int, float, float);
 int launch_pad_rows_vec(hipStream_t, const void *, int, int64_t, int64_t, int64_t, float *, int64_t, const float *, const float *);
 

@@ -51,6 +51,8 @@ struct FusedActArgs {
     int64_t *actions;
     float *logp;
     float *probs_out;        // optional [n][A]
+    unsigned *done_words;    // optional (host-visible): done_words[blockIdx.x] <- done_value when this workgroup's outputs are visible
+    unsigned done_value;
 };
 
 // NW waves; JH: output blocks a wave owns in a hidden layer (H = 16 JH NW); the head's blocks are dealt ceil(nblk / NW) per wave.
@@ -294,6 +296,13 @@ __global__ __launch_bounds__(64 * NW, 1) void discrete_act_fused_kernel(FusedAct
             if (a.actions_f32) a.actions_f32[row] = (float)besti;
         }
     }
+    // [r5] completion word of this workgroup's 16 rows: every wave releases its stores at system scope, then ONE word follows them
+    // (a host that polls the word -- pinned memory -- reads the results without synchronising the stream: rlppo_act_opts)
+    if (a.done_words) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(a.done_words + blockIdx.x, a.done_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 
 // Does the network have the form the fused kernel covers?  n_layers in [2, 6]; all hidden widths equal, 64 / 128 / 256; the first
@@ -358,6 +367,8 @@ int launch_discrete_act_fused(hipStream_t st, const NetLayout &net, const float 
     a.actions = io.actions;
     a.logp = io.logp;
     a.probs_out = io.probs_out;
+    a.done_words = io.done_words;
+    a.done_value = io.done_value;
     const int H = net.L[0].pout;
     dim3 grid((unsigned)cdiv(n, FA_ROWS));
     static PerDeviceOnce attr_set[3];

@@ -590,11 +590,15 @@ __device__ __forceinline__ void tn_tile(float *lds, const float *__restrict__ dY
         }
     };
 
-    f32x4 acc[NI][NJ];
+    // [r5] TWO accumulation chains per output block, taking the 16-row halves of every stage in turn: a split's rows are summed as
+    // two fp32 chains of half the length (added once, at the end), so the rounding of a split of R rows is that of chains of R / 2
+    // -- the grouped launch's splits are 2,700-7,300 rows long where rounds 1-4 ran at most 4,096 -- and the MFMA stream has two
+    // independent chains per block to interleave.  64 more VGPRs; the launch bound (two workgroups per CU: LDS) is unchanged.
+    f32x4 acc[NI][NJ], acc2[NI][NJ];
 #pragma unroll
     for (int i = 0; i < NI; ++i)
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < NJ; ++j) acc[i][j] = acc2[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     f32x4 bs4 = f32x4{0.f, 0.f, 0.f, 0.f};
     const bool want_db = with_db && by == 0;
 
@@ -644,7 +648,10 @@ __device__ __forceinline__ void tn_tile(float *lds, const float *__restrict__ dY
 #pragma unroll
                 for (int i = 0; i < NI; ++i)
 #pragma unroll
-                    for (int j = 0; j < NJ; ++j) acc[i][j] = MFMA16(fa[i], fb[j], acc[i][j]);
+                    for (int j = 0; j < NJ; ++j) {
+                        if (c & 1) acc2[i][j] = MFMA16(fa[i], fb[j], acc2[i][j]);
+                        else acc[i][j] = MFMA16(fa[i], fb[j], acc[i][j]);
+                    }
             }
         }
         __builtin_amdgcn_sched_barrier(0);  // keep the MFMAs above the wait: they are what hides the DMA latency
@@ -669,6 +676,11 @@ __device__ __forceinline__ void tn_tile(float *lds, const float *__restrict__ dY
     // The partial-tile stores are the LAST instructions of the wave: 16-byte buffer stores whose data registers are written
     // again soon afterwards can pick up the new values (the hazard of section 5 / tests/test_gpu_stress.py); here the
     // accumulators are never touched after them.
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) acc[i][j] += acc2[i][j];
+    __builtin_amdgcn_sched_barrier(0);
     {
         const size_t tile_id = (size_t)bz * (tiles_x * tiles_y) + (size_t)by * tiles_x + bx;
         const __amdgpu_buffer_rsrc_t p_rs = make_rsrc(partial + tile_id * TILE_F, TILE_F * 4);
@@ -989,7 +1001,7 @@ __global__ __launch_bounds__(256) void tn_reduce_group_kernel(TnRedGroupArgs g) 
 // The plan of a grouped launch: splits per product such that every workgroup multiplies (about) the same number of 16 x 16 x 4
 // blocks and the grid is at most `budget` workgroups (one round at two per CU).  Depends on the SET of shapes and M only.
 static int g_tn_group_budget = 0;  // rlppo_dbg_set(38, n): 0 = two per CU
-constexpr int TN_MAX_CHAIN = 8192;  // longest row split (fp32 accumulation chain) of a grouped launch
+constexpr int TN_MAX_CHAIN = 8192;  // longest row split of a grouped launch (two interleaved fp32 accumulation chains of half that: tn_tile)
 void set_tn_group_budget(int v) { g_tn_group_budget = v; }
 struct TnPlanItem {
     TnGeom g;

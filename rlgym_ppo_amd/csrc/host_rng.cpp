@@ -313,6 +313,7 @@ inline void temper8(const uint32_t *src, uint32_t *dst) {
 }  // namespace
 
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <mutex>
 
@@ -688,4 +689,22 @@ extern "C" int rlppo_exponential_from_words(const uint32_t *words, int64_t n, do
     if (n < 0 || (n > 0 && (!words || !out)) || !(lambda > 0.0)) return RLPPO_ERR_ARG;
     if (n > 0) exp_transform(words, out, 0, n, -1.0 / lambda);
     return 0;
+}
+
+// [r5] Host side of rlppo_act_opts.done_words: spins (no system call, no GIL: the Python host calls it through ctypes) until the
+// `count` words all hold `value`, or `timeout_us` has passed (returns 1: the caller synchronises the stream instead).  The words live
+// in pinned host memory the kernel stores into with release semantics at system scope; the acquire loads here order the reads of
+// the results behind them.
+extern "C" int rlppo_host_wait_words(const uint32_t *words, int64_t count, uint32_t value, int64_t timeout_us) {
+    if (count < 0 || (count > 0 && !words)) return RLPPO_ERR_ARG;
+    const auto t0 = std::chrono::steady_clock::now();
+    int64_t first = 0;
+    for (unsigned spins = 0;; ++spins) {
+        while (first < count && __atomic_load_n(words + first, __ATOMIC_ACQUIRE) == value) ++first;
+        if (first >= count) return 0;
+        __builtin_ia32_pause();
+        if ((spins & 1023) == 1023 &&
+            std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() > timeout_us)
+            return 1;
+    }
 }

@@ -148,6 +148,18 @@ __global__ __launch_bounds__(256) void i64_to_f32_kernel(const int64_t *__restri
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i < n) dst[i] = (float)src[i];
 }
+// [r5] rlppo_act_opts.done_words for the calls whose last kernel does not write them itself: stream order puts this launch behind
+// every output of the call; the words are stored with release semantics at system scope (visible to a polling host)
+__global__ void signal_words_kernel(unsigned *__restrict__ words, int count, unsigned value) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+    for (int i = threadIdx.x; i < count; i += blockDim.x) __hip_atomic_store(words + i, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+int launch_signal_words(hipStream_t st, unsigned *words, int count, unsigned value) {
+    if (count <= 0) return 0;
+    hipLaunchKernelGGL(signal_words_kernel, dim3(1), dim3(64), 0, st, words, count, value);
+    RLPPO_LAUNCH_CHECK();
+    return 0;
+}
 int launch_i64_to_f32(hipStream_t st, const int64_t *src, float *dst, int64_t n) {
     if (n <= 0) return 0;
     hipLaunchKernelGGL(i64_to_f32_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st, src, dst, n);
@@ -248,11 +260,13 @@ __global__ __launch_bounds__(256) void gather_meta_kernel(const int64_t *__restr
                                                           const float *__restrict__ adv, const float *__restrict__ targets,
                                                           float *__restrict__ g_act, float *__restrict__ g_old,
                                                           float *__restrict__ g_adv, float *__restrict__ g_tgt, int64_t n,
-                                                          int64_t ring_base, int64_t ring_cap, unsigned *__restrict__ rowtab) {
+                                                          int64_t ring_base, int64_t ring_cap, unsigned *__restrict__ rowtab,
+                                                          float *__restrict__ zero_n) {
     const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (r >= n) return;
     const int64_t src = ring_row(idx[r], ring_base, ring_cap);
     if (rowtab) rowtab[r] = (unsigned)src;  // [r3] the row table of the fused state gather (gemm.hip, GATHER)
+    if (zero_n) zero_n[r] = 0.f;            // [r5] the critic's folded value head accumulates into zeros: no fill launch of its own (23 us at 65,536 rows)
     g_old[r] = old_logp[src];
     g_adv[r] = adv[src];
     g_tgt[r] = targets[src];
@@ -261,10 +275,10 @@ __global__ __launch_bounds__(256) void gather_meta_kernel(const int64_t *__restr
 
 int launch_gather_meta(hipStream_t st, const int64_t *idx, const float *actions, int act_dim, const float *old_logp,
                        const float *adv, const float *targets, float *g_act, float *g_old, float *g_adv, float *g_tgt, int64_t n,
-                       int64_t ring_base, int64_t ring_cap, unsigned *rowtab) {
+                       int64_t ring_base, int64_t ring_cap, unsigned *rowtab, float *zero_n) {
     if (n <= 0) return 0;
     hipLaunchKernelGGL(gather_meta_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st, idx, actions, act_dim, old_logp, adv,
-                       targets, g_act, g_old, g_adv, g_tgt, n, ring_base, ring_cap, rowtab);
+                       targets, g_act, g_old, g_adv, g_tgt, n, ring_base, ring_cap, rowtab, zero_n);
     RLPPO_LAUNCH_CHECK();
     return 0;
 }

@@ -217,7 +217,7 @@ class NetArena:
         out = torch.empty((n, self.ld_out), dtype=torch.float32, device=self.device)
         ws = self.forward_ws(n)
         N.check(N.lib().rlppo_mlp_forward(stream_ptr(), self.dims_c, self.n_layers, ptr(self.packed), ptr(obs_padded),
-                                          obs_padded.shape[1], n, int(out_tanh), ptr(out), self.ld_out, ptr(ws), ws.numel()))
+                                          obs_padded.shape[1], n, int(out_tanh), ptr(out), self.ld_out, ptr(ws), ws.numel(), None))
         return out
 
 

@@ -5,6 +5,7 @@ constructors (rlgym_ppo/ppo/discrete_policy.py:21-31, continuous_policy.py:29-41
 multi_discrete_policy.py:22-32, value_estimator.py:18-28): layers are built on the CPU first (so a seeded run
 starts from the reference's weights bit for bit) and only then moved to the GPU arena.
 """
+import ctypes
 import os
 
 import numpy as np
@@ -53,12 +54,22 @@ class ActGraph:
         ws_bytes = max(int(L.rlppo_forward_workspace_bytes(a.dims_c, a.n_layers, cap)), raw(None, cap) if raw is not None else 0)
         self.ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
 
+        # [r5] completion by words the call's last kernel stores into pinned memory behind the results (rlppo_act_opts): run()
+        # clears them, launches and polls them in C (rlppo_host_wait_words) instead of hipStreamSynchronize, which cost ~20 us of
+        # a 66 us call; a poll that times out falls back to the synchronisation.  RLPPO_ACT_POLL=0: always synchronise.
+        self.n_done = int(L.rlppo_act_done_words(cap))
+        self.done_pin = torch.zeros(max(self.n_done, 1), dtype=torch.int32).pin_memory()
+        self.poll = os.environ.get("RLPPO_ACT_POLL", "1") != "0"
+        self.opts = N.ActOpts(N.PRECISION_DEFAULT, 1, self.done_pin.data_ptr()) if self.poll else None
+        self.polled = self.poll_timeouts = 0
+        self.seq = self.graph_value = 1   # (the warm-up launch and the capture below store 1)
+
         def body():
             if raw is not None:
-                raw(self, cap)
+                raw(self, cap, self.opts)
                 return
             N.check(L.rlppo_pad_rows(stream_ptr(), ptr(self.obs_pin), 0, cap, d, d, ptr(self.rows), a.ld_in, 0, 0.0, 1.0))
-            pol._act_launch(self.rows, cap, self.q_pin, self.act_pin, self.logp_pin, self.ws)
+            pol._act_launch(self.rows, cap, self.q_pin, self.act_pin, self.logp_pin, self.ws, self.opts)
 
         self.body = body
         # a body that is ONE launch (the discrete head) is issued as such on the pinned buffers: a replay of a one-node graph costs
@@ -75,6 +86,9 @@ class ActGraph:
             body()
         self.obs_np, self.q_np = self.obs_pin.numpy(), self.q_pin.view(-1).numpy()
         self.act_np, self.logp_np = self.act_pin.numpy(), self.logp_pin.numpy()
+        self.done_np = self.done_pin.numpy()
+        self._done_ptr = ctypes.c_void_p(self.done_pin.data_ptr())
+        self._wait = L.rlppo_host_wait_words
 
     def run(self, obs, q, n):
         # plain memcpy through numpy views made once: Tensor.copy_ fans out to an OpenMP team above 32k elements (10 ms on a
@@ -82,10 +96,26 @@ class ActGraph:
         self.obs_np[:n] = obs
         self.q_np[:q.numel()] = q.reshape(-1).numpy()
         if self.eager:
+            # a fresh completion value per call: a workgroup of an EARLIER launch that finishes late (rows past that call's n, which
+            # nobody waited for) stores the earlier value and cannot be mistaken for this call's; only the words of the rows the
+            # caller asked for are awaited
+            self.seq = self.seq % 0x7FFFFFFF + 1
+            if self.poll:
+                self.opts.done_value = self.seq
             self.body()
+            value, count = self.seq, (n + 15) // 16
         else:
+            # a replayed graph stores the value it was captured with: clear the words, wait for ALL of them (nothing of this
+            # launch is then still running when the next call clears them again)
+            if self.poll:
+                self.done_np[:] = 0
             self.graph.replay()
-        torch.cuda.current_stream(self.dev).synchronize()
+            value, count = self.graph_value, self.n_done
+        if self.poll and self._wait(self._done_ptr, count, value, 2000) == 0:
+            self.polled += 1
+        else:
+            self.poll_timeouts += int(self.poll)
+            torch.cuda.current_stream(self.dev).synchronize()
         return torch.from_numpy(self.act_np[:n].copy()), torch.from_numpy(self.logp_np[:n].copy())
 
 

@@ -51,11 +51,11 @@ class ContinuousPolicy(ArenaModule):
     def _action_buffer(self, cap):
         return torch.zeros((cap, self.n_out // 2), dtype=torch.float32)
 
-    def _act_launch(self, rows, n, noise, actions, logp, ws):
+    def _act_launch(self, rows, n, noise, actions, logp, ws, opts=None):
         a = self.arena
         N.check(N.lib().rlppo_gaussian_act(stream_ptr(), a.dims_c, a.n_layers, ptr(a.packed), ptr(rows), rows.shape[1], n,
                                            ptr(noise), float(self.affine_map.m), float(self.affine_map.b), ptr(actions),
-                                           ptr(logp), ptr(ws), ws.numel()))
+                                           ptr(logp), ptr(ws), ws.numel(), opts))
 
     def act_padded(self, rows, noise=None):
         """Padded device rows -> (actions fp32 [n, k], summed log_probs fp32 [n]) on the device (see DiscreteFF.act_padded)."""
@@ -72,7 +72,7 @@ class ContinuousPolicy(ArenaModule):
         ws = a.forward_ws(n)
         N.check(N.lib().rlppo_gaussian_act(stream_ptr(), a.dims_c, a.n_layers, ptr(a.packed), ptr(rows), rows.shape[1], n,
                                            ptr(eps), float(self.affine_map.m), float(self.affine_map.b), ptr(actions),
-                                           ptr(logp), ptr(ws), ws.numel()))
+                                           ptr(logp), ptr(ws), ws.numel(), None))
         return actions, logp
 
     @staticmethod

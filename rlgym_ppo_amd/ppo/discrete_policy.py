@@ -33,7 +33,7 @@ class DiscreteFF(ArenaModule):
         ws = a.forward_ws(n)
         N.check(N.lib().rlppo_discrete_probs(stream_ptr(), a.dims_c, a.n_layers, ptr(a.packed), ptr(rows), rows.shape[1], n, int(clamp),
                                              ptr(probs) if want_probs else None, self.n_actions, ptr(best) if want_argmax else None,
-                                             ptr(ws), ws.numel()))
+                                             ptr(ws), ws.numel(), None))
         return probs, best
 
     @torch.no_grad()
@@ -118,7 +118,7 @@ class DiscreteFF(ArenaModule):
         ws = a.ws.get(L.rlppo_discrete_step_workspace_bytes(a.dims_c, a.n_layers, n))
         N.check(L.rlppo_discrete_step(stream_ptr(), a.dims_c, a.n_layers, ptr(a.packed), ptr(t), int(t.dtype == torch.float64), d, n,
                                       mode, mean0, std0, ptr(mean_v), ptr(std_v), ptr(q), ptr(actions), ptr(actions_f32), ptr(logp),
-                                      ptr(rows_out), rows_out.stride(0) if rows_out is not None else 0, ptr(ws), ws.numel()))
+                                      ptr(rows_out), rows_out.stride(0) if rows_out is not None else 0, ptr(ws), ws.numel(), None))
         if to_host:
             torch.cuda.current_stream(a.device).synchronize()
             return actions.clone(), (logp.clone() if to_host is True else logp)
@@ -139,12 +139,12 @@ class DiscreteFF(ArenaModule):
     def _action_buffer(self, cap):
         return torch.zeros(cap, dtype=torch.int64)
 
-    def _act_launch(self, rows, n, noise, actions, logp, ws):
+    def _act_launch(self, rows, n, noise, actions, logp, ws, opts=None):
         a = self.arena
         N.check(N.lib().rlppo_discrete_act(stream_ptr(), a.dims_c, a.n_layers, ptr(a.packed), ptr(rows), rows.shape[1], n,
-                                           ptr(noise), ptr(actions), ptr(logp), None, ptr(ws), ws.numel()))
+                                           ptr(noise), ptr(actions), ptr(logp), None, ptr(ws), ws.numel(), opts))
 
-    def _act_launch_raw(self, g, cap):
+    def _act_launch_raw(self, g, cap, opts=None):
         """ActGraph's body as one node: rlppo_discrete_step on the graph's pinned observations / noise / outputs (g=None: the
         workspace bytes that takes)."""
         a = self.arena
@@ -152,7 +152,7 @@ class DiscreteFF(ArenaModule):
         if g is None:
             return int(L.rlppo_discrete_step_workspace_bytes(a.dims_c, a.n_layers, cap))
         N.check(L.rlppo_discrete_step(stream_ptr(), a.dims_c, a.n_layers, ptr(a.packed), ptr(g.obs_pin), 0, a.d_in, cap, 0, 0.0, 1.0,
-                                      None, None, ptr(g.q_pin), ptr(g.act_pin), None, ptr(g.logp_pin), None, 0, ptr(g.ws), g.ws.numel()))
+                                      None, None, ptr(g.q_pin), ptr(g.act_pin), None, ptr(g.logp_pin), None, 0, ptr(g.ws), g.ws.numel(), opts))
 
     def act_padded(self, rows, noise=None):
         """Padded device rows [n, ld_in] -> (actions int64 [n], log_probs fp32 [n]) ON THE DEVICE: the part of get_action
@@ -169,7 +169,7 @@ class DiscreteFF(ArenaModule):
         logp = torch.empty(n, dtype=torch.float32, device=a.device)
         ws = a.forward_ws(n)
         N.check(N.lib().rlppo_discrete_act(stream_ptr(), a.dims_c, a.n_layers, ptr(a.packed), ptr(rows), rows.shape[1], n,
-                                           ptr(q), ptr(actions), ptr(logp), None, ptr(ws), ws.numel()))
+                                           ptr(q), ptr(actions), ptr(logp), None, ptr(ws), ws.numel(), None))
         return actions, logp
 
     def get_backprop_data(self, obs, acts):

@@ -50,10 +50,10 @@ class MultiDiscreteFF(ArenaModule):
     def _action_buffer(self, cap):
         return torch.zeros((cap, 8), dtype=torch.int64)
 
-    def _act_launch(self, rows, n, noise, actions, logp, ws):
+    def _act_launch(self, rows, n, noise, actions, logp, ws, opts=None):
         a = self.arena
         N.check(N.lib().rlppo_multidiscrete_act(stream_ptr(), a.dims_c, a.n_layers, ptr(a.packed), ptr(rows), rows.shape[1],
-                                                n, ptr(noise), ptr(actions), ptr(logp), ptr(ws), ws.numel()))
+                                                n, ptr(noise), ptr(actions), ptr(logp), ptr(ws), ws.numel(), opts))
 
     def act_padded(self, rows, noise=None):
         """Padded device rows -> (actions int64 [n, 8], log_probs fp32 [n]) on the device (see DiscreteFF.act_padded)."""
@@ -69,7 +69,7 @@ class MultiDiscreteFF(ArenaModule):
         logp = torch.empty(n, dtype=torch.float32, device=a.device)
         ws = a.forward_ws(n)
         N.check(N.lib().rlppo_multidiscrete_act(stream_ptr(), a.dims_c, a.n_layers, ptr(a.packed), ptr(rows), rows.shape[1],
-                                                n, ptr(q), ptr(actions), ptr(logp), ptr(ws), ws.numel()))
+                                                n, ptr(q), ptr(actions), ptr(logp), ptr(ws), ws.numel(), None))
         return actions, logp
 
     def get_backprop_data(self, obs, acts):

@@ -167,6 +167,8 @@ def gate(L, head, pol, val, obs, acts, old, adv, tgt, clip, ent, mb_ratio, got, 
     assert e_hip <= max(floor, 1.5 * e_cpu), (label, e_hip, e_cpu)
     # statistics: means over the rows -> float64 truth at 1e-5 (clip fraction: the edge rows may fall either way)
     ref = out["hip"]["ref"]
+    if stats is None:  # (a caller that has the gradient only: the first optimiser step of a learn())
+        return out
     for name, k, tol in (("entropy", 0, 1e-5), ("kl", 1, 1e-5), ("value_loss", 2, 1e-5), ("policy_loss", 4, 1e-5)):
         want = float(ref[name])
         assert abs(stats[k] - want) <= tol * max(abs(want), 1e-3) + 1e-7, (label, name, stats[k], want)

@@ -6,6 +6,8 @@ import os
 import subprocess
 import sys
 
+import pytest
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -44,3 +46,24 @@ def test_eight_ranks_the_drivers_top_configuration():
     assert len(lines) == 1, r.stdout
     line = json.loads(lines[0])
     assert line["n_gpus"] == 8 and line["hip_initialised"] is False
+
+
+@pytest.mark.gpu
+def test_two_rank_dry_run_on_the_one_gpu_walks_the_whole_multi_rank_path():
+    """[r5] What first executes on the driver's 8-GPU node, as far as a one-GPU box can take it: `bench.py --gpus 2` through its
+    own spawn path with both ranks on cuda:0 and gloo as the collective (RLPPO_BENCH_DRYRUN=1; RCCL refuses two ranks on one GPU):
+    rendezvous + init watchdog, the warm all-reduce probe, PPOLearner.learn with world = 2 (slice dealing, the gradient exchange
+    before clipping, the statistics exchange with the give-up word), max-over-ranks timing and ONE JSON line whose fields say
+    what ran.  The number is meaningless and tagged so."""
+    r = _run(["--gpus", "2", "--steps", "1", "--warmup", "1", "--no-extras", "--epochs", "2"], {"RLPPO_BENCH_DRYRUN": "1"})
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 1 and line["metric"] == "ppo_update_samples_per_sec" and line["value"] > 0
+    assert "DRY RUN" in line["data"] and line["config"]["parallelism"].startswith("dp2: 4 minibatch slice(s) per rank")
+    assert line["allreduce_us"] > 0 and line["scaling"] == "strong"
+    pr = line["per_rank_ms_per_step"]
+    assert len(pr["all"]) == 2 and pr["min"] <= pr["max"] and abs(pr["max"] - line["ms_per_step"]) <= 0.05 * line["ms_per_step"] + 1.0
+    assert "exiting 4" not in r.stderr                               # the init watchdog did not trip
+    assert line["config"]["last_report"]["Cumulative Model Updates"] == 4   # (warm-up + 1 step) x 2 epochs x 1 batch

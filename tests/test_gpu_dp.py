@@ -63,11 +63,16 @@ def test_two_ranks_equal_one_rank():
     mp.spawn(_worker, args=(2, _free_port(), out), nprocs=2, join=True)
     for rank in (0, 1):
         p, v, report = out[rank]
-        # summation order differs (atomics + all-reduce); Adam turns 1e-7 gradient noise into up to ~1e-5 relative parameter
-        # noise after 4 steps (two identical single-process runs already differ by up to 9e-6: scratch/determinism.py), while
-        # a real defect shows up as O(lr / max|p|) ~ 2e-3
-        assert ((p - ref_p).abs().max() / ref_p.abs().max()).item() < 5e-5
-        assert ((v - ref_v).abs().max() / ref_v.abs().max()).item() < 5e-5
+        # [r5] The update is bit-reproducible (fixed-order reductions everywhere, test_update_is_bit_reproducible), so two ranks differ
+        # from one by exactly ONE thing: the batch gradient is the all-reduced sum of two per-rank sums instead of one sum over all
+        # rows -- a different order of the same fp32 additions, ~1e-7 of the gradient -- which Adam's normalised step carries into
+        # the parameters (4 steps of lr 3e-4: well below 1e-5 of max|p| except where a gradient entry is itself ~1e-7 of the
+        # largest; a real defect shows up as O(lr / max|p|) ~ 2e-3).  Held to the north star's 1e-5 on all but 0.1 % of the entries,
+        # 2e-5 on every one (was 5e-5 with a comment about run-to-run noise that no longer exists).
+        for got, ref in ((p, ref_p), (v, ref_v)):
+            dd = ((got - ref).abs() / ref.abs().max())
+            print(f"[2 ranks vs 1] rank {rank}: max {dd.max().item():.2e}, 99.9 % quantile {torch.quantile(dd, 0.999).item():.2e} of max|p|")
+            assert torch.quantile(dd, 0.999).item() < 1e-5 and dd.max().item() < 2e-5
         for k in ("Policy Entropy", "Mean KL Divergence", "Value Function Loss", "SB3 Clip Fraction",
                   "Policy Update Magnitude", "Value Function Update Magnitude"):
             assert abs(report[k] - ref_report[k]) <= 2e-5 * max(abs(ref_report[k]), 1e-3) + 1e-7, (k, report[k], ref_report[k])
@@ -92,8 +97,10 @@ def test_two_ranks_equal_one_rank_in_the_bf16_update_precision():
     mp.spawn(_worker, args=(2, _free_port(), out, 2048, "bf16", (256, 256)), nprocs=2, join=True)
     for rank in (0, 1):
         p, v, report = out[rank]
-        assert ((p - ref_p).abs().max() / ref_p.abs().max()).item() < 5e-5
-        assert ((v - ref_v).abs().max() / ref_v.abs().max()).item() < 5e-5
+        for got, ref in ((p, ref_p), (v, ref_v)):   # (bf16 activations: the same one-summation-order difference, in bf16-rounded products)
+            dd = ((got - ref).abs() / ref.abs().max())
+            print(f"[2 ranks vs 1, bf16] rank {rank}: max {dd.max().item():.2e}, 99.9 % quantile {torch.quantile(dd, 0.999).item():.2e} of max|p|")
+            assert torch.quantile(dd, 0.999).item() < 1e-5 and dd.max().item() < 3e-5
         for k in ("Policy Entropy", "Mean KL Divergence", "Value Function Loss", "SB3 Clip Fraction"):
             assert abs(report[k] - ref_report[k]) <= 2e-5 * max(abs(ref_report[k]), 1e-3) + 1e-7, (k, report[k], ref_report[k])
     assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1])
@@ -157,19 +164,31 @@ def _same_update(p, v, report, ref_p, ref_v, ref_report, n_updates, tol=5e-5):
     assert report["Cumulative Model Updates"] == ref_report["Cumulative Model Updates"] == n_updates
 
 
-def _adam_noise(p, v, ref_p, ref_v, n_updates, what, lr=3e-4):
+def _adam_noise(p, v, ref_p, ref_v, n_updates, what, lr=3e-4, g0=None):
     """Two correct float32 evaluations of the same batch gradient that add their 524,288 per-sample terms in different orders differ
-    by ~1e-6 of sum|terms| per entry; Adam's step lr * m / (sqrt(v) + eps) is scale-free, so for an entry whose terms largely
-    cancel (|g| a few tens of that noise) the STEP differs by percents of lr whatever the entry's size.  Measured here between
-    the one-pass (524,288 rows) and the eight-pass (8 x 65,536, the reference's own minibatch structure) evaluation: reported,
-    and bounded by a tenth of an Adam step per update for every parameter, 5e-5 of the largest parameter for 99 % of them."""
-    worst = 0.0
+    by < 1e-6 of max|g| per entry (measured below: 6.6e-7 between the one-pass and the eight-pass evaluation).  Through Adam that is
+    nothing in the FIRST step -- but parameters that differ in their last bits give the SECOND step's forward a handful of ReLU
+    units whose pre-activation crosses zero in one run and not in the other, each worth a row's share of a unit's gradient (~3e-4
+    of a tensor's largest entry at this size, tests/fp64_gate.py), and Adam's step lr m / (sqrt(v) + eps) is scale-free: an entry
+    whose gradient is as small as that moves by a sizeable fraction of lr.  [r5: measured -- the entry furthest apart, 0.22 steps
+    per update, has |g| = 4.3e-4 of max|g| and a first-step gradient difference of 1.6e-5 of ITSELF.]  Reported, and bounded: 5e-5
+    of the largest parameter for 99 % of the entries; a tenth of an Adam step per update for every entry whose first-step gradient
+    (g0: [grad_policy | grad_value] of the run) is at least 1e-2 of the largest -- 30 x what a flipped unit is worth; one whole
+    step per update for the others."""
+    worst, o = 0.0, 0
     for got, ref in ((p, ref_p), (v, ref_v)):
-        err = (got - ref).abs() / ref.abs().max()
+        d = (got - ref).abs()
+        err = d / ref.abs().max()
         q99 = torch.quantile(err[torch.randperm(err.numel())[:100000]], 0.99).item()
-        steps = (got - ref).abs().max().item() / (n_updates * lr)
-        print(f"[summation order through Adam] {what}: max {err.max().item():.2e} of max|p| (= {steps:.3f} Adam steps per update), 99 % of parameters within {q99:.1e}")
-        assert steps <= 0.1 and q99 < 5e-5, (what, steps, q99)
+        steps = d / (n_updates * lr)
+        well = torch.ones_like(d, dtype=torch.bool)
+        if g0 is not None:
+            g = g0[o:o + d.numel()].abs()
+            well = g >= 1e-2 * g.max()
+        o += d.numel()
+        print(f"[summation order through Adam] {what}: max {err.max().item():.2e} of max|p| (= {steps.max().item():.3f} Adam steps per update; "
+              f"{steps[well].max().item():.3f} over the {int(well.sum())} entries with a well-conditioned step), 99 % of parameters within {q99:.1e}")
+        assert steps[well].max().item() <= 0.1 and steps.max().item() <= (1.0 if g0 is not None else 0.1) and q99 < 5e-5, (what, steps.max().item(), q99)
         worst = max(worst, err.max().item())
     return worst
 
@@ -205,9 +224,21 @@ def test_configs3_eight_rank_partition_literal():
     world = 8
     ref_p, ref_v, ref_report, rows = _ref_cfg3(fuse=1)
     assert rows == 65536
+    grads8 = _ref_cfg3.grads
     one_p, one_v, one_report, rows = _ref_cfg3(fuse=8)
     assert rows == 524288                                      # one GPU: the 8 slices of a batch in one pass
-    _adam_noise(one_p, one_v, ref_p, ref_v, CFG3["epochs"], "1 rank, one 524,288-row pass vs eight 65,536-row passes")
+    g0 = _ref_cfg3.grads[0]   # the one-pass run's first batch gradient
+    # what the two evaluations' first batch gradients differ by (the same per-row terms, added in another order), and what that is
+    # relative to the entry whose parameter ends up furthest apart
+    dg = (g0 - grads8[0]).abs()
+    n_p = one_p.numel()
+    worst = int(torch.argmax(torch.cat(((one_p - ref_p).abs(), (one_v - ref_v).abs()))))
+    seg = slice(0, n_p) if worst < n_p else slice(n_p, None)
+    print(f"[summation order] first batch gradient, one pass vs eight passes: max |dg| = {(dg[:n_p].max() / g0[:n_p].abs().max()).item():.2e} (policy) / "
+          f"{(dg[n_p:].max() / g0[n_p:].abs().max()).item():.2e} (critic) of max|g|; the parameter furthest apart (index {worst}) has |g| = "
+          f"{(g0[worst].abs() / g0[seg].abs().max()).item():.2e} of max|g| and |dg| / |g| = {(dg[worst] / g0[worst].abs().clamp_min(1e-30)).item():.2e}")
+    assert (dg[:n_p].max() / g0[:n_p].abs().max()).item() < 5e-6 and (dg[n_p:].max() / g0[n_p:].abs().max()).item() < 5e-6
+    _adam_noise(one_p, one_v, ref_p, ref_v, CFG3["epochs"], "1 rank, one 524,288-row pass vs eight 65,536-row passes", g0=g0)
     with contextlib.redirect_stdout(open(os.devnull, "w")):
         replicas = [_build_cfg3() for _ in range(world)]
     learners, bufs = [r[0] for r in replicas], [r[1] for r in replicas]
@@ -218,7 +249,7 @@ def test_configs3_eight_rank_partition_literal():
         assert l._fused_rows == 65536                          # one 65,536-row pass per rank and optimiser step
         _same_update(l.policy.arena.flat.cpu(), l.value_net.arena.flat.cpu(), report, ref_p, ref_v, ref_report, CFG3["epochs"])
     _adam_noise(learners[0].policy.arena.flat.cpu(), learners[0].value_net.arena.flat.cpu(), one_p, one_v, CFG3["epochs"],
-                "8 ranks vs 1 rank (one pass)")
+                "8 ranks vs 1 rank (one pass)", g0=g0)
     for l in learners[1:]:
         assert torch.equal(l.policy.arena.flat, learners[0].policy.arena.flat) and torch.equal(l.value_net.arena.flat, learners[0].value_net.arena.flat)
         assert torch.equal(l.policy_optimizer.exp_avg_sq, learners[0].policy_optimizer.exp_avg_sq)
@@ -264,7 +295,7 @@ def test_configs3_shape_four_process_ranks():
         # the four partial gradients are the 1-rank run's own, bit for bit; gloo adds them in another order than the 1-rank run's
         # accumulation into .grad, and Adam turns that into up to a few percent of a step for entries that cancel (_adam_noise)
         _same_update(p, v, report, ref_p, ref_v, ref_report, CFG3["epochs"], tol=float("inf"))
-        _adam_noise(p, v, ref_p, ref_v, CFG3["epochs"], "4 process ranks (gloo) vs 1 rank, same passes" if rank == 0 else "rank %d" % rank)
+        _adam_noise(p, v, ref_p, ref_v, CFG3["epochs"], "4 process ranks (gloo) vs 1 rank, same passes" if rank == 0 else "rank %d" % rank, g0=ref_grads[0])
     assert all(torch.equal(out[0][0], out[r][0]) and torch.equal(out[0][1], out[r][1]) for r in range(1, 4))
 
 

@@ -602,7 +602,7 @@ def test_g2_value_forward(L, golden):
         out = torch.empty(64, net.ld_out, device="cuda")
         w = net.ws(64)
         check(L, L.rlppo_mlp_forward(stream(), net.dims_c, net.nl, P(net.packed), P(rows), net.ld_in, 64, 0, P(out),
-                                     net.ld_out, P(w), w.numel()))
+                                     net.ld_out, P(w), w.numel(), None))
         assert relerr(out[:, :1], g["values"]) < 1e-5
         assert (out[:, 1:] == 0).all()
 
@@ -628,13 +628,13 @@ def test_g1bc_fused_rollout_kernel_against_the_reference(L, golden, name):
             probs = torch.empty(n, 90, device="cuda")
             w = net.ws(n)
             check(L, L.rlppo_discrete_act(stream(), net.dims_c, net.nl, P(net.packed), P(rows), net.ld_in, n, P(qd), P(act), P(logp),
-                                          P(probs), P(w), w.numel()))
+                                          P(probs), P(w), w.numel(), None))
             assert relerr(probs, g["probs"]) < 1e-5
         else:
             raw = dev(g["obs"])
             w = torch.empty(int(L.rlppo_discrete_step_workspace_bytes(net.dims_c, net.nl, n)), dtype=torch.uint8, device="cuda")
             check(L, L.rlppo_discrete_step(stream(), net.dims_c, net.nl, P(net.packed), P(raw), 0, raw.shape[1], n, 0, 0.0, 1.0, None, None,
-                                           P(qd), P(act), None, P(logp), None, 0, P(w), w.numel()))
+                                           P(qd), P(act), None, P(logp), None, 0, P(w), w.numel(), None))
         assert int(L.rlppo_dbg_counter(0)) == fused0 + 1 and int(L.rlppo_dbg_counter(1)) == chain0, "the fused kernel did not run"
         assert np.array_equal(act.cpu().numpy(), g["actions"]), entry
         assert np.abs(logp.cpu().numpy() - g["logp"]).max() < 1e-5, entry
@@ -645,7 +645,7 @@ def test_g1bc_fused_rollout_kernel_against_the_reference(L, golden, name):
         rows, w = net.pad(g["obs"]), net.ws(n)
         chain0 = int(L.rlppo_dbg_counter(1))
         check(L, L.rlppo_discrete_act(stream(), net.dims_c, net.nl, P(net.packed), P(rows), net.ld_in, n, P(qd), P(act2), P(logp2), None,
-                                      P(w), w.numel()))
+                                      P(w), w.numel(), None))
         assert int(L.rlppo_dbg_counter(1)) == chain0 + 1
     finally:
         check(L, L.rlppo_dbg_set(27, 1))
@@ -662,7 +662,7 @@ def test_g1_discrete_act(L, golden):
     w = net.ws(64)
     qd, pd = dev(g["q"]), dev(g["probs"])
     check(L, L.rlppo_discrete_act(stream(), net.dims_c, net.nl, P(net.packed), P(rows), net.ld_in, 64, P(qd),
-                                  P(act), P(logp), P(probs), P(w), w.numel()))
+                                  P(act), P(logp), P(probs), P(w), w.numel(), None))
     assert relerr(probs, g["probs"]) < 1e-5
     assert np.abs(logp.cpu().numpy() - g["logp"]).max() < 1e-5
     assert np.array_equal(act.cpu().numpy(), g["actions"])
@@ -696,7 +696,7 @@ def test_fused_rollout_step_is_bit_identical_to_the_layer_chain(L, d, hidden, A)
             check(L, L.rlppo_dbg_set(27, fused))
             try:
                 check(L, L.rlppo_discrete_act(stream(), net.dims_c, net.nl, P(net.packed), P(rows), net.ld_in, n, P(q), P(act), P(logp),
-                                              P(probs), P(w), w.numel()))
+                                              P(probs), P(w), w.numel(), None))
             finally:
                 check(L, L.rlppo_dbg_set(27, 1))
             outs.append((act.cpu(), logp.cpu(), probs.cpu()))
@@ -711,10 +711,69 @@ def test_fused_rollout_step_is_bit_identical_to_the_layer_chain(L, d, hidden, A)
     logp = torch.empty(n, device="cuda")
     w = net.ws(n)
     check(L, L.rlppo_discrete_act(stream(), net.dims_c, net.nl, P(net.packed), P(net.pad(obs)), net.ld_in, n, P(dev(qh)), P(act), P(logp),
-                                  None, P(w), w.numel()))
+                                  None, P(w), w.numel(), None))
     oact, ologp = nets.discrete_sample(nets.discrete_probs(net.params, obs), qh)
     same = act.cpu() == oact
     assert (~same).sum().item() <= 2 and (logp.cpu() - ologp)[same].abs().max().item() < 1e-5
+
+
+@pytest.mark.parametrize("hidden", [(256, 256, 256), (96, 96)], ids=["fused256", "chain_only"])
+def test_act_options_completion_words_and_per_call_precision(L, hidden):
+    """[r5] rlppo_act_opts: (a) done_words -- the call's last kernel stores one word per 16 rows into pinned host memory behind the
+    results (the one-launch kernel workgroup by workgroup, the layer chain through one more tiny launch); a host that polls them
+    with rlppo_host_wait_words reads the SAME actions / log-probabilities a stream synchronisation would have delivered, without
+    synchronising; a wait for a value nobody stores times out (return 1), never hangs.  (b) precision -- the inference precision
+    is an argument of the call: bf16 operands through the option == bf16 operands through the process-wide switch, bit for bit,
+    and a call without the option is untouched by another call's option."""
+    from rlgym_ppo_amd import _native as N
+    d, A, n = 107, 90, 200
+    torch.manual_seed(5 + hidden[0])
+    net = Net(L, nets.init_mlp(d, hidden, A))
+    rs = np.random.RandomState(hidden[0])
+    obs = torch.from_numpy(np.clip(rs.randn(n, d), -5, 5).astype(np.float32)).pin_memory()     # host inputs, as ActGraph hands them over
+    q = torch.from_numpy(rs.exponential(size=(n, A)).astype(np.float32)).pin_memory()
+    ws = torch.empty(int(L.rlppo_discrete_step_workspace_bytes(net.dims_c, net.nl, n)), dtype=torch.uint8, device="cuda")
+    n_words = int(L.rlppo_act_done_words(n))
+    assert n_words == 13 and L.rlppo_act_done_words(0) == 0 and L.rlppo_act_done_words(16) == 1 and L.rlppo_act_done_words(17) == 2
+
+    def step(opts, act, logp):
+        check(L, L.rlppo_discrete_step(stream(), net.dims_c, net.nl, P(net.packed), P(obs), 0, d, n, 0, 0.0, 1.0, None, None, P(q), P(act), None,
+                                       P(logp), None, 0, P(ws), ws.numel(), opts))
+
+    ref_a, ref_l = torch.empty(n, dtype=torch.int64).pin_memory(), torch.empty(n).pin_memory()
+    step(None, ref_a, ref_l)
+    torch.cuda.synchronize()
+    done = torch.zeros(n_words, dtype=torch.int32).pin_memory()
+    for value in (7, 8, 0x7FFFFFFF):
+        act, logp = torch.full((n,), -1, dtype=torch.int64).pin_memory(), torch.full((n,), float("nan")).pin_memory()
+        opts = N.ActOpts(N.PRECISION_DEFAULT, value, done.data_ptr())
+        step(ctypes.byref(opts), act, logp)
+        assert L.rlppo_host_wait_words(P(done), n_words, value, 5_000_000) == 0      # no stream synchronisation before the reads below
+        assert torch.equal(act, ref_a) and torch.equal(logp, ref_l), value
+        assert (done.numpy() == value).all()
+    torch.cuda.synchronize()
+    assert L.rlppo_host_wait_words(P(done), n_words, 12345, 20_000) == 1             # nobody stores that value: a bounded wait
+    assert L.rlppo_host_wait_words(P(done), 0, 1, 0) == 0
+    # (b) per-call precision
+    bad = N.ActOpts(7, 0, None)
+    a0, l0 = torch.empty(n, dtype=torch.int64, device="cuda"), torch.empty(n, device="cuda")
+    assert L.rlppo_discrete_step(stream(), net.dims_c, net.nl, P(net.packed), P(obs), 0, d, n, 0, 0.0, 1.0, None, None, P(q), P(a0), None, P(l0), None,
+                                 0, P(ws), ws.numel(), ctypes.byref(bad)) == 1001
+    rows = net.pad(obs.numpy())
+    w = net.ws(n)
+    outs = {}
+    for key, glob, opt in (("fp32", 0, None), ("bf16_switch", 1, None), ("bf16_option", 0, N.PRECISION_BF16), ("fp32_option_under_bf16_switch", 1, N.PRECISION_FP32)):
+        check(L, L.rlppo_set_inference_precision(glob))
+        try:
+            out = torch.empty(n, net.ld_out, device="cuda")
+            o = N.ActOpts(opt, 0, None) if opt is not None else None
+            check(L, L.rlppo_mlp_forward(stream(), net.dims_c, net.nl, P(net.packed), P(rows), net.ld_in, n, 0, P(out), net.ld_out, P(w), w.numel(),
+                                         ctypes.byref(o) if o is not None else None))
+            outs[key] = out.cpu()
+        finally:
+            check(L, L.rlppo_set_inference_precision(0))
+    assert torch.equal(outs["bf16_switch"], outs["bf16_option"]) and torch.equal(outs["fp32"], outs["fp32_option_under_bf16_switch"])
+    assert not torch.equal(outs["fp32"], outs["bf16_option"]) and relerr(outs["bf16_option"], outs["fp32"]) < 3e-2
 
 
 @pytest.mark.parametrize("hidden", [(256, 256, 256), (64, 64), (96, 96)], ids=["fused256", "fused64", "chain_only"])
@@ -745,7 +804,7 @@ def test_discrete_step_raw_observations_all_modes(L, hidden):
                 try:
                     check(L, L.rlppo_discrete_step(stream(), net.dims_c, net.nl, P(net.packed), P(obs), int(f64), d + 5, n, mode, 0.3, 1.7,
                                                     P(mean_v) if mode == 2 else None, P(std_v) if mode == 2 else None, P(q), P(act), P(actf),
-                                                    P(logp), P(rows), rows.shape[1], P(ws), ws.numel()))
+                                                    P(logp), P(rows), rows.shape[1], P(ws), ws.numel(), None))
                 finally:
                     check(L, L.rlppo_dbg_set(27, 1))
                 outs.append((act.cpu(), actf.cpu(), logp.cpu(), rows[:, :net.ld_in].cpu()))
@@ -760,7 +819,7 @@ def test_discrete_step_raw_observations_all_modes(L, hidden):
             if mode == 0:
                 assert torch.equal(rows[:, :d], want)
     assert L.rlppo_discrete_step(stream(), net.dims_c, net.nl, P(net.packed), P(obs), 0, d - 1, n, 0, 0.0, 1.0, None, None, P(q), P(act), None,
-                                 P(logp), None, 0, P(ws), ws.numel()) != 0   # ld_obs < d is refused
+                                 P(logp), None, 0, P(ws), ws.numel(), None) != 0   # ld_obs < d is refused
 
 
 @pytest.mark.parametrize("A", [90, 300, 1000])
@@ -773,7 +832,7 @@ def test_discrete_probs_and_deterministic_choice(L, golden, A):
         rows = net.pad(g["obs"])
         probs, best, w = torch.full((64, 96), float("nan"), device="cuda"), torch.full((1,), -7, dtype=torch.int64, device="cuda"), net.ws(64)
         check(L, L.rlppo_discrete_probs(stream(), net.dims_c, net.nl, P(net.packed), P(rows), net.ld_in, 64, 1, P(probs), 96, P(best),
-                                        P(w), w.numel()))
+                                        P(w), w.numel(), None))
         assert relerr(probs[:, :90], g["probs"]) < 1e-5 and torch.isnan(probs[:, 90:]).all()  # ld_probs respected
         assert int(best) == int(g["det_action"]) == int(probs[:, :90].cpu().numpy().argmax())
     rs = np.random.RandomState(A)
@@ -785,8 +844,8 @@ def test_discrete_probs_and_deterministic_choice(L, golden, A):
     rows, w = net.pad(obs), net.ws(n)
     soft, clamped = torch.empty(n, A, device="cuda"), torch.empty(n, A, device="cuda")
     best = torch.empty(1, dtype=torch.int64, device="cuda")
-    check(L, L.rlppo_discrete_probs(stream(), net.dims_c, net.nl, P(net.packed), P(rows), net.ld_in, n, 0, P(soft), A, None, P(w), w.numel()))
-    check(L, L.rlppo_discrete_probs(stream(), net.dims_c, net.nl, P(net.packed), P(rows), net.ld_in, n, 1, P(clamped), A, P(best), P(w), w.numel()))
+    check(L, L.rlppo_discrete_probs(stream(), net.dims_c, net.nl, P(net.packed), P(rows), net.ld_in, n, 0, P(soft), A, None, P(w), w.numel(), None))
+    check(L, L.rlppo_discrete_probs(stream(), net.dims_c, net.nl, P(net.packed), P(rows), net.ld_in, n, 1, P(clamped), A, P(best), P(w), w.numel(), None))
     ref = torch.softmax(nets.mlp(params, torch.as_tensor(obs)).double(), -1)
     assert relerr(soft, ref) < 2e-6 and float(soft.min()) < 1e-11
     assert torch.equal(clamped, soft.clamp(min=1e-11, max=1))
@@ -796,9 +855,9 @@ def test_discrete_probs_and_deterministic_choice(L, golden, A):
     bias[[A - 3, 17]] = 4.0
     tie = Net(L, [(torch.zeros(A, d), bias)])
     only = torch.empty(1, dtype=torch.int64, device="cuda")
-    check(L, L.rlppo_discrete_probs(stream(), tie.dims_c, tie.nl, P(tie.packed), P(rows), tie.ld_in, n, 1, None, 0, P(only), P(w), w.numel()))
+    check(L, L.rlppo_discrete_probs(stream(), tie.dims_c, tie.nl, P(tie.packed), P(rows), tie.ld_in, n, 1, None, 0, P(only), P(w), w.numel(), None))
     assert int(only) == 17
-    assert L.rlppo_discrete_probs(stream(), tie.dims_c, tie.nl, P(tie.packed), P(rows), tie.ld_in, n, 1, None, 0, None, P(w), w.numel()) != 0
+    assert L.rlppo_discrete_probs(stream(), tie.dims_c, tie.nl, P(tie.packed), P(rows), tie.ld_in, n, 1, None, 0, None, P(w), w.numel(), None) != 0
 
 
 def test_categorical_select_exact_at_scale(L):
@@ -837,7 +896,7 @@ def test_rollout_shape_discrete_act_vs_oracle(L):
     w = net.ws(4096)
     qd = dev(q)
     check(L, L.rlppo_discrete_act(stream(), net.dims_c, net.nl, P(net.packed), P(rows), net.ld_in, 4096, P(qd), P(act),
-                                  P(logp), P(probs), P(w), w.numel()))
+                                  P(logp), P(probs), P(w), w.numel(), None))
     assert relerr(probs, oprobs) < 1e-5
     # with its own (ulp-different) probs the indices agree except on near-ties: margin stated = 1e-4 relative in p/q
     a = act.cpu()
@@ -862,14 +921,14 @@ def test_g9_gaussian_and_multidiscrete_act(L, golden):
     m, b = nets.var_map(0.1, 1.0)
     epsd = dev(g["eps"])
     check(L, L.rlppo_gaussian_act(stream(), net.dims_c, net.nl, P(net.packed), P(rows), net.ld_in, n, P(epsd), m, b,
-                                  P(act), P(logp), P(w), w.numel()))
+                                  P(act), P(logp), P(w), w.numel(), None))
     np.testing.assert_allclose(act.cpu().numpy(), g["act"], rtol=1e-5, atol=2e-6)
     clamped = np.abs(g["act"]) == 1.0
     assert np.array_equal(np.abs(act.cpu().numpy()) == 1.0, clamped)
     # log-probabilities: float64 truth with the bound the 4-term formula's conditioning implies (tests/fp64_gate.py), and the
     # reference's own float32 numbers within the sum of the two implementations' bounds
     y = torch.empty(n, net.ld_out, device="cuda")
-    check(L, L.rlppo_mlp_forward(stream(), net.dims_c, net.nl, P(net.packed), P(rows), net.ld_in, n, 1, P(y), net.ld_out, P(w), w.numel()))
+    check(L, L.rlppo_mlp_forward(stream(), net.dims_c, net.nl, P(net.packed), P(rows), net.ld_in, n, 1, P(y), net.ld_out, P(w), w.numel(), None))
     res = fp64_gate.gauss_logp_check(net.params, g["obs"], g["eps"], y, act, logp, label="G9")
     assert np.abs(logp.cpu().numpy() - g["logp"]).max() <= res["hip"][2] * (res["hip"][1] + res["cpu"][1]) + 1e-7
 
@@ -882,7 +941,7 @@ def test_g9_gaussian_and_multidiscrete_act(L, golden):
     w = net.ws(n)
     qd = dev(g["q"])
     check(L, L.rlppo_multidiscrete_act(stream(), net.dims_c, net.nl, P(net.packed), P(rows), net.ld_in, n, P(qd),
-                                       P(act), P(logp), P(w), w.numel()))
+                                       P(act), P(logp), P(w), w.numel(), None))
     assert np.array_equal(act.cpu().numpy(), g["act"])
     np.testing.assert_allclose(logp.cpu().numpy(), g["logp"], rtol=1e-5, atol=1e-5)
 
@@ -1223,6 +1282,56 @@ def test_gemm_nt_x3_forward_and_dx(L, M, N, K):
     print(f"[x3] dX {M}x{N2}x{N}: split-bf16 max {d3.max().item() / sc:.2e} rms {d3.pow(2).mean().sqrt().item() / sc:.2e}; fp32 MFMA max {d32.max().item() / sc:.2e} rms {d32.pow(2).mean().sqrt().item() / sc:.2e}")
     assert torch.equal(dX3 == 0, dX32 == 0) or ((dX3 == 0) != (dX32 == 0)).sum().item() <= 4   # the same entries masked
     assert d3.max().item() <= max(1.0 * d32.max().item(), 2e-7 * sc) and d3.pow(2).mean().sqrt().item() <= 1.05 * d32.pow(2).mean().sqrt().item() + 1e-9 * sc
+
+
+def test_gemm_nt_x3_special_values(L):
+    """[r5] The split-bf16 products beside the fp32 MFMA kernel on operands the N(0, 1) tests never draw (include/rlppo.h states
+    the behaviour this pins): rows of 1e-30-scale and of denormal activations stay as accurate, relative to their own magnitude,
+    as the fp32 kernel's; rows WITHOUT a special value are bit-identical to the run without any (a special value does not leak
+    beyond its row); a row holding +-inf, NaN or a finite |x| >= 3.396e38 (which rounds to a bf16 infinity) comes out NaN over the
+    whole row -- the documented deviation: x - bf16(x) is inf - inf there, where the fp32 MFMA's fmaf chain returns +-inf (or, for
+    the huge finite value, a finite product)."""
+    M, N, K = 512, 256, 256
+    g = torch.Generator(device="cuda").manual_seed(99)
+    A = torch.randn(M, K, device="cuda", generator=g).contiguous()
+    W = ((torch.rand(N, K, device="cuda", generator=g) * 2 - 1) / np.sqrt(K)).contiguous()
+    planes = torch.zeros(3 * N * K, dtype=torch.bfloat16, device="cuda")
+    check(L, L.rlppo_dbg_pack_x3(stream(), P(W), K, N, K, P(planes)))
+    nb = max(int(L.rlppo_dbg_gemm_nt_bits_bytes(M, N)), 8)
+    ones = torch.full((nb,), 0xFF, dtype=torch.uint8, device="cuda")           # a mask that keeps everything: the product itself (mode 1 = dX)
+
+    def both(a):
+        c32, c3 = torch.empty(M, N, device="cuda"), torch.empty(M, N, device="cuda")
+        check(L, L.rlppo_dbg_gemm_nt_bits(stream(), P(a), K, P(W), K, None, P(c32), N, M, N, K, 3, P(ones)))
+        check(L, L.rlppo_dbg_gemm_nt_x3(stream(), P(a), K, P(planes), None, P(c3), N, M, N, K, 1, P(ones)))
+        return c32, c3
+
+    base32, base3 = both(A)
+    S = A.clone()
+    special = {3: float("inf"), 10: float("nan"), 20: 3.4e38, 30: float("-inf")}
+    for r, v in special.items():
+        S[r, 5] = v
+    S[40:48] *= 1e-30
+    S[50:58] *= 1e-38                                                           # fp32 denormals (|x| < 1.18e-38) among them
+    c32, c3 = both(S)
+    plain = torch.ones(M, dtype=torch.bool, device="cuda")
+    plain[list(special)] = False
+    plain[40:48] = plain[50:58] = False
+    assert torch.equal(c3[plain], base3[plain]) and torch.equal(c32[plain], base32[plain])   # no leak beyond the row
+    truth = S.double() @ W.double().t()
+    for lo, hi, tag in ((40, 48, "1e-30 scale"), (50, 58, "1e-38 scale (denormal operands)")):
+        sc = truth[lo:hi].abs().max().item()
+        e32, e3 = (c32[lo:hi].double() - truth[lo:hi]).abs().max().item() / sc, (c3[lo:hi].double() - truth[lo:hi]).abs().max().item() / sc
+        print(f"[x3 special] {tag}: err / max|C| of the rows: split-bf16 {e3:.2e}, fp32 MFMA {e32:.2e}")
+        if lo == 40:
+            assert e3 <= max(e32, 2e-7)         # normal fp32 range: the pieces are normal bf16 numbers, nothing is lost
+        else:
+            assert e3 <= 1e-2                    # pieces below bf16's normal range (2^-126) lose their low bits: relative to 1e-38, not to the data
+    for r, v in special.items():
+        print(f"[x3 special] row {r} holds {v}: fp32 MFMA -> {int(torch.isinf(c32[r]).sum())} inf / {int(torch.isnan(c32[r]).sum())} NaN / "
+              f"{int(torch.isfinite(c32[r]).sum())} finite; split-bf16 -> {int(torch.isinf(c3[r]).sum())} inf / {int(torch.isnan(c3[r]).sum())} NaN")
+        assert torch.isnan(c3[r]).all()                                          # the documented deviation (never a finite wrong number)
+        assert not torch.isfinite(c32[r]).all() or v == 3.4e38
 
 
 def test_minibatch_x3_precision_cfg2_shape(L):

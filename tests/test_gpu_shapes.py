@@ -32,7 +32,7 @@ def test_discrete_odd_shapes(L, d, hidden, A, n, mb):
     w = net.ws(n)
     qd = dev(q)
     check(L, L.rlppo_discrete_act(stream(), net.dims_c, net.nl, P(net.packed), P(rows), net.ld_in, n, P(qd), P(act), P(logp),
-                                  P(probs), P(w), w.numel()))
+                                  P(probs), P(w), w.numel(), None))
     assert relerr(probs, oprobs) < 1e-5
     assert (act.cpu() != oact).sum().item() <= max(1, n // 500)
     old = (ologp + torch.as_tensor(rs.randn(n).astype(np.float32) * 0.2)).numpy()
@@ -55,18 +55,18 @@ def test_single_row_and_empty_calls(L):
     logp = torch.empty(1, device="cuda")
     w = net.ws(1)
     check(L, L.rlppo_discrete_act(stream(), net.dims_c, net.nl, P(net.packed), P(rows), net.ld_in, 1, P(qd), P(act), P(logp), None,
-                                  P(w), w.numel()))
+                                  P(w), w.numel(), None))
     oact, ologp = nets.discrete_sample(nets.discrete_probs(pol, obs), q)
     assert act.item() == oact.item() and abs(logp.item() - ologp.item()) < 1e-5
     # n == 0 is a no-op for every entry point that takes a row count
-    check(L, L.rlppo_discrete_act(stream(), net.dims_c, net.nl, P(net.packed), None, net.ld_in, 0, None, None, None, None, None, 0))
-    check(L, L.rlppo_mlp_forward(stream(), net.dims_c, net.nl, P(net.packed), None, net.ld_in, 0, 0, None, net.ld_out, None, 0))
+    check(L, L.rlppo_discrete_act(stream(), net.dims_c, net.nl, P(net.packed), None, net.ld_in, 0, None, None, None, None, None, 0, None))
+    check(L, L.rlppo_mlp_forward(stream(), net.dims_c, net.nl, P(net.packed), None, net.ld_in, 0, 0, None, net.ld_out, None, 0, None))
     check(L, L.rlppo_pad_rows(stream(), None, 0, 0, 107, 107, None, 128, 0, 0.0, 1.0))
     check(L, L.rlppo_categorical_select(stream(), None, 90, 0, 90, None, None, None))
     # argument errors are reported, not crashed on
-    assert L.rlppo_mlp_forward(stream(), net.dims_c, net.nl, P(net.packed), P(rows), 64, 1, 0, P(logp), net.ld_out, P(w), w.numel()) == 1001
+    assert L.rlppo_mlp_forward(stream(), net.dims_c, net.nl, P(net.packed), P(rows), 64, 1, 0, P(logp), net.ld_out, P(w), w.numel(), None) == 1001
     assert b"ld_obs" in L.rlppo_last_error()
-    assert L.rlppo_mlp_forward(stream(), net.dims_c, net.nl, P(net.packed), P(rows), net.ld_in, 1, 0, P(logp), net.ld_out, P(w), 16) == 1002
+    assert L.rlppo_mlp_forward(stream(), net.dims_c, net.nl, P(net.packed), P(rows), net.ld_in, 1, 0, P(logp), net.ld_out, P(w), 16, None) == 1002
 
 
 def test_obs_standardisation_fused_in_staging(L):

@@ -28,8 +28,20 @@ db = torch.zeros(256, device=dev)
 tn_ws = torch.empty(max(int(L.rlppo_dbg_gemm_tn_workspace_bytes(o, i, M)) for o, i in ((256, 256), (256, 107), (90, 256))),
                     dtype=torch.uint8, device=dev)
 bits = torch.zeros(int(L.rlppo_dbg_gemm_nt_bits_bytes(M, 256)), dtype=torch.uint8, device=dev)  # ReLU bitmask: forward writes, dX reads
+# [r5] the grouped weight-gradient launch of a pass (7 products: 2 first-layer, 4 hidden, the policy head) + its one reduction
+gshapes = [(256, 107, A256, 256, A128, K0), (256, 256, A256, 256, A256b, 256), (256, 256, A256b, 256, A256, 256), (90, 256, A96, 96, A256, 256),
+           (256, 107, A256b, 256, A128, K0), (256, 256, A256, 256, A256b, 256), (256, 256, A256b, 256, A256, 256)]
+gprods = (N.TnProduct * len(gshapes))()
+gkeep = []
+for q, (out, in_, dY, ny, X, kx) in zip(gprods, gshapes):
+    gw, gb = torch.zeros(out * in_, device=dev), torch.zeros(out, device=dev)
+    gkeep.append((gw, gb))
+    q.dY, q.ldy, q.ny_valid, q.X, q.ldx, q.kx_valid = dY.data_ptr(), ny, ny, X.data_ptr(), kx, kx
+    q.dW, q.db, q.out, q.in_, q.rowtab, q.src_rows = gw.data_ptr(), gb.data_ptr(), out, in_, None, 0
+g_ws = torch.empty(int(L.rlppo_dbg_gemm_tn_group_workspace_bytes(gprods, len(gshapes), M)), dtype=torch.uint8, device=dev)
 reps = int(os.environ.get("REPS", 3))
 for _ in range(reps):
+    N.check(L.rlppo_dbg_gemm_tn_group(st(), gprods, len(gshapes), M, P(g_ws), g_ws.numel()))
     N.check(L.rlppo_dbg_gemm_nt_bits(st(), P(A256), 256, P(W), 256, P(bias), P(C256), 256, M, 256, 256, 1, P(bits)))
     N.check(L.rlppo_dbg_gemm_nt_bits(st(), P(A128), K0, P(W), K0, P(bias), P(C256), 256, M, 256, K0, 1, P(bits)))
     N.check(L.rlppo_dbg_gemm_nt(st(), P(A256), 256, P(W), 256, P(bias), None, 0, P(C96), 96, M, 96, 256, 0))
