@@ -155,9 +155,12 @@ class ArenaModule(nn.Module):
         if (isinstance(obs, torch.Tensor) and obs.is_cuda) or (isinstance(noise, torch.Tensor) and noise.is_cuda):
             return None
         a = self.arena
-        o = np.asarray(obs.detach().numpy() if isinstance(obs, torch.Tensor) else obs)
-        if o.ndim == 1:
-            o = o.reshape(1, -1)
+        if type(obs) is np.ndarray and obs.ndim == 2:  # (the per-environment-step call: no conversions)
+            o = obs
+        else:
+            o = np.asarray(obs.detach().numpy() if isinstance(obs, torch.Tensor) else obs)
+            if o.ndim == 1:
+                o = o.reshape(1, -1)
         if o.ndim != 2 or o.shape[1] != a.d_in or not (0 < o.shape[0] <= self.act_graph_max):
             return None
         n = o.shape[0]
@@ -174,7 +177,7 @@ class ArenaModule(nn.Module):
         if g is None:
             g = self._graphs[_bucket(n)] = ActGraph(self, _bucket(n))
         a.ensure_packed()
-        return g.run(o.astype(np.float32, copy=False), q.contiguous(), n)
+        return g.run(o if o.dtype == np.float32 else o.astype(np.float32), q if q.is_contiguous() else q.contiguous(), n)
 
     def _apply(self, fn, *a, **k):  # .to()/.float()/... : re-bind afterwards so the kernels keep seeing the params
         out = super()._apply(fn, *a, **k)

@@ -4,6 +4,8 @@ get_action runs librlppo's fused forward + softmax + clamp + argmax(p/q) kernel.
 on the host with torch's CPU generator, because that is exactly what torch.multinomial(probs, 1, True) consumes
 in the reference's CPU path; a seeded run therefore picks the reference's action indices.
 """
+import ctypes
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -151,8 +153,12 @@ class DiscreteFF(ArenaModule):
         L = N.lib()
         if g is None:
             return int(L.rlppo_discrete_step_workspace_bytes(a.dims_c, a.n_layers, cap))
-        N.check(L.rlppo_discrete_step(stream_ptr(), a.dims_c, a.n_layers, ptr(a.packed), ptr(g.obs_pin), 0, a.d_in, cap, 0, 0.0, 1.0,
-                                      None, None, ptr(g.q_pin), ptr(g.act_pin), None, ptr(g.logp_pin), None, 0, ptr(g.ws), g.ws.numel(), opts))
+        args = getattr(g, "_raw_args", None)
+        if args is None or args[0] is not opts:  # every pointer of the call is fixed for the graph's lifetime: built once
+            args = g._raw_args = (opts, (a.dims_c, a.n_layers, ptr(a.packed), ptr(g.obs_pin), 0, a.d_in, cap, 0, 0.0, 1.0, None, None, ptr(g.q_pin),
+                                         ptr(g.act_pin), None, ptr(g.logp_pin), None, 0, ptr(g.ws), g.ws.numel(),
+                                         ctypes.byref(opts) if opts is not None else None))
+        N.check(L.rlppo_discrete_step(stream_ptr(), *args[1]))
 
     def act_padded(self, rows, noise=None):
         """Padded device rows [n, ld_in] -> (actions int64 [n], log_probs fp32 [n]) ON THE DEVICE: the part of get_action
