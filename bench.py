@@ -101,7 +101,7 @@ def time_region(fn, reps, warm=3, warm_s=0.0):
     return e0.elapsed_time(e1) / reps
 
 
-def kernel_breakdown(learner):
+def kernel_breakdown(learner, only=None):
     """Times every GEMM launch shape of one pass of the update through the diagnostic entry points, at the row count the
     update really launches (learner._fused_rows: at one GPU the 8 minibatches of a batch are evaluated in ONE pass of
     524,288 rows, PPOLearner.max_fused_minibatches; with 8 ranks a pass is one 65,536-row minibatch), and returns
@@ -177,6 +177,8 @@ def kernel_breakdown(learner):
     ]
     rows = []
     for name, count, fn, flop_exec, flop in shapes:
+        if only is not None and not name.startswith(only):
+            continue
         ms = time_region(fn, 20, warm_s=0.3)
         # compact keys (the driver keeps ~12 KB of the line): n = launches per pass, ms = per launch, tflops / frac on ALGORITHMIC flop
         # (K = 107, N = 90), exec_tflops on the padded tile shape the kernel multiplies

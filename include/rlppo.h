@@ -443,7 +443,8 @@ int rlppo_dbg_gemm_nt_x3(void *stream, const float *A, int64_t lda, const void *
  *     (forward / dX; default) | 1 = 256 x 256, one workgroup per tile | 0 = 128 x 128]
  *  24 rlppo_torch_cpu_exponential transform [1 = AVX2 logarithm certified element by element against float32 rounding, libm for the
  *     rest (default) | 0 = libm for every element]
- *  26 minibatch gather [1 = fused into the first layer's GEMM launches through a row table (default) | 0 = a gather pass of its own]
+ *  26 minibatch gather [1 = fused into the first layer's GEMM launches through a row table from 262,144 rows per pass, a gather pass of its
+ *     own below (default; [r5]: measured, csrc/api.hip) | 2 = fused at every size | 0 = always a gather pass of its own]
  *  27 rlppo_discrete_act / rlppo_discrete_step [1 = one fused launch where the network has that form (default) | 0 = layer chain]
  *  29 policy + critic layers of equal widths as ONE launch [1 = from 262,144 rows per pass (default) | 0 = never | 2 = always]
  *  31 paired pass: the critic's output-layer backward waits for the policy's loss kernel [1 (default) | 0 = both chains free-running]

@@ -864,6 +864,7 @@ static int backward_b16(hipStream_t st, const NetLayout &net, const float *packe
 static int g_head_order = 1;  // rlppo_dbg_set(31, 0/1): the critic's output-layer backward waits for the policy's loss kernel (both HBM-bound)
 static int g_paired = 1;  // rlppo_dbg_set(29, 0 / 1 / 2): never / from PAIRED_MIN_ROWS rows / always (tests)
 constexpr int64_t PAIRED_MIN_ROWS = 262144;
+constexpr int64_t FUSED_GATHER_MIN_ROWS = 262144;
 static bool twin_ok(const NetLayout &p, const NetLayout &v, int64_t mb) {
     if (p.n_layers != v.n_layers || p.n_layers < 2) return false;
     for (int l = 0; l + 1 < p.n_layers; ++l) {
@@ -1050,7 +1051,12 @@ int rlppo_ppo_minibatch(void *stream, const rlppo_minibatch_args *a) {
         return n.n_layers > 1 && nt_gather_ok(a->ld_states, src_rows, n.L[0].pout, n.L[0].pin) && tn_gather_ok(a->ld_states, src_rows) &&
                !(n.L[0].out > 64 && n.L[0].out <= 96 && !(n.L[0].in > 96 && n.L[0].in <= 112));
     };
-    const bool fused_gather = !b16 && g_fused_gather && src_rows > 0 && gather_form(pol) && gather_form(val);
+    // [r5] ... from FUSED_GATHER_MIN_ROWS rows per pass: with the weight gradients grouped (section 4.6) a 65,536-row pass is 1 % FASTER
+    // with the 10 us gather pass and contiguous first-layer operands than with rows fetched through the table inside four of its
+    // launches (11.59 against 11.71 ms per 10-epoch learn() at the 8-rank share, tools/ab_update.py, profiles/r05_ab_update_final.txt);
+    // at 524,288 rows per pass the two are equal and the fused form saves the 268 MB copy.  rlppo_dbg_set(26, 2): at every size (tests).
+    const bool fused_gather = !b16 && (g_fused_gather == 2 || (g_fused_gather == 1 && mb >= FUSED_GATHER_MIN_ROWS)) && src_rows > 0 &&
+                              gather_form(pol) && gather_form(val);
     if (!b16 && !fused_gather) rc = launch_gather_rows(st, a->states, a->ld_states, a->idx, states, pol.L[0].pin, mb, ring_base, ring_cap);
     if (rc) return rc;
     const float *pol_w = b16 ? a->pol_packed_r : a->pol_packed, *val_w = b16 ? a->val_packed_r : a->val_packed;

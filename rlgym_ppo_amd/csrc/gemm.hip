@@ -1021,6 +1021,7 @@ static int tn_group_plan(const int *outs, const int *ins, int n, int64_t M, int 
             const int blocks = it[p].g.ni * it[p].g.nj;
             int64_t rows = (int64_t)(t / blocks);
             rows = round_up(rows < 32 ? 32 : rows, 32);
+            if (g_tn_group_budget <= 0 && rows > TN_MAX_CHAIN) rows = TN_MAX_CHAIN;  // (a product of few MFMA blocks per row is not given longer chains for balance's sake)
             int64_t sp = cdiv(M, rows);
             if (sp > max_splits) sp = max_splits;
             rows = round_up(cdiv(M, sp), 32);
@@ -1034,19 +1035,18 @@ static int tn_group_plan(const int *outs, const int *ins, int n, int64_t M, int 
     // per output element, and its rounding error grows with the square root of its length -- the per-layer launches of rounds 1-4
     // never ran more than 4096 rows per split, TN_MAX_CHAIN keeps the grouped launch within sqrt(2) of that at any M (524,288 rows:
     // three rounds of 7,296-row splits).  (An explicit budget -- rlppo_dbg_set(38), tests -- is taken as it is.)
-    for (int rounds = 1;; ++rounds) {
+    // (from TWO rounds of the grid: at every size measured the two-round plan beats the one-round plan by 2-3 % -- workgroups of the second
+    // round start as those of the first finish, one by one, so stores, stage fills and MFMA streams of different workgroups overlap --
+    // and more rounds than the cap on the split length needs cost 1-3 % each: tools/tn_group_budget_sweep.py, profiles/r05_tn_group_budget_sweep.txt)
+    for (int rounds = g_tn_group_budget > 0 ? 1 : 2;; ++rounds) {
         const int64_t cap = (int64_t)budget * rounds;
-        double lo = 32.0, hi = (double)round_up(M, 32) * 32.0;  // fill(hi): one split per product
-        if (fill(lo) > cap) {
-            for (int i = 0; i < 60; ++i) {
-                const double mid = 0.5 * (lo + hi);
-                if (fill(mid) > cap) lo = mid; else hi = mid;
-            }
-            fill(hi);
+        double lo = 32.0, hi = (double)round_up(M, 32) * 32.0;  // fill(hi): the fewest splits the cap on their length allows
+        if (fill(lo) <= cap) break;                              // (hardly any rows: 32-row splits fit the grid)
+        for (int i = 0; i < 60; ++i) {
+            const double mid = 0.5 * (lo + hi);
+            if (fill(mid) > cap) lo = mid; else hi = mid;
         }
-        int longest = 0;
-        for (int p = 0; p < n; ++p) longest = it[p].rows_per_wg > longest ? it[p].rows_per_wg : longest;
-        if (longest <= TN_MAX_CHAIN || g_tn_group_budget > 0 || rounds >= 64) break;
+        if (fill(hi) <= cap || g_tn_group_budget > 0 || rounds >= 256) break;  // (with the splits capped, large M needs more than one round)
     }
     int wg = 0;
     size_t off = 0;

@@ -72,9 +72,11 @@ class ActGraph:
             pol._act_launch(self.rows, cap, self.q_pin, self.act_pin, self.logp_pin, self.ws, self.opts)
 
         self.body = body
-        # a body that is ONE launch (the discrete head) is issued as such on the pinned buffers: a replay of a one-node graph costs
-        # 2-3 us more than the launch (tools/small_batch_latency.py); RLPPO_ACT_EAGER=0/1 forces either form
-        self.eager = os.environ.get("RLPPO_ACT_EAGER", "1" if raw is not None else "0") == "1"
+        # The body is replayed as a hipGraph.  (Rounds 3-4 issued a ONE-launch body -- the discrete head -- eagerly: the replay of a
+        # one-node graph then cost 2-3 us more than the launch.  [r5] With completion polled instead of synchronised the replay is
+        # the cheaper of the two by 2-3 us -- one hipGraphLaunch against a 22-argument ctypes call + hipLaunchKernel --
+        # tools/small_batch_latency.py, profiles/r05_small_batch_latency.txt.)  RLPPO_ACT_EAGER=0/1 forces either form.
+        self.eager = os.environ.get("RLPPO_ACT_EAGER", "0") == "1"
         side = torch.cuda.Stream(dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):

@@ -1098,8 +1098,9 @@ def test_fused_gather_and_paired_launches_are_bitwise_neutral(L):
     idx = rs.randint(0, n, mb)
     idx[:3] = [n - 1, 0, n - 1]
     runs = {}
-    forms = dict(fused=(1, 2, 0, 1), separate_gather=(0, 2, 0, 1), two_chains=(1, 0, 0, 1), round2=(0, 0, 0, 1), stacked_pairs=(1, 2, 0, 0),
-                 folded_value_head=(1, 2, 1, 1))
+    # (26 = 2: the fused gather at every size -- the library's default engages it from 262,144 rows per pass)
+    forms = dict(fused=(2, 2, 0, 1), separate_gather=(0, 2, 0, 1), two_chains=(2, 0, 0, 1), round2=(0, 0, 0, 1), stacked_pairs=(2, 2, 0, 0),
+                 folded_value_head=(2, 2, 1, 1))
     for key, (k26, k29, k32, k33) in forms.items():
         check(L, L.rlppo_dbg_set(26, k26))
         check(L, L.rlppo_dbg_set(29, k29))   # paired launches (policy + critic layer in one grid) against one chain per network
