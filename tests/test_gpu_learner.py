@@ -146,6 +146,7 @@ def test_learn_at_the_paired_launch_size_matches_the_reference_fixture(golden, p
     assert np.array_equal(np.asarray([mg.param_hash(x.reshape(-1)) for x in exp[:3] + exp[7:]]), g["exp.hash"])   # the same experience
     buf = ExperienceBuffer(cfg["n"], cfg["seed"], "cpu")
     buf.submit_experience(*exp)
+    _G5BIG["exp"], _G5BIG["v0"] = exp, v0
 
     # float64 truth of both optimiser steps (CPU oracle, ~1 TFLOP of float64)
     layers = [cfg["d"]] + list(cfg["layers"])
@@ -174,6 +175,9 @@ def test_learn_at_the_paired_launch_size_matches_the_reference_fixture(golden, p
         _g5big_body(L, g, cfg, learner, buf, truth, grad64, n_steps, p0, vec, precision)
     finally:
         set_update_precision("fp32")
+
+
+_G5BIG = {}  # the G5big experience / critic parameters of the running test and, once measured, the worth D of its batch's ReLU decisions
 
 
 def _g5big_body(L, g, cfg, learner, buf, truth, grad64, n_steps, p0, vec, precision):
@@ -214,9 +218,40 @@ def _g5big_body(L, g, cfg, learner, buf, truth, grad64, n_steps, p0, vec, precis
         n_ill = int((wp < 1e-4).sum() + (wv < 1e-4).sum())
         print(f"[fp64 gate] g5big_learn_discrete_256x3 ({precision}) after optimiser step {s}: err(HIP, fp64)={errs['hip'][0]:.2e}  err(reference fp32 "
               f"fixture, fp64)={errs['ref'][0]:.2e}  | {n_ill} of {wp.size + wv.size} parameters with an ill-conditioned Adam step: HIP "
-              f"{errs['hip'][1]:.1e} = {errs['hip'][2]:.3f} of the derived bound, reference {errs['ref'][1]:.1e} = {errs['ref'][2]:.3f}")
+              f"{errs['hip'][1]:.1e} = {errs['hip'][2]:.3f} of the ARITHMETIC bound (d = 1e-5), reference {errs['ref'][1]:.1e} = {errs['ref'][2]:.3f}")
         assert errs["hip"][0] <= max(1e-5, 1.5 * errs["ref"][0]), errs
         assert errs["hip"][1] <= max(1e-5, 1.5 * errs["ref"][1]), errs
+        # [r5] The bound above prices a gradient tolerance of d = 1e-5 -- arithmetic -- and BOTH float32 results exceed it (the
+        # reference's own by more than the product's): what separates any float32 evaluation from float64's here is not
+        # arithmetic but the ReLU decisions a last bit decides.  With d = D, the measured worth of those decisions on this batch
+        # (fp64_gate.gate: the same float64 gradient under the implementation's own masks against float64's own), every entry
+        # of both results is inside (steps) lr min(1, D / w_i) + 1e-5 max|p|: a derived bound that holds, no yardstick.
+        if "D" not in _G5BIG:
+            import fp64_gate as _gate
+            n_pol_, lay = p0.size, [cfg["d"]] + list(cfg["layers"])
+
+            def unflat(flat, outs):
+                params, o, dims = [], 0, lay + [outs]
+                for i in range(len(dims) - 1):
+                    w = flat[o:o + dims[i + 1] * dims[i]].reshape(dims[i + 1], dims[i]); o += w.size
+                    bb = flat[o:o + dims[i + 1]]; o += bb.size
+                    params.append((w, bb))
+                return params
+            exp_, v0_ = _G5BIG["exp"], _G5BIG["v0"]
+            idx = np.random.RandomState(cfg["seed"]).permutation(cfg["n"])[:cfg["B"]]
+            tt = lambda ps: [(torch.as_tensor(w.copy()), torch.as_tensor(b.copy())) for w, b in ps]
+            res = _gate.gate(L, "discrete", tt(unflat(p0, cfg["n_act"])), tt(unflat(v0_, 1)), exp_[0][idx], exp_[1][idx], exp_[2][idx], exp_[8][idx],
+                             exp_[7][idx], cfg["clip"], cfg["ent"], 1.0, (unflat(hip_grads[0][:n_pol_], cfg["n_act"]), unflat(hip_grads[0][n_pol_:], 1), None),
+                             label=f"g5big first-step batch gradient ({precision})", x3=precision == "x3")
+            _G5BIG["D"] = res["hip"]["ambiguity"] + res["cpu"]["ambiguity"] + 2e-5
+        D = _G5BIG["D"]
+        for who, p_, v_ in (("HIP", pv, vv), ("reference", g[f"step{s}.policy"].astype(np.float64), g[f"step{s}.value"].astype(np.float64))):
+            worst = 0.0
+            for got, tr, weak in ((p_, tp, wp), (v_, tv, wv)):
+                allow = (s + 1) * cfg["lr"] * np.minimum(1.0, D / np.maximum(weak, 1e-300)) + 1e-5 * np.abs(tr).max()
+                worst = max(worst, float((np.abs(got - tr) / allow).max()))
+            print(f"[fp64 gate] g5big ({precision}) parameters after step {s}, {who} against float64: worst entry at {worst:.3f} of the decision-priced bound (D = {D:.1e})")
+            assert worst <= 1.0, (who, worst)
     passes, paired, gfused = (int(L.rlppo_dbg_counter(k)) for k in (2, 3, 4))
     assert passes - passes0 == n_steps and paired - paired0 == (n_steps if precision == "fp32" else 0) and gfused - gfused0 == n_steps, \
         "the paired / gather-fused launches did not run: (passes, paired, gather-fused) = %s" % ((passes - passes0, paired - paired0, gfused - gfused0),)
