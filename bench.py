@@ -426,16 +426,17 @@ def rollout_bench(learner):
                 ms_fused_launch=round(t_kernel, 4))
 
 
-def cpu_baseline(seed=123, reps=3):
+def cpu_baseline(seed=123, reps=2):
     """The oracle's learn() (torch-CPU eager, the reference's op sequence; kind "port") on a BOUNDED sample of the same
-    workload: one optimiser step over 131,072 samples of the cfg2 buffer = 2 minibatches of 65,536 (same nets, same minibatch
-    size, same per-sample work as the GPU run), `reps` warm repetitions per thread count, median.
+    workload: [r5] ONE FULL EPOCH of it -- the whole 524,288-sample configs[1] buffer, batch 524,288, 8 minibatches of 65,536, one
+    optimiser step: exactly a tenth of the GPU line's 10-epoch step, sample for sample (rounds 1-4 timed a 131,072-sample slice) --
+    `reps` warm repetitions per thread count, median.
     Thread counts: 16 and min(cores, 64) are both timed and both reported -- on the 256-thread GPU-box host torch-CPU with all
     hardware threads is ~20x SLOWER than with 16-64 (oversubscribed MKL/OpenMP), which would misrepresent the reference;
     `value` is the better median."""
     from oracle import nets, ppo
     cores = os.cpu_count() or 1
-    n = B = 2 * MINIBATCH
+    n = B = N_SAMPLES
     torch.manual_seed(seed)
     g = torch.Generator().manual_seed(seed)
     states = torch.randn(n, OBS, generator=g).clamp_(-5, 5)
@@ -461,8 +462,8 @@ def cpu_baseline(seed=123, reps=3):
     threads = min(per_threads, key=per_threads.get)
     return dict(value=round(n / per_threads[threads]), unit="samples/s", cores=threads, kind="port",
                 by_threads={str(k): round(n / v) for k, v in per_threads.items()}, host_cores=cores, physical_cores=physical_cores(),
-                sample="1 optimiser step over 131,072 cfg2 samples (2 minibatches of 65,536), torch-CPU eager oracle, median of %d warm reps per "
-                       "thread count, best count reported; %.0f s" % (reps, time.perf_counter() - t_all))
+                sample="one full epoch of the GPU line's workload (524,288 samples = 8 minibatches of 65,536, 1 optimiser step; the GPU step is 10 such "
+                       "epochs), torch-CPU eager oracle, median of %d warm reps per thread count, best count reported; %.0f s" % (reps, time.perf_counter() - t_all))
 
 
 REF_BATCH, REF_BUFFER = 50_000, 150_000  # /root/reference: learner.py:34-53 (ppo_batch_size 50,000, minibatch = batch), example.py:74-88 (buffer 150,000)
