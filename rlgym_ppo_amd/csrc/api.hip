@@ -1057,15 +1057,26 @@ int rlppo_ppo_minibatch(void *stream, const rlppo_minibatch_args *a) {
     // at 524,288 rows per pass the two are equal and the fused form saves the 268 MB copy.  rlppo_dbg_set(26, 2): at every size (tests).
     const bool fused_gather = !b16 && (g_fused_gather == 2 || (g_fused_gather == 1 && mb >= FUSED_GATHER_MIN_ROWS)) && src_rows > 0 &&
                               gather_form(pol) && gather_form(val);
-    if (!b16 && !fused_gather) rc = launch_gather_rows(st, a->states, a->ld_states, a->idx, states, pol.L[0].pin, mb, ring_base, ring_cap);
+    // (the per-row scalars -- old log-prob, advantage, target, actions -- ride in the same launch: wmeta below)
+    if (!b16 && !fused_gather) {
+        RLPPO_CHECK_ARG(a->act_dim >= 1 && a->act_dim <= pol.L[pol.n_layers - 1].pout, "ppo_minibatch: act_dim=%d", a->act_dim);
+        GatherMeta gm;
+        gm.actions = a->actions; gm.old_logp = a->old_logp; gm.adv = a->advantages; gm.targets = a->targets;
+        gm.g_old = wmeta; gm.g_adv = wmeta + mb; gm.g_tgt = wmeta + 2 * (size_t)mb; gm.g_act = wmeta + 3 * (size_t)mb;  // (= g_old, g_adv, g_tgt, g_act below)
+        gm.zero_n = vact[val.n_layers - 1];
+        gm.act_dim = a->act_dim;
+        rc = launch_gather_rows(st, a->states, a->ld_states, a->idx, states, pol.L[0].pin, mb, ring_base, ring_cap, &gm);
+    }
     if (rc) return rc;
     const float *pol_w = b16 ? a->pol_packed_r : a->pol_packed, *val_w = b16 ? a->val_packed_r : a->val_packed;
     // the minibatch's per-row scalars, gathered once (the loss kernels stream them)
     RLPPO_CHECK_ARG(a->act_dim >= 1 && a->act_dim <= pol.L[pol.n_layers - 1].pout, "ppo_minibatch: act_dim=%d", a->act_dim);
     float *g_old = wmeta, *g_adv = wmeta + mb, *g_tgt = wmeta + 2 * (size_t)mb, *g_act = wmeta + 3 * (size_t)mb;
-    // ([r5] it also zeroes the first mb floats of the critic's output buffer: a folded value head accumulates into them)
-    rc = launch_gather_meta(st, a->idx, a->actions, a->act_dim, a->old_logp, a->advantages, a->targets, g_act, g_old, g_adv, g_tgt, mb,
-                            ring_base, ring_cap, fused_gather ? rowtab : nullptr, vact[val.n_layers - 1]);
+    // ([r5] it also zeroes the first mb floats of the critic's output buffer: a folded value head accumulates into them; when the
+    // rows were gathered by a pass of their own, that launch has done all of this already)
+    if (b16 || fused_gather)
+        rc = launch_gather_meta(st, a->idx, a->actions, a->act_dim, a->old_logp, a->advantages, a->targets, g_act, g_old, g_adv, g_tgt, mb,
+                                ring_base, ring_cap, fused_gather ? rowtab : nullptr, vact[val.n_layers - 1]);
     if (rc) return rc;
     // forward of both nets
     // The two networks are independent until the loss epilogue and again after it, so their launch chains run on

@@ -271,8 +271,13 @@ int launch_clip_adam_pack2(hipStream_t st, const NetLayout *nets, float *const *
 int launch_welford(hipStream_t st, const float *x, int64_t ld, int64_t n, int d, void *mean, void *m2, long long count0, int state_f64);
 int launch_welford_merge(hipStream_t st, int d, void *mean, void *m2, long long count, const float *omean, const float *om2,
                          long long ocount, int state_f64);
+struct GatherMeta {  // [r5] the per-row scalars of gather_meta_kernel, gathered by gather_rows_kernel in the same launch
+    const float *actions = nullptr, *old_logp = nullptr, *adv = nullptr, *targets = nullptr;
+    float *g_act = nullptr, *g_old = nullptr, *g_adv = nullptr, *g_tgt = nullptr, *zero_n = nullptr;
+    int act_dim = 0;
+};
 int launch_gather_rows(hipStream_t st, const float *src, int64_t ld_src, const int64_t *idx, float *dst, int width, int64_t n,
-                       int64_t ring_base = 0, int64_t ring_cap = INT64_MAX);
+                       int64_t ring_base = 0, int64_t ring_cap = INT64_MAX, const GatherMeta *meta = nullptr);
 int launch_gather_meta(hipStream_t st, const int64_t *idx, const float *actions, int act_dim, const float *old_logp,
                        const float *adv, const float *targets, float *g_act, float *g_old, float *g_adv, float *g_tgt, int64_t n,
                        int64_t ring_base, int64_t ring_cap, unsigned *rowtab = nullptr, float *zero_n = nullptr);

@@ -203,16 +203,26 @@ __global__ __launch_bounds__(256) void pad_rows_vec_kernel(const T *__restrict__
 // Minibatch gather (experience_buffer.py:82-87): dst[r][0..width) = src[idx[r]][0..width), 16 bytes per thread.  One pass
 // per minibatch, shared by the policy and the critic: the four first-layer GEMMs (two forwards, two dW) then read
 // contiguous rows through the LDS-DMA kernels instead of each chasing the index vector.
+// [r5] `meta` (optional): the per-row scalars of gather_meta_kernel ride along -- the thread of a row's chunk 0 gathers them -- so a
+// pass that gathers its rows (every pass below 262,144 rows) starts with ONE launch instead of two.
 __global__ __launch_bounds__(256) void gather_rows_kernel(const float *__restrict__ src, int64_t ld_src,
                                                           const int64_t *__restrict__ idx, float *__restrict__ dst,
-                                                          int chunks_per_row, int64_t n, int64_t ring_base, int64_t ring_cap) {
+                                                          int chunks_per_row, int64_t n, int64_t ring_base, int64_t ring_cap, GatherMeta meta) {
     typedef float f32x4 __attribute__((ext_vector_type(4)));
     const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t row = t / chunks_per_row;
     const int c = (int)(t - row * chunks_per_row);
     if (row >= n) return;
-    const f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(src + ring_row(idx[row], ring_base, ring_cap) * ld_src) + c);
+    const int64_t srow = ring_row(idx[row], ring_base, ring_cap);
+    const f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(src + srow * ld_src) + c);
     reinterpret_cast<f32x4 *>(dst)[t] = v;
+    if (c == 0 && meta.g_old) {
+        meta.g_old[row] = meta.old_logp[srow];
+        meta.g_adv[row] = meta.adv[srow];
+        meta.g_tgt[row] = meta.targets[srow];
+        for (int k = 0; k < meta.act_dim; ++k) meta.g_act[row * meta.act_dim + k] = meta.actions[srow * meta.act_dim + k];
+        if (meta.zero_n) meta.zero_n[row] = 0.f;
+    }
 }
 
 // The same gather for the bf16 update precision: the gathered observation rows are rounded to bf16 on the way -- written as
@@ -284,13 +294,13 @@ int launch_gather_meta(hipStream_t st, const int64_t *idx, const float *actions,
 }
 
 int launch_gather_rows(hipStream_t st, const float *src, int64_t ld_src, const int64_t *idx, float *dst, int width,
-                       int64_t n, int64_t ring_base, int64_t ring_cap) {
+                       int64_t n, int64_t ring_base, int64_t ring_cap, const GatherMeta *meta) {
     if (n <= 0) return 0;
     RLPPO_CHECK_ARG(width > 0 && width % 4 == 0 && ld_src >= width && ld_src % 4 == 0, "gather_rows: width=%d ld=%ld", width,
                     (long)ld_src);
     const int cpr = width / 4;
     hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)cdiv(n * cpr, 256)), dim3(256), 0, st, src, ld_src, idx, dst, cpr, n, ring_base,
-                       ring_cap);
+                       ring_cap, meta ? *meta : GatherMeta{});
     RLPPO_LAUNCH_CHECK();
     return 0;
 }

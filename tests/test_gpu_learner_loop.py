@@ -99,7 +99,12 @@ def test_add_new_experience_matches_oracle(tmp_path):
 def test_configs0_literal_loop(tmp_path, capsys):
     """BASELINE configs[0] as written: 8 parallel env processes (1v1: two agents each), obs 107, 90 discrete actions, the
     DEFAULT 256x3 policy and critic -- the reference's own CPU-runnable configuration (example.py) -- through the whole loop
-    on the GPU path: collection over the worker processes, value pass + GAE, PPO update, report."""
+    on the GPU path: collection over the worker processes, value pass + GAE, PPO update, report.
+    This test asserts STRUCTURE (counts, shapes, bookkeeping, finiteness), not values: the order in which 8 worker processes' UDP
+    datagrams arrive is not deterministic, so the collected batch -- and every number derived from it -- differs from run to run,
+    in the reference as here.  The VALUES of this configuration are pinned where the inputs can be fixed: the reference's own batch
+    size in test_gpu_learner.py::test_reference_default_batch_of_50000_rows_against_the_oracle and bench.py's ref_defaults leg, the
+    loop's pieces (value pass, GAE, buffer, update) against the oracle in test_add_new_experience_matches_oracle and the G fixtures."""
     learner = run(synthetic_env.make_discrete_env, tmp_path, n_proc=8, min_inference_size=8, timestep_limit=4000,
                   exp_buffer_size=4096, ts_per_iteration=2048, ppo_epochs=2, ppo_batch_size=2048, ppo_minibatch_size=1024,
                   policy_layer_sizes=(256, 256, 256), critic_layer_sizes=(256, 256, 256), save_every_ts=10_000_000)
