@@ -96,15 +96,43 @@ int rlppo_pad_rows_per_feature(void *stream, const void *src, int32_t src_is_f64
  *     rlppo_discrete_act / _step stores it itself, workgroup by workgroup; the layer chains append one tiny launch that stores them
  *     all).  A host whose outputs live in pinned memory clears the words, makes the call and polls them (rlppo_host_wait_words)
  *     instead of hipStreamSynchronize: batched_agent_manager.py:202-204 calls get_action on 8-80 observations per environment
- *     step, where the synchronisation was a third of the call. */
+ *     step, where the synchronisation was a third of the call.
+ *   noise_ctl (rlppo_discrete_step's one-launch kernel only; needs done_words, done_value < 2^31): the noise arrives WHILE the
+ *     kernel runs -- the bit-exact Exp(1) draw of the reference's CPU stream (5-11 us at 8-80 rows) hides behind the launch
+ *     latency and the layers.  noise_ctl points at 32 uint32 the host can write and the kernel reads past its caches (pinned
+ *     memory, or better a host window, below): [0] the call's sequence (never the previous call's), [1] live rows -- both written
+ *     BEFORE the call -- [2] the sequence of the noise that is complete in noise_q, [3..] statistics the kernel writes
+ *     ([3] polls / [4] 10 ns ticks the first wave spent on its noise after the last layer; [8..11] 100 MHz time stamps of the last
+ *     workgroup: start, observations staged, layers done, sampled).  noise_q
+ *     is [n][n_actions] floats in such memory too; the host fills it AFTER the launch and then stores the call's sequence into
+ *     word 2 (rlppo_host_push does both in order).  The waves that have nothing to multiply in the head layer look at word 2 when
+ *     that layer starts and bring the numbers in; if the host was not done by then every wave waits for the word after the last
+ *     layer.  Rows >= live rows are not sampled (their outputs are untouched).  Between the launch and word 2 the host must not
+ *     wait for the GPU (the kernel waits for the host).  A workgroup that has waited 20 ms gives up: it stores
+ *     done_value | 0x80000000 (rlppo_host_wait_words returns 2), its outputs are void; the caller completes word 2 and makes the
+ *     call again. */
 typedef struct rlppo_act_opts {
     int32_t precision;
     uint32_t done_value;
     uint32_t *done_words;
+    uint32_t *noise_ctl;
 } rlppo_act_opts;
 int64_t rlppo_act_done_words(int64_t n);
-/* HOST: spins until words[0..count) all hold `value` (acquire loads) or timeout_us has passed; 0 = all there, 1 = timed out. */
+/* HOST: spins until words[0..count) all hold `value` (acquire loads) or timeout_us has passed; 0 = all there, 1 = timed out,
+ * 2 = a word holds value | 0x80000000 (the kernel gave up: noise_ctl above). */
 int rlppo_host_wait_words(const uint32_t *words, int64_t count, uint32_t value, int64_t timeout_us);
+/* [r5] Host window: DEVICE memory (fine-grained, zeroed) that the host writes directly through the PCIe aperture -- a posted write
+ * of a small call's observations costs the host 1.5-2.5 us, where the kernel's own reads of pinned host memory cost it 11-20 us
+ * (a GPU-initiated PCIe read is a round trip of microseconds and ~30 ns per 64 bytes behind it).  Write-only for the host
+ * (its reads are uncached: 65 us per 3 KB).  Fails (RLPPO_ERR_ARG) on a device that does not expose its memory (no large BAR).
+ * rlppo_host_push: HOST: memcpy(dst, src, bytes), a store fence, then -- if flag is not NULL -- *flag = value and another fence:
+ * nothing that follows (the doorbell of a launch, the flag) can overtake the bytes. */
+int rlppo_host_window_alloc(size_t bytes, void **ptr);
+int rlppo_host_window_free(void *ptr);
+int rlppo_host_push(void *dst, const void *src, size_t bytes, uint32_t *flag, uint32_t value);
+/* HOST: what precedes the launch of a small rollout call, in one call: ctl[0] = sequence, ctl[1] = live_rows (ctl may be NULL),
+ * memcpy(obs_dst, obs_src, obs_bytes), one store fence. */
+int rlppo_host_stage_call(uint32_t *ctl, uint32_t sequence, uint32_t live_rows, void *obs_dst, const void *obs_src, size_t obs_bytes);
 
 /* Bytes of workspace needed by the forward entry points for `n` rows. */
 size_t rlppo_forward_workspace_bytes(const int32_t *dims, int32_t n_layers, int64_t n);
@@ -133,6 +161,8 @@ int rlppo_discrete_act(void *stream, const int32_t *dims, int32_t n_layers, cons
  * (optional: the padded, standardised rows [n][ld_rows_out] -- the policy-input rows a device-resident rollout stores).
  * workspace: rlppo_discrete_step_workspace_bytes(dims, n_layers, n). */
 size_t rlppo_discrete_step_workspace_bytes(const int32_t *dims, int32_t n_layers, int64_t n);
+/* 1: rlppo_discrete_step(dims, n rows, opts) runs as the one-launch kernel under the current switches; 0: as the chain; -1: bad argument */
+int rlppo_discrete_step_one_launch(const int32_t *dims, int32_t n_layers, int64_t n, const rlppo_act_opts *opts);
 int rlppo_discrete_step(void *stream, const int32_t *dims, int32_t n_layers, const float *packed, const void *obs, int32_t obs_is_f64,
                         int64_t ld_obs, int64_t n, int32_t standardize, float mean0, float std0, const float *mean_v,
                         const float *std_v, const float *noise_q, int64_t *actions, float *actions_f32, float *logp, float *rows_out,
@@ -461,6 +491,7 @@ int rlppo_dbg_set(int32_t key, int32_t value);
 /* Counter bumped by every call that changes which kernels later launches select (rlppo_dbg_set, rlppo_set_*_precision): a
  * host that caches captured graphs of library calls keys them on it (rlgym_ppo_amd/ppo/_mlp.py::ActGraph). */
 int64_t rlppo_selection_epoch(void);
+const int64_t *rlppo_selection_epoch_ptr(void);   /* the counter itself (a host that reads it per call) */
 /* Which form calls took so far in this process (tests assert that the kernel they mean to pin is the one that ran): 0 = rollout steps
  * served by the one-launch kernel (rlppo_discrete_act / rlppo_discrete_step), 1 = by the layer chain, 2 = rlppo_ppo_minibatch passes,
  * 3 = of them with paired policy + critic launches, 4 = of them with the gather fused into the first layer, 5 = of them with the

@@ -42,7 +42,7 @@ class OptNet(ctypes.Structure):
 
 class ActOpts(ctypes.Structure):
     """struct rlppo_act_opts (include/rlppo.h)."""
-    _fields_ = [("precision", c_int32), ("done_value", c_uint32), ("done_words", c_void_p)]
+    _fields_ = [("precision", c_int32), ("done_value", c_uint32), ("done_words", c_void_p), ("noise_ctl", c_void_p)]
 
 
 class TnProduct(ctypes.Structure):
@@ -100,6 +100,12 @@ SIGNATURES = {
                                           c_void_p, c_void_p, c_void_p, c_size_t, _PACT]),
     "rlppo_act_done_words": (c_int64, [c_int64]),
     "rlppo_host_wait_words": (c_int32, [c_void_p, c_int64, c_uint32, c_int64]),
+    "rlppo_discrete_step_one_launch": (c_int32, [_P32, c_int32, c_int64, _PACT]),
+    "rlppo_host_window_alloc": (c_int32, [c_size_t, POINTER(c_void_p)]),
+    "rlppo_host_window_free": (c_int32, [c_void_p]),
+    "rlppo_host_push": (c_int32, [c_void_p, c_void_p, c_size_t, c_void_p, c_uint32]),
+    "rlppo_host_stage_call": (c_int32, [c_void_p, c_uint32, c_uint32, c_void_p, c_void_p, c_size_t]),
+    "rlppo_selection_epoch_ptr": (c_void_p, []),
     "rlppo_gae_workspace_bytes": (c_size_t, [c_int64]),
     "rlppo_gae": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_double, c_double, c_float,
                             c_void_p, c_void_p, c_void_p, c_void_p, c_size_t]),

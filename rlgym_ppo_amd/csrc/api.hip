@@ -278,8 +278,10 @@ struct ActCtx {
     int bf16 = 0;
     unsigned *done = nullptr;
     unsigned done_value = 0;
+    unsigned *noise_ctl = nullptr;
 };
-static int act_ctx(const rlppo_act_opts *o, ActCtx *c) {
+// late_noise: the entry point can take its noise while it runs (rlppo_act_opts.noise_ctl; rlppo_discrete_step alone)
+static int act_ctx(const rlppo_act_opts *o, ActCtx *c, bool late_noise = false) {
     c->bf16 = get_infer_bf16();
     if (!o) return 0;
     RLPPO_CHECK_ARG(o->precision == RLPPO_PRECISION_DEFAULT || o->precision == RLPPO_PRECISION_FP32 || o->precision == RLPPO_PRECISION_BF16,
@@ -287,6 +289,10 @@ static int act_ctx(const rlppo_act_opts *o, ActCtx *c) {
     if (o->precision != RLPPO_PRECISION_DEFAULT) c->bf16 = o->precision == RLPPO_PRECISION_BF16;
     c->done = o->done_words;
     c->done_value = o->done_value;
+    c->noise_ctl = o->noise_ctl;
+    RLPPO_CHECK_ARG(!o->noise_ctl || late_noise, "act options: noise_ctl is an option of rlppo_discrete_step");
+    RLPPO_CHECK_ARG(!o->noise_ctl || (o->done_words && !(o->done_value & 0x80000000u)),
+                    "act options: noise_ctl needs done_words (a kernel that gives up on the noise reports it there) and done_value < 2^31");
     return 0;
 }
 // the completion words of a call whose last launch does not write them itself: one more (tiny) launch behind it
@@ -405,6 +411,31 @@ size_t rlppo_discrete_step_workspace_bytes(const int32_t *dims, int32_t n_layers
     return forward_ws_floats(net, n) * sizeof(float) + ((size_t)n * net.L[0].pin * sizeof(float) + 255) / 256 * 256 + 512;
 }
 
+int rlppo_host_window_alloc(size_t bytes, void **ptr) {
+    RLPPO_CHECK_ARG(ptr && bytes > 0, "host_window_alloc: bad argument");
+    *ptr = nullptr;
+    int dev = 0, large_bar = 0;
+    RLPPO_HIP(hipGetDevice(&dev));
+    RLPPO_HIP(hipDeviceGetAttribute(&large_bar, hipDeviceAttributeIsLargeBar, dev));
+    RLPPO_CHECK_ARG(large_bar, "host_window_alloc: device %d does not expose its memory to the host (no large BAR)", dev);
+    RLPPO_HIP(hipExtMallocWithFlags(ptr, bytes, hipDeviceMallocFinegrained));
+    RLPPO_HIP(hipMemset(*ptr, 0, bytes));
+    RLPPO_HIP(hipDeviceSynchronize());
+    return 0;
+}
+int rlppo_host_window_free(void *ptr) {
+    if (ptr) RLPPO_HIP(hipFree(ptr));
+    return 0;
+}
+
+int rlppo_discrete_step_one_launch(const int32_t *dims, int32_t n_layers, int64_t n, const rlppo_act_opts *opts) {
+    NetLayout net;
+    if (make_layout(dims, n_layers, &net)) return -1;
+    ActCtx cx;
+    if (act_ctx(opts, &cx, true)) return -1;
+    return g_fused_act && !cx.bf16 && fused_act_ok(net) && n <= FUSED_ACT_MAX_ROWS ? 1 : 0;
+}
+
 int rlppo_discrete_step(void *stream, const int32_t *dims, int32_t n_layers, const float *packed, const void *obs, int32_t obs_is_f64,
                         int64_t ld_obs, int64_t n, int32_t standardize, float mean0, float std0, const float *mean_v,
                         const float *std_v, const float *noise_q, int64_t *actions, float *actions_f32, float *logp, float *rows_out,
@@ -413,7 +444,7 @@ int rlppo_discrete_step(void *stream, const int32_t *dims, int32_t n_layers, con
     int rc = make_layout(dims, n_layers, &net);
     if (rc) return rc;
     ActCtx cx;
-    rc = act_ctx(opts, &cx);
+    rc = act_ctx(opts, &cx, true);
     if (rc) return rc;
     if (n == 0) return 0;
     const int d = net.L[0].in, pin = net.L[0].pin;
@@ -440,9 +471,11 @@ int rlppo_discrete_step(void *stream, const int32_t *dims, int32_t n_layers, con
         io.logp = logp;
         io.done_words = cx.done;
         io.done_value = cx.done_value;
+        io.noise_ctl = cx.noise_ctl;
         ++g_cnt_fused_act;
         return launch_discrete_act_fused(st, net, packed, io, n);
     }
+    RLPPO_CHECK_ARG(!cx.noise_ctl, "discrete_step: noise_ctl needs the one-launch kernel (rlppo_discrete_step_one_launch tells)");
     ++g_cnt_act_chain;
     // the same step launch by launch: pad (+ standardise) into rows_out (or the head of the workspace), forward chain, sample
     float *rows = rows_out;
@@ -1473,6 +1506,7 @@ int rlppo_dbg_set(int32_t key, int32_t value) {
     return RLPPO_ERR_ARG;
 }
 int64_t rlppo_selection_epoch(void) { return g_selection_epoch; }
+const int64_t *rlppo_selection_epoch_ptr(void) { return &g_selection_epoch; }
 int64_t rlppo_dbg_counter(int32_t key) {
     switch (key) {
         case 0: return g_cnt_fused_act;

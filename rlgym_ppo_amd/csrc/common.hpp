@@ -241,6 +241,7 @@ struct FusedActIO {
     float *logp = nullptr, *probs_out = nullptr;
     unsigned *done_words = nullptr;  // [r5] optional, host-visible: word b <- done_value once the outputs of rows 16 b .. 16 b + 15 are visible
     unsigned done_value = 0;
+    unsigned *noise_ctl = nullptr;  // [r5] optional control words of noise the host writes after the launch (rlppo_act_opts)
 };
 bool fused_act_ok(const NetLayout &net);
 int launch_discrete_act_fused(hipStream_t st, const NetLayout &net, const float *packed, const FusedActIO &io, int64_t n);

@@ -24,6 +24,8 @@ constexpr int FA_STAGES = 4;     // weight tiles per wave in flight / being read
 constexpr int FA_MAX_LAYERS = 6;
 constexpr float FA_PROB_MIN = 1e-11f;
 constexpr unsigned FA_OOR = 0x80000000u;  // a scalar offset no descriptor's range check passes
+constexpr int FA_QLD = 128;               // floats per row of the late-noise buffer (the kernel's limit of 128 actions)
+constexpr int FA_QFLOATS = FA_ROWS * FA_QLD + FA_ROWS;
 }  // namespace
 
 struct FusedActArgs {
@@ -53,7 +55,15 @@ struct FusedActArgs {
     float *probs_out;        // optional [n][A]
     unsigned *done_words;    // optional (host-visible): done_words[blockIdx.x] <- done_value when this workgroup's outputs are visible
     unsigned done_value;
+    // [r5] noise that arrives WHILE the kernel runs (rlppo_act_opts.noise_ctl): {sequence of this call, rows that are sampled,
+    // sequence of the noise that is complete in `noise`, 2 statistics words} in memory the host writes directly
+    unsigned *noise_ctl;
 };
+
+// 20 ms of the 100 MHz wall clock (100-1000 x what the host needs for the draw): a host that is held up between launch and publish --
+// worst of all by something that itself waits for the GPU -- gets the kernel out of its way soon and launches again (ActGraph.run)
+constexpr long long FA_NOISE_WAIT_TICKS = 2000000LL;
+constexpr unsigned FA_DONE_FAILED = 0x80000000u;         // or-ed into the completion word by a workgroup that gave up
 
 // NW waves; JH: output blocks a wave owns in a hidden layer (H = 16 JH NW); the head's blocks are dealt ceil(nblk / NW) per wave.
 // H = 256 runs 8 waves x 2 blocks: with one wave per SIMD (4 x 4) a K-step was LDS-DMA issue (4 pieces, ~100 cycles each) + fragment
@@ -68,10 +78,16 @@ __global__ __launch_bounds__(64 * NW, 1) void discrete_act_fused_kernel(FusedAct
     float *act1 = lds + H * FA_ROWS;
     float *wring = lds + 2 * H * FA_ROWS;     // [NW waves][FA_STAGES][TILE]
     float *biasl = wring + NW * FA_STAGES * TILE;  // [FA_MAX_LAYERS][H]: the biases, so that no register-destination load sits in the weight stream's vmcnt window
+    float *qbuf = biasl + FA_MAX_LAYERS * H;       // [r5] [FA_ROWS][FA_QLD] late noise fetched by the waves that have no block of the head layer
+    int *qok = reinterpret_cast<int *>(qbuf + FA_ROWS * FA_QLD);  // [FA_ROWS] 1: the row's noise is in qbuf
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     const int r16 = lane & 15, q = lane >> 4;
-    const int64_t row0 = (int64_t)blockIdx.x * FA_ROWS;
+    const int tile = (int)blockIdx.x;
+    const int64_t row0 = (int64_t)tile * FA_ROWS;
+    // (time stamps of the call's last workgroup in the statistics words of late noise: tools/get_action_modes.py)
+#define FA_TS(k) do { if (a.noise_ctl && tid == 0 && tile == (int)gridDim.x - 1) a.noise_ctl[8 + (k)] = (unsigned)wall_clock64(); } while (0)
+    FA_TS(0);
     const int last = a.n_layers - 1;
     float *const wr = wring + wave_u * FA_STAGES * TILE;
 
@@ -117,15 +133,24 @@ __global__ __launch_bounds__(64 * NW, 1) void discrete_act_fused_kernel(FusedAct
 
     for (int l = 0; l <= last; ++l)
         for (int c = tid; c < a.nblk[l] * 16; c += NT) biasl[l * H + c] = a.packed[a.off_b[l] + c];
-    // ---- the Exp(1) noise of this wave's 4 rows: requested now, used after the last layer
+    // ---- the Exp(1) noise of this wave's rows: requested now, used after the last layer
+    // [r5] with noise_ctl the host writes the noise AFTER it has launched (the draw hides behind the launch latency and the layers)
+    // and then control word 2.  The waves that have no block of the head layer look at that word when the head layer starts and
+    // bring the noise of all 16 rows into LDS while the others multiply; if the host was not done by then, every wave waits for the
+    // word after the last layer and reads its own rows
     float qn[RPWV][2];
+    unsigned want = 0, live_raw = 0;
+    if (a.noise_ctl) {  // (used from the head layer on: nobody waits for these two loads here)
+        want = __hip_atomic_load(a.noise_ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        live_raw = __hip_atomic_load(a.noise_ctl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 #pragma unroll
     for (int rr = 0; rr < RPWV; ++rr)
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
             const int64_t row = row0 + wave * RPWV + rr;
             const int c = lane + 64 * e;
-            qn[rr][e] = (row < a.n && c < a.A) ? a.noise[row * a.A + c] : 1.f;
+            qn[rr][e] = (!a.noise_ctl && row < a.n && c < a.A) ? a.noise[row * a.A + c] : 1.f;
         }
     // ---- stage the 16 observation rows into act0 (K-step-major image), zero rows past n
     if (a.rows) {
@@ -137,22 +162,47 @@ __global__ __launch_bounds__(64 * NW, 1) void discrete_act_fused_kernel(FusedAct
             *reinterpret_cast<f32x4 *>(&act0[(ch >> 2) * 256 + dswz<16>(r, ch & 3)]) = v;
         }
     } else {  // pad_rows_kernel / pad_rows_vec_kernel, element for element
+        // [r5] every request of a thread is in flight before the first is used: the observations of a small call sit in memory the
+        // HOST writes (pinned, or device memory it writes through the PCIe aperture), where a round trip is microseconds -- one per
+        // loop iteration was 11 us of a 35 us kernel at 8 rows
         const int k0 = a.k[0];
-        for (int e = tid; e < FA_ROWS * k0; e += NT) {
+        constexpr int SE = FA_ROWS * H / NT;  // elements per thread at the widest input (k0 <= H)
+        float v[SE];
+        if (a.raw_is_f64) {
+            double vd[SE];
+#pragma unroll
+            for (int i = 0; i < SE; ++i) {
+                const int e = tid + i * NT, r = e / k0, c = e - r * k0;
+                vd[i] = 0.0;
+                if (e < FA_ROWS * k0 && row0 + r < a.n && c < a.d) vd[i] = reinterpret_cast<const double *>(a.raw)[(row0 + r) * a.ld_raw + c];
+            }
+#pragma unroll
+            for (int i = 0; i < SE; ++i) v[i] = (float)vd[i];
+        } else {
+#pragma unroll
+            for (int i = 0; i < SE; ++i) {
+                const int e = tid + i * NT, r = e / k0, c = e - r * k0;
+                v[i] = 0.f;
+                if (e < FA_ROWS * k0 && row0 + r < a.n && c < a.d) v[i] = reinterpret_cast<const float *>(a.raw)[(row0 + r) * a.ld_raw + c];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < SE; ++i) {
+            const int e = tid + i * NT;
+            if (e >= FA_ROWS * k0) break;
             const int r = e / k0, c = e - r * k0;
             const int64_t row = row0 + r;
-            float v = 0.f;
+            float x = v[i];
             if (row < a.n && c < a.d) {
-                v = a.raw_is_f64 ? (float)reinterpret_cast<const double *>(a.raw)[row * a.ld_raw + c]
-                                 : reinterpret_cast<const float *>(a.raw)[row * a.ld_raw + c];
-                if (a.standardize == 1) v = fminf(fmaxf((v - a.mean0) / a.std0, -5.f), 5.f);
-                else if (a.standardize == 2) v = fminf(fmaxf((v - a.mean_v[c]) / a.std_v[c], -5.f), 5.f);
+                if (a.standardize == 1) x = fminf(fmaxf((x - a.mean0) / a.std0, -5.f), 5.f);
+                else if (a.standardize == 2) x = fminf(fmaxf((x - a.mean_v[c]) / a.std_v[c], -5.f), 5.f);
             }
-            act0[(c >> 4) * 256 + dswz<16>(r, (c >> 2) & 3) + (c & 3)] = v;
-            if (a.rows_out && row < a.n) a.rows_out[row * a.ld_rows_out + c] = v;
+            act0[(c >> 4) * 256 + dswz<16>(r, (c >> 2) & 3) + (c & 3)] = x;
+            if (a.rows_out && row < a.n) a.rows_out[row * a.ld_rows_out + c] = x;
         }
     }
     __syncthreads();  // (drains the stream's first tiles too: once per launch)
+    FA_TS(1);
 
     float *cur = act0, *nxt = act1;
     int consumed = 0;
@@ -166,6 +216,38 @@ __global__ __launch_bounds__(64 * NW, 1) void discrete_act_fused_kernel(FusedAct
         for (int j = 0; j < JH; ++j) {
             acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
             if (j < nj) acc[j] = *reinterpret_cast<const f32x4 *>(&biasl[l * H + (jb0 + j) * 16 + q * 4]);
+        }
+        if (head && a.noise_ctl && nj == 0) {
+            // this wave has nothing to multiply in the head layer: it fetches late noise.  Idle waves are [first_idle, NW); wave i of
+            // them takes rows i, i + n_idle, ...; all its requests are in flight together, one wait
+            const int first_idle = (a.nblk[l] + own - 1) / own, n_idle = NW - first_idle, iw = wave_u - first_idle;
+            const int64_t n_live = (int64_t)live_raw < a.n ? (int64_t)live_raw : a.n;
+            const bool there = __hip_atomic_load(a.noise_ctl + 2, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) == want;  // (wave-uniform)
+            const unsigned *src = reinterpret_cast<const unsigned *>(a.noise);
+            unsigned pp[FA_ROWS][2];
+#pragma unroll
+            for (int i = 0; i < FA_ROWS; ++i) {
+                const int r = iw + i * n_idle;
+                const int64_t row = row0 + r;
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    pp[i][e] = 0x3f800000u;
+                    if (there && r < FA_ROWS && row < n_live && lane + 64 * e < a.A)
+                        pp[i][e] = __hip_atomic_load(src + row * a.A + lane + 64 * e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < FA_ROWS; ++i) {
+                const int r = iw + i * n_idle;
+                if (r >= FA_ROWS) break;
+                if (there) {
+                    qbuf[r * FA_QLD + lane] = __uint_as_float(pp[i][0]);
+                    qbuf[r * FA_QLD + 64 + lane] = __uint_as_float(pp[i][1]);
+                }
+                if (lane == 0) qok[r] = there && row0 + r < n_live;
+            }
+        } else if (head && a.noise_ctl && wave_u == 0 && (a.nblk[l] + own - 1) / own >= NW) {
+            if (lane < FA_ROWS) qok[lane] = 0;  // no idle wave in this network: every row is fetched after the layer
         }
         // K loop in groups of FA_STAGES steps, unrolled: ring slot and activation K-step are immediates of the ds_reads, so a step is
         // DMA issue (scalar), a counted wait, three ds_read_b128 and 4 JH MFMAs with NO vector ALU instruction (while the other wave
@@ -232,13 +314,59 @@ __global__ __launch_bounds__(64 * NW, 1) void discrete_act_fused_kernel(FusedAct
         nxt = t;
     }
 
+    FA_TS(2);
     // ---- sampling: wave w takes RPWV rows; element c = lane + 64 e (discrete_sample_kernel<2, false>, op for op)
     const int A = a.A, ldz = a.nblk[last] * 16;
+    bool gave_up = false;
+    const int64_t n_live = a.noise_ctl && (int64_t)live_raw < a.n ? (int64_t)live_raw : a.n;
+    if (a.noise_ctl) {
+        const unsigned *src = reinterpret_cast<const unsigned *>(a.noise);
+        bool need[RPWV];
+        bool any = false;
+#pragma unroll
+        for (int rr = 0; rr < RPWV; ++rr) {
+            const int r = wave * RPWV + rr;
+            need[rr] = row0 + r < n_live && !qok[r];
+            any |= need[rr];
+            if (row0 + r < n_live && !need[rr]) {
+                qn[rr][0] = qbuf[r * FA_QLD + lane];
+                qn[rr][1] = qbuf[r * FA_QLD + 64 + lane];
+            }
+        }
+        const long long t0 = wall_clock64();
+        unsigned rounds = 0;
+        if (any) {  // (wave-uniform) the host was not done when the head layer started: wait for its word, then read
+            while (__hip_atomic_load(a.noise_ctl + 2, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != want) {
+                ++rounds;
+                if (wall_clock64() - t0 > FA_NOISE_WAIT_TICKS) {
+                    gave_up = true;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(8);
+            }
+            if (!gave_up) {
+#pragma unroll
+                for (int rr = 0; rr < RPWV; ++rr)
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const int64_t row = row0 + wave * RPWV + rr;
+                        const int c = lane + 64 * e;
+                        if (need[rr] && c < A)
+                            qn[rr][e] = __uint_as_float(__hip_atomic_load(src + row * A + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
+                    }
+            }
+        }
+        // statistics of the call's first wave (for tools): polls it made itself, 10 ns ticks from the last layer to its noise
+        if (tile == 0 && tid == 0) {
+            a.noise_ctl[3] = rounds + (any ? 1u : 0u);
+            a.noise_ctl[4] = (unsigned)(wall_clock64() - t0);
+        }
+    }
 #pragma unroll
     for (int rr = 0; rr < RPWV; ++rr) {
         const int r = wave * RPWV + rr;
         const int64_t row = row0 + r;
-        if (row >= a.n) break;
+        if (row >= n_live) break;
         const float *z = cur + r * ldz;
         float p[2], pc[2];
         float mx = -INFINITY;
@@ -298,12 +426,24 @@ __global__ __launch_bounds__(64 * NW, 1) void discrete_act_fused_kernel(FusedAct
     }
     // [r5] completion word of this workgroup's 16 rows: every wave releases its stores at system scope, then ONE word follows them
     // (a host that polls the word -- pinned memory -- reads the results without synchronising the stream: rlppo_act_opts)
+    FA_TS(3);
     if (a.done_words) {
+        __shared__ int fa_gave_up;
+        if (a.noise_ctl) {  // (the layers' last barrier is behind every wave)
+            if (tid == 0) fa_gave_up = 0;
+            __syncthreads();
+            if (gave_up && lane == 0) fa_gave_up = 1;
+        }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
         __syncthreads();
-        if (tid == 0) __hip_atomic_store(a.done_words + blockIdx.x, a.done_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (tid == 0) {
+            const unsigned v = a.noise_ctl && fa_gave_up ? a.done_value | FA_DONE_FAILED : a.done_value;
+            __hip_atomic_store(a.done_words + tile, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
 }
+
+#undef FA_TS
 
 // Does the network have the form the fused kernel covers?  n_layers in [2, 6]; all hidden widths equal, 64 / 128 / 256; the first
 // layer's padded input at most the hidden width; at most 128 actions.
@@ -319,7 +459,7 @@ bool fused_act_ok(const NetLayout &net) {
     // the kernel's dynamic LDS (up to 102 KiB at H = 256) against what THIS device grants a workgroup: a device with a 64 KiB
     // limit takes the bit-identical layer chain instead of failing the launch (advisor finding, round 3)
     const int J = H == 256 ? 2 : 1, W = H == 64 ? 4 : 8;
-    const size_t need = (size_t)(2 * 16 * J * W * FA_ROWS + W * FA_STAGES * J * 256 + FA_MAX_LAYERS * 16 * J * W) * 4;
+    const size_t need = (size_t)(2 * 16 * J * W * FA_ROWS + W * FA_STAGES * J * 256 + FA_MAX_LAYERS * 16 * J * W + FA_QFLOATS) * 4;
     static std::atomic<long> lds_limit[64];
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
@@ -369,13 +509,14 @@ int launch_discrete_act_fused(hipStream_t st, const NetLayout &net, const float 
     a.probs_out = io.probs_out;
     a.done_words = io.done_words;
     a.done_value = io.done_value;
+    a.noise_ctl = io.noise_ctl;
     const int H = net.L[0].pout;
     dim3 grid((unsigned)cdiv(n, FA_ROWS));
     static PerDeviceOnce attr_set[3];
 #define FA_LAUNCH(J, W, SLOT)                                                                                                    \
     do {                                                                                                                         \
-        constexpr int LDS_BYTES = (2 * 16 * J * W * FA_ROWS + W * FA_STAGES * J * 256 + FA_MAX_LAYERS * 16 * J * W) * 4;          \
-        /* up to 102 KiB of dynamic LDS (H = 256): above the default 64 KiB limit */                                             \
+        constexpr int LDS_BYTES = (2 * 16 * J * W * FA_ROWS + W * FA_STAGES * J * 256 + FA_MAX_LAYERS * 16 * J * W + FA_QFLOATS) * 4; \
+        /* up to 110 KiB of dynamic LDS (H = 256): above the default 64 KiB limit */                                             \
         if (int rc_ = set_dynamic_lds_once((const void *)discrete_act_fused_kernel<J, W>, LDS_BYTES, attr_set[SLOT])) return rc_; \
         hipLaunchKernelGGL((discrete_act_fused_kernel<J, W>), grid, dim3(64 * W), LDS_BYTES, st, a);                              \
     } while (0)

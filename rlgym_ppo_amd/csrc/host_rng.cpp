@@ -8,6 +8,7 @@
 // outside the GIL while the GPU works on the previous epoch.
 #include <immintrin.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <vector>
@@ -695,12 +696,45 @@ extern "C" int rlppo_exponential_from_words(const uint32_t *words, int64_t n, do
 // `count` words all hold `value`, or `timeout_us` has passed (returns 1: the caller synchronises the stream instead).  The words live
 // in pinned host memory the kernel stores into with release semantics at system scope; the acquire loads here order the reads of
 // the results behind them.
+// [r5] Host writes into DEVICE memory (rlppo_host_window_alloc: fine-grained VRAM behind the PCIe aperture, write-combined on the host
+// side): a posted write costs the host 1.5 us per 3 KB / 2.5 us per 34 KB, where a GPU-initiated read of the same bytes from pinned
+// host memory cost the rollout kernel 11-20 us (tools/get_action_profile.py).  The copy is fenced (write-combining buffers drain, and
+// nothing after it -- the doorbell of a launch, the flag below -- can overtake it); the optional flag word follows, fenced again.
+extern "C" int rlppo_host_push(void *dst, const void *src, size_t bytes, uint32_t *flag, uint32_t value) {
+    if (bytes && (!dst || !src)) return RLPPO_ERR_ARG;
+    if (bytes) memcpy(dst, src, bytes);
+    _mm_sfence();
+    if (flag) {
+        __atomic_store_n(flag, value, __ATOMIC_RELAXED);
+        _mm_sfence();
+    }
+    return 0;
+}
+
+// the host half of a small rollout call before its launch, in one call: control words {sequence, live rows} (ctl may be NULL) and
+// the observations, one fence behind both
+extern "C" int rlppo_host_stage_call(uint32_t *ctl, uint32_t sequence, uint32_t live_rows, void *obs_dst, const void *obs_src, size_t obs_bytes) {
+    if (obs_bytes && (!obs_dst || !obs_src)) return RLPPO_ERR_ARG;
+    if (ctl) {
+        ctl[0] = sequence;
+        ctl[1] = live_rows;
+    }
+    if (obs_bytes) memcpy(obs_dst, obs_src, obs_bytes);
+    _mm_sfence();
+    return 0;
+}
+
 extern "C" int rlppo_host_wait_words(const uint32_t *words, int64_t count, uint32_t value, int64_t timeout_us) {
     if (count < 0 || (count > 0 && !words)) return RLPPO_ERR_ARG;
     const auto t0 = std::chrono::steady_clock::now();
     int64_t first = 0;
     for (unsigned spins = 0;; ++spins) {
-        while (first < count && __atomic_load_n(words + first, __ATOMIC_ACQUIRE) == value) ++first;
+        while (first < count) {
+            const uint32_t w = __atomic_load_n(words + first, __ATOMIC_ACQUIRE);
+            if (w == (value | 0x80000000u) && w != value) return 2;  // the kernel gave up on its late noise (rlppo_act_opts.noise_ctl)
+            if (w != value) break;
+            ++first;
+        }
         if (first >= count) return 0;
         __builtin_ia32_pause();
         if ((spins & 1023) == 1023 &&

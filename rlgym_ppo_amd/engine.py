@@ -124,6 +124,11 @@ class NetArena:
             i += 2
         return True
 
+    def packed_is_current(self):
+        """Would ensure_packed() have nothing to do?  (ActGraph.run asks AFTER its launch, while the GPU works: a call on a stale
+        copy is repeated, and the 5 us of these checks leave the call's critical path.)"""
+        return self.is_bound() and self._pack_key() == self._packed_key
+
     def ensure_packed(self):
         if not self.is_bound():  # e.g. the user called module.to(...) or replaced .data
             self.bind()
@@ -811,10 +816,18 @@ def host_exponential(shape, device=None):
     return _HOST_EXP.draw(shape, device)
 
 
+_EPOCH = None
+
+
 def selection_epoch():
     """Counter the library bumps whenever a call changes which kernels later launches select (precision setters, A/B
-    switches): captured graphs of library calls are keyed on it (ppo/_mlp.py::ActGraph)."""
-    return int(N.lib().rlppo_selection_epoch())
+    switches): captured graphs of library calls are keyed on it (ppo/_mlp.py::ActGraph).  (Read in place: it sits on the
+    per-call path of get_action.)"""
+    global _EPOCH
+    if _EPOCH is None:
+        import ctypes
+        _EPOCH = ctypes.c_int64.from_address(N.lib().rlppo_selection_epoch_ptr())
+    return _EPOCH.value
 
 
 def set_update_precision(mode):

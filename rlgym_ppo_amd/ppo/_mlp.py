@@ -61,17 +61,42 @@ class ActGraph:
         self.done_pin = torch.zeros(max(self.n_done, 1), dtype=torch.int32).pin_memory()
         self.poll = os.environ.get("RLPPO_ACT_POLL", "1") != "0"
         self.opts = N.ActOpts(N.PRECISION_DEFAULT, 1, self.done_pin.data_ptr()) if self.poll else None
-        self.polled = self.poll_timeouts = 0
+        self.polled = self.poll_timeouts = self.late_retries = self.stale_relaunches = 0
         self.seq = self.graph_value = 1   # (the warm-up launch and the capture below store 1)
+        # [r5] host window (rlppo_host_window_alloc): the one-launch step reads its observations, noise and control words from DEVICE
+        # memory that run() writes directly through the PCIe aperture (posted writes: 1.5-2.5 us for 8-80 observations) instead of
+        # reading pinned host memory itself (GPU-initiated PCIe reads: 11-20 us of the kernel).  RLPPO_ACT_PUSH=0: pinned memory.
+        self.window = None
+        self.obs_arg, self.q_arg = self.obs_pin.data_ptr(), self.q_pin.data_ptr()   # what _act_launch_raw hands to the kernel
+        self.push = bool(self.poll and raw is not None and os.environ.get("RLPPO_ACT_PUSH", "1") != "0")
+        if self.push:
+            r256 = lambda x: (x + 255) // 256 * 256
+            obs_bytes, q_bytes = r256(cap * d * 4), r256(int(self.q_pin.numel()) * 4)
+            win = ctypes.c_void_p()
+            if L.rlppo_host_window_alloc(256 + obs_bytes + q_bytes, ctypes.byref(win)) == 0:
+                self.window = win.value
+                self.ctl_arg, self.obs_arg, self.q_arg = win.value, win.value + 256, win.value + 256 + obs_bytes
+                self._push, self._stage = L.rlppo_host_push, L.rlppo_host_stage_call
+            else:
+                self.push = False   # (a device that does not expose its memory to the host)
+        # [r5] late noise (rlppo_act_opts.noise_ctl): run() launches FIRST and draws the Exp(1) numbers afterwards -- the bit-exact
+        # draw (5-11 us at 8-80 rows) then costs the call nothing, it hides behind the launch latency and the layers; the kernel
+        # looks for control word 2 when its head layer starts.  Up to 256 rows: beyond that the draw outlasts the kernel.
+        # RLPPO_ACT_LATE_NOISE=0: noise staged before the launch (round 4).
+        self.late = bool(self.push and cap <= 256 and os.environ.get("RLPPO_ACT_LATE_NOISE", "1") != "0")
+        if self.late:
+            self.opts.noise_ctl = self.ctl_arg
+            self.late = L.rlppo_discrete_step_one_launch(a.dims_c, a.n_layers, cap, ctypes.byref(self.opts)) == 1
+            if not self.late:
+                self.opts.noise_ctl = None
+        if self.late:
+            self.noise_seq = 0   # (control words {sequence, live rows}: 0 rows while capturing)
+        self.q_per_row = int(self.q_pin.numel()) // cap
 
-        def body():
-            if raw is not None:
-                raw(self, cap, self.opts)
-                return
-            N.check(L.rlppo_pad_rows(stream_ptr(), ptr(self.obs_pin), 0, cap, d, d, ptr(self.rows), a.ld_in, 0, 0.0, 1.0))
-            pol._act_launch(self.rows, cap, self.q_pin, self.act_pin, self.logp_pin, self.ws, self.opts)
-
-        self.body = body
+        # (no closure over self: an ActGraph dropped from the policy's cache dies there and then, by reference count -- a cyclic
+        # collection that destroyed its hipGraph later, at a random allocation, could wait for the GPU while a kernel waits for us)
+        self._raw, self._pol = raw, pol
+        body = self.body
         # The body is replayed as a hipGraph.  (Rounds 3-4 issued a ONE-launch body -- the discrete head -- eagerly: the replay of a
         # one-node graph then cost 2-3 us more than the launch.  [r5] With completion polled instead of synchronised the replay is
         # the cheaper of the two by 2-3 us -- one hipGraphLaunch against a 22-argument ctypes call + hipLaunchKernel --
@@ -92,11 +117,94 @@ class ActGraph:
         self._done_ptr = ctypes.c_void_p(self.done_pin.data_ptr())
         self._wait = L.rlppo_host_wait_words
 
-    def run(self, obs, q, n):
+    def __del__(self):
+        win, self.window = getattr(self, "window", None), None
+        if win:
+            try:
+                torch.cuda.synchronize(self.dev)   # (its graph may still be running)
+                N.lib().rlppo_host_window_free(ctypes.c_void_p(win))
+            except Exception:  # noqa: BLE001 -- interpreter shutdown
+                pass
+
+    def read_control_words(self):
+        """The 32 control / statistics words of the late noise (a slow uncached read of device memory: tools only)."""
+        out = np.zeros(32, dtype=np.uint32)
+        torch.cuda.synchronize(self.dev)
+        ctypes.memmove(out.ctypes.data, self.ctl_arg, 128)
+        return out
+
+    def body(self):
+        pol, a, cap = self._pol, self._pol.arena, self.cap
+        if self._raw is not None:
+            self._raw(self, cap, self.opts)
+            return
+        N.check(N.lib().rlppo_pad_rows(stream_ptr(), ptr(self.obs_pin), 0, cap, a.d_in, a.d_in, ptr(self.rows), a.ld_in, 0, 0.0, 1.0))
+        pol._act_launch(self.rows, cap, self.q_pin, self.act_pin, self.logp_pin, self.ws, self.opts)
+
+    def run(self, obs, q, n, draw=None, verify=None):
+        """obs [n, d] float32 numpy; q: the call's noise (CPU tensor) or None with draw(): called for it -- AFTER the launch when
+        the graph takes late noise.  verify (optional): () -> bool, asked after the launch whether what the launch read (the packed
+        weights) was current; on False redo() -- its second return value -- is run and the call made again."""
         # plain memcpy through numpy views made once: Tensor.copy_ fans out to an OpenMP team above 32k elements (10 ms on a
         # 256-thread host), and slicing tensors costs more than these copies at 8-80 rows
-        self.obs_np[:n] = obs
-        self.q_np[:q.numel()] = q.reshape(-1).numpy()
+        m = n * self.q_per_row
+        if self.push:
+            if not obs.flags.c_contiguous:
+                obs = np.ascontiguousarray(obs)
+            if self.late:
+                self.noise_seq = self.noise_seq % 0x7FFFFFFF + 1
+                self._stage(self.ctl_arg, self.noise_seq, n, self.obs_arg, obs.ctypes.data, obs.nbytes)
+            else:
+                if q is None:
+                    q = draw()
+                q = q if q.is_contiguous() else q.contiguous()
+                if q.numel() != m or q.dtype != torch.float32:
+                    raise ValueError("noise: expected %d float32 numbers" % m)
+                self._push(self.q_arg, q.data_ptr(), 4 * m, None, 0)
+                self._stage(None, 0, 0, self.obs_arg, obs.ctypes.data, obs.nbytes)
+        else:
+            self.obs_np[:n] = obs
+            if q is None:
+                q = draw()
+            self.q_np[:m] = q.reshape(-1).numpy()
+        value, count = self._launch(n)
+        if self.late:
+            # the kernel is on its way: now the noise.  Whatever happens here control word 2 gets this call's sequence (a kernel left
+            # waiting sits on the GPU until it gives up, 20 ms).  Nothing in here may wait for the GPU: the kernel waits for us.
+            try:
+                if q is None:
+                    q = draw()
+                q = q if q.is_contiguous() else q.contiguous()
+                if q.numel() != m or q.dtype != torch.float32:
+                    raise ValueError("noise: expected %d float32 numbers" % m)
+                self._push(self.q_arg, q.data_ptr(), 4 * m, self.ctl_arg + 8, self.noise_seq)
+            except BaseException:
+                self._push(None, None, 0, self.ctl_arg + 8, self.noise_seq)
+                self._wait(self._done_ptr, count, value, 100000)
+                raise
+        rc = None
+        if verify is not None:
+            ok, redo = verify()
+            if not ok:
+                # the launch read a stale copy of the weights (somebody wrote the parameters since the last call): let it finish,
+                # bring the copy up to date, make the call again -- the noise is in place
+                rc = self._finish(value, count)
+                redo()
+                self.stale_relaunches += 1
+                value, count = self._launch(n)
+                rc = None
+        if (self._finish(value, count) if rc is None else rc) == 2:
+            # the noise came later than the kernel's patience (the host was held up between the launch and the publish: a
+            # collector pause that destroys device objects, a descheduled thread): the pairs are there now, launch again
+            self.late_retries += 1
+            value, count = self._launch(n)
+            if self._finish(value, count) != 0:
+                raise RuntimeError("rollout step: the kernel gave up on noise that is there (rlppo_act_opts.noise_ctl): sequence %d, "
+                                   "completion words %s" % (self.noise_seq, self.done_np.astype(np.uint32).tolist()))
+        return torch.from_numpy(self.act_np[:n].copy()), torch.from_numpy(self.logp_np[:n].copy())
+
+    def _launch(self, n):
+        """-> (value, count): the completion words to wait for."""
         if self.eager:
             # a fresh completion value per call: a workgroup of an EARLIER launch that finishes late (rows past that call's n, which
             # nobody waited for) stores the earlier value and cannot be mistaken for this call's; only the words of the rows the
@@ -105,20 +213,24 @@ class ActGraph:
             if self.poll:
                 self.opts.done_value = self.seq
             self.body()
-            value, count = self.seq, (n + 15) // 16
-        else:
-            # a replayed graph stores the value it was captured with: clear the words, wait for ALL of them (nothing of this
-            # launch is then still running when the next call clears them again)
-            if self.poll:
-                self.done_np[:] = 0
-            self.graph.replay()
-            value, count = self.graph_value, self.n_done
-        if self.poll and self._wait(self._done_ptr, count, value, 2000) == 0:
+            return self.seq, (n + 15) // 16
+        # a replayed graph stores the value it was captured with: clear the words, wait for ALL of them (nothing of this
+        # launch is then still running when the next call clears them again)
+        if self.poll:
+            self.done_np[:] = 0
+        self.graph.replay()
+        return self.graph_value, self.n_done
+
+    def _finish(self, value, count):
+        """Waits for the launch: 0 = results are there, 2 = the kernel gave up on its late noise."""
+        rc = self._wait(self._done_ptr, count, value, 2000) if self.poll else 1
+        if rc == 0:
             self.polled += 1
-        else:
+        elif rc == 1:
             self.poll_timeouts += int(self.poll)
             torch.cuda.current_stream(self.dev).synchronize()
-        return torch.from_numpy(self.act_np[:n].copy()), torch.from_numpy(self.logp_np[:n].copy())
+            rc = self._wait(self._done_ptr, count, value, 0) if self.late else 0   # (every word is stored by now: 0 or 2)
+        return rc
 
 
 def _bucket(n):
@@ -166,9 +278,13 @@ class ArenaModule(nn.Module):
         if o.ndim != 2 or o.shape[1] != a.d_in or not (0 < o.shape[0] <= self.act_graph_max):
             return None
         n = o.shape[0]
-        q = self._draw_noise(n) if noise is None else torch.as_tensor(noise, dtype=torch.float32)
-        if tuple(q.shape) != tuple(self._noise_shape(n)):
-            return None
+        q = None  # drawn by the graph: after its launch when it takes late noise (ActGraph.run)
+        if noise is not None:
+            q = torch.as_tensor(noise, dtype=torch.float32)
+            if tuple(q.shape) != tuple(self._noise_shape(n)):
+                return None
+            if not q.is_contiguous():
+                q = q.contiguous()
         # a captured graph replays the kernels that were selected at capture time: the library's selection epoch (bumped by
         # rlppo_set_inference_precision and the A/B switches) is part of the cache key, stale graphs are dropped
         epoch = selection_epoch()
@@ -178,8 +294,22 @@ class ArenaModule(nn.Module):
         g = self._graphs.get(_bucket(n))
         if g is None:
             g = self._graphs[_bucket(n)] = ActGraph(self, _bucket(n))
+        if o.dtype != np.float32:
+            o = o.astype(np.float32)
+        if g.late:
+            # launch on the packed copy as it is and check that it was current WHILE the GPU works (8 Parameters' versions and
+            # addresses: 5 us of the call's critical path otherwise); a stale one -- rare: a stock optimiser stepped, the module
+            # moved -- costs a second launch
+            return g.run(o, q, n, self._draw_bound(n), self._verify)
         a.ensure_packed()
-        return g.run(o if o.dtype == np.float32 else o.astype(np.float32), q if q.is_contiguous() else q.contiguous(), n)
+        return g.run(o, q, n, self._draw_bound(n))
+
+    def _draw_bound(self, n):
+        return lambda: self._draw_noise(n)
+
+    def _verify(self):
+        a = self.arena
+        return a.packed_is_current(), a.ensure_packed
 
     def _apply(self, fn, *a, **k):  # .to()/.float()/... : re-bind afterwards so the kernels keep seeing the params
         out = super()._apply(fn, *a, **k)

@@ -43,16 +43,22 @@ class DiscreteFF(ArenaModule):
         """Softmax probabilities [n, n_actions] on the device (discrete_policy.py:34-42)."""
         return self._probs(self.arena.stage_obs(obs), clamp=False)[0]
 
-    @torch.no_grad()
     def get_action(self, obs, deterministic=False, noise=None, standardize=None):
         """-> (actions int64 CPU [n], log_probs fp32 CPU [n]) like discrete_policy.py:44-62.
         `noise`: optional [n, n_actions] Exp(1) draws (default: torch.empty(n, A).exponential_(1) from the CPU
         generator, the reference's stream).  `standardize`: optional (mean0, std0) scalars fused into staging."""
-        a = self.arena
         if not deterministic:
-            out = self._graph_act(obs, noise, standardize)  # small host batches: one hipGraph replay (ppo/_mlp.py)
+            # small host batches: one hipGraph replay (ppo/_mlp.py).  (Nothing in there touches autograd: the no_grad scope -- 2 us
+            # of a 45 us call -- is entered below, where torch operators run.)
+            out = self._graph_act(obs, noise, standardize)
             if out is not None:
                 return out
+        return self._get_action_general(obs, deterministic, noise, standardize)
+
+    @torch.no_grad()
+    def _get_action_general(self, obs, deterministic, noise, standardize):
+        a = self.arena
+        if not deterministic:
             return self.step(obs, noise, standardize)       # [r3] the whole step in one launch (rlppo_discrete_step)
         rows = a.stage_obs(obs, standardize)
         n = rows.shape[0]
@@ -155,7 +161,7 @@ class DiscreteFF(ArenaModule):
             return int(L.rlppo_discrete_step_workspace_bytes(a.dims_c, a.n_layers, cap))
         args = getattr(g, "_raw_args", None)
         if args is None or args[0] is not opts:  # every pointer of the call is fixed for the graph's lifetime: built once
-            args = g._raw_args = (opts, (a.dims_c, a.n_layers, ptr(a.packed), ptr(g.obs_pin), 0, a.d_in, cap, 0, 0.0, 1.0, None, None, ptr(g.q_pin),
+            args = g._raw_args = (opts, (a.dims_c, a.n_layers, ptr(a.packed), g.obs_arg, 0, a.d_in, cap, 0, 0.0, 1.0, None, None, g.q_arg,
                                          ptr(g.act_pin), None, ptr(g.logp_pin), None, 0, ptr(g.ws), g.ws.numel(),
                                          ctypes.byref(opts) if opts is not None else None))
         N.check(L.rlppo_discrete_step(stream_ptr(), *args[1]))

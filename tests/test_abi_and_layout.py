@@ -448,6 +448,20 @@ def test_host_exponential_self_check_falls_back_to_torch(monkeypatch):
     assert all(torch.equal(a, b) for a, b in zip(want, got)) and torch.equal(s_want, torch.get_rng_state())
 
 
+def test_wait_words_tells_a_give_up_from_a_word_that_is_not_there_yet():
+    """[r5] Host half of rlppo_act_opts.noise_ctl: rlppo_host_wait_words tells a completion word that carries the give-up bit (2)
+    from one that is not there yet (1)."""
+    from rlgym_ppo_amd import _native as N
+    L = N.lib()
+    words = np.array([5, 5, 0, 5], dtype=np.uint32)
+    P = lambda a: ctypes.c_void_p(a.ctypes.data)
+    assert L.rlppo_host_wait_words(P(words), 2, 5, 0) == 0 and L.rlppo_host_wait_words(P(words), 4, 5, 1000) == 1
+    words[2] = 5 | 0x80000000
+    assert L.rlppo_host_wait_words(P(words), 4, 5, 1000) == 2 and L.rlppo_host_wait_words(P(words), 2, 5, 0) == 0
+    words[2] = 0x80000000                        # value 0x80000000 itself is just a value
+    assert L.rlppo_host_wait_words(P(words[2:]), 1, 0x80000000, 0) == 0
+
+
 def test_split_plane_image_is_conflict_free_for_ds_read_b128():
     """[r4] The 16-column block of a split-bf16 weight plane (csrc/gemm_split.hip, wpos(): the 16-byte chunk of column r, k quarter q
     sits at chunk 4 r + (q ^ (-(r // 4) & 3)) of the block's 1 KiB).  A fragment read is one ds_read_b128 with lane = 16 q + r, which

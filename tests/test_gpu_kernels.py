@@ -776,6 +776,104 @@ def test_act_options_completion_words_and_per_call_precision(L, hidden):
     assert not torch.equal(outs["fp32"], outs["bf16_option"]) and relerr(outs["bf16_option"], outs["fp32"]) < 3e-2
 
 
+@pytest.mark.parametrize("where", ["host_window", "pinned"])
+@pytest.mark.parametrize("hidden", [(256, 256, 256), (128, 128)], ids=["fused256", "fused128"])
+def test_discrete_step_takes_its_noise_while_it_runs(L, hidden, where):
+    """[r5] rlppo_act_opts.noise_ctl: the one-launch step is launched BEFORE its noise exists; the host then fills the noise matrix
+    and stores the call's sequence into control word 2 (rlppo_host_push: bytes, fence, word, fence); the kernel -- which looks for
+    that word when its head layer starts and waits for it after the last layer if it was not there -- samples with exactly those
+    numbers: actions / log-probabilities bit-identical to the call that had its noise staged beforehand, for a host that completes
+    at once and for one that takes 4 ms; rows past the live count are untouched; a host that does not complete gets completion
+    words with the failure bit after 20 ms (rlppo_host_wait_words returns 2), not a hung GPU, and the same call made again after
+    the completion delivers; entry points / networks without the one-launch kernel refuse the option.  Observations, noise and
+    control words live in a host window (device memory the host writes through the PCIe aperture: what ActGraph uses) or in
+    pinned host memory."""
+    import time
+    from rlgym_ppo_amd import _native as N
+    d, A, n, live = 107, 90, 96, 83
+    torch.manual_seed(11 + hidden[0])
+    net = Net(L, nets.init_mlp(d, hidden, A))
+    rs = np.random.RandomState(hidden[0] + 1)
+    obs_h = np.clip(rs.randn(n, d), -5, 5).astype(np.float32)
+    ws = torch.empty(int(L.rlppo_discrete_step_workspace_bytes(net.dims_c, net.nl, n)), dtype=torch.uint8, device="cuda")
+    n_words = int(L.rlppo_act_done_words(n))
+    done = torch.zeros(n_words, dtype=torch.int32).pin_memory()
+    win = ctypes.c_void_p()
+    if where == "host_window":
+        check(L, L.rlppo_host_window_alloc(256 + 4 * n * d + 4 * n * A, ctypes.byref(win)))
+        ctl_p, obs_p, q_p = win.value, win.value + 256, win.value + 256 + 4 * n * d
+    else:
+        keep = (torch.zeros(32, dtype=torch.int32).pin_memory(), torch.zeros(n, d).pin_memory(), torch.ones(n, A).pin_memory())
+        ctl_p, obs_p, q_p = (t.data_ptr() for t in keep)
+    V = ctypes.c_void_p
+    check(L, L.rlppo_host_push(V(obs_p), V(obs_h.ctypes.data), obs_h.nbytes, None, 0))
+    obs_pin = torch.from_numpy(obs_h).pin_memory()
+    hdr = np.zeros(2, dtype=np.uint32)
+
+    def step(opts, obs_ptr, noise_ptr, act, logp):
+        return L.rlppo_discrete_step(stream(), net.dims_c, net.nl, P(net.packed), V(obs_ptr), 0, d, n, 0, 0.0, 1.0, None, None, V(noise_ptr), P(act), None,
+                                     P(logp), None, 0, P(ws), ws.numel(), opts)
+
+    try:
+        opts = N.ActOpts(N.PRECISION_DEFAULT, 1, done.data_ptr(), ctl_p)
+        assert L.rlppo_discrete_step_one_launch(net.dims_c, net.nl, n, ctypes.byref(opts)) == 1
+        for seq, delay in ((1, 0.0), (2, 0.004), (0x7FFFFFFF, 0.0), (3, 0.0)):
+            q = torch.from_numpy(rs.exponential(size=(n, A)).astype(np.float32)).pin_memory()
+            ref_a, ref_l = torch.empty(n, dtype=torch.int64).pin_memory(), torch.empty(n).pin_memory()
+            check(L, step(None, obs_pin.data_ptr(), q.data_ptr(), ref_a, ref_l))
+            torch.cuda.synchronize()
+            act, logp = torch.full((n,), -1, dtype=torch.int64).pin_memory(), torch.full((n,), float("nan")).pin_memory()
+            done.zero_()
+            hdr[:] = (seq, live)
+            check(L, L.rlppo_host_push(V(ctl_p), V(hdr.ctypes.data), 8, None, 0))
+            opts.done_value = seq
+            check(L, step(ctypes.byref(opts), obs_p, q_p, act, logp))       # (the noise matrix still holds the previous round's numbers)
+            if delay:
+                time.sleep(delay)
+                assert L.rlppo_host_wait_words(P(done), n_words, seq, 0) == 1   # still waiting for its noise
+            check(L, L.rlppo_host_push(V(q_p), V(q.data_ptr()), 4 * live * A, V(ctl_p + 8), seq))
+            assert L.rlppo_host_wait_words(P(done), n_words, seq, 5_000_000) == 0
+            assert torch.equal(act[:live], ref_a[:live]) and torch.equal(logp[:live], ref_l[:live]), (seq, delay)
+            assert (act[live:] == -1).all() and torch.isnan(logp[live:]).all()
+        torch.cuda.synchronize()
+        # a host that does not complete: the kernel gives up after 20 ms and says so; the call made again after the completion delivers
+        done.zero_()
+        hdr[:] = (77, live)
+        check(L, L.rlppo_host_push(V(ctl_p), V(hdr.ctypes.data), 8, None, 0))
+        opts.done_value = 5
+        act, logp = torch.full((n,), -1, dtype=torch.int64).pin_memory(), torch.full((n,), float("nan")).pin_memory()
+        t0 = time.time()
+        check(L, step(ctypes.byref(opts), obs_p, q_p, act, logp))
+        assert L.rlppo_host_wait_words(P(done), n_words, 5, 10_000_000) == 2
+        torch.cuda.synchronize()
+        assert 0.015 < time.time() - t0 < 1.0
+        assert (done.numpy().astype(np.uint32) == np.uint32(5 | 0x80000000)).all()
+        check(L, L.rlppo_host_push(None, None, 0, V(ctl_p + 8), 77))
+        done.zero_()
+        check(L, step(ctypes.byref(opts), obs_p, q_p, act, logp))
+        assert L.rlppo_host_wait_words(P(done), n_words, 5, 5_000_000) == 0
+        assert torch.equal(act[:live], ref_a[:live]) and torch.equal(logp[:live], ref_l[:live])
+        # refused where no one-launch kernel runs and without completion words
+        a0, l0 = torch.empty(n, dtype=torch.int64, device="cuda"), torch.empty(n, device="cuda")
+        rows = net.pad(obs_h)
+        w = net.ws(n)
+        assert L.rlppo_discrete_act(stream(), net.dims_c, net.nl, P(net.packed), P(rows), net.ld_in, n, V(q_p), P(a0), P(l0), None, P(w), w.numel(),
+                                    ctypes.byref(opts)) == 1001
+        no_words = N.ActOpts(N.PRECISION_DEFAULT, 1, None, ctl_p)
+        assert step(ctypes.byref(no_words), obs_p, q_p, act, logp) == 1001
+        check(L, L.rlppo_dbg_set(27, 0))   # the layer chain instead of the one-launch kernel
+        try:
+            assert L.rlppo_discrete_step_one_launch(net.dims_c, net.nl, n, ctypes.byref(opts)) == 0
+            assert step(ctypes.byref(opts), obs_p, q_p, act, logp) == 1001
+        finally:
+            check(L, L.rlppo_dbg_set(27, 1))
+        torch.cuda.synchronize()
+    finally:
+        torch.cuda.synchronize()
+        if win.value:
+            check(L, L.rlppo_host_window_free(win))
+
+
 @pytest.mark.parametrize("hidden", [(256, 256, 256), (64, 64), (96, 96)], ids=["fused256", "fused64", "chain_only"])
 def test_discrete_step_raw_observations_all_modes(L, hidden):
     """[r3] rlppo_discrete_step -- raw observations (fp32 / fp64, ragged row stride) -> standardise (none / the reference's scalars of

@@ -780,6 +780,65 @@ def test_get_action_graph_replay_equals_eager_path():
     assert set(pol._graphs) == {16, 32, 80, 256, 1024, 48}
 
 
+def test_get_action_draws_its_noise_behind_the_launch(monkeypatch):
+    """[r5] The graph-served get_action of the discrete head writes its observations into a host window (device memory behind the
+    PCIe aperture), launches, and draws its Exp(1) noise afterwards (ActGraph.push / .late, rlppo_act_opts.noise_ctl): same
+    actions, log-probabilities and generator state as the forms that stage the noise before the launch (RLPPO_ACT_LATE_NOISE=0)
+    and that keep everything in pinned host memory (RLPPO_ACT_PUSH=0), call after call with changing n inside one bucket; a draw
+    that raises leaves no kernel waiting and the next call is served normally; a host that is held up gets a second launch."""
+    from rlgym_ppo_amd.ppo import DiscreteFF
+    torch.manual_seed(3)
+    pol = DiscreteFF(107, 90, (256, 256, 256), "cuda:0")
+    rs = np.random.RandomState(4)
+    calls = [np.clip(rs.randn(n, 107), -5, 5).astype(np.float32) for n in (8, 3, 16, 80, 70, 80, 1, 33, 128, 200, 700)]
+    out = {}
+    for late, push in (("1", "1"), ("0", "1"), ("1", "0")):
+        monkeypatch.setenv("RLPPO_ACT_LATE_NOISE", late)
+        monkeypatch.setenv("RLPPO_ACT_PUSH", push)
+        pol._graphs.clear()
+        torch.manual_seed(99)
+        out[late, push] = [pol.get_action(o) for o in calls] + [torch.get_rng_state()]
+        assert all(g.push == (push == "1") and g.late == (late == "1" and push == "1" and g.cap <= 256) for g in pol._graphs.values())
+        assert set(pol._graphs) == {16, 48, 80, 128, 256, 1024}
+        assert all(g.poll_timeouts == 0 and g.late_retries == 0 for g in pol._graphs.values())
+    for other in (("0", "1"), ("1", "0")):
+        for (a1, l1), (a0, l0) in zip(out["1", "1"][:-1], out[other][:-1]):
+            assert torch.equal(a1, a0) and torch.equal(l1, l0)
+        assert torch.equal(out["1", "1"][-1], out[other][-1])
+    monkeypatch.setenv("RLPPO_ACT_LATE_NOISE", "1")
+    monkeypatch.setenv("RLPPO_ACT_PUSH", "1")
+    pol._graphs.clear()
+    good = pol._draw_noise
+
+    def broken(n):
+        raise KeyError("no noise today")
+
+    torch.manual_seed(99)
+    a_first = pol.get_action(calls[0])
+    pol._draw_noise = broken
+    with pytest.raises(KeyError):
+        pol.get_action(calls[0])
+    torch.cuda.synchronize()
+    pol._draw_noise = good
+    torch.manual_seed(99)
+    a_again = pol.get_action(calls[0])
+    assert torch.equal(a_first[0], a_again[0]) and torch.equal(a_first[1], a_again[1])
+    # a host that is held up between the launch and the publish for longer than the kernel's patience (20 ms): the kernel gets
+    # out of the way, the call is made again with the noise in place -- same results, one retry counted
+    import time
+
+    def slow(n):
+        time.sleep(0.05)
+        return good(n)
+
+    pol._draw_noise = slow
+    torch.manual_seed(99)
+    a_slow = pol.get_action(calls[0])
+    pol._draw_noise = good
+    g = pol._graphs[16]
+    assert g.late_retries == 1 and torch.equal(a_first[0], a_slow[0]) and torch.equal(a_first[1], a_slow[1])
+
+
 @pytest.mark.parametrize("n_agents,steps", [(64, 128), (768, 24)], ids=["on_the_spot", "look_ahead"])
 def test_seeded_rollout_draws_the_reference_noise_stream(n_agents, steps):
     """Rollout steps from one seed: DiscreteFF.get_action's default noise (librlppo's host implementation of torch's CPU

@@ -27,20 +27,21 @@ def wall(fn, reps=300, warm=30):
 
 
 def parts(n, obs):
-    """Where a graph-served call spends its time: noise draw, staging + replay, wait."""
+    """Where a graph-served call spends its time: the noise draw (behind the launch when the graph takes late noise), everything
+    up to the wait, the whole call with the noise handed in."""
     g_ = pol._graphs[pol._graphs and sorted(k for k in pol._graphs if k >= n)[0]]
     t = {}
     t["noise draw"] = wall(lambda: pol._draw_noise(n))
     q = pol._draw_noise(n).clone()
-    def stage_replay():
-        g_.obs_np[:n] = obs
-        g_.q_np[:q.numel()] = q.reshape(-1).numpy()
-        g_.graph.replay()
-    t["stage + replay (no wait)"] = wall(lambda: (stage_replay(), None)[1])   # back-pressure-free: one WG per replay
-    def replay_wait():
-        g_.graph.replay()
-        torch.cuda.current_stream().synchronize()
-    t["replay + wait"] = wall(replay_wait)
+    wait = g_._wait
+    try:
+        g_._wait = lambda *a: 0   # (the kernels of consecutive calls queue up on the stream; the last wall() call synchronises)
+        t["stage + replay" + (" + publish" if g_.late else "") + " (no wait)"] = wall(lambda: g_.run(obs, q, n))
+    finally:
+        g_._wait = wait
+    torch.cuda.synchronize()
+    t["the call without its draw"] = wall(lambda: g_.run(obs, q, n))
+    t["late noise"] = float(g_.late)
     return t
 
 
