@@ -837,6 +837,22 @@ def test_get_action_draws_its_noise_behind_the_launch(monkeypatch):
     pol._draw_noise = good
     g = pol._graphs[16]
     assert g.late_retries == 1 and torch.equal(a_first[0], a_slow[0]) and torch.equal(a_first[1], a_slow[1])
+    # parameters written behind the packed copy's back (a stock optimiser's in-place step): the launch goes out on the stale copy,
+    # the check behind it notices, the call is made again on the new weights -- exactly what the eager path computes
+    before = g.stale_relaunches
+    with torch.no_grad():
+        for p in pol.parameters():
+            p.add_(torch.randn_like(p) * 0.05)
+    q = torch.empty(8, 90).exponential_(1)
+    a_new = pol.get_action(calls[0], noise=q)
+    assert g.stale_relaunches == before + 1
+    pol.act_graphs = False
+    a_ref = pol.get_action(calls[0], noise=q)
+    pol.act_graphs = True
+    assert torch.equal(a_new[0], a_ref[0]) and torch.equal(a_new[1], a_ref[1])
+    assert not torch.equal(a_new[1], a_first[1])
+    a_new2 = pol.get_action(calls[0], noise=q)
+    assert g.stale_relaunches == before + 1 and torch.equal(a_new2[1], a_ref[1])
 
 
 @pytest.mark.parametrize("n_agents,steps", [(64, 128), (768, 24)], ids=["on_the_spot", "look_ahead"])
