@@ -486,7 +486,9 @@ int rlppo_dbg_gemm_nt_x3(void *stream, const float *A, int64_t lda, const void *
  *  36 split-bf16 products (update precision 2) [1 = persistent workgroups for large launches (default) | 0 = one workgroup per tile]
  *  37 [r5] the weight-gradient products of a pass [1 = ONE grouped launch + ONE reduction after the chains have joined (default; fp32 and
  *     split-bf16 precisions) | 0 = one launch + reduction per layer inside the chains]
- *  38 [r5] workgroups of a grouped weight-gradient launch [0 = two per CU (default) | n] */
+ *  38 [r5] workgroups of a grouped weight-gradient launch [0 = two per CU (default) | n]
+ *  40 [r5] forward layers of up to 1024 rows (the layer chain of a small rollout call) [1 = one wave per 16 x 16 output block, operands
+ *     straight from L2 (default) | 0 = the 128-row tiles of the large kernel]: bit-identical outputs */
 int rlppo_dbg_set(int32_t key, int32_t value);
 /* Counter bumped by every call that changes which kernels later launches select (rlppo_dbg_set, rlppo_set_*_precision): a
  * host that caches captured graphs of library calls keys them on it (rlgym_ppo_amd/ppo/_mlp.py::ActGraph). */

@@ -1500,6 +1500,7 @@ int rlppo_dbg_set(int32_t key, int32_t value) {
         case 33: set_pair_interleave(value); return 0;
         case 37: g_group_dw = value; return 0;
         case 38: set_tn_group_budget(value); return 0;
+        case 40: set_nt_skinny(value); return 0;
         default: break;
     }
     set_error("dbg_set: unknown key %d", key);

@@ -131,6 +131,7 @@ int launch_gemm_nt_bf16(hipStream_t st, const float *A, int64_t lda, const float
                         int64_t ldc, int64_t M, int N, int nb, int K, int epi);
 void set_infer_bf16(int v);
 void set_pair_interleave(int v);
+void set_nt_skinny(int on);  // rlppo_dbg_set(40): gemm_nt up to 1024 rows as one wave per 16 x 16 output block (1, default) or as 128-row tiles
 int get_infer_bf16();
 // dW[n][k] += sum_m dY[m][n] X[m][k] ; db[n] += sum_m dY[m][n]: partial tiles in `ws` (>= tn_partial_floats(out, in, M)
 // floats) + a fixed-order reduction into the flat arena

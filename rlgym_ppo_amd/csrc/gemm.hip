@@ -356,6 +356,90 @@ static int launch_nt_1(hipStream_t st, dim3 grid, int epi, const float *A, unsig
     return 0;
 }
 
+// ------------------------------------------------------------------------------------------------ gemm_nt for a FEW rows [r5]
+// The layer chain at rollout sizes (8 ... a few hundred rows: the Gaussian / multi-discrete heads, networks wider than the one-launch
+// kernel's 256): gemm_nt_dma_kernel gives a 128-row tile to a workgroup, so 16 rows of a 512 -> 512 layer are TWO workgroups that
+// multiply 7/8 padding -- ~28 us per layer, 172 us for a 5-layer call.  Here one WAVE owns one 16 x 16 output block (16 rows x 16
+// columns) over the whole K and a workgroup is four of them: 128 waves for 16 x 512 outputs, each a dependent chain of K/4 MFMAs
+// (1.7 us at K = 512) fed straight from L2 into registers, 8 K-tiles of both operands requested ahead.  The arithmetic is
+// gemm_nt_dma_kernel's, operation for operation (accumulators start from the bias; K-tile kt, MFMA s contracts k = 16 kt + 4 q + s;
+// relu as v_med3): outputs are BIT-identical (tests/test_gpu_kernels.py::test_gemm_nt_skinny).
+namespace {
+constexpr int SK_AHEAD = 8;          // K-tiles of 16 in flight per operand
+constexpr int64_t SK_MAX_ROWS = 1024;  // beyond that the 128-row tiles fill the chip as well, at half the operand traffic
+int g_nt_skinny = 1;                 // rlppo_dbg_set(40, 0/1)
+}  // namespace
+void set_nt_skinny(int on) { g_nt_skinny = on; }
+
+template <int EPI>
+__global__ __launch_bounds__(256) void gemm_nt_skinny_kernel(const float *__restrict__ A, int64_t lda, const float *__restrict__ B, int64_t ldb,
+                                                             const float *__restrict__ bias, float *__restrict__ C, int64_t ldc, int64_t M, int N,
+                                                             int K) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r16 = lane & 15, q = lane >> 4;
+    const int n0 = ((int)blockIdx.x * 4 + wave) * 16;
+    if (n0 >= N) return;  // (whole waves; the kernel has no barrier)
+    const int64_t m0 = (int64_t)blockIdx.y * 16;
+    const int64_t arow = m0 + r16 < M ? m0 + r16 : M - 1;  // rows past M multiply a valid row; their products are not stored
+    const float *ap = A + arow * lda + q * 4;
+    const float *bp = B + (int64_t)(n0 + r16) * ldb + q * 4;
+    f32x4 acc = *reinterpret_cast<const f32x4 *>(bias + n0 + q * 4);
+    const int nk = K / 16;
+    f32x4 fa[2][SK_AHEAD], fb[2][SK_AHEAD];
+    auto fetch = [&](int buf, int kt0) {
+#pragma unroll
+        for (int i = 0; i < SK_AHEAD; ++i) {
+            // (unconditional: a K-tile past the end is the last one again, its products are skipped -- a branch per request would
+            // make the compiler wait for everything in flight before the first product)
+            const int kt = kt0 + i < nk ? kt0 + i : nk - 1;
+            fa[buf][i] = *reinterpret_cast<const f32x4 *>(ap + kt * 16);
+            fb[buf][i] = *reinterpret_cast<const f32x4 *>(bp + kt * 16);
+        }
+    };
+    fetch(0, 0);
+    for (int kt0 = 0; kt0 < nk; kt0 += 2 * SK_AHEAD) {
+        fetch(1, kt0 + SK_AHEAD);
+#pragma unroll
+        for (int i = 0; i < SK_AHEAD; ++i)
+            if (kt0 + i < nk) {
+#pragma unroll
+                for (int s = 0; s < 4; ++s) acc = MFMA16(fb[0][i][s], fa[0][i][s], acc);
+            }
+        fetch(0, kt0 + 2 * SK_AHEAD);
+#pragma unroll
+        for (int i = 0; i < SK_AHEAD; ++i)
+            if (kt0 + SK_AHEAD + i < nk) {
+#pragma unroll
+                for (int s = 0; s < 4; ++s) acc = MFMA16(fb[1][i][s], fa[1][i][s], acc);
+            }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        if (EPI == EPI_BIAS_RELU) acc[e] = relu1(acc[e]);
+        if (EPI == EPI_BIAS_TANH) acc[e] = tanhf(acc[e]);
+    }
+    // lane (r16, q) holds C[row m0 + r16][columns n0 + 4 q .. + 3]
+    if (m0 + r16 < M) *reinterpret_cast<f32x4 *>(C + (m0 + r16) * ldc + n0 + q * 4) = acc;
+}
+
+static int launch_gemm_nt_skinny(hipStream_t st, const float *A, int64_t lda, const float *B, int64_t ldb, const float *bias, float *C,
+                                 int64_t ldc, int64_t M, int N, int K, int epi) {
+    dim3 grid((unsigned)cdiv(N, 64), (unsigned)cdiv(M, 16));
+#define SK(E)                                                                                                              \
+    case E:                                                                                                                \
+        hipLaunchKernelGGL((gemm_nt_skinny_kernel<E>), grid, dim3(256), 0, st, A, lda, B, ldb, bias, C, ldc, M, N, K);      \
+        break;
+    switch (epi) {
+        SK(EPI_BIAS) SK(EPI_BIAS_RELU) SK(EPI_BIAS_TANH)
+        default:
+            set_error("gemm_nt (few rows): bad epilogue %d", epi);
+            return RLPPO_ERR_ARG;
+    }
+#undef SK
+    RLPPO_LAUNCH_CHECK();
+    return 0;
+}
+
 static int g_infer_bf16 = 0;  // rlppo_set_inference_precision
 void set_infer_bf16(int v) { g_infer_bf16 = v; }
 int get_infer_bf16() { return g_infer_bf16; }
@@ -466,6 +550,7 @@ int launch_gemm_nt(hipStream_t st, const float *A, int64_t lda, const float *B, 
     // (the bf16-operand inference kernel steps K by 32: a layer whose K is only a multiple of 16 -- a first layer padded to 16 --
     // keeps the fp32 kernel, i.e. is computed MORE precisely than the mode asks)
     if (bf16_operands && epi != EPI_MASK && K % 32 == 0) return launch_gemm_nt_bf16(st, A, lda, B, ldb, bias, C, ldc, M, N, nb, K, epi);
+    if (g_nt_skinny && M <= SK_MAX_ROWS && epi != EPI_MASK && !bf16_operands) return launch_gemm_nt_skinny(st, A, lda, B, ldb, bias, C, ldc, M, N, K, epi);
     dim3 grid((unsigned)cdiv(M, SBM), (unsigned)(N / (nb * 16)));
     const unsigned la = (unsigned)(lda * 4), lb = (unsigned)(ldb * 4), lc = (unsigned)(ldc * 4), lm = (unsigned)(ld_mask * 4);
     switch (nb) {

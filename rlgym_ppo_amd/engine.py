@@ -38,7 +38,10 @@ def stream_ptr():
 
 
 def ptr(t):
-    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+    """Tensor (or None, or a raw address: memory of a host window, ppo/_mlp.py::ActGraph) -> void *."""
+    if t is None:
+        return ctypes.c_void_p(0)
+    return ctypes.c_void_p(t if isinstance(t, int) else t.data_ptr())
 
 
 class Workspace:

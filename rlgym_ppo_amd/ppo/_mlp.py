@@ -68,7 +68,7 @@ class ActGraph:
         # reading pinned host memory itself (GPU-initiated PCIe reads: 11-20 us of the kernel).  RLPPO_ACT_PUSH=0: pinned memory.
         self.window = None
         self.obs_arg, self.q_arg = self.obs_pin.data_ptr(), self.q_pin.data_ptr()   # what _act_launch_raw hands to the kernel
-        self.push = bool(self.poll and raw is not None and os.environ.get("RLPPO_ACT_PUSH", "1") != "0")
+        self.push = bool(self.poll and os.environ.get("RLPPO_ACT_PUSH", "1") != "0")   # (the layer chains of the other heads read the window too)
         if self.push:
             r256 = lambda x: (x + 255) // 256 * 256
             obs_bytes, q_bytes = r256(cap * d * 4), r256(int(self.q_pin.numel()) * 4)
@@ -83,7 +83,7 @@ class ActGraph:
         # draw (5-11 us at 8-80 rows) then costs the call nothing, it hides behind the launch latency and the layers; the kernel
         # looks for control word 2 when its head layer starts.  Up to 256 rows: beyond that the draw outlasts the kernel.
         # RLPPO_ACT_LATE_NOISE=0: noise staged before the launch (round 4).
-        self.late = bool(self.push and cap <= 256 and os.environ.get("RLPPO_ACT_LATE_NOISE", "1") != "0")
+        self.late = bool(self.push and raw is not None and cap <= 256 and os.environ.get("RLPPO_ACT_LATE_NOISE", "1") != "0")
         if self.late:
             self.opts.noise_ctl = self.ctl_arg
             self.late = L.rlppo_discrete_step_one_launch(a.dims_c, a.n_layers, cap, ctypes.byref(self.opts)) == 1
@@ -138,8 +138,8 @@ class ActGraph:
         if self._raw is not None:
             self._raw(self, cap, self.opts)
             return
-        N.check(N.lib().rlppo_pad_rows(stream_ptr(), ptr(self.obs_pin), 0, cap, a.d_in, a.d_in, ptr(self.rows), a.ld_in, 0, 0.0, 1.0))
-        pol._act_launch(self.rows, cap, self.q_pin, self.act_pin, self.logp_pin, self.ws, self.opts)
+        N.check(N.lib().rlppo_pad_rows(stream_ptr(), ptr(self.obs_arg), 0, cap, a.d_in, a.d_in, ptr(self.rows), a.ld_in, 0, 0.0, 1.0))
+        pol._act_launch(self.rows, cap, self.q_arg, self.act_pin, self.logp_pin, self.ws, self.opts)
 
     def run(self, obs, q, n, draw=None, verify=None):
         """obs [n, d] float32 numpy; q: the call's noise (CPU tensor) or None with draw(): called for it -- AFTER the launch when

@@ -776,6 +776,36 @@ def test_act_options_completion_words_and_per_call_precision(L, hidden):
     assert not torch.equal(outs["fp32"], outs["bf16_option"]) and relerr(outs["bf16_option"], outs["fp32"]) < 3e-2
 
 
+@pytest.mark.parametrize("n", [1, 8, 17, 80, 300, 1024])
+def test_gemm_nt_skinny(L, n):
+    """[r5] The forward layers of a small call (up to 1024 rows) run as one wave per 16 x 16 output block with both operands straight
+    from L2 (gemm_nt_skinny_kernel) instead of 128-row tiles that are mostly padding at 8-80 rows: outputs BIT-identical to the
+    large kernel's (rlppo_dbg_set(40, 0)) for every layer shape of the three heads -- first layers padded to 112 / 240, hidden 256 /
+    512, heads of 90 (padded 96), 16 + tanh, 32 -- and against the oracle's float64 forward within fp32 accumulation error."""
+    rs = np.random.RandomState(n)
+    for d, hidden, out, tanh in ((107, (256, 256, 256), 90, 0), (231, (512, 512, 512, 512), 16, 1), (107, (64, 128), 24, 0), (40, (512,), 90, 0)):
+        torch.manual_seed(d + n)
+        net = Net(L, nets.init_mlp(d, hidden, out))
+        obs = np.clip(rs.randn(n, d), -5, 5).astype(np.float32)
+        rows = net.pad(obs)
+        outs = []
+        for skinny in (1, 0):
+            check(L, L.rlppo_dbg_set(40, skinny))
+            try:
+                o = torch.full((n, net.ld_out), float("nan"), device="cuda")
+                w = net.ws(n)
+                check(L, L.rlppo_mlp_forward(stream(), net.dims_c, net.nl, P(net.packed), P(rows), net.ld_in, n, tanh, P(o), net.ld_out, P(w), w.numel(), None))
+                outs.append(o.cpu())
+            finally:
+                check(L, L.rlppo_dbg_set(40, 1))
+        assert torch.equal(outs[0], outs[1]), (n, d, hidden)
+        h = torch.from_numpy(obs).double()
+        for i, (w_, b_) in enumerate(net.params):       # the reference's op sequence (value_estimator.py:30-36) in float64
+            h = torch.nn.functional.linear(h, w_.double(), b_.double())
+            h = torch.relu(h) if i < len(net.params) - 1 else (torch.tanh(h) if tanh else h)
+        assert relerr(outs[0][:, :out].double(), h) < 2e-5
+
+
 @pytest.mark.parametrize("where", ["host_window", "pinned"])
 @pytest.mark.parametrize("hidden", [(256, 256, 256), (128, 128)], ids=["fused256", "fused128"])
 def test_discrete_step_takes_its_noise_while_it_runs(L, hidden, where):
