@@ -362,66 +362,90 @@ __global__ __launch_bounds__(64 * NW, 1) void discrete_act_fused_kernel(FusedAct
             a.noise_ctl[4] = (unsigned)(wall_clock64() - t0);
         }
     }
+    // [r5] the wave's RPWV rows go through the stages TOGETHER (each cross-lane step is a ~100-cycle round trip through the LDS
+    // crossbar: the rows' chains are independent and overlap) -- same operations per row as before, bit for bit; rows past n_live
+    // run on whatever their logits hold and store nothing
+    {
+        float p[RPWV][2], pc[RPWV][2], mx[RPWV], sm[RPWV], best[RPWV], bestp[RPWV];
+        int besti[RPWV];
+        bool live[RPWV];
 #pragma unroll
-    for (int rr = 0; rr < RPWV; ++rr) {
-        const int r = wave * RPWV + rr;
-        const int64_t row = row0 + r;
-        if (row >= n_live) break;
-        const float *z = cur + r * ldz;
-        float p[2], pc[2];
-        float mx = -INFINITY;
+        for (int rr = 0; rr < RPWV; ++rr) {
+            const int r = wave * RPWV + rr;
+            live[rr] = row0 + r < n_live;
+            const float *z = cur + r * ldz;
+            mx[rr] = -INFINITY;
 #pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            const int c = lane + 64 * e;
-            p[e] = c < A ? z[c] : -INFINITY;
-            mx = fmaxf(mx, p[e]);
+            for (int e = 0; e < 2; ++e) {
+                const int c = lane + 64 * e;
+                p[rr][e] = c < A ? z[c] : -INFINITY;
+                mx[rr] = fmaxf(mx[rr], p[rr][e]);
+            }
         }
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
-        float s = 0.f;
+        for (int o = 32; o > 0; o >>= 1)
 #pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            const int c = lane + 64 * e;
-            p[e] = c < A ? expf(p[e] - mx) : 0.f;
-            s += p[e];
+            for (int rr = 0; rr < RPWV; ++rr) mx[rr] = fmaxf(mx[rr], __shfl_xor(mx[rr], o));
+#pragma unroll
+        for (int rr = 0; rr < RPWV; ++rr) {
+            sm[rr] = 0.f;
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int c = lane + 64 * e;
+                p[rr][e] = c < A ? expf(p[rr][e] - mx[rr]) : 0.f;
+                sm[rr] += p[rr][e];
+            }
         }
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        for (int o = 32; o > 0; o >>= 1)
 #pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            p[e] = p[e] / s;
-            pc[e] = fminf(fmaxf(p[e], FA_PROB_MIN), 1.0f);
-        }
-        float best = -INFINITY, bestp = 1.f;
-        int besti = 0x7fffffff;
+            for (int rr = 0; rr < RPWV; ++rr) sm[rr] += __shfl_xor(sm[rr], o);
 #pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            const int c = lane + 64 * e;
-            if (c < A) {
-                const float v = pc[e] / qn[rr][e];  // IEEE fp32 division, as at::div
-                if (v > best) {
-                    best = v;
-                    besti = c;
-                    bestp = pc[e];
+        for (int rr = 0; rr < RPWV; ++rr) {
+            const int64_t row = row0 + wave * RPWV + rr;
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                p[rr][e] = p[rr][e] / sm[rr];
+                pc[rr][e] = fminf(fmaxf(p[rr][e], FA_PROB_MIN), 1.0f);
+            }
+            best[rr] = -INFINITY;
+            bestp[rr] = 1.f;
+            besti[rr] = 0x7fffffff;
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int c = lane + 64 * e;
+                if (c < A) {
+                    const float v = pc[rr][e] / qn[rr][e];  // IEEE fp32 division, as at::div
+                    if (v > best[rr]) {
+                        best[rr] = v;
+                        besti[rr] = c;
+                        bestp[rr] = pc[rr][e];
+                    }
+                    if (a.probs_out && live[rr]) a.probs_out[row * A + c] = pc[rr][e];
                 }
-                if (a.probs_out) a.probs_out[row * A + c] = pc[e];
             }
         }
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const float ov = __shfl_xor(best, o);
-            const int oi = __shfl_xor(besti, o);
-            const float op = __shfl_xor(bestp, o);
-            if (ov > best || (ov == best && oi < besti)) {
-                best = ov;
-                besti = oi;
-                bestp = op;
+        for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+            for (int rr = 0; rr < RPWV; ++rr) {
+                const float ov = __shfl_xor(best[rr], o);
+                const int oi = __shfl_xor(besti[rr], o);
+                const float op = __shfl_xor(bestp[rr], o);
+                if (ov > best[rr] || (ov == best[rr] && oi < besti[rr])) {
+                    best[rr] = ov;
+                    besti[rr] = oi;
+                    bestp[rr] = op;
+                }
             }
-        }
-        if (lane == 0) {
-            a.actions[row] = besti;
-            a.logp[row] = logf(bestp);
-            if (a.actions_f32) a.actions_f32[row] = (float)besti;
+#pragma unroll
+        for (int rr = 0; rr < RPWV; ++rr) {
+            const int64_t row = row0 + wave * RPWV + rr;
+            if (lane == 0 && live[rr]) {
+                a.actions[row] = besti[rr];
+                a.logp[row] = logf(bestp[rr]);
+                if (a.actions_f32) a.actions_f32[row] = (float)besti[rr];
+            }
         }
     }
     // [r5] completion word of this workgroup's 16 rows: every wave releases its stores at system scope, then ONE word follows them
