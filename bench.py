@@ -1168,6 +1168,7 @@ def main():
             gae_us=g["us_per_scan"], gae_frac_hbm_cold=g["roofline"]["frac"], gae_frac_hbm_hot=g["roofline"]["hot_frac"],
             gae_traffic_ratio=round(g["roofline"]["traffic"] / g["roofline"]["algorithmic_bytes"], 3) if g["roofline"]["traffic"] else None,
             rollout_ms_host_noise=ro["ms_per_step_host_noise"], rollout_ms_resident=ro["ms_per_step_resident_noise"],
+            us_get_action_8=ro["us_get_action_8"], us_get_action_80=ro["us_get_action_80"],
             collect_ms=it["collect_ms"], iteration_steps_per_s=it["steps_per_s"],
             cfg5_fp32_samples_per_s=out["cfg5"]["fp32"]["value"], cfg5_bf16_samples_per_s=out["cfg5"]["bf16"]["value"],
             cfg5_bf16_update_frac_of_bf16_peak=out["cfg5"]["bf16"]["update_flop_efficiency"]["frac"],

@@ -296,7 +296,7 @@ class ArenaModule(nn.Module):
             g = self._graphs[_bucket(n)] = ActGraph(self, _bucket(n))
         if o.dtype != np.float32:
             o = o.astype(np.float32)
-        if g.late:
+        if g.poll and a._packed_key is not None:
             # launch on the packed copy as it is and check that it was current WHILE the GPU works (8 Parameters' versions and
             # addresses: 5 us of the call's critical path otherwise); a stale one -- rare: a stock optimiser stepped, the module
             # moved -- costs a second launch
