@@ -851,6 +851,67 @@ def iteration_leg(iters=3):
                 iteration_ms=round(c + a + l, 2), steps_per_s=round(N_SAMPLES / (c + a + l) * 1e3))
 
 
+def process_collect_leg(n_proc=8, timesteps=50_000, limit_s=120):
+    """Collection as the reference's defaults run it (rlgym_ppo/learner.py:34-53: n_proc 8, min_inference_size 80 -> 0.9 n_proc;
+    batched_agent_manager.py:180-221): 8 env WORKER PROCESSES (a 1v1 match each: two agents, 107-float observations, 90 actions;
+    tools/bench_process_env.py, pre-drawn observations) speak the reference's wire format to BatchedAgentManager, which calls
+    policy.get_action on whatever the ready workers handed in -- the 8-80-observation call of DESIGN 5f-5g -- until 50,000 timesteps are
+    in.  One warm collection, one timed.  Bounded by an alarm: a collector whose workers died would wait on its socket for ever."""
+    import contextlib
+    import signal
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools"))
+    import bench_process_env
+    from rlgym_ppo_amd import Learner
+
+    def on_alarm(signum, frame):
+        raise TimeoutError("process_collect: no result within %d s" % limit_s)
+
+    old = signal.signal(signal.SIGALRM, on_alarm)
+    signal.alarm(limit_s)
+    learner = None
+    try:
+        with contextlib.redirect_stdout(sys.stderr):
+            learner = Learner(bench_process_env.make_env, n_proc=n_proc, min_inference_size=80, timestep_limit=10**9, exp_buffer_size=150_000,
+                              ts_per_iteration=timesteps, ppo_epochs=1, ppo_batch_size=50_000, ppo_minibatch_size=50_000,
+                              policy_layer_sizes=HID, critic_layer_sizes=HID, checkpoints_save_folder=None, checkpoint_load_folder=None,
+                              save_every_ts=10**12, log_to_wandb=False, random_seed=123)
+        pol = learner.ppo_learner.policy
+        calls = []
+        inner = pol.get_action
+
+        def counted(obs, *a, **k):
+            t = time.perf_counter()
+            out = inner(obs, *a, **k)
+            calls.append((len(obs), time.perf_counter() - t))
+            return out
+
+        learner.agent.collect_timesteps(4_000)
+        pol.get_action = counted
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        _, _, n, _ = learner.agent.collect_timesteps(timesteps)
+        dt = time.perf_counter() - t0
+        rows = np.array([c[0] for c in calls])
+        secs = np.array([c[1] for c in calls])
+        log("process_collect: %d worker processes, %d timesteps in %.3f s; %d get_action calls of %.1f observations on average, %.1f us each "
+            "(median), %.1f %% of the collection's wall clock inside get_action" % (n_proc, n, dt, len(calls), rows.mean(), 1e6 * np.median(secs),
+                                                                                   100 * secs.sum() / dt))
+        return dict(workload="reference defaults: %d env worker processes x 2 agents (obs 107, 90 actions, 256x3 policy) through BatchedAgentManager "
+                             "and its wire format, %d timesteps" % (n_proc, timesteps),
+                    n_proc=n_proc, timesteps=int(n), seconds=round(dt, 3), steps_per_s=round(n / dt), get_action_calls=len(calls),
+                    mean_obs_per_call=round(float(rows.mean()), 1), us_per_get_action_median=round(1e6 * float(np.median(secs)), 1),
+                    frac_of_wall_in_get_action=round(float(secs.sum() / dt), 3))
+    except Exception as e:  # noqa: BLE001 -- a leg that fails must not take the line with it
+        log("process_collect failed: %r" % (e,))
+        return dict(error=repr(e))
+    finally:
+        signal.alarm(0)
+        signal.signal(signal.SIGALRM, old)
+        if learner is not None:
+            with contextlib.suppress(Exception):
+                learner.agent.cleanup()
+
+
 # ---------------------------------------------------------------------------------------------------- main
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
@@ -1157,6 +1218,8 @@ def main():
         del learner, buf  # the other legs build their own workloads
         torch.cuda.empty_cache()
         out["iteration"] = iteration_leg()
+        out["process_collect"] = process_collect_leg(8)                 # learner.py:34-53's default
+        out["process_collect"]["n_proc_32"] = process_collect_leg(32)    # example.py:74-88
         out["cfg5"] = cfg5_leg(device)
         out["cpu_baseline"] = cpu_baseline()
         out["ref_defaults"] = ref_defaults_leg(device)
@@ -1170,6 +1233,7 @@ def main():
             rollout_ms_host_noise=ro["ms_per_step_host_noise"], rollout_ms_resident=ro["ms_per_step_resident_noise"],
             us_get_action_8=ro["us_get_action_8"], us_get_action_80=ro["us_get_action_80"],
             collect_ms=it["collect_ms"], iteration_steps_per_s=it["steps_per_s"],
+            process_collect_steps_per_s=out["process_collect"].get("steps_per_s"),
             cfg5_fp32_samples_per_s=out["cfg5"]["fp32"]["value"], cfg5_bf16_samples_per_s=out["cfg5"]["bf16"]["value"],
             cfg5_bf16_update_frac_of_bf16_peak=out["cfg5"]["bf16"]["update_flop_efficiency"]["frac"],
             cpu_port_samples_per_s=out["cpu_baseline"]["value"], update_x3_optin_samples_per_s=out["update_x3"]["value"],
