@@ -1218,11 +1218,12 @@ def main():
         del learner, buf  # the other legs build their own workloads
         torch.cuda.empty_cache()
         out["iteration"] = iteration_leg()
-        out["process_collect"] = process_collect_leg(8)                 # learner.py:34-53's default
-        out["process_collect"]["n_proc_32"] = process_collect_leg(32)    # example.py:74-88
         out["cfg5"] = cfg5_leg(device)
         out["cpu_baseline"] = cpu_baseline()
         out["ref_defaults"] = ref_defaults_leg(device)
+        # (last: 8 + 32 worker processes come and go here -- nothing that is timed runs beside their start-up or their exit)
+        out["process_collect"] = process_collect_leg(8)                 # learner.py:34-53's default
+        out["process_collect"]["n_proc_32"] = process_collect_leg(32)    # example.py:74-88
         # The scalars a reader wants first, once more at the END of the line (a truncated record keeps its tail)
         g, ro, it = out["gae"], out["rollout"], out["iteration"]
         out["summary"] = dict(
