@@ -16,14 +16,16 @@ class BatchedTrajectory(object):
 
     def update(self):
         """Bank the pending timestep if all seven fields are present; True when that timestep ended the episode."""
-        if any(getattr(self, f) is None for f in _FIELDS):
+        # (written out field by field: this runs once per environment step of every worker)
+        if (self.state is None or self.action is None or self.log_prob is None or self.reward is None or self.next_state is None
+                or self.done is None or self.truncated is None):
             return False
         if not isinstance(self.reward, (list, tuple, np.ndarray)):
             self.reward = [self.reward]
-        self.complete_timesteps.append(tuple(getattr(self, f) for f in _FIELDS))
+        self.complete_timesteps.append((self.state, self.action, self.log_prob, self.reward, self.next_state, self.done, self.truncated))
         ended = bool(self.done)
-        for f in _FIELDS[:-1]:  # `truncated` keeps its last value, like the reference
-            setattr(self, f, None)
+        # `truncated` keeps its last value, like the reference
+        self.state = self.action = self.log_prob = self.reward = self.next_state = self.done = None
         return ended
 
     def get_all(self):
