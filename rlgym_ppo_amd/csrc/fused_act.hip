@@ -131,8 +131,11 @@ __global__ __launch_bounds__(64 * NW, 1) void discrete_act_fused_kernel(FusedAct
 #pragma unroll
     for (int s = 0; s < FA_STAGES - 1; ++s) issue_next();
 
-    for (int l = 0; l <= last; ++l)
-        for (int c = tid; c < a.nblk[l] * 16; c += NT) biasl[l * H + c] = a.packed[a.off_b[l] + c];
+    // the biases: one element per thread and layer (16 nblk <= H <= NT), all layers' requests in flight together -- and together
+    // with the observation requests below ([r5]: a request + LDS store per layer was four round trips one after the other)
+    float bias_v[FA_MAX_LAYERS];
+#pragma unroll
+    for (int l = 0; l < FA_MAX_LAYERS; ++l) bias_v[l] = l <= last && tid < a.nblk[l] * 16 ? a.packed[a.off_b[l] + tid] : 0.f;
     // ---- the Exp(1) noise of this wave's rows: requested now, used after the last layer
     // [r5] with noise_ctl the host writes the noise AFTER it has launched (the draw hides behind the launch latency and the layers)
     // and then control word 2.  The waves that have no block of the head layer look at that word when the head layer starts and
@@ -201,6 +204,9 @@ __global__ __launch_bounds__(64 * NW, 1) void discrete_act_fused_kernel(FusedAct
             if (a.rows_out && row < a.n) a.rows_out[row * a.ld_rows_out + c] = x;
         }
     }
+#pragma unroll
+    for (int l = 0; l < FA_MAX_LAYERS; ++l)
+        if (l <= last && tid < a.nblk[l] * 16) biasl[l * H + tid] = bias_v[l];
     __syncthreads();  // (drains the stream's first tiles too: once per launch)
     FA_TS(1);
 
