@@ -65,6 +65,22 @@ struct FusedActArgs {
 constexpr long long FA_NOISE_WAIT_TICKS = 2000000LL;
 constexpr unsigned FA_DONE_FAILED = 0x80000000u;         // or-ed into the completion word by a workgroup that gave up
 
+// [r5] Lane exchange of the sampling stage's butterflies (offsets 32, 16, 8, 4, 2, 1 in that order).  Offsets 32 and 16 cross the
+// 16-lane rows: ds_bpermute (a ~100-cycle trip through the LDS crossbar).  From offset 8 down the partner sits in the lane's own row
+// and a DPP move delivers it: row_ror:8 IS lane ^ 8; row_ror:4 delivers lane ^ 4 or (lane ^ 4) ^ 8 -- the same value, because the
+// offset-8 step has just made lanes l and l ^ 8 equal (sum, max and the arg-max triple are all computed identically by both
+// partners of a step); quad_perm delivers lane ^ 2 and lane ^ 1 exactly.  Same values as __shfl_xor, so the same bits out.
+template <int O>
+__device__ __forceinline__ int fa_xor_i(int v) {
+    if (O >= 16) return __shfl_xor(v, O);
+    if (O == 8) return __builtin_amdgcn_update_dpp(v, v, 0x128, 0xF, 0xF, false);  // row_ror:8
+    if (O == 4) return __builtin_amdgcn_update_dpp(v, v, 0x124, 0xF, 0xF, false);  // row_ror:4
+    if (O == 2) return __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xF, 0xF, false);   // quad_perm:[2,3,0,1]
+    return __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xF, 0xF, false);               // quad_perm:[1,0,3,2]
+}
+template <int O>
+__device__ __forceinline__ float fa_xor_f(float v) { return __int_as_float(fa_xor_i<O>(__float_as_int(v))); }
+
 // NW waves; JH: output blocks a wave owns in a hidden layer (H = 16 JH NW); the head's blocks are dealt ceil(nblk / NW) per wave.
 // H = 256 runs 8 waves x 2 blocks: with one wave per SIMD (4 x 4) a K-step was LDS-DMA issue (4 pieces, ~100 cycles each) + fragment
 // reads + 16 MFMAs one after the other, ~1350 cycles for 512 cycles of MFMA (36 us per 4096-row step); two waves per SIMD take
@@ -388,10 +404,10 @@ __global__ __launch_bounds__(64 * NW, 1) void discrete_act_fused_kernel(FusedAct
                 mx[rr] = fmaxf(mx[rr], p[rr][e]);
             }
         }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1)
-#pragma unroll
-            for (int rr = 0; rr < RPWV; ++rr) mx[rr] = fmaxf(mx[rr], __shfl_xor(mx[rr], o));
+#define FA_BFLY(STEP) STEP(32) STEP(16) STEP(8) STEP(4) STEP(2) STEP(1)
+#define FA_MAX_STEP(O)                                                                  \
+    _Pragma("unroll") for (int rr = 0; rr < RPWV; ++rr) mx[rr] = fmaxf(mx[rr], fa_xor_f<O>(mx[rr]));
+        FA_BFLY(FA_MAX_STEP)
 #pragma unroll
         for (int rr = 0; rr < RPWV; ++rr) {
             sm[rr] = 0.f;
@@ -402,10 +418,9 @@ __global__ __launch_bounds__(64 * NW, 1) void discrete_act_fused_kernel(FusedAct
                 sm[rr] += p[rr][e];
             }
         }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1)
-#pragma unroll
-            for (int rr = 0; rr < RPWV; ++rr) sm[rr] += __shfl_xor(sm[rr], o);
+#define FA_SUM_STEP(O)                                                                  \
+    _Pragma("unroll") for (int rr = 0; rr < RPWV; ++rr) sm[rr] += fa_xor_f<O>(sm[rr]);
+        FA_BFLY(FA_SUM_STEP)
 #pragma unroll
         for (int rr = 0; rr < RPWV; ++rr) {
             const int64_t row = row0 + wave * RPWV + rr;
@@ -431,19 +446,22 @@ __global__ __launch_bounds__(64 * NW, 1) void discrete_act_fused_kernel(FusedAct
                 }
             }
         }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1)
-#pragma unroll
-            for (int rr = 0; rr < RPWV; ++rr) {
-                const float ov = __shfl_xor(best[rr], o);
-                const int oi = __shfl_xor(besti[rr], o);
-                const float op = __shfl_xor(bestp[rr], o);
-                if (ov > best[rr] || (ov == best[rr] && oi < besti[rr])) {
-                    best[rr] = ov;
-                    besti[rr] = oi;
-                    bestp[rr] = op;
-                }
-            }
+#define FA_ARG_STEP(O)                                                                  \
+    _Pragma("unroll") for (int rr = 0; rr < RPWV; ++rr) {                               \
+        const float ov = fa_xor_f<O>(best[rr]);                                         \
+        const int oi = fa_xor_i<O>(besti[rr]);                                          \
+        const float op = fa_xor_f<O>(bestp[rr]);                                        \
+        if (ov > best[rr] || (ov == best[rr] && oi < besti[rr])) {                      \
+            best[rr] = ov;                                                              \
+            besti[rr] = oi;                                                             \
+            bestp[rr] = op;                                                             \
+        }                                                                               \
+    }
+        FA_BFLY(FA_ARG_STEP)
+#undef FA_ARG_STEP
+#undef FA_SUM_STEP
+#undef FA_MAX_STEP
+#undef FA_BFLY
 #pragma unroll
         for (int rr = 0; rr < RPWV; ++rr) {
             const int64_t row = row0 + wave * RPWV + rr;
