@@ -855,6 +855,51 @@ def test_get_action_draws_its_noise_behind_the_launch(monkeypatch):
     assert g.stale_relaunches == before + 1 and torch.equal(a_new2[1], a_ref[1])
 
 
+@pytest.mark.parametrize("head", ["discrete", "gaussian", "multidiscrete"])
+def test_small_call_switches_all_give_the_same_bits(monkeypatch, head):
+    """The documented switches of the small get_action call (README): RLPPO_ACT_POLL=0 (synchronise instead of polling completion
+    words), RLPPO_ACT_EAGER=1 (plain launches instead of the graph replay), RLPPO_ACT_PUSH=0 (pinned transport), RLPPO_ACT_LATE_NOISE=0
+    (noise before the launch), RLPPO_ACT_GRAPH=0 (the general path) and RLPPO_TUNE="40=0" (128-row tiles in the layer chain): same
+    actions, log-probabilities and generator state as the default, for every head, at 1 / 8 / 80 / 200 observations."""
+    from rlgym_ppo_amd import _native as N
+    from rlgym_ppo_amd.ppo import ContinuousPolicy, DiscreteFF, MultiDiscreteFF
+    torch.manual_seed(17)
+    if head == "discrete":
+        pol, d = DiscreteFF(107, 90, (256, 256, 256), "cuda:0"), 107
+    elif head == "gaussian":
+        pol, d = ContinuousPolicy(61, 16, (512, 512), "cuda:0"), 61
+    else:
+        pol, d = MultiDiscreteFF(107, (256, 256), "cuda:0"), 107
+    rs = np.random.RandomState(6)
+    calls = [np.clip(rs.randn(n, d), -5, 5).astype(np.float32) for n in (1, 8, 80, 200, 8)]
+
+    def run(env, tune=None):
+        for k in ("RLPPO_ACT_POLL", "RLPPO_ACT_EAGER", "RLPPO_ACT_PUSH", "RLPPO_ACT_LATE_NOISE"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        pol._graphs.clear()
+        pol.act_graphs = env.get("RLPPO_ACT_GRAPH", "1") != "0"
+        if tune:
+            N.check(N.lib().rlppo_dbg_set(*tune[0]))
+        try:
+            torch.manual_seed(4321)
+            out = [pol.get_action(o) for o in calls]
+            return out, torch.get_rng_state()
+        finally:
+            if tune:
+                N.check(N.lib().rlppo_dbg_set(*tune[1]))
+            pol.act_graphs = True
+
+    ref, ref_state = run({})
+    for env, tune in (({"RLPPO_ACT_POLL": "0"}, None), ({"RLPPO_ACT_EAGER": "1"}, None), ({"RLPPO_ACT_PUSH": "0"}, None),
+                      ({"RLPPO_ACT_LATE_NOISE": "0"}, None), ({"RLPPO_ACT_GRAPH": "0"}, None), ({}, ((40, 0), (40, 1)))):
+        out, state = run(env, tune)
+        for (a1, l1), (a0, l0) in zip(out, ref):
+            assert torch.equal(torch.as_tensor(a1), torch.as_tensor(a0)) and torch.equal(torch.as_tensor(l1), torch.as_tensor(l0)), (head, env, tune)
+        assert torch.equal(state, ref_state), (head, env)
+
+
 @pytest.mark.parametrize("n_agents,steps", [(64, 128), (768, 24)], ids=["on_the_spot", "look_ahead"])
 def test_seeded_rollout_draws_the_reference_noise_stream(n_agents, steps):
     """Rollout steps from one seed: DiscreteFF.get_action's default noise (librlppo's host implementation of torch's CPU
