@@ -153,15 +153,16 @@ class ActGraph:
                 obs = np.ascontiguousarray(obs)
             if self.late:
                 self.noise_seq = self.noise_seq % 0x7FFFFFFF + 1
-                self._stage(self.ctl_arg, self.noise_seq, n, self.obs_arg, obs.ctypes.data, obs.nbytes)
+                rc = self._stage(self.ctl_arg, self.noise_seq, n, self.obs_arg, obs.ctypes.data, obs.nbytes)
             else:
                 if q is None:
                     q = draw()
                 q = q if q.is_contiguous() else q.contiguous()
                 if q.numel() != m or q.dtype != torch.float32:
                     raise ValueError("noise: expected %d float32 numbers" % m)
-                self._push(self.q_arg, q.data_ptr(), 4 * m, None, 0)
-                self._stage(None, 0, 0, self.obs_arg, obs.ctypes.data, obs.nbytes)
+                rc = self._push(self.q_arg, q.data_ptr(), 4 * m, None, 0) or self._stage(None, 0, 0, self.obs_arg, obs.ctypes.data, obs.nbytes)
+            if rc:
+                N.check(rc)
         else:
             self.obs_np[:n] = obs
             if q is None:
@@ -177,7 +178,7 @@ class ActGraph:
                 q = q if q.is_contiguous() else q.contiguous()
                 if q.numel() != m or q.dtype != torch.float32:
                     raise ValueError("noise: expected %d float32 numbers" % m)
-                self._push(self.q_arg, q.data_ptr(), 4 * m, self.ctl_arg + 8, self.noise_seq)
+                N.check(self._push(self.q_arg, q.data_ptr(), 4 * m, self.ctl_arg + 8, self.noise_seq))
             except BaseException:
                 self._push(None, None, 0, self.ctl_arg + 8, self.noise_seq)
                 self._wait(self._done_ptr, count, value, 100000)
