@@ -1,6 +1,8 @@
+"""Does learn() time depend on how long the GPU was busy before the timed region (clock ramp)?  The 10-epoch learn() of bench.py's workload at the
+one-rank and the 8-rank-share size after 0 / 0.3 / 1 s of the same work and after 2 s of idling.  usage: python tools/clock_ramp_learn.py"""
 import contextlib, os, sys, time
 import numpy as np, torch
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 import rlgym_ppo_amd.ppo.ppo_learner as PL
 with contextlib.redirect_stdout(sys.stderr):

@@ -1,3 +1,6 @@
+"""Round-2 issue-stall probe: a synthetic MFMA + LDS-read loop of the diagnostic library (csrc/diag, rlppo_dbg_probe2) timed by mode / threads /
+blocks -- what a K step of the fp32 NT kernel costs when nothing but issue limits it.  usage: python tools/probe2.py (needs the diag library:
+make -C rlgym_ppo_amd/csrc diag)"""
 import ctypes, os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -1,3 +1,5 @@
+"""Round-2 clock stamps inside the fp32 NT kernel (diagnostic library, rlppo_dbg_gemm_nt_stamped): where a workgroup's time goes between its
+first DMA issue and its last store.  usage: python tools/stamps_nt.py (needs the diag library: make -C rlgym_ppo_amd/csrc diag)"""
 import ctypes, os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
