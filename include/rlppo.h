@@ -129,10 +129,22 @@ int rlppo_host_wait_words(const uint32_t *words, int64_t count, uint32_t value, 
  * nothing that follows (the doorbell of a launch, the flag) can overtake the bytes. */
 int rlppo_host_window_alloc(size_t bytes, void **ptr);
 int rlppo_host_window_free(void *ptr);
+/* HOST: flushes the host data path of the window's device (a store to the HDP flush register HIP maps into the process): every
+ * host write that has left the CPU is in device memory on return.  ~1-2.5 us.  Ordering without it: host writes reach the device in
+ * program order (posted PCIe writes behind a store fence), so a flag word written after the bytes it announces arrives after them
+ * (the late noise), and a launch's doorbell arrives after the bytes staged before it, with the packet fetch and the dispatch (>= 3 us)
+ * between the doorbell and the kernel's first read.  ActGraph issues the flush between staging and launch (by the book: 0.9 us of a
+ * 39 us call); behind the launch it is free. */
+int rlppo_host_window_flush(const void *window);
 int rlppo_host_push(void *dst, const void *src, size_t bytes, uint32_t *flag, uint32_t value);
 /* HOST: what precedes the launch of a small rollout call, in one call: ctl[0] = sequence, ctl[1] = live_rows (ctl may be NULL),
  * memcpy(obs_dst, obs_src, obs_bytes), one store fence. */
 int rlppo_host_stage_call(uint32_t *ctl, uint32_t sequence, uint32_t live_rows, void *obs_dst, const void *obs_src, size_t obs_bytes);
+/* ... with the observations as ROWS of a padded image: row r (row_bytes, src_stride apart) goes to dst + r * dst_stride.  A host window
+ * that only ever receives the first row_bytes of its rows stays zero beyond them: it IS the zero-padded input the forward entry points
+ * read (ld = dst_stride / 4), and the layer chain of a small call needs no rlppo_pad_rows launch. */
+int rlppo_host_stage_rows(uint32_t *ctl, uint32_t sequence, uint32_t live_rows, void *dst, size_t dst_stride, const void *src,
+                          size_t src_stride, size_t row_bytes, int64_t rows);
 
 /* Bytes of workspace needed by the forward entry points for `n` rows. */
 size_t rlppo_forward_workspace_bytes(const int32_t *dims, int32_t n_layers, int64_t n);

@@ -103,8 +103,10 @@ SIGNATURES = {
     "rlppo_discrete_step_one_launch": (c_int32, [_P32, c_int32, c_int64, _PACT]),
     "rlppo_host_window_alloc": (c_int32, [c_size_t, POINTER(c_void_p)]),
     "rlppo_host_window_free": (c_int32, [c_void_p]),
+    "rlppo_host_window_flush": (c_int32, [c_void_p]),
     "rlppo_host_push": (c_int32, [c_void_p, c_void_p, c_size_t, c_void_p, c_uint32]),
     "rlppo_host_stage_call": (c_int32, [c_void_p, c_uint32, c_uint32, c_void_p, c_void_p, c_size_t]),
+    "rlppo_host_stage_rows": (c_int32, [c_void_p, c_uint32, c_uint32, c_void_p, c_size_t, c_void_p, c_size_t, c_size_t, c_int64]),
     "rlppo_selection_epoch_ptr": (c_void_p, []),
     "rlppo_gae_workspace_bytes": (c_size_t, [c_int64]),
     "rlppo_gae": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_double, c_double, c_float,

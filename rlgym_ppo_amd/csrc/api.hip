@@ -421,10 +421,17 @@ int rlppo_host_window_alloc(size_t bytes, void **ptr) {
     RLPPO_HIP(hipExtMallocWithFlags(ptr, bytes, hipDeviceMallocFinegrained));
     RLPPO_HIP(hipMemset(*ptr, 0, bytes));
     RLPPO_HIP(hipDeviceSynchronize());
+    // the register whose store flushes the device's host data path: rlppo_host_push / _stage_* store to it behind their bytes
+    hipDeviceProp_t prop;
+    RLPPO_HIP(hipGetDeviceProperties(&prop, dev));
+    host_window_register(*ptr, bytes, prop.hdpMemFlushCntl);
     return 0;
 }
 int rlppo_host_window_free(void *ptr) {
-    if (ptr) RLPPO_HIP(hipFree(ptr));
+    if (ptr) {
+        host_window_unregister(ptr);
+        RLPPO_HIP(hipFree(ptr));
+    }
     return 0;
 }
 
@@ -547,8 +554,8 @@ int rlppo_gaussian_act(void *stream, const int32_t *dims, int32_t n_layers, cons
     int64_t ldo;
     rc = forward_pingpong((hipStream_t)stream, net, packed, obs, ld_obs, n, 1, workspace, ws_bytes, nullptr, &o, &ldo, cx.bf16);
     if (rc) return rc;
-    rc = launch_gaussian_sample((hipStream_t)stream, o, ldo, n, dims[n_layers] / 2, noise_eps, var_m, var_b, actions, logp);
-    return rc ? rc : act_done((hipStream_t)stream, cx, n);
+    // (the completion words ride in the sampling kernel: a block of it holds 256 whole rows)
+    return launch_gaussian_sample((hipStream_t)stream, o, ldo, n, dims[n_layers] / 2, noise_eps, var_m, var_b, actions, logp, cx.done, cx.done_value);
 }
 
 int rlppo_multidiscrete_act(void *stream, const int32_t *dims, int32_t n_layers, const float *packed, const float *obs,
@@ -567,8 +574,7 @@ int rlppo_multidiscrete_act(void *stream, const int32_t *dims, int32_t n_layers,
     int64_t ldo;
     rc = forward_pingpong((hipStream_t)stream, net, packed, obs, ld_obs, n, 0, workspace, ws_bytes, nullptr, &o, &ldo, cx.bf16);
     if (rc) return rc;
-    rc = launch_multidiscrete_sample((hipStream_t)stream, o, ldo, n, noise_q, actions, logp);
-    return rc ? rc : act_done((hipStream_t)stream, cx, n);
+    return launch_multidiscrete_sample((hipStream_t)stream, o, ldo, n, noise_q, actions, logp, cx.done, cx.done_value);
 }
 
 int64_t rlppo_act_done_words(int64_t n) { return n > 0 ? cdiv(n, 16) : 0; }

@@ -214,8 +214,10 @@ int launch_discrete_sample_logits(hipStream_t, const float *, int64_t, int64_t, 
 int launch_discrete_probs(hipStream_t st, const float *logits, int64_t ld, int64_t n, int A, int clamp, float *probs,
                           int64_t ld_p, int64_t *flat_argmax);
 int launch_categorical_select(hipStream_t, const float *, int64_t, int64_t, int, const float *, int64_t *, float *);
-int launch_gaussian_sample(hipStream_t, const float *, int64_t, int64_t, int, const float *, float, float, float *, float *);
-int launch_multidiscrete_sample(hipStream_t, const float *, int64_t, int64_t, const float *, int64_t *, float *);
+int launch_gaussian_sample(hipStream_t, const float *, int64_t, int64_t, int, const float *, float, float, float *, float *,
+                           unsigned *done_words = nullptr, unsigned done_value = 0);
+int launch_multidiscrete_sample(hipStream_t, const float *, int64_t, int64_t, const float *, int64_t *, float *,
+                                unsigned *done_words = nullptr, unsigned done_value = 0);
 int launch_value_loss(hipStream_t st, float *vout, int64_t ldv, const int64_t *idx, const float *targets, int64_t mb,
                       const LossCfg &cfg, double *stats);
 int launch_discrete_loss(hipStream_t, float *, int64_t, int, float *, int64_t, const int64_t *, const float *, const float *,
@@ -245,6 +247,10 @@ struct FusedActIO {
     unsigned *noise_ctl = nullptr;  // [r5] optional control words of noise the host writes after the launch (rlppo_act_opts)
 };
 bool fused_act_ok(const NetLayout &net);
+}  // namespace rlppo
+void host_window_register(void *base, size_t bytes, unsigned *hdp_flush);  // host_rng.cpp: the windows of rlppo_host_window_alloc
+void host_window_unregister(void *base);
+namespace rlppo {
 int launch_discrete_act_fused(hipStream_t st, const NetLayout &net, const float *packed, const FusedActIO &io, int64_t n);
 
 // gae.hip ---------------------------------------------------------------------------------------------

@@ -490,30 +490,44 @@ __device__ __forceinline__ float gauss_logpdf(float x, float mean, float sd) {
     return t1 + t2 + t3 + t4;
 }
 
+// [r5] completion words of a sampling kernel that gives a block 256 whole rows = the 16 words 16 b .. 16 b + 15 (rlppo_act_opts.done_words):
+// every thread releases its stores at system scope, a barrier, sixteen stores -- the words ride in the call's last kernel instead of
+// a launch of their own behind it (one graph node fewer of the small call's eight)
+__device__ __forceinline__ void block_done_words(unsigned *done_words, unsigned done_value, int64_t n) {
+    if (!done_words) return;  // (uniform)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+    __syncthreads();
+    const int64_t w = (int64_t)blockIdx.x * 16 + threadIdx.x;
+    if (threadIdx.x < 16 && w < (n + 15) / 16) __hip_atomic_store(done_words + w, done_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // y[row][0:2k] holds tanh outputs.  action = clamp(mean + sd*eps, -1, 1); logp = sum logpdf(action)
 __global__ __launch_bounds__(256) void gaussian_sample_kernel(const float *__restrict__ y, int64_t ld, int64_t n, int k,
                                                                const float *__restrict__ eps, float var_m, float var_b,
-                                                               float *__restrict__ actions, float *__restrict__ logp) {
+                                                               float *__restrict__ actions, float *__restrict__ logp,
+                                                               unsigned *done_words, unsigned done_value) {
     const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (row >= n) return;
-    const float *yr = y + row * ld;
-    float lp = 0.f;
-    for (int j = 0; j < k; ++j) {
-        const float mean = yr[j];
-        const float sd = yr[k + j] * var_m + var_b;
-        float a = eps[row * k + j] * sd + mean;  // at::normal: output.mul_(std).add_(mean)
-        a = fminf(fmaxf(a, -1.f), 1.f);
-        actions[row * k + j] = a;
-        lp += gauss_logpdf(a, mean, sd);
+    if (row < n) {
+        const float *yr = y + row * ld;
+        float lp = 0.f;
+        for (int j = 0; j < k; ++j) {
+            const float mean = yr[j];
+            const float sd = yr[k + j] * var_m + var_b;
+            float a = eps[row * k + j] * sd + mean;  // at::normal: output.mul_(std).add_(mean)
+            a = fminf(fmaxf(a, -1.f), 1.f);
+            actions[row * k + j] = a;
+            lp += gauss_logpdf(a, mean, sd);
+        }
+        logp[row] = lp;
     }
-    logp[row] = lp;
+    block_done_words(done_words, done_value, n);
 }
 
 int launch_gaussian_sample(hipStream_t st, const float *y, int64_t ld, int64_t n, int k, const float *eps, float var_m,
-                           float var_b, float *actions, float *logp) {
+                           float var_b, float *actions, float *logp, unsigned *done_words, unsigned done_value) {
     if (n <= 0) return 0;
     hipLaunchKernelGGL(gaussian_sample_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st, y, ld, n, k, eps, var_m,
-                       var_b, actions, logp);
+                       var_b, actions, logp, done_words, done_value);
     RLPPO_LAUNCH_CHECK();
     return 0;
 }
@@ -590,9 +604,12 @@ __device__ __forceinline__ int md_bins(int h) { return h < 5 ? 3 : 2; }
 __global__ __launch_bounds__(256) void multidiscrete_sample_kernel(const float *__restrict__ logits, int64_t ld,
                                                                     int64_t n, const float *__restrict__ noise,
                                                                     int64_t *__restrict__ actions,
-                                                                    float *__restrict__ logp) {
+                                                                    float *__restrict__ logp, unsigned *done_words,
+                                                                    unsigned done_value) {
     const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (row >= n) return;
+    // (one barrier site for the whole block: a wave whose lanes split at `row < n` would otherwise arrive at the barrier of
+    // block_done_words twice -- and release it before its live lanes have stored)
+    if (row < n) {
     const float *z = logits + row * ld;
     float lp = 0.f;
 #pragma unroll
@@ -619,13 +636,15 @@ __global__ __launch_bounds__(256) void multidiscrete_sample_kernel(const float *
         lp += z[s + bi] - lse;
     }
     logp[row] = lp;
+    }
+    block_done_words(done_words, done_value, n);
 }
 
 int launch_multidiscrete_sample(hipStream_t st, const float *logits, int64_t ld, int64_t n, const float *noise,
-                                int64_t *actions, float *logp) {
+                                int64_t *actions, float *logp, unsigned *done_words, unsigned done_value) {
     if (n <= 0) return 0;
     hipLaunchKernelGGL(multidiscrete_sample_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st, logits, ld, n, noise,
-                       actions, logp);
+                       actions, logp, done_words, done_value);
     RLPPO_LAUNCH_CHECK();
     return 0;
 }

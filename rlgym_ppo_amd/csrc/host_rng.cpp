@@ -696,14 +696,64 @@ extern "C" int rlppo_exponential_from_words(const uint32_t *words, int64_t n, do
 // `count` words all hold `value`, or `timeout_us` has passed (returns 1: the caller synchronises the stream instead).  The words live
 // in pinned host memory the kernel stores into with release semantics at system scope; the acquire loads here order the reads of
 // the results behind them.
+// [r5] The windows rlppo_host_window_alloc has handed out, with the HDP flush register of their device.  A host write through the PCIe
+// aperture passes through the GPU's host data path on its way to memory; a store of 1 to HDP_MEM_COHERENCY_FLUSH_CNTL -- which HIP maps
+// into the process (hipDeviceProp_t::hdpMemFlushCntl) -- waits until everything in it has landed (rlppo_host_window_flush).
+namespace {
+struct HostWindow {
+    uintptr_t base, end;
+    volatile uint32_t *hdp_flush;
+};
+constexpr int MAX_WINDOWS = 256;
+HostWindow g_windows[MAX_WINDOWS];
+std::atomic<int> g_n_windows{0};
+std::mutex g_windows_mutex;
+
+inline void hdp_flush_for(const void *p) {
+    const uintptr_t a = reinterpret_cast<uintptr_t>(p);
+    const int n = g_n_windows.load(std::memory_order_acquire);
+    for (int i = 0; i < n; ++i)
+        if (a >= g_windows[i].base && a < g_windows[i].end) {
+            if (g_windows[i].hdp_flush) {
+                *g_windows[i].hdp_flush = 1u;
+                _mm_sfence();
+            }
+            return;
+        }
+}
+}  // namespace
+void host_window_register(void *base, size_t bytes, unsigned *hdp_flush) {
+    std::lock_guard<std::mutex> lock(g_windows_mutex);
+    const int n = g_n_windows.load(std::memory_order_relaxed);
+    for (int i = 0; i < n; ++i)
+        if (g_windows[i].base == 0) {  // a freed slot
+            g_windows[i].end = reinterpret_cast<uintptr_t>(base) + bytes;
+            g_windows[i].hdp_flush = hdp_flush;
+            g_windows[i].base = reinterpret_cast<uintptr_t>(base);
+            return;
+        }
+    if (n < MAX_WINDOWS) {
+        g_windows[n] = HostWindow{reinterpret_cast<uintptr_t>(base), reinterpret_cast<uintptr_t>(base) + bytes, hdp_flush};
+        g_n_windows.store(n + 1, std::memory_order_release);
+    }
+}
+void host_window_unregister(void *base) {
+    std::lock_guard<std::mutex> lock(g_windows_mutex);
+    const int n = g_n_windows.load(std::memory_order_relaxed);
+    for (int i = 0; i < n; ++i)
+        if (g_windows[i].base == reinterpret_cast<uintptr_t>(base)) g_windows[i].base = g_windows[i].end = 0;
+}
+
 // [r5] Host writes into DEVICE memory (rlppo_host_window_alloc: fine-grained VRAM behind the PCIe aperture, write-combined on the host
 // side): a posted write costs the host 1.5 us per 3 KB / 2.5 us per 34 KB, where a GPU-initiated read of the same bytes from pinned
 // host memory cost the rollout kernel 11-20 us (tools/get_action_profile.py).  The copy is fenced (write-combining buffers drain, and
 // nothing after it -- the doorbell of a launch, the flag below -- can overtake it); the optional flag word follows, fenced again.
 extern "C" int rlppo_host_push(void *dst, const void *src, size_t bytes, uint32_t *flag, uint32_t value) {
     if (bytes && (!dst || !src)) return RLPPO_ERR_ARG;
-    if (bytes) memcpy(dst, src, bytes);
-    _mm_sfence();
+    if (bytes) {
+        memcpy(dst, src, bytes);
+        _mm_sfence();
+    }
     if (flag) {
         __atomic_store_n(flag, value, __ATOMIC_RELAXED);
         _mm_sfence();
@@ -721,6 +771,32 @@ extern "C" int rlppo_host_stage_call(uint32_t *ctl, uint32_t sequence, uint32_t 
     }
     if (obs_bytes) memcpy(obs_dst, obs_src, obs_bytes);
     _mm_sfence();
+    return 0;
+}
+
+// ... the same with the observations written as ROWS of a padded image: row r of `rows` (row_bytes each, src_stride apart) goes to
+// dst + r * dst_stride -- a window that was zeroed once and only ever receives the first row_bytes of its rows IS the zero-padded
+// input of the first layer (the layer chain of a small call then needs no pad launch)
+extern "C" int rlppo_host_stage_rows(uint32_t *ctl, uint32_t sequence, uint32_t live_rows, void *dst, size_t dst_stride, const void *src,
+                                     size_t src_stride, size_t row_bytes, int64_t rows) {
+    if (rows < 0 || (rows > 0 && (!dst || !src || row_bytes > dst_stride || row_bytes > src_stride))) return RLPPO_ERR_ARG;
+    if (ctl) {
+        ctl[0] = sequence;
+        ctl[1] = live_rows;
+    }
+    for (int64_t r = 0; r < rows; ++r)
+        memcpy(static_cast<char *>(dst) + r * dst_stride, static_cast<const char *>(src) + r * src_stride, row_bytes);
+    _mm_sfence();
+    return 0;
+}
+
+// HDP flush of the device `window` lives on (see the windows' table above): every host write that has left the CPU is in device
+// memory when this returns.  ~2.5 us (an uncached register write): ActGraph issues it BEHIND the launch, where it costs the call
+// nothing -- the launch's own way to the first wave (doorbell, the packet fetched over PCIe, dispatch: >= 3 us) already orders the
+// staged bytes before the kernel's reads, the flush closes the window from the other side.
+extern "C" int rlppo_host_window_flush(const void *window) {
+    if (!window) return RLPPO_ERR_ARG;
+    hdp_flush_for(window);
     return 0;
 }
 

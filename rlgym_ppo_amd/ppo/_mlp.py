@@ -30,6 +30,16 @@ def build_body(input_shape, layer_sizes, n_out, final_activation=None):
     return nn.Sequential(*layers)
 
 
+class _WindowRows:
+    """The padded observation rows of a host window as the launchers see a tensor: a shape and an address."""
+
+    def __init__(self, address, n, ld):
+        self.shape, self._address = (n, ld), address
+
+    def data_ptr(self):
+        return self._address
+
+
 class ActGraph:
     """One hipGraph of the whole rollout step of a policy head for up to `cap` observations, with no copy in it:
     rlppo_pad_rows reads the observations and the head's act entry point (forward + sampling) reads its noise straight from
@@ -71,14 +81,23 @@ class ActGraph:
         self.push = bool(self.poll and os.environ.get("RLPPO_ACT_PUSH", "1") != "0")   # (the layer chains of the other heads read the window too)
         if self.push:
             r256 = lambda x: (x + 255) // 256 * 256
-            obs_bytes, q_bytes = r256(cap * d * 4), r256(int(self.q_pin.numel()) * 4)
+            # (the layer chains read their first layer's input straight from the window: rows of ld_in floats, zero beyond d -- the
+            # window is zeroed once and the host only ever writes the first d floats of a row: no pad launch)
+            self.padded = raw is None
+            obs_bytes, q_bytes = r256(cap * (a.ld_in if self.padded else d) * 4), r256(int(self.q_pin.numel()) * 4)
             win = ctypes.c_void_p()
             if L.rlppo_host_window_alloc(256 + obs_bytes + q_bytes, ctypes.byref(win)) == 0:
                 self.window = win.value
                 self.ctl_arg, self.obs_arg, self.q_arg = win.value, win.value + 256, win.value + 256 + obs_bytes
-                self._push, self._stage = L.rlppo_host_push, L.rlppo_host_stage_call
+                self._push, self._stage, self._stage_rows = L.rlppo_host_push, L.rlppo_host_stage_call, L.rlppo_host_stage_rows
+                # the device's host data path is flushed between the staged bytes and the launch (by the book: 0.9 us of the call);
+                # RLPPO_ACT_HDP_FLUSH=after issues the flush behind the launch, where it is free (include/rlppo.h)
+                self._flush, self.flush_first = L.rlppo_host_window_flush, os.environ.get("RLPPO_ACT_HDP_FLUSH", "first") != "after"
+                if self.padded:
+                    self.rows = _WindowRows(self.obs_arg, cap, a.ld_in)
             else:
                 self.push = False   # (a device that does not expose its memory to the host)
+        self.padded = self.push and raw is None
         # [r5] late noise (rlppo_act_opts.noise_ctl): run() launches FIRST and draws the Exp(1) numbers afterwards -- the bit-exact
         # draw (5-11 us at 8-80 rows) then costs the call nothing, it hides behind the launch latency and the layers; the kernel
         # looks for control word 2 when its head layer starts.  Up to 256 rows: beyond that the draw outlasts the kernel.
@@ -138,7 +157,8 @@ class ActGraph:
         if self._raw is not None:
             self._raw(self, cap, self.opts)
             return
-        N.check(N.lib().rlppo_pad_rows(stream_ptr(), ptr(self.obs_arg), 0, cap, a.d_in, a.d_in, ptr(self.rows), a.ld_in, 0, 0.0, 1.0))
+        if not self.padded:
+            N.check(N.lib().rlppo_pad_rows(stream_ptr(), ptr(self.obs_arg), 0, cap, a.d_in, a.d_in, ptr(self.rows), a.ld_in, 0, 0.0, 1.0))
         pol._act_launch(self.rows, cap, self.q_arg, self.act_pin, self.logp_pin, self.ws, self.opts)
 
     def run(self, obs, q, n, draw=None, verify=None):
@@ -160,7 +180,12 @@ class ActGraph:
                 q = q if q.is_contiguous() else q.contiguous()
                 if q.numel() != m or q.dtype != torch.float32:
                     raise ValueError("noise: expected %d float32 numbers" % m)
-                rc = self._push(self.q_arg, q.data_ptr(), 4 * m, None, 0) or self._stage(None, 0, 0, self.obs_arg, obs.ctypes.data, obs.nbytes)
+                rc = self._push(self.q_arg, q.data_ptr(), 4 * m, None, 0)
+                if self.padded:
+                    d4 = 4 * obs.shape[1]
+                    rc = rc or self._stage_rows(None, 0, 0, self.obs_arg, 4 * self.rows.shape[1], obs.ctypes.data, d4, d4, n)
+                else:
+                    rc = rc or self._stage(None, 0, 0, self.obs_arg, obs.ctypes.data, obs.nbytes)
             if rc:
                 N.check(rc)
         else:
@@ -168,7 +193,11 @@ class ActGraph:
             if q is None:
                 q = draw()
             self.q_np[:m] = q.reshape(-1).numpy()
+        if self.push and self.flush_first:
+            self._flush(self.window)
         value, count = self._launch(n)
+        if self.push and not self.flush_first:
+            self._flush(self.window)
         if self.late:
             # the kernel is on its way: now the noise.  Whatever happens here control word 2 gets this call's sequence (a kernel left
             # waiting sits on the GPU until it gives up, 20 ms).  Nothing in here may wait for the GPU: the kernel waits for us.
