@@ -856,6 +856,7 @@ def test_discrete_step_takes_its_noise_while_it_runs(L, hidden, where):
             done.zero_()
             hdr[:] = (seq, live)
             check(L, L.rlppo_host_push(V(ctl_p), V(hdr.ctypes.data), 8, None, 0))
+            check(L, L.rlppo_host_window_flush(V(ctl_p)))                   # (a no-op for memory that is not a host window)
             opts.done_value = seq
             check(L, step(ctypes.byref(opts), obs_p, q_p, act, logp))       # (the noise matrix still holds the previous round's numbers)
             if delay:
