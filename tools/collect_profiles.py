@@ -22,7 +22,7 @@ copies = {
     "cfg5_pmc_sq.csv": f"{tag}_cfg5_bf16_pmc_sq.csv", "cfg5_traffic.json": f"{tag}_cfg5_bf16_traffic.json",
     "rank_share.txt": f"{tag}_rank_share.txt", "gae_floor.txt": f"{tag}_gae_floor.txt", "ab_update.txt": f"{tag}_ab_update_final.txt",
     "breakdown_rows.txt": f"{tag}_breakdown_rows.txt", "act_kernel_time.txt": f"{tag}_act_kernel_time.txt",
-    "rollout_breakdown.txt": f"{tag}_rollout_breakdown.txt", "small_batch_latency.txt": f"{tag}_small_batch_latency.txt", "get_action_profile.txt": f"{tag}_get_action_profile.txt", "get_action_modes.txt": f"{tag}_get_action_modes.txt", "host_noise_pipeline.txt": f"{tag}_host_noise_pipeline.txt", "fused_act_depth.txt": f"{tag}_fused_act_depth.txt", "rank_share_step_gaps.txt": f"{tag}_rank_share_step_gaps.txt",
+    "rollout_breakdown.txt": f"{tag}_rollout_breakdown.txt", "small_batch_latency.txt": f"{tag}_small_batch_latency.txt", "get_action_profile.txt": f"{tag}_get_action_profile.txt", "get_action_modes.txt": f"{tag}_get_action_modes.txt", "heads_latency.txt": f"{tag}_heads_latency.txt", "host_window_probe.txt": f"{tag}_host_window_probe.txt", "host_noise_pipeline.txt": f"{tag}_host_noise_pipeline.txt", "fused_act_depth.txt": f"{tag}_fused_act_depth.txt", "rank_share_step_gaps.txt": f"{tag}_rank_share_step_gaps.txt",
     "b16_k_sweep.txt": f"{tag}_b16_k_sweep.txt", "f32_k_sweep.txt": f"{tag}_f32_k_sweep.txt", "ceilings.txt": f"{tag}_ceilings.txt",
 }
 for a, b in copies.items():
