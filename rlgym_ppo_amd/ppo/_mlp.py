@@ -86,7 +86,9 @@ class ActGraph:
             self.padded = raw is None
             obs_bytes, q_bytes = r256(cap * (a.ld_in if self.padded else d) * 4), r256(int(self.q_pin.numel()) * 4)
             win = ctypes.c_void_p()
-            if L.rlppo_host_window_alloc(256 + obs_bytes + q_bytes, ctypes.byref(win)) == 0:
+            with torch.cuda.device(dev):   # (the window belongs to the device that is current when it is made)
+                rc_win = L.rlppo_host_window_alloc(256 + obs_bytes + q_bytes, ctypes.byref(win))
+            if rc_win == 0:
                 self.window = win.value
                 self.ctl_arg, self.obs_arg, self.q_arg = win.value, win.value + 256, win.value + 256 + obs_bytes
                 self._push, self._stage, self._stage_rows = L.rlppo_host_push, L.rlppo_host_stage_call, L.rlppo_host_stage_rows
@@ -141,7 +143,8 @@ class ActGraph:
         if win:
             try:
                 torch.cuda.synchronize(self.dev)   # (its graph may still be running)
-                N.lib().rlppo_host_window_free(ctypes.c_void_p(win))
+                with torch.cuda.device(self.dev):
+                    N.lib().rlppo_host_window_free(ctypes.c_void_p(win))
             except Exception:  # noqa: BLE001 -- interpreter shutdown
                 pass
 
