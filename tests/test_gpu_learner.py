@@ -855,6 +855,32 @@ def test_get_action_draws_its_noise_behind_the_launch(monkeypatch):
     assert g.stale_relaunches == before + 1 and torch.equal(a_new2[1], a_ref[1])
 
 
+@pytest.mark.parametrize("name,hidden", [("g1b_discrete_forward_128x2", (128, 128)), ("g1c_discrete_forward_256x3", (256, 256, 256))])
+def test_g1bc_through_the_collectors_small_call(golden, name, hidden):
+    """[r5] The reference-held vectors G1b / G1c through DiscreteFF.get_action AS THE COLLECTOR CALLS IT -- host observations, a graph
+    replay on a host window, the noise published behind the launch, completion words polled (ActGraph.push / .late): action indices
+    EXACT, log-probabilities within 1e-5, in chunks of the reference's call sizes (8 ... 80 observations) and whole; the library's
+    counter says the one-launch kernel was what the graphs captured."""
+    from rlgym_ppo_amd import _native as N
+    from rlgym_ppo_amd.ppo import DiscreteFF
+    g = golden(name)
+    assert float(g["margin"].min()) > 1e-4
+    pol = DiscreteFF(107, 90, hidden, "cuda:0")
+    pol.load_state_dict({k[2:]: torch.as_tensor(g[k]) for k in list(g.keys()) if k.startswith("p.")})
+    obs, q = np.asarray(g["obs"], dtype=np.float32), torch.as_tensor(np.asarray(g["q"], dtype=np.float32))
+    n = obs.shape[0]
+    fused0 = int(N.lib().rlppo_dbg_counter(0))
+    start = 0
+    for size in (8, 16, 3, 80, 33, n):
+        lo, hi = (0, n) if size == n else (start % n, min(start % n + size, n))
+        start += size
+        a, lp = pol.get_action(obs[lo:hi], noise=q[lo:hi])
+        assert np.array_equal(a.numpy(), g["actions"][lo:hi]), (name, lo, hi)
+        assert np.abs(lp.numpy() - g["logp"][lo:hi]).max() < 1e-5
+    assert pol._graphs and all(gr.push and gr.late == (gr.cap <= 256) and gr.late_retries == 0 for gr in pol._graphs.values())
+    assert int(N.lib().rlppo_dbg_counter(0)) > fused0
+
+
 @pytest.mark.parametrize("head", ["discrete", "gaussian", "multidiscrete"])
 def test_small_call_switches_all_give_the_same_bits(monkeypatch, head):
     """The documented switches of the small get_action call (README): RLPPO_ACT_POLL=0 (synchronise instead of polling completion
