@@ -55,3 +55,32 @@ def test_lockstep_restatement_equals_host_manager_for_one_agent():
             got = np.asarray(got, np.float32).reshape(np.asarray(want).shape)
             assert np.array_equal(got, want), name
     mgr.cleanup()
+
+
+def test_trajectory_assembler_semantics():
+    """BatchedTrajectory as rlgym_ppo/batched_agents/batched_trajectory.py:23-104 specifies it: a timestep is banked only when all
+    seven fields are there; a scalar reward becomes a one-element list; `truncated` keeps its value across the reset of the other
+    six; update() is True exactly when the banked step was terminal; get_all() splits the match's steps into one trajectory per
+    agent (seven parallel lists) and empties the assembler."""
+    from rlgym_ppo_amd.batched_agents.batched_trajectory import BatchedTrajectory
+    t = BatchedTrajectory()
+    assert t.update() is False and t.get_all() == []
+    s0, s1 = np.arange(6, dtype=np.float32).reshape(2, 3), np.arange(6, 12, dtype=np.float32).reshape(2, 3)
+    t.state, t.action, t.log_prob = s0, np.array([[1.0], [2.0]], np.float32), np.array([-0.5, -0.25], np.float32)
+    assert t.update() is False                      # the environment's half is missing
+    t.reward, t.next_state, t.done, t.truncated = [0.5, -1.0], s1, 0.0, 1.0
+    assert t.update() is False and len(t.complete_timesteps) == 1
+    assert t.state is None and t.reward is None and t.done is None and t.truncated == 1.0
+    t.state, t.action, t.log_prob = s1, np.array([[3.0], [4.0]], np.float32), np.array([-0.75, -1.5], np.float32)
+    t.reward, t.next_state, t.done = [1.0, 2.0], s0, 1.0
+    assert t.update() is True                       # terminal step; truncated still holds 1.0 from the step before
+    out = t.get_all()
+    assert len(out) == 2 and t.complete_timesteps == [] and t.get_all() == []
+    for i, cols in enumerate(out):
+        states, actions, log_probs, rewards, next_states, dones, truncs = cols
+        assert np.array_equal(states[0], s0[i]) and np.array_equal(states[1], s1[i]) and np.array_equal(next_states[1], s0[i])
+        assert [float(a[0]) for a in actions] == [1.0 + i, 3.0 + i] and [float(x) for x in log_probs] == [[-0.5, -0.75], [-0.25, -1.5]][i]
+        assert rewards == [[0.5, 1.0], [-1.0, 2.0]][i] and dones == [0.0, 1.0] and truncs == [1.0, 1.0]
+    one = BatchedTrajectory()                       # a single agent: scalar reward
+    one.state, one.action, one.log_prob, one.reward, one.next_state, one.done, one.truncated = s0[:1], np.zeros((1, 1)), np.zeros(1), 0.25, s1[:1], 0.0, 0.0
+    assert one.update() is False and one.complete_timesteps[0][3] == [0.25]
