@@ -67,3 +67,21 @@ def test_two_rank_dry_run_on_the_one_gpu_walks_the_whole_multi_rank_path():
     assert len(pr["all"]) == 2 and pr["min"] <= pr["max"] and abs(pr["max"] - line["ms_per_step"]) <= 0.05 * line["ms_per_step"] + 1.0
     assert "exiting 4" not in r.stderr                               # the init watchdog did not trip
     assert line["config"]["last_report"]["Cumulative Model Updates"] == 4   # (warm-up + 1 step) x 2 epochs x 1 batch
+
+
+@pytest.mark.gpu
+def test_process_collect_leg_runs_and_counts_what_it_says():
+    """[r5] bench.py's process_collect leg at a small size (3 worker processes, 3,000 timesteps): it returns the keys the line
+    carries, collected at least what was asked, counted get_action calls whose sizes add up to the timesteps, and left no worker
+    behind.  (The worker processes import the main module: the test runs the leg in a child interpreter, as bench.py does.)"""
+    code = ("import json, bench\n"
+            "r = bench.process_collect_leg(3, 3000, limit_s=90)\n"
+            "print(json.dumps(r))\n")
+    env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert "error" not in out, out
+    assert out["n_proc"] == 3 and out["timesteps"] >= 3000 and out["steps_per_s"] > 1000
+    assert out["get_action_calls"] > 0 and abs(out["mean_obs_per_call"] * out["get_action_calls"] - out["timesteps"]) <= 6 * 8
+    assert 0.0 < out["frac_of_wall_in_get_action"] < 1.0 and out["us_per_get_action_median"] > 5
