@@ -813,7 +813,7 @@ def test_discrete_step_takes_its_noise_while_it_runs(L, hidden, where):
     and stores the call's sequence into control word 2 (rlppo_host_push: bytes, fence, word, fence); the kernel -- which looks for
     that word when its head layer starts and waits for it after the last layer if it was not there -- samples with exactly those
     numbers: actions / log-probabilities bit-identical to the call that had its noise staged beforehand, for a host that completes
-    at once and for one that takes 4 ms; rows past the live count are untouched; a host that does not complete gets completion
+    at once and for one that takes 2 ms; rows past the live count are untouched; a host that does not complete gets completion
     words with the failure bit after 20 ms (rlppo_host_wait_words returns 2), not a hung GPU, and the same call made again after
     the completion delivers; entry points / networks without the one-launch kernel refuse the option.  Observations, noise and
     control words live in a host window (device memory the host writes through the PCIe aperture: what ActGraph uses) or in
@@ -847,7 +847,7 @@ def test_discrete_step_takes_its_noise_while_it_runs(L, hidden, where):
     try:
         opts = N.ActOpts(N.PRECISION_DEFAULT, 1, done.data_ptr(), ctl_p)
         assert L.rlppo_discrete_step_one_launch(net.dims_c, net.nl, n, ctypes.byref(opts)) == 1
-        for seq, delay in ((1, 0.0), (2, 0.004), (0x7FFFFFFF, 0.0), (3, 0.0)):
+        for seq, delay in ((1, 0.0), (2, 0.002), (0x7FFFFFFF, 0.0), (3, 0.0)):
             q = torch.from_numpy(rs.exponential(size=(n, A)).astype(np.float32)).pin_memory()
             ref_a, ref_l = torch.empty(n, dtype=torch.int64).pin_memory(), torch.empty(n).pin_memory()
             check(L, step(None, obs_pin.data_ptr(), q.data_ptr(), ref_a, ref_l))
