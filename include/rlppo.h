@@ -35,7 +35,7 @@ extern "C" {
  * the matching pop have default visibility (`nm -D` shows them and nothing else of the library's own; tests/test_abi_and_layout.py). */
 #pragma GCC visibility push(default)
 
-#define RLPPO_ABI_VERSION 5
+#define RLPPO_ABI_VERSION 6
 #define RLPPO_MAX_LAYERS 16
 
 #define RLPPO_OK 0
@@ -339,6 +339,37 @@ typedef struct rlppo_opt_net {
     int64_t step;         /* 1-based Adam step count of THIS update */
 } rlppo_opt_net;
 int rlppo_clip_adam_pack2(void *stream, const rlppo_opt_net *a, const rlppo_opt_net *b, void *sync_ws);
+
+/* [r6] The tail of PPOLearner.learn in ONE launch (ppo_learner.py:213-234: the update magnitudes ||theta_before - theta_after||_2 of
+ * both networks, the report means' sums read out, one device -> host synchronisation): round 5 spent ten dependent eager launches
+ * and a blocking copy here, 0.1 ms of a 3 ms learn() at the reference's own batch size.  The kernel
+ *   - adds add_passes to stats[RLPPO_STAT_PASSES], copies the RLPPO_N_STATS accumulators to out[0 .. RLPPO_N_STATS) and ZEROES them
+ *     (the next learn() starts from clean sums without a fill of its own);
+ *   - out[RLPPO_N_STATS], out[RLPPO_N_STATS + 1] <- sqrt(sum (before_i - now_i)^2) of the policy / the critic: float32 differences as
+ *     the reference forms them, squares and sums in double, partial sums added in a fixed order (bit-reproducible);
+ *   - out[RLPPO_N_STATS + 2] <- *timeout_word (the give-up counter of rlppo_clip_adam_pack2's sync block; 0 when NULL),
+ *     out[RLPPO_N_STATS + 3] <- *extra (a device double the caller wants back with the report -- the give-up count summed over the
+ *     ranks of a data-parallel run; out[RLPPO_N_STATS + 2] again when NULL);
+ *   - then stores done_value into *done_word with release semantics at system scope (rlppo_host_wait_words polls it).
+ * `out` and `done_word` are HOST-VISIBLE (pinned) memory; ws: RLPPO_REPORT_WS_BYTES of device memory owned by the caller, zeroed
+ * once when it is allocated (arrival counter + one partial-sum slot per workgroup; every call leaves it armed for the next). */
+#define RLPPO_REPORT_WS_BYTES 4096
+#define RLPPO_REPORT_OUT_DOUBLES (RLPPO_N_STATS + 4)
+typedef struct rlppo_report_args {
+    const float *pol_before, *pol_now;
+    int64_t n_pol;
+    const float *val_before, *val_now;
+    int64_t n_val;
+    double *stats;
+    double add_passes;
+    const uint32_t *timeout_word;
+    const double *extra;
+    double *out;
+    uint32_t *done_word;
+    uint32_t done_value;
+    void *ws;
+} rlppo_report_args;
+int rlppo_learn_report(void *stream, const rlppo_report_args *args);
 
 /* ------------------------------------------------------------------------------------- data-parallel exchange */
 

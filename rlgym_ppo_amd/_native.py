@@ -11,12 +11,14 @@ from ctypes import POINTER, c_char_p, c_double, c_float, c_int32, c_int64, c_siz
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("RLPPO_LIB") or os.path.join(HERE, "librlppo.so")  # RLPPO_LIB: an alternative build (A/B of compile-time variants)
-ABI_VERSION = 5
+ABI_VERSION = 6
 COMM_ID_BYTES = 128  # RLPPO_COMM_ID_BYTES
 MAX_LAYERS = 16
 N_STATS = 8
 OPT_SYNC_BYTES = 16384  # RLPPO_OPT_SYNC_BYTES
 OPT_SYNC_TIMEOUT_WORD = 2  # uint32 index of the barrier-timeout counter in the sync block
+REPORT_WS_BYTES = 4096  # RLPPO_REPORT_WS_BYTES
+REPORT_OUT_DOUBLES = N_STATS + 4  # RLPPO_REPORT_OUT_DOUBLES
 EXP_LINK_HEADER = 64  # RLPPO_EXP_LINK_HEADER
 MAX_SLOTS = 8
 STAT_ENTROPY, STAT_KL, STAT_VLOSS, STAT_CLIPFRAC, STAT_PLOSS = 0, 1, 2, 3, 4
@@ -43,6 +45,15 @@ class OptNet(ctypes.Structure):
 class ActOpts(ctypes.Structure):
     """struct rlppo_act_opts (include/rlppo.h)."""
     _fields_ = [("precision", c_int32), ("done_value", c_uint32), ("done_words", c_void_p), ("noise_ctl", c_void_p)]
+
+
+class ReportArgs(ctypes.Structure):
+    """struct rlppo_report_args (include/rlppo.h)."""
+    _fields_ = [
+        ("pol_before", c_void_p), ("pol_now", c_void_p), ("n_pol", c_int64), ("val_before", c_void_p), ("val_now", c_void_p), ("n_val", c_int64),
+        ("stats", c_void_p), ("add_passes", c_double), ("timeout_word", c_void_p), ("extra", c_void_p), ("out", c_void_p),
+        ("done_word", c_void_p), ("done_value", c_uint32), ("ws", c_void_p),
+    ]
 
 
 class TnProduct(ctypes.Structure):
@@ -118,6 +129,7 @@ SIGNATURES = {
     "rlppo_clip_adam": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_double, c_double,
                                   c_double, c_double, c_double, c_int64, c_void_p]),
     "rlppo_clip_adam_pack2": (c_int32, [c_void_p, POINTER(OptNet), POINTER(OptNet), c_void_p]),
+    "rlppo_learn_report": (c_int32, [c_void_p, POINTER(ReportArgs)]),
     "rlppo_comm_set_library": (c_int32, [ctypes.c_char_p]),
     "rlppo_comm_unique_id": (c_int32, [c_void_p]),
     "rlppo_comm_init": (c_int32, [c_int32, c_int32, c_void_p]),

@@ -1398,6 +1398,15 @@ int rlppo_clip_adam_pack2(void *stream, const rlppo_opt_net *a, const rlppo_opt_
                                   omb2, eps, sync_ws);
 }
 
+int rlppo_learn_report(void *stream, const rlppo_report_args *a) {
+    RLPPO_CHECK_ARG(a != nullptr, "learn_report: null args");
+    RLPPO_CHECK_ARG(a->n_pol >= 0 && a->n_val >= 0 && (a->n_pol == 0 || (a->pol_before && a->pol_now)) && (a->n_val == 0 || (a->val_before && a->val_now)),
+                    "learn_report: parameter vectors missing");
+    RLPPO_CHECK_ARG(a->stats && a->out && a->done_word && a->ws, "learn_report: null pointer (stats / out / done_word / ws)");
+    RLPPO_CHECK_ARG((reinterpret_cast<uintptr_t>(a->ws) & 15) == 0, "learn_report: ws must be 16-byte aligned");
+    return launch_learn_report((hipStream_t)stream, *a);
+}
+
 }  // extern "C"
 
 // ------------------------------------------------------------------------------------------ diagnostics

@@ -290,6 +290,7 @@ int launch_gather_meta(hipStream_t st, const int64_t *idx, const float *actions,
                        const float *adv, const float *targets, float *g_act, float *g_old, float *g_adv, float *g_tgt, int64_t n,
                        int64_t ring_base, int64_t ring_cap, unsigned *rowtab = nullptr, float *zero_n = nullptr);
 int launch_i64_to_f32(hipStream_t st, const int64_t *src, float *dst, int64_t n);
+int launch_learn_report(hipStream_t st, const rlppo_report_args &r);  // [r6] the tail of a learn(): norms of the update, statistics out, one completion word
 int launch_signal_words(hipStream_t st, unsigned *words, int count, unsigned value);  // words[0..count) <- value, released at system scope
 int launch_pad_rows(hipStream_t, const void *, int, int64_t, int64_t, int64_t, float *, int64_t, int, float, float);
 int launch_pad_rows_vec(hipStream_t, const void *, int, int64_t, int64_t, int64_t, float *, int64_t, const float *, const float *);

@@ -791,4 +791,75 @@ int launch_clip_adam_pack2(hipStream_t st, const NetLayout *nets, float *const *
     return 0;
 }
 
+// ------------------------------------------------------------------------------------------------ the report of a learn() [r6]
+// ppo_learner.py:213-234 in one launch: REPORT_BLOCKS workgroups sum (before - now)^2 over both flat arenas (float32 differences,
+// double squares), each parks its two partial sums in its slot of `ws` and takes a ticket; the last arriver adds the slots in slot
+// order (bit-reproducible), writes the statistics, the two norms and the give-up words into the caller's pinned `out`, zeroes the
+// device accumulators for the next learn(), re-arms the ticket counter and releases the completion word at system scope.
+namespace {
+constexpr int REPORT_BLOCKS = 64;
+struct ReportWs {
+    unsigned tickets;
+    unsigned pad[3];
+    double partial[REPORT_BLOCKS][2];
+};
+static_assert(sizeof(ReportWs) <= RLPPO_REPORT_WS_BYTES, "report workspace");
+}  // namespace
+
+__global__ __launch_bounds__(256) void learn_report_kernel(rlppo_report_args r) {
+    ReportWs *const ws = reinterpret_cast<ReportWs *>(r.ws);
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    double s[2] = {0.0, 0.0};
+    for (int k = 0; k < 2; ++k) {
+        const float *b = k ? r.val_before : r.pol_before, *a = k ? r.val_now : r.pol_now;
+        const int64_t n = k ? r.n_val : r.n_pol;
+        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+            const float d = b[i] - a[i];
+            s[k] += (double)d * (double)d;
+        }
+    }
+    __shared__ double red[4][2];
+    __shared__ int last;
+    for (int k = 0; k < 2; ++k) {
+        double v = s[k];
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][k] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        ws->partial[blockIdx.x][0] = (red[0][0] + red[1][0]) + (red[2][0] + red[3][0]);
+        ws->partial[blockIdx.x][1] = (red[0][1] + red[1][1]) + (red[2][1] + red[3][1]);
+        __threadfence();
+        last = atomicAdd(&ws->tickets, 1u) == gridDim.x - 1;
+    }
+    __syncthreads();
+    if (!last || threadIdx.x != 0) return;
+    __threadfence();
+    double t0 = 0.0, t1 = 0.0;
+    for (unsigned b = 0; b < gridDim.x; ++b) {
+        t0 += __hip_atomic_load(&ws->partial[b][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        t1 += __hip_atomic_load(&ws->partial[b][1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    r.stats[RLPPO_STAT_PASSES] += r.add_passes;
+    for (int k = 0; k < RLPPO_N_STATS; ++k) {
+        r.out[k] = r.stats[k];
+        r.stats[k] = 0.0;
+    }
+    r.out[RLPPO_N_STATS] = sqrt(t0);
+    r.out[RLPPO_N_STATS + 1] = sqrt(t1);
+    const double own = r.timeout_word ? (double)__hip_atomic_load(r.timeout_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+    r.out[RLPPO_N_STATS + 2] = own;
+    r.out[RLPPO_N_STATS + 3] = r.extra ? *r.extra : own;
+    __hip_atomic_store(&ws->tickets, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+    __hip_atomic_store(r.done_word, r.done_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+int launch_learn_report(hipStream_t st, const rlppo_report_args &r) {
+    hipLaunchKernelGGL(learn_report_kernel, dim3(REPORT_BLOCKS), dim3(256), 0, st, r);
+    RLPPO_LAUNCH_CHECK();
+    return 0;
+}
+
+
 }  // namespace rlppo

@@ -289,6 +289,19 @@ class LegacyPermutation:
         self._chain = None      # {"st": uint32[625] owned by the draw thread, "dead": bool}
         self._expected = None   # generator state the head of the queue was drawn from
         self._seq = 0
+        # [r6] a live uint32[625] view of the generator's MT19937 state (key[624], pos) through numpy's documented BitGenerator
+        # interface (`.ctypes.state_address`): comparing / advancing the state costs 3 us instead of the 50 + 50 us of
+        # get_state() / set_state(), which sat in front of every learn()'s first launch.  Checked once against get_state();
+        # anything unexpected leaves the legacy accessors in charge.
+        self._view = None
+        try:
+            bg = rng._bit_generator
+            view = np.ctypeslib.as_array((ctypes.c_uint32 * 625).from_address(bg.ctypes.state_address))
+            kind, key, pos = rng.get_state()[:3]
+            if kind == "MT19937" and np.array_equal(view[:624], key) and int(view[624]) == int(pos):
+                self._view, self._bg = view, bg   # (the view borrows the bit generator's memory: keep it alive)
+        except Exception:  # noqa: BLE001 -- another numpy: get_state / set_state
+            self._view = None
 
     def _rng_state(self):
         kind, key, pos, has_gauss, cached = self.rng.get_state()
@@ -348,10 +361,16 @@ class LegacyPermutation:
 
     close = _flush
 
-    def take(self, n):
-        """The next permutation of arange(n) as a completed pipeline entry (`.out`: int64 host array, `.slot`)."""
+    def take(self, n, refill=True):
+        """The next permutation of arange(n) as a completed pipeline entry (`.out`: int64 host array, `.slot`).  refill=False: the
+        queue is not topped up before returning (allocating the next entry and waking a helper thread costs ~50 us; a caller on a
+        latency-critical path calls refill() itself once its launches are out)."""
         n = int(n)
-        st, extra = self._rng_state()
+        view = self._view
+        if view is not None:
+            st, extra = view, None
+        else:
+            st, extra = self._rng_state()
         if not (self._q and self._q[0].n == n and self._expected is not None and np.array_equal(st, self._expected)):
             self._flush()
             if self._ring is not None:
@@ -364,11 +383,23 @@ class LegacyPermutation:
         if e.error is not None:
             self._flush()
             raise e.error
-        self.rng.set_state((extra[0], e.after[:624].copy(), int(e.after[624]), extra[1], extra[2]))
+        if view is not None:
+            view[:] = e.after   # (key and position: what set_state would write; the legacy Gaussian cache is not touched by either)
+        else:
+            self.rng.set_state((extra[0], e.after[:624].copy(), int(e.after[624]), extra[1], extra[2]))
         self._expected = e.after
-        while len(self._q) < self.lookahead:
-            self._enqueue(n)
+        self._refill_n = n
+        if refill:
+            self.refill()
         return e
+
+    def refill(self):
+        """Top the look-ahead queue up after a take(n, refill=False)."""
+        n = getattr(self, "_refill_n", None)
+        if n is not None and self._chain is not None and not self._chain.get("dead"):
+            # (1 + lookahead is what the next take() wants to find: it then enqueues nothing before its wait; lookahead 0 = nothing speculative)
+            while len(self._q) < (1 + self.lookahead if self.lookahead > 0 else 0):
+                self._enqueue(n)
 
     def permutation(self, n):
         return self.take(n).out

@@ -155,11 +155,15 @@ class ExperienceBuffer(object):
         per epoch from the persistent generator (experience_buffer.py:97-98)."""
         return self._perm.permutation(len(self)).copy()  # the pipeline's own vector is recycled two requests later
 
-    def epoch_indices_device(self):
+    def epoch_indices_device(self, refill=True):
         """The same permutation as a device int64 vector, ordered on the current stream (uploaded by the shuffle pipeline
-        on its own stream, normally long before it is asked for).  It stays valid until the next call."""
+        on its own stream, normally long before it is asked for).  It stays valid until the next call.  refill=False: the caller
+        tops the pipeline's look-ahead up itself (refill_shuffle) once its own launches are out."""
         self._ring.release_held()
-        return self._ring.take(self._perm.take(len(self)))
+        return self._ring.take(self._perm.take(len(self), refill=refill))
+
+    def refill_shuffle(self):
+        self._perm.refill()
 
     def _get_samples(self, indices):
         idx = torch.as_tensor(np.asarray(indices), device=self._dev)

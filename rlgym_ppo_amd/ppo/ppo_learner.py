@@ -173,6 +173,14 @@ class PPOLearner(object):
         pa.bind()
         va.bind()
         self._stats = torch.zeros(N.N_STATS, dtype=torch.float64, device=self._dev)
+        self._stats_clean = True   # rlppo_learn_report leaves the accumulators zeroed for the next learn()
+        # [r6] the tail of learn() as one launch (rlppo_learn_report): the parameters before the first optimiser step (copied behind the
+        # first pass's launches, where the copy is free), the kernel's ticket block, its pinned output and completion word
+        self._before = (torch.empty_like(pa.flat), torch.empty_like(va.flat))
+        self._report_ws = torch.zeros(N.REPORT_WS_BYTES, dtype=torch.uint8, device=self._dev)
+        self._report_out = torch.zeros(N.REPORT_OUT_DOUBLES, dtype=torch.float64).pin_memory()
+        self._report_done = torch.zeros(1, dtype=torch.int32).pin_memory()
+        self._report_out_np, self._report_seq = self._report_out.numpy(), 0
         self._ws = Workspace(self._dev)
         self.n_slots = int(os.environ.get("RLPPO_SLOTS", 1))  # minibatches of a batch kept in flight concurrently
         # Minibatch fusion.  The reference sums the gradients of a batch's minibatches, each the MB/B-scaled mean over its
@@ -259,9 +267,13 @@ class PPOLearner(object):
         B, MB = self.batch_size, self.mini_batch_size
         n_slices = B // MB
 
-        policy_before = pa.flat.clone()
-        critic_before = va.flat.clone()
-        self._stats.zero_()
+        # [r6] nothing is enqueued before the first pass that the pass does not need: the report sums were zeroed by the previous
+        # learn()'s report kernel, and the "before" copies of the parameters (ppo_learner.py:111-116) follow the first pass's launches
+        # in stream order -- the first optimiser step is still behind them
+        if not self._stats_clean:
+            self._stats.zero_()
+        self._stats_clean = False
+        have_before = False
         n_iterations = 0
         n_minibatch_iterations = 0
         n_passes = 0  # launches of rlppo_ppo_minibatch on this rank (each adds one mean to every report statistic)
@@ -281,7 +293,8 @@ class PPOLearner(object):
             # With 8 ranks the GPU share of an epoch is ~1.1 ms; the serial stream phase (~0.8 ms per 512k indices) is
             # the only part of the shuffle that cannot be spread over threads.
             for epoch in range(self.n_epochs):
-                idx_dev = exp.epoch_indices_device()
+                idx_dev = exp.epoch_indices_device(refill=False)   # (the look-ahead is topped up behind the epoch's first launches)
+                refilled = False
                 for b in range(n_batches):
                     if not grads_zero:
                         self._grad_all.zero_()
@@ -304,6 +317,13 @@ class PPOLearner(object):
                         N.check(L.rlppo_ppo_minibatch(st, ctypes.byref(args)))
                         n_passes += 1
                     N.check(L.rlppo_ppo_join(st))
+                    if not refilled:
+                        exp.refill_shuffle()
+                        refilled = True
+                    if not have_before:
+                        self._before[0].copy_(pa.flat)
+                        self._before[1].copy_(va.flat)
+                        have_before = True
                     n_minibatch_iterations += n_slices
                     if world > 1:
                         yield self._grad_all  # summed over the ranks (RCCL over xGMI) before clipping
@@ -323,24 +343,44 @@ class PPOLearner(object):
                         self.value_optimizer.step(max_norm=MAX_GRAD_NORM)
                         self.policy_optimizer.step(max_norm=MAX_GRAD_NORM)
                     n_iterations += 1
+                if not refilled:
+                    exp.refill_shuffle()
         else:
             for _ in range(self.n_epochs):
                 exp.epoch_indices()  # the reference consumes one permutation per epoch even if no batch fits
 
         # every pass added one mean to each report statistic; the number of passes travels with the sums, so the report is the
         # mean over the passes of ALL ranks even when the slices do not divide evenly over them (3 slices on 2 ranks)
-        self._stats[N.STAT_PASSES] += float(n_passes)
-        to_word = self._opt_sync[N.OPT_SYNC_TIMEOUT_WORD:N.OPT_SYNC_TIMEOUT_WORD + 1].double()  # optimiser steps THIS rank's barrier skipped
-        to_all = to_word
+        if not have_before:   # (no batch fitted: nothing moved)
+            self._before[0].copy_(pa.flat)
+            self._before[1].copy_(va.flat)
+        rep = N.ReportArgs()
+        rep.pol_before, rep.pol_now, rep.n_pol = self._before[0].data_ptr(), pa.flat.data_ptr(), pa.n_flat
+        rep.val_before, rep.val_now, rep.n_val = self._before[1].data_ptr(), va.flat.data_ptr(), va.n_flat
+        rep.stats, rep.add_passes = self._stats.data_ptr(), float(n_passes)
+        rep.timeout_word = self._opt_sync.data_ptr() + 4 * N.OPT_SYNC_TIMEOUT_WORD   # optimiser steps THIS rank's barrier skipped
+        to_all = None
         if world > 1:
             # the give-up count travels with the statistics: a give-up on ANY rank is known to EVERY rank after this exchange
-            ex = torch.cat((self._stats, to_word))
+            self._stats[N.STAT_PASSES] += float(n_passes)
+            rep.add_passes = 0.0
+            ex = torch.cat((self._stats, self._opt_sync[N.OPT_SYNC_TIMEOUT_WORD:N.OPT_SYNC_TIMEOUT_WORD + 1].double()))
             yield ex
             self._stats.copy_(ex[:N.N_STATS])
-            to_all = ex[N.N_STATS:]
-        # update magnitudes (ppo_learner.py:214-222: fp32 norms) travel with the statistics: ONE device->host sync per learn()
-        mags = torch.stack(((policy_before - pa.flat).norm(), (critic_before - va.flat).norm()))
-        stats = torch.cat((self._stats, mags.double(), to_word, to_all)).cpu().numpy()
+            to_all = ex[N.N_STATS:].contiguous()
+            rep.extra = to_all.data_ptr()
+        # [r6] update magnitudes (ppo_learner.py:214-222), the statistics and the give-up words in ONE launch that writes pinned memory
+        # and releases a completion word (rlppo_learn_report): one device->host hand-over per learn(), no eager tail
+        self._report_seq = self._report_seq % 0x7FFFFFFF + 1
+        rep.out, rep.done_word, rep.done_value, rep.ws = (self._report_out.data_ptr(), self._report_done.data_ptr(), self._report_seq,
+                                                          self._report_ws.data_ptr())
+        N.check(L.rlppo_learn_report(stream_ptr(), ctypes.byref(rep)))
+        if L.rlppo_host_wait_words(self._report_done.data_ptr(), 1, self._report_seq, 5000) != 0:
+            torch.cuda.current_stream(self._dev).synchronize()   # (a long learn(): sleep instead of spinning)
+            if L.rlppo_host_wait_words(self._report_done.data_ptr(), 1, self._report_seq, 1000000) != 0:
+                raise RuntimeError("rlppo_learn_report: the completion word did not arrive")
+        self._stats_clean = True
+        stats = self._report_out_np.copy()
         if stats[N.N_STATS + 3] != 0:
             # A grid-barrier wait of the one-launch optimiser step gave up on some rank (GPU shared with a kernel that never yields,
             # a partitioned device, or a defect).  Giving up is all or nothing (include/rlppo.h): on the rank it happened, that step

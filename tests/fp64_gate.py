@@ -99,19 +99,36 @@ def _check_flips(params, masks, det, who):
     return n_flips
 
 
+def _edge_contributions(head, pol, val, obs, acts, old, adv, tgt, clip, ent, mb_ratio, var, masks_pol, masks_val, edge, n):
+    """Full-branch contribution c_i of every clip-edge row i to the policy gradient (a list over the edge rows of per-layer
+    [dW, db] pairs, float64, under the imposed ReLU masks).  The gradient is linear in the branch weights and row i's term
+    mb_ratio * (-(A_i w_i ratio_i) / n) reaches the parameters through row i alone, so c_i is evaluated on the SUB-BATCH of the edge
+    rows (n' rows with mb_ratio' = mb_ratio n' / n: the same 1 / n scaling) as (w_i = 1) - (w_i = 0) -- what round 5 computed with
+    one full-batch float64 pass per edge row (145 s of the suite at 262,144 rows)."""
+    sub = lambda a: np.asarray(a)[edge]
+    mp = None if masks_pol is None else [np.asarray(m)[edge] for m in masks_pol]
+    mv = None if masks_val is None else [np.asarray(m)[edge] for m in masks_val]
+    ne = len(edge)
+    args = (head, pol, val, sub(obs), sub(acts), sub(old), sub(adv), sub(tgt), clip, ent, mb_ratio * ne / n, var, mp, mv)
+    base = ppo.minibatch_analytic(*args, np.zeros(ne))["grad_policy"]
+    out = []
+    for k in range(ne):
+        wk = np.zeros(ne)
+        wk[k] = 1.0
+        one = ppo.minibatch_analytic(*args, wk)["grad_policy"]
+        out.append([(np.asarray(ow, np.float64) - np.asarray(bw, np.float64), np.asarray(ob, np.float64) - np.asarray(bb, np.float64))
+                    for (ow, ob), (bw, bb) in zip(one, base)])
+    return out
+
+
 def _edge_decisions(head, pol, val, obs, acts, old, adv, tgt, clip, ent, mb_ratio, var, masks_pol, masks_val, got_pol, edge, n):
     """Surrogate branch of the rows within rounding of a clip edge, read off the implementation's output-layer gradient (which is
     linear in them): least squares over the edge rows' contributions, rounded to {0, 1}."""
     w0 = np.full(n, np.nan)
     w0[edge] = 0.0
     base = ppo.minibatch_analytic(head, pol, val, obs, acts, old, adv, tgt, clip, ent, mb_ratio, var, masks_pol, masks_val, w0)
-    cols = []
-    for i in edge:
-        wi = w0.copy()
-        wi[i] = 1.0
-        one = ppo.minibatch_analytic(head, pol, val, obs, acts, old, adv, tgt, clip, ent, mb_ratio, var, masks_pol, masks_val, wi)
-        cols.append(np.concatenate([(one["grad_policy"][-1][0] - base["grad_policy"][-1][0]).ravel(),
-                                    one["grad_policy"][-1][1] - base["grad_policy"][-1][1]]))
+    contrib = _edge_contributions(head, pol, val, obs, acts, old, adv, tgt, clip, ent, mb_ratio, var, masks_pol, masks_val, edge, n)
+    cols = [np.concatenate([c[-1][0].ravel(), c[-1][1]]) for c in contrib]
     A = np.stack(cols, 1)
     gw, gb = got_pol[-1]
     rhs = np.concatenate([np.asarray(gw, np.float64).ravel() - base["grad_policy"][-1][0].ravel(),
@@ -225,17 +242,14 @@ def without_edge_rows(head, pol, val, obs, acts, old, adv, tgt, clip, ent, mb_ra
     left depends on no knife-edge decision, so two implementations can be compared on it DIRECTLY."""
     n = np.asarray(obs).shape[0]
     mp, mv = masks
-    w0 = np.full(n, np.nan)
-    w0[edge] = 0.0
-    base = ppo.minibatch_analytic(head, pol, val, obs, acts, old, adv, tgt, clip, ent, mb_ratio, var, mp, mv, w0)["grad_policy"]
     out = [[np.asarray(gw, np.float64).copy(), np.asarray(gb, np.float64).copy()] for gw, gb in grads_pol]
-    for i in edge:
+    if len(edge) == 0:
+        return out
+    contrib = _edge_contributions(head, pol, val, obs, acts, old, adv, tgt, clip, ent, mb_ratio, var, mp, mv, edge, n)
+    for i, c in zip(edge, contrib):
         if w[i] == 0:
             continue
-        wi = w0.copy()
-        wi[i] = 1.0
-        one = ppo.minibatch_analytic(head, pol, val, obs, acts, old, adv, tgt, clip, ent, mb_ratio, var, mp, mv, wi)["grad_policy"]
-        for l, ((ow, ob), (bw, bb)) in enumerate(zip(one, base)):
-            out[l][0] -= w[i] * (np.asarray(ow, np.float64) - np.asarray(bw, np.float64))
-            out[l][1] -= w[i] * (np.asarray(ob, np.float64) - np.asarray(bb, np.float64))
+        for l, (cw, cb) in enumerate(c):
+            out[l][0] -= w[i] * cw
+            out[l][1] -= w[i] * cb
     return out

@@ -142,11 +142,14 @@ def test_learn_at_the_paired_launch_size_matches_the_reference_fixture(golden, p
     p0, v0 = vec(learner.policy), vec(learner.value_net)
     assert mg.param_hash(p0) == g["p0.hash"] and mg.param_hash(v0) == g["v0.hash"]      # the reference's initial weights, bit for bit
     assert np.array_equal(p0[:64], g["p0.head"]) and np.array_equal(v0[:64], g["v0.head"])
-    exp = mg.g5big_inputs(cfg)
+    # (the experience and its float64 truth are computed once per session: the fp32 and x3 parametrisations share them)
+    if "exp" not in _G5BIG:
+        _G5BIG["exp"] = mg.g5big_inputs(cfg)
+    exp = _G5BIG["exp"]
     assert np.array_equal(np.asarray([mg.param_hash(x.reshape(-1)) for x in exp[:3] + exp[7:]]), g["exp.hash"])   # the same experience
     buf = ExperienceBuffer(cfg["n"], cfg["seed"], "cpu")
     buf.submit_experience(*exp)
-    _G5BIG["exp"], _G5BIG["v0"] = exp, v0
+    _G5BIG["v0"] = v0
 
     # float64 truth of both optimiser steps (CPU oracle, ~1 TFLOP of float64)
     layers = [cfg["d"]] + list(cfg["layers"])
@@ -158,14 +161,17 @@ def test_learn_at_the_paired_launch_size_matches_the_reference_fixture(golden, p
             b = flat[o:o + dims[i + 1]]; o += b.size
             params.append((torch.as_tensor(w.copy()), torch.as_tensor(b.copy())))
         return params
-    truth, weakest, grad64 = {}, {}, {}
-    ppo.learn64("discrete", split(p0, cfg["n_act"]), split(v0, 1),
-                dict(states=exp[0], actions=exp[1], log_probs=exp[2], values=exp[7], advantages=exp[8]), cfg["B"], cfg["MB"], cfg["epochs"],
-                cfg["clip"], cfg["ent"], cfg["lr"], cfg["lr"], np.random.RandomState(cfg["seed"]), weakest=weakest,
-                on_grad=lambda i, gp, gv: grad64.__setitem__(i, (gp.copy(), gv.copy())),
-                on_step=lambda i, p, v: truth.__setitem__(i, (np.concatenate([t.ravel() for wb in p for t in wb]),
-                                                              np.concatenate([t.ravel() for wb in v for t in wb]),
-                                                              weakest["pol"].copy(), weakest["val"].copy())))
+    if "truth" not in _G5BIG:
+        truth, weakest, grad64 = {}, {}, {}
+        ppo.learn64("discrete", split(p0, cfg["n_act"]), split(v0, 1),
+                    dict(states=exp[0], actions=exp[1], log_probs=exp[2], values=exp[7], advantages=exp[8]), cfg["B"], cfg["MB"], cfg["epochs"],
+                    cfg["clip"], cfg["ent"], cfg["lr"], cfg["lr"], np.random.RandomState(cfg["seed"]), weakest=weakest,
+                    on_grad=lambda i, gp, gv: grad64.__setitem__(i, (gp.copy(), gv.copy())),
+                    on_step=lambda i, p, v: truth.__setitem__(i, (np.concatenate([t.ravel() for wb in p for t in wb]),
+                                                                  np.concatenate([t.ravel() for wb in v for t in wb]),
+                                                                  weakest["pol"].copy(), weakest["val"].copy())))
+        _G5BIG["truth"], _G5BIG["grad64"] = truth, grad64
+    truth, grad64 = _G5BIG["truth"], _G5BIG["grad64"]
     n_steps = int(g["n_steps"])
     assert n_steps == 2 and sorted(truth) == [0, 1]
     learner.n_epochs = 1
@@ -447,14 +453,33 @@ def test_reference_default_batch_of_50000_rows_against_the_oracle():
     res = fp64_gate.gate(L, "discrete", pol0, val0, obs[idx], acts[idx].astype(np.float32), old[idx], adv[idx], tgt[idx], 0.2, 0.005, 1.0,
                          (unflat(hip_grads[0][:n_pol], dims_p), unflat(hip_grads[0][n_pol:], dims_v), None), label="50,000-row pass of learn()")
     print(f"[50,000-row learn()] first-step gradient: err(HIP, float64 under HIP's decisions) = {res['hip']['err']:.2e}, CPU float32 oracle {res['cpu']['err']:.2e}")
-    # Parameters after both steps against the CPU oracle's: the two float32 implementations take a dozen ReLU decisions differently
-    # (above: worth ~1e-3 of a tensor's gradient at 50,000 rows) and Adam's scale-free step turns that into a fraction of lr for
-    # every entry whose gradient is that small -- so: half of the entries within 1e-5 of max|p|, 98 % within 1e-4, none further than
-    # the two steps themselves
-    for tag, got, ref in (("policy", got_p, nets.flatten(opol).detach()), ("value", got_v, nets.flatten(oval).detach())):
-        dd = (got.detach() - ref).abs().numpy() / float(ref.abs().max())
-        print(f"[50,000-row learn()] {tag} parameters, HIP against the CPU oracle: median {np.median(dd):.1e}, 98 % {np.quantile(dd, 0.98):.1e}, max {dd.max():.1e} of max|p|")
-        assert np.median(dd) <= 1e-5 and np.quantile(dd, 0.98) <= 1e-4 and dd.max() <= 2 * 3e-4 / float(ref.abs().max()) + 1e-5, (tag, float(np.quantile(dd, 0.98)), float(dd.max()))
+    # Parameters after both steps against the CPU oracle's, ENTRY BY ENTRY and with no entry excluded (G5big-b's method; round 5 gated
+    # quantiles here, which left 2 % of the entries ungated).  Adam's step lr m / (sqrt(v) + eps) is scale-free: a gradient difference
+    # d (relative to max|g|) moves the step of an entry whose gradient fell to w_i max|g| in some step by up to lr min(1, d / w_i).
+    # Between two float32 implementations d is not their arithmetic (5e-7 / 5e-6 above) but the ReLU decisions and the clip-edge row
+    # they legitimately take differently: D = the measured worth of both sides' decisions on this batch + 2e-5; w_i = the entry's
+    # smallest |g_i| / max|g| over the two steps in float64 (oracle/ppo.py::learn64).  Every entry is held to
+    # (steps) lr min(1, D / w_i) + 1e-5 max|p|.
+    truth, weakest = {}, {}
+    ppo.learn64("discrete", pol0, val0, dict(states=obs, actions=acts.astype(np.float32), log_probs=old, values=tgt, advantages=adv), B, B, 1,
+                0.2, 0.005, 3e-4, 3e-4, np.random.RandomState(seed), weakest=weakest,
+                on_step=lambda i, p, v: truth.__setitem__(i, (np.concatenate([t.ravel() for wb in p for t in wb]),
+                                                              np.concatenate([t.ravel() for wb in v for t in wb]))))
+    assert sorted(truth) == [0, 1]
+    D = res["hip"]["ambiguity"] + res["cpu"]["ambiguity"] + 2e-5
+    for tag, got, ref, weak, t64 in (("policy", got_p, nets.flatten(opol).detach(), weakest["pol"], truth[1][0]),
+                                     ("value", got_v, nets.flatten(oval).detach(), weakest["val"], truth[1][1])):
+        got64, ref64 = got.detach().numpy().astype(np.float64), ref.numpy().astype(np.float64)
+        scale = float(np.abs(ref64).max())
+        dd = np.abs(got64 - ref64)
+        allow = 2 * 3e-4 * np.minimum(1.0, D / np.maximum(weak, 1e-300)) + 1e-5 * scale
+        frac = dd / allow
+        n_ill = int((weak < 1e-4).sum())
+        print(f"[50,000-row learn()] {tag} parameters, HIP against the CPU oracle: median {np.median(dd) / scale:.1e}, 98 % {np.quantile(dd, 0.98) / scale:.1e}, "
+              f"max {dd.max() / scale:.1e} of max|p|; worst entry at {frac.max():.3f} of its derived allowance (D = {D:.1e}; {n_ill} of {weak.size} entries "
+              f"with an ill-conditioned Adam step); against float64: HIP {np.abs(got64 - t64).max() / scale:.1e}, CPU oracle {np.abs(ref64 - t64).max() / scale:.1e}")
+        assert frac.max() <= 1.0, (tag, float(frac.max()))
+        assert np.median(dd) / scale <= 1e-5, (tag, float(np.median(dd) / scale))
     for k in ("Policy Entropy", "Mean KL Divergence", "Value Function Loss", "SB3 Clip Fraction"):
         tol = 4.0 / B if k == "SB3 Clip Fraction" else 2e-5 * max(abs(oreport[k]), 1e-4) + 1e-7
         assert abs(report[k] - oreport[k]) <= tol, (k, report[k], oreport[k])
@@ -518,6 +543,45 @@ def test_learn_single_call_report_and_magnitudes(golden):
         ref = float(g["report." + key])
         assert abs(report[key] - ref) <= 5e-5 * max(abs(ref), 1e-4) + 1e-7, (key, report[key], ref)
     assert (learner.policy.arena.grad == 0).all()  # learn() leaves grads zeroed (ppo_learner.py:235-236)
+
+
+def test_report_kernel_leaves_clean_sums_and_exact_magnitudes(golden):
+    """[r6] rlppo_learn_report (the tail of learn() as one launch): the update magnitudes are the float64 norm of the float32 parameter
+    differences (1e-6: the reference's own float32 norm is that far from it), the report sums are zeroed BY the kernel -- three
+    consecutive learn() calls report what a learner whose sums are zeroed eagerly before every call reports, bit for bit -- and a
+    learn() that raised half way leaves no stale sums behind."""
+    from rlgym_ppo_amd.ppo import ExperienceBuffer
+    g = golden("g5_learn_discrete")
+    cfg = json.loads(str(g["cfg"]))
+    names = ["states", "actions", "log_probs", "rewards", "next_states", "dones", "truncated", "values", "advantages"]
+    runs = []
+    for eager_zero in (False, True):
+        learner = make_learner(cfg)
+        buf = ExperienceBuffer(cfg["n"], cfg["seed"], "cpu")
+        buf.submit_experience(*[g["exp." + k] for k in names])
+        reports = []
+        for _ in range(3):
+            if eager_zero:
+                learner._stats_clean = False   # forces the fill at the start of learn()
+            before = (learner.policy.arena.flat.clone(), learner.value_net.arena.flat.clone())
+            r = learner.learn(buf)
+            assert learner._stats_clean and float(learner._stats.abs().sum()) == 0.0
+            for key, b, now in (("Policy Update Magnitude", before[0], learner.policy.arena.flat),
+                                ("Value Function Update Magnitude", before[1], learner.value_net.arena.flat)):
+                want = float((b - now).double().norm())
+                assert want > 0 and abs(r[key] - want) <= 1e-6 * want, (key, r[key], want)
+            reports.append({k: v for k, v in r.items() if k != "PPO Batch Consumption Time"})
+        runs.append(reports)
+    assert runs[0] == runs[1]
+    # a learn() that dies between its passes and its report: the next call starts from clean sums all the same
+    learner.grad_probe = lambda gr: (_ for _ in ()).throw(RuntimeError("probe"))
+    with pytest.raises(RuntimeError, match="probe"):
+        learner.learn(buf)
+    assert not learner._stats_clean
+    learner.grad_probe = None
+    learner._grad_all.zero_()
+    r = learner.learn(buf)
+    assert 0.0 < r["Policy Entropy"] < np.log(cfg["n_act"]) + 1e-6
 
 
 def test_buffer_too_small_reports_zeros(golden):

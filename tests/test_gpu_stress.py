@@ -18,25 +18,67 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 LOAD = """
-import sys, time, torch
+import os, sys, time, torch
 a = torch.randn(4096, 4096, device="cuda")
 t0 = time.time()
-while time.time() - t0 < float(sys.argv[1]):
+b = a @ a
+torch.cuda.synchronize()
+open(sys.argv[2], "w").close()                      # running: the tests may start
+while time.time() - t0 < float(sys.argv[1]) and os.path.exists(sys.argv[2]):   # ... until the fixture removes the file (or the time limit)
     for _ in range(20):
         b = a @ a
     torch.cuda.synchronize()
 """
 
 
-def test_gemm_nt_repeatable_under_gpu_sharing():
+@pytest.fixture(scope="module")
+def gpu_neighbour(tmp_path_factory):
+    """ONE second process that keeps the GPU busy (4096^3 products back to back) for as long as the tests of this module that ask for
+    it run -- round 5 started one per test for a fixed 14-25 s and waited it out (88 s of the suite).  It stops when its flag file
+    disappears (a clean exit: no signal to a process that holds the GPU), at the latest after 300 s."""
+    flag = str(tmp_path_factory.mktemp("neighbour") / "running")
+    bg = subprocess.Popen([sys.executable, "-c", LOAD, "300", flag])
+    t0 = time.time()
+    while not os.path.exists(flag) and bg.poll() is None and time.time() - t0 < 120:
+        time.sleep(0.05)
+    assert os.path.exists(flag), "the neighbour process did not start"
+    time.sleep(0.5)
+    yield bg
+    os.remove(flag)
+    bg.wait(timeout=60)
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16", "x3"])
+def test_update_is_bit_reproducible(precision):
+    """Weight and bias gradients go through partial tiles / block partials summed in a fixed order (no fp32 atomics whose
+    arrival order would leak into the sums), so two runs of the same update from the same state end in bit-identical
+    parameters -- with the policy and critic chains racing on two streams and at a size where every launch splits."""
+    import contextlib
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_gpu_dp import _build
+    from rlgym_ppo_amd.engine import set_update_precision
+    finals = []
+    set_update_precision(precision)  # bf16: the transposing dW kernel, the narrow-head partial sums and their fixed-order reductions
+    try:
+        for _ in range(3):
+            with contextlib.redirect_stdout(open(os.devnull, "w")):
+                learner, buf = _build(hidden=(64, 64) if precision == "fp32" else (256, 256))
+            learner.learn(buf)
+            finals.append((learner.policy.arena.flat.clone(), learner.value_net.arena.flat.clone()))
+    finally:
+        set_update_precision("fp32")
+    for p, v in finals[1:]:
+        assert torch.equal(p, finals[0][0]) and torch.equal(v, finals[0][1])
+
+
+def test_gemm_nt_repeatable_under_gpu_sharing(gpu_neighbour):
     from rlgym_ppo_amd import _native as N
     L = N.lib()
     st = lambda: ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     P = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
     torch.manual_seed(0)
-    bg = subprocess.Popen([sys.executable, "-c", LOAD, "25"])
     try:
-        time.sleep(4.0)  # let the other process get going
+        assert gpu_neighbour.poll() is None
         # (M, N, K, epilogue): the shapes of a small learner's forward / backward and one cfg2 hidden layer
         for (M, n, k, epi) in [(512, 64, 128, 1), (512, 64, 64, 1), (512, 64, 96, 3), (512, 96, 64, 0), (4096, 256, 256, 1)]:
             A = torch.randn(M, k, device="cuda")
@@ -60,10 +102,10 @@ def test_gemm_nt_repeatable_under_gpu_sharing():
                 differ += (C != ref).any()
             assert int(differ.item()) == 0, (M, n, k, epi, int(differ.item()))
     finally:
-        bg.wait()
+        assert gpu_neighbour.poll() is None, "the neighbour process ended before the test did: nothing was shared"
 
 
-def test_bf16_products_repeatable_under_gpu_sharing():
+def test_bf16_products_repeatable_under_gpu_sharing(gpu_neighbour):
     """The same regression for the kernels of the bf16 update precision (bf16 8-byte buffer stores of the forward / dX epilogues in
     both tile shapes, the partial-tile stores of the transposing dW kernel): no atomics in any of them, so every run of the same
     product must be bitwise the same while another process backs up the memory pipeline."""
@@ -72,9 +114,8 @@ def test_bf16_products_repeatable_under_gpu_sharing():
     st = lambda: ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     P = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
     torch.manual_seed(1)
-    bg = subprocess.Popen([sys.executable, "-c", LOAD, "25"])
     try:
-        time.sleep(4.0)
+        assert gpu_neighbour.poll() is None
         for (M, n, k) in [(512, 256, 128), (4096, 256, 256), (4096 + 33, 512, 512)]:  # 128 x 128 tiles, 256 x 256 tiles, ragged
             A = torch.randn(M, k, device="cuda").bfloat16()
             W = (torch.randn(n, k, device="cuda") * 0.1).bfloat16()
@@ -105,10 +146,10 @@ def test_bf16_products_repeatable_under_gpu_sharing():
                         differ += (o != r).any()
                 assert int(differ.item()) == 0, (M, n, k, run, int(differ.item()))
     finally:
-        bg.wait()
+        assert gpu_neighbour.poll() is None, "the neighbour process ended before the test did: nothing was shared"
 
 
-def test_split_bf16_products_repeatable_under_gpu_sharing():
+def test_split_bf16_products_repeatable_under_gpu_sharing(gpu_neighbour):
     """[r4] The same regression for the kernels of the split-bf16 update precision (csrc/gemm_split.hip: 16-byte buffer stores of a
     tile parked in LDS, the 8-byte bitmask stores): no atomics, so every run of the same product is bitwise the same while another
     process backs up the memory pipeline -- forward (values and bitmask) and masked dX, a full and a ragged row count."""
@@ -117,9 +158,8 @@ def test_split_bf16_products_repeatable_under_gpu_sharing():
     st = lambda: ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     P = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
     torch.manual_seed(2)
-    bg = subprocess.Popen([sys.executable, "-c", LOAD, "20"])
     try:
-        time.sleep(4.0)
+        assert gpu_neighbour.poll() is None
         for (M, n, k) in [(4096, 256, 256), (4096 + 77, 512, 96)]:
             A = torch.randn(M, k, device="cuda")
             W = torch.randn(n, k, device="cuda") * 0.1
@@ -146,33 +186,10 @@ def test_split_bf16_products_repeatable_under_gpu_sharing():
                         differ += (o != r).any()
                 assert int(differ.item()) == 0, (M, n, k, int(differ.item()))
     finally:
-        bg.wait()
+        assert gpu_neighbour.poll() is None, "the neighbour process ended before the test did: nothing was shared"
 
 
-@pytest.mark.parametrize("precision", ["fp32", "bf16", "x3"])
-def test_update_is_bit_reproducible(precision):
-    """Weight and bias gradients go through partial tiles / block partials summed in a fixed order (no fp32 atomics whose
-    arrival order would leak into the sums), so two runs of the same update from the same state end in bit-identical
-    parameters -- with the policy and critic chains racing on two streams and at a size where every launch splits."""
-    import contextlib
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    from test_gpu_dp import _build
-    from rlgym_ppo_amd.engine import set_update_precision
-    finals = []
-    set_update_precision(precision)  # bf16: the transposing dW kernel, the narrow-head partial sums and their fixed-order reductions
-    try:
-        for _ in range(3):
-            with contextlib.redirect_stdout(open(os.devnull, "w")):
-                learner, buf = _build(hidden=(64, 64) if precision == "fp32" else (256, 256))
-            learner.learn(buf)
-            finals.append((learner.policy.arena.flat.clone(), learner.value_net.arena.flat.clone()))
-    finally:
-        set_update_precision("fp32")
-    for p, v in finals[1:]:
-        assert torch.equal(p, finals[0][0]) and torch.equal(v, finals[0][1])
-
-
-def test_gemm_tn_partial_tiles_repeatable_under_gpu_sharing():
+def test_gemm_tn_partial_tiles_repeatable_under_gpu_sharing(gpu_neighbour):
     """Same screen for the weight-gradient path: partial tiles are written with 16-byte buffer stores (the last
     instructions of every wave) and reduced in a fixed order, so repeated launches must agree bit for bit."""
     from rlgym_ppo_amd import _native as N
@@ -180,9 +197,8 @@ def test_gemm_tn_partial_tiles_repeatable_under_gpu_sharing():
     st = lambda: ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     P = lambda t: ctypes.c_void_p(t.data_ptr())
     torch.manual_seed(1)
-    bg = subprocess.Popen([sys.executable, "-c", LOAD, "14"])
     try:
-        time.sleep(4.0)
+        assert gpu_neighbour.poll() is None
         for (M, out, in_) in [(4096, 256, 256), (4096, 90, 256), (65536, 256, 107)]:
             ny, kx = int(L.rlppo_padded_out(out)), int(L.rlppo_padded_out(in_))
             dY = torch.zeros(M, ny, device="cuda")
@@ -202,4 +218,4 @@ def test_gemm_tn_partial_tiles_repeatable_under_gpu_sharing():
                 differ += (dW != ref_w).any() | (db != ref_b).any()
             assert int(differ.item()) == 0, (M, out, in_, int(differ.item()))
     finally:
-        bg.wait()
+        assert gpu_neighbour.poll() is None, "the neighbour process ended before the test did: nothing was shared"
