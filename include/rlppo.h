@@ -531,7 +531,10 @@ int rlppo_dbg_gemm_nt_x3(void *stream, const float *A, int64_t lda, const void *
  *     split-bf16 precisions) | 0 = one launch + reduction per layer inside the chains]
  *  38 [r5] workgroups of a grouped weight-gradient launch [0 = two per CU (default) | n]
  *  40 [r5] forward layers of up to 1024 rows (the layer chain of a small rollout call) [1 = one wave per 16 x 16 output block, operands
- *     straight from L2 (default) | 0 = the 128-row tiles of the large kernel]: bit-identical outputs */
+ *     straight from L2 (default) | 0 = the 128-row tiles of the large kernel]: bit-identical outputs
+ *  41 [r6] test hook of rlppo_host_window_alloc [0 = as the device is (default) | 1 = answer like a device that does not expose its
+ *     memory to the host (no large BAR: the call fails, the host falls back to pinned memory) | 2 = windows are registered without a
+ *     flush register (rlppo_host_window_flush then does nothing)] */
 int rlppo_dbg_set(int32_t key, int32_t value);
 /* Counter bumped by every call that changes which kernels later launches select (rlppo_dbg_set, rlppo_set_*_precision): a
  * host that caches captured graphs of library calls keys them on it (rlgym_ppo_amd/ppo/_mlp.py::ActGraph). */

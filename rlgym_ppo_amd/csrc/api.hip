@@ -411,12 +411,14 @@ size_t rlppo_discrete_step_workspace_bytes(const int32_t *dims, int32_t n_layers
     return forward_ws_floats(net, n) * sizeof(float) + ((size_t)n * net.L[0].pin * sizeof(float) + 255) / 256 * 256 + 512;
 }
 
+static int g_window_mode = 0;  // rlppo_dbg_set(41, v), test hook: 1 = answer as a device without a large BAR, 2 = windows without a flush register
 int rlppo_host_window_alloc(size_t bytes, void **ptr) {
     RLPPO_CHECK_ARG(ptr && bytes > 0, "host_window_alloc: bad argument");
     *ptr = nullptr;
     int dev = 0, large_bar = 0;
     RLPPO_HIP(hipGetDevice(&dev));
     RLPPO_HIP(hipDeviceGetAttribute(&large_bar, hipDeviceAttributeIsLargeBar, dev));
+    if (g_window_mode == 1) large_bar = 0;
     RLPPO_CHECK_ARG(large_bar, "host_window_alloc: device %d does not expose its memory to the host (no large BAR)", dev);
     RLPPO_HIP(hipExtMallocWithFlags(ptr, bytes, hipDeviceMallocFinegrained));
     RLPPO_HIP(hipMemset(*ptr, 0, bytes));
@@ -424,7 +426,7 @@ int rlppo_host_window_alloc(size_t bytes, void **ptr) {
     // the register whose store flushes the device's host data path: rlppo_host_push / _stage_* store to it behind their bytes
     hipDeviceProp_t prop;
     RLPPO_HIP(hipGetDeviceProperties(&prop, dev));
-    host_window_register(*ptr, bytes, prop.hdpMemFlushCntl);
+    host_window_register(*ptr, bytes, g_window_mode == 2 ? nullptr : prop.hdpMemFlushCntl);
     return 0;
 }
 int rlppo_host_window_free(void *ptr) {
@@ -1516,6 +1518,7 @@ int rlppo_dbg_set(int32_t key, int32_t value) {
         case 37: g_group_dw = value; return 0;
         case 38: set_tn_group_budget(value); return 0;
         case 40: set_nt_skinny(value); return 0;
+        case 41: g_window_mode = value; return 0;
         default: break;
     }
     set_error("dbg_set: unknown key %d", key);

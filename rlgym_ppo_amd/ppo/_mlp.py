@@ -66,19 +66,21 @@ class ActGraph:
 
         # [r5] completion by words the call's last kernel stores into pinned memory behind the results (rlppo_act_opts): run()
         # clears them, launches and polls them in C (rlppo_host_wait_words) instead of hipStreamSynchronize, which cost ~20 us of
-        # a 66 us call; a poll that times out falls back to the synchronisation.  RLPPO_ACT_POLL=0: always synchronise.
+        # a 66 us call; a poll that times out falls back to the synchronisation.
+        # [r6] ONE configuration + ONE fallback: host window, late noise and polled completion words are what every call uses;
+        # RLPPO_ACT_PUSH=0 (or a device that refuses a host window) keeps inputs and noise in pinned host memory.  Round 5's other
+        # switches (RLPPO_ACT_POLL / _EAGER / _LATE_NOISE / _HDP_FLUSH / _GRAPH) were configurations nobody ran and are gone.
         self.n_done = int(L.rlppo_act_done_words(cap))
         self.done_pin = torch.zeros(max(self.n_done, 1), dtype=torch.int32).pin_memory()
-        self.poll = os.environ.get("RLPPO_ACT_POLL", "1") != "0"
-        self.opts = N.ActOpts(N.PRECISION_DEFAULT, 1, self.done_pin.data_ptr()) if self.poll else None
-        self.polled = self.poll_timeouts = self.late_retries = self.stale_relaunches = 0
-        self.seq = self.graph_value = 1   # (the warm-up launch and the capture below store 1)
+        self.opts = N.ActOpts(N.PRECISION_DEFAULT, 1, self.done_pin.data_ptr())
+        self.calls = self.polled = self.poll_timeouts = self.late_retries = self.stale_relaunches = 0
+        self.graph_value = 1   # (the warm-up launch and the capture below store 1)
         # [r5] host window (rlppo_host_window_alloc): the one-launch step reads its observations, noise and control words from DEVICE
         # memory that run() writes directly through the PCIe aperture (posted writes: 1.5-2.5 us for 8-80 observations) instead of
         # reading pinned host memory itself (GPU-initiated PCIe reads: 11-20 us of the kernel).  RLPPO_ACT_PUSH=0: pinned memory.
         self.window = None
         self.obs_arg, self.q_arg = self.obs_pin.data_ptr(), self.q_pin.data_ptr()   # what _act_launch_raw hands to the kernel
-        self.push = bool(self.poll and os.environ.get("RLPPO_ACT_PUSH", "1") != "0")   # (the layer chains of the other heads read the window too)
+        self.push = os.environ.get("RLPPO_ACT_PUSH", "1") != "0"   # (the layer chains of the other heads read the window too)
         if self.push:
             r256 = lambda x: (x + 255) // 256 * 256
             # (the layer chains read their first layer's input straight from the window: rows of ld_in floats, zero beyond d -- the
@@ -92,9 +94,9 @@ class ActGraph:
                 self.window = win.value
                 self.ctl_arg, self.obs_arg, self.q_arg = win.value, win.value + 256, win.value + 256 + obs_bytes
                 self._push, self._stage, self._stage_rows = L.rlppo_host_push, L.rlppo_host_stage_call, L.rlppo_host_stage_rows
-                # the device's host data path is flushed between the staged bytes and the launch (by the book: 0.9 us of the call);
-                # RLPPO_ACT_HDP_FLUSH=after issues the flush behind the launch, where it is free (include/rlppo.h)
-                self._flush, self.flush_first = L.rlppo_host_window_flush, os.environ.get("RLPPO_ACT_HDP_FLUSH", "first") != "after"
+                # the device's host data path is flushed between the staged bytes and the launch (by the book: 0.9 us of the call;
+                # round 5's "flush behind the launch" ordered data by launch latency -- a timing argument, not a guarantee -- and is gone)
+                self._flush = L.rlppo_host_window_flush
                 if self.padded:
                     self.rows = _WindowRows(self.obs_arg, cap, a.ld_in)
             else:
@@ -103,8 +105,7 @@ class ActGraph:
         # [r5] late noise (rlppo_act_opts.noise_ctl): run() launches FIRST and draws the Exp(1) numbers afterwards -- the bit-exact
         # draw (5-11 us at 8-80 rows) then costs the call nothing, it hides behind the launch latency and the layers; the kernel
         # looks for control word 2 when its head layer starts.  Up to 256 rows: beyond that the draw outlasts the kernel.
-        # RLPPO_ACT_LATE_NOISE=0: noise staged before the launch (round 4).
-        self.late = bool(self.push and raw is not None and cap <= 256 and os.environ.get("RLPPO_ACT_LATE_NOISE", "1") != "0")
+        self.late = bool(self.push and raw is not None and cap <= 256)
         if self.late:
             self.opts.noise_ctl = self.ctl_arg
             self.late = L.rlppo_discrete_step_one_launch(a.dims_c, a.n_layers, cap, ctypes.byref(self.opts)) == 1
@@ -121,8 +122,7 @@ class ActGraph:
         # The body is replayed as a hipGraph.  (Rounds 3-4 issued a ONE-launch body -- the discrete head -- eagerly: the replay of a
         # one-node graph then cost 2-3 us more than the launch.  [r5] With completion polled instead of synchronised the replay is
         # the cheaper of the two by 2-3 us -- one hipGraphLaunch against a 22-argument ctypes call + hipLaunchKernel --
-        # tools/small_batch_latency.py, profiles/r05_small_batch_latency.txt.)  RLPPO_ACT_EAGER=0/1 forces either form.
-        self.eager = os.environ.get("RLPPO_ACT_EAGER", "0") == "1"
+        # tools/small_batch_latency.py, profiles/r05_small_batch_latency.txt.)
         side = torch.cuda.Stream(dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):
@@ -196,11 +196,10 @@ class ActGraph:
             if q is None:
                 q = draw()
             self.q_np[:m] = q.reshape(-1).numpy()
-        if self.push and self.flush_first:
+        if self.push:
             self._flush(self.window)
+        self.calls += 1
         value, count = self._launch(n)
-        if self.push and not self.flush_first:
-            self._flush(self.window)
         if self.late:
             # the kernel is on its way: now the noise.  Whatever happens here control word 2 gets this call's sequence (a kernel left
             # waiting sits on the GPU until it gives up, 20 ms).  Nothing in here may wait for the GPU: the kernel waits for us.
@@ -237,30 +236,19 @@ class ActGraph:
         return torch.from_numpy(self.act_np[:n].copy()), torch.from_numpy(self.logp_np[:n].copy())
 
     def _launch(self, n):
-        """-> (value, count): the completion words to wait for."""
-        if self.eager:
-            # a fresh completion value per call: a workgroup of an EARLIER launch that finishes late (rows past that call's n, which
-            # nobody waited for) stores the earlier value and cannot be mistaken for this call's; only the words of the rows the
-            # caller asked for are awaited
-            self.seq = self.seq % 0x7FFFFFFF + 1
-            if self.poll:
-                self.opts.done_value = self.seq
-            self.body()
-            return self.seq, (n + 15) // 16
-        # a replayed graph stores the value it was captured with: clear the words, wait for ALL of them (nothing of this
-        # launch is then still running when the next call clears them again)
-        if self.poll:
-            self.done_np[:] = 0
+        """-> (value, count): the completion words to wait for.  A replayed graph stores the value it was captured with: clear the
+        words, wait for ALL of them (nothing of this launch is then still running when the next call clears them again)."""
+        self.done_np[:] = 0
         self.graph.replay()
         return self.graph_value, self.n_done
 
     def _finish(self, value, count):
         """Waits for the launch: 0 = results are there, 2 = the kernel gave up on its late noise."""
-        rc = self._wait(self._done_ptr, count, value, 2000) if self.poll else 1
+        rc = self._wait(self._done_ptr, count, value, 2000)
         if rc == 0:
             self.polled += 1
         elif rc == 1:
-            self.poll_timeouts += int(self.poll)
+            self.poll_timeouts += 1
             torch.cuda.current_stream(self.dev).synchronize()
             rc = self._wait(self._done_ptr, count, value, 0) if self.late else 0   # (every word is stored by now: 0 or 2)
         return rc
@@ -289,7 +277,7 @@ class ArenaModule(nn.Module):
         dev = require_gpu(device)
         self.model = self.model.to(dev)
         self.arena = NetArena(linears_of(self.model), dev)
-        self.act_graphs = os.environ.get("RLPPO_ACT_GRAPH", "1") != "0"  # get_action through a hipGraph per batch-size bucket
+        self.act_graphs = True  # get_action through a hipGraph per batch-size bucket (False: every call takes the general path)
         self.act_graph_max = 1024  # beyond that the explicit copies of the eager path are the better transport for the noise
         self._graphs = {}
         self._graph_epoch = -1
@@ -329,7 +317,7 @@ class ArenaModule(nn.Module):
             g = self._graphs[_bucket(n)] = ActGraph(self, _bucket(n))
         if o.dtype != np.float32:
             o = o.astype(np.float32)
-        if g.poll and a._packed_key is not None:
+        if a._packed_key is not None:
             # launch on the packed copy as it is and check that it was current WHILE the GPU works (8 Parameters' versions and
             # addresses: 5 us of the call's critical path otherwise); a stale one -- rare: a stock optimiser stepped, the module
             # moved -- costs a second launch

@@ -847,8 +847,8 @@ def test_get_action_graph_replay_equals_eager_path():
 def test_get_action_draws_its_noise_behind_the_launch(monkeypatch):
     """[r5] The graph-served get_action of the discrete head writes its observations into a host window (device memory behind the
     PCIe aperture), launches, and draws its Exp(1) noise afterwards (ActGraph.push / .late, rlppo_act_opts.noise_ctl): same
-    actions, log-probabilities and generator state as the forms that stage the noise before the launch (RLPPO_ACT_LATE_NOISE=0)
-    and that keep everything in pinned host memory (RLPPO_ACT_PUSH=0), call after call with changing n inside one bucket; a draw
+    actions, log-probabilities and generator state as the form that keeps everything in pinned host memory and stages the noise
+    before the launch (RLPPO_ACT_PUSH=0: [r6] the one fallback left), call after call with changing n inside one bucket; a draw
     that raises leaves no kernel waiting and the next call is served normally; a host that is held up gets a second launch."""
     from rlgym_ppo_amd.ppo import DiscreteFF
     torch.manual_seed(3)
@@ -856,20 +856,17 @@ def test_get_action_draws_its_noise_behind_the_launch(monkeypatch):
     rs = np.random.RandomState(4)
     calls = [np.clip(rs.randn(n, 107), -5, 5).astype(np.float32) for n in (8, 3, 16, 80, 70, 80, 1, 33, 128, 200, 700)]
     out = {}
-    for late, push in (("1", "1"), ("0", "1"), ("1", "0")):
-        monkeypatch.setenv("RLPPO_ACT_LATE_NOISE", late)
+    for push in ("1", "0"):
         monkeypatch.setenv("RLPPO_ACT_PUSH", push)
         pol._graphs.clear()
         torch.manual_seed(99)
-        out[late, push] = [pol.get_action(o) for o in calls] + [torch.get_rng_state()]
-        assert all(g.push == (push == "1") and g.late == (late == "1" and push == "1" and g.cap <= 256) for g in pol._graphs.values())
+        out[push] = [pol.get_action(o) for o in calls] + [torch.get_rng_state()]
+        assert all(g.push == (push == "1") and g.late == (push == "1" and g.cap <= 256) for g in pol._graphs.values())
         assert set(pol._graphs) == {16, 48, 80, 128, 256, 1024}
         # (poll timeouts / second launches are allowed -- a busy host may hold a call up -- and change nothing: the results below decide)
-    for other in (("0", "1"), ("1", "0")):
-        for (a1, l1), (a0, l0) in zip(out["1", "1"][:-1], out[other][:-1]):
-            assert torch.equal(a1, a0) and torch.equal(l1, l0)
-        assert torch.equal(out["1", "1"][-1], out[other][-1])
-    monkeypatch.setenv("RLPPO_ACT_LATE_NOISE", "1")
+    for (a1, l1), (a0, l0) in zip(out["1"][:-1], out["0"][:-1]):
+        assert torch.equal(a1, a0) and torch.equal(l1, l0)
+    assert torch.equal(out["1"][-1], out["0"][-1])
     monkeypatch.setenv("RLPPO_ACT_PUSH", "1")
     pol._graphs.clear()
     good = pol._draw_noise
@@ -946,11 +943,13 @@ def test_g1bc_through_the_collectors_small_call(golden, name, hidden):
 
 
 @pytest.mark.parametrize("head", ["discrete", "gaussian", "multidiscrete"])
-def test_small_call_switches_all_give_the_same_bits(monkeypatch, head):
-    """The documented switches of the small get_action call (README): RLPPO_ACT_POLL=0 (synchronise instead of polling completion
-    words), RLPPO_ACT_EAGER=1 (plain launches instead of the graph replay), RLPPO_ACT_PUSH=0 (pinned transport), RLPPO_ACT_LATE_NOISE=0
-    (noise before the launch), RLPPO_ACT_GRAPH=0 (the general path) and RLPPO_TUNE="40=0" (128-row tiles in the layer chain): same
-    actions, log-probabilities and generator state as the default, for every head, at 1 / 8 / 80 / 200 observations."""
+def test_small_call_fallbacks_all_give_the_same_bits(monkeypatch, head):
+    """[r6] The small get_action call has ONE configuration (host window, late noise where the head has the one-launch step, polled
+    completion words) and these ways of NOT using it, every one the same actions, log-probabilities and generator state, for every
+    head, at 1 / 8 / 80 / 200 observations: RLPPO_ACT_PUSH=0 (the documented fallback: pinned host memory); a device that refuses a
+    host window (rlppo_dbg_set(41, 1) answers like one without a large BAR: the graphs fall back to pinned memory by themselves); a
+    device whose windows have no flush register (41, 2: rlppo_host_window_flush does nothing); the general path (policy.act_graphs =
+    False: what calls above 1024 rows take); RLPPO_TUNE-style 128-row tiles in the layer chain (40, 0)."""
     from rlgym_ppo_amd import _native as N
     from rlgym_ppo_amd.ppo import ContinuousPolicy, DiscreteFF, MultiDiscreteFF
     torch.manual_seed(17)
@@ -963,31 +962,33 @@ def test_small_call_switches_all_give_the_same_bits(monkeypatch, head):
     rs = np.random.RandomState(6)
     calls = [np.clip(rs.randn(n, d), -5, 5).astype(np.float32) for n in (1, 8, 80, 200, 8)]
 
-    def run(env, tune=None):
-        for k in ("RLPPO_ACT_POLL", "RLPPO_ACT_EAGER", "RLPPO_ACT_PUSH", "RLPPO_ACT_LATE_NOISE"):
-            monkeypatch.delenv(k, raising=False)
-        for k, v in env.items():
+    def run(env=None, tune=None, graphs=True, want_push=None):
+        monkeypatch.delenv("RLPPO_ACT_PUSH", raising=False)
+        for k, v in (env or {}).items():
             monkeypatch.setenv(k, v)
         pol._graphs.clear()
-        pol.act_graphs = env.get("RLPPO_ACT_GRAPH", "1") != "0"
+        pol.act_graphs = graphs
         if tune:
             N.check(N.lib().rlppo_dbg_set(*tune[0]))
         try:
             torch.manual_seed(4321)
             out = [pol.get_action(o) for o in calls]
+            if want_push is not None:
+                assert pol._graphs and all(g.push == want_push for g in pol._graphs.values()), (head, env, tune)
             return out, torch.get_rng_state()
         finally:
             if tune:
                 N.check(N.lib().rlppo_dbg_set(*tune[1]))
             pol.act_graphs = True
+            pol._graphs.clear()
 
-    ref, ref_state = run({})
-    for env, tune in (({"RLPPO_ACT_POLL": "0"}, None), ({"RLPPO_ACT_EAGER": "1"}, None), ({"RLPPO_ACT_PUSH": "0"}, None),
-                      ({"RLPPO_ACT_LATE_NOISE": "0"}, None), ({"RLPPO_ACT_GRAPH": "0"}, None), ({}, ((40, 0), (40, 1)))):
-        out, state = run(env, tune)
+    ref, ref_state = run(want_push=True)
+    for kw in (dict(env={"RLPPO_ACT_PUSH": "0"}, want_push=False), dict(tune=((41, 1), (41, 0)), want_push=False),
+               dict(tune=((41, 2), (41, 0)), want_push=True), dict(graphs=False), dict(tune=((40, 0), (40, 1)))):
+        out, state = run(**kw)
         for (a1, l1), (a0, l0) in zip(out, ref):
-            assert torch.equal(torch.as_tensor(a1), torch.as_tensor(a0)) and torch.equal(torch.as_tensor(l1), torch.as_tensor(l0)), (head, env, tune)
-        assert torch.equal(state, ref_state), (head, env)
+            assert torch.equal(torch.as_tensor(a1), torch.as_tensor(a0)) and torch.equal(torch.as_tensor(l1), torch.as_tensor(l0)), (head, kw)
+        assert torch.equal(state, ref_state), (head, kw)
 
 
 @pytest.mark.parametrize("n_agents,steps", [(64, 128), (768, 24)], ids=["on_the_spot", "look_ahead"])

@@ -219,3 +219,60 @@ def test_gemm_tn_partial_tiles_repeatable_under_gpu_sharing(gpu_neighbour):
             assert int(differ.item()) == 0, (M, out, in_, int(differ.item()))
     finally:
         assert gpu_neighbour.poll() is None, "the neighbour process ended before the test did: nothing was shared"
+
+
+HOG = """
+import os, sys, time
+t0 = time.time()
+while time.time() - t0 < float(sys.argv[1]) and os.path.exists(sys.argv[2]):
+    x = 0
+    for i in range(200000):
+        x += i * i
+"""
+
+
+def test_small_get_action_soak_under_host_and_gpu_contention(gpu_neighbour, tmp_path):
+    """[r6] The collector's small call (batched_agent_manager.py:180-221 -> DiscreteFF.get_action: observations pushed into a host
+    window, the kernel launched BEFORE its noise is drawn and spinning on host-written device memory, completion words polled)
+    soaked: 20,000 calls with a random number of observations in 1 ... 256 and fresh observations every call, while every host core
+    is kept busy by another process and a second process keeps the GPU busy -- the conditions under which a launch outlives the
+    kernel's patience, a poll times out, or a late word could be missed.  EVERY call is compared bit for bit (actions,
+    log-probabilities, the generator state it leaves) with the general path on the same generator state; the parameters are moved
+    behind the packed copy's back every 2,000 calls (the stale-weights relaunch).  The transport's counters are reported."""
+    from rlgym_ppo_amd.ppo import DiscreteFF
+    assert gpu_neighbour.poll() is None
+    torch.manual_seed(8)
+    pol = DiscreteFF(107, 90, (256, 256, 256), "cuda:0")
+    flag = str(tmp_path / "hog")
+    open(flag, "w").close()
+    hogs = [subprocess.Popen([sys.executable, "-c", HOG, "240", flag]) for _ in range(min(os.cpu_count() or 4, 16))]
+    rs = __import__("numpy").random.RandomState(9)
+    n_calls, t0 = 20000, time.time()
+    try:
+        torch.manual_seed(10)
+        for i in range(n_calls):
+            n = int(rs.randint(1, 257))
+            obs = rs.standard_normal((n, 107)).astype("float32")
+            st = torch.get_rng_state()
+            a1, l1 = pol.get_action(obs)                 # the graph-served call: host window, late noise, completion words
+            after = torch.get_rng_state()
+            torch.set_rng_state(st)
+            pol.act_graphs = False
+            a0, l0 = pol.get_action(obs)                 # the general path: explicit copies, stream synchronisation
+            pol.act_graphs = True
+            assert torch.equal(a1, a0) and torch.equal(l1, l0) and torch.equal(after, torch.get_rng_state()), (i, n)
+            if i % 2000 == 1999:
+                with torch.no_grad():
+                    for p in pol.parameters():
+                        p.add_(torch.randn_like(p) * 0.01)
+    finally:
+        os.remove(flag)
+        for h in hogs:
+            h.wait(timeout=30)
+    gs = list(pol._graphs.values())
+    tot = {k: sum(getattr(g, k) for g in gs) for k in ("calls", "polled", "poll_timeouts", "late_retries", "stale_relaunches")}
+    print(f"[soak] {n_calls} small get_action calls (n in 1..256) against the general path, {len(hogs)} host hogs + 1 GPU neighbour, "
+          f"{time.time() - t0:.1f} s: {len(gs)} graphs, all push {all(g.push for g in gs)}, all late {all(g.late for g in gs)}; {tot}")
+    assert all(g.push and g.late for g in gs) and tot["calls"] == n_calls
+    assert tot["stale_relaunches"] >= n_calls // 2000 - 1
+    assert gpu_neighbour.poll() is None, "the neighbour process ended before the test did: nothing was shared"

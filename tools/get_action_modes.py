@@ -1,8 +1,7 @@
 """DiscreteFF.get_action at 8 / 80 / 256 host observations in the forms of ppo/_mlp.py::ActGraph, one process per form (the environment
-switches are read when a graph is built): default = host window + late noise; RLPPO_ACT_LATE_NOISE=0 = host window, noise staged before
-the launch; RLPPO_ACT_PUSH=0 = everything in pinned host memory (round 4's transport).  With late noise the kernel's own statistics are
+switches are read when a graph is built): default = host window + late noise; RLPPO_ACT_PUSH=0 = everything in pinned host memory (round 4's transport).  With late noise the kernel's own statistics are
 printed: polls / wait of the first wave for its noise, and the timeline of the last workgroup (100 MHz wall clock).
-usage: python tools/get_action_modes.py ; RLPPO_ACT_LATE_NOISE=0 python tools/get_action_modes.py ; RLPPO_ACT_PUSH=0 python tools/get_action_modes.py"""
+usage: python tools/get_action_modes.py ; RLPPO_ACT_PUSH=0 python tools/get_action_modes.py"""
 import contextlib, os, sys, time
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -31,4 +30,4 @@ for n in (8, 80, 256):
         a_ = np.array(st[10:], dtype=np.int64)
         d = lambda i, j: np.median((a_[:, i] - a_[:, j]) & 0xFFFFFFFF) / 100
         out.append("[polls %.2f, wait %.2f us; last tile: start->obs staged %.1f, ->layers done %.1f, ->sampled %.1f]" % (a_[:, 0].mean(), a_[:, 1].mean() / 100, d(3, 2), d(4, 3), d(5, 4)))
-print("push", os.environ.get("RLPPO_ACT_PUSH", "1"), "late", os.environ.get("RLPPO_ACT_LATE_NOISE", "1"), " ".join(out))
+print("push", os.environ.get("RLPPO_ACT_PUSH", "1"), " ".join(out))

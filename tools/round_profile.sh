@@ -49,7 +49,7 @@ python tools/small_batch_latency.py > $OUT/small_batch_latency.txt 2> $OUT/small
 python tools/get_action_profile.py > $OUT/get_action_profile.txt 2> $OUT/get_action_profile.log
 { python tools/heads_latency.py; RLPPO_TUNE="40=0" python tools/heads_latency.py; python tools/heads_latency.py; } > $OUT/heads_latency.txt 2> $OUT/heads_latency.log
 { python tools/host_window_probe.py 0; python tools/host_window_probe.py 1; python tools/host_window_probe.py 3; } 2>&1 | grep -v amdgpu.ids > $OUT/host_window_probe.txt
-{ python tools/get_action_modes.py; RLPPO_ACT_LATE_NOISE=0 python tools/get_action_modes.py; RLPPO_ACT_PUSH=0 python tools/get_action_modes.py; python tools/get_action_modes.py; RLPPO_ACT_LATE_NOISE=0 python tools/get_action_modes.py; RLPPO_ACT_PUSH=0 python tools/get_action_modes.py; } > $OUT/get_action_modes.txt 2> $OUT/get_action_modes.log
+{ python tools/get_action_modes.py; RLPPO_ACT_PUSH=0 python tools/get_action_modes.py; python tools/get_action_modes.py; RLPPO_ACT_PUSH=0 python tools/get_action_modes.py; } > $OUT/get_action_modes.txt 2> $OUT/get_action_modes.log
 python tools/host_noise_pipeline.py 0:1 1:1 2:2 3:2 3:3 4:2 > $OUT/host_noise_pipeline.txt 2> $OUT/host_noise_pipeline.log
 rocprofv3 --kernel-trace --output-format csv -d $OUT/fa_depth -- python3 tools/fused_act_depth_time.py > $OUT/fa_depth.log 2>&1
 python tools/fused_act_depth_report.py $(find $OUT/fa_depth -name "*kernel_trace.csv" | head -1) > $OUT/fused_act_depth.txt

@@ -66,13 +66,3 @@ for n in (8, 80):
     obs = np.clip(np.random.RandomState(n).randn(n, bench.OBS), -5, 5).astype(np.float32)
     pol.get_action(obs)
     print("n = %d:" % n, ", ".join("%s %.1f us" % kv for kv in parts(n, obs).items()))
-for n in (8, 80):
-    obs = np.clip(np.random.RandomState(n).randn(n, bench.OBS), -5, 5).astype(np.float32)
-    row = []
-    for eager in (False, True):
-        for g_ in pol._graphs.values():
-            g_.eager = eager
-        row.append(wall(lambda: pol.get_action(obs)))
-    for g_ in pol._graphs.values():
-        g_.eager = False
-    print("n = %d: graph replay %.1f us, the same launch issued eagerly on the pinned buffers %.1f us" % (n, *row))
