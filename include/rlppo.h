@@ -56,6 +56,10 @@ extern "C" {
 
 int rlppo_abi_version(void);
 const char *rlppo_last_error(void);
+/* [r6] 16 hex digits: SHA-256 over the sources this library was built from (csrc/Makefile).  Evidence replayed from profiles/
+ * (bench.py's `roofline.traffic`: PMC bytes per launch, measured by a builder-run rocprofv3 pass) is stamped with the id of the
+ * library it was measured on and reported only while that is the library in use. */
+const char *rlppo_build_id(void);
 
 /* ---------------------------------------------------------------------------------------------- layout */
 

@@ -85,6 +85,7 @@ _PACT = POINTER(ActOpts)
 SIGNATURES = {
     "rlppo_abi_version": (c_int32, []),
     "rlppo_last_error": (c_char_p, []),
+    "rlppo_build_id": (c_char_p, []),
     "rlppo_padded_width": (c_int64, [c_int64]),
     "rlppo_padded_out": (c_int64, [c_int64]),
     "rlppo_packed_floats": (c_int64, [_P32, c_int32]),

@@ -1,6 +1,7 @@
 // api.hip -- the extern "C" surface declared in include/rlppo.h: argument checking, packed-layout bookkeeping and
 // the launch sequences (forward, sampling, GAE, one PPO minibatch, clip+Adam).  No device allocation, no
 // synchronisation: everything is enqueued on the caller's stream.
+#include "build_id.h"
 #include <math.h>
 #include <stdarg.h>
 #include <string.h>
@@ -303,6 +304,7 @@ static int act_done(hipStream_t st, const ActCtx &c, int64_t n) {
 extern "C" {
 
 int rlppo_abi_version(void) { return RLPPO_ABI_VERSION; }
+const char *rlppo_build_id(void) { return RLPPO_BUILD_ID; }
 const char *rlppo_last_error(void) { return g_err; }
 
 int64_t rlppo_padded_width(int64_t d) { return padded_width(d); }

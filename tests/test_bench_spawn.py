@@ -85,3 +85,7 @@ def test_process_collect_leg_runs_and_counts_what_it_says():
     assert out["n_proc"] == 3 and out["timesteps"] >= 3000 and out["steps_per_s"] > 1000
     assert out["get_action_calls"] > 0 and abs(out["mean_obs_per_call"] * out["get_action_calls"] - out["timesteps"]) <= 6 * 8
     assert 0.0 < out["frac_of_wall_in_get_action"] < 1.0 and out["us_per_get_action_median"] > 5
+    # [r6] the transport's counters cover every call of the timed collection and the 1 % spot check against the general path is clean
+    tr = out["transport"]
+    assert tr["calls"] >= out["get_action_calls"] and tr["polled"] + tr["poll_timeouts"] >= tr["calls"]
+    assert out["spot_checked"] >= out["get_action_calls"] // 100 and out["spot_check_mismatches"] == 0
