@@ -8,6 +8,10 @@
 #include "gemm_detail.hpp"
 // -DB16_ABL=bits builds TIMING-ONLY variants of the persistent kernel (results are garbage) for tools/b16_ablation.py: 1 the K steps'
 // stage requests go outside their descriptors (issued and counted, no traffic), 16 the tile's stores dropped, 32 no epilogue work.
+// [r6] pricing of a weight-stationary form: 2 only the WEIGHT half of every stage request dropped (what a workgroup that kept its
+// column slab of W resident would not stage), 4 only the activation half, 8 the weight fragments are not read from LDS either (the
+// registers loaded at the tile's first K step are multiplied again and again) -- 2 + 8 = the ceiling of ANY weight-stationary kernel
+// with this tile: weights neither staged nor read.
 #ifndef B16_ABL
 #define B16_ABL 0
 #endif
@@ -459,12 +463,13 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_b16p_kernel(const unsigned sho
     auto issue_tile = [&](const __amdgpu_buffer_rsrc_t &a_rs, int buf, unsigned kb) {
         float *Ad = wlds + buf * STAGE + wave_u * RPI * BKT;
         float *Bd = wlds + buf * STAGE + TM * BKT + wave_u * RPI * BKT;
+        const unsigned kba = ((B16_ABL & 4) && kb != 0) ? 0x80000000u : kb, kbb = ((B16_ABL & 2) && kb != 0) ? 0x80000000u : kb;
 #pragma unroll
         for (int i = 0; i < TM / PASS; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rs, Ad + i * PASS * BKT, 16, a_off, kb + i * a_step, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rs, Ad + i * PASS * BKT, 16, a_off, kba + i * a_step, 0, 0);
 #pragma unroll
         for (int i = 0; i < TN / PASS; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(b_rs, Bd + i * PASS * BKT, 16, b_off, kb + i * b_step, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(b_rs, Bd + i * PASS * BKT, 16, b_off, kbb + i * b_step, 0, 0);
     };
     // byte offsets of this wave's two bitmask words of a row tile (128 x 128-tile layout of relu_bits); a slot past the last
     // 128-row tile gets an offset outside the descriptor: the access is dropped but still counted
@@ -502,6 +507,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_b16p_kernel(const unsigned sho
                 acc[1][j] = acc[2][j] = acc[3][j] = acc[0][j];
             }
         }
+        bf16x8 fb_keep[8];  // (timing-only builds with B16_ABL & 8: the weight fragments of the tile's first K step, multiplied again and again)
         for (int kt = 0; kt < nk; ++kt) {
             const int cur = kt & 1;
             // stage kt of this tile is in LDS: stage 0 was requested before the previous tile's epilogue (18 younger operations
@@ -518,9 +524,18 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_b16p_kernel(const unsigned sho
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
                     fa[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4 *>(&Ac[dswz<BKT>(i * 16 + r16, kc * 4 + q)]));
+                if (!(B16_ABL & 8) || (kt == 0 && kc == 0)) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j)
-                    fb[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4 *>(&Bc[dswz<BKT>(j * 16 + r16, kc * 4 + q)]));
+                    for (int j = 0; j < 8; ++j)
+                        fb[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4 *>(&Bc[dswz<BKT>(j * 16 + r16, kc * 4 + q)]));
+                    if (B16_ABL & 8) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) fb_keep[j] = fb[j];
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) fb[j] = fb_keep[j];
+                }
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll

@@ -156,14 +156,25 @@ __device__ __forceinline__ void apply_bits(f32x4 (&acc)[2][NB], unsigned long lo
 // time: ids are taken in groups of 8 * (column tiles); within a group, id g -> row tile 8*group + g % 8, column tile g / 8.
 // With row tiles as the fast index instead, the second reader of an A tile came 512-4096 workgroups later and, once A no
 // longer fitted the 256 MB memory-side cache (fused minibatches), from HBM again.
+// [r6] A row count that is not a multiple of 8 tiles (the reference's own batch: 50,000 rows = 391 tiles) used to switch the order
+// OFF altogether -- every A tile was then fetched by two XCDs: 1.52 x the operand bytes per hidden launch by PMC
+// (profiles/r06_traffic_rows.txt).  Now the first 8 * (nr / 8) row tiles are ordered as above and only the last nr % 8 take the plain
+// order (ids behind all grouped ones: row tile fastest).
 __device__ __forceinline__ void xcd_tile(int &row_tile, int &col_tile) {
     const int nr = gridDim.x, nc = gridDim.y;
     row_tile = blockIdx.x;
     col_tile = blockIdx.y;
-    if ((nr & 7) == 0 && nc > 1) {
-        const int id = blockIdx.y * nr + blockIdx.x, g = id % (8 * nc);
-        row_tile = (id / (8 * nc)) * 8 + (g & 7);
-        col_tile = g >> 3;
+    if (nc > 1 && nr >= 8) {
+        const int id = blockIdx.y * nr + blockIdx.x, full = nr & ~7, grouped = full * nc;
+        if (id < grouped) {
+            const int g = id % (8 * nc);
+            row_tile = (id / (8 * nc)) * 8 + (g & 7);
+            col_tile = g >> 3;
+        } else {
+            const int t = id - grouped, r = nr - full;
+            row_tile = full + t % r;
+            col_tile = t / r;
+        }
     }
 }
 

@@ -7,31 +7,32 @@ import numpy as np
 
 
 class WelfordRunningStat(object):
+    """Attribute names (`running_mean`, `running_variance`, `count`, `shape`, `ones`, `zeros`), the JSON keys and the float32 operation
+    ORDER of `update` / `std` are the contract (checkpoints interchange with the reference's; the return std GAE divides by is
+    bit-identical: tests/test_abi_and_layout.py::test_welford_matches_reference, fixture G7); everything else is this file's own."""
+
     def __init__(self, shape):
-        self.ones = np.ones(shape=shape, dtype=np.float32)
-        self.zeros = np.zeros(shape=shape, dtype=np.float32)
-        self.running_mean = np.zeros(shape=shape, dtype=np.float32)
-        self.running_variance = np.zeros(shape=shape, dtype=np.float32)
-        self.count = 0
-        self.shape = shape
+        self.shape, self.count = shape, 0
+        # float32 state and float32 constants: `mean` / `std` hand these very arrays out while fewer than two samples have been seen
+        self.zeros, self.ones = (np.full(shape, fill, dtype=np.float32) for fill in (0.0, 1.0))
+        self.running_mean, self.running_variance = self.zeros.copy(), self.zeros.copy()
 
     def increment(self, samples, num):
-        if num > 1:
-            for i in range(num):
-                self.update(samples[i])
-        else:
-            self.update(samples)
+        # num > 1: samples[0 .. num) one by one; otherwise `samples` IS the one sample (running_stats.py:28-33)
+        for sample in ([samples[i] for i in range(num)] if num > 1 else [samples]):
+            self.update(sample)
 
     def update(self, sample):
-        if type(sample) == dict:
+        if type(sample) is dict:     # a frame-stacked observation: its newest frame (running_stats.py:36-37)
             sample = sample["frame"]
-        prev = self.count
-        self.count = prev + 1
-        shape = self.running_mean.shape
-        delta = (sample - self.running_mean).reshape(shape)
-        delta_n = (delta / self.count).reshape(shape)
+        seen = self.count            # samples before this one
+        self.count = seen + 1
+        like = self.running_mean.shape
+        # Welford's recurrence in the reference's operation order (float32 arrays: every step rounds where the reference's does)
+        delta = (sample - self.running_mean).reshape(like)
+        delta_n = (delta / self.count).reshape(like)
         self.running_mean += delta_n
-        self.running_variance += delta * delta_n * prev
+        self.running_variance += delta * delta_n * seen
 
     def reset(self):
         self.__init__(self.shape)
