@@ -245,7 +245,7 @@ def non_gemm_tail():
     from the newest committed single-stream kernel trace of `bench.py --steps 2 --warmup 1 --no-extras` (3 learn() x 10 epochs = 30
     passes; tools/round_profile.sh): {kernel: us per epoch}.  Like `traffic`, read from profiles/ -- bench.py cannot trace itself."""
     import csv
-    for tag in ("r05", "r04", "r03"):
+    for tag in ("r06", "r05", "r04", "r03"):
         path = os.path.join(ROOT, "profiles", tag + "_bench_kernel_stats_single_stream.csv")
         if not os.path.exists(path):
             continue

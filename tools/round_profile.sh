@@ -1,5 +1,5 @@
 #!/bin/bash
-# One GPU-box session that regenerates the evidence under profiles/: usage  tools/round_profile.sh <tag>   (run from the repo root)
+# One GPU-box session that regenerates the evidence under profiles/: usage  tools/round_profile.sh <tag> [bench-only|profiles-only] [stage-a|stage-b]   (run from the repo root)
 # Collects into gpurun_out/<tag>/; tools/collect_profiles.py then condenses it into profiles/<tag>_*.
 set -eo pipefail
 TAG=${1:-r04}
@@ -14,6 +14,8 @@ python bench.py --config cfg5 --precision fp32 --steps 3 --warmup 1 > $OUT/bench
 python bench.py --config cfg5 --precision bf16 --steps 3 --warmup 1 > $OUT/bench_cfg5_bf16.json 2> $OUT/bench_cfg5_bf16.log
 fi
 if [ "$2" == "bench-only" ]; then exit 0; fi
+# a third argument splits the profile passes over two GPU-box calls of <= 20 minutes: stage-a = kernel traces + PMC passes, stage-b = the tools
+if [ "$3" != "stage-b" ]; then
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 bench.py --steps 2 --warmup 1 --no-extras > $OUT/stats.log 2>&1
 RLPPO_TUNE=4=0 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_single -- python3 bench.py --steps 2 --warmup 1 --no-extras > $OUT/stats_single.log 2>&1
 REPS=40 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/iso -- python3 tools/prof_kernels.py > $OUT/iso.log 2>&1   # 40 launches per shape: the clock ramps as in the bench
@@ -40,6 +42,8 @@ PMC_CYCLE= python tools/pmc_summary.py $OUT/cfg5_fetch > $OUT/cfg5_pmc_fetch.csv
 PMC_CYCLE= python tools/pmc_summary.py $OUT/cfg5_write > $OUT/cfg5_pmc_write.csv
 PMC_CYCLE= python tools/pmc_summary.py $OUT/cfg5_sq > $OUT/cfg5_pmc_sq.csv
 python tools/pmc_traffic.py $OUT/cfg5_pmc_fetch.csv $OUT/cfg5_pmc_write.csv $OUT/cfg5_traffic.json
+if [ "$3" == "stage-a" ]; then echo DONE-A; exit 0; fi
+fi  # (stage-b starts here)
 python tools/rank_share.py > $OUT/rank_share.txt 2> $OUT/rank_share.log
 python tools/ab_update.py 3 > $OUT/ab_update.txt 2> $OUT/ab_update.log
 python tools/breakdown_rows.py > $OUT/breakdown_rows.txt 2> $OUT/breakdown_rows.log
