@@ -41,6 +41,7 @@ extern "C" {
 #define RLPPO_OK 0
 #define RLPPO_ERR_ARG 1001        /* bad argument / unsupported shape */
 #define RLPPO_ERR_WORKSPACE 1002  /* workspace too small */
+#define RLPPO_ERR_COLLECT_TIMEOUT 1003  /* rlppo_collector_collect: no worker message for a minute */
 
 /* policy head codes == the reference's `policy_type` (ppo_learner.py:34-50) */
 #define RLPPO_HEAD_DISCRETE 0
@@ -374,6 +375,43 @@ typedef struct rlppo_report_args {
     void *ws;
 } rlppo_report_args;
 int rlppo_learn_report(void *stream, const rlppo_report_args *args);
+
+/* ---------------------------------------------------------------------------- process-mode collection (host only) */
+
+/* [r6] The learner-side loop of the reference's process-per-environment collection (rlgym_ppo/batched_agents/
+ * batched_agent_manager.py:126-350, batched_trajectory.py:58-105) as host C++ behind the SAME wire format (UDP headers of three magic
+ * floats + one slab per worker of a shared float32 array: rlgym_ppo_amd/batched_agents/comm_consts.py): wait for the ready sockets,
+ * read the datagram, parse the slab, advance the observation statistics (Welford, in the state's dtype and the reference's operation
+ * order), standardise, keep the episode-reward bookkeeping, bank the timestep into the environment's trajectory, and lay the
+ * trajectories out agent by agent at the end of a collect_timesteps call (last step force-marked truncated unless done: quirk Q4).
+ * The policy call stays with the host; one inference is  _ready -> [policy.get_action] -> _send -> _collect.  All pointers HOST.
+ *   create: socket_fds[i] = the learner's UDP socket of worker i (owned by the caller), peer_ports[i] = that worker's port on
+ *     127.0.0.1, shm_base + i * shm_floats_per_worker = its slab.
+ *   set_obs: current_obs[worker] <- rows x obs_dim floats (a reset state, as received: not standardised), ready != 0: the worker
+ *     waits for actions.
+ *   ready: the stacked observations of the workers waiting for actions (at most cap_rows rows) -> n_rows.
+ *   send: actions[n_rows][act_width] float32 and log_probs[n_rows] for exactly those rows: recorded, and sent to the workers.
+ *   collect: blocks until messages worth >= min_obs agent-steps have been banked (a message counts its prev_n_agents) -> n_collected;
+ *     standardize 0 = off, 1 = (x - mean[0]) / std[0] clipped to +-5 (the reference's scalars, quirk Q5), 2 = per feature;
+ *     stats_mean / stats_var / stats_count / steps_since_increment: the WelfordRunningStat's state (float32 arrays, float64 when
+ *     stats_f64) and the manager's cadence counter, advanced in place every steps_per_increment-th message with the RAW rows.
+ *   finish: flushes every trajectory -> the sizes _emit needs; emit: states / next_states [n][obs_dim], actions [n][act_width],
+ *     log_probs [n] float32, rewards / dones / truncated [n] float64 (the dtypes the reference's lists become), and every message's
+ *     metrics record (values flat; 9 ints per record: rank, dimensions).
+ *   average_reward: get (set == 0) / set the manager's running average (is_none: it has not seen an episode end yet). */
+int rlppo_collector_create(int32_t n_workers, const int32_t *socket_fds, const int32_t *peer_ports, const float *shm_base,
+                           int64_t shm_floats_per_worker, int32_t obs_dim, void **handle);
+int rlppo_collector_destroy(void *handle);
+int rlppo_collector_set_obs(void *handle, int32_t worker, const float *obs, int32_t rows, int32_t ready);
+int rlppo_collector_ready(void *handle, float *obs_out, int64_t cap_rows, int64_t *n_rows);
+int rlppo_collector_send(void *handle, const float *actions, int32_t act_width, const float *log_probs);
+int rlppo_collector_collect(void *handle, int64_t min_obs, int32_t standardize, const float *mean, const float *stdv, void *stats_mean,
+                            void *stats_var, int64_t *stats_count, int32_t stats_f64, int64_t steps_per_increment, int64_t *steps_since_increment,
+                            int64_t *n_collected);
+int rlppo_collector_finish(void *handle, int64_t *n_steps, int32_t *act_width, int64_t *n_metrics, int64_t *metrics_floats);
+int rlppo_collector_emit(void *handle, float *states, float *actions, float *log_probs, double *rewards, float *next_states, double *dones,
+                         double *truncated, float *metrics_values, int32_t *metrics_shapes);
+int rlppo_collector_average_reward(void *handle, int32_t set, double *value, int32_t *is_none);
 
 /* ------------------------------------------------------------------------------------- data-parallel exchange */
 

@@ -131,6 +131,16 @@ SIGNATURES = {
                                   c_double, c_double, c_double, c_int64, c_void_p]),
     "rlppo_clip_adam_pack2": (c_int32, [c_void_p, POINTER(OptNet), POINTER(OptNet), c_void_p]),
     "rlppo_learn_report": (c_int32, [c_void_p, POINTER(ReportArgs)]),
+    "rlppo_collector_create": (c_int32, [c_int32, c_void_p, c_void_p, c_void_p, c_int64, c_int32, POINTER(c_void_p)]),
+    "rlppo_collector_destroy": (c_int32, [c_void_p]),
+    "rlppo_collector_set_obs": (c_int32, [c_void_p, c_int32, c_void_p, c_int32, c_int32]),
+    "rlppo_collector_ready": (c_int32, [c_void_p, c_void_p, c_int64, POINTER(c_int64)]),
+    "rlppo_collector_send": (c_int32, [c_void_p, c_void_p, c_int32, c_void_p]),
+    "rlppo_collector_collect": (c_int32, [c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, POINTER(c_int64), c_int32, c_int64,
+                                          POINTER(c_int64), POINTER(c_int64)]),
+    "rlppo_collector_finish": (c_int32, [c_void_p, POINTER(c_int64), POINTER(c_int32), POINTER(c_int64), POINTER(c_int64)]),
+    "rlppo_collector_emit": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "rlppo_collector_average_reward": (c_int32, [c_void_p, c_int32, POINTER(c_double), POINTER(c_int32)]),
     "rlppo_comm_set_library": (c_int32, [ctypes.c_char_p]),
     "rlppo_comm_unique_id": (c_int32, [c_void_p]),
     "rlppo_comm_init": (c_int32, [c_int32, c_int32, c_void_p]),

@@ -8,6 +8,7 @@ worker of a shared RawArray('f') for the step data (comm_consts.py; reference ba
 worker process built for the reference can serve this manager and vice versa.  With n_processes=0 one environment runs inside
 the learner process (no IPC), and VectorAgentManager keeps a vectorised environment's rollout on the GPU.
 """
+import ctypes
 import multiprocessing as mp
 import multiprocessing.sharedctypes
 import pickle
@@ -18,6 +19,7 @@ import time
 import numpy as np
 import torch
 
+from .. import _native as N
 from ..util import WelfordRunningStat
 from . import comm_consts as C
 from .batched_agent import _as_f32, batched_agent_process, describe_action_space
@@ -155,7 +157,12 @@ class BatchedAgentManager(object):
         self.seed = seed
         self.processes = []
         self.next_obs, self.current_obs, self.current_pids = [], [], []
-        self.average_reward = None
+        self._average_reward = None
+        # [r6] the per-message half of the collection loop in C++ (csrc/collector.cpp, rlppo_collector_*): used for worker PROCESSES
+        # whose observation statistics are float32 (always, unless they were restored from JSON); False keeps the Python loop below,
+        # which is the readable statement of the same behaviour and what an in-process environment (n_processes = 0) runs
+        self.native_collect = True
+        self._native = None
         self.cumulative_timesteps = 0
         self.min_inference_size = min_inference_size
         self.standardize_obs = standardize_obs
@@ -167,6 +174,21 @@ class BatchedAgentManager(object):
         self.trajectory_map = []
         self.completed_trajectories = []
         self.n_procs = 0
+
+    @property
+    def average_reward(self):
+        if self._native is not None:
+            v, none = ctypes.c_double(0.0), ctypes.c_int32(1)
+            N.check(N.lib().rlppo_collector_average_reward(self._native, 0, ctypes.byref(v), ctypes.byref(none)))
+            return None if none.value else v.value
+        return self._average_reward
+
+    @average_reward.setter
+    def average_reward(self, value):
+        self._average_reward = value
+        if self._native is not None:
+            v, none = ctypes.c_double(0.0 if value is None else float(value)), ctypes.c_int32(1 if value is None else 0)
+            N.check(N.lib().rlppo_collector_average_reward(self._native, 1, ctypes.byref(v), ctypes.byref(none)))
 
     # --------------------------------------------------------------------------------------------- set-up
     def init_processes(self, n_processes, build_env_fn, collect_metrics_fn=None, spawn_delay=None, render=False,
@@ -313,6 +335,8 @@ class BatchedAgentManager(object):
     def collect_timesteps(self, n):
         """-> ((states, actions, log_probs, rewards, next_states, dones, truncated), metrics, n_collected, seconds),
         trajectory-concatenated, last step of every flushed trajectory force-marked truncated if not done (quirk Q4)."""
+        if self._native_ok():
+            return self._collect_timesteps_native(n)
         t1 = time.perf_counter()
         cols = [[] for _ in range(7)]
         n_collected = 0
@@ -345,7 +369,114 @@ class BatchedAgentManager(object):
         self.cumulative_timesteps += n_collected
         return tuple(np.asarray(c) for c in cols), metrics, n_collected, time.perf_counter() - t1
 
+    # ----------------------------------------------------------------------------------- native collection
+    def _stats_native_ok(self):
+        st = self.obs_stats
+        return (not self.standardize_obs) or (st is not None and all(
+            isinstance(a, np.ndarray) and a.dtype == np.float32 and a.flags.c_contiguous and a.ndim == 1
+            for a in (st.running_mean, st.running_variance)))
+
+    def _native_ok(self):
+        if self._native is not None:
+            if not self._stats_native_ok():
+                raise RuntimeError("BatchedAgentManager: the observation statistics changed dtype / layout after the native collector "
+                                   "started (restored from JSON mid-run?); set agent.native_collect = False before the first collect")
+            return True
+        if not (self.native_collect and self.processes and all(isinstance(w, _ProcessWorker) for w in self.processes)):
+            return False
+        if not self._stats_native_ok() or any(o is not None and np.ndim(o) != 2 for o in self.current_obs):
+            return False
+        obs = next((o for o in self.current_obs if o is not None), None)
+        if obs is None:
+            return False
+        # hand the state of the Python loop (the handshake's reset states, who waits for actions) over to the C++ one
+        n = len(self.processes)
+        fds = (ctypes.c_int32 * n)(*[w.sock.fileno() for w in self.processes])
+        ports = (ctypes.c_int32 * n)(*[int(w.child[1]) for w in self.processes])
+        h = ctypes.c_void_p()
+        self._nat_d = int(obs.shape[1])
+        N.check(N.lib().rlppo_collector_create(n, fds, ports, ctypes.c_void_p(ctypes.addressof(self.shm_buffer)), self.shm_size, self._nat_d,
+                                               ctypes.byref(h)))
+        self._native = h
+        for pid, o in enumerate(self.current_obs):
+            if o is not None and pid not in self.current_pids:
+                a = np.ascontiguousarray(o, dtype=np.float32)
+                N.check(N.lib().rlppo_collector_set_obs(h, pid, a.ctypes.data, a.shape[0], 0))
+        for pid in self.current_pids:   # (in the order the Python loop would serve them)
+            a = np.ascontiguousarray(self.current_obs[pid], dtype=np.float32)
+            N.check(N.lib().rlppo_collector_set_obs(h, pid, a.ctypes.data, a.shape[0], 1))
+        self.average_reward = self._average_reward
+        self._nat_obs = np.zeros((max(64, 8 * n), self._nat_d), dtype=np.float32)
+        self._nat_act_shape = None
+        return True
+
+    @torch.no_grad()
+    def _collect_timesteps_native(self, n):
+        """collect_timesteps with the per-message work in C++ (csrc/collector.cpp): per inference ready -> policy.get_action -> send ->
+        collect; same results as the Python loop above, value for value (tests/test_native_collector.py)."""
+        t1 = time.perf_counter()
+        L, h = N.lib(), self._native
+        n_collected = 0
+        n_obs_per_inference = min(self.min_inference_size, max(1, len(self.processes)))
+        rows, got = ctypes.c_int64(0), ctypes.c_int64(0)
+        st = self.obs_stats
+        count, since = ctypes.c_int64(0), ctypes.c_int64(0)
+        one = np.ones(1, dtype=np.float32)
+        while n_collected < n:
+            rc = L.rlppo_collector_ready(h, self._nat_obs.ctypes.data, self._nat_obs.shape[0], ctypes.byref(rows))
+            if rc == 1002:  # more waiting agents than the staging matrix holds: grow it
+                self._nat_obs = np.zeros((2 * self._nat_obs.shape[0], self._nat_d), dtype=np.float32)
+                continue
+            N.check(rc)
+            if rows.value:
+                actions, log_probs = self.policy.get_action(self._nat_obs[:rows.value])
+                a = np.ascontiguousarray(actions.numpy() if isinstance(actions, torch.Tensor) else actions, dtype=np.float32)
+                lp = np.ascontiguousarray(log_probs.numpy() if isinstance(log_probs, torch.Tensor) else log_probs, dtype=np.float32)
+                self._nat_act_shape = a.shape[1:]
+                N.check(L.rlppo_collector_send(h, a.ctypes.data, max(1, a.size // rows.value), lp.ctypes.data))
+            mode, mean, std = 0, one, one
+            if self.standardize_obs:
+                if self.per_feature_obs_standardization:
+                    mode, mean, std = 2, np.ascontiguousarray(st.mean.reshape(-1), np.float32), np.ascontiguousarray(st.std.reshape(-1), np.float32)
+                else:   # the scalars of feature 0 (quirk Q5), as they stand when the wait begins
+                    mode, mean, std = 1, np.asarray([st.mean[0]], np.float32), np.asarray([st.std[0]], np.float32)
+                count.value, since.value = int(st.count), int(self.steps_since_obs_stats_update)
+            rc = L.rlppo_collector_collect(h, n_obs_per_inference, mode, mean.ctypes.data, std.ctypes.data,
+                                           st.running_mean.ctypes.data if mode else None, st.running_variance.ctypes.data if mode else None,
+                                           ctypes.byref(count), 0, int(self.steps_per_obs_stats_increment), ctypes.byref(since), ctypes.byref(got))
+            if rc == 1003:
+                raise TimeoutError("BatchedAgentManager: no worker message for a minute")
+            N.check(rc)
+            if mode:
+                st.count, self.steps_since_obs_stats_update = int(count.value), int(since.value)
+            n_collected += got.value
+        n_steps, aw, n_met, met_floats = ctypes.c_int64(0), ctypes.c_int32(0), ctypes.c_int64(0), ctypes.c_int64(0)
+        N.check(L.rlppo_collector_finish(h, ctypes.byref(n_steps), ctypes.byref(aw), ctypes.byref(n_met), ctypes.byref(met_floats)))
+        k, d, w = int(n_steps.value), self._nat_d, max(1, int(aw.value))
+        states, nxt = np.empty((k, d), np.float32), np.empty((k, d), np.float32)
+        actions, logp = np.empty((k, w), np.float32), np.empty(k, np.float32)
+        rewards, dones, trunc = np.empty(k, np.float64), np.empty(k, np.float64), np.empty(k, np.float64)
+        mvals, mshapes = np.empty(int(met_floats.value), np.float32), np.zeros((int(n_met.value), 9), np.int32)
+        N.check(L.rlppo_collector_emit(h, states.ctypes.data, actions.ctypes.data, logp.ctypes.data, rewards.ctypes.data, nxt.ctypes.data,
+                                       dones.ctypes.data, trunc.ctypes.data, mvals.ctypes.data, mshapes.ctypes.data))
+        metrics, o = [], 0
+        for rec in mshapes:
+            shape = tuple(int(x) for x in rec[1:1 + rec[0]]) if rec[0] else (0,)
+            size = int(np.prod(shape)) if rec[0] else 0
+            metrics.append(mvals[o:o + size].copy().reshape(shape))
+            o += size
+        if k == 0:
+            cols = tuple(np.asarray([]) for _ in range(7))
+        else:
+            cols = (states, actions.reshape((k,) + tuple(self._nat_act_shape or ())), logp, rewards, nxt, dones, trunc)
+        self.cumulative_timesteps += n_collected
+        return cols, metrics, n_collected, time.perf_counter() - t1
+
     def cleanup(self):
+        if self._native is not None:
+            self._average_reward = self.average_reward
+            N.lib().rlppo_collector_destroy(self._native)
+            self._native = None
         for w in self.processes:
             try:
                 w.stop()

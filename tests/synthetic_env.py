@@ -150,3 +150,30 @@ def make_wire_env():
 def step_count_metrics(state):
     """A metrics function (what Learner passes as collect_metrics_fn): float32 vector of length 3."""
     return np.asarray([state, 2.0 * state, -1.0], dtype=np.float32)
+
+
+class SyntheticVaryingEnv(SyntheticEnv):
+    """A match whose number of agents changes at every reset (2 -> 3 -> 1 -> 2 ...): the collector must flush the environment's
+    trajectory and pad the last step's next states (batched_agent_manager.py: `nxt.shape[0] != prev_n`)."""
+
+    def __init__(self):
+        super().__init__(obs_dim=13, n_actions=7, n_agents=2, ep_len=4, seed=3)
+        self._cycle, self._k = (2, 3, 1), 0
+
+    def reset(self):
+        self.n_agents = self._cycle[self._k % 3]
+        self._k += 1
+        return super().reset()
+
+    def step(self, actions):
+        obs, rew, done, truncated, info = super().step(actions)
+        info = {"state": self.t}
+        return obs, rew, done, truncated, info
+
+
+def make_varying_env():
+    return SyntheticVaryingEnv()
+
+
+def make_continuous_wire_env():
+    return SyntheticEnv(obs_dim=13, n_actions=3, n_agents=2, ep_len=6, seed=4, kind="continuous")
