@@ -42,6 +42,7 @@ extern "C" {
 #define RLPPO_ERR_ARG 1001        /* bad argument / unsupported shape */
 #define RLPPO_ERR_WORKSPACE 1002  /* workspace too small */
 #define RLPPO_ERR_COLLECT_TIMEOUT 1003  /* rlppo_collector_collect: no worker message for a minute */
+#define RLPPO_ERR_INTERRUPTED 1004     /* rlppo_collector_collect: a signal arrived; n_collected holds the progress, call again with resume = 1 */
 
 /* policy head codes == the reference's `policy_type` (ppo_learner.py:34-50) */
 #define RLPPO_HEAD_DISCRETE 0
@@ -392,6 +393,7 @@ int rlppo_learn_report(void *stream, const rlppo_report_args *args);
  *   ready: the stacked observations of the workers waiting for actions (at most cap_rows rows) -> n_rows.
  *   send: actions[n_rows][act_width] float32 and log_probs[n_rows] for exactly those rows: recorded, and sent to the workers.
  *   collect: blocks until messages worth >= min_obs agent-steps have been banked (a message counts its prev_n_agents) -> n_collected;
+ *     a signal makes it return RLPPO_ERR_INTERRUPTED with the progress so far (the host's handlers run; resume = 1 continues the wait);
  *     standardize 0 = off, 1 = (x - mean[0]) / std[0] clipped to +-5 (the reference's scalars, quirk Q5), 2 = per feature;
  *     stats_mean / stats_var / stats_count / steps_since_increment: the WelfordRunningStat's state (float32 arrays, float64 when
  *     stats_f64) and the manager's cadence counter, advanced in place every steps_per_increment-th message with the RAW rows.
@@ -405,7 +407,7 @@ int rlppo_collector_destroy(void *handle);
 int rlppo_collector_set_obs(void *handle, int32_t worker, const float *obs, int32_t rows, int32_t ready);
 int rlppo_collector_ready(void *handle, float *obs_out, int64_t cap_rows, int64_t *n_rows);
 int rlppo_collector_send(void *handle, const float *actions, int32_t act_width, const float *log_probs);
-int rlppo_collector_collect(void *handle, int64_t min_obs, int32_t standardize, const float *mean, const float *stdv, void *stats_mean,
+int rlppo_collector_collect(void *handle, int64_t min_obs, int32_t resume, int32_t standardize, const float *mean, const float *stdv, void *stats_mean,
                             void *stats_var, int64_t *stats_count, int32_t stats_f64, int64_t steps_per_increment, int64_t *steps_since_increment,
                             int64_t *n_collected);
 int rlppo_collector_finish(void *handle, int64_t *n_steps, int32_t *act_width, int64_t *n_metrics, int64_t *metrics_floats);

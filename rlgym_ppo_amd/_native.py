@@ -136,7 +136,7 @@ SIGNATURES = {
     "rlppo_collector_set_obs": (c_int32, [c_void_p, c_int32, c_void_p, c_int32, c_int32]),
     "rlppo_collector_ready": (c_int32, [c_void_p, c_void_p, c_int64, POINTER(c_int64)]),
     "rlppo_collector_send": (c_int32, [c_void_p, c_void_p, c_int32, c_void_p]),
-    "rlppo_collector_collect": (c_int32, [c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, POINTER(c_int64), c_int32, c_int64,
+    "rlppo_collector_collect": (c_int32, [c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, POINTER(c_int64), c_int32, c_int64,
                                           POINTER(c_int64), POINTER(c_int64)]),
     "rlppo_collector_finish": (c_int32, [c_void_p, POINTER(c_int64), POINTER(c_int32), POINTER(c_int64), POINTER(c_int64)]),
     "rlppo_collector_emit": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),

@@ -441,15 +441,21 @@ class BatchedAgentManager(object):
                 else:   # the scalars of feature 0 (quirk Q5), as they stand when the wait begins
                     mode, mean, std = 1, np.asarray([st.mean[0]], np.float32), np.asarray([st.std[0]], np.float32)
                 count.value, since.value = int(st.count), int(self.steps_since_obs_stats_update)
-            rc = L.rlppo_collector_collect(h, n_obs_per_inference, mode, mean.ctypes.data, std.ctypes.data,
-                                           st.running_mean.ctypes.data if mode else None, st.running_variance.ctypes.data if mode else None,
-                                           ctypes.byref(count), 0, int(self.steps_per_obs_stats_increment), ctypes.byref(since), ctypes.byref(got))
+            want, resume = n_obs_per_inference, 0
+            while True:
+                rc = L.rlppo_collector_collect(h, want, resume, mode, mean.ctypes.data, std.ctypes.data,
+                                               st.running_mean.ctypes.data if mode else None, st.running_variance.ctypes.data if mode else None,
+                                               ctypes.byref(count), 0, int(self.steps_per_obs_stats_increment), ctypes.byref(since), ctypes.byref(got))
+                if mode:
+                    st.count, self.steps_since_obs_stats_update = int(count.value), int(since.value)
+                n_collected += got.value
+                if rc != 1004:
+                    break
+                # a signal interrupted the wait; python's handlers have run by now (a KeyboardInterrupt never gets here): wait on
+                want, resume = max(1, want - got.value), 1
             if rc == 1003:
                 raise TimeoutError("BatchedAgentManager: no worker message for a minute")
             N.check(rc)
-            if mode:
-                st.count, self.steps_since_obs_stats_update = int(count.value), int(since.value)
-            n_collected += got.value
         n_steps, aw, n_met, met_floats = ctypes.c_int64(0), ctypes.c_int32(0), ctypes.c_int64(0), ctypes.c_int64(0)
         N.check(L.rlppo_collector_finish(h, ctypes.byref(n_steps), ctypes.byref(aw), ctypes.byref(n_met), ctypes.byref(met_floats)))
         k, d, w = int(n_steps.value), self._nat_d, max(1, int(aw.value))

@@ -185,14 +185,15 @@ int rlppo_collector_send(void *handle, const float *actions, int32_t act_width, 
 }
 
 // _collect_responses(min_obs) + the promotion of next_obs + _sync_trajectories of one collect_timesteps iteration.
+// resume != 0: the continuation of a wait that returned RLPPO_ERR_INTERRUPTED (min_obs = what is still missing).
 // standardize: 0 = off; 1 = (x - mean[0]) / std[0] (the reference's scalars, quirk Q5); 2 = per feature.  stats_*: the
 // WelfordRunningStat's arrays (float32 when stats_f64 == 0) and count, advanced in place every steps_per_increment-th message.
-int rlppo_collector_collect(void *handle, int64_t min_obs, int32_t standardize, const float *mean, const float *stdv, void *stats_mean,
+int rlppo_collector_collect(void *handle, int64_t min_obs, int32_t resume, int32_t standardize, const float *mean, const float *stdv, void *stats_mean,
                             void *stats_var, int64_t *stats_count, int32_t stats_f64, int64_t steps_per_increment, int64_t *steps_since_increment,
                             int64_t *n_collected) {
     Collector *c = static_cast<Collector *>(handle);
     if (!c || !n_collected || (standardize && (!mean || !stdv || !stats_mean || !stats_var || !stats_count || !steps_since_increment))) return RLPPO_ERR_ARG;
-    c->current_pids.clear();
+    if (!resume) c->current_pids.clear();
     std::vector<pollfd> fds(c->n);
     for (int i = 0; i < c->n; ++i) fds[i] = pollfd{c->w[i].fd, POLLIN, 0};
     alignas(16) unsigned char buf[PACKET_MAX];
@@ -200,9 +201,13 @@ int rlppo_collector_collect(void *handle, int64_t min_obs, int32_t standardize, 
     const int d = c->d;
     while (got < min_obs) {
         int rc = poll(fds.data(), (nfds_t)c->n, 60000);
-        if (rc < 0 && errno == EINTR) continue;
+        if (rc < 0 && errno == EINTR) {  // a signal: hand control back so that the host's handlers run (Ctrl-C, alarms); resume != 0 continues this wait
+            *n_collected = got;
+            return RLPPO_ERR_INTERRUPTED;
+        }
         if (rc <= 0) return RLPPO_ERR_COLLECT_TIMEOUT;  // a minute without a worker message: the Python side reports it
         for (int pid = 0; pid < c->n; ++pid) {
+            if ((fds[pid].revents & (POLLERR | POLLHUP | POLLNVAL)) && !(fds[pid].revents & POLLIN)) return RLPPO_ERR_ARG;  // a dead socket would spin this loop
             if (!(fds[pid].revents & POLLIN)) continue;
             Worker &w = c->w[pid];
             const ssize_t len = recv(w.fd, buf, sizeof(buf), 0);

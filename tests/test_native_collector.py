@@ -101,3 +101,40 @@ def test_native_loop_with_three_workers_is_structurally_right():
         assert (dones + truncated).max() <= 1.0 and (dones + truncated)[-1] == 1.0
         assert np.abs(next_states).max() <= 5.0 and len(metrics) > 0
     assert state["total"] == total and state["stats"][2] > 6 and state["avg"] is not None
+
+
+def test_signals_interrupt_the_native_wait_without_changing_the_results():
+    """A signal that arrives while the C++ loop waits for workers makes it hand control back (RLPPO_ERR_INTERRUPTED) so that python's
+    handlers run -- Ctrl-C works -- and the wait is resumed: with a 1 kHz timer firing throughout, the rollout is still the Python
+    loop's, value for value; a handler that raises ends the collection with its exception."""
+    import signal
+    kw = dict(env_fn=synthetic_env.make_wire_env, policy=_DiscretePolicy(), calls=(60, 25))
+    py = _run(False, **kw)
+    ticks = []
+    old = signal.signal(signal.SIGALRM, lambda *a: ticks.append(1))
+    signal.setitimer(signal.ITIMER_REAL, 0.001, 0.001)
+    try:
+        nat = _run(True, **kw)
+    finally:
+        signal.setitimer(signal.ITIMER_REAL, 0, 0)
+        signal.signal(signal.SIGALRM, old)
+    assert len(ticks) > 10
+    _same(py, nat)
+
+    class Stop(Exception):
+        pass
+
+    def raising(*a):
+        raise Stop()
+    from rlgym_ppo_amd.batched_agents import BatchedAgentManager
+    mgr = BatchedAgentManager(_DiscretePolicy(), min_inference_size=1, seed=5, standardize_obs=True)
+    old = signal.signal(signal.SIGALRM, raising)
+    try:
+        mgr.init_processes(1, synthetic_env.make_wire_env, shm_buffer_size=4096)
+        signal.setitimer(signal.ITIMER_REAL, 0.05, 0)
+        with pytest.raises(Stop):
+            mgr.collect_timesteps(10_000_000)
+    finally:
+        signal.setitimer(signal.ITIMER_REAL, 0, 0)
+        signal.signal(signal.SIGALRM, old)
+        mgr.cleanup()
