@@ -395,8 +395,10 @@ int rlppo_learn_report(void *stream, const rlppo_report_args *args);
  *   collect: blocks until messages worth >= min_obs agent-steps have been banked (a message counts its prev_n_agents) -> n_collected;
  *     a signal makes it return RLPPO_ERR_INTERRUPTED with the progress so far (the host's handlers run; resume = 1 continues the wait);
  *     standardize 0 = off, 1 = (x - mean[0]) / std[0] clipped to +-5 (the reference's scalars, quirk Q5), 2 = per feature;
- *     stats_mean / stats_var / stats_count / steps_since_increment: the WelfordRunningStat's state (float32 arrays, float64 when
- *     stats_f64) and the manager's cadence counter, advanced in place every steps_per_increment-th message with the RAW rows.
+ *     stats_mean / stats_var / stats_count / steps_since_increment: the WelfordRunningStat's state (float32 arrays; float64 when
+ *     stats_f64 -- statistics restored from JSON -- and then mean / std are doubles too and the standardisation is formed in float64
+ *     and rounded once, as numpy does) and the manager's cadence counter, advanced in place every steps_per_increment-th message with
+ *     the RAW rows.
  *   finish: flushes every trajectory -> the sizes _emit needs; emit: states / next_states [n][obs_dim], actions [n][act_width],
  *     log_probs [n] float32, rewards / dones / truncated [n] float64 (the dtypes the reference's lists become), and every message's
  *     metrics record (values flat; 9 ints per record: rank, dimensions).
@@ -407,7 +409,7 @@ int rlppo_collector_destroy(void *handle);
 int rlppo_collector_set_obs(void *handle, int32_t worker, const float *obs, int32_t rows, int32_t ready);
 int rlppo_collector_ready(void *handle, float *obs_out, int64_t cap_rows, int64_t *n_rows);
 int rlppo_collector_send(void *handle, const float *actions, int32_t act_width, const float *log_probs);
-int rlppo_collector_collect(void *handle, int64_t min_obs, int32_t resume, int32_t standardize, const float *mean, const float *stdv, void *stats_mean,
+int rlppo_collector_collect(void *handle, int64_t min_obs, int32_t resume, int32_t standardize, const void *mean, const void *stdv, void *stats_mean,
                             void *stats_var, int64_t *stats_count, int32_t stats_f64, int64_t steps_per_increment, int64_t *steps_since_increment,
                             int64_t *n_collected);
 int rlppo_collector_finish(void *handle, int64_t *n_steps, int32_t *act_width, int64_t *n_metrics, int64_t *metrics_floats);

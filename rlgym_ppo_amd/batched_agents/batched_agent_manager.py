@@ -372,15 +372,20 @@ class BatchedAgentManager(object):
     # ----------------------------------------------------------------------------------- native collection
     def _stats_native_ok(self):
         st = self.obs_stats
-        return (not self.standardize_obs) or (st is not None and all(
-            isinstance(a, np.ndarray) and a.dtype == np.float32 and a.flags.c_contiguous and a.ndim == 1
-            for a in (st.running_mean, st.running_variance)))
+        if not self.standardize_obs:
+            return True
+        if st is None:
+            return False
+        arrs = (st.running_mean, st.running_variance)
+        # float32 (a fresh run) or float64 (restored from JSON: running_stats.py:120-125 -- numpy then standardises in float64)
+        return all(isinstance(a, np.ndarray) and a.flags.c_contiguous and a.ndim == 1 for a in arrs) and \
+            arrs[0].dtype == arrs[1].dtype and arrs[0].dtype in (np.float32, np.float64) and isinstance(st.count, (int, np.integer))
 
     def _native_ok(self):
         if self._native is not None:
             if not self._stats_native_ok():
-                raise RuntimeError("BatchedAgentManager: the observation statistics changed dtype / layout after the native collector "
-                                   "started (restored from JSON mid-run?); set agent.native_collect = False before the first collect")
+                raise RuntimeError("BatchedAgentManager: the observation statistics are no longer 1-D float32 / float64 arrays of one dtype "
+                                   "(the native collector advances them in place); set agent.native_collect = False before the first collect")
             return True
         if not (self.native_collect and self.processes and all(isinstance(w, _ProcessWorker) for w in self.processes)):
             return False
@@ -434,18 +439,21 @@ class BatchedAgentManager(object):
                 lp = np.ascontiguousarray(log_probs.numpy() if isinstance(log_probs, torch.Tensor) else log_probs, dtype=np.float32)
                 self._nat_act_shape = a.shape[1:]
                 N.check(L.rlppo_collector_send(h, a.ctypes.data, max(1, a.size // rows.value), lp.ctypes.data))
-            mode, mean, std = 0, one, one
+            mode, mean, std, f64 = 0, one, one, 0
             if self.standardize_obs:
+                f64 = int(st.running_mean.dtype == np.float64)
+                dt = np.float64 if f64 else np.float32
                 if self.per_feature_obs_standardization:
-                    mode, mean, std = 2, np.ascontiguousarray(st.mean.reshape(-1), np.float32), np.ascontiguousarray(st.std.reshape(-1), np.float32)
+                    bc = lambda a: np.ascontiguousarray(np.broadcast_to(np.asarray(a).reshape(-1), (self._nat_d,)), dt)  # (fewer than two samples: a (1,) constant)
+                    mode, mean, std = 2, bc(st.mean), bc(st.std)
                 else:   # the scalars of feature 0 (quirk Q5), as they stand when the wait begins
-                    mode, mean, std = 1, np.asarray([st.mean[0]], np.float32), np.asarray([st.std[0]], np.float32)
+                    mode, mean, std = 1, np.asarray([st.mean[0]], dt), np.asarray([st.std[0]], dt)
                 count.value, since.value = int(st.count), int(self.steps_since_obs_stats_update)
             want, resume = n_obs_per_inference, 0
             while True:
                 rc = L.rlppo_collector_collect(h, want, resume, mode, mean.ctypes.data, std.ctypes.data,
                                                st.running_mean.ctypes.data if mode else None, st.running_variance.ctypes.data if mode else None,
-                                               ctypes.byref(count), 0, int(self.steps_per_obs_stats_increment), ctypes.byref(since), ctypes.byref(got))
+                                               ctypes.byref(count), f64, int(self.steps_per_obs_stats_increment), ctypes.byref(since), ctypes.byref(got))
                 if mode:
                     st.count, self.steps_since_obs_stats_update = int(count.value), int(since.value)
                 n_collected += got.value

@@ -188,7 +188,7 @@ int rlppo_collector_send(void *handle, const float *actions, int32_t act_width, 
 // resume != 0: the continuation of a wait that returned RLPPO_ERR_INTERRUPTED (min_obs = what is still missing).
 // standardize: 0 = off; 1 = (x - mean[0]) / std[0] (the reference's scalars, quirk Q5); 2 = per feature.  stats_*: the
 // WelfordRunningStat's arrays (float32 when stats_f64 == 0) and count, advanced in place every steps_per_increment-th message.
-int rlppo_collector_collect(void *handle, int64_t min_obs, int32_t resume, int32_t standardize, const float *mean, const float *stdv, void *stats_mean,
+int rlppo_collector_collect(void *handle, int64_t min_obs, int32_t resume, int32_t standardize, const void *mean, const void *stdv, void *stats_mean,
                             void *stats_var, int64_t *stats_count, int32_t stats_f64, int64_t steps_per_increment, int64_t *steps_since_increment,
                             int64_t *n_collected) {
     Collector *c = static_cast<Collector *>(handle);
@@ -245,13 +245,27 @@ int rlppo_collector_collect(void *handle, int64_t min_obs, int32_t resume, int32
                 } else {
                     ++*steps_since_increment;
                 }
-                for (int r = 0; r < rows; ++r)
-                    for (int k = 0; k < d; ++k) {
-                        const float mu = standardize == 2 ? mean[k] : mean[0], sd = standardize == 2 ? stdv[k] : stdv[0];
-                        float v = (nxt[(size_t)r * d + k] - mu) / sd;
-                        v = v < -5.f ? -5.f : (v > 5.f ? 5.f : v);  // np.clip: NaN stays NaN
-                        nxt[(size_t)r * d + k] = v;
-                    }
+                if (stats_f64) {
+                    // statistics restored from JSON are float64 (running_stats.py:120-125): numpy then forms (x - mean) / std in
+                    // float64 and the observation is rounded to float32 once, when it meets the policy / the experience buffer
+                    const double *m64 = static_cast<const double *>(mean), *s64 = static_cast<const double *>(stdv);
+                    for (int r = 0; r < rows; ++r)
+                        for (int k = 0; k < d; ++k) {
+                            const double mu = standardize == 2 ? m64[k] : m64[0], sd = standardize == 2 ? s64[k] : s64[0];
+                            double v = ((double)nxt[(size_t)r * d + k] - mu) / sd;
+                            v = v < -5.0 ? -5.0 : (v > 5.0 ? 5.0 : v);
+                            nxt[(size_t)r * d + k] = (float)v;
+                        }
+                } else {
+                    const float *m32 = static_cast<const float *>(mean), *s32 = static_cast<const float *>(stdv);
+                    for (int r = 0; r < rows; ++r)
+                        for (int k = 0; k < d; ++k) {
+                            const float mu = standardize == 2 ? m32[k] : m32[0], sd = standardize == 2 ? s32[k] : s32[0];
+                            float v = (nxt[(size_t)r * d + k] - mu) / sd;
+                            v = v < -5.f ? -5.f : (v > 5.f ? 5.f : v);  // np.clip: NaN stays NaN
+                            nxt[(size_t)r * d + k] = v;
+                        }
+                }
             }
             // episode-reward bookkeeping (python floats: doubles)
             for (int i = 0; i < prev_n; ++i) {

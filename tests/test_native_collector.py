@@ -23,13 +23,17 @@ class _ContinuousPolicy:
         return torch.as_tensor(np.tanh(obs[:, :3] * 0.3).astype(np.float32)), torch.as_tensor(-np.abs(obs[:, 1]).astype(np.float32))
 
 
-def _run(native, env_fn, policy, calls, n_proc=1, metrics_fn=None, standardize=True, per_feature=False, min_inference_size=1):
+def _run(native, env_fn, policy, calls, n_proc=1, metrics_fn=None, standardize=True, per_feature=False, min_inference_size=1, restored=None):
     from rlgym_ppo_amd.batched_agents import BatchedAgentManager
+    from rlgym_ppo_amd.util import WelfordRunningStat
     mgr = BatchedAgentManager(policy, min_inference_size=min_inference_size, seed=5, standardize_obs=standardize)
     mgr.native_collect = native
     mgr.per_feature_obs_standardization = per_feature
     try:
         shapes = mgr.init_processes(n_proc, env_fn, collect_metrics_fn=metrics_fn, shm_buffer_size=4096)
+        if restored is not None:   # what Learner.load does with a checkpoint's statistics: float64 arrays from JSON (learner.py:308-310)
+            mgr.obs_stats = WelfordRunningStat(1)
+            mgr.obs_stats.from_json(restored)
         out = [mgr.collect_timesteps(k) for k in calls]
         assert (mgr._native is not None) == native, "the loop that ran is not the one the test asked for"
         st = mgr.obs_stats
@@ -82,6 +86,27 @@ def test_native_loop_equals_the_python_loop_with_one_worker(case):
     if case == "varying_team":   # the flush at a team-size change really happened: some next-state rows are the zero padding
         nxt = np.concatenate([o[0][4] for o in nat[1]])
         assert (np.abs(nxt).sum(1) == 0).any()
+
+
+@pytest.mark.parametrize("per_feature,count", [(False, 40), (True, 40), (True, 1)])
+def test_native_loop_with_statistics_restored_from_a_checkpoint(per_feature, count, capsys):
+    """A resumed run: WelfordRunningStat.from_json leaves float64 arrays (running_stats.py:120-125), numpy then forms the standardised
+    observation in float64 and it is rounded to float32 where it meets the policy / the experience buffer.  The C++ loop does the same
+    -- float64 statistics advanced in place bit for bit, (x - mean) / std in double, one rounding -- so a resumed run keeps the fast
+    loop: equal to the Python loop's float64 arrays once those are rounded to float32.  (count 1: the constant mean / std branch.)"""
+    rs = np.random.RandomState(3)
+    book = {"mean": (rs.randn(13) * 0.3).tolist(), "var": (np.abs(rs.randn(13)) * 30 + 5).tolist(), "shape": [13], "count": count}
+    kw = dict(env_fn=synthetic_env.make_wire_env, policy=_DiscretePolicy(), calls=(40, 17), per_feature=per_feature, restored=book)
+    (s0, o0, t0), (s1, o1, t1) = _run(False, **kw), _run(True, **kw)
+    assert s0 == s1 and t0["total"] == t1["total"] and t0["since"] == t1["since"] and t0["avg"] == t1["avg"]
+    for x, y in zip(t0["stats"][:2], t1["stats"][:2]):
+        assert x.dtype == y.dtype == np.float64 and np.array_equal(x, y)
+    assert t0["stats"][2] == t1["stats"][2] > count
+    for (ea, _, na, _), (eb, _, nb, _) in zip(o0, o1):
+        assert na == nb
+        for x, y, name in zip(ea, eb, ("states", "actions", "log_probs", "rewards", "next_states", "dones", "truncated")):
+            assert x.shape == y.shape and np.array_equal(np.asarray(x, y.dtype), y), name
+        assert ea[0].dtype == np.float64 and eb[0].dtype == np.float32
 
 
 def test_native_loop_with_three_workers_is_structurally_right():
