@@ -427,6 +427,7 @@ class BatchedAgentManager(object):
         st = self.obs_stats
         count, since = ctypes.c_int64(0), ctypes.c_int64(0)
         one = np.ones(1, dtype=np.float32)
+        stats_key, cached = None, None
         while n_collected < n:
             rc = L.rlppo_collector_ready(h, self._nat_obs.ctypes.data, self._nat_obs.shape[0], ctypes.byref(rows))
             if rc == 1002:  # more waiting agents than the staging matrix holds: grow it
@@ -441,13 +442,17 @@ class BatchedAgentManager(object):
                 N.check(L.rlppo_collector_send(h, a.ctypes.data, max(1, a.size // rows.value), lp.ctypes.data))
             mode, mean, std, f64 = 0, one, one, 0
             if self.standardize_obs:
-                f64 = int(st.running_mean.dtype == np.float64)
-                dt = np.float64 if f64 else np.float32
-                if self.per_feature_obs_standardization:
-                    bc = lambda a: np.ascontiguousarray(np.broadcast_to(np.asarray(a).reshape(-1), (self._nat_d,)), dt)  # (fewer than two samples: a (1,) constant)
-                    mode, mean, std = 2, bc(st.mean), bc(st.std)
-                else:   # the scalars of feature 0 (quirk Q5), as they stand when the wait begins
-                    mode, mean, std = 1, np.asarray([st.mean[0]], dt), np.asarray([st.std[0]], dt)
+                key = (int(st.count), self.per_feature_obs_standardization, id(st.running_mean))
+                if key != stats_key:   # (mean / std move only when the statistics advanced: every ~6th message)
+                    stats_key = key
+                    f64 = int(st.running_mean.dtype == np.float64)
+                    dt = np.float64 if f64 else np.float32
+                    if self.per_feature_obs_standardization:
+                        bc = lambda a: np.ascontiguousarray(np.broadcast_to(np.asarray(a).reshape(-1), (self._nat_d,)), dt)  # (fewer than two samples: a (1,) constant)
+                        cached = (2, bc(st.mean), bc(st.std), f64)
+                    else:   # the scalars of feature 0 (quirk Q5), as they stand when the wait begins
+                        cached = (1, np.asarray([st.mean[0]], dt), np.asarray([st.std[0]], dt), f64)
+                mode, mean, std, f64 = cached
                 count.value, since.value = int(st.count), int(self.steps_since_obs_stats_update)
             want, resume = n_obs_per_inference, 0
             while True:
