@@ -192,7 +192,7 @@ def kernel_breakdown(learner, only=None):
 # line is READ FROM THESE FILES (builder-run rocprofv3 --pmc passes: bench.py cannot profile itself) and carries a `traffic_source`.
 # [r6] Each file is stamped with rlppo_build_id() of the library it was measured on; a number is replayed only while that is the
 # library this process has loaded -- after a kernel change the line says `traffic: null, stale` until the pass is regenerated.
-PMC_NOTE = " (builder-run rocprofv3 --pmc pass on this build, not measured in this run)"
+PMC_NOTE = " (builder-run rocprofv3 --pmc passes, replayed)"
 
 
 def build_id():
@@ -214,7 +214,7 @@ def replay_traffic(stem, key):
             if theirs != mine:
                 seen.append("%s (build %s)" % (name, theirs or "unstamped"))
                 continue
-            return round(t[key]["hbm_bytes"]), "profiles/" + name + PMC_NOTE + ", build " + mine
+            return round(t[key]["hbm_bytes"]), "build " + mine + ": profiles/" + name + PMC_NOTE
         except Exception:
             continue
     if seen:
@@ -797,7 +797,7 @@ def cfg5_traffic(bf16):
             continue
         for k, v in t.items():
             if "gemm_nt_b16" in k and ("<1," in k or "<1>" in k or "fwd" in k):
-                return round(v["hbm_bytes"]), "profiles/" + name + PMC_NOTE + ", build " + mine
+                return round(v["hbm_bytes"]), "build " + mine + ": profiles/" + name + PMC_NOTE
     if seen:
         return None, "stale: " + seen[0] + " was not measured on this library (build " + mine + ")"
     return None, "no committed PMC pass"
