@@ -991,8 +991,24 @@ def process_collect_leg(n_proc=8, timesteps=50_000, limit_s=120):
         pol.get_action = counted
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        _, _, n, _ = learner.agent.collect_timesteps(timesteps)
+        exp, _, n, _ = learner.agent.collect_timesteps(timesteps)
         dt = time.perf_counter() - t0
+        # ... and the rest of the reference's iteration on what was collected (learner.py:157-162: add_new_experience = value pass + GAE +
+        # buffer submit, then PPOLearner.learn at its defaults' batch = minibatch = 50,000, 1 epoch as in example.py:74-88)
+        # -- in its steady state: the 150,000-sample buffer full (three collections), one learn() behind it to warm the launches
+        pol.get_action = inner
+        for _ in range(3):
+            learner.add_new_experience(exp)
+        learner.ppo_learner.learn(learner.experience_buffer)
+        torch.cuda.synchronize()
+        t_add = time.perf_counter()
+        learner.add_new_experience(exp)
+        torch.cuda.synchronize()
+        t_learn = time.perf_counter()
+        lrep = learner.ppo_learner.learn(learner.experience_buffer)
+        torch.cuda.synchronize()
+        t_end = time.perf_counter()
+        add_ms, learn_ms = (t_learn - t_add) * 1e3, (t_end - t_learn) * 1e3
         rows = np.array([c[0] for c in calls])
         secs = np.array([c[1] for c in calls])
         log("process_collect: %d worker processes, %d timesteps in %.3f s; %d get_action calls of %.1f observations on average, %.1f us each "
@@ -1003,6 +1019,9 @@ def process_collect_leg(n_proc=8, timesteps=50_000, limit_s=120):
                     n_proc=n_proc, timesteps=int(n), seconds=round(dt, 3), steps_per_s=round(n / dt), get_action_calls=len(calls),
                     mean_obs_per_call=round(float(rows.mean()), 1), us_per_get_action_median=round(1e6 * float(np.median(secs)), 1),
                     frac_of_wall_in_get_action=round(float(secs.sum() / dt), 3),
+                    collector="C++ (rlppo_collector_*)" if getattr(learner.agent, "_native", None) is not None else "Python",
+                    # the whole iteration of the reference's loop on this collection: collect + add_new_experience + learn (1 epoch)
+                    add_new_experience_ms=round(add_ms, 2), learn_ms=round(learn_ms, 2), iteration_steps_per_s=round(n / (dt + (add_ms + learn_ms) / 1e3)),
                     # the small call's transport counters over this collection (ppo/_mlp.py::ActGraph) and the 1 % spot check
                     transport={k: int(sum(getattr(g, k) for g in pol._graphs.values())) for k in ("calls", "polled", "poll_timeouts", "late_retries", "stale_relaunches")},
                     spot_checked=check["n"], spot_check_mismatches=check["bad"], spot_check_s=round(check["s"], 4))

@@ -89,3 +89,5 @@ def test_process_collect_leg_runs_and_counts_what_it_says():
     tr = out["transport"]
     assert tr["calls"] >= out["get_action_calls"] and tr["polled"] + tr["poll_timeouts"] >= tr["calls"]
     assert out["spot_checked"] >= out["get_action_calls"] // 100 and out["spot_check_mismatches"] == 0
+    # [r6] the leg also runs the rest of the reference's iteration on what it collected, and says which collection loop served it
+    assert out["collector"].startswith("C++") and out["add_new_experience_ms"] > 0 and out["learn_ms"] > 0 and out["iteration_steps_per_s"] > 0

@@ -8,7 +8,7 @@ if __name__ == "__main__":   # (the worker processes re-import the main module: 
     import bench
     from rlgym_ppo_amd.batched_agents import BatchedAgentManager
     keys = ("n_proc", "steps_per_s", "seconds", "get_action_calls", "mean_obs_per_call", "us_per_get_action_median", "frac_of_wall_in_get_action",
-            "transport", "spot_checked", "spot_check_mismatches", "error")
+            "transport", "spot_checked", "spot_check_mismatches", "collector", "add_new_experience_ms", "learn_ms", "iteration_steps_per_s", "error")
     init = BatchedAgentManager.__init__
     for n in ([int(x) for x in sys.argv[1:]] or [8, 32]):
         for rnd in range(2):
