@@ -833,12 +833,19 @@ __global__ __launch_bounds__(256) void learn_report_kernel(rlppo_report_args r) 
         last = atomicAdd(&ws->tickets, 1u) == gridDim.x - 1;
     }
     __syncthreads();
-    if (!last || threadIdx.x != 0) return;
+    if (!last) return;
+    // the last arriver: its threads fetch the slots side by side (one thread walking 128 dependent loads took 19 of the kernel's 24 us),
+    // thread 0 adds them in slot order
+    __shared__ double slots[REPORT_BLOCKS][2];
     __threadfence();
+    if (threadIdx.x < 2 * gridDim.x)
+        slots[threadIdx.x >> 1][threadIdx.x & 1] = __hip_atomic_load(&ws->partial[threadIdx.x >> 1][threadIdx.x & 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (threadIdx.x != 0) return;
     double t0 = 0.0, t1 = 0.0;
     for (unsigned b = 0; b < gridDim.x; ++b) {
-        t0 += __hip_atomic_load(&ws->partial[b][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        t1 += __hip_atomic_load(&ws->partial[b][1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        t0 += slots[b][0];
+        t1 += slots[b][1];
     }
     r.stats[RLPPO_STAT_PASSES] += r.add_passes;
     for (int k = 0; k < RLPPO_N_STATS; ++k) {
