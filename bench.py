@@ -469,7 +469,7 @@ def cpu_baseline(seed=123, reps=2):
     for threads in sorted({min(cores, 16), min(cores, 64)}):
         torch.set_num_threads(threads)
         times = []
-        for rep in range(reps + 1):  # the first repetition is the warm-up
+        for rep in range((reps if threads <= 16 else 1) + 1):  # the first repetition is the warm-up; the wider count (slower on this host) is timed once
             pol = [(w.clone(), b.clone()) for w, b in pol0]
             val = [(w.clone(), b.clone()) for w, b in val0]
             t = time.perf_counter()
@@ -481,7 +481,7 @@ def cpu_baseline(seed=123, reps=2):
     return dict(value=round(n / per_threads[threads]), unit="samples/s", cores=threads, kind="port",
                 by_threads={str(k): round(n / v) for k, v in per_threads.items()}, host_cores=cores, physical_cores=physical_cores(),
                 sample="one full epoch of the GPU line's workload (524,288 samples = 8 minibatches of 65,536, 1 optimiser step; the GPU step is 10 such "
-                       "epochs), torch-CPU eager oracle, median of %d warm reps per thread count, best count reported; %.0f s" % (reps, time.perf_counter() - t_all))
+                       "epochs), torch-CPU eager oracle, median of %d warm reps at 16 threads (1 at the wider count), best count reported; %.0f s" % (reps, time.perf_counter() - t_all))
 
 
 REF_BATCH, REF_BUFFER = 50_000, 150_000  # /root/reference: learner.py:34-53 (ppo_batch_size 50,000, minibatch = batch), example.py:74-88 (buffer 150,000)
