@@ -1511,6 +1511,48 @@ def test_minibatch_x3_precision_cfg2_shape(L):
         assert worst < 2e-3   # (a ReLU decision within rounding of 0 may differ between the two: O(1/sqrt(rows)) of a first-layer row)
 
 
+def test_learn_report_entry_point(L):
+    """[r6] rlppo_learn_report through the C ABI alone (ppo_learner.py:213-236: the update magnitudes, the report sums read out): the
+    two norms against float64 of the float32 differences (any sizes, incl. lengths that are no multiple of anything), the accumulators
+    copied out with add_passes added and ZEROED, the give-up word and the extra double passed through, the completion word released
+    with the call's value; the ticket block re-arms itself (five calls on one block), results are bit-identical from call to call."""
+    from rlgym_ppo_amd import _native as N
+    torch.manual_seed(5)
+    ws = torch.zeros(N.REPORT_WS_BYTES, dtype=torch.uint8, device="cuda")
+    out = torch.zeros(N.REPORT_OUT_DOUBLES, dtype=torch.float64).pin_memory()
+    done = torch.zeros(1, dtype=torch.int32).pin_memory()
+    word = torch.tensor([3], dtype=torch.int32, device="cuda")
+    extra = torch.tensor([11.0], dtype=torch.float64, device="cuda")
+    seen = []
+    for call, (n_pol, n_val) in enumerate(((182362, 159489), (1, 0), (70001, 13), (182362, 159489), (182362, 159489))):
+        g = torch.Generator(device="cuda").manual_seed(100 if call >= 3 else call)
+        pb, pn = torch.randn(n_pol, device="cuda", generator=g), torch.randn(n_pol, device="cuda", generator=g)
+        vb, vn = torch.randn(max(n_val, 1), device="cuda", generator=g), torch.randn(max(n_val, 1), device="cuda", generator=g)
+        stats = torch.arange(1, N.N_STATS + 1, dtype=torch.float64, device="cuda") * 0.5
+        a = N.ReportArgs()
+        a.pol_before, a.pol_now, a.n_pol, a.val_before, a.val_now, a.n_val = pb.data_ptr(), pn.data_ptr(), n_pol, vb.data_ptr(), vn.data_ptr(), n_val
+        a.stats, a.add_passes = stats.data_ptr(), 4.0
+        a.timeout_word, a.extra = (word.data_ptr(), extra.data_ptr()) if call % 2 == 0 else (None, None)
+        a.out, a.done_word, a.done_value, a.ws = out.data_ptr(), done.data_ptr(), 1000 + call, ws.data_ptr()
+        done.zero_()
+        check(L, L.rlppo_learn_report(stream(), ctypes.byref(a)))
+        assert L.rlppo_host_wait_words(done.data_ptr(), 1, 1000 + call, 2_000_000) == 0
+        got = out.numpy().copy()
+        want = (np.arange(1, N.N_STATS + 1) * 0.5)
+        want[N.STAT_PASSES] += 4.0
+        assert np.array_equal(got[:N.N_STATS], want) and float(stats.abs().sum()) == 0.0
+        for k, (b, n_, cnt) in enumerate(((pb, pn, n_pol), (vb, vn, n_val))):
+            ref = float((b[:cnt] - n_[:cnt]).double().norm()) if cnt else 0.0
+            assert abs(got[N.N_STATS + k] - ref) <= 1e-12 * max(ref, 1.0), (call, k, got[N.N_STATS + k], ref)
+        assert got[N.N_STATS + 2] == (3.0 if call % 2 == 0 else 0.0) and got[N.N_STATS + 3] == (11.0 if call % 2 == 0 else 0.0)
+        seen.append(got[N.N_STATS:N.N_STATS + 2].copy())
+    assert np.array_equal(seen[3], seen[4])      # the same inputs, the same bits (fixed-order sums)
+    assert int(ws[:4].view(torch.int32).item()) == 0   # the ticket counter is back at zero
+    # argument errors come back as codes
+    bad = N.ReportArgs()
+    assert L.rlppo_learn_report(stream(), ctypes.byref(bad)) == 1001
+
+
 def test_clip_adam_matches_oracle(L):
     torch.manual_seed(0)
     params = nets.init_mlp(20, (16,), 5)
