@@ -21,6 +21,16 @@
 
 #include "../../include/rlppo.h"
 
+namespace rlppo {
+void set_error(const char *fmt, ...);  // api.hip: the text behind rlppo_last_error()
+}
+
+#define COLLECTOR_FAIL(code, ...)      \
+    do {                               \
+        rlppo::set_error(__VA_ARGS__); \
+        return code;                   \
+    } while (0)
+
 namespace {
 constexpr float STEP_HEADER0 = 83775.f;                                 // comm_consts.ENV_STEP_DATA_HEADER[0]
 constexpr float ACTIONS_HEADER[3] = {12782.f, 83783.f, 80784.f};        // comm_consts.POLICY_ACTIONS_HEADER
@@ -60,7 +70,6 @@ struct Collector {
     std::vector<Metrics> metrics;
     bool avg_none = true;
     double avg = 0.0;
-    char err[256] = {0};
 };
 
 // BatchedTrajectory.update(): bank the pending timestep if all of its fields are there; true when it ended the episode
@@ -103,9 +112,10 @@ extern "C" {
 
 int rlppo_collector_create(int32_t n_workers, const int32_t *socket_fds, const int32_t *peer_ports, const float *shm_base,
                            int64_t shm_floats_per_worker, int32_t obs_dim, void **handle) {
-    if (!handle || n_workers <= 0 || !socket_fds || !peer_ports || !shm_base || shm_floats_per_worker < 8 || obs_dim <= 0) return RLPPO_ERR_ARG;
+    if (!handle || n_workers <= 0 || !socket_fds || !peer_ports || !shm_base || shm_floats_per_worker < 8 || obs_dim <= 0)
+        COLLECTOR_FAIL(RLPPO_ERR_ARG, "collector_create: bad argument (n_workers=%d, obs_dim=%d, %ld floats per slab)", n_workers, obs_dim, (long)shm_floats_per_worker);
     Collector *c = new (std::nothrow) Collector();
-    if (!c) return RLPPO_ERR_ARG;
+    if (!c) COLLECTOR_FAIL(RLPPO_ERR_ARG, "collector_create: out of memory");
     c->n = n_workers;
     c->d = obs_dim;
     c->slab_floats = shm_floats_per_worker;
@@ -131,7 +141,7 @@ int rlppo_collector_destroy(void *handle) {
 // ready != 0 also appends the worker to current_pids
 int rlppo_collector_set_obs(void *handle, int32_t worker, const float *obs, int32_t rows, int32_t ready) {
     Collector *c = static_cast<Collector *>(handle);
-    if (!c || worker < 0 || worker >= c->n || rows < 0 || (rows > 0 && !obs)) return RLPPO_ERR_ARG;
+    if (!c || worker < 0 || worker >= c->n || rows < 0 || (rows > 0 && !obs)) COLLECTOR_FAIL(RLPPO_ERR_ARG, "collector_set_obs: bad argument (worker %d, %d rows)", worker, rows);
     Worker &w = c->w[worker];
     w.cur_obs.assign(obs, obs + (size_t)rows * c->d);
     w.cur_n = rows;
@@ -146,12 +156,12 @@ int rlppo_collector_set_obs(void *handle, int32_t worker, const float *obs, int3
 // _send_actions, first half: the stacked observations of the workers that wait for actions (current_pids that have an observation)
 int rlppo_collector_ready(void *handle, float *obs_out, int64_t cap_rows, int64_t *n_rows) {
     Collector *c = static_cast<Collector *>(handle);
-    if (!c || !n_rows) return RLPPO_ERR_ARG;
+    if (!c || !n_rows) COLLECTOR_FAIL(RLPPO_ERR_ARG, "collector_ready: null argument");
     c->ready_pids.clear();
     int64_t rows = 0;
     for (int pid : c->current_pids)
         if (c->w[pid].cur_n >= 0) {
-            if (rows + c->w[pid].cur_n > cap_rows) return RLPPO_ERR_WORKSPACE;
+            if (rows + c->w[pid].cur_n > cap_rows) COLLECTOR_FAIL(RLPPO_ERR_WORKSPACE, "collector_ready: more than %ld waiting observations", (long)cap_rows);
             if (c->w[pid].cur_n > 0) memcpy(obs_out + rows * c->d, c->w[pid].cur_obs.data(), (size_t)c->w[pid].cur_n * c->d * sizeof(float));
             rows += c->w[pid].cur_n;
             c->ready_pids.push_back(pid);
@@ -164,7 +174,7 @@ int rlppo_collector_ready(void *handle, float *obs_out, int64_t cap_rows, int64_
 // pending timestep of each ready worker records (state, action, log_prob) and the worker is sent POLICY_ACTIONS_HEADER + its rows
 int rlppo_collector_send(void *handle, const float *actions, int32_t act_width, const float *log_probs) {
     Collector *c = static_cast<Collector *>(handle);
-    if (!c || act_width <= 0 || !actions || !log_probs) return RLPPO_ERR_ARG;
+    if (!c || act_width <= 0 || !actions || !log_probs) COLLECTOR_FAIL(RLPPO_ERR_ARG, "collector_send: bad argument (act_width %d)", act_width);
     if (c->ready_pids.empty()) return 0;
     c->act_width = act_width;
     int64_t row = 0;
@@ -198,7 +208,7 @@ int rlppo_collector_send(void *handle, const float *actions, int32_t act_width, 
         const int rc = sendmmsg(fd, hdrs.data() + sent, (unsigned)(nr - sent), 0);
         if (rc < 0) {
             if (errno == EINTR) continue;
-            return RLPPO_ERR_ARG;
+            COLLECTOR_FAIL(RLPPO_ERR_ARG, "collector_send: sendmmsg failed: %s", strerror(errno));
         }
         sent += (size_t)rc;
     }
@@ -215,7 +225,8 @@ int rlppo_collector_collect(void *handle, int64_t min_obs, int32_t resume, int32
                             void *stats_var, int64_t *stats_count, int32_t stats_f64, int64_t steps_per_increment, int64_t *steps_since_increment,
                             int64_t *n_collected) {
     Collector *c = static_cast<Collector *>(handle);
-    if (!c || !n_collected || (standardize && (!mean || !stdv || !stats_mean || !stats_var || !stats_count || !steps_since_increment))) return RLPPO_ERR_ARG;
+    if (!c || !n_collected || (standardize && (!mean || !stdv || !stats_mean || !stats_var || !stats_count || !steps_since_increment)))
+        COLLECTOR_FAIL(RLPPO_ERR_ARG, "collector_collect: null argument");
     if (!resume) c->current_pids.clear();
     std::vector<pollfd> fds(c->n);
     for (int i = 0; i < c->n; ++i) fds[i] = pollfd{c->w[i].fd, POLLIN, 0};
@@ -228,9 +239,11 @@ int rlppo_collector_collect(void *handle, int64_t min_obs, int32_t resume, int32
             *n_collected = got;
             return RLPPO_ERR_INTERRUPTED;
         }
-        if (rc <= 0) return RLPPO_ERR_COLLECT_TIMEOUT;  // a minute without a worker message: the Python side reports it
+        if (rc < 0) COLLECTOR_FAIL(RLPPO_ERR_ARG, "collector_collect: poll failed: %s", strerror(errno));
+        if (rc == 0) COLLECTOR_FAIL(RLPPO_ERR_COLLECT_TIMEOUT, "collector_collect: no worker message for a minute (%ld of %ld agent-steps of this wait arrived)", (long)got, (long)min_obs);
         for (int pid = 0; pid < c->n; ++pid) {
-            if ((fds[pid].revents & (POLLERR | POLLHUP | POLLNVAL)) && !(fds[pid].revents & POLLIN)) return RLPPO_ERR_ARG;  // a dead socket would spin this loop
+            if ((fds[pid].revents & (POLLERR | POLLHUP | POLLNVAL)) && !(fds[pid].revents & POLLIN))  // a dead socket would spin this loop
+                COLLECTOR_FAIL(RLPPO_ERR_ARG, "collector_collect: the socket of worker %d is dead (revents 0x%x)", pid, (unsigned)fds[pid].revents);
             if (!(fds[pid].revents & POLLIN)) continue;
             Worker &w = c->w[pid];
             const ssize_t len = recv(w.fd, buf, sizeof(buf), 0);
@@ -242,7 +255,8 @@ int rlppo_collector_collect(void *handle, int64_t min_obs, int32_t resume, int32
             const float *s = w.slab;
             const int prev_n = (int)s[0], state_rank = (int)s[3], metrics_rank = (int)s[4];
             const double done = s[1], trunc = s[2];
-            if (prev_n < 0 || state_rank < 1 || state_rank > 2 || metrics_rank < 0 || metrics_rank > 8 || 5 + metrics_rank + state_rank + prev_n > c->slab_floats) return RLPPO_ERR_ARG;
+            if (prev_n < 0 || state_rank < 1 || state_rank > 2 || metrics_rank < 0 || metrics_rank > 8 || 5 + metrics_rank + state_rank + prev_n > c->slab_floats)
+                COLLECTOR_FAIL(RLPPO_ERR_ARG, "collector_collect: worker %d's slab has no valid step header (prev_n %d, state rank %d, metrics rank %d)", pid, prev_n, state_rank, metrics_rank);
             int64_t o = 5;
             Metrics m;
             int64_t n_metrics = metrics_rank ? 1 : 0;
@@ -253,7 +267,8 @@ int rlppo_collector_collect(void *handle, int64_t min_obs, int32_t resume, int32
             o += metrics_rank;
             const int rows = state_rank == 1 ? 1 : (int)s[o], width = state_rank == 1 ? (int)s[o] : (int)s[o + 1];
             o += state_rank;
-            if (width != d || rows < 0 || n_metrics < 0 || o + prev_n + n_metrics + (int64_t)rows * d > c->slab_floats) return RLPPO_ERR_ARG;
+            if (width != d || rows < 0 || n_metrics < 0 || o + prev_n + n_metrics + (int64_t)rows * d > c->slab_floats)
+                COLLECTOR_FAIL(RLPPO_ERR_ARG, "collector_collect: worker %d's step does not fit (observation %d x %d against width %d, %ld metrics, %ld floats per slab)", pid, rows, width, d, (long)n_metrics, (long)c->slab_floats);
             std::vector<double> rews(s + o, s + o + prev_n);
             o += prev_n;
             m.values.assign(s + o, s + o + n_metrics);
@@ -348,7 +363,7 @@ int rlppo_collector_collect(void *handle, int64_t min_obs, int32_t resume, int32
 // width, the number of metrics records and their total size
 int rlppo_collector_finish(void *handle, int64_t *n_steps, int32_t *act_width, int64_t *n_metrics, int64_t *metrics_floats) {
     Collector *c = static_cast<Collector *>(handle);
-    if (!c || !n_steps || !act_width || !n_metrics || !metrics_floats) return RLPPO_ERR_ARG;
+    if (!c || !n_steps || !act_width || !n_metrics || !metrics_floats) COLLECTOR_FAIL(RLPPO_ERR_ARG, "collector_finish: null argument");
     for (int pid = 0; pid < c->n; ++pid) {
         Worker &w = c->w[pid];
         c->completed.push_back(std::move(w.traj));
@@ -375,7 +390,7 @@ int rlppo_collector_finish(void *handle, int64_t *n_steps, int32_t *act_width, i
 int rlppo_collector_emit(void *handle, float *states, float *actions, float *log_probs, double *rewards, float *next_states, double *dones,
                          double *truncated, float *metrics_values, int32_t *metrics_shapes) {
     Collector *c = static_cast<Collector *>(handle);
-    if (!c) return RLPPO_ERR_ARG;
+    if (!c) COLLECTOR_FAIL(RLPPO_ERR_ARG, "collector_emit: null handle");
     const int d = c->d, aw = c->act_width;
     int64_t r = 0;
     for (const auto &t : c->completed) {
@@ -384,7 +399,8 @@ int rlppo_collector_emit(void *handle, float *states, float *actions, float *log
         for (int i = 0; i < agents; ++i) {
             for (size_t k = 0; k < t.size(); ++k) {
                 const Step &s = t[k];
-                if (i >= s.n_state || i >= (int)s.rew.size() || (int64_t)s.action.size() != (int64_t)s.n_state * aw) return RLPPO_ERR_ARG;
+                if (i >= s.n_state || i >= (int)s.rew.size() || (int64_t)s.action.size() != (int64_t)s.n_state * aw)
+                    COLLECTOR_FAIL(RLPPO_ERR_ARG, "collector_emit: a trajectory's steps disagree about its agents (agent %d of %d, %d state rows, action width %d)", i, agents, s.n_state, aw);
                 memcpy(states + r * d, s.state.data() + (size_t)i * d, d * sizeof(float));
                 memcpy(actions + r * aw, s.action.data() + (size_t)i * aw, aw * sizeof(float));
                 log_probs[r] = s.logp[i];
@@ -416,7 +432,7 @@ int rlppo_collector_emit(void *handle, float *states, float *actions, float *log
 // average_reward of the manager (python float or None): get / set (a checkpoint restores it)
 int rlppo_collector_average_reward(void *handle, int32_t set, double *value, int32_t *is_none) {
     Collector *c = static_cast<Collector *>(handle);
-    if (!c || !value || !is_none) return RLPPO_ERR_ARG;
+    if (!c || !value || !is_none) COLLECTOR_FAIL(RLPPO_ERR_ARG, "collector_average_reward: null argument");
     if (set) {
         c->avg_none = *is_none != 0;
         c->avg = *value;

@@ -163,3 +163,16 @@ def test_signals_interrupt_the_native_wait_without_changing_the_results():
         signal.setitimer(signal.ITIMER_REAL, 0, 0)
         signal.signal(signal.SIGALRM, old)
         mgr.cleanup()
+
+
+def test_collector_entry_points_report_errors_as_codes_and_text():
+    import ctypes
+    from rlgym_ppo_amd import _native as N
+    L = N.lib()
+    h = ctypes.c_void_p()
+    assert L.rlppo_collector_create(0, None, None, None, 0, 0, ctypes.byref(h)) == 1001 and b"collector_create" in L.rlppo_last_error()
+    rows = ctypes.c_int64(0)
+    assert L.rlppo_collector_ready(None, None, 0, ctypes.byref(rows)) == 1001 and b"collector_ready" in L.rlppo_last_error()
+    assert L.rlppo_collector_send(None, None, 0, None) == 1001 and b"collector_send" in L.rlppo_last_error()
+    with pytest.raises(RuntimeError, match="collector_send"):
+        N.check(L.rlppo_collector_send(None, None, 0, None))
