@@ -480,8 +480,8 @@ def cpu_baseline(seed=123, reps=2):
     threads = min(per_threads, key=per_threads.get)
     return dict(value=round(n / per_threads[threads]), unit="samples/s", cores=threads, kind="port",
                 by_threads={str(k): round(n / v) for k, v in per_threads.items()}, host_cores=cores, physical_cores=physical_cores(),
-                sample="one full epoch of the GPU line's workload (524,288 samples = 8 minibatches of 65,536, 1 optimiser step; the GPU step is 10 such "
-                       "epochs), torch-CPU eager oracle, median of %d warm reps at 16 threads (1 at the wider count), best count reported; %.0f s" % (reps, time.perf_counter() - t_all))
+                sample="one full epoch of the GPU workload (524,288 samples, 8 minibatches, 1 optimiser step); torch-CPU oracle, median of %d reps at 16 threads (1 at 64); %.0f s"
+                       % (reps, time.perf_counter() - t_all))
 
 
 REF_BATCH, REF_BUFFER = 50_000, 150_000  # /root/reference: learner.py:34-53 (ppo_batch_size 50,000, minibatch = batch), example.py:74-88 (buffer 150,000)
@@ -621,8 +621,7 @@ def ref_defaults_leg(device, seed=123):
     cpu_10 = time.perf_counter() - t
     thr = torch.get_num_threads()
     out["cpu_baseline"] = dict(kind="port", cores=thr, unit="samples/s", epochs_1=round(n / float(np.median(cpu_1))), epochs_10=round(2 * n / cpu_10),
-                               sample="the IDENTICAL workload (150,000-sample buffer, B = MB = 50,000): 1 epoch = median of 3 runs; the multi-epoch rate is measured over "
-                                      "2 epochs (the CPU's cost per epoch is flat: 104.4 k / 104.2 k samples/s at 1 / 10 epochs in round 5), torch-CPU eager oracle at %d threads, %.0f s"
+                               sample="identical workload (150,000 buffer, B = MB = 50,000): 1 epoch median of 3; multi-epoch rate over 2 epochs; torch-CPU oracle, %d threads, %.0f s"
                                       % (thr, sum(cpu_1) + cpu_10))
     out["gpu_over_cpu"] = dict(epochs_1=round(out["epochs_1"]["value"] / out["cpu_baseline"]["epochs_1"], 1),
                                epochs_10=round(out["epochs_10"]["value"] / out["cpu_baseline"]["epochs_10"], 1))
@@ -1074,8 +1073,9 @@ def fit_line(out, limit=LINE_LIMIT):
             return False
         return fn
     steps = [lambda: walk(out, drop_keys({"note", "method", "how", "sample_note"})),
+             lambda: walk(out, drop_keys({"exec_tflops", "gflop"})),   # (derivable: flop per launch is the shape, executed = padded shape)
              lambda: walk(out, cut_strings(160)), lambda: walk(out, cut_strings(90)),
-             lambda: walk(out, drop_keys({"exec_tflops", "gflop", "source", "traffic_source"})),
+             lambda: walk(out, drop_keys({"source", "traffic_source"})),
              lambda: out.get("process_collect", {}).pop("n_proc_32", None),
              lambda: walk(out, cut_strings(48)),
              lambda: out.pop("update_x3", None), lambda: out.pop("non_gemm_tail", None), lambda: out.pop("iteration", None)]
