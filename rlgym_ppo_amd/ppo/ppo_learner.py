@@ -9,6 +9,8 @@ state_dict layouts).  What changed underneath:
   * the epoch permutation is drawn on the host (bit-identical numpy legacy stream) while the GPU is still busy
     with the previous epoch, and only the index vector crosses PCIe;
   * clip_grad_norm_ + Adam.step() are one fused pass over a flat parameter arena (rlppo_clip_adam);
+  * the tail of learn() (ppo_learner.py:213-236: update magnitudes, report means) is ONE launch that writes pinned memory and
+    releases a completion word (rlppo_learn_report); nothing is enqueued in front of the first pass that the pass does not need;
   * data-parallel: the minibatch slices of a batch are dealt round-robin to the ranks of the default
     torch.distributed group and ONE RCCL all-reduce of the flat gradient arena precedes clipping -- algebraically
     the reference's own gradient accumulation (ppo_learner.py:134-193) with slice j living on rank j % world.
